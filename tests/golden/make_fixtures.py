@@ -1,0 +1,450 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (imported through oracle/ref_shim.py).
+
+Test infrastructure.  Needs /root/reference (not present on the GPU box): run it in the build
+container only; the resulting small .npz fixtures are committed, the reference never travels.
+
+    python tests/golden/make_fixtures.py            # regenerate everything
+
+Each fixture holds inputs + the reference's outputs for one hot-path function
+(SURVEY.md section 8a rows in brackets):
+  gae.npz          Algorithm.compute_episodic_return / _gae            [a12]
+  vrb_trace.npz    VectorReplayBuffer.add / sample_indices(0) / prev / next / unfinished_index /
+                   get_buffer_indices / reset                           [a8, a9]
+  ppo_update.npz   PPO._preprocess_batch + PPO._update_with_batch (loss scalars, gradients,
+                   Adam-updated weights, minibatch permutation)         [a7, a11, a13, a14, a15]
+  marl_dispatch.npz MultiAgentPolicy.forward scatter + MARLDispatcher per-agent GAE (incl. quirk Q1),
+                   FlexibleMultiAgentPolicyManager shared forward       [a5, a6, a10]
+  ctde.npz         GlobalStateConstructor.build + CTDEPolicy.learn      [a16]
+  misc.npz         Batch.split bounds, RunningMeanStd, episode_mc_return_to_go   [a11, a14]
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+import logging  # noqa: E402
+
+logging.getLogger("tianshou.data.buffer.buffer_base").setLevel(logging.CRITICAL)
+
+import torch  # noqa: E402
+from tianshou.algorithm import Algorithm  # noqa: E402
+from tianshou.algorithm.algorithm_base import episode_mc_return_to_go  # noqa: E402
+from tianshou.algorithm.modelfree.ppo import PPO  # noqa: E402
+from tianshou.algorithm.modelfree.reinforce import DiscreteActorPolicy  # noqa: E402
+from tianshou.algorithm.multiagent.ctde import (  # noqa: E402
+    CentralizedCritic,
+    CTDEPolicy,
+    DecentralizedActor,
+    GlobalStateConstructor,
+)
+from tianshou.algorithm.multiagent.flexible_policy import FlexibleMultiAgentPolicyManager  # noqa: E402
+from tianshou.algorithm.multiagent.marl import MultiAgentOnPolicyAlgorithm, MultiAgentPolicy  # noqa: E402
+from tianshou.algorithm.algorithm_base import Policy  # noqa: E402
+from tianshou.algorithm.optim import AdamOptimizerFactory  # noqa: E402
+from tianshou.data import Batch, ReplayBuffer, VectorReplayBuffer  # noqa: E402
+from tianshou.utils import RunningMeanStd  # noqa: E402
+from tianshou.utils.net.common import Net  # noqa: E402
+from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic  # noqa: E402
+from tianshou.utils.torch_utils import policy_within_training_step  # noqa: E402
+import gymnasium as gym  # noqa: E402  (the shim's fake)
+
+
+def save(name: str, **arrays) -> None:
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}: {len(arrays)} arrays, {os.path.getsize(path)} bytes")
+
+
+# ------------------------------------------------------------------------------------------------
+def fill_vector_buffer(rng, n_env, T, obs_dim, p_term=0.05, trunc_at=None, rew_dim=0, n_act=5):
+    """Fill a reference VectorReplayBuffer with T vector steps of synthetic rows."""
+    buf = VectorReplayBuffer(n_env * T, n_env)
+    obs = rng.standard_normal((n_env, obs_dim)).astype(np.float32)
+    for t in range(T):
+        obs_next = rng.standard_normal((n_env, obs_dim)).astype(np.float32)
+        rew = rng.standard_normal((n_env, rew_dim) if rew_dim else (n_env,))
+        term = rng.random(n_env) < p_term
+        trunc = np.zeros(n_env, bool)
+        if trunc_at is not None and (t + 1) % trunc_at == 0:
+            trunc[:] = True
+        b = Batch(obs=obs, act=rng.integers(0, n_act, n_env), rew=rew, terminated=term,
+                  truncated=trunc, obs_next=obs_next, info=Batch(env_id=np.arange(n_env)))
+        buf.add(b, buffer_ids=np.arange(n_env))
+        obs = obs_next
+    return buf
+
+
+def make_gae() -> None:
+    rng = np.random.default_rng(0)
+    out = {}
+    cases = [
+        dict(n_env=4, T=25, p_term=0.05, trunc_at=None, gamma=0.99, lam=0.95),
+        dict(n_env=3, T=10, p_term=0.2, trunc_at=5, gamma=0.9, lam=0.8),
+        dict(n_env=16, T=25, p_term=0.01, trunc_at=25, gamma=0.99, lam=0.95),
+        dict(n_env=2, T=7, p_term=0.0, trunc_at=None, gamma=0.99, lam=1.0),
+    ]
+    for ci, c in enumerate(cases):
+        buf = fill_vector_buffer(rng, c["n_env"], c["T"], 3, c["p_term"], c["trunc_at"])
+        batch, indices = buf.sample(0)
+        n = len(indices)
+        v_s = rng.standard_normal(n).astype(np.float32)
+        v_s_ = rng.standard_normal(n).astype(np.float32)
+        ret, adv = Algorithm.compute_episodic_return(
+            batch, buf, indices, torch.from_numpy(v_s_), torch.from_numpy(v_s),
+            gamma=c["gamma"], gae_lambda=c["lam"])
+        p = f"c{ci}_"
+        out.update({
+            p + "rew": batch.rew, p + "terminated": batch.terminated, p + "truncated": batch.truncated,
+            p + "indices": indices, p + "unfinished": buf.unfinished_index(), p + "v_s": v_s,
+            p + "v_s_next": v_s_, p + "gamma": c["gamma"], p + "lam": c["lam"],
+            p + "returns": ret, p + "adv": adv, p + "n_env": c["n_env"], p + "T": c["T"],
+        })
+        assert ret.dtype == np.float64
+    # v_s=None (roll) and v_s_=None (MC return, gae_lambda=1) branches
+    buf = fill_vector_buffer(rng, 3, 9, 3, 0.15, None)
+    batch, indices = buf.sample(0)
+    v_s_ = rng.standard_normal(len(indices))
+    ret, adv = Algorithm.compute_episodic_return(batch, buf, indices, v_s_, None, gamma=0.97, gae_lambda=0.9)
+    out.update(roll_rew=batch.rew, roll_terminated=batch.terminated, roll_truncated=batch.truncated,
+               roll_indices=indices, roll_unfinished=buf.unfinished_index(), roll_v_s_next=v_s_,
+               roll_returns=ret, roll_adv=adv)
+    ret, adv = Algorithm.compute_episodic_return(batch, buf, indices, None, None, gamma=0.97, gae_lambda=1.0)
+    out.update(mc_returns=ret, mc_adv=adv)
+    save("gae.npz", n_cases=len(cases), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def make_vrb_trace() -> None:
+    rng = np.random.default_rng(1)
+    out = {}
+    configs = [(20, 4, 0), (23, 5, 0), (12, 3, 4), (64, 8, 3)]  # (total_size, buffer_num, rew_dim)
+    for ci, (total, num, rew_dim) in enumerate(configs):
+        buf = VectorReplayBuffer(total, num)
+        p = f"c{ci}_"
+        out[p + "cfg"] = np.array([total, num, rew_dim])
+        n_add = 40
+        out[p + "n_add"] = n_add
+        for ai in range(n_add):
+            if ai == 25:  # exercise reset(keep_statistics=True) mid-trace (trainer.py:1104)
+                buf.reset(keep_statistics=True)
+                out[p + "reset_at"] = ai
+            k = int(rng.integers(1, num + 1))
+            ids = np.sort(rng.choice(num, size=k, replace=False))
+            rew = rng.integers(-3, 4, size=(k, rew_dim) if rew_dim else (k,)).astype(np.float64)
+            term = rng.random(k) < 0.2
+            trunc = rng.random(k) < 0.1
+            b = Batch(obs=np.zeros(k), act=np.zeros(k, int), rew=rew, terminated=term, truncated=trunc)
+            ptr, ep_rew, ep_len, ep_idx = buf.add(b, buffer_ids=ids)
+            q = f"{p}a{ai}_"
+            out.update({q + "ids": ids, q + "rew": rew, q + "term": term, q + "trunc": trunc,
+                        q + "ptr": ptr, q + "ep_rew": np.asarray(ep_rew, np.float64),
+                        q + "ep_len": ep_len, q + "ep_idx": ep_idx,
+                        q + "len": len(buf), q + "unfinished": buf.unfinished_index(),
+                        q + "sample0": buf.sample_indices(0)})
+            if ai % 5 == 4:
+                allidx = np.arange(-2, buf.maxsize + 2)
+                out[q + "prev"] = buf.prev(allidx)
+                out[q + "next"] = buf.next(allidx)
+                out[q + "done"] = np.array(buf.done, copy=True)
+                out[q + "last_index"] = np.array(buf.last_index, copy=True)
+        # get_buffer_indices (buffer_base.py:173-228), incl. wrap-around and errors
+        gbi = []
+        S = buf.maxsize // num
+        for start in range(0, buf.maxsize):
+            for stop in range(0, buf.maxsize + 1):
+                try:
+                    r = buf.get_buffer_indices(start, stop)
+                    gbi.append((start, stop, len(r), int(r.sum()) if len(r) else 0,
+                                int(r[0]) if len(r) else -1, int(r[-1]) if len(r) else -1))
+                except ValueError:
+                    gbi.append((start, stop, -1, 0, -1, -1))
+        out[p + "gbi"] = np.array(gbi, np.int64)
+        out[p + "sub_size"] = S
+    save("vrb_trace.npz", n_cfg=len(configs), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def build_ppo(obs_dim, n_act, hidden, seed, lr=3e-4, **ppo_kw):
+    torch.manual_seed(seed)
+    actor = DiscreteActor(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=hidden),
+                          action_shape=n_act, softmax_output=False)
+    critic = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=hidden))
+    for m in list(actor.modules()) + list(critic.modules()):
+        if isinstance(m, torch.nn.Linear):  # test/discrete/test_ppo_discrete.py:103-106
+            torch.nn.init.orthogonal_(m.weight)
+            torch.nn.init.zeros_(m.bias)
+    policy = DiscreteActorPolicy(actor=actor, action_space=gym.spaces.Discrete(n_act))
+    algo = PPO(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kw)
+    return algo, actor, critic
+
+
+def net_params(actor, critic):
+    lin = lambda m: [x for x in m.modules() if isinstance(x, torch.nn.Linear)]  # noqa: E731
+    d = {}
+    for name, mod in (("actor", actor), ("critic", critic)):
+        for i, l in enumerate(lin(mod)):
+            d[f"{name}_w{i}"] = l.weight.detach().numpy().copy()
+            d[f"{name}_b{i}"] = l.bias.detach().numpy().copy()
+    return d
+
+
+def net_grads(actor, critic):
+    lin = lambda m: [x for x in m.modules() if isinstance(x, torch.nn.Linear)]  # noqa: E731
+    d = {}
+    for name, mod in (("actor", actor), ("critic", critic)):
+        for i, l in enumerate(lin(mod)):
+            d[f"{name}_gw{i}"] = l.weight.grad.detach().numpy().copy()
+            d[f"{name}_gb{i}"] = l.bias.grad.detach().numpy().copy()
+    return d
+
+
+def make_ppo_update() -> None:
+    out = {}
+    variants = [
+        dict(name="default", ppo={}, batch_size=None, repeat=1),
+        dict(name="mb64", ppo={}, batch_size=64, repeat=2),
+        dict(name="dualclip_vclip", ppo=dict(dual_clip=2.0, value_clip=True, max_grad_norm=0.5),
+             batch_size=100, repeat=1),
+        dict(name="noadvnorm_retscale", ppo=dict(advantage_normalization=False, return_scaling=True),
+             batch_size=None, repeat=1),
+    ]
+    n_env, T, obs_dim, n_act = 8, 25, 18, 5
+    for v in variants:
+        rng = np.random.default_rng(7)
+        p = v["name"] + "_"
+        algo, actor, critic = build_ppo(obs_dim, n_act, [64, 64], seed=3, **v["ppo"])
+        buf = fill_vector_buffer(rng, n_env, T, obs_dim, p_term=0.03, trunc_at=25, n_act=n_act)
+        batch, indices = buf.sample(0)
+        out.update({p + k: val for k, val in net_params(actor, critic).items()})
+        out.update({p + "obs": batch.obs, p + "obs_next": batch.obs_next, p + "act": batch.act,
+                    p + "rew": batch.rew, p + "terminated": batch.terminated,
+                    p + "truncated": batch.truncated, p + "indices": indices,
+                    p + "unfinished": buf.unfinished_index()})
+        if v["ppo"].get("return_scaling"):
+            algo.ret_rms.update(rng.standard_normal(50) * 3.0)  # non-trivial running stats
+            out[p + "rms_before"] = np.array([algo.ret_rms.mean, algo.ret_rms.var, algo.ret_rms.count], np.float64)
+        with policy_within_training_step(algo.policy):
+            pb = algo._preprocess_batch(batch, buf, indices)
+            out.update({p + "v_s": pb.v_s.numpy().copy(), p + "returns": pb.returns.numpy().copy(),
+                        p + "adv": pb.adv.numpy().copy(), p + "logp_old": pb.logp_old.numpy().copy()})
+            if v["ppo"].get("return_scaling"):
+                out[p + "rms_after"] = np.array([algo.ret_rms.mean, algo.ret_rms.var, algo.ret_rms.count], np.float64)
+            # logits of the pre-update policy for the loss-kernel fixture
+            with torch.no_grad():
+                lg, _ = actor(torch.from_numpy(batch.obs))
+                out[p + "logits"] = lg.numpy().copy()
+            # the permutation Batch.split will draw (batch.py:1219): replay np.random state
+            np.random.seed(11)
+            n = len(indices)
+            perms = []
+            st = np.random.get_state()
+            for _ in range(v["repeat"]):
+                perms.append(np.random.permutation(n))
+            np.random.set_state(st)
+            out[p + "perms"] = np.stack(perms)
+            with torch.enable_grad():
+                algo.train()
+                stats = algo._update_with_batch(pb, v["batch_size"], v["repeat"])
+        out[p + "batch_size"] = -1 if v["batch_size"] is None else v["batch_size"]
+        out[p + "repeat"] = v["repeat"]
+        out[p + "gradient_steps"] = stats.gradient_steps
+        # per-gradient-step loss values are summarised by SequenceSummaryStats; keep mean/std/min/max
+        for k in ("loss", "actor_loss", "vf_loss", "ent_loss"):
+            s = getattr(stats, k)
+            out[p + "stat_" + k] = np.array([s.mean, s.std, s.max, s.min], np.float64)
+        out.update({p + "after_" + k: val for k, val in net_params(actor, critic).items()})
+        out.update({p + "last_" + k: val for k, val in net_grads(actor, critic).items()})
+        out[p + "ppo_cfg"] = np.array([algo.eps_clip, algo.dual_clip or 0.0, float(algo.value_clip),
+                                       float(algo.advantage_normalization), algo.vf_coef, algo.ent_coef,
+                                       algo.gamma, algo.gae_lambda,
+                                       v["ppo"].get("max_grad_norm") or 0.0, 3e-4], np.float64)
+    save("ppo_update.npz", variants=np.array([v["name"] for v in variants]), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+class _FakeAECEnv:
+    """Minimal stand-in exposing what MARLDispatcher reads (marl.py:197-203)."""
+
+    def __init__(self, n):
+        self.agents = [f"agent_{i}" for i in range(n)]
+        self.agent_idx = {a: i for i, a in enumerate(self.agents)}
+
+
+class _ArgmaxPolicy(Policy):
+    """Deterministic mock policy: act = argmax(obs @ W) (lets the scatter be pinned exactly)."""
+
+    def __init__(self, W, n_act):
+        super().__init__(action_space=gym.spaces.Discrete(n_act))
+        self.W = torch.nn.Parameter(torch.from_numpy(W), requires_grad=False)
+        self.calls = 0
+
+    def forward(self, batch, state=None, **kw):
+        self.calls += 1
+        obs = batch.obs.obs if hasattr(batch.obs, "obs") else batch.obs
+        logits = torch.as_tensor(obs, dtype=torch.float32) @ self.W
+        return Batch(act=logits.argmax(-1).numpy(), state=None, logits=logits.numpy())
+
+
+def make_marl_dispatch() -> None:
+    rng = np.random.default_rng(5)
+    out = {}
+    N, obs_dim, n_act, B = 3, 6, 5, 37
+    env = _FakeAECEnv(N)
+    Ws = [rng.standard_normal((obs_dim, n_act)).astype(np.float32) for _ in range(N)]
+    agent_rows = rng.integers(0, N, B)
+    agent_id = np.array([env.agents[i] for i in agent_rows], dtype=object)
+    obs = rng.standard_normal((B, obs_dim)).astype(np.float32)
+    batch = Batch(obs=Batch(agent_id=agent_id, obs=obs), info=Batch())
+    # independent policies via MultiAgentPolicy.forward (marl.py:108-185)
+    pols = {a: _ArgmaxPolicy(Ws[i], n_act) for i, a in enumerate(env.agents)}
+    res = MultiAgentPolicy(pols)(batch)
+    out.update(agent_rows=agent_rows, obs=obs, Ws=np.stack(Ws), act_independent=np.asarray(res.act))
+    # shared mode via FlexibleMultiAgentPolicyManager (flexible_policy.py:189-231): ONE forward
+    shared = _ArgmaxPolicy(Ws[0], n_act)
+    mgr = FlexibleMultiAgentPolicyManager(policies=shared, env=env, mode="shared")
+    res = mgr(batch)
+    out.update(act_shared=np.asarray(res.act), shared_calls=shared.calls)
+    # grouped mode: agents 0,1 -> policy A ; agent 2 -> policy B
+    pa, pb = _ArgmaxPolicy(Ws[1], n_act), _ArgmaxPolicy(Ws[2], n_act)
+    mgr = FlexibleMultiAgentPolicyManager(
+        policies={"g0": pa, "g1": pb}, env=env, mode="grouped",
+        agent_groups={"g0": ["agent_0", "agent_1"], "g1": ["agent_2"]})
+    res = mgr(batch)
+    # Reference defect (quirk Q6): grouped mode re-keys `self.policies` by GROUP name
+    # (flexible_policy.py:96-98) and then falls back to MultiAgentPolicy.forward (:200), which
+    # matches `obs.agent_id == <group name>` (marl.py:148) -> no rows match, no `act` is produced.
+    out.update(grouped_forward_has_act=int("act" in res.get_keys()),
+               grouped_policy_of_agent=np.array([0, 0, 1]))
+    # the intended semantics (policy_map, flexible_policy.py:138-158) evaluated by hand:
+    exp = np.zeros(B, np.int64)
+    for a_i, pol in enumerate([pa, pa, pb]):
+        rows = np.nonzero(agent_rows == a_i)[0]
+        exp[rows] = pol(Batch(obs=obs[rows])).act
+    out.update(act_grouped_policy_map=exp)
+
+    # ---- MARLDispatcher per-agent GAE over AEC rows incl. quirk Q1 ----
+    n_env, T = 2, 3
+    buf = VectorReplayBuffer(n_env * T * 2, n_env)
+    k = 0
+    for t in range(T):
+        for a in range(2):  # AEC: agents alternate turns, one row per turn
+            k += 1
+            rew = np.zeros((n_env, 2))
+            rew[:, a] = np.arange(1, n_env + 1) * k
+            ids = np.array([f"agent_{a}"] * n_env, dtype=object)
+            b = Batch(obs=Batch(agent_id=ids, obs=np.zeros((n_env, 2), np.float32)),
+                      act=np.zeros(n_env, int), rew=rew,
+                      terminated=np.zeros(n_env, bool), truncated=np.zeros(n_env, bool),
+                      obs_next=Batch(agent_id=ids, obs=np.zeros((n_env, 2), np.float32)))
+            buf.add(b, buffer_ids=np.arange(n_env))
+    batch, indices = buf.sample(0)
+    env2 = _FakeAECEnv(2)
+    q1 = {}
+    for a_i, agent in enumerate(env2.agents):
+        idx = np.nonzero(batch.obs.agent_id == agent)[0]
+        tmp, tind = batch[idx], indices[idx]
+        tmp.rew = tmp.rew[:, a_i]
+        save_rew, buf._meta.rew = buf.rew, Batch()
+        buf._meta.rew = save_rew[:, a_i]
+        ret, adv = Algorithm.compute_episodic_return(tmp, buf, tind, np.zeros(len(idx)), np.zeros(len(idx)),
+                                                     gamma=1.0, gae_lambda=1.0)
+        buf._meta.rew = save_rew
+        q1[f"q1_agent{a_i}_idx"] = idx
+        q1[f"q1_agent{a_i}_indices"] = tind
+        q1[f"q1_agent{a_i}_rew"] = np.asarray(tmp.rew)
+        q1[f"q1_agent{a_i}_returns"] = ret
+    out.update(q1, q1_unfinished=buf.unfinished_index(), q1_all_indices=indices,
+               q1_agent_of_row=np.array([0 if a == "agent_0" else 1 for a in batch.obs.agent_id]))
+    save("marl_dispatch.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def make_ctde() -> None:
+    rng = np.random.default_rng(9)
+    torch.manual_seed(9)
+    N, obs_dim, n_act, B, hid = 3, 6, 5, 32, 16
+    out = {}
+    obs_by_agent = {f"agent_{i}": torch.from_numpy(rng.standard_normal((B, obs_dim)).astype(np.float32))
+                    for i in range(N)}
+    for mode in ("concatenate", "mean"):
+        g = GlobalStateConstructor(mode=mode, obs_dim=obs_dim, n_agents=N).build(obs_by_agent)
+        out["global_" + mode] = g.numpy()
+    out["obs_by_agent"] = np.stack([v.numpy() for v in obs_by_agent.values()])
+    actor = DecentralizedActor(obs_dim, n_act, hidden_dim=hid)
+    critic = CentralizedCritic(N * obs_dim, N, hidden_dim=hid)
+    pol = CTDEPolicy(actor=actor, critic=critic,
+                     optim_actor=torch.optim.Adam(actor.parameters(), lr=1e-3),
+                     optim_critic=torch.optim.Adam(critic.parameters(), lr=1e-3),
+                     observation_space=gym.spaces.Box(-np.inf, np.inf, (obs_dim,)),
+                     action_space=gym.spaces.Discrete(n_act))
+    for name, mod in (("actor", actor), ("critic", critic)):
+        for i, l in enumerate([mod.fc1, mod.fc2, mod.fc3]):
+            out[f"{name}_w{i}"] = l.weight.detach().numpy().copy()
+            out[f"{name}_b{i}"] = l.bias.detach().numpy().copy()
+    batch = Batch(
+        obs=obs_by_agent["agent_0"].numpy(), act=rng.integers(0, n_act, B),
+        rew=rng.standard_normal(B).astype(np.float32),
+        obs_next=rng.standard_normal((B, obs_dim)).astype(np.float32),
+        terminated=rng.random(B) < 0.1,
+        global_obs=out["global_concatenate"],
+        global_obs_next=rng.standard_normal((B, N * obs_dim)).astype(np.float32))
+    fwd = pol.forward(Batch(obs=batch.obs))
+    out["fwd_act_logits"] = fwd.act.detach().numpy().copy()
+    losses = pol.learn(batch)
+    out.update(b_obs=batch.obs, b_act=batch.act, b_rew=batch.rew, b_obs_next=batch.obs_next,
+               b_terminated=batch.terminated, b_global_obs=batch.global_obs,
+               b_global_obs_next=batch.global_obs_next,
+               actor_loss=losses["actor_loss"], critic_loss=losses["critic_loss"])
+    for name, mod in (("actor", actor), ("critic", critic)):
+        for i, l in enumerate([mod.fc1, mod.fc2, mod.fc3]):
+            out[f"after_{name}_w{i}"] = l.weight.detach().numpy().copy()
+            out[f"after_{name}_b{i}"] = l.bias.detach().numpy().copy()
+            out[f"grad_{name}_w{i}"] = l.weight.grad.detach().numpy().copy()
+            out[f"grad_{name}_b{i}"] = l.bias.grad.detach().numpy().copy()
+    save("ctde.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def make_misc() -> None:
+    out = {}
+    rows = []
+    for length in (1, 5, 63, 64, 65, 127, 128, 129, 150, 192, 200, 4800):
+        for size in (-1, 1, 7, 64, 100, 256, 5000):
+            b = Batch(x=np.arange(length))
+            sizes = [len(mb) for mb in b.split(size, shuffle=False, merge_last=True)]
+            firsts = [int(mb.x[0]) for mb in b.split(size, shuffle=False, merge_last=True)]
+            rows.append((length, size, len(sizes), sum(s * (i + 1) for i, s in enumerate(sizes)),
+                         sum(f * (i + 1) for i, f in enumerate(firsts))))
+    out["split_rows"] = np.array(rows, np.int64)
+    rng = np.random.default_rng(2)
+    rms = RunningMeanStd()
+    xs, states = [], []
+    for n in (10, 1, 33, 100):
+        x = rng.standard_normal(n) * 2.5 + 1.0
+        rms.update(x)
+        xs.append(x)
+        states.append([float(rms.mean), float(rms.var), float(rms.count)])
+    out["rms_x"] = np.concatenate(xs)
+    out["rms_lens"] = np.array([len(x) for x in xs])
+    out["rms_states"] = np.array(states)
+    r = rng.standard_normal(17)
+    out["mc_rew"] = r
+    out["mc_ret"] = episode_mc_return_to_go(r, 0.97)
+    save("misc.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "marl_dispatch", "ctde", "misc"]
+    for w in which:
+        globals()["make_" + w]()
