@@ -1,0 +1,229 @@
+/*
+ * tsmarl.h -- C-ABI of the MI355X-native multi-agent rollout + update hot path.
+ *
+ * Drop-in boundary for the data-parallel hot path of eric-downes/tianshou_marl
+ * (BASELINE.json north_star; scope table SURVEY.md section 8).  The reference is pure Python:
+ * its only "native" entry points on this path are the numba @njit kernels and the numpy/torch
+ * calls listed next to each function below (paths relative to /root/reference).  A maintainer
+ * binds these symbols with ctypes (INTEGRATION.md shows the stubs) in place of those call sites.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / C++ types.
+ *  - Every data pointer is a DEVICE (HBM) pointer unless its name ends in `_host`.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous
+ *    on that stream; nothing here allocates, frees or synchronises (graph-capture safe) except
+ *    the tsm_mem_* / tsm_stream_sync helpers.
+ *  - Return value: 0 = TSM_OK, otherwise a TSM_ERR_* code; tsm_last_error() returns a
+ *    thread-local message.  The Python host maps TSM_ERR_INVALID -> ValueError,
+ *    TSM_ERR_MALFORMED_BUFFER -> MalformedBufferError (tianshou/data/buffer/buffer_base.py:380),
+ *    others -> RuntimeError.
+ *  - Device layout ("joint-step lanes"): time-major SoA
+ *      field[slot][env][agent][...]   slot in [0, sub_size), env in [0, buffer_num)
+ *    so that the (env, agent) lane index is the fastest-varying dimension of every per-step scalar.
+ *    Reference flat buffer index  <->  (env, slot):  index = env * sub_size + slot
+ *    (tianshou/data/buffer/manager.py:38-46, vecbuf.py:35).
+ *  - dtypes: payload f32, actions i32, flags u8 (0/1), indices/counters i64, episode-return
+ *    accumulators f64 (the reference keeps rew/ep_return in f64, buffer_base.py:377,484).
+ */
+#ifndef TSMARL_H
+#define TSMARL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSM_ABI_VERSION 1
+
+enum {
+    TSM_OK = 0,
+    TSM_ERR_INVALID = 1,          /* bad argument (ValueError) */
+    TSM_ERR_HIP = 2,              /* HIP runtime / launch failure */
+    TSM_ERR_MALFORMED_BUFFER = 3, /* buffer_base.py:380-386 */
+    TSM_ERR_UNSUPPORTED = 4
+};
+
+int tsm_abi_version(void);
+const char *tsm_last_error(void);
+/* name_out: >= 64 bytes.  Fails with TSM_ERR_HIP when no gfx950 device is visible. */
+int tsm_device_info(int *n_cu, int *wave_size, int64_t *hbm_bytes, char *name_out);
+
+/* memory / stream helpers for hosts that do not bring their own allocator (PyTorch does) */
+int tsm_mem_alloc(void **dptr, int64_t bytes);
+int tsm_mem_free(void *dptr);
+int tsm_mem_h2d(void *dst, const void *src_host, int64_t bytes, void *stream);
+int tsm_mem_d2h(void *dst_host, const void *src, int64_t bytes, void *stream);
+int tsm_mem_set(void *dst, int value, int64_t bytes, void *stream);
+int tsm_stream_sync(void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GAE  [SURVEY 8a: a11, a12]
+ * Replaces  Algorithm.compute_episodic_return + value_mask + numba `_gae`
+ *           (tianshou/algorithm/algorithm_base.py:631-717, 1079-1134)
+ *           and the return_scaling arithmetic of a2c.py:132-146.
+ * One independent series per lane; inputs/outputs are [T][n_lane] time-major.
+ *   v_next' = v_s_next * v_scale * !terminated;  v' = v_s * v_scale
+ *   end     = terminated | truncated | (row is the lane's last row)      (unfinished_index forcing)
+ *   delta = rew + gamma*v_next' - v';  adv_t = delta_t + gamma*lambda*(1-end_t)*adv_{t+1}  (f64)
+ *   adv_out = f32(adv);  returns_out = f32((adv + v') / v_scale)
+ * env_len / env_start (nullable, [n_lane / lanes_per_env] i32): ragged / rotated sub-buffers --
+ *   lane rows are slots (start + k) % T for k in [0, len); rows outside are left untouched.
+ * terminated / truncated: u8 [T][n_lane] when flags_per_lane != 0, else [T][n_lane/lanes_per_env].
+ * ------------------------------------------------------------------------------------------- */
+int tsm_gae_lanes(const float *v_s, const float *v_s_next, const float *rew,
+                  const uint8_t *terminated, const uint8_t *truncated, int flags_per_lane,
+                  int64_t T, int64_t n_lane, int64_t lanes_per_env, const int32_t *env_start,
+                  const int32_t *env_len, double gamma, double gae_lambda, double v_scale,
+                  float *returns_out, float *adv_out, void *stream);
+
+/* `episode_mc_return_to_go` (algorithm_base.py:1137-1151) over n_lane independent episodes
+ * stored [T][n_lane]; out f32. */
+int tsm_mc_return_to_go_lanes(const float *rew, int64_t T, int64_t n_lane, double gamma,
+                              float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * VectorReplayBuffer  [a8, a9]
+ * Replaces  ReplayBufferManager.add / _update_state_pre_add / sample_indices(0) /
+ *           unfinished_index / _prev_index / _next_index / reset
+ *           (tianshou/data/buffer/manager.py:70-229,306-358; buffer_base.py:292-410,495-531;
+ *            vecbuf.py:33-37).
+ * `state` is one device allocation of tsm_vrb_state_bytes() bytes owned by the caller:
+ *   i64 insertion_idx[B], size[B], ep_len[B], ep_start_idx[B], last_index[B], lengths[B];
+ *   f64 ep_return[B][rew_dim];  i64 error_flag[1]
+ * ------------------------------------------------------------------------------------------- */
+int64_t tsm_vrb_state_bytes(int64_t buffer_num, int64_t rew_dim);
+int tsm_vrb_init(void *state, int64_t buffer_num, int64_t sub_size, int64_t rew_dim, void *stream);
+int tsm_vrb_reset(void *state, int64_t buffer_num, int64_t sub_size, int64_t rew_dim,
+                  int keep_statistics, void *stream);
+
+/* One payload field scattered by tsm_vrb_add: row r of `src` ([R][row_bytes], the vector env's
+ * AoS step output) goes to `dst` + ((slot * buffer_num + env) * row_bytes)  (time-major SoA). */
+typedef struct {
+    const void *src;
+    void *dst;
+    int64_t row_bytes;
+} tsm_field;
+
+/* add(): R rows, row r belongs to sub-buffer buffer_ids[r] (NULL = arange(R)); ids must be unique
+ * within one call (the reference's Collector never repeats an env id within a step).
+ *   rew [R][rew_dim] f32, done [R] u8 (= terminated | truncated, manager.py:150).
+ *   done_store: u8 [sub_size][buffer_num] (read by prev/next/unfinished_index).
+ * Outputs [R]: ptr (flat reference index env*sub_size+slot), ep_rew [R][rew_dim] f64, ep_len,
+ * ep_idx -- the reference's 4-tuple (manager.py:193).  MalformedBufferError is reported through
+ * state.error_flag (checked by tsm_vrb_check). */
+int tsm_vrb_add(void *state, int64_t buffer_num, int64_t sub_size, int64_t rew_dim,
+                const int64_t *buffer_ids, int64_t R, const float *rew, const uint8_t *done,
+                uint8_t *done_store, const tsm_field *fields_host, int n_fields, int64_t *ptr_out,
+                double *ep_rew_out, int64_t *ep_len_out, int64_t *ep_idx_out, void *stream);
+/* synchronises `stream`; returns TSM_ERR_MALFORMED_BUFFER if any add() tripped buffer_base.py:380 */
+int tsm_vrb_check(void *state, int64_t buffer_num, int64_t rew_dim, void *stream);
+
+/* sample_indices(0): out [buffer_num*sub_size] i64 (first *n_out valid), env-major, time-ordered.
+ * n_out: device i64[1].  scratch: device i64[buffer_num + 1]. */
+int tsm_vrb_sample_indices_all(const void *state, int64_t buffer_num, int64_t sub_size,
+                               int64_t *out, int64_t *n_out, int64_t *scratch, void *stream);
+/* unfinished_index(): out [buffer_num] i64 (first *n_out valid, ascending env order). */
+int tsm_vrb_unfinished_index(const void *state, int64_t buffer_num, int64_t sub_size,
+                             const uint8_t *done_store, int64_t *out, int64_t *n_out, void *stream);
+int tsm_vrb_prev(const void *state, int64_t buffer_num, int64_t sub_size, const uint8_t *done_store,
+                 const int64_t *index, int64_t n, int64_t *out, void *stream);
+int tsm_vrb_next(const void *state, int64_t buffer_num, int64_t sub_size, const uint8_t *done_store,
+                 const int64_t *index, int64_t n, int64_t *out, void *stream);
+/* gather rows by flat reference index (ReplayBuffer.__getitem__, buffer_base.py:591-635):
+ * out[i] = store[(slot*buffer_num + env)] for index[i] = env*sub_size + slot. */
+int tsm_vrb_gather(const void *store, int64_t buffer_num, int64_t sub_size, int64_t row_bytes,
+                   const int64_t *index, int64_t n, void *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Agent dispatch  [a5, a10]
+ * Replaces  `np.nonzero(batch.obs.agent_id == agent_id)[0]` per agent and the scatter
+ *           `holder.act[agent_index] = act`  (tianshou/algorithm/multiagent/marl.py:148,170-180,233).
+ * agent_id [B] i32 in [0, n_agent).  index_out [B] i64: rows of agent 0 (ascending), then agent 1 ...
+ * offsets_out [n_agent+1] i64.  scratch: i64 [n_agent * n_blocks + 1], n_blocks = ceil(B/1024).
+ * ------------------------------------------------------------------------------------------- */
+int tsm_agent_index(const int32_t *agent_id, int64_t B, int32_t n_agent, int64_t *index_out,
+                    int64_t *offsets_out, int64_t *scratch, void *stream);
+/* dst[index[i]] = src[i]  /  dst[i] = src[index[i]]   rows of row_bytes */
+int tsm_scatter_rows(const void *src, const int64_t *index, int64_t n, int64_t row_bytes, void *dst,
+                     void *stream);
+int tsm_gather_rows(const void *src, const int64_t *index, int64_t n, int64_t row_bytes, void *dst,
+                    void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Categorical policy head  [a7, a13]
+ * Replaces  torch.distributions.Categorical(logits=...).sample / log_prob / entropy
+ *           (tianshou/utils/net/discrete.py:22-24; reinforce.py:183-189; ppo.py:160,187,210).
+ * logits [B][A] f32 row-major.  Sampling uses a counter-based Philox4x32-10 stream keyed by
+ * (seed, offset + row): reproducible, order-independent, NOT bit-identical to torch's CPU RNG.
+ * deterministic != 0 -> dist.mode (argmax) (reinforce.py:185-189).
+ * ------------------------------------------------------------------------------------------- */
+int tsm_categorical_sample(const float *logits, int64_t B, int32_t A, uint64_t seed,
+                           uint64_t offset, int deterministic, int32_t *act_out, float *logp_out,
+                           void *stream);
+int tsm_categorical_logp_entropy(const float *logits, const int32_t *act, int64_t B, int32_t A,
+                                 float *logp_out, float *ent_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * PPO clip loss, forward + backward w.r.t. logits and value  [a14]
+ * Replaces  the body of PPO._update_with_batch (tianshou/algorithm/modelfree/ppo.py:182-211)
+ *           between the network forward and optim.step.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    double eps_clip;    /* 0.2 */
+    double dual_clip;   /* <= 0: off */
+    double vf_coef;     /* 0.5 */
+    double ent_coef;    /* 0.01 */
+    int32_t value_clip; /* 0 */
+    int32_t adv_norm;   /* 1 */
+} tsm_ppo_cfg;
+
+/* Per-minibatch advantage statistics (ppo.py:185, torch unbiased std).  Minibatch k covers
+ * perm[mb_start[k] .. mb_start[k+1]) (perm == NULL: identity; mb_start: device i64[n_mb+1]).
+ * stats_out [n_mb][2] f32 = {mean, std}.  One launch serves every minibatch of an epoch. */
+int tsm_ppo_adv_stats(const float *adv, const int64_t *perm, const int64_t *mb_start,
+                      int32_t n_mb, float *stats_out, void *stream);
+
+/* One minibatch of M samples: sample i is row perm[i] of the full-batch arrays (perm == NULL:
+ * row first_row + i).  logits [M][A] and value [M] are minibatch-contiguous network outputs.
+ * Outputs: dlogits [M][A], dvalue [M] (already scaled by 1/M and the coefficients, i.e. d loss),
+ * partial [n_blocks(M)][4] f64 per-block sums {clip_obj, vf, ent, 0}; tsm_ppo_loss_finalize
+ * folds them into scalars_out[4] = {loss, clip_loss, vf_loss, ent_loss}. */
+int64_t tsm_ppo_loss_partial_elems(int64_t M);
+int tsm_ppo_loss_fwd_bwd(const float *logits, const float *value, const int32_t *act,
+                         const float *logp_old, const float *adv, const float *returns,
+                         const float *v_s_old, const int64_t *perm, int64_t first_row, int64_t M,
+                         int32_t A, const float *adv_stats, const tsm_ppo_cfg *cfg_host,
+                         float *dlogits_out, float *dvalue_out, double *partial_out, void *stream);
+int tsm_ppo_loss_finalize(const double *partial, int64_t M, const tsm_ppo_cfg *cfg_host,
+                          float *scalars_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer step  [a15]
+ * Replaces  Algorithm.Optimizer.step: clip_grad_norm_ + torch.optim.Adam.step
+ *           (tianshou/algorithm/algorithm_base.py:485-498; optim.py:91-111) on one flat f32
+ *           parameter vector (actor+critic union, utils/net/common.py:461-474).
+ * grad_slabs [n_slab][n] f32: per-workgroup partial gradients, summed here in slab order
+ * (deterministic).  max_grad_norm <= 0: no clipping.  norm_scratch: f32[64] device.
+ * step: 1-based Adam step count.
+ * ------------------------------------------------------------------------------------------- */
+int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
+                  float *exp_avg_sq, int64_t step, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, double max_grad_norm, float *norm_scratch,
+                  void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CTDE global state  [a16]
+ * Replaces  GlobalStateConstructor.build("concatenate" | "mean")
+ *           (tianshou/algorithm/multiagent/ctde.py:291-300) for per-agent arrays [B][D] given in
+ *           env.agents order (quirk Q5).  mode 0: out [B][N*D] concat; mode 1: out [B][D] mean.
+ * With the joint-lane layout obs[..][N][D] the concatenation is a free reshape; this entry point
+ * serves hosts that hold one array per agent (the reference's dict-of-tensors AoS).
+ * ------------------------------------------------------------------------------------------- */
+int tsm_global_state(const float *const *obs_by_agent_host, int32_t n_agent, int64_t B, int32_t D,
+                     int mode, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSMARL_H */

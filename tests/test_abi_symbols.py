@@ -1,0 +1,67 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads here (no GPU) and exports every
+symbol declared in include/tsmarl.h; argument validation that needs no device works."""
+import ctypes as C
+import os
+
+import pytest
+
+from tianshou_marl_amd import _abi, _build
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _build.build()
+    return _abi.load()
+
+
+def test_every_header_symbol_is_exported_and_bound(lib):
+    declared = _abi.header_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in tsmarl.h but not exported"
+        assert name in _abi.SIGNATURES, f"{name} declared in tsmarl.h but not bound in _abi.SIGNATURES"
+    for name in _abi.SIGNATURES:
+        assert name in declared, f"{name} bound but not declared in tsmarl.h"
+
+
+def test_abi_version_and_sizes(lib):
+    assert lib.tsm_abi_version() == 1
+    assert lib.tsm_vrb_state_bytes(4, 1) == (6 * 4 + 4 + 1) * 8
+    assert lib.tsm_vrb_state_bytes(8, 3) == (6 * 8 + 24 + 1) * 8
+    assert lib.tsm_ppo_loss_partial_elems(0) == 0
+    assert lib.tsm_ppo_loss_partial_elems(257) == 8
+
+
+def test_argument_validation_maps_to_python_errors(lib):
+    # invalid sizes are rejected on the host before any device work (no GPU needed)
+    with pytest.raises(ValueError):
+        _abi.call("tsm_gae_lanes", None, None, None, None, None, 1, -1, 4, 1, None, None, 0.99, 0.95, 1.0,
+                  None, None, None)
+    with pytest.raises(ValueError):  # n_lane not a multiple of lanes_per_env
+        _abi.call("tsm_gae_lanes", 1, 1, 1, 1, 1, 1, 5, 7, 3, None, None, 0.99, 0.95, 1.0, 1, 1, None)
+    with pytest.raises(ValueError):
+        _abi.call("tsm_vrb_init", None, 0, 5, 1, None)
+    cfg = _abi.tsm_ppo_cfg(0.2, 0.5, 0.5, 0.01, 0, 1)  # dual_clip must be > 1 (ppo.py:124-126)
+    with pytest.raises(ValueError, match="Dual-clip"):
+        _abi.call("tsm_ppo_loss_fwd_bwd", 1, 1, 1, 1, 1, 1, None, None, 0, 8, 5, 1, C.byref(cfg), 1, 1, 1, None)
+
+
+def test_product_has_no_oracle_import():
+    """The product package must never import the oracle (test infrastructure)."""
+    root = os.path.dirname(os.path.abspath(_abi.__file__))
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "ref_shim" not in src, f
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+
+    from tianshou_marl_amd import ops
+
+    x = torch.zeros(4, 8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.gae_lanes(x, x, x, x.to(torch.uint8), x.to(torch.uint8))

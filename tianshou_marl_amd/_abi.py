@@ -1,0 +1,141 @@
+"""ctypes binding of the C-ABI in include/tsmarl.h (lib/libtsmarl_hip.so).
+
+This is the only place the package touches native code.  There is NO fallback: if the HIP
+library is missing or a call fails, the op raises (ImportError / RuntimeError / ValueError /
+MalformedBufferError) -- nothing here ever routes through oracle/ or a CPU path.
+PyTorch is used by callers only to own device memory and streams; this module sees raw pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtsmarl_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tsmarl.h")
+
+TSM_OK, TSM_ERR_INVALID, TSM_ERR_HIP, TSM_ERR_MALFORMED_BUFFER, TSM_ERR_UNSUPPORTED = range(5)
+
+
+class MalformedBufferError(RuntimeError):
+    """Mirror of tianshou.data.buffer.buffer_base.MalformedBufferError (buffer_base.py:17-18)."""
+
+
+class tsm_field(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64)]
+
+
+class tsm_ppo_cfg(C.Structure):
+    _fields_ = [("eps_clip", C.c_double), ("dual_clip", C.c_double), ("vf_coef", C.c_double),
+                ("ent_coef", C.c_double), ("value_clip", C.c_int32), ("adv_norm", C.c_int32)]
+
+
+_p, _i64, _i32, _f64, _int, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int, C.c_uint64
+
+# name -> (restype, argtypes); must list every function declared in include/tsmarl.h
+SIGNATURES = {
+    "tsm_abi_version": (_int, []),
+    "tsm_last_error": (C.c_char_p, []),
+    "tsm_device_info": (_int, [C.POINTER(_int), C.POINTER(_int), C.POINTER(_i64), C.c_char_p]),
+    "tsm_mem_alloc": (_int, [C.POINTER(_p), _i64]),
+    "tsm_mem_free": (_int, [_p]),
+    "tsm_mem_h2d": (_int, [_p, _p, _i64, _p]),
+    "tsm_mem_d2h": (_int, [_p, _p, _i64, _p]),
+    "tsm_mem_set": (_int, [_p, _int, _i64, _p]),
+    "tsm_stream_sync": (_int, [_p]),
+    "tsm_gae_lanes": (_int, [_p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _p, _p, _f64, _f64, _f64, _p, _p, _p]),
+    "tsm_mc_return_to_go_lanes": (_int, [_p, _i64, _i64, _f64, _p, _p]),
+    "tsm_vrb_state_bytes": (_i64, [_i64, _i64]),
+    "tsm_vrb_init": (_int, [_p, _i64, _i64, _i64, _p]),
+    "tsm_vrb_reset": (_int, [_p, _i64, _i64, _i64, _int, _p]),
+    "tsm_vrb_add": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _p, _p, C.POINTER(tsm_field), _int,
+                           _p, _p, _p, _p, _p]),
+    "tsm_vrb_check": (_int, [_p, _i64, _i64, _p]),
+    "tsm_vrb_sample_indices_all": (_int, [_p, _i64, _i64, _p, _p, _p, _p]),
+    "tsm_vrb_unfinished_index": (_int, [_p, _i64, _i64, _p, _p, _p, _p]),
+    "tsm_vrb_prev": (_int, [_p, _i64, _i64, _p, _p, _i64, _p, _p]),
+    "tsm_vrb_next": (_int, [_p, _i64, _i64, _p, _p, _i64, _p, _p]),
+    "tsm_vrb_gather": (_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _p]),
+    "tsm_agent_index": (_int, [_p, _i64, _i32, _p, _p, _p, _p]),
+    "tsm_scatter_rows": (_int, [_p, _p, _i64, _i64, _p, _p]),
+    "tsm_gather_rows": (_int, [_p, _p, _i64, _i64, _p, _p]),
+    "tsm_categorical_sample": (_int, [_p, _i64, _i32, _u64, _u64, _int, _p, _p, _p]),
+    "tsm_categorical_logp_entropy": (_int, [_p, _p, _i64, _i32, _p, _p, _p]),
+    "tsm_ppo_adv_stats": (_int, [_p, _p, _p, _i32, _p, _p]),
+    "tsm_ppo_loss_partial_elems": (_i64, [_i64]),
+    "tsm_ppo_loss_fwd_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p,
+                                    C.POINTER(tsm_ppo_cfg), _p, _p, _p, _p]),
+    "tsm_ppo_loss_finalize": (_int, [_p, _i64, C.POINTER(tsm_ppo_cfg), _p, _p]),
+    "tsm_adam_step": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _p, _p]),
+    "tsm_global_state": (_int, [C.POINTER(_p), _i32, _i64, _i32, _int, _p, _p]),
+}
+
+_NO_STATUS = {"tsm_abi_version", "tsm_last_error", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems"}
+
+_lib = None
+
+
+def header_symbols() -> list[str]:
+    """Every function name declared in include/tsmarl.h."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m tianshou_marl_amd._build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tsm_abi_version() != 1:
+        raise ImportError(f"ABI version mismatch: library reports {lib.tsm_abi_version()}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc == TSM_OK:
+        return
+    msg = load().tsm_last_error().decode("utf-8", "replace")
+    if rc == TSM_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == TSM_ERR_MALFORMED_BUFFER:
+        raise MalformedBufferError(msg)
+    raise RuntimeError(f"tsmarl error {rc}: {msg}")
+
+
+def call(name: str, *args):
+    """Call an ABI function; status-returning functions raise on failure."""
+    fn = getattr(load(), name)
+    out = fn(*args)
+    if name in _NO_STATUS:
+        return out
+    check(out)
+    return None
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a torch tensor (None -> NULL).  Requires a contiguous CUDA/HIP tensor."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("tianshou_marl_amd ops need device (HIP) tensors; there is no CPU path")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

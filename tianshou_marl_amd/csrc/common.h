@@ -1,0 +1,99 @@
+// common.h -- shared helpers for the gfx950 kernels behind include/tsmarl.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tsmarl.h"
+
+#define TSM_EXPORT extern "C" __attribute__((visibility("default")))
+
+// thread-local last-error message (abi.hip)
+void tsm_set_error(const char *fmt, ...);
+
+#define TSM_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            tsm_set_error(__VA_ARGS__);   \
+            return TSM_ERR_INVALID;       \
+        }                                 \
+    } while (0)
+
+#define TSM_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            tsm_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),       \
+                          __FILE__, __LINE__);                                         \
+            return TSM_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define TSM_LAUNCH_CHECK()                                                             \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            tsm_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_),   \
+                          __FILE__, __LINE__);                                         \
+            return TSM_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+static inline hipStream_t tsm_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- wave / block reductions (64-wide) ----
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sum over a block of NT threads (NT multiple of 64, <= 1024); result valid in every thread
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum(T v, T *smem /* NT/64 entries */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    T r = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += smem[i];
+    return r;
+}
+
+// inclusive prefix sum across the 64 lanes of a wave
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        T n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+// block-wide exclusive scan for a 1-D block of NT threads (NT multiple of 64, <= 1024).
+// Returns this thread's exclusive prefix; *total receives the block sum (valid in all threads).
+template <typename T, int NT>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *smem /* NT/64 + 1 entries */, T *total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const T inc = wave_inclusive_scan(v);
+    __syncthreads();
+    if (lane == 63) smem[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T run = 0;
+        for (int i = 0; i < NT / 64; ++i) { T t = smem[i]; smem[i] = run; run += t; }
+        smem[NT / 64] = run;
+    }
+    __syncthreads();
+    *total = smem[NT / 64];
+    return smem[w] + inc - v;
+}

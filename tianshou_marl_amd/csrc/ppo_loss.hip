@@ -1,0 +1,217 @@
+// ppo_loss.hip -- PPO clip loss: per-minibatch advantage statistics, fused forward + backward
+// w.r.t. logits and value, deterministic scalar reduction.
+//
+// Replaces the loss body of PPO._update_with_batch
+// (/root/reference/tianshou/algorithm/modelfree/ppo.py:182-211): advantage normalisation with torch's
+// unbiased std (:184-186), ratio/clip/dual-clip (:187-196), value(-clip) loss (:198-208), entropy
+// (:210), total loss (:211).  Gradients follow torch autograd conventions (minimum/maximum split ties
+// 50/50, clamp passes gradient on the closed interval) -- restated in oracle/oracle.c:orc_ppo_loss.
+//
+// HBM traffic per sample and gradient step (A = 5, no value clip): read logits 20 + act 4 +
+// logp_old 4 + adv 4 + returns 4 + value 4, write dlogits 20 + dvalue 4 = 64 B.
+#include "common.h"
+
+namespace {
+
+// ---- advantage statistics: one 1024-thread block per minibatch, two passes in f64 ----
+__global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict__ adv,
+                                                         const int64_t *__restrict__ perm,
+                                                         const int64_t *__restrict__ mb_start,
+                                                         float *__restrict__ stats_out) {
+    __shared__ double sm[1024 / 64];
+    const int64_t s0 = mb_start[blockIdx.x], s1 = mb_start[blockIdx.x + 1];
+    const int64_t M = s1 - s0;
+    double acc = 0.0;
+    for (int64_t i = s0 + threadIdx.x; i < s1; i += 1024) acc += (double)adv[perm ? perm[i] : i];
+    const double mean = block_sum<double, 1024>(acc, sm) / (double)M;
+    acc = 0.0;
+    for (int64_t i = s0 + threadIdx.x; i < s1; i += 1024) {
+        const double d = (double)adv[perm ? perm[i] : i] - mean;
+        acc += d * d;
+    }
+    const double ss = block_sum<double, 1024>(acc, sm);
+    if (threadIdx.x == 0) {
+        stats_out[2 * blockIdx.x + 0] = (float)mean;
+        stats_out[2 * blockIdx.x + 1] = M > 1 ? (float)sqrt(ss / (double)(M - 1)) : NAN;  // torch.std
+    }
+}
+
+struct Cfg {
+    float eps_clip, dual_clip, vf_coef, ent_coef;
+    int value_clip, adv_norm;
+};
+
+constexpr int kLossThreads = 256;
+constexpr int kMaxA = 64;
+
+template <int A_T>
+__global__ __launch_bounds__(kLossThreads) void loss_kernel(
+    const float *__restrict__ logits, const float *__restrict__ value, const int32_t *__restrict__ act,
+    const float *__restrict__ logp_old, const float *__restrict__ adv, const float *__restrict__ returns,
+    const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first_row, int64_t M,
+    int32_t A_rt, const float *__restrict__ adv_stats, Cfg cfg, float *__restrict__ dlogits,
+    float *__restrict__ dvalue, double *__restrict__ partial) {
+    __shared__ double sm[kLossThreads / 64];
+    const int A = A_T > 0 ? A_T : A_rt;
+    const int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x;
+    double t_clip = 0.0, t_vf = 0.0, t_ent = 0.0;
+    if (i < M) {
+        const int64_t row = perm ? perm[i] : first_row + i;
+        const float invM = 1.0f / (float)M;
+        float lg[A_T > 0 ? A_T : kMaxA];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < A; ++j) { lg[j] = logits[i * A + j]; m = fmaxf(m, lg[j]); }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) s += expf(lg[j] - m);
+        const float lse = m + logf(s);
+        const int a_idx = act[row];
+        float a = adv[row];
+        if (cfg.adv_norm) a = (a - adv_stats[0]) / (adv_stats[1] + 1e-8f);
+        float logp = 0.f, h = 0.f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float l = lg[j] - lse;
+            lg[j] = l;
+            h -= expf(l) * l;
+            if (j == a_idx) logp = l;
+        }
+        const float ratio = expf(logp - logp_old[row]);
+        const float lo = 1.0f - cfg.eps_clip, hi = 1.0f + cfg.eps_clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = ratio * a, s2 = rc * a;
+        const bool in_range = ratio >= lo && ratio <= hi;
+        float obj, g_ratio;
+        if (s1 < s2) { obj = s1; g_ratio = a; }
+        else if (s1 > s2) { obj = s2; g_ratio = in_range ? a : 0.f; }
+        else { obj = s1; g_ratio = 0.5f * a + (in_range ? 0.5f * a : 0.f); }
+        if (cfg.dual_clip > 0.f && a < 0.f) {
+            const float c = cfg.dual_clip * a;
+            if (c > obj) { obj = c; g_ratio = 0.f; }
+            else if (c == obj) g_ratio *= 0.5f;
+        }
+        const float v = value[i], ret = returns[row];
+        float vf, g_v;
+        if (cfg.value_clip) {
+            const float vs = v_s_old[row];
+            const float d = v - vs;
+            const float dc = fminf(fmaxf(d, -cfg.eps_clip), cfg.eps_clip);
+            const bool v_in = d >= -cfg.eps_clip && d <= cfg.eps_clip;
+            const float vclip = vs + dc;
+            const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vclip) * (ret - vclip);
+            const float g1 = 2.f * (v - ret), g2 = v_in ? 2.f * (vclip - ret) : 0.f;
+            if (vf1 > vf2) { vf = vf1; g_v = g1; }
+            else if (vf1 < vf2) { vf = vf2; g_v = g2; }
+            else { vf = vf1; g_v = 0.5f * g1 + 0.5f * g2; }
+        } else {
+            vf = (ret - v) * (ret - v);
+            g_v = 2.f * (v - ret);
+        }
+        dvalue[i] = cfg.vf_coef * g_v * invM;
+        const float g_logp = -g_ratio * ratio * invM;
+        const float ec = cfg.ent_coef * invM;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float l = lg[j], p = expf(l);
+            const float dlogp = (j == a_idx ? 1.f : 0.f) - p;
+            const float dent = -p * (l + h);
+            dlogits[i * A + j] = g_logp * dlogp - ec * dent;
+        }
+        t_clip = obj; t_vf = vf; t_ent = h;
+    }
+    const double b_clip = block_sum<double, kLossThreads>(t_clip, sm);
+    const double b_vf = block_sum<double, kLossThreads>(t_vf, sm);
+    const double b_ent = block_sum<double, kLossThreads>(t_ent, sm);
+    if (threadIdx.x == 0) {
+        partial[4 * blockIdx.x + 0] = b_clip;
+        partial[4 * blockIdx.x + 1] = b_vf;
+        partial[4 * blockIdx.x + 2] = b_ent;
+        partial[4 * blockIdx.x + 3] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const double *__restrict__ partial, int64_t n_blocks,
+                                                       int64_t M, float vf_coef, float ent_coef,
+                                                       float *__restrict__ scalars) {
+    __shared__ double sm[256 / 64];
+    double c = 0.0, v = 0.0, e = 0.0;
+    for (int64_t b = threadIdx.x; b < n_blocks; b += 256) {
+        c += partial[4 * b + 0];
+        v += partial[4 * b + 1];
+        e += partial[4 * b + 2];
+    }
+    c = block_sum<double, 256>(c, sm);
+    v = block_sum<double, 256>(v, sm);
+    e = block_sum<double, 256>(e, sm);
+    if (threadIdx.x == 0) {
+        const double clip_loss = -c / (double)M, vf_loss = v / (double)M, ent_loss = e / (double)M;
+        scalars[0] = (float)(clip_loss + (double)vf_coef * vf_loss - (double)ent_coef * ent_loss);
+        scalars[1] = (float)clip_loss;
+        scalars[2] = (float)vf_loss;
+        scalars[3] = (float)ent_loss;
+    }
+}
+
+Cfg to_cfg(const tsm_ppo_cfg *c) {
+    Cfg k;
+    k.eps_clip = (float)c->eps_clip;
+    k.dual_clip = (float)c->dual_clip;
+    k.vf_coef = (float)c->vf_coef;
+    k.ent_coef = (float)c->ent_coef;
+    k.value_clip = c->value_clip;
+    k.adv_norm = c->adv_norm;
+    return k;
+}
+
+}  // namespace
+
+TSM_EXPORT int tsm_ppo_adv_stats(const float *adv, const int64_t *perm, const int64_t *mb_start,
+                                 int32_t n_mb, float *stats_out, void *stream) {
+    TSM_REQUIRE(n_mb >= 0, "tsm_ppo_adv_stats: negative n_mb");
+    if (n_mb == 0) return TSM_OK;
+    TSM_REQUIRE(adv && mb_start && stats_out, "tsm_ppo_adv_stats: null pointer");
+    hipLaunchKernelGGL(adv_stats_kernel, dim3((unsigned)n_mb), dim3(1024), 0, tsm_stream(stream), adv, perm,
+                       mb_start, stats_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+TSM_EXPORT int64_t tsm_ppo_loss_partial_elems(int64_t M) { return M <= 0 ? 0 : 4 * ceil_div(M, kLossThreads); }
+
+TSM_EXPORT int tsm_ppo_loss_fwd_bwd(const float *logits, const float *value, const int32_t *act,
+                                    const float *logp_old, const float *adv, const float *returns,
+                                    const float *v_s_old, const int64_t *perm, int64_t first_row, int64_t M,
+                                    int32_t A, const float *adv_stats, const tsm_ppo_cfg *cfg_host,
+                                    float *dlogits_out, float *dvalue_out, double *partial_out, void *stream) {
+    TSM_REQUIRE(M >= 0 && A >= 1 && A <= kMaxA, "tsm_ppo_loss_fwd_bwd: bad sizes M=%lld A=%d", (long long)M, A);
+    if (M == 0) return TSM_OK;
+    TSM_REQUIRE(cfg_host, "tsm_ppo_loss_fwd_bwd: null cfg");
+    TSM_REQUIRE(logits && value && act && logp_old && adv && returns && dlogits_out && dvalue_out && partial_out,
+                "tsm_ppo_loss_fwd_bwd: null pointer");
+    TSM_REQUIRE(!cfg_host->value_clip || v_s_old, "tsm_ppo_loss_fwd_bwd: value_clip needs v_s_old");
+    TSM_REQUIRE(!cfg_host->adv_norm || adv_stats, "tsm_ppo_loss_fwd_bwd: adv_norm needs adv_stats");
+    TSM_REQUIRE(cfg_host->dual_clip <= 0.0 || cfg_host->dual_clip > 1.0,
+                "Dual-clip PPO parameter should greater than 1.0 but got %g", cfg_host->dual_clip);  // ppo.py:124-126
+    const Cfg cfg = to_cfg(cfg_host);
+    const dim3 grid((unsigned)ceil_div(M, kLossThreads)), block(kLossThreads);
+    hipStream_t st = tsm_stream(stream);
+#define LAUNCH(AT)                                                                                         \
+    hipLaunchKernelGGL((loss_kernel<AT>), grid, block, 0, st, logits, value, act, logp_old, adv, returns,  \
+                       v_s_old, perm, first_row, M, A, adv_stats, cfg, dlogits_out, dvalue_out, partial_out)
+    if (A == 5) LAUNCH(5);
+    else LAUNCH(0);
+#undef LAUNCH
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+TSM_EXPORT int tsm_ppo_loss_finalize(const double *partial, int64_t M, const tsm_ppo_cfg *cfg_host,
+                                     float *scalars_out, void *stream) {
+    TSM_REQUIRE(M >= 1 && partial && cfg_host && scalars_out, "tsm_ppo_loss_finalize: bad args");
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, tsm_stream(stream), partial,
+                       ceil_div(M, kLossThreads), M, (float)cfg_host->vf_coef, (float)cfg_host->ent_coef,
+                       scalars_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}

@@ -1,0 +1,302 @@
+"""Tensor-level front-end of the C-ABI (one thin function per entry point of include/tsmarl.h).
+
+Inputs/outputs are torch tensors that live in HBM; every function launches hand-written HIP
+kernels through `_abi.call` on torch's current stream.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._abi import call, ptr, stream_ptr, tsm_field, tsm_ppo_cfg
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# GAE  (algorithm_base.py:651-717,1079-1134; a2c.py:132-146)
+# --------------------------------------------------------------------------------------------
+def gae_lanes(v_s, v_s_next, rew, terminated, truncated, gamma=0.99, gae_lambda=0.95, v_scale=1.0,
+              lanes_per_env=1, env_start=None, env_len=None, out=None):
+    """Per-lane GAE on time-major tensors [T, ...lanes]; returns (returns, adv) f32 tensors.
+
+    terminated/truncated: u8/bool, either the lane shape [T, n_lane] or env-level [T, n_env].
+    """
+    v_s = _chk(v_s, torch.float32, "v_s")
+    T = v_s.shape[0]
+    L = v_s[0].numel() if T > 0 else 0
+    v_s_next = _chk(v_s_next, torch.float32, "v_s_next")
+    rew = _chk(rew, torch.float32, "rew")
+    term = terminated.contiguous().view(torch.uint8) if terminated.dtype == torch.bool else _chk(terminated, torch.uint8, "terminated")
+    trunc = truncated.contiguous().view(torch.uint8) if truncated.dtype == torch.bool else _chk(truncated, torch.uint8, "truncated")
+    if v_s_next.shape != v_s.shape or rew.shape != v_s.shape:
+        raise ValueError("gae_lanes: v_s, v_s_next, rew must have identical shapes")
+    flags_per_lane = 1 if term.numel() == v_s.numel() else 0
+    if not flags_per_lane and term.numel() * lanes_per_env != v_s.numel():
+        raise ValueError("gae_lanes: flag tensors must be lane-shaped or env-shaped")
+    if trunc.numel() != term.numel():
+        raise ValueError("gae_lanes: terminated/truncated shape mismatch")
+    if out is None:
+        ret, adv = torch.empty_like(v_s), torch.empty_like(v_s)
+    else:
+        ret, adv = out
+    call("tsm_gae_lanes", ptr(v_s), ptr(v_s_next), ptr(rew), ptr(term), ptr(trunc), flags_per_lane, T, L,
+         lanes_per_env, ptr(env_start), ptr(env_len), float(gamma), float(gae_lambda), float(v_scale),
+         ptr(ret), ptr(adv), stream_ptr())
+    return ret, adv
+
+
+def mc_return_to_go_lanes(rew, gamma=0.99):
+    rew = _chk(rew, torch.float32, "rew")
+    out = torch.empty_like(rew)
+    T = rew.shape[0]
+    call("tsm_mc_return_to_go_lanes", ptr(rew), T, rew[0].numel() if T else 0, float(gamma), ptr(out), stream_ptr())
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# VectorReplayBuffer index state (manager.py / buffer_base.py)
+# --------------------------------------------------------------------------------------------
+class VrbState:
+    """Device-resident episode/index bookkeeping of a VectorReplayBuffer(total_size, buffer_num)."""
+
+    def __init__(self, total_size: int, buffer_num: int, rew_dim: int = 1, device="cuda"):
+        self.buffer_num = int(buffer_num)
+        self.sub_size = -(-int(total_size) // self.buffer_num)  # ceil, vecbuf.py:35
+        self.maxsize = self.sub_size * self.buffer_num
+        self.rew_dim = max(1, int(rew_dim))
+        self.device = torch.device(device)
+        nbytes = call("tsm_vrb_state_bytes", self.buffer_num, self.rew_dim)
+        self.state = torch.zeros(nbytes // 8, dtype=torch.int64, device=self.device)
+        self.done_store = torch.zeros(self.sub_size, self.buffer_num, dtype=torch.uint8, device=self.device)
+        self._scratch = torch.zeros(self.buffer_num + 1, dtype=torch.int64, device=self.device)
+        self._n_out = torch.zeros(1, dtype=torch.int64, device=self.device)
+        call("tsm_vrb_init", ptr(self.state), self.buffer_num, self.sub_size, self.rew_dim, stream_ptr())
+
+    # views into the packed state (i64 [6][B] | f64 [B][D] | i64 flag)
+    def _i64(self, k):
+        B = self.buffer_num
+        return self.state[k * B:(k + 1) * B]
+
+    insertion_idx = property(lambda s: s._i64(0))
+    size = property(lambda s: s._i64(1))
+    last_index = property(lambda s: s._i64(4))
+    lengths = property(lambda s: s._i64(5))
+
+    def __len__(self) -> int:
+        return int(self.lengths.sum().item())
+
+    def reset(self, keep_statistics: bool = False) -> None:
+        call("tsm_vrb_reset", ptr(self.state), self.buffer_num, self.sub_size, self.rew_dim,
+             int(keep_statistics), stream_ptr())
+
+    def add(self, rew, done, buffer_ids=None, fields=()):
+        """manager.py:131-193.  fields: iterable of (src[R, ...], dst[sub_size, buffer_num, ...])."""
+        rew = _chk(rew, torch.float32, "rew").reshape(rew.shape[0], -1)
+        R = rew.shape[0]
+        if rew.shape[1] != self.rew_dim:
+            raise ValueError(f"rew has {rew.shape[1]} columns, buffer was created with rew_dim={self.rew_dim}")
+        done = done.contiguous().view(torch.uint8) if done.dtype == torch.bool else _chk(done, torch.uint8, "done")
+        ids = None if buffer_ids is None else _chk(buffer_ids, torch.int64, "buffer_ids")
+        dev = self.device
+        ptr_out = torch.empty(R, dtype=torch.int64, device=dev)
+        ep_rew = torch.empty(R, self.rew_dim, dtype=torch.float64, device=dev)
+        ep_len = torch.empty(R, dtype=torch.int64, device=dev)
+        ep_idx = torch.empty(R, dtype=torch.int64, device=dev)
+        farr = (tsm_field * max(1, len(fields)))()
+        keep = []
+        for i, (src, dst) in enumerate(fields):
+            src = src.contiguous()
+            keep.append(src)
+            rb = src[0].numel() * src.element_size() if R else dst[0, 0].numel() * dst.element_size()
+            if dst[0, 0].numel() * dst.element_size() != rb:
+                raise ValueError(f"field {i}: row size mismatch between source and store")
+            farr[i] = tsm_field(ptr(src), ptr(dst), rb)
+        call("tsm_vrb_add", ptr(self.state), self.buffer_num, self.sub_size, self.rew_dim, ptr(ids), R,
+             ptr(rew), ptr(done), ptr(self.done_store), farr, len(fields), ptr(ptr_out), ptr(ep_rew),
+             ptr(ep_len), ptr(ep_idx), stream_ptr())
+        return ptr_out, ep_rew, ep_len, ep_idx
+
+    def check(self) -> None:
+        call("tsm_vrb_check", ptr(self.state), self.buffer_num, self.rew_dim, stream_ptr())
+
+    def sample_indices_all(self) -> torch.Tensor:
+        out = torch.empty(self.maxsize, dtype=torch.int64, device=self.device)
+        call("tsm_vrb_sample_indices_all", ptr(self.state), self.buffer_num, self.sub_size, ptr(out),
+             ptr(self._n_out), ptr(self._scratch), stream_ptr())
+        return out[: int(self._n_out.item())]
+
+    def unfinished_index(self) -> torch.Tensor:
+        out = torch.empty(self.buffer_num, dtype=torch.int64, device=self.device)
+        call("tsm_vrb_unfinished_index", ptr(self.state), self.buffer_num, self.sub_size,
+             ptr(self.done_store), ptr(out), ptr(self._n_out), stream_ptr())
+        return out[: int(self._n_out.item())]
+
+    def _pn(self, name, index):
+        index = _chk(torch.as_tensor(index, device=self.device), torch.int64, "index").reshape(-1)
+        out = torch.empty_like(index)
+        call(name, ptr(self.state), self.buffer_num, self.sub_size, ptr(self.done_store), ptr(index),
+             index.numel(), ptr(out), stream_ptr())
+        return out
+
+    def prev(self, index):
+        return self._pn("tsm_vrb_prev", index)
+
+    def next(self, index):
+        return self._pn("tsm_vrb_next", index)
+
+    def gather(self, store: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+        """ReplayBuffer.__getitem__ for one field: rows of a [sub_size, buffer_num, ...] store by flat index."""
+        index = _chk(index, torch.int64, "index").reshape(-1)
+        row_shape = store.shape[2:]
+        out = torch.empty((index.numel(), *row_shape), dtype=store.dtype, device=store.device)
+        rb = store[0, 0].numel() * store.element_size()
+        call("tsm_vrb_gather", ptr(store), self.buffer_num, self.sub_size, rb, ptr(index), index.numel(),
+             ptr(out), stream_ptr())
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# agent dispatch (marl.py:148,170-180,233)
+# --------------------------------------------------------------------------------------------
+def agent_index(agent_id: torch.Tensor, n_agent: int):
+    """Stable partition of row numbers by agent -> (index[B] i64, offsets[n_agent+1] i64)."""
+    agent_id = _chk(agent_id, torch.int32, "agent_id").reshape(-1)
+    B = agent_id.numel()
+    dev = agent_id.device
+    index = torch.empty(B, dtype=torch.int64, device=dev)
+    offsets = torch.empty(n_agent + 1, dtype=torch.int64, device=dev)
+    n_blocks = max(1, -(-B // 1024))
+    scratch = torch.empty(n_agent * n_blocks + 1, dtype=torch.int64, device=dev)
+    call("tsm_agent_index", ptr(agent_id), B, n_agent, ptr(index), ptr(offsets), ptr(scratch), stream_ptr())
+    return index, offsets
+
+
+def scatter_rows(src: torch.Tensor, index: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[index[i]] = src[i]"""
+    src = src.contiguous()
+    n = index.numel()
+    rb = (src[0].numel() if n else 1) * src.element_size()
+    call("tsm_scatter_rows", ptr(src), ptr(_chk(index, torch.int64, "index")), n, rb, ptr(dst), stream_ptr())
+    return dst
+
+
+def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """out[i] = src[index[i]]"""
+    src = src.contiguous()
+    n = index.numel()
+    out = torch.empty((n, *src.shape[1:]), dtype=src.dtype, device=src.device)
+    rb = src[0].numel() * src.element_size()
+    call("tsm_gather_rows", ptr(src), ptr(_chk(index, torch.int64, "index")), n, rb, ptr(out), stream_ptr())
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# categorical head (discrete.py:22-24; reinforce.py:183-189)
+# --------------------------------------------------------------------------------------------
+def categorical_sample(logits, seed: int, offset: int = 0, deterministic: bool = False, want_logp: bool = True):
+    logits = _chk(logits, torch.float32, "logits")
+    B, A = logits.shape
+    act = torch.empty(B, dtype=torch.int32, device=logits.device)
+    logp = torch.empty(B, dtype=torch.float32, device=logits.device) if want_logp else None
+    call("tsm_categorical_sample", ptr(logits), B, A, seed & (2**64 - 1), offset & (2**64 - 1),
+         int(deterministic), ptr(act), ptr(logp), stream_ptr())
+    return act, logp
+
+
+def categorical_logp_entropy(logits, act):
+    logits = _chk(logits, torch.float32, "logits")
+    act = _chk(act, torch.int32, "act")
+    B, A = logits.shape
+    logp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    ent = torch.empty(B, dtype=torch.float32, device=logits.device)
+    call("tsm_categorical_logp_entropy", ptr(logits), ptr(act), B, A, ptr(logp), ptr(ent), stream_ptr())
+    return logp, ent
+
+
+# --------------------------------------------------------------------------------------------
+# PPO loss (ppo.py:182-211)
+# --------------------------------------------------------------------------------------------
+def make_ppo_cfg(eps_clip=0.2, dual_clip=None, value_clip=False, adv_norm=True, vf_coef=0.5, ent_coef=0.01):
+    return tsm_ppo_cfg(float(eps_clip), float(dual_clip or 0.0), float(vf_coef), float(ent_coef),
+                       int(bool(value_clip)), int(bool(adv_norm)))
+
+
+def ppo_adv_stats(adv, mb_start, perm=None):
+    """Per-minibatch (mean, unbiased std) of adv[perm[mb_start[k]:mb_start[k+1]]] -> [n_mb, 2] f32."""
+    adv = _chk(adv, torch.float32, "adv").reshape(-1)
+    mb_start = _chk(mb_start, torch.int64, "mb_start")
+    n_mb = mb_start.numel() - 1
+    stats = torch.empty(n_mb, 2, dtype=torch.float32, device=adv.device)
+    call("tsm_ppo_adv_stats", ptr(adv), ptr(perm), ptr(mb_start), n_mb, ptr(stats), stream_ptr())
+    return stats
+
+
+def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, returns, cfg: tsm_ppo_cfg, adv_stats=None,
+                     v_s_old=None, perm=None, first_row=0):
+    """One minibatch -> (dlogits[M,A], dvalue[M], scalars[4]={loss, clip, vf, ent})."""
+    logits = _chk(logits, torch.float32, "logits")
+    M, A = logits.shape
+    value = _chk(value, torch.float32, "value").reshape(-1)
+    dev = logits.device
+    dlogits = torch.empty_like(logits)
+    dvalue = torch.empty(M, dtype=torch.float32, device=dev)
+    partial = torch.empty(max(1, call("tsm_ppo_loss_partial_elems", M)), dtype=torch.float64, device=dev)
+    scalars = torch.empty(4, dtype=torch.float32, device=dev)
+    s = stream_ptr()
+    call("tsm_ppo_loss_fwd_bwd", ptr(logits), ptr(value), ptr(_chk(act, torch.int32, "act")),
+         ptr(_chk(logp_old, torch.float32, "logp_old")), ptr(_chk(adv, torch.float32, "adv")),
+         ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old), ptr(perm), first_row, M, A,
+         ptr(adv_stats), C.byref(cfg), ptr(dlogits), ptr(dvalue), ptr(partial), s)
+    if M > 0:
+        call("tsm_ppo_loss_finalize", ptr(partial), M, C.byref(cfg), ptr(scalars), s)
+    return dlogits, dvalue, scalars
+
+
+# --------------------------------------------------------------------------------------------
+# optimizer (algorithm_base.py:485-498; optim.py:91-111)
+# --------------------------------------------------------------------------------------------
+def adam_step(param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+              weight_decay=0.0, max_grad_norm=None, norm_scratch=None):
+    """In-place Adam on a flat f32 vector; grad_slabs [n_slab, n] are summed in slab order."""
+    n = param.numel()
+    grad_slabs = _chk(grad_slabs, torch.float32, "grad_slabs").reshape(-1, n)
+    if max_grad_norm and norm_scratch is None:
+        norm_scratch = torch.empty(64, dtype=torch.float32, device=param.device)
+    call("tsm_adam_step", ptr(param), ptr(grad_slabs), grad_slabs.shape[0], n, ptr(exp_avg), ptr(exp_avg_sq),
+         int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+         float(max_grad_norm or 0.0), ptr(norm_scratch), stream_ptr())
+    return param
+
+
+# --------------------------------------------------------------------------------------------
+# CTDE (ctde.py:291-300)
+# --------------------------------------------------------------------------------------------
+def global_state(obs_by_agent, mode: str = "concatenate") -> torch.Tensor:
+    """obs_by_agent: list of [B, D] f32 tensors in env.agents order."""
+    if mode not in ("concatenate", "mean"):
+        raise ValueError(f"unsupported global-state mode {mode!r} (concatenate | mean)")
+    obs = [_chk(o, torch.float32, "obs") for o in obs_by_agent]
+    N = len(obs)
+    B, D = obs[0].shape
+    arr = (C.c_void_p * N)(*[ptr(o) for o in obs])
+    out = torch.empty((B, N * D) if mode == "concatenate" else (B, D), dtype=torch.float32, device=obs[0].device)
+    call("tsm_global_state", arr, N, B, D, 0 if mode == "concatenate" else 1, ptr(out), stream_ptr())
+    return out
+
+
+def device_info() -> dict:
+    n_cu, wave, hbm = C.c_int(), C.c_int(), C.c_int64()
+    name = C.create_string_buffer(64)
+    call("tsm_device_info", C.byref(n_cu), C.byref(wave), C.byref(hbm), name)
+    return dict(n_cu=n_cu.value, wave_size=wave.value, hbm_bytes=hbm.value, arch=name.value.decode())
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]
+_ = _abi
