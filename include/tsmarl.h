@@ -213,6 +213,41 @@ int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t
                   void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused actor + critic MLP (f32 MFMA)  [a7, a11, a13, a14]
+ * Networks: obs[D] -> Linear(H) ReLU -> Linear(H) ReLU -> {Linear(A) logits | Linear(1) value},
+ * i.e. Net(hidden_sizes=[H,H]) + DiscreteActor(softmax_output=False) / DiscreteCritic with separate
+ * trunks (tianshou/utils/net/common.py:246-369, discrete.py:27-124).  `params` is ONE flat f32 vector
+ * in ActorCritic.parameters() order (common.py:461-474):
+ *   actor W1[H][D] b1[H] W2[H][H] b2[H] W3[A][H] b3[A] | critic W1[H][D] b1[H] W2[H][H] b2[H] W3[1][H] b3[1]
+ * Supported: H == 64, D <= 64, A <= 16 (others: TSM_ERR_INVALID).
+ *
+ * tsm_policy_forward replaces ProbabilisticActorPolicy.forward + critic(obs) + dist.log_prob
+ * (reinforce.py:167-192, a2c.py:121-127, ppo.py:157-161) for obs [B][D]:
+ *   mode 0: logits/value only;  1: sample (Philox, key=seed, counter=offset+row);  2: dist.mode;
+ *   mode 3: log-prob of the GIVEN actions act_io.   logits_out/value_out/logp_out are nullable.
+ *
+ * tsm_ppo_update_fused replaces one gradient step of PPO._update_with_batch (ppo.py:182-212) up to the
+ * parameter gradients: network forward, loss (as tsm_ppo_loss_fwd_bwd) and the whole backward pass.
+ * Sample i of the minibatch is row perm[i] (perm == NULL: first_row + i) of obs [n][D], act, logp_old,
+ * adv, returns, v_s_old.  Each of the n_blocks workgroups writes one gradient slab:
+ * grad_slabs_out [n_blocks][P]; feed them to tsm_adam_step(n_slab = n_blocks).
+ * loss_partial_out: f64 [n_blocks][4]; scalars_out (nullable) f32[4] = {loss, clip, vf, ent}.
+ * ------------------------------------------------------------------------------------------- */
+int64_t tsm_policy_param_count(int32_t obs_dim, int32_t hidden, int32_t n_act);
+int tsm_policy_forward(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+                       const float *obs, int64_t B, int mode, uint64_t seed, uint64_t offset,
+                       float *logits_out, float *value_out, int32_t *act_io, float *logp_out,
+                       void *stream);
+/* recommended number of workgroups (= gradient slabs) for a minibatch of M rows */
+int tsm_ppo_update_grid(int64_t M, int32_t max_blocks);
+int tsm_ppo_update_fused(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+                         const float *obs, const int32_t *act, const float *logp_old, const float *adv,
+                         const float *returns, const float *v_s_old, const int64_t *perm,
+                         int64_t first_row, int64_t M, const float *adv_stats,
+                         const tsm_ppo_cfg *cfg_host, int32_t n_blocks, float *grad_slabs_out,
+                         double *loss_partial_out, float *scalars_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * CTDE global state  [a16]
  * Replaces  GlobalStateConstructor.build("concatenate" | "mean")
  *           (tianshou/algorithm/multiagent/ctde.py:291-300) for per-agent arrays [B][D] given in

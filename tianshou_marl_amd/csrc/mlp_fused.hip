@@ -1,0 +1,630 @@
+// mlp_fused.hip -- actor + critic MLP (obs -> H -> H -> {A logits | 1 value}) on f32 MFMA, fused with
+// the categorical head (rollout) and with the PPO loss + full backward pass (update).
+//
+// Replaces, for the discrete-action actor/critic of the path:
+//   rollout : ProbabilisticActorPolicy.forward = actor(obs) -> Categorical(logits).sample()/mode
+//             (/root/reference/tianshou/algorithm/modelfree/reinforce.py:167-192) with
+//             DiscreteActor / Net / MLP (utils/net/discrete.py:67-89, common.py:172-181,343-369),
+//             critic(obs) of _add_returns_and_advantages (a2c.py:121-127) and logp_old (ppo.py:157-161);
+//   update  : one gradient step of PPO._update_with_batch (ppo.py:182-212) up to the parameter gradients:
+//             dist = policy(mb).dist; value = critic(mb.obs); loss; loss.backward().
+// Parameter vector (flat f32, torch nn.Linear layouts, actor then critic == ActorCritic.parameters()
+// order, utils/net/common.py:461-474):
+//   actor : W1[H][D] b1[H] W2[H][H] b2[H] W3[A][H] b3[A]     critic: W1[H][D] b1[H] W2[H][H] b2[H] W3[1][H] b3[1]
+//
+// gfx950 mapping: a workgroup = 4 waves owns tiles of R = 16 rows.  Weights of both nets are staged once
+// per workgroup in LDS (row stride = 2 * odd dwords => conflict-free 16-row x 2-k ds_read_b32 patterns);
+// every GEMM is v_mfma_f32_16x16x4_f32 (exact f32 FMA chains, 256 FLOP/clk/CU).  Wave w owns output
+// column block w of each net, so L1/L2/backward run two independent accumulator chains per wave
+// (actor | critic).  Weight gradients accumulate in registers across all tiles of the workgroup and are
+// written once as a per-workgroup slab [P]; tsm_adam_step sums the slabs in fixed order (deterministic).
+//
+// HBM traffic per sample and gradient step: obs 4*D + act 4 + logp_old 4 + adv 4 + returns 4 (+ perm 8)
+// = 88 B at D = 18 (SURVEY.md 8d "fully fused update step").
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int R = 16;      // rows per tile
+constexpr int NT = 256;    // threads per workgroup (4 waves)
+constexpr int kMaxJ = 4;   // obs_dim <= 64
+
+struct Dims {
+    int D, A;       // obs dim, n actions
+    int Kp1;        // D rounded up to 4 (L1 k extent)
+    int nJ;         // ceil(D / 16)
+    int ld1;        // 16*nJ + 2
+};
+
+template <int H>
+struct Lay {  // LDS layout in floats
+    static constexpr int ldh = H + 2;       // 66: 2*33
+    static constexpr int ld2 = 2 * H + 2;   // 130: 2*65
+    static constexpr int ldo = 18;          // logits(16) | value | pad
+    int W1, W2a, W2c, W3a, W3c, B1, B2, B3a, B3c, X, H1, H2, OUT, D3, D2, D1, total;
+    __host__ __device__ Lay(const Dims &d, bool bwd) {
+        int o = 0;
+        W1 = o; o += 2 * H * d.ld1;
+        W2a = o; o += H * ldh;
+        W2c = o; o += H * ldh;
+        W3a = o; o += 16 * ldh;
+        W3c = o; o += H;
+        B1 = o; o += 2 * H;
+        B2 = o; o += 2 * H;
+        B3a = o; o += 16;
+        B3c = o; o += 2;
+        X = o; o += R * d.ld1;
+        H1 = o; o += R * ld2;
+        H2 = o; o += R * ld2;
+        OUT = o; o += R * ldo;
+        D3 = o; o += bwd ? R * ldo : 0;
+        D2 = o; o += bwd ? R * ld2 : 0;
+        D1 = o; o += bwd ? R * ld2 : 0;
+        total = o;
+    }
+};
+
+__device__ __forceinline__ f4 mfma(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// parameter offsets in the flat vector
+template <int H>
+struct POff {
+    int aW1, ab1, aW2, ab2, aW3, ab3, cW1, cb1, cW2, cb2, cW3, cb3, total;
+    __host__ __device__ POff(int D, int A) {
+        int o = 0;
+        aW1 = o; o += H * D; ab1 = o; o += H; aW2 = o; o += H * H; ab2 = o; o += H; aW3 = o; o += A * H; ab3 = o; o += A;
+        cW1 = o; o += H * D; cb1 = o; o += H; cW2 = o; o += H * H; cb2 = o; o += H; cW3 = o; o += H; cb3 = o; o += 1;
+        total = o;
+    }
+};
+
+template <int H>
+__device__ void stage_weights(float *lds, const Lay<H> &ly, const Dims &d, const float *__restrict__ P) {
+    const POff<H> po(d.D, d.A);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 2 * H * d.ld1; e += NT) {  // W1 actor|critic, zero padded
+        const int row = e / d.ld1, c = e - row * d.ld1;
+        float v = 0.f;
+        if (c < d.D) v = row < H ? P[po.aW1 + row * d.D + c] : P[po.cW1 + (row - H) * d.D + c];
+        lds[ly.W1 + e] = v;
+    }
+    for (int e = tid; e < H * ly.ldh; e += NT) {
+        const int row = e / ly.ldh, c = e - row * ly.ldh;
+        lds[ly.W2a + e] = c < H ? P[po.aW2 + row * H + c] : 0.f;
+        lds[ly.W2c + e] = c < H ? P[po.cW2 + row * H + c] : 0.f;
+    }
+    for (int e = tid; e < 16 * ly.ldh; e += NT) {
+        const int row = e / ly.ldh, c = e - row * ly.ldh;
+        lds[ly.W3a + e] = (row < d.A && c < H) ? P[po.aW3 + row * H + c] : 0.f;
+    }
+    for (int e = tid; e < H; e += NT) {
+        lds[ly.W3c + e] = P[po.cW3 + e];
+        lds[ly.B1 + e] = P[po.ab1 + e];
+        lds[ly.B1 + H + e] = P[po.cb1 + e];
+        lds[ly.B2 + e] = P[po.ab2 + e];
+        lds[ly.B2 + H + e] = P[po.cb2 + e];
+    }
+    if (tid < 16) lds[ly.B3a + tid] = tid < d.A ? P[po.ab3 + tid] : 0.f;
+    if (tid == 0) lds[ly.B3c] = P[po.cb3];
+}
+
+// forward of one 16-row tile already staged in lds[ly.X]; leaves H1, H2, OUT (logits | value) in LDS
+template <int H>
+__device__ __forceinline__ void tile_forward(float *lds, const Lay<H> &ly, const Dims &d) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    // ---- L1: [R x D] x W1^T -> H1 (actor cols 0..H-1 | critic cols H..2H-1) ----
+    {
+        f4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_c = {0.f, 0.f, 0.f, 0.f};
+        const float *xa = lds + ly.X + r16 * d.ld1 + kq;
+        const float *wa = lds + ly.W1 + (16 * w + r16) * d.ld1 + kq;
+        const float *wc = lds + ly.W1 + (H + 16 * w + r16) * d.ld1 + kq;
+        for (int k0 = 0; k0 < d.Kp1; k0 += 4) {
+            const float a = xa[k0];
+            acc_a = mfma(a, wa[k0], acc_a);
+            acc_c = mfma(a, wc[k0], acc_c);
+        }
+        const int col = 16 * w + r16;
+        const float ba = lds[ly.B1 + col], bc = lds[ly.B1 + H + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = kq * 4 + r;
+            lds[ly.H1 + row * ly.ld2 + col] = fmaxf(acc_a[r] + ba, 0.f);
+            lds[ly.H1 + row * ly.ld2 + H + col] = fmaxf(acc_c[r] + bc, 0.f);
+        }
+    }
+    __syncthreads();
+    // ---- L2 ----
+    {
+        f4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_c = {0.f, 0.f, 0.f, 0.f};
+        const float *ha = lds + ly.H1 + r16 * ly.ld2 + kq;
+        const float *hc = ha + H;
+        const float *wa = lds + ly.W2a + (16 * w + r16) * ly.ldh + kq;
+        const float *wc = lds + ly.W2c + (16 * w + r16) * ly.ldh + kq;
+#pragma unroll 4
+        for (int k0 = 0; k0 < H; k0 += 4) {
+            acc_a = mfma(ha[k0], wa[k0], acc_a);
+            acc_c = mfma(hc[k0], wc[k0], acc_c);
+        }
+        const int col = 16 * w + r16;
+        const float ba = lds[ly.B2 + col], bc = lds[ly.B2 + H + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = kq * 4 + r;
+            lds[ly.H2 + row * ly.ld2 + col] = fmaxf(acc_a[r] + ba, 0.f);
+            lds[ly.H2 + row * ly.ld2 + H + col] = fmaxf(acc_c[r] + bc, 0.f);
+        }
+    }
+    __syncthreads();
+    // ---- L3: wave 0 -> logits (MFMA, A padded to 16); wave 1 -> value (VALU dot) ----
+    if (w == 0) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float *ha = lds + ly.H2 + r16 * ly.ld2 + kq;
+        const float *wa = lds + ly.W3a + r16 * ly.ldh + kq;
+#pragma unroll 4
+        for (int k0 = 0; k0 < H; k0 += 4) acc = mfma(ha[k0], wa[k0], acc);
+        const float b = lds[ly.B3a + r16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[ly.OUT + (kq * 4 + r) * ly.ldo + r16] = acc[r] + b;
+    } else if (w == 1 && lane < R) {
+        const float *hc = lds + ly.H2 + lane * ly.ld2 + H;
+        float s = 0.f;
+        for (int j = 0; j < H; ++j) s = fmaf(hc[j], lds[ly.W3c + j], s);
+        lds[ly.OUT + lane * ly.ldo + 16] = s + lds[ly.B3c];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void load_tile_x(float *lds, int X, const Dims &d, const float *__restrict__ obs,
+                                            const int64_t *__restrict__ perm, int64_t first, int64_t row0,
+                                            int64_t M) {
+    for (int e = threadIdx.x; e < R * d.ld1; e += NT) {
+        const int r = e / d.ld1, c = e - r * d.ld1;
+        float v = 0.f;
+        const int64_t i = row0 + r;
+        if (c < d.D && i < M) {
+            const int64_t src = perm ? perm[i] : first + i;
+            v = obs[src * d.D + c];
+        }
+        lds[X + e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rollout / inference: logits, value, optional sampling + log-prob
+// ------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(NT) void policy_forward_kernel(
+    const float *__restrict__ P, Dims d, const float *__restrict__ obs, int64_t B, uint64_t seed,
+    uint64_t offset, int mode /*0 none, 1 sample, 2 argmax, 3 given*/, float *__restrict__ logits_out,
+    float *__restrict__ value_out, int32_t *__restrict__ act_io, float *__restrict__ logp_out) {
+    extern __shared__ float lds[];
+    const Lay<H> ly(d, false);
+    stage_weights<H>(lds, ly, d, P);
+    const int64_t n_tiles = (B + R - 1) / R;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t row0 = t * R;
+        __syncthreads();  // previous tile's epilogue reads / weight staging complete
+        load_tile_x(lds, ly.X, d, obs, nullptr, 0, row0, B);
+        __syncthreads();
+        tile_forward<H>(lds, ly, d);
+        // epilogue: one thread per (row, col) for the stores, one thread per row for the head
+        if (logits_out) {
+            for (int e = threadIdx.x; e < R * d.A; e += NT) {
+                const int r = e / d.A, c = e - r * d.A;
+                if (row0 + r < B) logits_out[(row0 + r) * d.A + c] = lds[ly.OUT + r * ly.ldo + c];
+            }
+        }
+        if (threadIdx.x < R && row0 + threadIdx.x < B) {
+            const int r = threadIdx.x;
+            const int64_t i = row0 + r;
+            const float *lg = lds + ly.OUT + r * ly.ldo;
+            if (value_out) value_out[i] = lg[16];
+            if (mode != 0) {
+                float m = -INFINITY;
+                int arg = 0;
+                for (int j = 0; j < d.A; ++j) if (lg[j] > m) { m = lg[j]; arg = j; }
+                float s = 0.f;
+                for (int j = 0; j < d.A; ++j) s += expf(lg[j] - m);
+                int a = arg;
+                if (mode == 1) {
+                    const float u = tsm_philox_uniform(seed, offset + (uint64_t)i) * s;
+                    float c = 0.f;
+                    a = d.A - 1;
+                    for (int j = 0; j < d.A; ++j) { c += expf(lg[j] - m); if (u < c) { a = j; break; } }
+                } else if (mode == 3) {
+                    a = act_io[i];
+                }
+                if (mode != 3) act_io[i] = a;
+                if (logp_out) logp_out[i] = lg[a] - (m + logf(s));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// update: forward + PPO loss + backward -> per-workgroup gradient slab + loss partial sums
+// ------------------------------------------------------------------------------------------------
+struct LossCfg {
+    float eps_clip, dual_clip, vf_coef, ent_coef;
+    int value_clip, adv_norm;
+};
+
+template <int H>
+__global__ __launch_bounds__(NT) void ppo_update_kernel(
+    const float *__restrict__ P, Dims d, const float *__restrict__ obs, const int32_t *__restrict__ act,
+    const float *__restrict__ logp_old, const float *__restrict__ adv, const float *__restrict__ returns,
+    const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first, int64_t M,
+    const float *__restrict__ adv_stats, LossCfg cfg, float *__restrict__ slabs,
+    double *__restrict__ loss_partial) {
+    extern __shared__ float lds[];
+    const Lay<H> ly(d, true);
+    const POff<H> po(d.D, d.A);
+    stage_weights<H>(lds, ly, d, P);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const float invM = 1.0f / (float)M;
+    float a_mean = 0.f, a_std = 1.f;
+    if (cfg.adv_norm) { a_mean = adv_stats[0]; a_std = adv_stats[1]; }
+
+    // register-resident gradient accumulators (MFMA C layout)
+    f4 g_W3a = {0.f, 0.f, 0.f, 0.f};        // rows i (A pad 16) x cols 16w..
+    f4 g_W2a[4], g_W2c[4];                  // rows 16w.. x col block jb
+    f4 g_W1a[kMaxJ], g_W1c[kMaxJ];          // rows 16w.. x obs col block jb
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { g_W2a[j] = g_W3a; g_W2c[j] = g_W3a; }
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) { g_W1a[j] = g_W3a; g_W1c[j] = g_W3a; }
+    float g_b1 = 0.f, g_b2 = 0.f;           // threads 0..2H-1: bias grads of column tid (actor | critic)
+    float g_W3c = 0.f;                      // threads 0..H-1
+    float g_b3 = 0.f;                       // threads 0..A-1: b3a ; thread 16: b3c
+    double s_clip = 0.0, s_vf = 0.0, s_ent = 0.0;  // threads 0..R-1
+
+    const int64_t n_tiles = (M + R - 1) / R;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t row0 = t * R;
+        __syncthreads();
+        load_tile_x(lds, ly.X, d, obs, perm, first, row0, M);
+        __syncthreads();
+        tile_forward<H>(lds, ly, d);
+
+        // ---- loss head: one thread per row (ppo.py:182-211) -> D3 = [dlogits(16) | dvalue] ----
+        if (threadIdx.x < R) {
+            const int r = threadIdx.x;
+            const int64_t i = row0 + r;
+            float *d3 = lds + ly.D3 + r * ly.ldo;
+            float dl[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dl[j] = 0.f;
+            float dv = 0.f;
+            if (i < M) {
+                const int64_t src = perm ? perm[i] : first + i;
+                const float *lg = lds + ly.OUT + r * ly.ldo;
+                float m = -INFINITY;
+                for (int j = 0; j < d.A; ++j) m = fmaxf(m, lg[j]);
+                float s = 0.f;
+                for (int j = 0; j < d.A; ++j) s += expf(lg[j] - m);
+                const float lse = m + logf(s);
+                const int a_idx = act[src];
+                float a = adv[src];
+                if (cfg.adv_norm) a = (a - a_mean) / (a_std + 1e-8f);
+                float h = 0.f;
+                for (int j = 0; j < d.A; ++j) { const float l = lg[j] - lse; h -= expf(l) * l; }
+                const float logp = lg[a_idx] - lse;
+                const float ratio = expf(logp - logp_old[src]);
+                const float lo = 1.0f - cfg.eps_clip, hi = 1.0f + cfg.eps_clip;
+                const float rc = fminf(fmaxf(ratio, lo), hi);
+                const float s1 = ratio * a, s2 = rc * a;
+                const bool in_range = ratio >= lo && ratio <= hi;
+                float obj, g_ratio;
+                if (s1 < s2) { obj = s1; g_ratio = a; }
+                else if (s1 > s2) { obj = s2; g_ratio = in_range ? a : 0.f; }
+                else { obj = s1; g_ratio = 0.5f * a + (in_range ? 0.5f * a : 0.f); }
+                if (cfg.dual_clip > 0.f && a < 0.f) {
+                    const float c = cfg.dual_clip * a;
+                    if (c > obj) { obj = c; g_ratio = 0.f; }
+                    else if (c == obj) g_ratio *= 0.5f;
+                }
+                const float v = lg[16], ret = returns[src];
+                float vf, g_v;
+                if (cfg.value_clip) {
+                    const float vs = v_s_old[src];
+                    const float dd = v - vs;
+                    const float dc = fminf(fmaxf(dd, -cfg.eps_clip), cfg.eps_clip);
+                    const bool v_in = dd >= -cfg.eps_clip && dd <= cfg.eps_clip;
+                    const float vclip = vs + dc;
+                    const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vclip) * (ret - vclip);
+                    const float g1 = 2.f * (v - ret), g2 = v_in ? 2.f * (vclip - ret) : 0.f;
+                    if (vf1 > vf2) { vf = vf1; g_v = g1; }
+                    else if (vf1 < vf2) { vf = vf2; g_v = g2; }
+                    else { vf = vf1; g_v = 0.5f * g1 + 0.5f * g2; }
+                } else {
+                    vf = (ret - v) * (ret - v);
+                    g_v = 2.f * (v - ret);
+                }
+                dv = cfg.vf_coef * g_v * invM;
+                const float g_logp = -g_ratio * ratio * invM, ec = cfg.ent_coef * invM;
+                for (int j = 0; j < d.A; ++j) {
+                    const float l = lg[j] - lse, p = expf(l);
+                    dl[j] = g_logp * ((j == a_idx ? 1.f : 0.f) - p) + ec * p * (l + h);
+                }
+                s_clip += (double)obj; s_vf += (double)vf; s_ent += (double)h;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d3[j] = dl[j];
+            d3[16] = dv;
+        }
+        __syncthreads();
+
+        // ---- output-layer gradients + dh2 ----
+        {
+            // dW3a[i][16w + j] += sum_r dlogits[r][i] * h2a[r][16w + j]
+            const float *dA = lds + ly.D3 + kq * ly.ldo + r16;            // C-type read: [k=r][i]
+            const float *hB = lds + ly.H2 + kq * ly.ld2 + 16 * w + r16;   // C-type read: [k=r][j]
+#pragma unroll
+            for (int k0 = 0; k0 < R; k0 += 4) g_W3a = mfma(dA[k0 * ly.ldo], hB[k0 * ly.ld2], g_W3a);
+            // dh2a = dlogits[R x 8] . W3a[8 x H]  (rows >= A of W3a and cols >= A of dlogits are zero)
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float *dR = lds + ly.D3 + r16 * ly.ldo + kq;            // R-type read
+            const float *wB = lds + ly.W3a + kq * ly.ldh + 16 * w + r16;  // C-type read: [k=i][j]
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4) acc = mfma(dR[k0], wB[k0 * ly.ldh], acc);
+            const int col = 16 * w + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kq * 4 + r;
+                lds[ly.D2 + row * ly.ld2 + col] = lds[ly.H2 + row * ly.ld2 + col] > 0.f ? acc[r] : 0.f;
+            }
+            // critic side (rank-1): dh2c[r][j] = dv[r] * W3c[j] * (h2c > 0)
+            for (int e = threadIdx.x; e < R * H; e += NT) {
+                const int r = e / H, j = e - r * H;
+                const float hv = lds[ly.H2 + r * ly.ld2 + H + j];
+                lds[ly.D2 + r * ly.ld2 + H + j] = hv > 0.f ? lds[ly.D3 + r * ly.ldo + 16] * lds[ly.W3c + j] : 0.f;
+            }
+            if (threadIdx.x < H) {  // dW3c[j] += sum_r dv[r] * h2c[r][j]
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s = fmaf(lds[ly.D3 + r * ly.ldo + 16], lds[ly.H2 + r * ly.ld2 + H + threadIdx.x], s);
+                g_W3c += s;
+            }
+            if (threadIdx.x < 17) {  // b3a (cols 0..15) | b3c (col 16)
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += lds[ly.D3 + r * ly.ldo + threadIdx.x];
+                g_b3 += s;
+            }
+        }
+        __syncthreads();
+
+        // ---- hidden layer 2 gradients + dh1 ----
+        {
+            const float *dAa = lds + ly.D2 + kq * ly.ld2 + 16 * w + r16;  // [k=r][i = 16w + r16]
+            const float *dAc = dAa + H;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const float *hBa = lds + ly.H1 + kq * ly.ld2 + 16 * jb + r16;
+                const float *hBc = hBa + H;
+#pragma unroll
+                for (int k0 = 0; k0 < R; k0 += 4) {
+                    g_W2a[jb] = mfma(dAa[k0 * ly.ld2], hBa[k0 * ly.ld2], g_W2a[jb]);
+                    g_W2c[jb] = mfma(dAc[k0 * ly.ld2], hBc[k0 * ly.ld2], g_W2c[jb]);
+                }
+            }
+            if (threadIdx.x < 2 * H) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += lds[ly.D2 + r * ly.ld2 + threadIdx.x];
+                g_b2 += s;
+            }
+            // dh1 = dh2 . W2   (A: R-type on D2, B: C-type on W2[k][j])
+            f4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_c = {0.f, 0.f, 0.f, 0.f};
+            const float *dRa = lds + ly.D2 + r16 * ly.ld2 + kq;
+            const float *dRc = dRa + H;
+            const float *wBa = lds + ly.W2a + kq * ly.ldh + 16 * w + r16;
+            const float *wBc = lds + ly.W2c + kq * ly.ldh + 16 * w + r16;
+#pragma unroll 4
+            for (int k0 = 0; k0 < H; k0 += 4) {
+                acc_a = mfma(dRa[k0], wBa[k0 * ly.ldh], acc_a);
+                acc_c = mfma(dRc[k0], wBc[k0 * ly.ldh], acc_c);
+            }
+            const int col = 16 * w + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kq * 4 + r;
+                lds[ly.D1 + row * ly.ld2 + col] = lds[ly.H1 + row * ly.ld2 + col] > 0.f ? acc_a[r] : 0.f;
+                lds[ly.D1 + row * ly.ld2 + H + col] = lds[ly.H1 + row * ly.ld2 + H + col] > 0.f ? acc_c[r] : 0.f;
+            }
+        }
+        __syncthreads();
+
+        // ---- layer 1 gradients ----
+        {
+            const float *dAa = lds + ly.D1 + kq * ly.ld2 + 16 * w + r16;
+            const float *dAc = dAa + H;
+#pragma unroll
+            for (int jb = 0; jb < kMaxJ; ++jb) {
+                if (jb < d.nJ) {
+                    const float *xB = lds + ly.X + kq * d.ld1 + 16 * jb + r16;
+#pragma unroll
+                    for (int k0 = 0; k0 < R; k0 += 4) {
+                        const float b = xB[k0 * d.ld1];
+                        g_W1a[jb] = mfma(dAa[k0 * ly.ld2], b, g_W1a[jb]);
+                        g_W1c[jb] = mfma(dAc[k0 * ly.ld2], b, g_W1c[jb]);
+                    }
+                }
+            }
+            if (threadIdx.x < 2 * H) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += lds[ly.D1 + r * ly.ld2 + threadIdx.x];
+                g_b1 += s;
+            }
+        }
+    }
+
+    // ---- write this workgroup's gradient slab (flat parameter layout) ----
+    float *S = slabs + (int64_t)blockIdx.x * po.total;
+    const int colq = r16;  // C layout: col = lane & 15, row = kq*4 + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kq * 4 + r;
+        if (row < d.A) S[po.aW3 + row * H + 16 * w + colq] = g_W3a[r];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            S[po.aW2 + (16 * w + row) * H + 16 * jb + colq] = g_W2a[jb][r];
+            S[po.cW2 + (16 * w + row) * H + 16 * jb + colq] = g_W2c[jb][r];
+        }
+#pragma unroll
+        for (int jb = 0; jb < kMaxJ; ++jb) {
+            const int c = 16 * jb + colq;
+            if (jb < d.nJ && c < d.D) {
+                S[po.aW1 + (16 * w + row) * d.D + c] = g_W1a[jb][r];
+                S[po.cW1 + (16 * w + row) * d.D + c] = g_W1c[jb][r];
+            }
+        }
+    }
+    if (threadIdx.x < 2 * H) {
+        const int c = threadIdx.x;
+        if (c < H) { S[po.ab1 + c] = g_b1; S[po.ab2 + c] = g_b2; S[po.cW3 + c] = g_W3c; }
+        else { S[po.cb1 + c - H] = g_b1; S[po.cb2 + c - H] = g_b2; }
+    }
+    if (threadIdx.x < d.A) S[po.ab3 + threadIdx.x] = g_b3;
+    if (threadIdx.x == 16) S[po.cb3] = g_b3;
+    // loss partial sums: rows live in threads 0..15 of wave 0
+    if (w == 0) {
+        double c = s_clip, v = s_vf, e = s_ent;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            c += __shfl_xor(c, off, 64);
+            v += __shfl_xor(v, off, 64);
+            e += __shfl_xor(e, off, 64);
+        }
+        if (lane == 0) {
+            loss_partial[4 * blockIdx.x + 0] = c;
+            loss_partial[4 * blockIdx.x + 1] = v;
+            loss_partial[4 * blockIdx.x + 2] = e;
+            loss_partial[4 * blockIdx.x + 3] = 0.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void update_finalize_kernel(const double *__restrict__ partial, int n_blocks,
+                                                              int64_t M, float vf_coef, float ent_coef,
+                                                              float *__restrict__ scalars) {
+    __shared__ double sm[256 / 64];
+    double c = 0.0, v = 0.0, e = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) {
+        c += partial[4 * b + 0];
+        v += partial[4 * b + 1];
+        e += partial[4 * b + 2];
+    }
+    c = block_sum<double, 256>(c, sm);
+    v = block_sum<double, 256>(v, sm);
+    e = block_sum<double, 256>(e, sm);
+    if (threadIdx.x == 0) {
+        const double clip_loss = -c / (double)M, vf_loss = v / (double)M, ent_loss = e / (double)M;
+        scalars[0] = (float)(clip_loss + (double)vf_coef * vf_loss - (double)ent_coef * ent_loss);
+        scalars[1] = (float)clip_loss;
+        scalars[2] = (float)vf_loss;
+        scalars[3] = (float)ent_loss;
+    }
+}
+
+int make_dims(int32_t obs_dim, int32_t hidden, int32_t n_act, Dims *d) {
+    TSM_REQUIRE(hidden == 64, "fused MLP supports hidden == 64 (got %d)", hidden);
+    TSM_REQUIRE(obs_dim >= 1 && obs_dim <= 16 * kMaxJ, "fused MLP supports 1 <= obs_dim <= %d (got %d)", 16 * kMaxJ,
+                obs_dim);
+    TSM_REQUIRE(n_act >= 1 && n_act <= 16, "fused MLP supports 1 <= n_act <= 16 (got %d)", n_act);
+    d->D = obs_dim;
+    d->A = n_act;
+    d->Kp1 = (obs_dim + 3) / 4 * 4;
+    d->nJ = (obs_dim + 15) / 16;
+    d->ld1 = 16 * d->nJ + 2;
+    return TSM_OK;
+}
+
+}  // namespace
+
+TSM_EXPORT int64_t tsm_policy_param_count(int32_t obs_dim, int32_t hidden, int32_t n_act) {
+    if (hidden != 64) return -1;
+    return POff<64>(obs_dim, n_act).total;
+}
+
+TSM_EXPORT int tsm_policy_forward(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+                                  const float *obs, int64_t B, int mode, uint64_t seed, uint64_t offset,
+                                  float *logits_out, float *value_out, int32_t *act_io, float *logp_out,
+                                  void *stream) {
+    Dims d;
+    if (int rc = make_dims(obs_dim, hidden, n_act, &d)) return rc;
+    TSM_REQUIRE(B >= 0 && mode >= 0 && mode <= 3, "tsm_policy_forward: bad B / mode");
+    if (B == 0) return TSM_OK;
+    TSM_REQUIRE(params && obs, "tsm_policy_forward: null pointer");
+    TSM_REQUIRE(mode == 0 || act_io, "tsm_policy_forward: mode %d needs act_io", mode);
+    const Lay<64> ly(d, false);
+    const size_t shmem = (size_t)ly.total * sizeof(float);
+    const int64_t n_tiles = ceil_div(B, R);
+    const unsigned grid = (unsigned)(n_tiles < 1024 ? n_tiles : 1024);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel<64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((policy_forward_kernel<64>), dim3(grid), dim3(NT), shmem, tsm_stream(stream), params, d, obs,
+                       B, seed, offset, mode, logits_out, value_out, act_io, logp_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+TSM_EXPORT int tsm_ppo_update_grid(int64_t M, int32_t max_blocks) {
+    const int64_t n_tiles = ceil_div(M > 0 ? M : 1, R);
+    int64_t g = n_tiles < 256 ? n_tiles : 256;
+    if (max_blocks > 0 && g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+TSM_EXPORT int tsm_ppo_update_fused(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+                                    const float *obs, const int32_t *act, const float *logp_old, const float *adv,
+                                    const float *returns, const float *v_s_old, const int64_t *perm,
+                                    int64_t first_row, int64_t M, const float *adv_stats,
+                                    const tsm_ppo_cfg *cfg_host, int32_t n_blocks, float *grad_slabs_out,
+                                    double *loss_partial_out, float *scalars_out, void *stream) {
+    Dims d;
+    if (int rc = make_dims(obs_dim, hidden, n_act, &d)) return rc;
+    TSM_REQUIRE(M >= 1, "tsm_ppo_update_fused: M must be >= 1");
+    TSM_REQUIRE(cfg_host && params && obs && act && logp_old && adv && returns && grad_slabs_out && loss_partial_out,
+                "tsm_ppo_update_fused: null pointer");
+    TSM_REQUIRE(!cfg_host->value_clip || v_s_old, "tsm_ppo_update_fused: value_clip needs v_s_old");
+    TSM_REQUIRE(!cfg_host->adv_norm || adv_stats, "tsm_ppo_update_fused: adv_norm needs adv_stats");
+    TSM_REQUIRE(cfg_host->dual_clip <= 0.0 || cfg_host->dual_clip > 1.0,
+                "Dual-clip PPO parameter should greater than 1.0 but got %g", cfg_host->dual_clip);
+    TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(M, R), "tsm_ppo_update_fused: n_blocks=%d out of range",
+                n_blocks);
+    LossCfg cfg;
+    cfg.eps_clip = (float)cfg_host->eps_clip;
+    cfg.dual_clip = (float)cfg_host->dual_clip;
+    cfg.vf_coef = (float)cfg_host->vf_coef;
+    cfg.ent_coef = (float)cfg_host->ent_coef;
+    cfg.value_clip = cfg_host->value_clip;
+    cfg.adv_norm = cfg_host->adv_norm;
+    const Lay<64> ly(d, true);
+    const size_t shmem = (size_t)ly.total * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ppo_update_kernel<64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipStream_t st = tsm_stream(stream);
+    hipLaunchKernelGGL((ppo_update_kernel<64>), dim3((unsigned)n_blocks), dim3(NT), shmem, st, params, d, obs, act,
+                       logp_old, adv, returns, v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out,
+                       loss_partial_out);
+    TSM_LAUNCH_CHECK();
+    if (scalars_out) {
+        hipLaunchKernelGGL(update_finalize_kernel, dim3(1), dim3(256), 0, st, loss_partial_out, n_blocks, M,
+                           cfg.vf_coef, cfg.ent_coef, scalars_out);
+        TSM_LAUNCH_CHECK();
+    }
+    return TSM_OK;
+}

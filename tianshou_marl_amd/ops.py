@@ -276,6 +276,68 @@ def adam_step(param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9,
 
 
 # --------------------------------------------------------------------------------------------
+# fused actor+critic MLP (reinforce.py:167-192, a2c.py:121-127, ppo.py:157-212)
+# --------------------------------------------------------------------------------------------
+POLICY_MODES = {"none": 0, "sample": 1, "mode": 2, "given": 3}
+
+
+def policy_param_count(obs_dim: int, hidden: int, n_act: int) -> int:
+    n = call("tsm_policy_param_count", obs_dim, hidden, n_act)
+    if n < 0:
+        raise ValueError(f"fused MLP does not support hidden={hidden}")
+    return n
+
+
+def policy_forward(params, obs, n_act: int, hidden: int = 64, mode: str = "none", seed: int = 0, offset: int = 0,
+                   act=None, want_logits=True, want_value=True, want_logp=True):
+    """obs [B, D] f32 -> dict(logits[B,A], value[B], act[B] i32, logp[B]) via one fused kernel."""
+    obs = _chk(obs, torch.float32, "obs")
+    B, D = obs.shape
+    dev = obs.device
+    m = POLICY_MODES[mode]
+    logits = torch.empty(B, n_act, dtype=torch.float32, device=dev) if want_logits else None
+    value = torch.empty(B, dtype=torch.float32, device=dev) if want_value else None
+    if m == 3:
+        act = _chk(act, torch.int32, "act")
+    elif m != 0:
+        act = torch.empty(B, dtype=torch.int32, device=dev)
+    logp = torch.empty(B, dtype=torch.float32, device=dev) if (want_logp and m != 0) else None
+    call("tsm_policy_forward", ptr(_chk(params, torch.float32, "params")), D, hidden, n_act, ptr(obs), B, m,
+         seed & (2**64 - 1), offset & (2**64 - 1), ptr(logits), ptr(value), ptr(act), ptr(logp), stream_ptr())
+    return dict(logits=logits, value=value, act=act, logp=logp)
+
+
+def ppo_update_grid(M: int, max_blocks: int = 0) -> int:
+    return call("tsm_ppo_update_grid", M, max_blocks)
+
+
+def ppo_update_fused(params, obs, act, logp_old, adv, returns, cfg: tsm_ppo_cfg, n_act: int, hidden: int = 64,
+                     adv_stats=None, v_s_old=None, perm=None, first_row=0, M=None, n_blocks=None,
+                     slabs=None, partial=None, scalars=None):
+    """One PPO gradient step up to the gradients -> (grad_slabs[n_blocks, P], scalars[4])."""
+    obs = _chk(obs, torch.float32, "obs")
+    D = obs.shape[-1]
+    if M is None:
+        M = perm.numel() if perm is not None else obs.shape[0] - first_row
+    if n_blocks is None:
+        n_blocks = ppo_update_grid(M)
+    P = params.numel()
+    dev = obs.device
+    if slabs is None:
+        slabs = torch.empty(n_blocks, P, dtype=torch.float32, device=dev)
+    if partial is None:
+        partial = torch.empty(n_blocks * 4, dtype=torch.float64, device=dev)
+    if scalars is None:
+        scalars = torch.empty(4, dtype=torch.float32, device=dev)
+    call("tsm_ppo_update_fused", ptr(_chk(params, torch.float32, "params")), D, hidden, n_act, ptr(obs),
+         ptr(_chk(act, torch.int32, "act")), ptr(_chk(logp_old, torch.float32, "logp_old")),
+         ptr(_chk(adv, torch.float32, "adv")), ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old),
+         ptr(perm), first_row, M, ptr(adv_stats), C.byref(cfg), n_blocks, ptr(slabs), ptr(partial), ptr(scalars),
+         stream_ptr())
+    return slabs, scalars
+
+
+# --------------------------------------------------------------------------------------------
 # CTDE (ctde.py:291-300)
 # --------------------------------------------------------------------------------------------
 def global_state(obs_by_agent, mode: str = "concatenate") -> torch.Tensor:
