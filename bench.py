@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the rollout + update hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic rollouts: collect T = max_cycles
+vector steps of `n_env` simple_spread worlds per GPU (fused actor+critic+sampling, batched env step,
+buffer index algebra + SoA scatter), then one PPO update on those rows (critic passes, GAE, minibatch
+loop of fused forward/loss/backward + Adam).  Workload at N=1: BASELINE configs[1] (simple_spread N=3,
+shared PPO, num_envs=1024, obs 18, A=5, T=25, MLP 64-64).  N>1: env shards per rank (weak scaling:
+1024 envs per GPU, BASELINE configs[3]) with one RCCL all-reduce of the flat gradient per gradient step.
+value = env-steps/s = (n_env * n_agent * T * n_gpus) / max-over-ranks step time.
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-env", type=int, default=1024, help="envs per GPU")
+    ap.add_argument("--n-agent", type=int, default=3)
+    ap.add_argument("--horizon", type=int, default=25)
+    ap.add_argument("--minibatch", type=int, default=4096)
+    ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--dispatch", default="per_agent", choices=["per_agent", "pooled"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=64)
+    return ap.parse_args()
+
+
+def build_job(a, device, rank):
+    from tianshou_marl_amd.algorithm.ppo import PPO
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+    env = DeviceSimpleSpreadVectorEnv(a.n_env, a.n_agent, max_cycles=a.horizon, device=device, seed=1626 + rank)
+    net = DiscreteActorCritic(env.obs_dim, env.n_act, 64, device=device, init="orthogonal", seed=1626)
+    algo = PPO(net=net, lr=3e-4, dispatch=a.dispatch, shuffle="device", seed=1626 + rank)
+    buf = DeviceVectorReplayBuffer(a.n_env * a.horizon, a.n_env, a.n_agent, env.obs_dim, device=device)
+    col = Collector(algo, env, buf)
+    col.reset()
+    return env, net, algo, buf, col
+
+
+def one_step(a, algo, buf, col):
+    from tianshou_marl_amd.algorithm.ppo import policy_within_training_step
+
+    with policy_within_training_step(algo):
+        cs = col.collect(n_step=a.n_env * a.horizon)
+        ts = algo.update(buf, a.minibatch, a.repeat)
+    col.reset_buffer(keep_statistics=True)  # trainer.py:1104
+    return cs, ts
+
+
+def phase_times(a, algo, buf, col, reps=5):
+    """Per-phase device time (HIP events on the launch stream) outside the timed region."""
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.algorithm.ppo import policy_within_training_step
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    t_col = t_upd = 0.0
+    for _ in range(reps):
+        e0, e1, e2 = ev(), ev(), ev()
+        with policy_within_training_step(algo):
+            e0.record()
+            col.collect(n_step=a.n_env * a.horizon)
+            e1.record()
+            algo.update(buf, a.minibatch, a.repeat)
+            e2.record()
+        torch.cuda.synchronize()
+        t_col += e0.elapsed_time(e1)
+        t_upd += e1.elapsed_time(e2)
+        col.reset_buffer(keep_statistics=True)
+    # dominant-kernel roofline: the GAE scan over the rows of this job, timed alone (avg of 50 launches)
+    T, L = a.horizon, a.n_env * a.n_agent
+    v = torch.randn(T, L, device=buf.device)
+    fl = torch.zeros(T, L, dtype=torch.uint8, device=buf.device)
+    out = (torch.empty_like(v), torch.empty_like(v))
+    for _ in range(5):
+        ops.gae_lanes(v, v, v, fl, fl, out=out)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(50):
+        ops.gae_lanes(v, v, v, fl, fl, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    gae_s = e0.elapsed_time(e1) * 1e-3 / 50
+    return t_col / reps, t_upd / reps, gae_s
+
+
+def cpu_baseline(a):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cpu_path  # test/benchmark infrastructure: the CPU port of the same step
+
+    return cpu_path.run_baseline(n_env=a.cpu_envs, n_agent=a.n_agent, horizon=a.horizon, minibatch=a.minibatch,
+                                 repeat=a.repeat, dispatch=a.dispatch, budget_s=15.0)
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    env, net, algo, buf, col = build_job(a, device, rank)
+    if world > 1:
+        from tianshou_marl_amd.parallel import attach_data_parallel
+
+        attach_data_parallel(algo, dist)
+    for _ in range(a.warmup):
+        one_step(a, algo, buf, col)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cs, ts = one_step(a, algo, buf, col)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / a.steps * 1e3
+    agent_steps = a.n_env * a.n_agent * a.horizon * world
+    value = agent_steps / (dt / a.steps)
+    if rank == 0:
+        t_col_ms, t_upd_ms, gae_s = phase_times(a, algo, buf, col)
+        gae_bytes = 22 * a.horizon * a.n_env * a.n_agent  # 22 B / sample
+        out = {
+            "metric": "env-steps/sec (n_env x n_agent) incl. PPO update, simple_spread N=%d" % a.n_agent,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "simple_spread_v3 N=%d shared PPO, num_envs=%d per GPU, obs %d, A=5, T=%d, MLP 64-64"
+                       % (a.n_agent, a.n_env, 6 * a.n_agent, a.horizon),
+                       "minibatch": a.minibatch, "repeat": a.repeat, "dispatch": a.dispatch, "parallelism": "env-shard x%d" % world},
+            "collect_ms": t_col_ms, "ppo_update_ms": t_upd_ms,
+            "collect_env_steps_per_s": a.n_env * a.n_agent * a.horizon / (t_col_ms * 1e-3),
+            "gradient_steps_per_update": getattr(ts, "gradient_steps", None) or sum(
+                s.gradient_steps for s in getattr(ts, "_agent_id_to_stats", {}).values()),
+            "roofline": {"bound": "hbm", "kernel": "gae_lanes_kernel", "achieved": gae_bytes / gae_s / 1e9,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gae_bytes / gae_s / HBM_PEAK, "traffic": None,
+                         "bytes_per_launch": gae_bytes, "us_per_launch": gae_s * 1e6},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -207,6 +207,10 @@ int tsm_ppo_loss_finalize(const double *partial, int64_t M, const tsm_ppo_cfg *c
  * (deterministic).  max_grad_norm <= 0: no clipping.  norm_scratch: f32[64] device.
  * step: 1-based Adam step count.
  * ------------------------------------------------------------------------------------------- */
+/* out[i] = scale * sum_s grad_slabs[s][i]: the flat gradient handed to the RCCL all-reduce of the
+ * env-sharded data-parallel path (no reference counterpart: the reference has no distributed backend). */
+int tsm_reduce_slabs(const float *grad_slabs, int32_t n_slab, int64_t n, double scale, float *out,
+                     void *stream);
 int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
                   float *exp_avg_sq, int64_t step, double lr, double beta1, double beta2,
                   double eps, double weight_decay, double max_grad_norm, float *norm_scratch,
@@ -225,6 +229,8 @@ int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t
  * (reinforce.py:167-192, a2c.py:121-127, ppo.py:157-161) for obs [B][D]:
  *   mode 0: logits/value only;  1: sample (Philox, key=seed, counter=offset+row);  2: dist.mode;
  *   mode 3: log-prob of the GIVEN actions act_io.   logits_out/value_out/logp_out are nullable.
+ *   offset_dev (nullable, device u64[1]) is added to `offset`: lets a captured hipGraph advance the
+ *   sampling counter from device memory (tsm_mpe_spread_step bumps it).
  *
  * tsm_ppo_update_fused replaces one gradient step of PPO._update_with_batch (ppo.py:182-212) up to the
  * parameter gradients: network forward, loss (as tsm_ppo_loss_fwd_bwd) and the whole backward pass.
@@ -236,7 +242,7 @@ int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t
 int64_t tsm_policy_param_count(int32_t obs_dim, int32_t hidden, int32_t n_act);
 int tsm_policy_forward(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
                        const float *obs, int64_t B, int mode, uint64_t seed, uint64_t offset,
-                       float *logits_out, float *value_out, int32_t *act_io, float *logp_out,
+                       const uint64_t *offset_dev, float *logits_out, float *value_out, int32_t *act_io, float *logp_out,
                        void *stream);
 /* recommended number of workgroups (= gradient slabs) for a minibatch of M rows */
 int tsm_ppo_update_grid(int64_t M, int32_t max_blocks);
@@ -246,6 +252,35 @@ int tsm_ppo_update_fused(const float *params, int32_t obs_dim, int32_t hidden, i
                          int64_t first_row, int64_t M, const float *adv_stats,
                          const tsm_ppo_cfg *cfg_host, int32_t n_blocks, float *grad_slabs_out,
                          double *loss_partial_out, float *scalars_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched MPE worlds  [SURVEY 8f-1; replaces the per-env Python loop of a1-a3 for simple_spread]
+ * Device-resident restatement of PettingZoo-MPE simple_spread behind the parallel-mode
+ * EnhancedPettingZooEnv data formats (tianshou/env/enhanced_pettingzoo_env.py:130-222) and the
+ * BaseVectorEnv.step/reset contract (tianshou/env/venvs.py:195-322).  pettingzoo's sources are not in
+ * the reference tree: dynamics parity is UNPINNED.  State (caller-owned, device):
+ *   agent_pos, agent_vel, landmark_pos f32 [n_env][N][2]; steps i32 [n_env]; episode_ctr u64 [n_env].
+ * obs layout per agent (6N): [vel(2), pos(2), landmarks rel (2N), others rel (2(N-1)), comm (2(N-1))].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_env, n_agent, max_cycles, _pad;
+    double dt, damping, contact_force, contact_margin, agent_size, landmark_size, accel, max_speed,
+        local_ratio;
+} tsm_mpe_cfg;
+
+/* env_ids NULL: reset every env.  obs_out [n_env][N][6N] (rows of the reset envs are written). */
+int tsm_mpe_spread_reset(const tsm_mpe_cfg *cfg_host, uint64_t seed, uint64_t *episode_ctr,
+                         const int64_t *env_ids, int64_t n_ids, float *agent_pos, float *agent_vel,
+                         float *landmark_pos, int32_t *steps, float *obs_out, void *stream);
+/* act i32 [n_env][N] in {0 noop, 1 -x, 2 +x, 3 -y, 4 +y}.  Outputs: obs_next (terminal obs for finished
+ * episodes), obs_cur (nullable; what the policy sees next: reset obs where done and auto_reset), rew f32
+ * [n_env][N], terminated/truncated u8 [n_env][N], done_env u8 [n_env].  rng_tick (nullable, device
+ * u64[1]) += rng_tick_inc once per call. */
+int tsm_mpe_spread_step(const tsm_mpe_cfg *cfg_host, uint64_t seed, uint64_t *episode_ctr,
+                        const int32_t *act, float *agent_pos, float *agent_vel, float *landmark_pos,
+                        int32_t *steps, float *obs_next_out, float *obs_cur_out, float *rew_out,
+                        uint8_t *terminated_out, uint8_t *truncated_out, uint8_t *done_env_out,
+                        int auto_reset, uint64_t *rng_tick, uint64_t rng_tick_inc, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CTDE global state  [a16]

@@ -1,0 +1,146 @@
+"""TEST / BENCHMARK INFRASTRUCTURE ONLY -- CPU port of one bench.py step, in the reference's loop structure.
+
+Used by bench.py's `cpu_baseline` leg (kind = "port"): the reference itself is pure Python and never
+travels to the GPU box, so the baseline is this restatement of its hot path, timed on the box's host
+cores on a bounded sample of the same workload:
+
+  rollout  -- per-env Python loop over env objects + np.stack of the results (DummyVectorEnv,
+              /root/reference/tianshou/env/venvs.py:281-322), policy forward in PyTorch-CPU with
+              Categorical.sample (modelfree/reinforce.py:167-192), device->host action copy
+              (data/collector.py:736), buffer index bookkeeping (oracle.VectorReplayBufferIndex ==
+              data/buffer/manager.py:131-193) + numpy fancy-index scatter (manager.py:180);
+  update   -- critic passes in chunks of max_batchsize=256 (modelfree/a2c.py:121-127), single-thread
+              serial GAE (oracle.gae_lanes == numba `_gae`, algorithm_base.py:1079-1134), logp_old,
+              minibatch loop with autograd + clip-loss + Adam (modelfree/ppo.py:164-224), 4 .item() per
+              minibatch (ppo.py:213-216), per-agent dispatch of the shared algorithm (multiagent/marl.py:251-268).
+It is a reported baseline, not a target.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+import mpe_oracle
+import oracle
+
+
+def _mlp(d_in, h, d_out):
+    net = torch.nn.Sequential(torch.nn.Linear(d_in, h), torch.nn.ReLU(), torch.nn.Linear(h, h), torch.nn.ReLU(),
+                              torch.nn.Linear(h, d_out))
+    for m in net:
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight)
+            torch.nn.init.zeros_(m.bias)
+    return net
+
+
+def run_baseline(n_env=64, n_agent=3, horizon=25, minibatch=4096, repeat=1, dispatch="per_agent", budget_s=15.0,
+                 seed=1626):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    N, D, A, T = n_agent, 6 * n_agent, 5, horizon
+    envs = [mpe_oracle.SimpleSpreadWorld(N, T, 0.5, seed + i) for i in range(n_env)]
+    actor, critic = _mlp(D, 64, A), _mlp(D, 64, 1)
+    opt = torch.optim.Adam(list(actor.parameters()) + list(critic.parameters()), lr=3e-4)
+    S = T
+    obs_buf = np.zeros((n_env * S, N, D), np.float32)
+    obs_next_buf = np.zeros_like(obs_buf)
+    act_buf = np.zeros((n_env * S, N), np.int64)
+    rew_buf = np.zeros((n_env * S, N), np.float64)
+    term_buf = np.zeros((n_env * S, N), bool)
+    trunc_buf = np.zeros((n_env * S, N), bool)
+    index = oracle.VectorReplayBufferIndex(n_env * S, n_env, N)
+    last_obs = np.stack([e.reset() for e in envs]).astype(np.float32)
+
+    def one_step():
+        nonlocal last_obs
+        t_c0 = time.perf_counter()
+        index.reset(keep_statistics=True)
+        for _ in range(T):
+            with torch.no_grad():
+                logits = actor(torch.from_numpy(last_obs.reshape(n_env * N, D)))
+                act = torch.distributions.Categorical(logits=logits).sample().numpy().reshape(n_env, N)
+            res = [envs[i].step(act[i]) for i in range(n_env)]            # venvs.py:281-287
+            obs_next = np.stack([r[0] for r in res]).astype(np.float32)   # venvs.py:311-322
+            rew = np.stack([r[1] for r in res])
+            term = np.stack([r[2] for r in res])
+            trunc = np.stack([r[3] for r in res])
+            done = (term | trunc).any(1)
+            ptr, _, _, _ = index.add(rew, done)
+            obs_buf[ptr], obs_next_buf[ptr], act_buf[ptr] = last_obs, obs_next, act
+            rew_buf[ptr], term_buf[ptr], trunc_buf[ptr] = rew, term, trunc
+            last_obs = obs_next.copy()
+            for i in np.where(done)[0]:
+                last_obs[i] = envs[i].reset()
+        t_c1 = time.perf_counter()
+        # ---- update ----
+        idx = index.sample_indices_all()                                   # env-major, time-ordered
+        ob, obn = torch.from_numpy(obs_buf[idx]), torch.from_numpy(obs_next_buf[idx])
+        with torch.no_grad():
+            chunks = lambda x: torch.split(x.reshape(-1, D), 256)          # noqa: E731  a2c.py:122
+            v_s = torch.cat([critic(c) for c in chunks(ob)]).reshape(len(idx), N).numpy()
+            v_n = torch.cat([critic(c) for c in chunks(obn)]).reshape(len(idx), N).numpy()
+        # lanes: [T, n_env*N] time-major view of the env-major flat batch
+        tl = lambda x: np.ascontiguousarray(x.reshape(n_env, T, N).transpose(1, 0, 2).reshape(T, n_env * N))  # noqa: E731
+        ret, adv = oracle.gae_lanes(tl(v_s), tl(v_n), tl(rew_buf[idx]).astype(np.float32), tl(term_buf[idx]),
+                                    tl(trunc_buf[idx]), 0.99, 0.95, threads=1)
+        back = lambda x: x.reshape(T, n_env, N).transpose(1, 0, 2).reshape(len(idx), N)  # noqa: E731
+        ret, adv = back(ret).astype(np.float32), back(adv).astype(np.float32)
+        act_t = torch.from_numpy(act_buf[idx])
+        with torch.no_grad():
+            logp_old = torch.distributions.Categorical(logits=actor(ob.reshape(-1, D))).log_prob(act_t.reshape(-1)).reshape(len(idx), N)
+        groups = [[a] for a in range(N)] if dispatch == "per_agent" else [list(range(N))]
+        n_grad = 0
+        for g in groups:
+            sel = lambda x: torch.as_tensor(x)[:, g].reshape(-1, *x.shape[2:])  # noqa: E731
+            o_g, a_g, lp_g = sel(ob), sel(act_t), sel(logp_old)
+            adv_g, ret_g = sel(adv), sel(ret)
+            n = o_g.shape[0]
+            for _ in range(repeat):
+                perm = np.random.permutation(n)
+                for lo, hi in oracle.split_bounds(n, minibatch, True):
+                    mb = torch.as_tensor(perm[lo:hi])
+                    dist = torch.distributions.Categorical(logits=actor(o_g[mb]))
+                    a_mb = adv_g[mb]
+                    a_mb = (a_mb - a_mb.mean()) / (a_mb.std() + 1e-8)
+                    ratio = (dist.log_prob(a_g[mb]) - lp_g[mb]).exp()
+                    clip_loss = -torch.min(ratio * a_mb, ratio.clamp(0.8, 1.2) * a_mb).mean()
+                    vf_loss = (ret_g[mb] - critic(o_g[mb]).flatten()).pow(2).mean()
+                    ent = dist.entropy().mean()
+                    loss = clip_loss + 0.5 * vf_loss - 0.01 * ent
+                    opt.zero_grad()
+                    loss.backward()
+                    opt.step()
+                    _ = (clip_loss.item(), vf_loss.item(), ent.item(), loss.item())
+                    n_grad += 1
+        t_u1 = time.perf_counter()
+        return t_c1 - t_c0, t_u1 - t_c1, n_grad
+
+    one_step()  # warm-up (allocator, torch thread pool)
+    t_col = t_upd = 0.0
+    n_steps = 0
+    t0 = time.perf_counter()
+    while True:
+        c, u, n_grad = one_step()
+        t_col += c
+        t_upd += u
+        n_steps += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    per_step = (t_col + t_upd) / n_steps
+    return {
+        "value": n_env * N * T / per_step, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{n_steps} steps of n_env={n_env} (GPU job: per-GPU n_env is larger), N={N}, T={T}, minibatch={minibatch}, "
+                  f"repeat={repeat}, dispatch={dispatch}; python per-env loop + torch-CPU MLP/Adam + single-thread C GAE",
+        "collect_env_steps_per_s": n_env * N * T / (t_col / n_steps), "ppo_update_ms": t_upd / n_steps * 1e3,
+        "gradient_steps_per_update": n_grad, "host_cpus": os.cpu_count(),
+    }
+
+
+if __name__ == "__main__":
+    import json
+
+    print(json.dumps(run_baseline(budget_s=5.0)))

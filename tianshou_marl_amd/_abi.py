@@ -31,6 +31,13 @@ class tsm_ppo_cfg(C.Structure):
                 ("ent_coef", C.c_double), ("value_clip", C.c_int32), ("adv_norm", C.c_int32)]
 
 
+class tsm_mpe_cfg(C.Structure):
+    _fields_ = [("n_env", C.c_int32), ("n_agent", C.c_int32), ("max_cycles", C.c_int32), ("_pad", C.c_int32),
+                ("dt", C.c_double), ("damping", C.c_double), ("contact_force", C.c_double),
+                ("contact_margin", C.c_double), ("agent_size", C.c_double), ("landmark_size", C.c_double),
+                ("accel", C.c_double), ("max_speed", C.c_double), ("local_ratio", C.c_double)]
+
+
 _p, _i64, _i32, _f64, _int, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int, C.c_uint64
 
 # name -> (restype, argtypes); must list every function declared in include/tsmarl.h
@@ -68,9 +75,13 @@ SIGNATURES = {
                                     C.POINTER(tsm_ppo_cfg), _p, _p, _p, _p]),
     "tsm_ppo_loss_finalize": (_int, [_p, _i64, C.POINTER(tsm_ppo_cfg), _p, _p]),
     "tsm_adam_step": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _p, _p]),
+    "tsm_reduce_slabs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
     "tsm_global_state": (_int, [C.POINTER(_p), _i32, _i64, _i32, _int, _p, _p]),
     "tsm_policy_param_count": (_i64, [_i32, _i32, _i32]),
-    "tsm_policy_forward": (_int, [_p, _i32, _i32, _i32, _p, _i64, _int, _u64, _u64, _p, _p, _p, _p, _p]),
+    "tsm_policy_forward": (_int, [_p, _i32, _i32, _i32, _p, _i64, _int, _u64, _u64, _p, _p, _p, _p, _p, _p]),
+    "tsm_mpe_spread_reset": (_int, [C.POINTER(tsm_mpe_cfg), _u64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "tsm_mpe_spread_step": (_int, [C.POINTER(tsm_mpe_cfg), _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                   _int, _p, _u64, _p]),
     "tsm_ppo_update_grid": (_int, [_i64, _i32]),
     "tsm_ppo_update_fused": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p,
                                     C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p]),

@@ -1,0 +1,286 @@
+"""PPO on the device-resident rollout: policy forward, GAE, clip loss, backward and Adam in HIP.
+
+API mirror of the reference's on-policy actor-critic stack:
+  `PPO(...)`                       tianshou/algorithm/modelfree/ppo.py:17-224 (same hyper-parameter names/defaults)
+  `policy(batch, state)`           ProbabilisticActorPolicy.forward, modelfree/reinforce.py:167-192
+  `update(buffer, batch_size, repeat)`   OnPolicyAlgorithm.update -> Algorithm._update, algorithm_base.py:584-629,852-863
+  `_preprocess_batch`              a2c.py:113-151 + ppo.py:146-162 (critic passes, GAE, logp_old)
+  `_update_with_batch`             ppo.py:164-224 (minibatch loop, Batch.split merge_last rule, 4 loss statistics)
+  `Optimizer.step`                 algorithm_base.py:485-498 (clip_grad_norm_ + Adam)
+  `learn(batch)`                   the `.learn()` entry the MARL trainers call (training_coordinator.py:336)
+(all paths relative to /root/reference).  Per-agent dispatch of a shared algorithm object
+(MARLDispatcher, multiagent/marl.py:208-268) is selected with `dispatch="per_agent"`.
+"""
+from __future__ import annotations
+
+import time
+from typing import Literal
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..data.batch import Batch, split_bounds
+from ..data.buffer import DeviceVectorReplayBuffer
+from ..data.stats import A2CTrainingStats, MapTrainingStats, SequenceSummaryStats
+from ..utils.net import DiscreteActorCritic, RunningMeanStd
+
+
+class PPO(nn.Module):
+    def __init__(self, *, net: DiscreteActorCritic, lr: float = 3e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8,
+                 weight_decay: float = 0.0, eps_clip: float = 0.2, dual_clip: float | None = None,
+                 value_clip: bool = False, advantage_normalization: bool = True,
+                 recompute_advantage: bool = False, vf_coef: float = 0.5, ent_coef: float = 0.01,
+                 max_grad_norm: float | None = None, gae_lambda: float = 0.95, max_batchsize: int = 256,
+                 gamma: float = 0.99, return_scaling: bool = False, deterministic_eval: bool = False,
+                 dispatch: Literal["per_agent", "pooled"] = "per_agent",
+                 shuffle: Literal["numpy", "device"] = "numpy", seed: int = 0) -> None:
+        super().__init__()
+        assert dual_clip is None or dual_clip > 1.0, f"Dual-clip PPO parameter should greater than 1.0 but got {dual_clip}"
+        assert 0.0 <= gae_lambda <= 1.0, f"GAE lambda should be in [0, 1] but got: {gae_lambda}"
+        self.net = net
+        self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
+        self.eps_clip, self.dual_clip, self.value_clip = eps_clip, dual_clip, value_clip
+        self.advantage_normalization, self.recompute_adv = advantage_normalization, recompute_advantage
+        self.vf_coef, self.ent_coef, self.max_grad_norm = vf_coef, ent_coef, max_grad_norm
+        self.gae_lambda, self.gamma, self.max_batchsize = gae_lambda, gamma, max_batchsize
+        self.return_scaling, self.ret_rms, self._eps = return_scaling, RunningMeanStd(), 1e-8
+        self.deterministic_eval = deterministic_eval
+        self.is_within_training_step = False
+        self.dispatch, self.shuffle = dispatch, shuffle
+        self.seed = int(seed)
+        dev = net.flat.device
+        self.exp_avg = torch.zeros_like(net.flat.data)
+        self.exp_avg_sq = torch.zeros_like(net.flat.data)
+        self.opt_step = 0
+        self._norm_scratch = torch.zeros(64, dtype=torch.float32, device=dev)
+        self._sample_ctr = 0  # Philox counter base for action sampling
+        self._cfg = ops.make_ppo_cfg(eps_clip, dual_clip, value_clip, advantage_normalization, vf_coef, ent_coef)
+        self._ws: dict = {}
+        self._grad_sync = None  # set by parallel.attach_data_parallel
+
+    # the reference collector accepts an Algorithm and uses `.policy` (collector.py:358)
+    @property
+    def policy(self) -> "PPO":
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return self.net.flat.device
+
+    # ---- rollout side -------------------------------------------------------------------------
+    def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None) -> dict:
+        """obs [..., D] in HBM -> dict(act i32, logp, value) for every row (one fused kernel)."""
+        rows = obs.reshape(-1, self.net.obs_dim)
+        mode = "mode" if (self.deterministic_eval and not self.is_within_training_step) else "sample"
+        res = ops.policy_forward(self.net.flat.data, rows, self.net.n_act, self.net.hidden, mode=mode, seed=self.seed,
+                                 offset=self._sample_ctr, want_logits=out is None, offset_dev=offset_dev, out=out)
+        if offset_dev is None:
+            self._sample_ctr += rows.shape[0]
+        return res
+
+    def forward(self, batch: Batch, state=None, **kwargs) -> Batch:
+        """reinforce.py:167-192: Batch(logits, act, state, ...) for `batch.obs` (array [B, D] or Batch(obs=...))."""
+        obs = batch.obs
+        if isinstance(obs, Batch) and "obs" in obs:  # MARL wrappers hand over obs.obs (marl.py:157-161)
+            obs = obs.obs
+        obs_t = torch.as_tensor(np.asarray(obs) if not isinstance(obs, torch.Tensor) else obs).to(self.device, torch.float32)
+        lead = obs_t.shape[:-1]
+        res = self.act_device(obs_t)
+        return Batch(logits=res["logits"].reshape(*lead, -1), act=res["act"].reshape(lead).to(torch.int64),
+                     state=None, policy=Batch(logp=res["logp"].reshape(lead), v_s=res["value"].reshape(lead)))
+
+    def map_action(self, act):
+        return act  # discrete: identity (algorithm_base.py:255-289)
+
+    def map_action_inverse(self, act):
+        return act
+
+    def add_exploration_noise(self, act, batch):
+        return act
+
+    # ---- update side --------------------------------------------------------------------------
+    def _valid_rows(self, buffer: DeviceVectorReplayBuffer):
+        """Time-major joint rows (slot*B + env) that hold data, plus per-env ragged descriptors."""
+        lengths = buffer.index.lengths
+        lens_h = lengths.cpu().numpy()
+        S, B = buffer.sub_size, buffer.buffer_num
+        uniform = bool((lens_h == lens_h[0]).all())
+        ins_h = buffer.index.insertion_idx.cpu().numpy()
+        start_h = (ins_h - lens_h) % S
+        if uniform and (start_h == 0).all():
+            T = int(lens_h[0])
+            return T, None, None, None
+        slot = (start_h[None, :] + np.arange(S)[:, None]) % S
+        valid = np.arange(S)[:, None] < lens_h[None, :]
+        rows = (slot * B + np.arange(B)[None, :])[valid]
+        dev = self.device
+        return S, torch.as_tensor(rows).to(dev), torch.as_tensor(start_h.astype(np.int32)).to(dev), \
+            torch.as_tensor(lens_h.astype(np.int32)).to(dev)
+
+    def _preprocess_batch(self, buffer: DeviceVectorReplayBuffer) -> dict:
+        """a2c.py:113-151 + ppo.py:146-162 on the whole buffer (sample(0) == every stored row)."""
+        T, rows, env_start, env_len = self._valid_rows(buffer)
+        B, N, D = buffer.buffer_num, buffer.n_agent, buffer.obs_dim
+        L = B * N
+        P = self.net.flat.data
+        obs = buffer.obs_store[:T].reshape(T * L, D)
+        act = buffer.act_store[:T].reshape(T * L)
+        if buffer.obs_next_store is None:
+            raise ValueError("PPO.update needs a buffer that stores obs_next (ignore_obs_next=False)")
+        # critic(obs), critic(obs_next), logp_old: two fused passes (no max_batchsize chunking needed in HBM)
+        cur = ops.policy_forward(P, obs, self.net.n_act, self.net.hidden, mode="given", act=act, want_logits=False)
+        nxt = ops.policy_forward(P, buffer.obs_next_store[:T].reshape(T * L, D), self.net.n_act, self.net.hidden,
+                                 mode="none", want_logits=False)
+        v_s, v_next, logp_old = cur["value"].view(T, L), nxt["value"].view(T, L), cur["logp"]
+        scale = float(np.sqrt(self.ret_rms.var + self._eps)) if self.return_scaling else 1.0
+        ret, adv = ops.gae_lanes(v_s, v_next, buffer.rew_store[:T].reshape(T, L), buffer.term_store[:T].reshape(T, L),
+                                 buffer.trunc_store[:T].reshape(T, L), self.gamma, self.gae_lambda, v_scale=scale,
+                                 lanes_per_env=N, env_start=env_start, env_len=env_len)
+        if self.return_scaling:  # a2c.py:144-146: update with the UNNORMALISED returns
+            un = ret * scale
+            sel = un.view(T * B, N)[rows] if rows is not None else un
+            self.ret_rms.update(sel)
+        return dict(T=T, rows=rows, obs=obs, act=act, v_s=v_s.reshape(-1), ret=ret.reshape(-1), adv=adv.reshape(-1),
+                    logp_old=logp_old, n_env=B, n_agent=N)
+
+    def _sample_ids(self, pb: dict, agent: int | None) -> torch.Tensor | None:
+        """Flat sample ids ((slot*B+env)*N + agent) of the rows to train on; None = all, contiguous."""
+        T, B, N, rows = pb["T"], pb["n_env"], pb["n_agent"], pb["rows"]
+        dev = self.device
+        if rows is None and agent is None:
+            return None
+        base = rows if rows is not None else torch.arange(T * B, device=dev)
+        if agent is None:
+            return (base[:, None] * N + torch.arange(N, device=dev)[None, :]).reshape(-1)
+        return base * N + agent
+
+    def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
+                           buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:
+        """ppo.py:164-224 for one sample set (all lanes, or one agent's lanes under per-agent dispatch)."""
+        ids = self._sample_ids(pb, agent)
+        n = ids.numel() if ids is not None else pb["obs"].shape[0]
+        dev = self.device
+        bounds = split_bounds(n, batch_size or -1, merge_last=True)
+        mb_start = torch.as_tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=dev)
+        P, A, H = self.net.flat.data, self.net.n_act, self.net.hidden
+        n_steps = repeat * len(bounds)
+        scal = torch.zeros(n_steps, 4, dtype=torch.float32, device=dev)
+        max_M = max(e - s for s, e in bounds)
+        n_blk_max = ops.ppo_update_grid(max_M)
+        slabs = self._ws.get(("slabs", n_blk_max))
+        if slabs is None:
+            slabs = torch.empty(n_blk_max, P.numel(), dtype=torch.float32, device=dev)
+            self._ws[("slabs", n_blk_max)] = slabs
+        partial = torch.empty(n_blk_max * 4, dtype=torch.float64, device=dev)
+        k = 0
+        for step in range(repeat):
+            if self.recompute_adv and step > 0:  # ppo.py:174-178
+                pb = self._preprocess_batch(buffer)
+            if self.shuffle == "numpy":  # Batch.split draws np.random.permutation (batch.py:1219)
+                perm_local = torch.as_tensor(np.random.permutation(n)).to(dev)
+            else:
+                perm_local = torch.randperm(n, device=dev)
+            perm = perm_local if ids is None else ids[perm_local]
+            stats = ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm) if self.advantage_normalization else None
+            for j, (s, e) in enumerate(bounds):
+                M = e - s
+                nb = ops.ppo_update_grid(M)
+                ops.ppo_update_fused(P, pb["obs"], pb["act"], pb["logp_old"], pb["adv"], pb["ret"], self._cfg, A, H,
+                                     adv_stats=None if stats is None else stats[j],
+                                     v_s_old=pb["v_s"] if self.value_clip else None, perm=perm[s:e], M=M,
+                                     n_blocks=nb, slabs=slabs[:nb], partial=partial, scalars=scal[k])
+                self.opt_step += 1
+                grads = slabs[:nb]
+                if self._grad_sync is not None:  # env-sharded data parallel: ONE flat all-reduce (parallel.py)
+                    flat_g = self._ws.setdefault("flat_grad", torch.empty_like(P))
+                    ops.reduce_slabs(grads, out=flat_g)
+                    self._grad_sync.all_reduce_mean_(flat_g)
+                    grads = flat_g.view(1, -1)
+                ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr,
+                              betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
+                              max_grad_norm=self.max_grad_norm, norm_scratch=self._norm_scratch)
+                k += 1
+        s_h = scal.cpu().numpy()  # the only host sync of the update (the reference does 4 .item() per minibatch)
+        return A2CTrainingStats(
+            loss=SequenceSummaryStats.from_sequence(s_h[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(s_h[:, 1]),
+            vf_loss=SequenceSummaryStats.from_sequence(s_h[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(s_h[:, 3]),
+            gradient_steps=n_steps)
+
+    def update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
+        """OnPolicyAlgorithm.update (algorithm_base.py:852-863): raises outside a training step (:610-615)."""
+        if not self.is_within_training_step:
+            raise RuntimeError(
+                "update() was called outside of a training step as signalled by `is_within_training_step=False`; "
+                "wrap the call in `policy_within_training_step(policy)` (tianshou/utils/torch_utils.py:31-46)")
+        t0 = time.time()
+        pb = self._preprocess_batch(buffer)
+        if self.dispatch == "per_agent":
+            # MARLDispatcher.dispatch_update_with_batch: the (shared) algorithm is updated once per agent id,
+            # each time on that agent's rows only (marl.py:251-268); stats keyed "{agent}/..." (marl.py:51-59)
+            per_agent = {}
+            for a in range(buffer.n_agent):
+                st = self._update_with_batch(pb, batch_size, repeat, agent=a, buffer=buffer)
+                st.train_time = time.time() - t0
+                per_agent[f"agent_{a}"] = st
+            out = MapTrainingStats(per_agent)
+        else:
+            out = self._update_with_batch(pb, batch_size, repeat, agent=None, buffer=buffer)
+        out.train_time = time.time() - t0
+        return out
+
+    # ---- `.learn(batch)` for the MARL trainers (training_coordinator.py:336) ----------------------
+    def learn(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
+        """One PPO pass on an explicit agent batch holding obs, act, rew, obs_next, terminated[, truncated].
+        Rows are one time-ordered lane (the reference's per-agent Batch); GAE treats the last row as end."""
+        dev = self.device
+        t = lambda x, dt: torch.as_tensor(np.asarray(x)).to(dev, dt)  # noqa: E731
+        obs = t(batch.obs, torch.float32)
+        n = obs.shape[0]
+        act = t(batch.act, torch.int32).reshape(n)
+        P = self.net.flat.data
+        cur = ops.policy_forward(P, obs, self.net.n_act, self.net.hidden, mode="given", act=act, want_logits=False)
+        nxt = ops.policy_forward(P, t(batch.obs_next, torch.float32), self.net.n_act, self.net.hidden, mode="none",
+                                 want_logits=False)
+        term = t(batch.terminated, torch.uint8).reshape(n, 1)
+        trunc = t(batch.truncated, torch.uint8).reshape(n, 1) if "truncated" in batch else torch.zeros_like(term)
+        ret, adv = ops.gae_lanes(cur["value"].view(n, 1), nxt["value"].view(n, 1), t(batch.rew, torch.float32).view(n, 1),
+                                 term, trunc, self.gamma, self.gae_lambda)
+        pb = dict(T=n, rows=None, obs=obs, act=act, v_s=cur["value"], ret=ret.reshape(-1), adv=adv.reshape(-1),
+                  logp_old=cur["logp"], n_env=1, n_agent=1)
+        st = self._update_with_batch(pb, batch_size, repeat)
+        return {"loss": st.loss.mean, "actor_loss": st.actor_loss.mean, "vf_loss": st.vf_loss.mean,
+                "ent_loss": st.ent_loss.mean}
+
+    # ---- checkpointing (algorithm_base.py:521-541: optimizer state under "_optimizers") ----------
+    def state_dict(self, *args, **kwargs):
+        return {"net": self.net.to_reference_state_dict(), "flat": self.net.flat.data.clone(),
+                "_optimizers": [{"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                                 "step": self.opt_step, "lr": self.lr}],
+                "ret_rms": (self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count), "sample_ctr": self._sample_ctr}
+
+    def load_state_dict(self, sd, *args, **kwargs):
+        self.net.flat.data.copy_(sd["flat"])
+        o = sd["_optimizers"][0]
+        self.exp_avg.copy_(o["exp_avg"])
+        self.exp_avg_sq.copy_(o["exp_avg_sq"])
+        self.opt_step, self.lr = o["step"], o["lr"]
+        self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = sd["ret_rms"]
+        self._sample_ctr = sd.get("sample_ctr", 0)
+
+
+class policy_within_training_step:
+    """tianshou.utils.torch_utils.policy_within_training_step (torch_utils.py:31-46)."""
+
+    def __init__(self, policy, enabled: bool = True) -> None:
+        self.policy, self.enabled = policy, enabled
+
+    def __enter__(self):
+        self.prev = self.policy.is_within_training_step
+        self.policy.is_within_training_step = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        self.policy.is_within_training_step = self.prev
+        return False

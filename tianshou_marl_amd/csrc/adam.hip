@@ -55,7 +55,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     p[i] = pi - step_size * (mi / denom);
 }
 
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int32_t n_slab,
+                                                           int64_t n, float scale, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float g = 0.f;
+    for (int s = 0; s < n_slab; ++s) g += slabs[(int64_t)s * n + i];
+    out[i] = g * scale;
+}
+
 }  // namespace
+
+// Sum per-workgroup gradient slabs into one flat gradient (slab order => deterministic), times `scale`.
+// Used in front of the RCCL all-reduce of the data-parallel path (one flat buffer per gradient step).
+TSM_EXPORT int tsm_reduce_slabs(const float *grad_slabs, int32_t n_slab, int64_t n, double scale, float *out,
+                                void *stream) {
+    TSM_REQUIRE(n >= 0 && n_slab >= 1, "tsm_reduce_slabs: bad sizes");
+    if (n == 0) return TSM_OK;
+    TSM_REQUIRE(grad_slabs && out, "tsm_reduce_slabs: null pointer");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, tsm_stream(stream),
+                       grad_slabs, n_slab, n, (float)scale, out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
 
 TSM_EXPORT int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
                              float *exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps,

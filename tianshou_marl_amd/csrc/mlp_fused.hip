@@ -201,11 +201,13 @@ __device__ __forceinline__ void load_tile_x(float *lds, int X, const Dims &d, co
 template <int H>
 __global__ __launch_bounds__(NT) void policy_forward_kernel(
     const float *__restrict__ P, Dims d, const float *__restrict__ obs, int64_t B, uint64_t seed,
-    uint64_t offset, int mode /*0 none, 1 sample, 2 argmax, 3 given*/, float *__restrict__ logits_out,
+    uint64_t offset, const uint64_t *__restrict__ offset_dev, int mode /*0 none, 1 sample, 2 argmax, 3 given*/,
+    float *__restrict__ logits_out,
     float *__restrict__ value_out, int32_t *__restrict__ act_io, float *__restrict__ logp_out) {
     extern __shared__ float lds[];
     const Lay<H> ly(d, false);
     stage_weights<H>(lds, ly, d, P);
+    if (offset_dev) offset += *offset_dev;
     const int64_t n_tiles = (B + R - 1) / R;
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int64_t row0 = t * R;
@@ -553,7 +555,7 @@ TSM_EXPORT int64_t tsm_policy_param_count(int32_t obs_dim, int32_t hidden, int32
 
 TSM_EXPORT int tsm_policy_forward(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
                                   const float *obs, int64_t B, int mode, uint64_t seed, uint64_t offset,
-                                  float *logits_out, float *value_out, int32_t *act_io, float *logp_out,
+                                  const uint64_t *offset_dev, float *logits_out, float *value_out, int32_t *act_io, float *logp_out,
                                   void *stream) {
     Dims d;
     if (int rc = make_dims(obs_dim, hidden, n_act, &d)) return rc;
@@ -572,7 +574,7 @@ TSM_EXPORT int tsm_policy_forward(const float *params, int32_t obs_dim, int32_t 
         attr_set = true;
     }
     hipLaunchKernelGGL((policy_forward_kernel<64>), dim3(grid), dim3(NT), shmem, tsm_stream(stream), params, d, obs,
-                       B, seed, offset, mode, logits_out, value_out, act_io, logp_out);
+                       B, seed, offset, offset_dev, mode, logits_out, value_out, act_io, logp_out);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

@@ -1,0 +1,230 @@
+"""DeviceVectorReplayBuffer -- HBM-resident VectorReplayBuffer for joint-step multi-agent rows.
+
+API mirror of `VectorReplayBuffer(total_size, buffer_num)` / `ReplayBufferManager`
+(/root/reference/tianshou/data/buffer/vecbuf.py:15-37, manager.py:13-229, buffer_base.py:173-655):
+`add(batch, buffer_ids) -> (ptr, ep_rew, ep_len, ep_idx)`, `sample(0)`, `sample_indices(0)`,
+`__getitem__`, `unfinished_index()`, `prev/next`, `reset(keep_statistics)`, `__len__`, `buffer_num`,
+`subbuffer_edges`, `get_buffer_indices`, attribute access to stored fields (`buf.rew`, `buf.done` ...).
+
+Storage is time-major SoA in HBM:
+    obs[S, B, N, D] f32, obs_next (optional), act[S, B, N] i32, rew[S, B, N] f32,
+    terminated/truncated[S, B, N] u8, done[S, B] u8, policy extras logp[S, B, N], v_s[S, B, N]
+with S = ceil(total_size / buffer_num) slots and B = buffer_num envs.  One buffer row is one JOINT
+step of one env (all N agents), i.e. the parallel-mode layout of EnhancedPettingZooEnv
+(enhanced_pettingzoo_env.py:175-222); rew is the reference's per-agent reward vector (R, N).
+Flat reference index <-> (env, slot): index = env * S + slot.
+All index algebra and payload movement run in HIP (csrc/vrb.hip); there is no host fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import ops
+from .batch import Batch
+
+_RESERVED = ("obs", "act", "rew", "terminated", "truncated", "done", "obs_next", "info", "policy")
+
+
+class DeviceVectorReplayBuffer:
+    def __init__(self, total_size: int, buffer_num: int, n_agent: int, obs_dim: int, device: str | torch.device = "cuda",
+                 ignore_obs_next: bool = False, store_policy_outputs: bool = True) -> None:
+        self.buffer_num = int(buffer_num)
+        self.n_agent = int(n_agent)
+        self.obs_dim = int(obs_dim)
+        self.device = torch.device(device)
+        self.index = ops.VrbState(total_size, buffer_num, rew_dim=n_agent, device=self.device)
+        self.sub_size = self.index.sub_size
+        self.maxsize = self.index.maxsize
+        self._save_obs_next = not ignore_obs_next
+        S, B, N, D = self.sub_size, self.buffer_num, self.n_agent, self.obs_dim
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.device)  # noqa: E731
+        self.obs_store = z((S, B, N, D), torch.float32)
+        self.obs_next_store = z((S, B, N, D), torch.float32) if self._save_obs_next else None
+        self.act_store = z((S, B, N), torch.int32)
+        self.rew_store = z((S, B, N), torch.float32)
+        self.term_store = z((S, B, N), torch.uint8)
+        self.trunc_store = z((S, B, N), torch.uint8)
+        self.logp_store = z((S, B, N), torch.float32) if store_policy_outputs else None
+        self.vs_store = z((S, B, N), torch.float32) if store_policy_outputs else None
+        self._arange = torch.arange(self.maxsize, dtype=torch.int64, device=self.device)
+
+    # ---- reference attributes ---------------------------------------------------------------
+    @property
+    def subbuffer_edges(self) -> np.ndarray:
+        return np.arange(self.buffer_num + 1, dtype=int) * self.sub_size  # manager.py:55-58
+
+    def __len__(self) -> int:
+        return len(self.index)
+
+    @property
+    def done_store(self) -> torch.Tensor:
+        return self.index.done_store
+
+    def reset(self, keep_statistics: bool = False) -> None:
+        self.index.reset(keep_statistics)
+
+    # ---- add --------------------------------------------------------------------------------
+    def add_device(self, obs, act, rew, terminated, truncated, obs_next=None, logp=None, v_s=None,
+                   buffer_ids=None, done=None):
+        """Device-path add: every argument is an HBM tensor with leading dim R (rows = envs).
+
+        Returns the reference 4-tuple as device tensors (ptr i64[R], ep_rew f64[R,N], ep_len i64[R], ep_idx i64[R]).
+        """
+        if done is None:
+            done = (terminated.reshape(terminated.shape[0], -1) | truncated.reshape(truncated.shape[0], -1)).any(1)
+            # env-level done = any agent done (identical for simple_spread where all agents end together; Q4)
+        fields = [(obs, self.obs_store), (act, self.act_store), (rew, self.rew_store),
+                  (terminated, self.term_store), (truncated, self.trunc_store)]
+        if self._save_obs_next and obs_next is not None:
+            fields.append((obs_next, self.obs_next_store))
+        if logp is not None and self.logp_store is not None:
+            fields.append((logp, self.logp_store))
+        if v_s is not None and self.vs_store is not None:
+            fields.append((v_s, self.vs_store))
+        return self.index.add(rew, done, buffer_ids, fields=fields)
+
+    def add(self, batch: Batch, buffer_ids=None):
+        """Reference signature (manager.py:131-193): host Batch in, numpy 4-tuple out."""
+        keys = set(batch.get_keys())
+        if not {"obs", "act", "rew", "terminated", "truncated"}.issubset(keys):
+            raise ValueError("Input batch must have the keys obs, act, rew, terminated, truncated")
+        dev = self.device
+        R = len(batch.rew)
+        obs = _obs_array(batch.obs)
+        t = lambda x, dt: torch.as_tensor(np.ascontiguousarray(x)).to(dev, dt)  # noqa: E731
+        N = self.n_agent
+        term = np.broadcast_to(np.asarray(batch.terminated, bool).reshape(R, -1), (R, N))
+        trunc = np.broadcast_to(np.asarray(batch.truncated, bool).reshape(R, -1), (R, N))
+        rew = np.broadcast_to(np.asarray(batch.rew, np.float32).reshape(R, -1), (R, N))
+        obs_next = _obs_array(batch.obs_next) if "obs_next" in keys and self._save_obs_next else None
+        ids = None if buffer_ids is None else t(np.asarray(buffer_ids, np.int64), torch.int64)
+        pol = batch.get("policy", None)
+        logp = t(pol.logp, torch.float32) if isinstance(pol, Batch) and "logp" in pol else None
+        v_s = t(pol.v_s, torch.float32) if isinstance(pol, Batch) and "v_s" in pol else None
+        out = self.add_device(
+            t(obs, torch.float32).reshape(R, N, self.obs_dim), t(np.asarray(batch.act).reshape(R, N), torch.int32),
+            t(rew, torch.float32), t(term, torch.uint8), t(trunc, torch.uint8),
+            None if obs_next is None else t(obs_next, torch.float32).reshape(R, N, self.obs_dim), logp, v_s, ids)
+        ptr, ep_rew, ep_len, ep_idx = (x.cpu().numpy() for x in out)
+        return ptr, ep_rew, ep_len, ep_idx
+
+    # ---- index algebra (all on device) ------------------------------------------------------
+    def sample_indices(self, batch_size: int | None = 0) -> np.ndarray:
+        if batch_size is not None and batch_size < 0:
+            return np.array([], int)  # manager.py:197-199
+        all_idx = self.index.sample_indices_all()
+        if batch_size == 0:
+            return all_idx.cpu().numpy()
+        n = len(all_idx) if batch_size is None else batch_size
+        if len(all_idx) == 0:
+            return np.array([], int)
+        pick = torch.randint(0, len(all_idx), (n,), device=self.device)
+        return all_idx[pick].cpu().numpy()
+
+    def unfinished_index(self) -> np.ndarray:
+        return self.index.unfinished_index().cpu().numpy()
+
+    def prev(self, index) -> np.ndarray:
+        scalar = np.isscalar(index)
+        out = self.index.prev(torch.as_tensor(np.atleast_1d(index), dtype=torch.int64)).cpu().numpy()
+        return out[0] if scalar else out
+
+    def next(self, index) -> np.ndarray:
+        scalar = np.isscalar(index)
+        out = self.index.next(torch.as_tensor(np.atleast_1d(index), dtype=torch.int64)).cpu().numpy()
+        return out[0] if scalar else out
+
+    def get_buffer_indices(self, start: int, stop: int) -> np.ndarray:
+        """buffer_base.py:173-228 (pure index arithmetic on the sub-buffer edges)."""
+        edges = self.subbuffer_edges
+        s_edge = int(np.searchsorted(edges, start, side="right")) - 1
+        e_edge = int(np.searchsorted(edges, stop - 1, side="right")) - 1
+        if s_edge != e_edge:
+            raise ValueError(f"Start and stop indices must be within the same subbuffer. Got {start=}, {stop=}.")
+        if stop >= start:
+            return np.arange(start, stop, dtype=int)
+        k_after = int(np.searchsorted(edges, start, side="left"))  # the crossed edge (buffer_base.py:156)
+        if k_after == 0:
+            raise ValueError(f"The start value should be larger than the first edge, but got {start=}.")
+        upper, lower = int(edges[k_after]), int(edges[k_after - 1])
+        if lower >= stop:
+            raise ValueError(f"The edge before the crossed edge should be smaller than the stop, but got {lower=}, {stop=}.")
+        return np.concatenate((np.arange(start, upper, dtype=int), np.arange(lower, stop, dtype=int)))
+
+    # ---- export -----------------------------------------------------------------------------
+    def _gather(self, store: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+        return self.index.gather(store, index)
+
+    def get_device(self, index) -> dict[str, torch.Tensor]:
+        """Rows by flat reference index as device tensors (ReplayBuffer.__getitem__, buffer_base.py:591-635)."""
+        idx = torch.as_tensor(np.asarray(index), dtype=torch.int64).to(self.device).reshape(-1)
+        out = {
+            "obs": self._gather(self.obs_store, idx), "act": self._gather(self.act_store, idx),
+            "rew": self._gather(self.rew_store, idx), "terminated": self._gather(self.term_store, idx),
+            "truncated": self._gather(self.trunc_store, idx),
+            "done": self._gather(self.done_store.unsqueeze(-1), idx).squeeze(-1),
+        }
+        if self._save_obs_next:
+            out["obs_next"] = self._gather(self.obs_next_store, idx)
+        else:  # ignore_obs_next: obs at next(index) (buffer_base.py:612-616)
+            out["obs_next"] = self._gather(self.obs_store, self.index.next(idx))
+        if self.logp_store is not None:
+            out["logp"] = self._gather(self.logp_store, idx)
+            out["v_s"] = self._gather(self.vs_store, idx)
+        return out
+
+    def __getitem__(self, index) -> Batch:
+        if isinstance(index, slice):
+            indices = self.sample_indices(0) if index == slice(None) else np.arange(len(self))[index]
+        else:
+            indices = index
+        d = self.get_device(indices)
+        pol = Batch(logp=d.pop("logp").cpu().numpy(), v_s=d.pop("v_s").cpu().numpy()) if "logp" in d else Batch()
+        b = Batch({k: v.cpu().numpy() for k, v in d.items()})
+        b.rew = b.rew.astype(np.float64)  # the reference stores rew as float (buffer_base.py:484)
+        for k in ("terminated", "truncated", "done"):
+            b[k] = b[k].astype(bool)
+        b.act = b.act.astype(np.int64)
+        b.info = Batch()
+        b.policy = pol
+        return b
+
+    def sample(self, batch_size: int | None = 0) -> tuple[Batch, np.ndarray]:
+        indices = self.sample_indices(batch_size)
+        return self[indices], indices
+
+    def __getattr__(self, key: str):
+        # reference: buffer.rew / buffer.done / ... -> full-length arrays in flat index order
+        if key in ("rew", "terminated", "truncated", "done", "obs", "act", "obs_next"):
+            b = self.get_device(np.arange(self.maxsize))
+            v = b[key].cpu().numpy()
+            if key in ("terminated", "truncated", "done"):
+                return v.astype(bool)
+            return v.astype(np.float64) if key == "rew" else v
+        raise AttributeError(key)
+
+    def hasnull(self) -> bool:
+        """NaN scan of the stored floats (collector.py:512, trainer.py:928) done on device."""
+        bad = torch.isnan(self.obs_store).any() | torch.isnan(self.rew_store).any()
+        if self._save_obs_next:
+            bad = bad | torch.isnan(self.obs_next_store).any()
+        return bool(bad.item())
+
+
+def _obs_array(obs) -> np.ndarray:
+    """Accept the reference's observation containers: plain array, Batch(obs=...), or the parallel-mode
+    Batch(observations=Batch(agent_i=...)) (enhanced_pettingzoo_env.py:202-205) -> [R, N, D] in agent order."""
+    if isinstance(obs, Batch):
+        if "observations" in obs:
+            o = obs.observations
+            names = list(o.get_keys())
+            if "agent_ids" in obs and len(np.asarray(obs.agent_ids)) > 0:
+                first = np.asarray(obs.agent_ids)
+                order = list(first[0]) if first.ndim > 1 else list(first)
+                names = [n for n in order if n in o]  # env.agents order, never dict order (quirk Q5)
+            return np.stack([np.asarray(o[n], np.float32) for n in names], axis=1)
+        if "obs" in obs:
+            return np.asarray(obs.obs, np.float32)
+        raise ValueError("unsupported observation Batch")
+    return np.asarray(obs, np.float32)

@@ -275,6 +275,16 @@ def adam_step(param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9,
     return param
 
 
+def reduce_slabs(grad_slabs, out=None, scale: float = 1.0):
+    """Flat gradient = scale * sum of per-workgroup slabs [n_slab, n] (deterministic slab order)."""
+    grad_slabs = _chk(grad_slabs, torch.float32, "grad_slabs")
+    n_slab, n = grad_slabs.shape
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=grad_slabs.device)
+    call("tsm_reduce_slabs", ptr(grad_slabs), n_slab, n, float(scale), ptr(out), stream_ptr())
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # fused actor+critic MLP (reinforce.py:167-192, a2c.py:121-127, ppo.py:157-212)
 # --------------------------------------------------------------------------------------------
@@ -289,21 +299,26 @@ def policy_param_count(obs_dim: int, hidden: int, n_act: int) -> int:
 
 
 def policy_forward(params, obs, n_act: int, hidden: int = 64, mode: str = "none", seed: int = 0, offset: int = 0,
-                   act=None, want_logits=True, want_value=True, want_logp=True):
+                   act=None, want_logits=True, want_value=True, want_logp=True, offset_dev=None, out=None):
     """obs [B, D] f32 -> dict(logits[B,A], value[B], act[B] i32, logp[B]) via one fused kernel."""
     obs = _chk(obs, torch.float32, "obs")
     B, D = obs.shape
     dev = obs.device
     m = POLICY_MODES[mode]
-    logits = torch.empty(B, n_act, dtype=torch.float32, device=dev) if want_logits else None
-    value = torch.empty(B, dtype=torch.float32, device=dev) if want_value else None
-    if m == 3:
-        act = _chk(act, torch.int32, "act")
-    elif m != 0:
-        act = torch.empty(B, dtype=torch.int32, device=dev)
-    logp = torch.empty(B, dtype=torch.float32, device=dev) if (want_logp and m != 0) else None
+    if out is not None:  # preallocated outputs (graph capture): dict(logits, value, act, logp), entries may be None
+        logits, value, logp = out.get("logits"), out.get("value"), out.get("logp")
+        act = out.get("act") if m != 3 else _chk(act, torch.int32, "act")
+    else:
+        logits = torch.empty(B, n_act, dtype=torch.float32, device=dev) if want_logits else None
+        value = torch.empty(B, dtype=torch.float32, device=dev) if want_value else None
+        if m == 3:
+            act = _chk(act, torch.int32, "act")
+        elif m != 0:
+            act = torch.empty(B, dtype=torch.int32, device=dev)
+        logp = torch.empty(B, dtype=torch.float32, device=dev) if (want_logp and m != 0) else None
     call("tsm_policy_forward", ptr(_chk(params, torch.float32, "params")), D, hidden, n_act, ptr(obs), B, m,
-         seed & (2**64 - 1), offset & (2**64 - 1), ptr(logits), ptr(value), ptr(act), ptr(logp), stream_ptr())
+         seed & (2**64 - 1), offset & (2**64 - 1), ptr(offset_dev), ptr(logits), ptr(value), ptr(act), ptr(logp),
+         stream_ptr())
     return dict(logits=logits, value=value, act=act, logp=logp)
 
 

@@ -1,0 +1,128 @@
+"""Actor / critic networks of the path as ONE flat HBM parameter vector.
+
+Mirrors the reference's network stack for discrete-action PPO:
+  Net(state_shape, hidden_sizes=[H, H]) -> DiscreteActor(softmax_output=False) / DiscreteCritic
+  (/root/reference/tianshou/utils/net/common.py:90-181,246-369; discrete.py:27-124) joined by
+  ActorCritic (common.py:461-474) so that one optimizer sees actor + critic parameters.
+The fused kernels (csrc/mlp_fused.hip) read the parameters as a single flat f32 vector in
+ActorCritic.parameters() order; per-layer tensors are views into it, so `state_dict()` can be
+exchanged with the reference (`to_reference_state_dict`).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def _layer_shapes(obs_dim: int, hidden: int, n_out: int):
+    return [("w0", (hidden, obs_dim)), ("b0", (hidden,)), ("w1", (hidden, hidden)), ("b1", (hidden,)),
+            ("w2", (n_out, hidden)), ("b2", (n_out,))]
+
+
+class DiscreteActorCritic(nn.Module):
+    """Separate actor and critic MLP trunks, obs[D] -> H -> H -> (A logits | 1 value), flat parameters."""
+
+    def __init__(self, obs_dim: int, n_act: int, hidden: int = 64, device: str | torch.device = "cuda",
+                 init: str = "orthogonal", seed: int | None = None) -> None:
+        super().__init__()
+        self.obs_dim, self.n_act, self.hidden = int(obs_dim), int(n_act), int(hidden)
+        n = ops.policy_param_count(self.obs_dim, self.hidden, self.n_act)
+        self.flat = nn.Parameter(torch.zeros(n, dtype=torch.float32, device=device), requires_grad=False)
+        self._slices: OrderedDict[str, tuple[int, tuple[int, ...]]] = OrderedDict()
+        o = 0
+        for net, n_out in (("actor", self.n_act), ("critic", 1)):
+            for name, shape in _layer_shapes(self.obs_dim, self.hidden, n_out):
+                self._slices[f"{net}.{name}"] = (o, shape)
+                o += int(np.prod(shape))
+        assert o == n
+        self.reset_parameters(init, seed)
+
+    def view(self, name: str) -> torch.Tensor:
+        o, shape = self._slices[name]
+        return self.flat.data[o:o + int(np.prod(shape))].view(shape)
+
+    def named_views(self):
+        return [(k, self.view(k)) for k in self._slices]
+
+    @torch.no_grad()
+    def reset_parameters(self, init: str = "orthogonal", seed: int | None = None) -> None:
+        """orthogonal weights + zero bias (the reference scripts' init, test/discrete/test_ppo_discrete.py:103-106)
+        or torch's nn.Linear default (kaiming-uniform)."""
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        for name, v in self.named_views():
+            if name.split(".")[1].startswith("w"):
+                w = torch.empty(v.shape)
+                if init == "orthogonal":
+                    if gen is not None:
+                        torch.manual_seed(int(torch.randint(0, 2**31 - 1, (1,), generator=gen)))
+                    nn.init.orthogonal_(w)
+                else:
+                    bound = 1.0 / math.sqrt(v.shape[1])
+                    w.uniform_(-bound, bound, generator=gen)
+                v.copy_(w)
+            elif init == "orthogonal":
+                v.zero_()
+            else:
+                fan_in = self.view(name.replace(".b", ".w")).shape[1]
+                b = torch.empty(v.shape).uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in), generator=gen)
+                v.copy_(b)
+
+    # ---- reference checkpoint compatibility --------------------------------------
+    _REF_KEYS = {
+        "w0": "preprocess.model.model.0.weight", "b0": "preprocess.model.model.0.bias",
+        "w1": "preprocess.model.model.2.weight", "b1": "preprocess.model.model.2.bias",
+        "w2": "last.model.0.weight", "b2": "last.model.0.bias",
+    }
+
+    def to_reference_state_dict(self) -> dict[str, OrderedDict]:
+        """{'actor': ..., 'critic': ...} with the key names of DiscreteActor/DiscreteCritic over Net."""
+        out = {"actor": OrderedDict(), "critic": OrderedDict()}
+        for name, v in self.named_views():
+            net, layer = name.split(".")
+            out[net][self._REF_KEYS[layer]] = v.detach().clone().cpu()
+        return out
+
+    @torch.no_grad()
+    def load_reference_state_dict(self, sd: dict) -> None:
+        for name, v in self.named_views():
+            net, layer = name.split(".")
+            v.copy_(torch.as_tensor(sd[net][self._REF_KEYS[layer]]).to(v.device, v.dtype).reshape(v.shape))
+
+    @torch.no_grad()
+    def load_layers(self, actor, critic) -> None:
+        """actor / critic: [(W, b)] * 3 (numpy or tensors) in torch nn.Linear layout."""
+        for net, layers in (("actor", actor), ("critic", critic)):
+            for i, (W, b) in enumerate(layers):
+                self.view(f"{net}.w{i}").copy_(torch.as_tensor(np.asarray(W)).to(self.flat.device, torch.float32))
+                self.view(f"{net}.b{i}").copy_(torch.as_tensor(np.asarray(b)).to(self.flat.device, torch.float32))
+
+
+class RunningMeanStd:
+    """tianshou.utils.statistics.RunningMeanStd (statistics.py:68-114), scalar statistics, host f64.
+    The batch moments come from a device reduction; only three scalars live on the host."""
+
+    def __init__(self, mean: float = 0.0, std: float = 1.0, clip_max: float | None = 10.0,
+                 epsilon: float = float(np.finfo(np.float32).eps)) -> None:
+        self.mean, self.var = mean, std  # NB: the reference stores `std` into var (statistics.py:92)
+        self.clip_max, self.count, self.eps = clip_max, 0, epsilon
+
+    def update_from_moments(self, batch_mean: float, batch_var: float, batch_count: int) -> None:
+        delta = batch_mean - self.mean
+        total = self.count + batch_count
+        new_mean = self.mean + delta * batch_count / total
+        m_2 = self.var * self.count + batch_var * batch_count + delta**2 * self.count * batch_count / total
+        self.mean, self.var, self.count = new_mean, m_2 / total, total
+
+    def update(self, x) -> None:
+        if isinstance(x, torch.Tensor):
+            xd = x.double()
+            self.update_from_moments(float(xd.mean()), float(xd.var(unbiased=False)), x.numel())
+        else:
+            a = np.asarray(x, np.float64)
+            self.update_from_moments(float(a.mean()), float(a.var()), a.size)
