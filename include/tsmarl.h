@@ -204,17 +204,23 @@ int tsm_ppo_loss_finalize(const double *partial, int64_t M, const tsm_ppo_cfg *c
  *           (tianshou/algorithm/algorithm_base.py:485-498; optim.py:91-111) on one flat f32
  *           parameter vector (actor+critic union, utils/net/common.py:461-474).
  * grad_slabs [n_slab][n] f32: per-workgroup partial gradients, summed here in slab order
- * (deterministic).  max_grad_norm <= 0: no clipping.  norm_scratch: f32[64] device.
- * step: 1-based Adam step count.
+ * (deterministic).  max_grad_norm <= 0: no clipping; otherwise work: f32[tsm_adam_work_elems(n)] device.
+ * param_image / image_map (nullable): padded LDS-layout copy of the parameters kept in sync for the fused
+ * MLP kernels (tsm_policy_image_elems / tsm_policy_image_map).
+ * step: 1-based Adam step count; when step_dev (device i64[1]) is given it overrides `step`.
  * ------------------------------------------------------------------------------------------- */
 /* out[i] = scale * sum_s grad_slabs[s][i]: the flat gradient handed to the RCCL all-reduce of the
  * env-sharded data-parallel path (no reference counterpart: the reference has no distributed backend). */
 int tsm_reduce_slabs(const float *grad_slabs, int32_t n_slab, int64_t n, double scale, float *out,
                      void *stream);
+int64_t tsm_adam_work_elems(int64_t n);
 int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
-                  float *exp_avg_sq, int64_t step, double lr, double beta1, double beta2,
-                  double eps, double weight_decay, double max_grad_norm, float *norm_scratch,
-                  void *stream);
+                  float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, double max_grad_norm, float *work, float *param_image,
+                  const int32_t *image_map, void *stream);
+/* param_image[image_map[i]] = param[i]  (initial fill of the padded image; pads must already be zero) */
+int tsm_scatter_image(const float *param, int64_t n, const int32_t *image_map, float *param_image,
+                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused actor + critic MLP (f32 MFMA)  [a7, a11, a13, a14]
@@ -238,20 +244,36 @@ int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t
  * adv, returns, v_s_old.  Each of the n_blocks workgroups writes one gradient slab:
  * grad_slabs_out [n_blocks][P]; feed them to tsm_adam_step(n_slab = n_blocks).
  * loss_partial_out: f64 [n_blocks][4]; scalars_out (nullable) f32[4] = {loss, clip, vf, ent}.
+ * opt_step_dev (nullable, device i64[1]): incremented by one per call -- the device-resident optimizer
+ * step count that tsm_adam_step(step_dev=...) reads, so a captured hipGraph can be replayed.
  * ------------------------------------------------------------------------------------------- */
 int64_t tsm_policy_param_count(int32_t obs_dim, int32_t hidden, int32_t n_act);
-int tsm_policy_forward(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+/* Padded parameter image: the exact LDS layout of both nets (zero pads included).  When `param_image` is
+ * given to the kernels below they stage it with straight 16-B copies instead of re-packing `params`. */
+int64_t tsm_policy_image_elems(int32_t obs_dim, int32_t hidden, int32_t n_act);
+int tsm_policy_image_map(int32_t obs_dim, int32_t hidden, int32_t n_act, int32_t *map_out_host);
+int tsm_policy_forward(const float *params, const float *param_image, int32_t obs_dim, int32_t hidden,
+                       int32_t n_act,
                        const float *obs, int64_t B, int mode, uint64_t seed, uint64_t offset,
                        const uint64_t *offset_dev, float *logits_out, float *value_out, int32_t *act_io, float *logp_out,
                        void *stream);
 /* recommended number of workgroups (= gradient slabs) for a minibatch of M rows */
 int tsm_ppo_update_grid(int64_t M, int32_t max_blocks);
-int tsm_ppo_update_fused(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+int tsm_ppo_update_fused(const float *params, const float *param_image, int32_t obs_dim, int32_t hidden,
+                         int32_t n_act,
                          const float *obs, const int32_t *act, const float *logp_old, const float *adv,
                          const float *returns, const float *v_s_old, const int64_t *perm,
                          int64_t first_row, int64_t M, const float *adv_stats,
                          const tsm_ppo_cfg *cfg_host, int32_t n_blocks, float *grad_slabs_out,
-                         double *loss_partial_out, float *scalars_out, void *stream);
+                         double *loss_partial_out, float *scalars_out, int64_t *opt_step_dev,
+                         void *stream);
+
+/* Loss statistics of many gradient steps in ONE launch (pass scalars_out = NULL to tsm_ppo_update_fused):
+ * step k reads loss partials at partial + k*stride_elems (n_blocks_dev[k] rows of 4 f64) and M_dev[k];
+ * scalars_out f32 [n_steps][4] = {loss, clip_loss, vf_loss, ent_loss} (the 4 .item() of ppo.py:213-216). */
+int tsm_ppo_finalize_many(const double *partial, int64_t stride_elems, const int32_t *n_blocks_dev,
+                          const int64_t *M_dev, int32_t n_steps, const tsm_ppo_cfg *cfg_host,
+                          float *scalars_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched MPE worlds  [SURVEY 8f-1; replaces the per-env Python loop of a1-a3 for simple_spread]

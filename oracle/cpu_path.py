@@ -41,6 +41,7 @@ def run_baseline(n_env=64, n_agent=3, horizon=25, minibatch=4096, repeat=1, disp
                  seed=1626):
     torch.manual_seed(seed)
     np.random.seed(seed)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU; tiny GEMMs do not scale further
     N, D, A, T = n_agent, 6 * n_agent, 5, horizon
     envs = [mpe_oracle.SimpleSpreadWorld(N, T, 0.5, seed + i) for i in range(n_env)]
     actor, critic = _mlp(D, 64, A), _mlp(D, 64, 1)

@@ -220,3 +220,33 @@ def test_ppo_update_pooled_and_options_run_and_learn():
               terminated=np.zeros(50, bool))
     out = algo.learn(b)
     assert set(out) == {"loss", "actor_loss", "vf_loss", "ent_loss"} and np.isfinite(list(out.values())).all()
+
+
+def test_graph_replay_equals_eager_launches():
+    """hipGraph capture of the rollout and of the update must not change a single bit of the results."""
+    def run(use_graph):
+        env = DeviceSimpleSpreadVectorEnv(64, 3, max_cycles=25, device=DEV, seed=11)
+        net = DiscreteActorCritic(env.obs_dim, env.n_act, 64, device=DEV, seed=11)
+        algo = PPO(net=net, seed=11, shuffle="numpy", dispatch="per_agent", use_graph=use_graph, max_grad_norm=0.5)
+        buf = DeviceVectorReplayBuffer(64 * 25, 64, 3, env.obs_dim, device=DEV)
+        col = Collector(algo, env, buf, use_graph=use_graph)
+        col.reset()
+        np.random.seed(5)
+        rets, losses = [], []
+        for _ in range(4):  # 1st collect is eager in both; graph capture happens on the 2nd, replay on 3rd/4th
+            with policy_within_training_step(algo):
+                cs = col.collect(n_step=64 * 25)
+                ts = algo.update(buf, 512, 2)
+            col.reset_buffer(keep_statistics=True)
+            rets.append(cs.returns.copy())
+            losses.append(ts.get_loss_stats_dict())
+        return net.flat.data.cpu().numpy(), rets, losses, buf.obs_store.cpu().numpy(), algo.opt_step
+
+    p_e, r_e, l_e, o_e, s_e = run(False)
+    p_g, r_g, l_g, o_g, s_g = run(True)
+    assert s_e == s_g == 4 * 3 * 2 * 3
+    assert np.array_equal(o_e, o_g)
+    for a, b in zip(r_e, r_g):
+        assert np.array_equal(a, b)
+    assert np.array_equal(p_e, p_g)
+    assert l_e == l_g

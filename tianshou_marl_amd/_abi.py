@@ -74,21 +74,26 @@ SIGNATURES = {
     "tsm_ppo_loss_fwd_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p,
                                     C.POINTER(tsm_ppo_cfg), _p, _p, _p, _p]),
     "tsm_ppo_loss_finalize": (_int, [_p, _i64, C.POINTER(tsm_ppo_cfg), _p, _p]),
-    "tsm_adam_step": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _p, _p]),
+    "tsm_adam_work_elems": (_i64, [_i64]),
+    "tsm_adam_step": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _p, _f64, _f64, _f64, _f64, _f64, _f64, _p, _p, _p, _p]),
+    "tsm_scatter_image": (_int, [_p, _i64, _p, _p, _p]),
+    "tsm_policy_image_elems": (_i64, [_i32, _i32, _i32]),
+    "tsm_policy_image_map": (_int, [_i32, _i32, _i32, _p]),
     "tsm_reduce_slabs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
     "tsm_global_state": (_int, [C.POINTER(_p), _i32, _i64, _i32, _int, _p, _p]),
     "tsm_policy_param_count": (_i64, [_i32, _i32, _i32]),
-    "tsm_policy_forward": (_int, [_p, _i32, _i32, _i32, _p, _i64, _int, _u64, _u64, _p, _p, _p, _p, _p, _p]),
+    "tsm_policy_forward": (_int, [_p, _p, _i32, _i32, _i32, _p, _i64, _int, _u64, _u64, _p, _p, _p, _p, _p, _p]),
     "tsm_mpe_spread_reset": (_int, [C.POINTER(tsm_mpe_cfg), _u64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "tsm_mpe_spread_step": (_int, [C.POINTER(tsm_mpe_cfg), _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                    _int, _p, _u64, _p]),
     "tsm_ppo_update_grid": (_int, [_i64, _i32]),
-    "tsm_ppo_update_fused": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p,
-                                    C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p]),
+    "tsm_ppo_finalize_many": (_int, [_p, _i64, _p, _p, _i32, C.POINTER(tsm_ppo_cfg), _p, _p]),
+    "tsm_ppo_update_fused": (_int, [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p,
+                                    C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p, _p]),
 }
 
 _NO_STATUS = {"tsm_abi_version", "tsm_last_error", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
-              "tsm_policy_param_count", "tsm_ppo_update_grid"}
+              "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems"}
 
 _lib = None
 

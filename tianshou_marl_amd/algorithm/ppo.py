@@ -35,7 +35,7 @@ class PPO(nn.Module):
                  max_grad_norm: float | None = None, gae_lambda: float = 0.95, max_batchsize: int = 256,
                  gamma: float = 0.99, return_scaling: bool = False, deterministic_eval: bool = False,
                  dispatch: Literal["per_agent", "pooled"] = "per_agent",
-                 shuffle: Literal["numpy", "device"] = "numpy", seed: int = 0) -> None:
+                 shuffle: Literal["numpy", "device"] = "numpy", seed: int = 0, use_graph: bool = True) -> None:
         super().__init__()
         assert dual_clip is None or dual_clip > 1.0, f"Dual-clip PPO parameter should greater than 1.0 but got {dual_clip}"
         assert 0.0 <= gae_lambda <= 1.0, f"GAE lambda should be in [0, 1] but got: {gae_lambda}"
@@ -49,12 +49,13 @@ class PPO(nn.Module):
         self.deterministic_eval = deterministic_eval
         self.is_within_training_step = False
         self.dispatch, self.shuffle = dispatch, shuffle
+        self.use_graph = use_graph
         self.seed = int(seed)
         dev = net.flat.device
         self.exp_avg = torch.zeros_like(net.flat.data)
         self.exp_avg_sq = torch.zeros_like(net.flat.data)
         self.opt_step = 0
-        self._norm_scratch = torch.zeros(64, dtype=torch.float32, device=dev)
+        self._adam_work = torch.zeros(ops.call("tsm_adam_work_elems", net.flat.numel()), dtype=torch.float32, device=dev)
         self._sample_ctr = 0  # Philox counter base for action sampling
         self._cfg = ops.make_ppo_cfg(eps_clip, dual_clip, value_clip, advantage_normalization, vf_coef, ent_coef)
         self._ws: dict = {}
@@ -74,7 +75,7 @@ class PPO(nn.Module):
         """obs [..., D] in HBM -> dict(act i32, logp, value) for every row (one fused kernel)."""
         rows = obs.reshape(-1, self.net.obs_dim)
         mode = "mode" if (self.deterministic_eval and not self.is_within_training_step) else "sample"
-        res = ops.policy_forward(self.net.flat.data, rows, self.net.n_act, self.net.hidden, mode=mode, seed=self.seed,
+        res = ops.policy_forward(self.net.flat.data, rows, self.net.n_act, self.net.hidden, image=self.net.image, mode=mode, seed=self.seed,
                                  offset=self._sample_ctr, want_logits=out is None, offset_dev=offset_dev, out=out)
         if offset_dev is None:
             self._sample_ctr += rows.shape[0]
@@ -130,7 +131,7 @@ class PPO(nn.Module):
         if buffer.obs_next_store is None:
             raise ValueError("PPO.update needs a buffer that stores obs_next (ignore_obs_next=False)")
         # critic(obs), critic(obs_next), logp_old: two fused passes (no max_batchsize chunking needed in HBM)
-        cur = ops.policy_forward(P, obs, self.net.n_act, self.net.hidden, mode="given", act=act, want_logits=False)
+        cur = ops.policy_forward(P, obs, self.net.n_act, self.net.hidden, image=self.net.image, mode="given", act=act, want_logits=False)
         nxt = ops.policy_forward(P, buffer.obs_next_store[:T].reshape(T * L, D), self.net.n_act, self.net.hidden,
                                  mode="none", want_logits=False)
         v_s, v_next, logp_old = cur["value"].view(T, L), nxt["value"].view(T, L), cur["logp"]
@@ -189,7 +190,7 @@ class PPO(nn.Module):
                 nb = ops.ppo_update_grid(M)
                 ops.ppo_update_fused(P, pb["obs"], pb["act"], pb["logp_old"], pb["adv"], pb["ret"], self._cfg, A, H,
                                      adv_stats=None if stats is None else stats[j],
-                                     v_s_old=pb["v_s"] if self.value_clip else None, perm=perm[s:e], M=M,
+                                     v_s_old=pb["v_s"] if self.value_clip else None, perm=perm[s:e], image=self.net.image, M=M,
                                      n_blocks=nb, slabs=slabs[:nb], partial=partial, scalars=scal[k])
                 self.opt_step += 1
                 grads = slabs[:nb]
@@ -200,13 +201,130 @@ class PPO(nn.Module):
                     grads = flat_g.view(1, -1)
                 ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr,
                               betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
-                              max_grad_norm=self.max_grad_norm, norm_scratch=self._norm_scratch)
+                              max_grad_norm=self.max_grad_norm, work=self._adam_work, image=self.net.image,
+                              image_map=self.net.image_map)
                 k += 1
         s_h = scal.cpu().numpy()  # the only host sync of the update (the reference does 4 .item() per minibatch)
         return A2CTrainingStats(
             loss=SequenceSummaryStats.from_sequence(s_h[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(s_h[:, 1]),
             vf_loss=SequenceSummaryStats.from_sequence(s_h[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(s_h[:, 3]),
             gradient_steps=n_steps)
+
+    # ---- hipGraph path: the whole update (critic passes, GAE, every gradient step) is ONE graph launch ----
+    def _warm_kernels(self, buffer: DeviceVectorReplayBuffer) -> None:
+        """Run each kernel once on scratch data so that one-time function attributes are set before capture."""
+        if self._ws.get("warm"):
+            return
+        dev, D, A, H = self.device, self.net.obs_dim, self.net.n_act, self.net.hidden
+        P = self.net.flat.data.clone()
+        obs = torch.zeros(32, D, device=dev)
+        act = torch.zeros(32, dtype=torch.int32, device=dev)
+        z = torch.zeros(32, device=dev)
+        ops.policy_forward(P, obs, A, H, mode="given", act=act)
+        st = ops.ppo_adv_stats(z + torch.arange(32, device=dev), torch.tensor([0, 32], device=dev))
+        slabs, _ = ops.ppo_update_fused(P, obs, act, z, z, z, self._cfg, A, H, adv_stats=st[0], v_s_old=z)
+        ops.adam_step(P, slabs, torch.zeros_like(P), torch.zeros_like(P), 1, max_grad_norm=self.max_grad_norm,
+                      work=self._adam_work)
+        ops.gae_lanes(z.view(32, 1), z.view(32, 1), z.view(32, 1), act.view(32, 1).to(torch.uint8),
+                      act.view(32, 1).to(torch.uint8))
+        torch.cuda.synchronize()
+        self._ws["warm"] = True
+
+    def _update_graph(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
+        lens_h = buffer.index.lengths.cpu().numpy()
+        ins_h = buffer.index.insertion_idx.cpu().numpy()
+        T = int(lens_h[0])
+        if T == 0 or not (lens_h == T).all() or not (((ins_h - lens_h) % buffer.sub_size) == 0).all():
+            return None  # ragged / rotated sub-buffers: eager path with explicit index lists
+        if buffer.obs_next_store is None:
+            raise ValueError("PPO.update needs a buffer that stores obs_next (ignore_obs_next=False)")
+        B, N, D = buffer.buffer_num, buffer.n_agent, buffer.obs_dim
+        L, dev = B * N, self.device
+        per_agent = self.dispatch == "per_agent"
+        groups = list(range(N)) if per_agent else [None]
+        n_g = T * B if per_agent else T * L
+        bounds = split_bounds(n_g, batch_size or -1, merge_last=True)
+        key = ("graph", id(buffer), T, batch_size, repeat, self.dispatch, self.lr, self.max_grad_norm)
+        g = self._ws.get(key)
+        P, A, H = self.net.flat.data, self.net.n_act, self.net.hidden
+        if g is None:
+            self._warm_kernels(buffer)
+            n_steps = len(groups) * repeat * len(bounds)
+            nb_max = ops.ppo_update_grid(max(e - s for s, e in bounds))
+            f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
+            w = dict(perm=torch.zeros(len(groups), repeat, n_g, dtype=torch.int64, device=dev),
+                     mb_start=torch.as_tensor([b[0] for b in bounds] + [n_g], dtype=torch.int64, device=dev),
+                     stats=f(len(groups), repeat, len(bounds), 2), scal=f(n_steps, 4), slabs=f(nb_max, P.numel()),
+                     partial=torch.zeros(n_steps, nb_max * 4, dtype=torch.float64, device=dev),
+                     nb_dev=torch.as_tensor([ops.ppo_update_grid(e - s) for s, e in bounds] * (len(groups) * repeat),
+                                            dtype=torch.int32, device=dev),
+                     M_dev=torch.as_tensor([e - s for s, e in bounds] * (len(groups) * repeat), dtype=torch.int64,
+                                           device=dev),
+                     step_dev=torch.zeros(1, dtype=torch.int64, device=dev), v_s=f(T, L), v_next=f(T, L),
+                     logp=f(T * L), ret=f(T, L), adv=f(T, L), n_steps=n_steps)
+            obs = buffer.obs_store[:T].reshape(T * L, D)
+            obs_next = buffer.obs_next_store[:T].reshape(T * L, D)
+            act = buffer.act_store[:T].reshape(T * L)
+            rew, term, trunc = (x[:T].reshape(T, L) for x in (buffer.rew_store, buffer.term_store, buffer.trunc_store))
+
+            def preprocess():
+                ops.policy_forward(P, obs, A, H, mode="given", act=act, image=self.net.image,
+                                   out=dict(value=w["v_s"].view(-1), logp=w["logp"], logits=None))
+                ops.policy_forward(P, obs_next, A, H, mode="none", image=self.net.image,
+                                   out=dict(value=w["v_next"].view(-1), logits=None))
+                ops.gae_lanes(w["v_s"], w["v_next"], rew, term, trunc, self.gamma, self.gae_lambda, lanes_per_env=N,
+                              out=(w["ret"], w["adv"]))
+
+            def body():
+                preprocess()
+                k = 0
+                for gi in range(len(groups)):
+                    for r in range(repeat):
+                        if self.recompute_adv and r > 0:
+                            preprocess()
+                        perm = w["perm"][gi, r]
+                        if self.advantage_normalization:
+                            ops.ppo_adv_stats(w["adv"], w["mb_start"], perm=perm, out=w["stats"][gi, r])
+                        for j, (s, e) in enumerate(bounds):
+                            nb = ops.ppo_update_grid(e - s)
+                            ops.ppo_update_fused(P, obs, act, w["logp"], w["adv"].view(-1), w["ret"].view(-1), self._cfg,
+                                                 A, H, adv_stats=w["stats"][gi, r, j] if self.advantage_normalization else None,
+                                                 v_s_old=w["v_s"].view(-1) if self.value_clip else None, perm=perm[s:e], image=self.net.image,
+                                                 M=e - s, n_blocks=nb, slabs=w["slabs"][:nb], partial=w["partial"][k],
+                                                 want_scalars=False, opt_step_dev=w["step_dev"])
+                            ops.adam_step(P, w["slabs"][:nb], self.exp_avg, self.exp_avg_sq, 1, lr=self.lr,
+                                          betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
+                                          max_grad_norm=self.max_grad_norm, work=self._adam_work,
+                                          step_dev=w["step_dev"], image=self.net.image, image_map=self.net.image_map)
+                            k += 1
+                # the 4 loss statistics of EVERY gradient step in one launch (reference: 4 .item() per minibatch)
+                ops.ppo_finalize_many(w["partial"], nb_max * 4, w["nb_dev"], w["M_dev"], self._cfg, w["scal"])
+
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body()
+            w["graph"] = graph
+            self._ws[key] = g = w
+        # fresh permutations for this update (Batch.split draws one per repeat, batch.py:1219)
+        for gi, a in enumerate(groups):
+            for r in range(repeat):
+                if self.shuffle == "numpy":
+                    pl = torch.as_tensor(np.random.permutation(n_g)).to(dev)
+                else:
+                    pl = torch.randperm(n_g, device=dev)
+                g["perm"][gi, r].copy_(pl if a is None else pl * N + a)
+        g["step_dev"].fill_(self.opt_step)
+        g["graph"].replay()
+        self.opt_step += g["n_steps"]
+        s_h = g["scal"].cpu().numpy()
+        mk = lambda x: A2CTrainingStats(  # noqa: E731
+            loss=SequenceSummaryStats.from_sequence(x[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(x[:, 1]),
+            vf_loss=SequenceSummaryStats.from_sequence(x[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(x[:, 3]),
+            gradient_steps=len(x))
+        if per_agent:
+            per = len(s_h) // N
+            return MapTrainingStats({f"agent_{a}": mk(s_h[a * per:(a + 1) * per]) for a in range(N)})
+        return mk(s_h)
 
     def update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
         """OnPolicyAlgorithm.update (algorithm_base.py:852-863): raises outside a training step (:610-615)."""
@@ -215,6 +333,12 @@ class PPO(nn.Module):
                 "update() was called outside of a training step as signalled by `is_within_training_step=False`; "
                 "wrap the call in `policy_within_training_step(policy)` (tianshou/utils/torch_utils.py:31-46)")
         t0 = time.time()
+        self.net.sync_image()  # `flat` may have been written from outside (load_state_dict, broadcast, tests)
+        if self.use_graph and self._grad_sync is None and not self.return_scaling:
+            out = self._update_graph(buffer, batch_size, repeat)
+            if out is not None:
+                out.train_time = time.time() - t0
+                return out
         pb = self._preprocess_batch(buffer)
         if self.dispatch == "per_agent":
             # MARLDispatcher.dispatch_update_with_batch: the (shared) algorithm is updated once per agent id,
@@ -240,8 +364,8 @@ class PPO(nn.Module):
         n = obs.shape[0]
         act = t(batch.act, torch.int32).reshape(n)
         P = self.net.flat.data
-        cur = ops.policy_forward(P, obs, self.net.n_act, self.net.hidden, mode="given", act=act, want_logits=False)
-        nxt = ops.policy_forward(P, t(batch.obs_next, torch.float32), self.net.n_act, self.net.hidden, mode="none",
+        cur = ops.policy_forward(P, obs, self.net.n_act, self.net.hidden, image=self.net.image, mode="given", act=act, want_logits=False)
+        nxt = ops.policy_forward(P, t(batch.obs_next, torch.float32), self.net.n_act, self.net.hidden, image=self.net.image, mode="none",
                                  want_logits=False)
         term = t(batch.terminated, torch.uint8).reshape(n, 1)
         trunc = t(batch.truncated, torch.uint8).reshape(n, 1) if "truncated" in batch else torch.zeros_like(term)
@@ -262,6 +386,7 @@ class PPO(nn.Module):
 
     def load_state_dict(self, sd, *args, **kwargs):
         self.net.flat.data.copy_(sd["flat"])
+        self.net.sync_image()
         o = sd["_optimizers"][0]
         self.exp_avg.copy_(o["exp_avg"])
         self.exp_avg_sq.copy_(o["exp_avg_sq"])

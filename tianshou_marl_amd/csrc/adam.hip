@@ -3,48 +3,94 @@
 // Replaces Algorithm.Optimizer.step (/root/reference/tianshou/algorithm/algorithm_base.py:485-498):
 // zero_grad -> backward -> nn.utils.clip_grad_norm_(params, max_grad_norm) -> torch.optim.Adam.step
 // (AdamOptimizerFactory, tianshou/algorithm/optim.py:91-111; torch single-tensor Adam, amsgrad off):
-//   g   = sum_slab grad_slab                      (deterministic slab order)
+//   g   = sum_slab grad_slab                      (fixed summation tree => deterministic)
 //   g  *= min(1, max_norm / (||g||_2 + 1e-6))     (only when max_grad_norm > 0)
 //   g  += weight_decay * p
 //   m   = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2
 //   p  -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
-// norm_scratch: f32[kNormBlocks] per-block partial sums of squares (fixed order -> deterministic).
+//
+// gfx950 mapping: the slab reduction is latency-bound (n ~ 11 k parameters, up to 256 slabs), so a
+// workgroup owns 64 parameters x 4 slab lanes: every wave reads 256-B coalesced rows of 64 parameters and
+// the 4 waves walk disjoint slab subsets with 8 loads in flight each; partial sums meet in LDS.
+// Optionally the kernel also refreshes a padded "LDS image" copy of the parameters (img[map[i]] = p[i]) that
+// the fused MLP kernels stage with straight 16-B copies (csrc/mlp_fused.hip).
 #include "common.h"
 
 namespace {
 
-constexpr int kNormBlocks = 64;
+constexpr int kCols = 64;  // parameters per workgroup
 
-__global__ __launch_bounds__(256) void gradnorm_kernel(const float *__restrict__ slabs, int32_t n_slab, int64_t n,
-                                                       float *__restrict__ norm_scratch) {
-    __shared__ double sm[256 / 64];
-    double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)kNormBlocks * 256) {
-        float g = 0.f;
-        for (int s = 0; s < n_slab; ++s) g += slabs[(int64_t)s * n + i];
-        acc += (double)g * (double)g;
+__device__ __forceinline__ float slab_sum_block(const float *__restrict__ slabs, int32_t n_slab, int64_t n,
+                                                int64_t i, float *sm /* [4][64] */) {
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (i < n) {
+        int s = sl;
+#pragma unroll 1
+        for (; s + 28 < n_slab; s += 32) {  // 8 independent loads in flight per lane
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += t[u];
+        }
+        for (; s < n_slab; s += 4) acc += slabs[(int64_t)s * n + i];
     }
-    acc = block_sum<double, 256>(acc, sm);
-    if (threadIdx.x == 0) norm_scratch[blockIdx.x] = (float)acc;
+    sm[sl * 64 + lane] = acc;
+    __syncthreads();
+    return sm[lane] + sm[64 + lane] + sm[128 + lane] + sm[192 + lane];
+}
+
+// pass 1 of the clipping path: g = sum of slabs -> work[0..n), per-block sum of squares -> work[n + blk]
+__global__ __launch_bounds__(256) void reduce_norm_kernel(const float *__restrict__ slabs, int32_t n_slab, int64_t n,
+                                                          float *__restrict__ work) {
+    __shared__ float sm[256];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kCols + lane;
+    const float g = slab_sum_block(slabs, n_slab, n, i, sm);
+    if (sl == 0) {
+        if (i < n) work[i] = g;
+        float q = i < n ? g * g : 0.f;
+        q = wave_sum(q);
+        if (lane == 0) work[n + blockIdx.x] = q;
+    }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ slabs,
                                                    int32_t n_slab, int64_t n, float *__restrict__ m,
-                                                   float *__restrict__ v, float step_size, float beta1,
-                                                   float beta2, float bc2_sqrt, float eps, float weight_decay,
-                                                   float max_norm, const float *__restrict__ norm_scratch) {
-    float coef = 1.f;
-    if (max_norm > 0.f) {
-        float tot = 0.f;
-        for (int b = 0; b < kNormBlocks; ++b) tot += norm_scratch[b];
-        const float c = max_norm / (sqrtf(tot) + 1e-6f);
-        coef = c < 1.f ? c : 1.f;
+                                                   float *__restrict__ v, double lr, double beta1d, double beta2d,
+                                                   int64_t step_host, const int64_t *__restrict__ step_dev,
+                                                   float eps, float weight_decay, float max_norm,
+                                                   const float *__restrict__ work, float *__restrict__ img,
+                                                   const int32_t *__restrict__ img_map) {
+    __shared__ float sm[256];
+    __shared__ float s_coef;
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kCols + lane;
+    float g;
+    if (max_norm > 0.f) {  // clipping path: slabs were already summed by reduce_norm_kernel
+        const int nblk = (int)((n + kCols - 1) / kCols);
+        float q = 0.f;
+        for (int b = threadIdx.x; b < nblk; b += 256) q += work[n + b];
+        q = wave_sum(q);
+        if (lane == 0) sm[sl] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float tot = sm[0] + sm[1] + sm[2] + sm[3];
+            const float c = max_norm / (sqrtf(tot) + 1e-6f);
+            s_coef = c < 1.f ? c : 1.f;
+        }
+        __syncthreads();
+        g = i < n ? work[i] * s_coef : 0.f;
+    } else {
+        g = slab_sum_block(slabs, n_slab, n, i, sm);
     }
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float g = 0.f;
-    for (int s = 0; s < n_slab; ++s) g += slabs[(int64_t)s * n + i];
-    g *= coef;
+    if (sl != 0 || i >= n) return;
+    // bias corrections from the (host or device-resident) step count, in f64 like torch's python scalars
+    const double step = (double)(step_dev ? *step_dev : step_host);
+    const float step_size = (float)(lr / (1.0 - pow(beta1d, step)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2d, step));
+    const float beta1 = (float)beta1d, beta2 = (float)beta2d;
     const float pi = p[i];
     if (weight_decay != 0.f) g += weight_decay * pi;
     const float mi = beta1 * m[i] + (1.f - beta1) * g;
@@ -52,51 +98,74 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - step_size * (mi / denom);
+    const float pn = pi - step_size * (mi / denom);
+    p[i] = pn;
+    if (img) img[img_map[i]] = pn;
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int32_t n_slab,
                                                            int64_t n, float scale, float *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float g = 0.f;
-    for (int s = 0; s < n_slab; ++s) g += slabs[(int64_t)s * n + i];
-    out[i] = g * scale;
+    __shared__ float sm[256];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kCols + lane;
+    const float g = slab_sum_block(slabs, n_slab, n, i, sm);
+    if (sl == 0 && i < n) out[i] = g * scale;
+}
+
+__global__ void scatter_image_kernel(const float *__restrict__ p, int64_t n, const int32_t *__restrict__ map,
+                                     float *__restrict__ img) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) img[map[i]] = p[i];
 }
 
 }  // namespace
 
-// Sum per-workgroup gradient slabs into one flat gradient (slab order => deterministic), times `scale`.
+// Sum per-workgroup gradient slabs into one flat gradient (fixed tree => deterministic), times `scale`.
 // Used in front of the RCCL all-reduce of the data-parallel path (one flat buffer per gradient step).
 TSM_EXPORT int tsm_reduce_slabs(const float *grad_slabs, int32_t n_slab, int64_t n, double scale, float *out,
                                 void *stream) {
     TSM_REQUIRE(n >= 0 && n_slab >= 1, "tsm_reduce_slabs: bad sizes");
     if (n == 0) return TSM_OK;
     TSM_REQUIRE(grad_slabs && out, "tsm_reduce_slabs: null pointer");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, tsm_stream(stream),
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(n, kCols)), dim3(256), 0, tsm_stream(stream),
                        grad_slabs, n_slab, n, (float)scale, out);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }
 
+TSM_EXPORT int64_t tsm_adam_work_elems(int64_t n) { return n < 0 ? -1 : n + ceil_div(n > 0 ? n : 1, kCols); }
+
 TSM_EXPORT int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
-                             float *exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps,
-                             double weight_decay, double max_grad_norm, float *norm_scratch, void *stream) {
-    TSM_REQUIRE(n >= 0 && n_slab >= 1 && step >= 1, "tsm_adam_step: bad sizes n=%lld n_slab=%d step=%lld",
+                             float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, double max_grad_norm, float *work,
+                             float *param_image, const int32_t *image_map, void *stream) {
+    TSM_REQUIRE(n >= 0 && n_slab >= 1 && (step >= 1 || step_dev), "tsm_adam_step: bad sizes n=%lld n_slab=%d step=%lld",
                 (long long)n, n_slab, (long long)step);
     if (n == 0) return TSM_OK;
     TSM_REQUIRE(param && grad_slabs && exp_avg && exp_avg_sq, "tsm_adam_step: null pointer");
-    TSM_REQUIRE(max_grad_norm <= 0.0 || norm_scratch, "tsm_adam_step: clipping needs norm_scratch[64]");
+    TSM_REQUIRE(max_grad_norm <= 0.0 || work, "tsm_adam_step: clipping needs work[tsm_adam_work_elems(n)]");
+    TSM_REQUIRE(!param_image || image_map, "tsm_adam_step: param_image needs image_map");
     hipStream_t st = tsm_stream(stream);
+    const dim3 grid((unsigned)ceil_div(n, kCols));
     if (max_grad_norm > 0.0) {
-        hipLaunchKernelGGL(gradnorm_kernel, dim3(kNormBlocks), dim3(256), 0, st, grad_slabs, n_slab, n,
-                           norm_scratch);
+        hipLaunchKernelGGL(reduce_norm_kernel, grid, dim3(256), 0, st, grad_slabs, n_slab, n, work);
         TSM_LAUNCH_CHECK();
     }
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, param, grad_slabs, n_slab,
-                       n, exp_avg, exp_avg_sq, (float)(lr / bc1), (float)beta1, (float)beta2, (float)sqrt(bc2),
-                       (float)eps, (float)weight_decay, (float)max_grad_norm, norm_scratch);
+    hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, st, param, grad_slabs, n_slab, n, exp_avg, exp_avg_sq, lr,
+                       beta1, beta2, step, step_dev, (float)eps, (float)weight_decay, (float)max_grad_norm, work,
+                       param_image, image_map);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+// img[map[i]] = param[i] (initial fill / after load_state_dict); pads of `img` must be zero already.
+TSM_EXPORT int tsm_scatter_image(const float *param, int64_t n, const int32_t *image_map, float *param_image,
+                                 void *stream) {
+    TSM_REQUIRE(n >= 0, "tsm_scatter_image: negative n");
+    if (n == 0) return TSM_OK;
+    TSM_REQUIRE(param && image_map && param_image, "tsm_scatter_image: null pointer");
+    hipLaunchKernelGGL(scatter_image_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, tsm_stream(stream), param,
+                       n, image_map, param_image);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

@@ -56,6 +56,7 @@ struct Lay {  // LDS layout in floats
         B2 = o; o += 2 * H;
         B3a = o; o += 16;
         B3c = o; o += 2;
+        o = (o + 3) & ~3;  // weights image [0, X) is a whole number of 16-B words
         X = o; o += R * d.ld1;
         H1 = o; o += R * ld2;
         H2 = o; o += R * ld2;
@@ -111,6 +112,16 @@ __device__ void stage_weights(float *lds, const Lay<H> &ly, const Dims &d, const
     }
     if (tid < 16) lds[ly.B3a + tid] = tid < d.A ? P[po.ab3 + tid] : 0.f;
     if (tid == 0) lds[ly.B3c] = P[po.cb3];
+}
+
+// Staging from the padded parameter image kept up to date by tsm_adam_step (img[0 .. ly.X) has exactly the
+// LDS layout W1..B3c incl. zero pads): straight 16-B copies, ~12 independent loads per thread.
+template <int H>
+__device__ __forceinline__ void stage_image(float *lds, const Lay<H> &ly, const float *__restrict__ img) {
+    const float4 *src = reinterpret_cast<const float4 *>(img);
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    const int n4 = ly.X / 4;
+    for (int e = threadIdx.x; e < n4; e += NT) dst[e] = src[e];
 }
 
 // forward of one 16-row tile already staged in lds[ly.X]; leaves H1, H2, OUT (logits | value) in LDS
@@ -200,13 +211,15 @@ __device__ __forceinline__ void load_tile_x(float *lds, int X, const Dims &d, co
 // ------------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(NT) void policy_forward_kernel(
-    const float *__restrict__ P, Dims d, const float *__restrict__ obs, int64_t B, uint64_t seed,
+    const float *__restrict__ P, const float *__restrict__ img, Dims d, const float *__restrict__ obs, int64_t B,
+    uint64_t seed,
     uint64_t offset, const uint64_t *__restrict__ offset_dev, int mode /*0 none, 1 sample, 2 argmax, 3 given*/,
     float *__restrict__ logits_out,
     float *__restrict__ value_out, int32_t *__restrict__ act_io, float *__restrict__ logp_out) {
     extern __shared__ float lds[];
     const Lay<H> ly(d, false);
-    stage_weights<H>(lds, ly, d, P);
+    if (img) stage_image<H>(lds, ly, img);
+    else stage_weights<H>(lds, ly, d, P);
     if (offset_dev) offset += *offset_dev;
     const int64_t n_tiles = (B + R - 1) / R;
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -259,15 +272,19 @@ struct LossCfg {
 
 template <int H>
 __global__ __launch_bounds__(NT) void ppo_update_kernel(
-    const float *__restrict__ P, Dims d, const float *__restrict__ obs, const int32_t *__restrict__ act,
+    const float *__restrict__ P, const float *__restrict__ img, Dims d, const float *__restrict__ obs,
+    const int32_t *__restrict__ act,
     const float *__restrict__ logp_old, const float *__restrict__ adv, const float *__restrict__ returns,
     const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first, int64_t M,
     const float *__restrict__ adv_stats, LossCfg cfg, float *__restrict__ slabs,
-    double *__restrict__ loss_partial) {
+    double *__restrict__ loss_partial, int64_t *__restrict__ opt_step_dev) {
     extern __shared__ float lds[];
+    // device-resident optimizer step count (hipGraph replay): bumped here, read by the Adam kernel that follows
+    if (opt_step_dev && blockIdx.x == 0 && threadIdx.x == 0) *opt_step_dev += 1;
     const Lay<H> ly(d, true);
     const POff<H> po(d.D, d.A);
-    stage_weights<H>(lds, ly, d, P);
+    if (img) stage_image<H>(lds, ly, img);
+    else stage_weights<H>(lds, ly, d, P);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const float invM = 1.0f / (float)M;
@@ -285,7 +302,7 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
     float g_b1 = 0.f, g_b2 = 0.f;           // threads 0..2H-1: bias grads of column tid (actor | critic)
     float g_W3c = 0.f;                      // threads 0..H-1
     float g_b3 = 0.f;                       // threads 0..A-1: b3a ; thread 16: b3c
-    double s_clip = 0.0, s_vf = 0.0, s_ent = 0.0;  // threads 0..R-1
+    double s_clip = 0.0, s_vf = 0.0, s_ent = 0.0;  // threads 16*r (one per tile row)
 
     const int64_t n_tiles = (M + R - 1) / R;
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -295,29 +312,33 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
         __syncthreads();
         tile_forward<H>(lds, ly, d);
 
-        // ---- loss head: one thread per row (ppo.py:182-211) -> D3 = [dlogits(16) | dvalue] ----
-        if (threadIdx.x < R) {
-            const int r = threadIdx.x;
+        // ---- loss head (ppo.py:182-211): 16 lanes per row, lane j owns action j -> D3 = [dlogits(16) | dvalue] ----
+        {
+            const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
             const int64_t i = row0 + r;
             float *d3 = lds + ly.D3 + r * ly.ldo;
-            float dl[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) dl[j] = 0.f;
-            float dv = 0.f;
-            if (i < M) {
+            float dl = 0.f, dv = 0.f;
+            if (i < M) {  // uniform over the 16 lanes of a row
                 const int64_t src = perm ? perm[i] : first + i;
                 const float *lg = lds + ly.OUT + r * ly.ldo;
-                float m = -INFINITY;
-                for (int j = 0; j < d.A; ++j) m = fmaxf(m, lg[j]);
-                float s = 0.f;
-                for (int j = 0; j < d.A; ++j) s += expf(lg[j] - m);
-                const float lse = m + logf(s);
+                const bool on = j < d.A;
+                const float x = on ? lg[j] : -INFINITY;
+                float m = x;
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                const float ex = on ? expf(x - m) : 0.f;
+                float s = ex;
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                const float l = on ? x - (m + logf(s)) : 0.f;   // log-softmax
+                const float p = ex / s;
+                float h = on ? -p * l : 0.f;                     // entropy
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) h += __shfl_xor(h, off, 64);
                 const int a_idx = act[src];
+                const float logp = __shfl(l, (threadIdx.x & 48) + a_idx, 64);
                 float a = adv[src];
                 if (cfg.adv_norm) a = (a - a_mean) / (a_std + 1e-8f);
-                float h = 0.f;
-                for (int j = 0; j < d.A; ++j) { const float l = lg[j] - lse; h -= expf(l) * l; }
-                const float logp = lg[a_idx] - lse;
                 const float ratio = expf(logp - logp_old[src]);
                 const float lo = 1.0f - cfg.eps_clip, hi = 1.0f + cfg.eps_clip;
                 const float rc = fminf(fmaxf(ratio, lo), hi);
@@ -351,15 +372,11 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
                 }
                 dv = cfg.vf_coef * g_v * invM;
                 const float g_logp = -g_ratio * ratio * invM, ec = cfg.ent_coef * invM;
-                for (int j = 0; j < d.A; ++j) {
-                    const float l = lg[j] - lse, p = expf(l);
-                    dl[j] = g_logp * ((j == a_idx ? 1.f : 0.f) - p) + ec * p * (l + h);
-                }
-                s_clip += (double)obj; s_vf += (double)vf; s_ent += (double)h;
+                if (on) dl = g_logp * ((j == a_idx ? 1.f : 0.f) - p) + ec * p * (l + h);
+                if (j == 0) { s_clip += (double)obj; s_vf += (double)vf; s_ent += (double)h; }
             }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) d3[j] = dl[j];
-            d3[16] = dv;
+            d3[j] = dl;
+            if (j == 0) d3[16] = dv;
         }
         __syncthreads();
 
@@ -493,19 +510,16 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
     }
     if (threadIdx.x < d.A) S[po.ab3 + threadIdx.x] = g_b3;
     if (threadIdx.x == 16) S[po.cb3] = g_b3;
-    // loss partial sums: rows live in threads 0..15 of wave 0
-    if (w == 0) {
-        double c = s_clip, v = s_vf, e = s_ent;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            c += __shfl_xor(c, off, 64);
-            v += __shfl_xor(v, off, 64);
-            e += __shfl_xor(e, off, 64);
-        }
-        if (lane == 0) {
-            loss_partial[4 * blockIdx.x + 0] = c;
-            loss_partial[4 * blockIdx.x + 1] = v;
-            loss_partial[4 * blockIdx.x + 2] = e;
+    // loss partial sums: row r accumulated in thread 16*r (lane j == 0 of its 16-lane group)
+    {
+        __shared__ double s_red[3][NT / 64];
+        double c = wave_sum(s_clip), v = wave_sum(s_vf), e = wave_sum(s_ent);
+        if (lane == 0) { s_red[0][w] = c; s_red[1][w] = v; s_red[2][w] = e; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            loss_partial[4 * blockIdx.x + 0] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+            loss_partial[4 * blockIdx.x + 1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+            loss_partial[4 * blockIdx.x + 2] = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
             loss_partial[4 * blockIdx.x + 3] = 0.0;
         }
     }
@@ -533,6 +547,34 @@ __global__ __launch_bounds__(256) void update_finalize_kernel(const double *__re
     }
 }
 
+// one workgroup per gradient step: scalars[k] from partial[k][0..n_blocks[k])
+__global__ __launch_bounds__(256) void update_finalize_many_kernel(const double *__restrict__ partial,
+                                                                   int64_t stride_elems,
+                                                                   const int32_t *__restrict__ n_blocks,
+                                                                   const int64_t *__restrict__ M, float vf_coef,
+                                                                   float ent_coef, float *__restrict__ scalars) {
+    __shared__ double sm[256 / 64];
+    const int k = blockIdx.x;
+    const double *p = partial + (int64_t)k * stride_elems;
+    double c = 0.0, v = 0.0, e = 0.0;
+    for (int b = threadIdx.x; b < n_blocks[k]; b += 256) {
+        c += p[4 * b + 0];
+        v += p[4 * b + 1];
+        e += p[4 * b + 2];
+    }
+    c = block_sum<double, 256>(c, sm);
+    v = block_sum<double, 256>(v, sm);
+    e = block_sum<double, 256>(e, sm);
+    if (threadIdx.x == 0) {
+        const double m = (double)M[k];
+        const double clip_loss = -c / m, vf_loss = v / m, ent_loss = e / m;
+        scalars[4 * k + 0] = (float)(clip_loss + (double)vf_coef * vf_loss - (double)ent_coef * ent_loss);
+        scalars[4 * k + 1] = (float)clip_loss;
+        scalars[4 * k + 2] = (float)vf_loss;
+        scalars[4 * k + 3] = (float)ent_loss;
+    }
+}
+
 int make_dims(int32_t obs_dim, int32_t hidden, int32_t n_act, Dims *d) {
     TSM_REQUIRE(hidden == 64, "fused MLP supports hidden == 64 (got %d)", hidden);
     TSM_REQUIRE(obs_dim >= 1 && obs_dim <= 16 * kMaxJ, "fused MLP supports 1 <= obs_dim <= %d (got %d)", 16 * kMaxJ,
@@ -553,7 +595,47 @@ TSM_EXPORT int64_t tsm_policy_param_count(int32_t obs_dim, int32_t hidden, int32
     return POff<64>(obs_dim, n_act).total;
 }
 
-TSM_EXPORT int tsm_policy_forward(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+TSM_EXPORT int64_t tsm_policy_image_elems(int32_t obs_dim, int32_t hidden, int32_t n_act) {
+    Dims d;
+    if (make_dims(obs_dim, hidden, n_act, &d)) return -1;
+    return Lay<64>(d, false).X;
+}
+
+// map_out_host[i] = offset of flat parameter i inside the padded image (tsm_policy_param_count entries)
+TSM_EXPORT int tsm_policy_image_map(int32_t obs_dim, int32_t hidden, int32_t n_act, int32_t *map_out_host) {
+    Dims d;
+    if (int rc = make_dims(obs_dim, hidden, n_act, &d)) return rc;
+    TSM_REQUIRE(map_out_host, "tsm_policy_image_map: null pointer");
+    constexpr int H = 64;
+    const Lay<H> ly(d, false);
+    const POff<H> po(d.D, d.A);
+    int32_t *m = map_out_host;
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < d.D; ++c) {
+            m[po.aW1 + r * d.D + c] = ly.W1 + r * d.ld1 + c;
+            m[po.cW1 + r * d.D + c] = ly.W1 + (H + r) * d.ld1 + c;
+        }
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < H; ++c) {
+            m[po.aW2 + r * H + c] = ly.W2a + r * ly.ldh + c;
+            m[po.cW2 + r * H + c] = ly.W2c + r * ly.ldh + c;
+        }
+    for (int r = 0; r < d.A; ++r)
+        for (int c = 0; c < H; ++c) m[po.aW3 + r * H + c] = ly.W3a + r * ly.ldh + c;
+    for (int c = 0; c < H; ++c) {
+        m[po.cW3 + c] = ly.W3c + c;
+        m[po.ab1 + c] = ly.B1 + c;
+        m[po.cb1 + c] = ly.B1 + H + c;
+        m[po.ab2 + c] = ly.B2 + c;
+        m[po.cb2 + c] = ly.B2 + H + c;
+    }
+    for (int c = 0; c < d.A; ++c) m[po.ab3 + c] = ly.B3a + c;
+    m[po.cb3] = ly.B3c;
+    return TSM_OK;
+}
+
+TSM_EXPORT int tsm_policy_forward(const float *params, const float *param_image, int32_t obs_dim, int32_t hidden,
+                                  int32_t n_act,
                                   const float *obs, int64_t B, int mode, uint64_t seed, uint64_t offset,
                                   const uint64_t *offset_dev, float *logits_out, float *value_out, int32_t *act_io, float *logp_out,
                                   void *stream) {
@@ -570,10 +652,11 @@ TSM_EXPORT int tsm_policy_forward(const float *params, int32_t obs_dim, int32_t 
     static bool attr_set = false;
     if (!attr_set) {
         TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel<64>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((policy_forward_kernel<64>), dim3(grid), dim3(NT), shmem, tsm_stream(stream), params, d, obs,
+    hipLaunchKernelGGL((policy_forward_kernel<64>), dim3(grid), dim3(NT), shmem, tsm_stream(stream), params,
+                       param_image, d, obs,
                        B, seed, offset, offset_dev, mode, logits_out, value_out, act_io, logp_out);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
@@ -586,12 +669,14 @@ TSM_EXPORT int tsm_ppo_update_grid(int64_t M, int32_t max_blocks) {
     return (int)g;
 }
 
-TSM_EXPORT int tsm_ppo_update_fused(const float *params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_image, int32_t obs_dim, int32_t hidden,
+                                    int32_t n_act,
                                     const float *obs, const int32_t *act, const float *logp_old, const float *adv,
                                     const float *returns, const float *v_s_old, const int64_t *perm,
                                     int64_t first_row, int64_t M, const float *adv_stats,
                                     const tsm_ppo_cfg *cfg_host, int32_t n_blocks, float *grad_slabs_out,
-                                    double *loss_partial_out, float *scalars_out, void *stream) {
+                                    double *loss_partial_out, float *scalars_out, int64_t *opt_step_dev,
+                                    void *stream) {
     Dims d;
     if (int rc = make_dims(obs_dim, hidden, n_act, &d)) return rc;
     TSM_REQUIRE(M >= 1, "tsm_ppo_update_fused: M must be >= 1");
@@ -614,19 +699,38 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, int32_t obs_dim, int32_
     const size_t shmem = (size_t)ly.total * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
+        // the kernel also has a few hundred bytes of static LDS: leave headroom below the 160 KiB of a CU
         TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ppo_update_kernel<64>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set = true;
     }
     hipStream_t st = tsm_stream(stream);
-    hipLaunchKernelGGL((ppo_update_kernel<64>), dim3((unsigned)n_blocks), dim3(NT), shmem, st, params, d, obs, act,
+    hipLaunchKernelGGL((ppo_update_kernel<64>), dim3((unsigned)n_blocks), dim3(NT), shmem, st, params, param_image, d,
+                       obs, act,
                        logp_old, adv, returns, v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out,
-                       loss_partial_out);
+                       loss_partial_out, opt_step_dev);
     TSM_LAUNCH_CHECK();
     if (scalars_out) {
         hipLaunchKernelGGL(update_finalize_kernel, dim3(1), dim3(256), 0, st, loss_partial_out, n_blocks, M,
                            cfg.vf_coef, cfg.ent_coef, scalars_out);
         TSM_LAUNCH_CHECK();
     }
+    return TSM_OK;
+}
+
+// Loss statistics of many gradient steps in ONE launch (the per-step finalize of tsm_ppo_update_fused is
+// skipped by passing scalars_out = NULL there): step k reads partial + k*stride_elems, n_blocks_dev[k]
+// workgroup rows, M_dev[k] samples; writes scalars_out[k][4] = {loss, clip, vf, ent} (ppo.py:213-216).
+TSM_EXPORT int tsm_ppo_finalize_many(const double *partial, int64_t stride_elems, const int32_t *n_blocks_dev,
+                                     const int64_t *M_dev, int32_t n_steps, const tsm_ppo_cfg *cfg_host,
+                                     float *scalars_out, void *stream) {
+    TSM_REQUIRE(n_steps >= 0, "tsm_ppo_finalize_many: negative n_steps");
+    if (n_steps == 0) return TSM_OK;
+    TSM_REQUIRE(partial && n_blocks_dev && M_dev && cfg_host && scalars_out && stride_elems >= 4,
+                "tsm_ppo_finalize_many: bad args");
+    hipLaunchKernelGGL(update_finalize_many_kernel, dim3((unsigned)n_steps), dim3(256), 0, tsm_stream(stream), partial,
+                       stride_elems, n_blocks_dev, M_dev, (float)cfg_host->vf_coef, (float)cfg_host->ent_coef,
+                       scalars_out);
+    TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

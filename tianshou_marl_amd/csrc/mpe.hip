@@ -46,10 +46,10 @@ __device__ void reset_env(const MpeCfg &c, int e, uint64_t seed, uint64_t episod
 }
 
 __device__ void write_obs(const MpeCfg &c, int e, const float *apos, const float *avel, const float *lpos,
-                          float *obs /* [n_env][N][obs_dim] */) {
+                          float *obs_env /* this env's [N][obs_dim] block (global or LDS) */) {
     const float *ap = apos + (int64_t)e * c.N * 2, *av = avel + (int64_t)e * c.N * 2, *lp = lpos + (int64_t)e * c.N * 2;
     for (int i = 0; i < c.N; ++i) {
-        float *o = obs + ((int64_t)e * c.N + i) * c.obs_dim;
+        float *o = obs_env + i * c.obs_dim;
         int k = 0;
         o[k++] = av[2 * i]; o[k++] = av[2 * i + 1];
         o[k++] = ap[2 * i]; o[k++] = ap[2 * i + 1];
@@ -66,7 +66,7 @@ __global__ void mpe_reset_kernel(MpeCfg c, uint64_t seed, uint64_t *episode_ctr,
     const int e = env_ids ? (int)env_ids[i] : (int)i;
     const uint64_t ep = episode_ctr[e]++;
     reset_env(c, e, seed, ep, apos, avel, lpos, steps);
-    write_obs(c, e, apos, avel, lpos, obs);
+    write_obs(c, e, apos, avel, lpos, obs + (int64_t)e * c.N * c.obs_dim);
 }
 
 // One joint step of every env.  Outputs (all [n_env][N] unless noted):
@@ -75,13 +75,10 @@ __global__ void mpe_reset_kernel(MpeCfg c, uint64_t seed, uint64_t *episode_ctr,
 //   rew f32, terminated u8 (always 0 here), truncated u8;  done_env [n_env] u8
 // auto_reset != 0: finished envs are re-initialised in place (Collector's env.reset(env_id=done ids),
 // /root/reference/tianshou/data/collector.py:971).
-__global__ void mpe_step_kernel(MpeCfg c, uint64_t seed, uint64_t *episode_ctr, const int32_t *__restrict__ act,
-                                float *apos, float *avel, float *lpos, int32_t *steps, float *obs_next,
-                                float *obs_cur, float *rew, uint8_t *term, uint8_t *trunc, uint8_t *done_env,
-                                int auto_reset, uint64_t *tick, uint64_t tick_inc) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e == 0 && tick) *tick += tick_inc;
-    if (e >= c.n_env) return;
+__device__ void step_one_env(const MpeCfg &c, int e, uint64_t seed, uint64_t *episode_ctr,
+                             const int32_t *__restrict__ act, float *apos, float *avel, float *lpos, int32_t *steps,
+                             float *obs_next /* env block */, float *obs_cur /* env block or null */, float *rew,
+                             uint8_t *term, uint8_t *trunc, uint8_t *done_env, int auto_reset) {
     const int N = c.N;
     float px[kMaxN], py[kMaxN], vx[kMaxN], vy[kMaxN], fx[kMaxN], fy[kMaxN];
     float *ap = apos + (int64_t)e * N * 2, *av = avel + (int64_t)e * N * 2;
@@ -162,6 +159,35 @@ __global__ void mpe_step_kernel(MpeCfg c, uint64_t seed, uint64_t *episode_ctr, 
     if (obs_cur) write_obs(c, e, apos, avel, lpos, obs_cur);
 }
 
+constexpr int kEnvPerBlock = 16;  // small workgroups: 1024 envs spread over 64 CUs (the step is latency-bound)
+
+// Lanes 0..15 of the single wave advance one env each and stage both observation blocks in LDS; then all 64
+// lanes stream them out as one contiguous, coalesced segment per workgroup (obs rows of consecutive envs
+// are adjacent in [n_env][N][obs_dim]).
+__global__ __launch_bounds__(64) void mpe_step_kernel(MpeCfg c, uint64_t seed, uint64_t *episode_ctr,
+                                                      const int32_t *__restrict__ act, float *apos, float *avel,
+                                                      float *lpos, int32_t *steps, float *obs_next, float *obs_cur,
+                                                      float *rew, uint8_t *term, uint8_t *trunc, uint8_t *done_env,
+                                                      int auto_reset, uint64_t *tick, uint64_t tick_inc) {
+    extern __shared__ float s_obs[];  // [2][kEnvPerBlock][N * obs_dim]
+    const int row = c.N * c.obs_dim;
+    const int e0 = blockIdx.x * kEnvPerBlock;
+    const int e = e0 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && tick) *tick += tick_inc;
+    float *s_next = s_obs, *s_cur = s_obs + kEnvPerBlock * row;
+    if (threadIdx.x < kEnvPerBlock && e < c.n_env)
+        step_one_env(c, e, seed, episode_ctr, act, apos, avel, lpos, steps, s_next + threadIdx.x * row,
+                     obs_cur ? s_cur + threadIdx.x * row : nullptr, rew, term, trunc, done_env, auto_reset);
+    __syncthreads();
+    const int n_here = min(kEnvPerBlock, c.n_env - e0);
+    float *g_next = obs_next + (int64_t)e0 * row;
+    for (int i = threadIdx.x; i < n_here * row; i += 64) g_next[i] = s_next[i];
+    if (obs_cur) {
+        float *g_cur = obs_cur + (int64_t)e0 * row;
+        for (int i = threadIdx.x; i < n_here * row; i += 64) g_cur[i] = s_cur[i];
+    }
+}
+
 int check_cfg(const tsm_mpe_cfg *h, MpeCfg *c) {
     TSM_REQUIRE(h, "mpe: null cfg");
     TSM_REQUIRE(h->n_env >= 1 && h->n_agent >= 1 && h->n_agent <= kMaxN, "mpe: n_env >= 1, 1 <= n_agent <= %d", kMaxN);
@@ -200,8 +226,9 @@ TSM_EXPORT int tsm_mpe_spread_step(const tsm_mpe_cfg *cfg_host, uint64_t seed, u
     TSM_REQUIRE(episode_ctr && act && agent_pos && agent_vel && landmark_pos && steps && obs_next_out && rew_out &&
                     terminated_out && truncated_out && done_env_out,
                 "tsm_mpe_spread_step: null pointer");
-    hipLaunchKernelGGL(mpe_step_kernel, dim3((unsigned)ceil_div(c.n_env, 64)), dim3(64), 0, tsm_stream(stream), c,
-                       seed, episode_ctr, act, agent_pos, agent_vel, landmark_pos, steps, obs_next_out, obs_cur_out,
+    const size_t shmem = (size_t)2 * kEnvPerBlock * c.N * c.obs_dim * sizeof(float);
+    hipLaunchKernelGGL(mpe_step_kernel, dim3((unsigned)ceil_div(c.n_env, kEnvPerBlock)), dim3(64), shmem,
+                       tsm_stream(stream), c, seed, episode_ctr, act, agent_pos, agent_vel, landmark_pos, steps, obs_next_out, obs_cur_out,
                        rew_out, terminated_out, truncated_out, done_env_out, auto_reset, rng_tick, rng_tick_inc);
     TSM_LAUNCH_CHECK();
     return TSM_OK;

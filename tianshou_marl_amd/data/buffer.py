@@ -66,7 +66,7 @@ class DeviceVectorReplayBuffer:
 
     # ---- add --------------------------------------------------------------------------------
     def add_device(self, obs, act, rew, terminated, truncated, obs_next=None, logp=None, v_s=None,
-                   buffer_ids=None, done=None):
+                   buffer_ids=None, done=None, outs=None):
         """Device-path add: every argument is an HBM tensor with leading dim R (rows = envs).
 
         Returns the reference 4-tuple as device tensors (ptr i64[R], ep_rew f64[R,N], ep_len i64[R], ep_idx i64[R]).
@@ -82,7 +82,7 @@ class DeviceVectorReplayBuffer:
             fields.append((logp, self.logp_store))
         if v_s is not None and self.vs_store is not None:
             fields.append((v_s, self.vs_store))
-        return self.index.add(rew, done, buffer_ids, fields=fields)
+        return self.index.add(rew, done, buffer_ids, fields=fields, outs=outs)
 
     def add(self, batch: Batch, buffer_ids=None):
         """Reference signature (manager.py:131-193): host Batch in, numpy 4-tuple out."""

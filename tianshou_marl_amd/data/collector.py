@@ -33,7 +33,8 @@ from .stats import CollectStats
 class Collector:
     def __init__(self, policy, env, buffer: DeviceVectorReplayBuffer | None = None, exploration_noise: bool = False,
                  on_episode_done_hook: Callable | None = None, on_step_hook: Callable | None = None,
-                 raise_on_nan_in_buffer: bool = False) -> None:
+                 raise_on_nan_in_buffer: bool = False, use_graph: bool = True) -> None:
+        self.use_graph = use_graph
         self.policy = getattr(policy, "policy", policy)  # an Algorithm is accepted (collector.py:358)
         self.env = env
         self.env_num = len(env)
@@ -102,6 +103,8 @@ class Collector:
         if prev_training is not None and hasattr(self.policy, "train"):
             self.policy.train(False)  # torch_train_mode(policy, False), collector.py:500
         try:
+            if hasattr(self.policy, "net") and hasattr(self.policy.net, "sync_image"):
+                self.policy.net.sync_image()
             if self._device_path and not random:
                 stats = self._collect_device(n_step, n_episode)
             else:
@@ -126,6 +129,8 @@ class Collector:
             self._ws[key] = dict(
                 act=torch.zeros(E, N, dtype=torch.int32, device=dev), logp=torch.zeros(E, N, device=dev),
                 value=torch.zeros(E, N, device=dev),
+                ptr=torch.zeros(n_iter, E, dtype=torch.int64, device=dev),
+                ep_idx=torch.zeros(n_iter, E, dtype=torch.int64, device=dev),
                 ep_len=torch.zeros(n_iter, E, dtype=torch.int64, device=dev),
                 ep_rew=torch.zeros(n_iter, E, N, dtype=torch.float64, device=dev))
         return self._ws[key]
@@ -137,14 +142,32 @@ class Collector:
             n_iter = -(-n_step // E)
             ws = self._device_ws(n_iter)
             out = dict(act=ws["act"].view(-1), logp=ws["logp"].view(-1), value=ws["value"].view(-1), logits=None)
-            for it in range(n_iter):
-                obs = env.obs_cur  # stays intact: the env writes the next policy input into its other buffer
-                pol.act_device(obs, out=out)
-                obs_next, rew, term, trunc, done = env.step_device(ws["act"])
-                _, ep_rew, ep_len, _ = buf.add_device(obs, ws["act"], rew, term, trunc, obs_next, ws["logp"],
-                                                      ws["value"], None, done)
-                ws["ep_len"][it].copy_(ep_len)
-                ws["ep_rew"][it].copy_(ep_rew)
+
+            def body():
+                pp0 = env._pp
+                for it in range(n_iter):
+                    obs = env.obs_cur  # stays intact: the env writes the next policy input into its other buffer
+                    # sampling counter lives in HBM (env.rng_tick) so that a captured graph advances it on replay
+                    pol.act_device(obs, out=out, offset_dev=env.rng_tick)
+                    obs_next, rew, term, trunc, done = env.step_device(ws["act"], rng_tick_inc=E * N)
+                    buf.add_device(obs, ws["act"], rew, term, trunc, obs_next, ws["logp"], ws["value"], None, done,
+                                   outs=(ws["ptr"][it], ws["ep_rew"][it], ws["ep_len"][it], ws["ep_idx"][it]))
+                if env._pp != pp0:  # odd number of ping-pong flips: restore the parity the graph was captured with
+                    env._obs_pp[pp0].copy_(env.obs_cur)
+                    env._pp = pp0
+
+            mode = bool(getattr(pol, "deterministic_eval", False) and not getattr(pol, "is_within_training_step", False))
+            gkey = ("graph", n_iter, mode, env._pp)
+            if self.use_graph and self._ws.get(("seen", n_iter)):
+                if gkey not in self._ws:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        body()
+                    self._ws[gkey] = g
+                self._ws[gkey].replay()
+            else:
+                body()  # first call: eager (also sets one-time kernel attributes before any capture)
+                self._ws[("seen", n_iter)] = True
             lens = ws["ep_len"][:n_iter]
             mask = lens > 0
             lens_h = lens[mask].cpu().numpy()  # the single host sync of this collect()

@@ -96,8 +96,9 @@ class VrbState:
         call("tsm_vrb_reset", ptr(self.state), self.buffer_num, self.sub_size, self.rew_dim,
              int(keep_statistics), stream_ptr())
 
-    def add(self, rew, done, buffer_ids=None, fields=()):
-        """manager.py:131-193.  fields: iterable of (src[R, ...], dst[sub_size, buffer_num, ...])."""
+    def add(self, rew, done, buffer_ids=None, fields=(), outs=None):
+        """manager.py:131-193.  fields: iterable of (src[R, ...], dst[sub_size, buffer_num, ...]).
+        outs: optional preallocated (ptr i64[R], ep_rew f64[R,D], ep_len i64[R], ep_idx i64[R])."""
         rew = _chk(rew, torch.float32, "rew").reshape(rew.shape[0], -1)
         R = rew.shape[0]
         if rew.shape[1] != self.rew_dim:
@@ -105,10 +106,13 @@ class VrbState:
         done = done.contiguous().view(torch.uint8) if done.dtype == torch.bool else _chk(done, torch.uint8, "done")
         ids = None if buffer_ids is None else _chk(buffer_ids, torch.int64, "buffer_ids")
         dev = self.device
-        ptr_out = torch.empty(R, dtype=torch.int64, device=dev)
-        ep_rew = torch.empty(R, self.rew_dim, dtype=torch.float64, device=dev)
-        ep_len = torch.empty(R, dtype=torch.int64, device=dev)
-        ep_idx = torch.empty(R, dtype=torch.int64, device=dev)
+        if outs is not None:
+            ptr_out, ep_rew, ep_len, ep_idx = outs
+        else:
+            ptr_out = torch.empty(R, dtype=torch.int64, device=dev)
+            ep_rew = torch.empty(R, self.rew_dim, dtype=torch.float64, device=dev)
+            ep_len = torch.empty(R, dtype=torch.int64, device=dev)
+            ep_idx = torch.empty(R, dtype=torch.int64, device=dev)
         farr = (tsm_field * max(1, len(fields)))()
         keep = []
         for i, (src, dst) in enumerate(fields):
@@ -228,12 +232,12 @@ def make_ppo_cfg(eps_clip=0.2, dual_clip=None, value_clip=False, adv_norm=True, 
                        int(bool(value_clip)), int(bool(adv_norm)))
 
 
-def ppo_adv_stats(adv, mb_start, perm=None):
+def ppo_adv_stats(adv, mb_start, perm=None, out=None):
     """Per-minibatch (mean, unbiased std) of adv[perm[mb_start[k]:mb_start[k+1]]] -> [n_mb, 2] f32."""
     adv = _chk(adv, torch.float32, "adv").reshape(-1)
     mb_start = _chk(mb_start, torch.int64, "mb_start")
     n_mb = mb_start.numel() - 1
-    stats = torch.empty(n_mb, 2, dtype=torch.float32, device=adv.device)
+    stats = out if out is not None else torch.empty(n_mb, 2, dtype=torch.float32, device=adv.device)
     call("tsm_ppo_adv_stats", ptr(adv), ptr(perm), ptr(mb_start), n_mb, ptr(stats), stream_ptr())
     return stats
 
@@ -263,15 +267,15 @@ def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, returns, cfg: tsm_ppo_cf
 # optimizer (algorithm_base.py:485-498; optim.py:91-111)
 # --------------------------------------------------------------------------------------------
 def adam_step(param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-              weight_decay=0.0, max_grad_norm=None, norm_scratch=None):
+              weight_decay=0.0, max_grad_norm=None, work=None, step_dev=None, image=None, image_map=None):
     """In-place Adam on a flat f32 vector; grad_slabs [n_slab, n] are summed in slab order."""
     n = param.numel()
     grad_slabs = _chk(grad_slabs, torch.float32, "grad_slabs").reshape(-1, n)
-    if max_grad_norm and norm_scratch is None:
-        norm_scratch = torch.empty(64, dtype=torch.float32, device=param.device)
+    if max_grad_norm and work is None:
+        work = torch.empty(call("tsm_adam_work_elems", n), dtype=torch.float32, device=param.device)
     call("tsm_adam_step", ptr(param), ptr(grad_slabs), grad_slabs.shape[0], n, ptr(exp_avg), ptr(exp_avg_sq),
-         int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-         float(max_grad_norm or 0.0), ptr(norm_scratch), stream_ptr())
+         int(step), ptr(step_dev), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+         float(max_grad_norm or 0.0), ptr(work), ptr(image), ptr(image_map), stream_ptr())
     return param
 
 
@@ -299,7 +303,8 @@ def policy_param_count(obs_dim: int, hidden: int, n_act: int) -> int:
 
 
 def policy_forward(params, obs, n_act: int, hidden: int = 64, mode: str = "none", seed: int = 0, offset: int = 0,
-                   act=None, want_logits=True, want_value=True, want_logp=True, offset_dev=None, out=None):
+                   act=None, want_logits=True, want_value=True, want_logp=True, offset_dev=None, out=None,
+                   image=None):
     """obs [B, D] f32 -> dict(logits[B,A], value[B], act[B] i32, logp[B]) via one fused kernel."""
     obs = _chk(obs, torch.float32, "obs")
     B, D = obs.shape
@@ -316,10 +321,33 @@ def policy_forward(params, obs, n_act: int, hidden: int = 64, mode: str = "none"
         elif m != 0:
             act = torch.empty(B, dtype=torch.int32, device=dev)
         logp = torch.empty(B, dtype=torch.float32, device=dev) if (want_logp and m != 0) else None
-    call("tsm_policy_forward", ptr(_chk(params, torch.float32, "params")), D, hidden, n_act, ptr(obs), B, m,
+    call("tsm_policy_forward", ptr(_chk(params, torch.float32, "params")), ptr(image), D, hidden, n_act, ptr(obs), B, m,
          seed & (2**64 - 1), offset & (2**64 - 1), ptr(offset_dev), ptr(logits), ptr(value), ptr(act), ptr(logp),
          stream_ptr())
     return dict(logits=logits, value=value, act=act, logp=logp)
+
+
+def policy_image(obs_dim: int, hidden: int, n_act: int, device):
+    """(zero image f32[elems], map i32[P]) of the padded LDS-layout parameter copy."""
+    import numpy as np
+
+    n_img = call("tsm_policy_image_elems", obs_dim, hidden, n_act)
+    n_par = policy_param_count(obs_dim, hidden, n_act)
+    m = np.zeros(n_par, np.int32)
+    call("tsm_policy_image_map", obs_dim, hidden, n_act, m.ctypes.data_as(C.c_void_p))
+    return torch.zeros(n_img, dtype=torch.float32, device=device), torch.from_numpy(m).to(device)
+
+
+def scatter_image(params, image, image_map):
+    call("tsm_scatter_image", ptr(params), params.numel(), ptr(image_map), ptr(image), stream_ptr())
+    return image
+
+
+def ppo_finalize_many(partial, stride_elems: int, n_blocks_dev, M_dev, cfg: tsm_ppo_cfg, scalars_out):
+    """scalars_out[k] = {loss, clip, vf, ent} of gradient step k from its loss partials (one launch for all k)."""
+    call("tsm_ppo_finalize_many", ptr(partial), stride_elems, ptr(_chk(n_blocks_dev, torch.int32, "n_blocks")),
+         ptr(_chk(M_dev, torch.int64, "M")), scalars_out.shape[0], C.byref(cfg), ptr(scalars_out), stream_ptr())
+    return scalars_out
 
 
 def ppo_update_grid(M: int, max_blocks: int = 0) -> int:
@@ -328,7 +356,7 @@ def ppo_update_grid(M: int, max_blocks: int = 0) -> int:
 
 def ppo_update_fused(params, obs, act, logp_old, adv, returns, cfg: tsm_ppo_cfg, n_act: int, hidden: int = 64,
                      adv_stats=None, v_s_old=None, perm=None, first_row=0, M=None, n_blocks=None,
-                     slabs=None, partial=None, scalars=None):
+                     slabs=None, partial=None, scalars=None, opt_step_dev=None, image=None, want_scalars=True):
     """One PPO gradient step up to the gradients -> (grad_slabs[n_blocks, P], scalars[4])."""
     obs = _chk(obs, torch.float32, "obs")
     D = obs.shape[-1]
@@ -342,13 +370,13 @@ def ppo_update_fused(params, obs, act, logp_old, adv, returns, cfg: tsm_ppo_cfg,
         slabs = torch.empty(n_blocks, P, dtype=torch.float32, device=dev)
     if partial is None:
         partial = torch.empty(n_blocks * 4, dtype=torch.float64, device=dev)
-    if scalars is None:
+    if scalars is None and want_scalars:
         scalars = torch.empty(4, dtype=torch.float32, device=dev)
-    call("tsm_ppo_update_fused", ptr(_chk(params, torch.float32, "params")), D, hidden, n_act, ptr(obs),
+    call("tsm_ppo_update_fused", ptr(_chk(params, torch.float32, "params")), ptr(image), D, hidden, n_act, ptr(obs),
          ptr(_chk(act, torch.int32, "act")), ptr(_chk(logp_old, torch.float32, "logp_old")),
          ptr(_chk(adv, torch.float32, "adv")), ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old),
          ptr(perm), first_row, M, ptr(adv_stats), C.byref(cfg), n_blocks, ptr(slabs), ptr(partial), ptr(scalars),
-         stream_ptr())
+         ptr(opt_step_dev), stream_ptr())
     return slabs, scalars
 
 

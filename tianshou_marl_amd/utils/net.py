@@ -41,7 +41,14 @@ class DiscreteActorCritic(nn.Module):
                 self._slices[f"{net}.{name}"] = (o, shape)
                 o += int(np.prod(shape))
         assert o == n
+        # padded LDS-layout copy of the parameters, refreshed by the Adam kernel (csrc/adam.hip) and by
+        # sync_image(); the fused kernels stage it with straight 16-B copies
+        self.image, self.image_map = ops.policy_image(self.obs_dim, self.hidden, self.n_act, device)
         self.reset_parameters(init, seed)
+
+    def sync_image(self) -> None:
+        """Re-derive the padded image from `flat` (call after modifying `flat` outside the optimizer)."""
+        ops.scatter_image(self.flat.data, self.image, self.image_map)
 
     def view(self, name: str) -> torch.Tensor:
         o, shape = self._slices[name]
@@ -72,6 +79,7 @@ class DiscreteActorCritic(nn.Module):
                 fan_in = self.view(name.replace(".b", ".w")).shape[1]
                 b = torch.empty(v.shape).uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in), generator=gen)
                 v.copy_(b)
+        self.sync_image()
 
     # ---- reference checkpoint compatibility --------------------------------------
     _REF_KEYS = {
@@ -93,6 +101,7 @@ class DiscreteActorCritic(nn.Module):
         for name, v in self.named_views():
             net, layer = name.split(".")
             v.copy_(torch.as_tensor(sd[net][self._REF_KEYS[layer]]).to(v.device, v.dtype).reshape(v.shape))
+        self.sync_image()
 
     @torch.no_grad()
     def load_layers(self, actor, critic) -> None:
@@ -101,6 +110,7 @@ class DiscreteActorCritic(nn.Module):
             for i, (W, b) in enumerate(layers):
                 self.view(f"{net}.w{i}").copy_(torch.as_tensor(np.asarray(W)).to(self.flat.device, torch.float32))
                 self.view(f"{net}.b{i}").copy_(torch.as_tensor(np.asarray(b)).to(self.flat.device, torch.float32))
+        self.sync_image()
 
 
 class RunningMeanStd:
