@@ -305,6 +305,45 @@ int tsm_mpe_spread_step(const tsm_mpe_cfg *cfg_host, uint64_t seed, uint64_t *ep
                         int auto_reset, uint64_t *rng_tick, uint64_t rng_tick_inc, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Persistent rollout  [a4 + a7 + a8 fused; SURVEY 8f-1]
+ * One launch == one Collector.collect(n_step = n_steps * n_env) on the batched simple_spread env with a
+ * shared actor/critic: policy forward + sample + log-prob + value, env step (+ reset of finished envs),
+ * buffer index algebra and payload scatter for n_steps vector steps
+ * (tianshou/data/collector.py:854-1069 loop body).  Bit-identical to calling tsm_policy_forward ->
+ * tsm_mpe_spread_step -> tsm_vrb_add n_steps times.  Additionally stores vnext = V(obs_next) per row
+ * (a2c.py:124), so the update needs no critic pass.  All pointers are device pointers; nullable:
+ * params (if param_image given), obs_next_store, logp_store, vs_store, vnext_store, obs_cur_out, offset_dev.
+ * Per-step outputs: ptr_out/ep_len_out/ep_idx_out i64 [n_steps][n_env], ep_rew_out f64 [n_steps][n_env][N].
+ * The sampling counter of step t, row i is  offset + *offset_dev + t*n_env*N + i  (advance it afterwards
+ * with tsm_u64_add).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *params, *param_image;
+    int32_t obs_dim, hidden, n_act, mode; /* mode 1 sample, 2 dist.mode */
+    uint64_t policy_seed, offset;
+    const uint64_t *offset_dev;
+    tsm_mpe_cfg env;
+    uint64_t env_seed;
+    uint64_t *episode_ctr;
+    float *agent_pos, *agent_vel, *landmark_pos;
+    int32_t *steps;
+    int32_t auto_reset, n_steps;
+    float *obs_cur_out;
+    void *vrb_state;
+    int64_t sub_size;
+    uint8_t *done_store;
+    float *obs_store, *obs_next_store, *rew_store, *logp_store, *vs_store, *vnext_store;
+    int32_t *act_store;
+    uint8_t *term_store, *trunc_store;
+    int64_t *ptr_out;
+    double *ep_rew_out;
+    int64_t *ep_len_out, *ep_idx_out;
+} tsm_rollout_desc;
+
+int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *stream);
+int tsm_u64_add(uint64_t *counter, uint64_t inc, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * CTDE global state  [a16]
  * Replaces  GlobalStateConstructor.build("concatenate" | "mean")
  *           (tianshou/algorithm/multiagent/ctde.py:291-300) for per-agent arrays [B][D] given in

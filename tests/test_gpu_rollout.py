@@ -1,0 +1,83 @@
+"""GPU tests (`-m gpu`) of the persistent rollout kernel (csrc/rollout.hip): one launch must reproduce,
+bit for bit, the unfused sequence policy_forward -> mpe_step -> vrb_add of the Collector loop, and its extra
+V(obs_next) output must equal a critic pass over the stored obs_next."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+DEV = "cuda"
+
+
+def _job(n_env, N, T, fused, seed=3, slots=None, **ppo_kw):
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=seed)
+    net = DiscreteActorCritic(env.obs_dim, env.n_act, 64, device=DEV, seed=seed)
+    algo = PPO(net=net, seed=seed, **ppo_kw)
+    buf = DeviceVectorReplayBuffer(n_env * (slots or T), n_env, N, env.obs_dim, device=DEV)
+    col = Collector(algo, env, buf, fused_rollout=fused, use_graph=False)
+    col.reset()
+    return env, net, algo, buf, col
+
+
+@pytest.mark.parametrize("n_env,N,T,steps", [(64, 3, 25, 25), (7, 3, 6, 15), (33, 8, 5, 12), (5, 1, 4, 9), (10, 2, 7, 7),
+                                             (1024, 3, 25, 25)])
+def test_fused_rollout_is_bit_identical_to_unfused(n_env, N, T, steps):
+    slots = steps + 3 + 1  # both collects fit without wrap-around
+    outs = []
+    for fused in (False, True):
+        env, net, algo, buf, col = _job(n_env, N, T, fused, slots=slots)
+        assert col._can_fuse() == fused
+        with policy_within_training_step(algo):
+            st1 = col.collect(n_step=n_env * steps)
+            st2 = col.collect(n_step=n_env * 3)  # continues mid-episode, crosses resets for short horizons
+        outs.append(dict(
+            obs=buf.obs_store.clone(), obs_next=buf.obs_next_store.clone(), act=buf.act_store.clone(),
+            rew=buf.rew_store.clone(), trunc=buf.trunc_store.clone(), term=buf.term_store.clone(),
+            logp=buf.logp_store.clone(), vs=buf.vs_store.clone(), done=buf.done_store.clone(),
+            state=buf.index.state.clone(), apos=env.agent_pos.clone(), avel=env.agent_vel.clone(),
+            lpos=env.landmark_pos.clone(), steps=env.steps.clone(), ep=env.episode_ctr.clone(), obs_cur=env.obs_cur.clone(),
+            tick=env.rng_tick.clone(), ret1=st1.returns, len1=st1.lens, n1=st1.n_collected_episodes,
+            ret2=st2.returns, n2=st2.n_collected_episodes))
+        if fused:
+            vnext = buf.vnext_store.clone()
+            # V(obs_next) == a critic pass over the stored obs_next rows (a2c.py:124)
+            n_rows = steps + 3
+            ref = ops.policy_forward(net.flat.data, buf.obs_next_store[:n_rows].reshape(-1, env.obs_dim), 5, 64,
+                                     mode="none")["value"].reshape(n_rows, n_env, N)
+            assert torch.equal(vnext[:n_rows], ref)
+            assert buf.policy_outputs_version == algo.param_version
+        else:
+            assert buf.policy_outputs_version is None
+    a, b = outs
+    for k in a:
+        if isinstance(a[k], torch.Tensor):
+            assert torch.equal(a[k], b[k]), k
+        elif isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+
+
+def test_update_from_stored_rollout_outputs_equals_recomputed():
+    """PPO.update fed by the rollout kernel's stored logp / v_s / V(obs_next) == update that recomputes them."""
+    res = []
+    for fused in (False, True):
+        env, net, algo, buf, col = _job(48, 3, 25, fused, shuffle="numpy", dispatch="per_agent", use_graph=True)
+        np.random.seed(1)
+        for _ in range(3):
+            with policy_within_training_step(algo):
+                col.collect(n_step=48 * 25)
+                st = algo.update(buf, 256, 2)
+            col.reset_buffer(keep_statistics=True)
+        res.append((net.flat.data.clone(), st.get_loss_stats_dict()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1]

@@ -38,6 +38,21 @@ class tsm_mpe_cfg(C.Structure):
                 ("accel", C.c_double), ("max_speed", C.c_double), ("local_ratio", C.c_double)]
 
 
+class tsm_rollout_desc(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("param_image", C.c_void_p),
+                ("obs_dim", C.c_int32), ("hidden", C.c_int32), ("n_act", C.c_int32), ("mode", C.c_int32),
+                ("policy_seed", C.c_uint64), ("offset", C.c_uint64), ("offset_dev", C.c_void_p),
+                ("env", tsm_mpe_cfg), ("env_seed", C.c_uint64), ("episode_ctr", C.c_void_p),
+                ("agent_pos", C.c_void_p), ("agent_vel", C.c_void_p), ("landmark_pos", C.c_void_p),
+                ("steps", C.c_void_p), ("auto_reset", C.c_int32), ("n_steps", C.c_int32),
+                ("obs_cur_out", C.c_void_p), ("vrb_state", C.c_void_p), ("sub_size", C.c_int64),
+                ("done_store", C.c_void_p), ("obs_store", C.c_void_p), ("obs_next_store", C.c_void_p),
+                ("rew_store", C.c_void_p), ("logp_store", C.c_void_p), ("vs_store", C.c_void_p),
+                ("vnext_store", C.c_void_p), ("act_store", C.c_void_p), ("term_store", C.c_void_p),
+                ("trunc_store", C.c_void_p), ("ptr_out", C.c_void_p), ("ep_rew_out", C.c_void_p),
+                ("ep_len_out", C.c_void_p), ("ep_idx_out", C.c_void_p)]
+
+
 _p, _i64, _i32, _f64, _int, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int, C.c_uint64
 
 # name -> (restype, argtypes); must list every function declared in include/tsmarl.h
@@ -86,6 +101,8 @@ SIGNATURES = {
     "tsm_mpe_spread_reset": (_int, [C.POINTER(tsm_mpe_cfg), _u64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "tsm_mpe_spread_step": (_int, [C.POINTER(tsm_mpe_cfg), _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                    _int, _p, _u64, _p]),
+    "tsm_rollout_spread": (_int, [C.POINTER(tsm_rollout_desc), _p]),
+    "tsm_u64_add": (_int, [_p, _u64, _p]),
     "tsm_ppo_update_grid": (_int, [_i64, _i32]),
     "tsm_ppo_finalize_many": (_int, [_p, _i64, _p, _p, _i32, C.POINTER(tsm_ppo_cfg), _p, _p]),
     "tsm_ppo_update_fused": (_int, [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p,

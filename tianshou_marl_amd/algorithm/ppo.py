@@ -60,6 +60,7 @@ class PPO(nn.Module):
         self._cfg = ops.make_ppo_cfg(eps_clip, dual_clip, value_clip, advantage_normalization, vf_coef, ent_coef)
         self._ws: dict = {}
         self._grad_sync = None  # set by parallel.attach_data_parallel
+        self.param_version = 0  # bumped whenever the parameters change (stored rollout outputs become stale)
 
     # the reference collector accepts an Algorithm and uses `.policy` (collector.py:358)
     @property
@@ -177,8 +178,8 @@ class PPO(nn.Module):
         partial = torch.empty(n_blk_max * 4, dtype=torch.float64, device=dev)
         k = 0
         for step in range(repeat):
-            if self.recompute_adv and step > 0:  # ppo.py:174-178
-                pb = self._preprocess_batch(buffer)
+            if self.recompute_adv and step > 0:  # ppo.py:174-178: returns / advantages only, logp_old stays
+                pb = dict(self._preprocess_batch(buffer), logp_old=pb["logp_old"])
             if self.shuffle == "numpy":  # Batch.split draws np.random.permutation (batch.py:1219)
                 perm_local = torch.as_tensor(np.random.permutation(n)).to(dev)
             else:
@@ -204,6 +205,7 @@ class PPO(nn.Module):
                               max_grad_norm=self.max_grad_norm, work=self._adam_work, image=self.net.image,
                               image_map=self.net.image_map)
                 k += 1
+        self.param_version += 1
         s_h = scal.cpu().numpy()  # the only host sync of the update (the reference does 4 .item() per minibatch)
         return A2CTrainingStats(
             loss=SequenceSummaryStats.from_sequence(s_h[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(s_h[:, 1]),
@@ -244,7 +246,8 @@ class PPO(nn.Module):
         groups = list(range(N)) if per_agent else [None]
         n_g = T * B if per_agent else T * L
         bounds = split_bounds(n_g, batch_size or -1, merge_last=True)
-        key = ("graph", id(buffer), T, batch_size, repeat, self.dispatch, self.lr, self.max_grad_norm)
+        stored = buffer.vnext_store is not None and buffer.policy_outputs_version == self.param_version
+        key = ("graph", id(buffer), T, batch_size, repeat, self.dispatch, self.lr, self.max_grad_norm, stored)
         g = self._ws.get(key)
         P, A, H = self.net.flat.data, self.net.n_act, self.net.hidden
         if g is None:
@@ -267,11 +270,21 @@ class PPO(nn.Module):
             act = buffer.act_store[:T].reshape(T * L)
             rew, term, trunc = (x[:T].reshape(T, L) for x in (buffer.rew_store, buffer.term_store, buffer.trunc_store))
 
-            def preprocess():
-                ops.policy_forward(P, obs, A, H, mode="given", act=act, image=self.net.image,
-                                   out=dict(value=w["v_s"].view(-1), logp=w["logp"], logits=None))
-                ops.policy_forward(P, obs_next, A, H, mode="none", image=self.net.image,
-                                   out=dict(value=w["v_next"].view(-1), logits=None))
+            def preprocess(recompute: bool = False):
+                if stored and not recompute:
+                    # logp_old / v_s / V(obs_next) were produced by the rollout kernel with these very parameters
+                    # (bit-identical to recomputing them as a2c.py:121-127 / ppo.py:157-161 do)
+                    w["v_s"].copy_(buffer.vs_store[:T].reshape(T, L))
+                    w["v_next"].copy_(buffer.vnext_store[:T].reshape(T, L))
+                    w["logp"].copy_(buffer.logp_store[:T].reshape(-1))
+                else:
+                    # recompute_advantage refreshes the critic values only; logp_old stays (ppo.py:174-178)
+                    ops.policy_forward(P, obs, A, H, mode="none" if recompute else "given", act=act,
+                                       image=self.net.image,
+                                       out=dict(value=w["v_s"].view(-1), logp=None if recompute else w["logp"],
+                                                logits=None))
+                    ops.policy_forward(P, obs_next, A, H, mode="none", image=self.net.image,
+                                       out=dict(value=w["v_next"].view(-1), logits=None))
                 ops.gae_lanes(w["v_s"], w["v_next"], rew, term, trunc, self.gamma, self.gae_lambda, lanes_per_env=N,
                               out=(w["ret"], w["adv"]))
 
@@ -281,7 +294,7 @@ class PPO(nn.Module):
                 for gi in range(len(groups)):
                     for r in range(repeat):
                         if self.recompute_adv and r > 0:
-                            preprocess()
+                            preprocess(recompute=True)
                         perm = w["perm"][gi, r]
                         if self.advantage_normalization:
                             ops.ppo_adv_stats(w["adv"], w["mb_start"], perm=perm, out=w["stats"][gi, r])
@@ -316,6 +329,7 @@ class PPO(nn.Module):
         g["step_dev"].fill_(self.opt_step)
         g["graph"].replay()
         self.opt_step += g["n_steps"]
+        self.param_version += 1
         s_h = g["scal"].cpu().numpy()
         mk = lambda x: A2CTrainingStats(  # noqa: E731
             loss=SequenceSummaryStats.from_sequence(x[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(x[:, 1]),
@@ -387,6 +401,7 @@ class PPO(nn.Module):
     def load_state_dict(self, sd, *args, **kwargs):
         self.net.flat.data.copy_(sd["flat"])
         self.net.sync_image()
+        self.param_version += 1
         o = sd["_optimizers"][0]
         self.exp_avg.copy_(o["exp_avg"])
         self.exp_avg_sq.copy_(o["exp_avg_sq"])

@@ -1,0 +1,202 @@
+// mlp_tile.h -- f32-MFMA tile engine of the fused actor + critic MLP (shared by mlp_fused.hip and rollout.hip).
+// See mlp_fused.hip for the network definition, parameter layout and the gfx950 mapping.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int R = 16;      // rows per tile
+constexpr int NT = 256;    // threads per workgroup (4 waves)
+constexpr int kMaxJ = 4;   // obs_dim <= 64
+
+struct Dims {
+    int D, A;       // obs dim, n actions
+    int Kp1;        // D rounded up to 4 (L1 k extent)
+    int nJ;         // ceil(D / 16)
+    int ld1;        // 16*nJ + 2
+};
+
+template <int H>
+struct Lay {  // LDS layout in floats
+    static constexpr int ldh = H + 2;       // 66: 2*33
+    static constexpr int ld2 = 2 * H + 2;   // 130: 2*65
+    static constexpr int ldo = 18;          // logits(16) | value | pad
+    int W1, W2a, W2c, W3a, W3c, B1, B2, B3a, B3c, X, H1, H2, OUT, D3, D2, D1, total;
+    __host__ __device__ Lay(const Dims &d, bool bwd) {
+        int o = 0;
+        W1 = o; o += 2 * H * d.ld1;
+        W2a = o; o += H * ldh;
+        W2c = o; o += H * ldh;
+        W3a = o; o += 16 * ldh;
+        W3c = o; o += H;
+        B1 = o; o += 2 * H;
+        B2 = o; o += 2 * H;
+        B3a = o; o += 16;
+        B3c = o; o += 2;
+        o = (o + 3) & ~3;  // weights image [0, X) is a whole number of 16-B words
+        X = o; o += R * d.ld1;
+        H1 = o; o += R * ld2;
+        H2 = o; o += R * ld2;
+        OUT = o; o += R * ldo;
+        D3 = o; o += bwd ? R * ldo : 0;
+        D2 = o; o += bwd ? R * ld2 : 0;
+        D1 = o; o += bwd ? R * ld2 : 0;
+        total = o;
+    }
+};
+
+__device__ __forceinline__ f4 mfma(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// parameter offsets in the flat vector
+template <int H>
+struct POff {
+    int aW1, ab1, aW2, ab2, aW3, ab3, cW1, cb1, cW2, cb2, cW3, cb3, total;
+    __host__ __device__ POff(int D, int A) {
+        int o = 0;
+        aW1 = o; o += H * D; ab1 = o; o += H; aW2 = o; o += H * H; ab2 = o; o += H; aW3 = o; o += A * H; ab3 = o; o += A;
+        cW1 = o; o += H * D; cb1 = o; o += H; cW2 = o; o += H * H; cb2 = o; o += H; cW3 = o; o += H; cb3 = o; o += 1;
+        total = o;
+    }
+};
+
+template <int H>
+__device__ void stage_weights(float *lds, const Lay<H> &ly, const Dims &d, const float *__restrict__ P) {
+    const POff<H> po(d.D, d.A);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 2 * H * d.ld1; e += NT) {  // W1 actor|critic, zero padded
+        const int row = e / d.ld1, c = e - row * d.ld1;
+        float v = 0.f;
+        if (c < d.D) v = row < H ? P[po.aW1 + row * d.D + c] : P[po.cW1 + (row - H) * d.D + c];
+        lds[ly.W1 + e] = v;
+    }
+    for (int e = tid; e < H * ly.ldh; e += NT) {
+        const int row = e / ly.ldh, c = e - row * ly.ldh;
+        lds[ly.W2a + e] = c < H ? P[po.aW2 + row * H + c] : 0.f;
+        lds[ly.W2c + e] = c < H ? P[po.cW2 + row * H + c] : 0.f;
+    }
+    for (int e = tid; e < 16 * ly.ldh; e += NT) {
+        const int row = e / ly.ldh, c = e - row * ly.ldh;
+        lds[ly.W3a + e] = (row < d.A && c < H) ? P[po.aW3 + row * H + c] : 0.f;
+    }
+    for (int e = tid; e < H; e += NT) {
+        lds[ly.W3c + e] = P[po.cW3 + e];
+        lds[ly.B1 + e] = P[po.ab1 + e];
+        lds[ly.B1 + H + e] = P[po.cb1 + e];
+        lds[ly.B2 + e] = P[po.ab2 + e];
+        lds[ly.B2 + H + e] = P[po.cb2 + e];
+    }
+    if (tid < 16) lds[ly.B3a + tid] = tid < d.A ? P[po.ab3 + tid] : 0.f;
+    if (tid == 0) lds[ly.B3c] = P[po.cb3];
+}
+
+// Staging from the padded parameter image kept up to date by tsm_adam_step (img[0 .. ly.X) has exactly the
+// LDS layout W1..B3c incl. zero pads): straight 16-B copies, ~12 independent loads per thread.
+template <int H>
+__device__ __forceinline__ void stage_image(float *lds, const Lay<H> &ly, const float *__restrict__ img) {
+    const float4 *src = reinterpret_cast<const float4 *>(img);
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    const int n4 = ly.X / 4;
+    for (int e = threadIdx.x; e < n4; e += NT) dst[e] = src[e];
+}
+
+// forward of one 16-row tile already staged in lds[ly.X]; leaves H1, H2, OUT (logits | value) in LDS
+template <int H>
+__device__ __forceinline__ void tile_forward(float *lds, const Lay<H> &ly, const Dims &d) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    // ---- L1: [R x D] x W1^T -> H1 (actor cols 0..H-1 | critic cols H..2H-1) ----
+    {
+        f4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_c = {0.f, 0.f, 0.f, 0.f};
+        const float *xa = lds + ly.X + r16 * d.ld1 + kq;
+        const float *wa = lds + ly.W1 + (16 * w + r16) * d.ld1 + kq;
+        const float *wc = lds + ly.W1 + (H + 16 * w + r16) * d.ld1 + kq;
+        for (int k0 = 0; k0 < d.Kp1; k0 += 4) {
+            const float a = xa[k0];
+            acc_a = mfma(a, wa[k0], acc_a);
+            acc_c = mfma(a, wc[k0], acc_c);
+        }
+        const int col = 16 * w + r16;
+        const float ba = lds[ly.B1 + col], bc = lds[ly.B1 + H + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = kq * 4 + r;
+            lds[ly.H1 + row * ly.ld2 + col] = fmaxf(acc_a[r] + ba, 0.f);
+            lds[ly.H1 + row * ly.ld2 + H + col] = fmaxf(acc_c[r] + bc, 0.f);
+        }
+    }
+    __syncthreads();
+    // ---- L2 ----
+    {
+        f4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_c = {0.f, 0.f, 0.f, 0.f};
+        const float *ha = lds + ly.H1 + r16 * ly.ld2 + kq;
+        const float *hc = ha + H;
+        const float *wa = lds + ly.W2a + (16 * w + r16) * ly.ldh + kq;
+        const float *wc = lds + ly.W2c + (16 * w + r16) * ly.ldh + kq;
+#pragma unroll
+        for (int k0 = 0; k0 < H; k0 += 4) {
+            acc_a = mfma(ha[k0], wa[k0], acc_a);
+            acc_c = mfma(hc[k0], wc[k0], acc_c);
+        }
+        const int col = 16 * w + r16;
+        const float ba = lds[ly.B2 + col], bc = lds[ly.B2 + H + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = kq * 4 + r;
+            lds[ly.H2 + row * ly.ld2 + col] = fmaxf(acc_a[r] + ba, 0.f);
+            lds[ly.H2 + row * ly.ld2 + H + col] = fmaxf(acc_c[r] + bc, 0.f);
+        }
+    }
+    __syncthreads();
+    // ---- L3: wave 0 -> logits (MFMA, A padded to 16); wave 1 -> value (VALU dot) ----
+    if (w == 0) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float *ha = lds + ly.H2 + r16 * ly.ld2 + kq;
+        const float *wa = lds + ly.W3a + r16 * ly.ldh + kq;
+#pragma unroll
+        for (int k0 = 0; k0 < H; k0 += 4) acc = mfma(ha[k0], wa[k0], acc);
+        const float b = lds[ly.B3a + r16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[ly.OUT + (kq * 4 + r) * ly.ldo + r16] = acc[r] + b;
+    } else if (w == 1 && lane < R) {
+        const float *hc = lds + ly.H2 + lane * ly.ld2 + H;
+        float s = 0.f;
+        for (int j = 0; j < H; ++j) s = fmaf(hc[j], lds[ly.W3c + j], s);
+        lds[ly.OUT + lane * ly.ldo + 16] = s + lds[ly.B3c];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void load_tile_x(float *lds, int X, const Dims &d, const float *__restrict__ obs,
+                                            const int64_t *__restrict__ perm, int64_t first, int64_t row0,
+                                            int64_t M) {
+    for (int e = threadIdx.x; e < R * d.ld1; e += NT) {
+        const int r = e / d.ld1, c = e - r * d.ld1;
+        float v = 0.f;
+        const int64_t i = row0 + r;
+        if (c < d.D && i < M) {
+            const int64_t src = perm ? perm[i] : first + i;
+            v = obs[src * d.D + c];
+        }
+        lds[X + e] = v;
+    }
+}
+
+static int make_dims(int32_t obs_dim, int32_t hidden, int32_t n_act, Dims *d) {
+    TSM_REQUIRE(hidden == 64, "fused MLP supports hidden == 64 (got %d)", hidden);
+    TSM_REQUIRE(obs_dim >= 1 && obs_dim <= 16 * kMaxJ, "fused MLP supports 1 <= obs_dim <= %d (got %d)", 16 * kMaxJ,
+                obs_dim);
+    TSM_REQUIRE(n_act >= 1 && n_act <= 16, "fused MLP supports 1 <= n_act <= 16 (got %d)", n_act);
+    d->D = obs_dim;
+    d->A = n_act;
+    d->Kp1 = (obs_dim + 3) / 4 * 4;
+    d->nJ = (obs_dim + 15) / 16;
+    d->ld1 = 16 * d->nJ + 2;
+    return TSM_OK;
+}
+
+
+}  // namespace

@@ -1,0 +1,115 @@
+// mpe_dev.h -- device-side simple_spread world step shared by the stand-alone env kernels (mpe.hip) and the
+// persistent rollout kernel (rollout.hip).  Specification and provenance: see mpe.hip (restated from the
+// published PettingZoo-MPE spec; pettingzoo sources are not in the reference tree -> parity unpinned).
+//
+// Everything is formulated per AGENT LANE (one lane = one (env, agent) row) on an env state block that lives
+// in LDS: ap/av/lp = this env's [N][2] positions / velocities / landmark positions.  A world step is
+//   1. mpe_agent_move      (reads the OLD state of all agents, returns the lane's new pos/vel in registers)
+//   --- barrier; lanes write their new pos/vel; barrier ---
+//   2. mpe_landmark_min_dist (lane i covers landmark i) and mpe_local_penalty (collisions of agent i)
+//   --- barrier ---
+//   3. mpe_reward           (folds the landmark terms in landmark order -- same order as a serial loop)
+// Serial sections on a handful of lanes are what a latency-bound step cannot afford: one wave issues a
+// dependent instruction only every ~8 cycles, so the N^2 pair work is spread over N lanes per env.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.h"
+
+constexpr int kMpeMaxN = 8;
+
+struct MpeCfg {
+    int n_env, N, obs_dim, max_cycles;
+    float dt, damping, contact_force, contact_margin, agent_size, landmark_size, accel, max_speed, local_ratio;
+};
+
+__device__ __forceinline__ float mpe_uni_pm1(uint32_t bits) { return tsm_u01(bits) * 2.f - 1.f; }
+
+// Reset of agent/landmark i of env e: positions ~ U(-1, 1)^2, velocity 0.
+// Philox counter = (episode * n_env + e) * 8 + i.
+__device__ __forceinline__ void mpe_reset_agent(const MpeCfg &c, int e, uint64_t seed, uint64_t episode, int i,
+                                                float *ap, float *av, float *lp) {
+    uint32_t r[4];
+    tsm_philox4(seed, (episode * (uint64_t)c.n_env + (uint64_t)e) * 8ull + (uint64_t)i, r);
+    ap[2 * i] = mpe_uni_pm1(r[0]); ap[2 * i + 1] = mpe_uni_pm1(r[1]);
+    lp[2 * i] = mpe_uni_pm1(r[2]); lp[2 * i + 1] = mpe_uni_pm1(r[3]);
+    av[2 * i] = 0.f; av[2 * i + 1] = 0.f;
+}
+
+// Element k of agent i's observation (6N): [vel(2), pos(2), landmarks rel (2N), others rel (2(N-1)), comm 0].
+__device__ __forceinline__ float mpe_obs_elem(const MpeCfg &c, const float *ap, const float *av, const float *lp,
+                                              int i, int k) {
+    const int N = c.N;
+    if (k < 2) return av[2 * i + k];
+    if (k < 4) return ap[2 * i + k - 2];
+    k -= 4;
+    if (k < 2 * N) { const int l = k >> 1, x = k & 1; return lp[2 * l + x] - ap[2 * i + x]; }
+    k -= 2 * N;
+    if (k < 2 * (N - 1)) {
+        int j = k >> 1;
+        const int x = k & 1;
+        if (j >= i) ++j;  // others in increasing index, skipping self
+        return ap[2 * j + x] - ap[2 * i + x];
+    }
+    return 0.f;  // communication channel of silent agents
+}
+
+// New position / velocity of agent i after one step (action force + soft contact forces, summed over the other
+// agents in increasing index; damping; optional speed clamp; explicit Euler).
+__device__ __forceinline__ void mpe_agent_move(const MpeCfg &c, const float *ap, const float *av, int i, int act,
+                                               float &npx, float &npy, float &nvx, float &nvy) {
+    const float px = ap[2 * i], py = ap[2 * i + 1];
+    float fx = (act == 1 ? -1.f : (act == 2 ? 1.f : 0.f)) * c.accel;
+    float fy = (act == 3 ? -1.f : (act == 4 ? 1.f : 0.f)) * c.accel;
+    for (int j = 0; j < c.N; ++j) {
+        if (j == i) continue;
+        // pair force seen from the lower index (a, b) = (min, max): f_a += s*d, f_b -= s*d with d = p_a - p_b
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const float dx = ap[2 * lo] - ap[2 * hi], dy = ap[2 * lo + 1] - ap[2 * hi + 1];
+        const float dist = sqrtf(dx * dx + dy * dy);
+        const float k = c.contact_margin;
+        const float z = -(dist - 2.f * c.agent_size) / k;
+        const float pen = (z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z))) * k;  // logaddexp(0, z) * k
+        const float s = c.contact_force * pen / dist;
+        if (i < j) { fx += s * dx; fy += s * dy; }
+        else { fx -= s * dx; fy -= s * dy; }
+    }
+    nvx = av[2 * i] * (1.f - c.damping) + fx * c.dt;
+    nvy = av[2 * i + 1] * (1.f - c.damping) + fy * c.dt;
+    if (c.max_speed > 0.f) {
+        const float sp = sqrtf(nvx * nvx + nvy * nvy);
+        if (sp > c.max_speed) { nvx = nvx / sp * c.max_speed; nvy = nvy / sp * c.max_speed; }
+    }
+    npx = px + nvx * c.dt;
+    npy = py + nvy * c.dt;
+}
+
+// min over agents of the distance to landmark l (on the NEW positions)
+__device__ __forceinline__ float mpe_landmark_min_dist(const MpeCfg &c, const float *ap, const float *lp, int l) {
+    float m = INFINITY;
+    for (int i = 0; i < c.N; ++i) {
+        const float dx = ap[2 * i] - lp[2 * l], dy = ap[2 * i + 1] - lp[2 * l + 1];
+        m = fminf(m, sqrtf(dx * dx + dy * dy));
+    }
+    return m;
+}
+
+// -1 per other agent that agent i collides with (on the NEW positions)
+__device__ __forceinline__ float mpe_local_penalty(const MpeCfg &c, const float *ap, int i) {
+    float local = 0.f;
+    for (int j = 0; j < c.N; ++j) {
+        if (j != i) {
+            const float dx = ap[2 * i] - ap[2 * j], dy = ap[2 * i + 1] - ap[2 * j + 1];
+            if (sqrtf(dx * dx + dy * dy) < 2.f * c.agent_size) local -= 1.f;
+        }
+    }
+    return local;
+}
+
+// reward of an agent from the per-landmark minima m[0..N) of its env (folded in landmark order) and its penalty
+__device__ __forceinline__ float mpe_reward(const MpeCfg &c, const float *m, float local) {
+    float global = 0.f;
+    for (int l = 0; l < c.N; ++l) global -= m[l];
+    return global * (1.f - c.local_ratio) + local * c.local_ratio;
+}

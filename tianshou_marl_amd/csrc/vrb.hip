@@ -12,28 +12,9 @@
 // Payload storage is time-major SoA: field[(slot * B + env) * row_bytes ...]; a vector step that
 // appends one row to every sub-buffer is therefore a single contiguous, fully coalesced copy.
 #include "common.h"
+#include "vrb_dev.h"
 
 namespace {
-
-struct VrbState {
-    int64_t *ins, *size, *ep_len, *ep_start, *last_index, *lengths;
-    double *ep_return;
-    int64_t *error_flag;
-};
-
-__host__ __device__ inline VrbState vrb_view(void *state, int64_t B, int64_t D) {
-    VrbState s;
-    int64_t *p = reinterpret_cast<int64_t *>(state);
-    s.ins = p;
-    s.size = p + B;
-    s.ep_len = p + 2 * B;
-    s.ep_start = p + 3 * B;
-    s.last_index = p + 4 * B;
-    s.lengths = p + 5 * B;
-    s.ep_return = reinterpret_cast<double *>(p + 6 * B);
-    s.error_flag = p + 6 * B + B * D;
-    return s;
-}
 
 __global__ void vrb_reset_kernel(void *state, int64_t B, int64_t S, int64_t D, int keep_stats,
                                  int init) {
@@ -74,29 +55,8 @@ __global__ __launch_bounds__(256) void vrb_add_kernel(
     if (threadIdx.x < nrow) {
         const int64_t r = r0 + threadIdx.x;
         const int64_t e = ids ? ids[r] : r;
-        const bool d = done[r] != 0;
-        const int64_t cur = s.ins[e];                       // :373
-        int64_t sz = s.size[e] + 1; if (sz > S) sz = S;      // :374
-        int64_t nxt = cur + 1; if (nxt >= S) nxt -= S;       // :375
-        const int64_t elen = s.ep_len[e] + 1;                // :378
-        const int64_t estart = s.ep_start[e];
-        if (estart > sz) atomicExch((unsigned long long *)s.error_flag, 1ull);  // :380-386
-        for (int64_t k = 0; k < D; ++k) {
-            const double acc = s.ep_return[e * D + k] + (double)rew[r * D + k];  // :377
-            ep_rew_out[r * D + k] = d ? acc : 0.0;            // :389-402
-            s.ep_return[e * D + k] = d ? 0.0 : acc;           // :409
-        }
-        ep_len_out[r] = d ? elen : 0;
-        const int64_t off = e * S;
-        ptr_out[r] = cur + off;                               // manager.py:170
-        ep_idx_out[r] = estart + off;                         // manager.py:171
-        s.ins[e] = nxt;
-        s.size[e] = sz;
-        s.ep_len[e] = d ? 0 : elen;
-        s.ep_start[e] = d ? nxt : estart;                     // :409
-        s.last_index[e] = cur + off;                          // manager.py:176
-        s.lengths[e] = sz;                                    // manager.py:177
-        done_store[cur * B + e] = d ? 1 : 0;
+        const int64_t cur = vrb_add_row(s, B, S, D, e, rew + r * D, done[r] != 0, done_store, ptr_out + r,
+                                        ep_rew_out + r * D, ep_len_out + r, ep_idx_out + r);
         s_dst_row[threadIdx.x] = cur * B + e;
     }
     __syncthreads();

@@ -47,6 +47,11 @@ class DeviceVectorReplayBuffer:
         self.trunc_store = z((S, B, N), torch.uint8)
         self.logp_store = z((S, B, N), torch.float32) if store_policy_outputs else None
         self.vs_store = z((S, B, N), torch.float32) if store_policy_outputs else None
+        # V(obs_next) per row, filled by the persistent rollout kernel (a2c.py:124 computes it at update time)
+        self.vnext_store = z((S, B, N), torch.float32) if store_policy_outputs else None
+        # parameter version the stored logp / v_s / v_next of EVERY row were computed with:
+        # "empty" (nothing stored yet), an int version, or None (mixed / incomplete -> the update recomputes them)
+        self.policy_outputs_version = "empty"
         self._arange = torch.arange(self.maxsize, dtype=torch.int64, device=self.device)
 
     # ---- reference attributes ---------------------------------------------------------------
@@ -63,6 +68,12 @@ class DeviceVectorReplayBuffer:
 
     def reset(self, keep_statistics: bool = False) -> None:
         self.index.reset(keep_statistics)
+        self.policy_outputs_version = "empty"
+
+    def mark_policy_outputs(self, version: int) -> None:
+        """Called by the fused rollout after it stored logp / v_s / v_next for every row it added."""
+        cur = self.policy_outputs_version
+        self.policy_outputs_version = version if cur in ("empty", version) else None
 
     # ---- add --------------------------------------------------------------------------------
     def add_device(self, obs, act, rew, terminated, truncated, obs_next=None, logp=None, v_s=None,
@@ -82,6 +93,7 @@ class DeviceVectorReplayBuffer:
             fields.append((logp, self.logp_store))
         if v_s is not None and self.vs_store is not None:
             fields.append((v_s, self.vs_store))
+        self.policy_outputs_version = None  # rows added without V(obs_next): the update recomputes critic passes
         return self.index.add(rew, done, buffer_ids, fields=fields, outs=outs)
 
     def add(self, batch: Batch, buffer_ids=None):

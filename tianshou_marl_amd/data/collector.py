@@ -33,8 +33,9 @@ from .stats import CollectStats
 class Collector:
     def __init__(self, policy, env, buffer: DeviceVectorReplayBuffer | None = None, exploration_noise: bool = False,
                  on_episode_done_hook: Callable | None = None, on_step_hook: Callable | None = None,
-                 raise_on_nan_in_buffer: bool = False, use_graph: bool = True) -> None:
+                 raise_on_nan_in_buffer: bool = False, use_graph: bool = True, fused_rollout: bool = True) -> None:
         self.use_graph = use_graph
+        self.fused_rollout = fused_rollout
         self.policy = getattr(policy, "policy", policy)  # an Algorithm is accepted (collector.py:358)
         self.env = env
         self.env_num = len(env)
@@ -158,7 +159,9 @@ class Collector:
 
             mode = bool(getattr(pol, "deterministic_eval", False) and not getattr(pol, "is_within_training_step", False))
             gkey = ("graph", n_iter, mode, env._pp)
-            if self.use_graph and self._ws.get(("seen", n_iter)):
+            if self._can_fuse():
+                self._rollout_fused(n_iter, ws, mode)  # the whole loop in ONE persistent kernel (csrc/rollout.hip)
+            elif self.use_graph and self._ws.get(("seen", n_iter)):
                 if gkey not in self._ws:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
@@ -180,6 +183,38 @@ class Collector:
         self.collect_episode += n_ep
         return CollectStats.with_autogenerated_stats(returns=rets_h, lens=lens_h, n_collected_episodes=n_ep,
                                                      n_collected_steps=steps)
+
+    def _can_fuse(self) -> bool:
+        env, buf, pol = self.env, self.buffer, self.policy
+        return bool(self.fused_rollout and hasattr(env, "_cfg") and getattr(env, "n_act", 0) == 5
+                    and hasattr(pol, "net") and getattr(pol.net, "hidden", 0) == 64 and buf.vnext_store is not None
+                    and buf.obs_next_store is not None and buf.buffer_num == self.env_num
+                    and self.on_step_hook is None and self.on_episode_done_hook is None)
+
+    def _rollout_fused(self, n_iter: int, ws: dict, deterministic: bool) -> None:
+        import ctypes as C
+
+        from .._abi import call, ptr, stream_ptr, tsm_rollout_desc
+
+        env, buf, pol = self.env, self.buffer, self.policy
+        d = tsm_rollout_desc()
+        d.params, d.param_image = ptr(pol.net.flat.data), ptr(pol.net.image)
+        d.obs_dim, d.hidden, d.n_act, d.mode = env.obs_dim, pol.net.hidden, env.n_act, 2 if deterministic else 1
+        d.policy_seed, d.offset, d.offset_dev = pol.seed & (2**64 - 1), 0, ptr(env.rng_tick)
+        d.env, d.env_seed, d.episode_ctr = env._cfg, env._seed & (2**64 - 1), ptr(env.episode_ctr)
+        d.agent_pos, d.agent_vel, d.landmark_pos = ptr(env.agent_pos), ptr(env.agent_vel), ptr(env.landmark_pos)
+        d.steps, d.auto_reset, d.n_steps = ptr(env.steps), int(env.auto_reset), n_iter
+        d.obs_cur_out = ptr(env.obs_cur)
+        d.vrb_state, d.sub_size, d.done_store = ptr(buf.index.state), buf.sub_size, ptr(buf.done_store)
+        d.obs_store, d.obs_next_store, d.rew_store = ptr(buf.obs_store), ptr(buf.obs_next_store), ptr(buf.rew_store)
+        d.logp_store, d.vs_store, d.vnext_store = ptr(buf.logp_store), ptr(buf.vs_store), ptr(buf.vnext_store)
+        d.act_store, d.term_store, d.trunc_store = ptr(buf.act_store), ptr(buf.term_store), ptr(buf.trunc_store)
+        d.ptr_out, d.ep_rew_out = ptr(ws["ptr"]), ptr(ws["ep_rew"])
+        d.ep_len_out, d.ep_idx_out = ptr(ws["ep_len"]), ptr(ws["ep_idx"])
+        s = stream_ptr()
+        call("tsm_rollout_spread", C.byref(d), s)
+        call("tsm_u64_add", ptr(env.rng_tick), n_iter * self.env_num * buf.n_agent, s)
+        buf.mark_policy_outputs(getattr(pol, "param_version", -1))
 
     def _collect_device_episodes(self, n_episode: int) -> CollectStats:
         env, buf, pol = self.env, self.buffer, self.policy
