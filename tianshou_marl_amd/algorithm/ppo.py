@@ -23,7 +23,7 @@ from torch import nn
 from .. import ops
 from ..data.batch import Batch, split_bounds
 from ..data.buffer import DeviceVectorReplayBuffer
-from ..data.stats import A2CTrainingStats, MapTrainingStats, SequenceSummaryStats
+from ..data.stats import A2CTrainingStats, LazyStats, MapTrainingStats, SequenceSummaryStats
 from ..utils.net import DiscreteActorCritic, RunningMeanStd
 
 
@@ -35,7 +35,8 @@ class PPO(nn.Module):
                  max_grad_norm: float | None = None, gae_lambda: float = 0.95, max_batchsize: int = 256,
                  gamma: float = 0.99, return_scaling: bool = False, deterministic_eval: bool = False,
                  dispatch: Literal["per_agent", "pooled"] = "per_agent",
-                 shuffle: Literal["numpy", "device"] = "numpy", seed: int = 0, use_graph: bool = True) -> None:
+                 shuffle: Literal["numpy", "device"] = "numpy", seed: int = 0, use_graph: bool = True,
+                 async_stats: bool = False) -> None:
         super().__init__()
         assert dual_clip is None or dual_clip > 1.0, f"Dual-clip PPO parameter should greater than 1.0 but got {dual_clip}"
         assert 0.0 <= gae_lambda <= 1.0, f"GAE lambda should be in [0, 1] but got: {gae_lambda}"
@@ -50,6 +51,7 @@ class PPO(nn.Module):
         self.is_within_training_step = False
         self.dispatch, self.shuffle = dispatch, shuffle
         self.use_graph = use_graph
+        self.async_stats = async_stats
         self.seed = int(seed)
         dev = net.flat.device
         self.exp_avg = torch.zeros_like(net.flat.data)
@@ -233,11 +235,15 @@ class PPO(nn.Module):
         self._ws["warm"] = True
 
     def _update_graph(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
-        lens_h = buffer.index.lengths.cpu().numpy()
-        ins_h = buffer.index.insertion_idx.cpu().numpy()
-        T = int(lens_h[0])
-        if T == 0 or not (lens_h == T).all() or not (((ins_h - lens_h) % buffer.sub_size) == 0).all():
-            return None  # ragged / rotated sub-buffers: eager path with explicit index lists
+        T = buffer.host_uniform_len()  # host mirror of the fill level (no device round trip)
+        if T is None:
+            lens_h = buffer.index.lengths.cpu().numpy()
+            ins_h = buffer.index.insertion_idx.cpu().numpy()
+            T = int(lens_h[0])
+            if not (lens_h == T).all() or not (((ins_h - lens_h) % buffer.sub_size) == 0).all():
+                return None  # ragged / rotated sub-buffers: eager path with explicit index lists
+        if T == 0:
+            return None
         if buffer.obs_next_store is None:
             raise ValueError("PPO.update needs a buffer that stores obs_next (ignore_obs_next=False)")
         B, N, D = buffer.buffer_num, buffer.n_agent, buffer.obs_dim
@@ -263,6 +269,7 @@ class PPO(nn.Module):
                                             dtype=torch.int32, device=dev),
                      M_dev=torch.as_tensor([e - s for s, e in bounds] * (len(groups) * repeat), dtype=torch.int64,
                                            device=dev),
+                     agent_off=torch.arange(len(groups), dtype=torch.int64, device=dev).view(-1, 1, 1),
                      step_dev=torch.zeros(1, dtype=torch.int64, device=dev), v_s=f(T, L), v_next=f(T, L),
                      logp=f(T * L), ret=f(T, L), adv=f(T, L), n_steps=n_steps)
             obs = buffer.obs_store[:T].reshape(T * L, D)
@@ -319,26 +326,57 @@ class PPO(nn.Module):
             w["graph"] = graph
             self._ws[key] = g = w
         # fresh permutations for this update (Batch.split draws one per repeat, batch.py:1219)
-        for gi, a in enumerate(groups):
-            for r in range(repeat):
-                if self.shuffle == "numpy":
+        if self.shuffle == "numpy":
+            for gi, a in enumerate(groups):
+                for r in range(repeat):
                     pl = torch.as_tensor(np.random.permutation(n_g)).to(dev)
-                else:
-                    pl = torch.randperm(n_g, device=dev)
-                g["perm"][gi, r].copy_(pl if a is None else pl * N + a)
+                    g["perm"][gi, r].copy_(pl if a is None else pl * N + a)
+        else:  # all permutations of this update in three launches: keys -> segmented argsort -> lane ids
+            keys = torch.rand(len(groups) * repeat, n_g, device=dev)
+            pl = torch.argsort(keys, dim=1).view(len(groups), repeat, n_g)
+            if per_agent:
+                torch.add(pl * N, g["agent_off"], out=g["perm"])
+            else:
+                g["perm"].copy_(pl)
         g["step_dev"].fill_(self.opt_step)
         g["graph"].replay()
         self.opt_step += g["n_steps"]
         self.param_version += 1
-        s_h = g["scal"].cpu().numpy()
-        mk = lambda x: A2CTrainingStats(  # noqa: E731
-            loss=SequenceSummaryStats.from_sequence(x[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(x[:, 1]),
-            vf_loss=SequenceSummaryStats.from_sequence(x[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(x[:, 3]),
-            gradient_steps=len(x))
-        if per_agent:
-            per = len(s_h) // N
-            return MapTrainingStats({f"agent_{a}": mk(s_h[a * per:(a + 1) * per]) for a in range(N)})
-        return mk(s_h)
+        # loss statistics: async D2H into a pinned ring; the host only blocks when the stats are read
+        ring = g.setdefault("ring", [])
+        if len(ring) < 4:
+            ring.append(dict(h=torch.empty(g["scal"].shape, dtype=torch.float32, pin_memory=True),
+                             event=torch.cuda.Event(), pending=None))
+            slot = ring[-1]
+        else:
+            slot = ring[g.get("ring_pos", 0) % 4]
+            g["ring_pos"] = g.get("ring_pos", 0) + 1
+            if slot["pending"] is not None:
+                if self.async_stats:
+                    slot["pending"].expire("training stats were not read within 4 update() calls (async_stats=True)")
+                else:
+                    slot["pending"].resolve()
+        slot["h"].copy_(g["scal"], non_blocking=True)
+        slot["event"].record()
+
+        def build():
+            slot["event"].synchronize()
+            s_h = slot["h"].numpy().copy()
+            slot["pending"] = None
+            mk = lambda x: A2CTrainingStats(  # noqa: E731
+                loss=SequenceSummaryStats.from_sequence(x[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(x[:, 1]),
+                vf_loss=SequenceSummaryStats.from_sequence(x[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(x[:, 3]),
+                gradient_steps=len(x))
+            if per_agent:
+                per = len(s_h) // N
+                return MapTrainingStats({f"agent_{a}": mk(s_h[a * per:(a + 1) * per]) for a in range(N)})
+            return mk(s_h)
+
+        out = LazyStats(build)
+        slot["pending"] = out
+        if not self.async_stats:
+            out.resolve()
+        return out
 
     def update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
         """OnPolicyAlgorithm.update (algorithm_base.py:852-863): raises outside a training step (:610-615)."""

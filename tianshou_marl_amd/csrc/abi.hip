@@ -61,3 +61,8 @@ TSM_EXPORT int tsm_stream_sync(void *stream) {
     TSM_HIP(hipStreamSynchronize(tsm_stream(stream)));
     return TSM_OK;
 }
+
+// diagnostic hook (not part of the public ABI header): device buffer of i64 phase time stamps written by
+// workgroup 0 of the rollout / update kernels when set (tools/stamp_*.py)
+long long *g_tsm_stamps = nullptr;
+extern "C" __attribute__((visibility("default"))) void tsm_debug_set_stamps(long long *p) { g_tsm_stamps = p; }

@@ -25,6 +25,8 @@
 #include "mlp_tile.h"
 #include "philox.h"
 
+extern long long *g_tsm_stamps;  // abi.hip (diagnostics)
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -98,14 +100,45 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
     const float *__restrict__ logp_old, const float *__restrict__ adv, const float *__restrict__ returns,
     const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first, int64_t M,
     const float *__restrict__ adv_stats, LossCfg cfg, float *__restrict__ slabs,
-    double *__restrict__ loss_partial, int64_t *__restrict__ opt_step_dev) {
+    double *__restrict__ loss_partial, int64_t *__restrict__ opt_step_dev, long long *stamps) {
+#define USTAMP(k) do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = (long long)wall_clock64(); } while (0)
     extern __shared__ float lds[];
+    USTAMP(0);
     // device-resident optimizer step count (hipGraph replay): bumped here, read by the Adam kernel that follows
     if (opt_step_dev && blockIdx.x == 0 && threadIdx.x == 0) *opt_step_dev += 1;
     const Lay<H> ly(d, true);
     const POff<H> po(d.D, d.A);
+    const int64_t n_tiles = (M + R - 1) / R;
+    // software pipeline: the dependent gathers (perm -> row id -> obs / act / adv / ...) of the NEXT tile are in
+    // flight while weights are staged / the current tile is computed
+    float xr[kXRegs];
+    struct RowIn { int a_idx; float adv, logp_old, ret, v_old; } rin;
+    auto row_id = [&](int64_t row0) -> int64_t {
+        const int64_t i = row0 + (threadIdx.x >> 4);
+        return i < M ? (perm ? perm[i] : first + i) : -1;
+    };
+    auto prefetch_row = [&](int64_t src) {
+        rin.a_idx = 0; rin.adv = 0.f; rin.logp_old = 0.f; rin.ret = 0.f; rin.v_old = 0.f;
+        if (src >= 0) {
+            rin.a_idx = act[src]; rin.adv = adv[src]; rin.logp_old = logp_old[src]; rin.ret = returns[src];
+            if (cfg.value_clip) rin.v_old = v_s_old[src];
+        }
+    };
+    // order matters (vector memory returns in issue order): row ids first, then the weight image, and the
+    // id-dependent gathers last, so that no round trip is serialised behind another
+    int64_t xs[kXRegs];
+    int64_t rsrc = -1;
+    const bool have_tile = (int64_t)blockIdx.x < n_tiles;
+    if (have_tile) {
+        prefetch_tile_ids(xs, d, perm, first, (int64_t)blockIdx.x * R, M);
+        rsrc = row_id((int64_t)blockIdx.x * R);
+    }
     if (img) stage_image<H>(lds, ly, img);
     else stage_weights<H>(lds, ly, d, P);
+    if (have_tile) {
+        prefetch_tile_vals(xr, xs, obs);
+        prefetch_row(rsrc);
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const float invM = 1.0f / (float)M;
@@ -125,13 +158,16 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
     float g_b3 = 0.f;                       // threads 0..A-1: b3a ; thread 16: b3c
     double s_clip = 0.0, s_vf = 0.0, s_ent = 0.0;  // threads 16*r (one per tile row)
 
-    const int64_t n_tiles = (M + R - 1) / R;
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int64_t row0 = t * R;
         __syncthreads();
-        load_tile_x(lds, ly.X, d, obs, perm, first, row0, M);
+        USTAMP(1);
+        commit_tile_x(lds, ly.X, d, xr);
+        const RowIn cur = rin;
         __syncthreads();
+        USTAMP(2);
         tile_forward<H>(lds, ly, d);
+        USTAMP(3);
 
         // ---- loss head (ppo.py:182-211): 16 lanes per row, lane j owns action j -> D3 = [dlogits(16) | dvalue] ----
         {
@@ -140,7 +176,6 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
             float *d3 = lds + ly.D3 + r * ly.ldo;
             float dl = 0.f, dv = 0.f;
             if (i < M) {  // uniform over the 16 lanes of a row
-                const int64_t src = perm ? perm[i] : first + i;
                 const float *lg = lds + ly.OUT + r * ly.ldo;
                 const bool on = j < d.A;
                 const float x = on ? lg[j] : -INFINITY;
@@ -156,11 +191,11 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
                 float h = on ? -p * l : 0.f;                     // entropy
 #pragma unroll
                 for (int off = 8; off > 0; off >>= 1) h += __shfl_xor(h, off, 64);
-                const int a_idx = act[src];
+                const int a_idx = cur.a_idx;
                 const float logp = __shfl(l, (threadIdx.x & 48) + a_idx, 64);
-                float a = adv[src];
+                float a = cur.adv;
                 if (cfg.adv_norm) a = (a - a_mean) / (a_std + 1e-8f);
-                const float ratio = expf(logp - logp_old[src]);
+                const float ratio = expf(logp - cur.logp_old);
                 const float lo = 1.0f - cfg.eps_clip, hi = 1.0f + cfg.eps_clip;
                 const float rc = fminf(fmaxf(ratio, lo), hi);
                 const float s1 = ratio * a, s2 = rc * a;
@@ -174,10 +209,10 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
                     if (c > obj) { obj = c; g_ratio = 0.f; }
                     else if (c == obj) g_ratio *= 0.5f;
                 }
-                const float v = lg[16], ret = returns[src];
+                const float v = lg[16], ret = cur.ret;
                 float vf, g_v;
                 if (cfg.value_clip) {
-                    const float vs = v_s_old[src];
+                    const float vs = cur.v_old;
                     const float dd = v - vs;
                     const float dc = fminf(fmaxf(dd, -cfg.eps_clip), cfg.eps_clip);
                     const bool v_in = dd >= -cfg.eps_clip && dd <= cfg.eps_clip;
@@ -201,6 +236,11 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
         }
         __syncthreads();
 
+        if (t + gridDim.x < n_tiles) {  // next tile's gathers fly under this tile's backward pass
+            prefetch_tile_x(xr, d, obs, perm, first, (t + gridDim.x) * R, M);
+            prefetch_row(row_id((t + gridDim.x) * R));
+        }
+        USTAMP(4);
         // ---- output-layer gradients + dh2 ----
         {
             // dW3a[i][16w + j] += sum_r dlogits[r][i] * h2a[r][16w + j]
@@ -303,6 +343,7 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
         }
     }
 
+    USTAMP(5);
     // ---- write this workgroup's gradient slab (flat parameter layout) ----
     float *S = slabs + (int64_t)blockIdx.x * po.total;
     const int colq = r16;  // C layout: col = lane & 15, row = kq*4 + r
@@ -344,6 +385,8 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
             loss_partial[4 * blockIdx.x + 3] = 0.0;
         }
     }
+    USTAMP(6);
+#undef USTAMP
 }
 
 __global__ __launch_bounds__(256) void update_finalize_kernel(const double *__restrict__ partial, int n_blocks,
@@ -406,7 +449,10 @@ TSM_EXPORT int64_t tsm_policy_param_count(int32_t obs_dim, int32_t hidden, int32
 TSM_EXPORT int64_t tsm_policy_image_elems(int32_t obs_dim, int32_t hidden, int32_t n_act) {
     Dims d;
     if (make_dims(obs_dim, hidden, n_act, &d)) return -1;
-    return Lay<64>(d, false).X;
+    const Lay<64> ly(d, false);
+    const int64_t padded = (int64_t)image_f4_padded(ly.X) * 4;
+    // the staging copy writes `padded` floats into LDS: must stay inside the smallest kernel layout
+    return padded <= ly.total ? padded : -1;
 }
 
 // map_out_host[i] = offset of flat parameter i inside the padded image (tsm_policy_param_count entries)
@@ -516,7 +562,7 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
     hipLaunchKernelGGL((ppo_update_kernel<64>), dim3((unsigned)n_blocks), dim3(NT), shmem, st, params, param_image, d,
                        obs, act,
                        logp_old, adv, returns, v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out,
-                       loss_partial_out, opt_step_dev);
+                       loss_partial_out, opt_step_dev, g_tsm_stamps);
     TSM_LAUNCH_CHECK();
     if (scalars_out) {
         hipLaunchKernelGGL(update_finalize_kernel, dim3(1), dim3(256), 0, st, loss_partial_out, n_blocks, M,

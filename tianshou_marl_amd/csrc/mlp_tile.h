@@ -93,14 +93,25 @@ __device__ void stage_weights(float *lds, const Lay<H> &ly, const Dims &d, const
     if (tid == 0) lds[ly.B3c] = P[po.cb3];
 }
 
+constexpr int kStageChunk = 4 * 256;  // float4 per full round of the staging loop (4 per thread x NT threads)
+__host__ __device__ inline int image_f4_padded(int x_floats) {
+    return ((x_floats / 4) + kStageChunk - 1) / kStageChunk * kStageChunk;
+}
+
 // Staging from the padded parameter image kept up to date by tsm_adam_step (img[0 .. ly.X) has exactly the
 // LDS layout W1..B3c incl. zero pads): straight 16-B copies, ~12 independent loads per thread.
 template <int H>
 __device__ __forceinline__ void stage_image(float *lds, const Lay<H> &ly, const float *__restrict__ img) {
     const float4 *src = reinterpret_cast<const float4 *>(img);
     float4 *dst = reinterpret_cast<float4 *>(lds);
-    const int n4 = ly.X / 4;
-    for (int e = threadIdx.x; e < n4; e += NT) dst[e] = src[e];
+    // The image is padded to a whole number of kStageChunk float4 (zeros), so every thread copies full groups of
+    // 4 independent 16-B loads with no tail predicate; the copy may run a few KB past ly.X into the activation
+    // buffers, which are (re)written after staging anyway.  Latency-bound: 4 loads in flight per thread.
+    const int n4p = image_f4_padded(ly.X);
+    for (int e = threadIdx.x; e < n4p; e += 4 * NT) {
+        const float4 v0 = src[e], v1 = src[e + NT], v2 = src[e + 2 * NT], v3 = src[e + 3 * NT];
+        dst[e] = v0; dst[e + NT] = v1; dst[e + 2 * NT] = v2; dst[e + 3 * NT] = v3;
+    }
 }
 
 // forward of one 16-row tile already staged in lds[ly.X]; leaves H1, H2, OUT (logits | value) in LDS
@@ -170,19 +181,55 @@ __device__ __forceinline__ void tile_forward(float *lds, const Lay<H> &ly, const
     __syncthreads();
 }
 
+constexpr int kXRegs = (R * (16 * kMaxJ + 2) + NT - 1) / NT;  // X tile elements per thread (worst case)
+
+// Gather one X tile into registers in two phases so that other loads can be issued in between:
+//   phase A  row ids (perm)   -> xs[]      phase B  obs values (dependent on the row ids) -> xr[]
+__device__ __forceinline__ void prefetch_tile_ids(int64_t (&xs)[kXRegs], const Dims &d,
+                                                  const int64_t *__restrict__ perm, int64_t first, int64_t row0,
+                                                  int64_t M) {
+#pragma unroll
+    for (int it = 0; it < kXRegs; ++it) {
+        const int e = threadIdx.x + it * NT;
+        int64_t src = -1;
+        if (e < R * d.ld1) {
+            const int r = e / d.ld1, c = e - r * d.ld1;
+            const int64_t i = row0 + r;
+            if (c < d.D && i < M) src = (perm ? perm[i] : first + i) * d.D + c;
+        }
+        xs[it] = src;
+    }
+}
+
+__device__ __forceinline__ void prefetch_tile_vals(float (&xr)[kXRegs], const int64_t (&xs)[kXRegs],
+                                                   const float *__restrict__ obs) {
+#pragma unroll
+    for (int it = 0; it < kXRegs; ++it) xr[it] = xs[it] >= 0 ? obs[xs[it]] : 0.f;
+}
+
+__device__ __forceinline__ void prefetch_tile_x(float (&xr)[kXRegs], const Dims &d, const float *__restrict__ obs,
+                                                const int64_t *__restrict__ perm, int64_t first, int64_t row0,
+                                                int64_t M) {
+    int64_t xs[kXRegs];
+    prefetch_tile_ids(xs, d, perm, first, row0, M);
+    prefetch_tile_vals(xr, xs, obs);
+}
+
+// ... and commit it to LDS once the previous tile no longer needs the buffer.
+__device__ __forceinline__ void commit_tile_x(float *lds, int X, const Dims &d, const float (&xr)[kXRegs]) {
+#pragma unroll
+    for (int it = 0; it < kXRegs; ++it) {
+        const int e = threadIdx.x + it * NT;
+        if (e < R * d.ld1) lds[X + e] = xr[it];
+    }
+}
+
 __device__ __forceinline__ void load_tile_x(float *lds, int X, const Dims &d, const float *__restrict__ obs,
                                             const int64_t *__restrict__ perm, int64_t first, int64_t row0,
                                             int64_t M) {
-    for (int e = threadIdx.x; e < R * d.ld1; e += NT) {
-        const int r = e / d.ld1, c = e - r * d.ld1;
-        float v = 0.f;
-        const int64_t i = row0 + r;
-        if (c < d.D && i < M) {
-            const int64_t src = perm ? perm[i] : first + i;
-            v = obs[src * d.D + c];
-        }
-        lds[X + e] = v;
-    }
+    float xr[kXRegs];
+    prefetch_tile_x(xr, d, obs, perm, first, row0, M);
+    commit_tile_x(lds, X, d, xr);
 }
 
 static int make_dims(int32_t obs_dim, int32_t hidden, int32_t n_act, Dims *d) {

@@ -23,6 +23,7 @@
 #include "vrb_dev.h"
 
 int tsm_mpe_check_cfg(const tsm_mpe_cfg *h, MpeCfg *c);  // mpe.hip
+extern long long *g_tsm_stamps;                               // abi.hip (diagnostics)
 
 namespace {
 
@@ -302,8 +303,6 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     }
 }
 
-long long *g_stamps = nullptr;
-
 __global__ void u64_add_kernel(uint64_t *p, uint64_t inc) { *p += inc; }
 
 }  // namespace
@@ -341,7 +340,7 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     a.act_store = h.act_store; a.term_store = h.term_store; a.trunc_store = h.trunc_store;
     a.ptr_out = h.ptr_out; a.ep_len_out = h.ep_len_out; a.ep_idx_out = h.ep_idx_out; a.ep_rew_out = h.ep_rew_out;
     a.n_steps = h.n_steps;
-    a.stamps = g_stamps;
+    a.stamps = g_tsm_stamps;
     const Lay<64> ly(a.d, false);
     const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8;
     const size_t shmem = ((size_t)ly.total + extra) * sizeof(float);
@@ -358,5 +357,3 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     return TSM_OK;
 }
 
-// diagnostic hook (not part of the public ABI header): device buffer of >= 32 i64 for phase stamps
-extern "C" __attribute__((visibility("default"))) void tsm_debug_set_stamps(long long *p) { g_stamps = p; }

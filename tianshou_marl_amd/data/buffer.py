@@ -52,6 +52,7 @@ class DeviceVectorReplayBuffer:
         # parameter version the stored logp / v_s / v_next of EVERY row were computed with:
         # "empty" (nothing stored yet), an int version, or None (mixed / incomplete -> the update recomputes them)
         self.policy_outputs_version = "empty"
+        self._host_rows: int | None = 0
         self._arange = torch.arange(self.maxsize, dtype=torch.int64, device=self.device)
 
     # ---- reference attributes ---------------------------------------------------------------
@@ -69,6 +70,20 @@ class DeviceVectorReplayBuffer:
     def reset(self, keep_statistics: bool = False) -> None:
         self.index.reset(keep_statistics)
         self.policy_outputs_version = "empty"
+        self._host_rows = 0
+
+    # host-side mirror of "every sub-buffer received the same number of rows since reset" (saves the update a
+    # device->host round trip just to learn the fill level); None = unknown -> ask the device
+    def note_uniform_rows(self, n: int) -> None:
+        if self._host_rows is not None:
+            self._host_rows += int(n)
+
+    def host_uniform_len(self) -> int | None:
+        """Rows per sub-buffer if all are equally filled and start at slot 0, else None."""
+        h = self._host_rows
+        if h is None or (h > self.sub_size and h % self.sub_size != 0):
+            return None
+        return min(h, self.sub_size)
 
     def mark_policy_outputs(self, version: int) -> None:
         """Called by the fused rollout after it stored logp / v_s / v_next for every row it added."""
@@ -94,6 +109,10 @@ class DeviceVectorReplayBuffer:
         if v_s is not None and self.vs_store is not None:
             fields.append((v_s, self.vs_store))
         self.policy_outputs_version = None  # rows added without V(obs_next): the update recomputes critic passes
+        if buffer_ids is None and rew.shape[0] == self.buffer_num:
+            self.note_uniform_rows(1)
+        else:
+            self._host_rows = None
         return self.index.add(rew, done, buffer_ids, fields=fields, outs=outs)
 
     def add(self, batch: Batch, buffer_ids=None):

@@ -332,6 +332,8 @@ def policy_image(obs_dim: int, hidden: int, n_act: int, device):
     import numpy as np
 
     n_img = call("tsm_policy_image_elems", obs_dim, hidden, n_act)
+    if n_img < 0:  # layout too small for the padded staging copy: kernels re-pack `params` themselves
+        return None, None
     n_par = policy_param_count(obs_dim, hidden, n_act)
     m = np.zeros(n_par, np.int32)
     call("tsm_policy_image_map", obs_dim, hidden, n_act, m.ctypes.data_as(C.c_void_p))
@@ -339,6 +341,8 @@ def policy_image(obs_dim: int, hidden: int, n_act: int, device):
 
 
 def scatter_image(params, image, image_map):
+    if image is None:
+        return None
     call("tsm_scatter_image", ptr(params), params.numel(), ptr(image_map), ptr(image), stream_ptr())
     return image
 
