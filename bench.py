@@ -29,6 +29,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+MFMA_F32_PEAK = 157.3e12  # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix) 157.3 TFLOPS" (f32-input MFMA)
 
 
 def parse():
@@ -92,21 +93,83 @@ def phase_times(a, algo, buf, col, reps=5):
         t_col += e0.elapsed_time(e1)
         t_upd += e1.elapsed_time(e2)
         col.reset_buffer(keep_statistics=True)
-    # dominant-kernel roofline: the GAE scan over the rows of this job, timed alone (avg of 50 launches)
-    T, L = a.horizon, a.n_env * a.n_agent
-    v = torch.randn(T, L, device=buf.device)
-    fl = torch.zeros(T, L, dtype=torch.uint8, device=buf.device)
+    return t_col / reps, t_upd / reps
+
+
+def kernel_rooflines(a, algo, buf):
+    """Live per-launch device time of the two kernels that dominate the step, on this job's own buffers:
+    graph-batched launches bracketed by HIP events on the launch stream (no host gaps inside the bracket)."""
+    from tianshou_marl_amd import ops
+
+    dev = buf.device
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+
+    def per_launch(fn, n=20, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        tot = 0.0
+        for _ in range(reps):
+            e0, e1 = ev(), ev()
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1) * 1e-3 / n
+        return tot / reps
+
+    T, L, D = a.horizon, a.n_env * a.n_agent, 6 * a.n_agent
+    net = algo.net
+    # (1) fused PPO gradient step (forward + loss + backward) on one minibatch of the real rollout rows
+    n = T * L
+    M = min(a.minibatch, n)
+    perm = torch.randperm(n, device=dev)[:M].contiguous()
+    adv = torch.randn(n, device=dev)
+    stats = ops.ppo_adv_stats(adv, torch.tensor([0, M], device=dev), perm=perm)
+    nb = ops.ppo_update_grid(M)
+    slabs = torch.empty(nb, net.flat.numel(), device=dev)
+    partial = torch.empty(nb * 4, dtype=torch.float64, device=dev)
+    obs, act = buf.obs_store[:T].reshape(n, D), buf.act_store[:T].reshape(n)
+    lp, ret = buf.logp_store[:T].reshape(n), torch.randn(n, device=dev)
+    m_, v_ = torch.zeros_like(net.flat.data), torch.zeros_like(net.flat.data)
+    p_ = net.flat.data.clone()
+    img_ = net.image.clone() if net.image is not None else None
+
+    def grad_step():  # exactly the in-situ kernel sequence of one gradient step (cold image / fresh slabs every time)
+        ops.ppo_update_fused(p_, obs, act, lp, adv, ret, algo._cfg, net.n_act, net.hidden, adv_stats=stats[0], perm=perm,
+                             M=M, n_blocks=nb, slabs=slabs, partial=partial, want_scalars=False, image=img_)
+        ops.adam_step(p_, slabs, m_, v_, 1, lr=0.0, image=img_, image_map=net.image_map)
+
+    step_s = per_launch(grad_step)
+    adam_s = per_launch(lambda: ops.adam_step(p_, slabs, m_, v_, 1, lr=0.0, image=img_, image_map=net.image_map))
+    upd_s = step_s - adam_s
+    # (2) GAE scan over the rows of this job
+    v = torch.randn(T, L, device=dev)
+    fl = torch.zeros(T, L, dtype=torch.uint8, device=dev)
     out = (torch.empty_like(v), torch.empty_like(v))
-    for _ in range(5):
-        ops.gae_lanes(v, v, v, fl, fl, out=out)
-    e0, e1 = ev(), ev()
-    e0.record()
-    for _ in range(50):
-        ops.gae_lanes(v, v, v, fl, fl, out=out)
-    e1.record()
-    torch.cuda.synchronize()
-    gae_s = e0.elapsed_time(e1) * 1e-3 / 50
-    return t_col / reps, t_upd / reps, gae_s
+    gae_s = per_launch(lambda: ops.gae_lanes(v, v, v, fl, fl, out=out))
+    H = net.hidden
+    fwd_flop = 2 * (2 * D * H + 2 * H * H + H * net.n_act + H)          # actor + critic forward per sample
+    upd_flop = 3 * fwd_flop * M                                          # forward + 2x backward (SURVEY 8d: ~65 kFLOP)
+    upd_bytes = (4 * D + 16 + 8) * M                                     # obs + act/logp/adv/ret + perm (SURVEY 8d: 88 B)
+    gae_bytes = 22 * T * L                                               # SURVEY 8d: 22 B / sample
+    return {
+        "roofline": {"bound": "mfma", "kernel": "ppo_update_kernel<64> (fused fwd+loss+bwd, f32 MFMA)",
+                     "achieved": upd_flop / upd_s / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": upd_flop / upd_s / MFMA_F32_PEAK, "traffic": None, "flop_per_launch": upd_flop,
+                     "algorithmic_bytes_per_launch": upd_bytes, "hbm_GBps": upd_bytes / upd_s / 1e9,
+                     "us_per_launch": upd_s * 1e6, "rows_per_launch": M,
+                     "how": "graph of 20 x (ppo_update_kernel, adam_kernel) timed with HIP events, minus the same graph "
+                            "of adam_kernel alone", "grad_step_us": step_s * 1e6, "adam_us": adam_s * 1e6},
+        "roofline_gae": {"bound": "hbm", "kernel": "gae_lanes_kernel", "achieved": gae_bytes / gae_s / 1e9,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gae_bytes / gae_s / HBM_PEAK, "traffic": None,
+                         "bytes_per_launch": gae_bytes, "us_per_launch": gae_s * 1e6},
+    }
 
 
 def cpu_baseline(a):
@@ -157,8 +220,9 @@ def main():
     agent_steps = a.n_env * a.n_agent * a.horizon * world
     value = agent_steps / (dt / a.steps)
     if rank == 0:
-        t_col_ms, t_upd_ms, gae_s = phase_times(a, algo, buf, col)
-        gae_bytes = 22 * a.horizon * a.n_env * a.n_agent  # 22 B / sample
+        grad_steps = getattr(ts, "gradient_steps", None) or sum(
+            s.gradient_steps for s in getattr(ts, "_agent_id_to_stats", {}).values())
+        t_col_ms, t_upd_ms = phase_times(a, algo, buf, col)
         out = {
             "metric": "env-steps/sec (n_env x n_agent) incl. PPO update, simple_spread N=%d" % a.n_agent,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -169,12 +233,9 @@ def main():
                        "minibatch": a.minibatch, "repeat": a.repeat, "dispatch": a.dispatch, "parallelism": "env-shard x%d" % world},
             "collect_ms": t_col_ms, "ppo_update_ms": t_upd_ms,
             "collect_env_steps_per_s": a.n_env * a.n_agent * a.horizon / (t_col_ms * 1e-3),
-            "gradient_steps_per_update": getattr(ts, "gradient_steps", None) or sum(
-                s.gradient_steps for s in getattr(ts, "_agent_id_to_stats", {}).values()),
-            "roofline": {"bound": "hbm", "kernel": "gae_lanes_kernel", "achieved": gae_bytes / gae_s / 1e9,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gae_bytes / gae_s / HBM_PEAK, "traffic": None,
-                         "bytes_per_launch": gae_bytes, "us_per_launch": gae_s * 1e6},
+            "gradient_steps_per_update": grad_steps,
         }
+        out.update(kernel_rooflines(a, algo, buf))
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))
