@@ -190,13 +190,17 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # TSM_FORCE_DIST=1 rehearses the N>1 code path (process group, replica broadcast, captured all-reduce) with a
+    # world of ONE rank on a single-GPU box
+    force_dist = os.environ.get("TSM_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
     env, net, algo, buf, col = build_job(a, device, rank)
-    if world > 1:
+    if dist is not None:
         from tianshou_marl_amd.parallel import attach_data_parallel
 
         attach_data_parallel(algo, dist)
@@ -219,10 +223,11 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     agent_steps = a.n_env * a.n_agent * a.horizon * world
     value = agent_steps / (dt / a.steps)
+    grad_steps = getattr(ts, "gradient_steps", None) or sum(
+        s.gradient_steps for s in getattr(ts, "_agent_id_to_stats", {}).values())
+    # every rank runs the phase split: update() contains the gradient all-reduce when N > 1
+    t_col_ms, t_upd_ms = phase_times(a, algo, buf, col)
     if rank == 0:
-        grad_steps = getattr(ts, "gradient_steps", None) or sum(
-            s.gradient_steps for s in getattr(ts, "_agent_id_to_stats", {}).values())
-        t_col_ms, t_upd_ms = phase_times(a, algo, buf, col)
         out = {
             "metric": "env-steps/sec (n_env x n_agent) incl. PPO update, simple_spread N=%d" % a.n_agent,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

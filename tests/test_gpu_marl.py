@@ -1,0 +1,285 @@
+"""GPU tests (`-m gpu`) of the multi-agent host layer on top of the HIP path:
+MultiAgentPolicy / FlexibleMultiAgentPolicyManager dispatch vs the reference fixture, per-agent (independent)
+algorithms through MARLDispatcher, the trainers' `.learn()` on device batches, and the reference-style HOST
+collect loop (DummyVectorEnv of parallel-mode envs = BASELINE configs[0]) feeding the device buffer."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.algorithm.multiagent import (
+        FlexibleMultiAgentPolicyManager,
+        MultiAgentOnPolicyAlgorithm,
+        MultiAgentPolicy,
+        SimultaneousTrainer,
+        agent_batches_from_buffer,
+    )
+    from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
+    from tianshou_marl_amd.data import Batch
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env import DummyVectorEnv, EnhancedPettingZooEnv
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.env.spaces import Box, Discrete
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+class Env:
+    def __init__(self, n):
+        self.agents = [f"agent_{i}" for i in range(n)]
+        self.agent_idx = {a: i for i, a in enumerate(self.agents)}
+
+
+class ArgmaxPolicy(torch.nn.Module if torch.cuda.is_available() else object):
+    """act = argmax(obs @ W): the deterministic mock the fixture was generated with (make_fixtures.py)."""
+
+    def __init__(self, W):
+        super().__init__()
+        self.W = torch.as_tensor(W).to(DEV)
+        self.device = torch.device(DEV)
+        self.calls = 0
+
+    def forward(self, batch, state=None, **kw):
+        self.calls += 1
+        obs = batch.obs.obs if isinstance(batch.obs, Batch) else batch.obs
+        obs = torch.as_tensor(obs).to(DEV, torch.float32)
+        logits = obs @ self.W
+        return Batch(act=logits.argmax(-1), state=None, logits=logits)
+
+
+def test_multiagent_policy_dispatch_matches_reference_fixture():
+    g = np.load(os.path.join(GOLD, "marl_dispatch.npz"))
+    env = Env(3)
+    agent_id = np.array([env.agents[i] for i in g["agent_rows"]], dtype=object)
+    batch = Batch(obs=Batch(agent_id=agent_id, obs=g["obs"]), info=Batch())
+    pols = {a: ArgmaxPolicy(g["Ws"][i]) for i, a in enumerate(env.agents)}
+    res = MultiAgentPolicy(pols, env.agent_idx)(batch)
+    assert np.array_equal(res.act.cpu().numpy(), g["act_independent"])  # bit-exact scatter
+    assert set(res.out.get_keys()) == set(env.agents) and all(p.calls == 1 for p in pols.values())
+    # shared: ONE forward over all rows (flexible_policy.py:202-231)
+    shared = ArgmaxPolicy(g["Ws"][0])
+    res = FlexibleMultiAgentPolicyManager(shared, env, mode="shared")(batch)
+    assert shared.calls == int(g["shared_calls"]) == 1
+    assert np.array_equal(res.act.cpu().numpy(), g["act_shared"])
+    # grouped: policy_map semantics (the reference's own grouped forward yields no act: quirk Q6)
+    assert int(g["grouped_forward_has_act"]) == 0
+    pa, pb = ArgmaxPolicy(g["Ws"][1]), ArgmaxPolicy(g["Ws"][2])
+    mgr = FlexibleMultiAgentPolicyManager({"g0": pa, "g1": pb}, env, mode="grouped",
+                                          agent_groups={"g0": ["agent_0", "agent_1"], "g1": ["agent_2"]})
+    res = mgr(batch)
+    assert np.array_equal(res.act.cpu().numpy(), g["act_grouped_policy_map"])
+    # an agent with no rows gets empty out/state entries and leaves act untouched (marl.py:149-152)
+    only0 = Batch(obs=Batch(agent_id=np.array(["agent_0"] * 4, dtype=object), obs=g["obs"][:4]), info=Batch())
+    res = MultiAgentPolicy(pols, env.agent_idx)(only0)
+    assert res.out.agent_1.is_empty() and res.act.shape == (4,)
+
+
+def _ppo(obs_dim, seed, **kw):
+    return PPO(net=DiscreteActorCritic(obs_dim, 5, 64, device=DEV, seed=seed), seed=seed, **kw)
+
+
+def test_joint_rows_forward_independent_policies():
+    N, D, R = 3, 18, 50
+    env = Env(N)
+    algos = [_ppo(D, 10 + i) for i in range(N)]
+    pol = MultiAgentPolicy({a: algos[i] for i, a in enumerate(env.agents)}, env.agent_idx)
+    assert pol.shared_policy is None
+    obs = torch.randn(R, N, D, device=DEV)
+    for a in algos:
+        a.deterministic_eval = True  # greedy: comparable across calls
+    out = pol(Batch(obs=obs))
+    assert out.act.shape == (R, N) and out.policy.logp.shape == (R, N)
+    for i, a in enumerate(algos):
+        ref = ops.policy_forward(a.net.flat.data, obs[:, i].contiguous(), 5, 64, mode="mode")
+        assert torch.equal(out.act[:, i].to(torch.int32), ref["act"])
+        assert torch.equal(out.policy.v_s[:, i], ref["value"])
+    # parallel-mode observation container (EnhancedPettingZooEnv layout) gives the same rows
+    cont = Batch(observations=Batch({a: obs[:, i].cpu().numpy() for i, a in enumerate(env.agents)}),
+                 agent_ids=np.array([env.agents] * R, dtype=object))
+    out2 = pol(Batch(obs=cont))
+    assert torch.equal(out2.act, out.act)
+
+
+def test_collector_with_shared_manager_equals_plain_ppo():
+    n_env, N, T = 32, 3, 25
+    stores = []
+    for wrap in (False, True):
+        env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=5)
+        algo = _ppo(env.obs_dim, 5)
+        buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=DEV)
+        policy = FlexibleMultiAgentPolicyManager(algo, env, mode="shared") if wrap else algo
+        col = Collector(policy, env, buf, fused_rollout=False, use_graph=False)
+        col.reset()
+        with policy_within_training_step(policy):
+            st = col.collect(n_step=n_env * T)
+        assert st.n_collected_episodes == n_env
+        stores.append((buf.obs_store.clone(), buf.act_store.clone(), buf.rew_store.clone(), buf.logp_store.clone()))
+    for x, y in zip(*stores):
+        assert torch.equal(x, y)
+
+
+def test_independent_algorithms_update_only_on_their_agents_rows():
+    n_env, N, T = 16, 3, 25
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=7)
+
+    def make():
+        return [_ppo(env.obs_dim, 20 + i, use_graph=False, shuffle="numpy") for i in range(N)]
+
+    algos = make()
+    ma = MultiAgentOnPolicyAlgorithm(algorithms=algos, env=env)
+    assert ma.get_algorithm("agent_1") is algos[1] and ma.policy.shared_policy is None
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=DEV)
+    col = Collector(ma, env, buf, use_graph=False)
+    col.reset()
+    with pytest.raises(RuntimeError, match="outside of a training step"):
+        ma.update(buf, 128, 1)
+    with policy_within_training_step(ma):
+        col.collect(n_step=n_env * T)
+        before = [a.net.flat.data.clone() for a in algos]
+        np.random.seed(11)
+        stats = ma.update(buf, batch_size=128, repeat=2)
+    d = stats.get_loss_stats_dict()
+    assert {f"agent_{i}/loss" for i in range(N)} <= set(d) and all(np.isfinite(v) for v in d.values())
+    n_rows, per = n_env * T, 128
+    assert d["agent_0/gradient_steps"] == 2 * (n_rows // per)  # 400 rows -> 3 minibatches (merge_last) x 2 repeats
+    assert all(not torch.equal(b, a.net.flat.data) for b, a in zip(before, algos))
+    # agent 1's algorithm, run alone on agent 1's lanes with the same permutation stream position, gives the same weights
+    ref = make()
+    for r, b in zip(ref, before):
+        r.net.flat.data.copy_(b)
+        r.net.sync_image()
+    np.random.seed(11)
+    for i in range(N):  # same order as the dispatcher: agent_0, agent_1, agent_2
+        with policy_within_training_step(ref[i]):
+            pb = ref[i]._preprocess_batch(buf)
+            ref[i]._update_with_batch(pb, 128, 2, agent=i, buffer=buf)
+    for r, a in zip(ref, algos):
+        assert torch.equal(r.net.flat.data, a.net.flat.data)
+    # checkpoint round trip keyed by agent id
+    sd = ma.state_dict()
+    assert set(sd) == {"agent_0", "agent_1", "agent_2"}
+    algos[0].net.flat.data.zero_()
+    ma.load_state_dict(sd)
+    assert torch.equal(algos[0].net.flat.data, ref[0].net.flat.data)
+
+
+def test_shared_algorithm_through_dispatcher_uses_the_fused_update():
+    n_env, N, T = 16, 3, 25
+    outs = []
+    for wrap in (False, True):
+        env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=9)
+        algo = _ppo(env.obs_dim, 9, shuffle="numpy")
+        top = MultiAgentOnPolicyAlgorithm(algorithms=[algo] * N, env=env) if wrap else algo
+        buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=DEV)
+        col = Collector(top, env, buf)
+        col.reset()
+        with policy_within_training_step(top):
+            col.collect(n_step=n_env * T)
+            np.random.seed(3)
+            top.update(buf, batch_size=200, repeat=1)
+        outs.append(algo.net.flat.data.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_trainers_learn_from_device_agent_batches():
+    n_env, N, T = 8, 3, 25
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=2)
+    algos = {a: _ppo(env.obs_dim, 30 + i, use_graph=False) for i, a in enumerate(env.agents)}
+    mgr = FlexibleMultiAgentPolicyManager(algos, env, mode="independent")
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=DEV)
+    col = Collector(mgr, env, buf, use_graph=False)
+    col.reset()
+    with policy_within_training_step(mgr):
+        col.collect(n_step=n_env * T)
+    batch = agent_batches_from_buffer(buf, env.agents)
+    idx = buf.sample_indices(0)
+    host = buf[idx]
+    assert batch.agent_1.obs.is_cuda and batch.agent_1.obs.shape == (n_env * T, env.obs_dim)
+    assert np.array_equal(batch.agent_1.obs.cpu().numpy(), host.obs[:, 1])
+    assert np.array_equal(batch.agent_2.rew.cpu().numpy(), host.rew[:, 2].astype(np.float32))
+    assert np.array_equal(batch.global_obs.cpu().numpy(), host.obs.reshape(n_env * T, -1))  # "concatenate" global state
+    before = {a: p.net.flat.data.clone() for a, p in algos.items()}
+    tr = SimultaneousTrainer(mgr, agent_train_freq={"agent_2": 2})
+    losses = tr.train_step(batch)
+    assert set(losses) == {"agent_0", "agent_1"} and all(np.isfinite(v["loss"]) for v in losses.values())
+    assert not torch.equal(before["agent_0"], algos["agent_0"].net.flat.data)
+    assert torch.equal(before["agent_2"], algos["agent_2"].net.flat.data)  # trains every 2nd step only
+    tr.train_step(batch)
+    assert not torch.equal(before["agent_2"], algos["agent_2"].net.flat.data)
+
+
+# ---- BASELINE configs[0]: 1-env DummyVectorEnv of a parallel-mode env through the reference-style host loop -------
+class HostSpread:
+    """ParallelEnv-shaped simple_spread on the host (the numpy oracle world; pettingzoo itself is not installed)."""
+
+    metadata = {"name": "simple_spread_host"}
+
+    def __init__(self, n_agent=3, max_cycles=25, seed=0):
+        import sys
+
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+        import mpe_oracle
+
+        self.world = mpe_oracle.SimpleSpreadWorld(n_agent, max_cycles=max_cycles, seed=seed)
+        self.possible_agents = [f"agent_{i}" for i in range(n_agent)]
+        self.observation_spaces = {a: Box(-np.inf, np.inf, (6 * n_agent,)) for a in self.possible_agents}
+        self.action_spaces = {a: Discrete(5) for a in self.possible_agents}
+
+    def _d(self, arr):
+        return {a: arr[i] for i, a in enumerate(self.possible_agents)}
+
+    def reset(self, seed=None, **kw):
+        obs = self.world.reset()
+        return self._d(obs.astype(np.float32)), {a: {} for a in self.possible_agents}
+
+    def step(self, actions):
+        act = np.array([actions[a] for a in self.possible_agents])
+        obs, rew, term, trunc = self.world.step(act)
+        return (self._d(obs.astype(np.float32)), self._d(rew), self._d(np.asarray(term, bool)),
+                self._d(np.asarray(trunc, bool)), {a: {} for a in self.possible_agents})
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("n_env", [1, 3])
+def test_host_collect_loop_with_dummy_vector_env(n_env):
+    N, T = 3, 25
+    venv = DummyVectorEnv([lambda i=i: EnhancedPettingZooEnv(HostSpread(N, T, seed=i), mode="parallel") for i in range(n_env)])
+    algo = _ppo(6 * N, 4)
+    buf = DeviceVectorReplayBuffer(n_env * 2 * T, n_env, N, 6 * N, device=DEV)
+    seen = []
+    col = Collector(algo, venv, buf, on_step_hook=lambda b: seen.append(len(b.rew)))
+    assert not col._device_path
+    col.reset()
+    with policy_within_training_step(algo):
+        st = col.collect(n_step=n_env * T)
+    assert st.n_collected_steps == n_env * T and st.n_collected_episodes == n_env
+    assert st.lens.tolist() == [T] * n_env and len(seen) == T and len(buf) == n_env * T
+    # episode return bookkeeping (HIP) == sum of the stored per-agent rewards
+    host = buf[buf.sample_indices(0)]
+    per_env = host.rew.reshape(n_env, T, N).sum(1)
+    np.testing.assert_allclose(st.returns.reshape(n_env, N), per_env, rtol=1e-6)
+    assert host.truncated.reshape(n_env, T, N)[:, -1].all() and not host.truncated.reshape(n_env, T, N)[:, :-1].any()
+    # obs_next of step t is obs of step t+1 inside an episode
+    o, on = host.obs.reshape(n_env, T, N, -1), host.obs_next.reshape(n_env, T, N, -1)
+    assert np.array_equal(on[:, :-1], o[:, 1:])
+    # stored policy outputs are the ones the policy produced for these rows
+    ref = ops.policy_forward(algo.net.flat.data, torch.as_tensor(host.obs).to(DEV).reshape(-1, 6 * N), 5, 64, mode="given",
+                             act=torch.as_tensor(host.act).to(DEV, torch.int32).reshape(-1))
+    np.testing.assert_allclose(host.policy.logp.reshape(-1), ref["logp"].cpu().numpy(), rtol=1e-6, atol=1e-7)
+    # random collection and n_episode collection run through the same loop
+    with policy_within_training_step(algo):
+        st = col.collect(n_episode=n_env, random=True, reset_before_collect=True)
+    assert st.n_collected_episodes == n_env
+    with policy_within_training_step(algo):
+        stats = algo.update(buf, batch_size=64, repeat=1)
+    assert np.isfinite(list(stats.get_loss_stats_dict().values())).all()

@@ -1,0 +1,132 @@
+"""Batch semantics at the host boundary, after the cases of the reference's
+test/base/test_batch.py that the hot path relies on: construction from dicts / lists of dicts, attribute and
+key access, numpy-style indexing and assignment of every leaf, cat / stack (incl. nested), split with the
+merge_last rule, conversions, emptiness and null checks."""
+import numpy as np
+import pytest
+import torch
+
+from tianshou_marl_amd.data import Batch, to_numpy, to_torch, to_torch_as
+from tianshou_marl_amd.data.batch import split_bounds
+
+
+def test_construction_and_access():
+    b = Batch(a=[1, 2, 3], b={"c": np.zeros((3, 2)), "d": ["x", "y", "z"]}, e=1.5)
+    assert isinstance(b.a, np.ndarray) and b.a.dtype.kind == "i"
+    assert isinstance(b.b, Batch) and b.b.c.shape == (3, 2) and b.b.d.dtype == object
+    assert b["a"] is b.a and "a" in b and "zz" not in b
+    assert set(b.get_keys()) == {"a", "b", "e"} and b.get("zz", 7) == 7
+    with pytest.raises(AttributeError):
+        _ = b.missing
+    b.f = [4.0, 5.0, 6.0]
+    assert b.f.dtype == np.float64
+    assert b.to_dict()["b"]["c"].shape == (3, 2)
+    rows = Batch([{"x": 1, "y": {"z": [0, 1]}}, {"x": 2, "y": {"z": [2, 3]}}])
+    assert rows.x.tolist() == [1, 2] and rows.y.z.shape == (2, 2)
+    assert Batch().is_empty() and Batch(a=Batch()).is_empty(recurse=True) and not Batch(a=Batch()).is_empty()
+
+
+def test_len_shape_and_iteration():
+    b = Batch(a=np.zeros((4, 3)), b=Batch(c=np.zeros((5, 2))), e=Batch())
+    assert len(b) == 4 and b.shape == []  # an empty nested Batch has shape [] and zip() stops there (as upstream)
+    assert Batch(a=np.zeros((4, 3)), b=Batch(c=np.zeros((5, 2)))).shape == [4, 2]  # elementwise min
+    assert [x.a.shape for x in b] == [(3,)] * 4
+    with pytest.raises(TypeError):
+        len(Batch(a=np.float64(1.0)))
+    assert len(Batch()) == 0 and Batch().shape == []
+
+
+def test_indexing_and_assignment():
+    b = Batch(a=np.arange(5), b=Batch(c=np.arange(10.0).reshape(5, 2)), info=Batch())
+    s = b[[0, 2]]
+    assert s.a.tolist() == [0, 2] and s.b.c.tolist() == [[0, 1], [4, 5]] and s.info.is_empty()
+    assert b[1:3].a.tolist() == [1, 2] and b[np.array([True, False, False, False, True])].a.tolist() == [0, 4]
+    assert b[3].a == 3 and b[3].b.c.tolist() == [6.0, 7.0]
+    b[[0, 1]] = Batch(a=np.array([9, 8]), b=Batch(c=np.ones((2, 2))))
+    assert b.a.tolist() == [9, 8, 2, 3, 4] and b.b.c[:2].tolist() == [[1, 1], [1, 1]]
+    b[2] = {"a": 7}  # key missing in the value: that leaf is reset to zero at the index
+    assert b.a[2] == 7 and b.b.c[2].tolist() == [0.0, 0.0]
+    with pytest.raises(ValueError, match="Creating keys"):
+        b[0] = Batch(zzz=1)
+    with pytest.raises(ValueError):
+        b[0] = 3
+    with pytest.raises(IndexError):
+        _ = Batch()[0]
+
+
+def test_cat_and_stack():
+    b1 = Batch(a=np.array([1, 2]), b=Batch(c=np.zeros((2, 3))))
+    b2 = Batch(a=np.array([3]), b=Batch(c=np.ones((1, 3))))
+    c = Batch.cat([b1, b2])
+    assert c.a.tolist() == [1, 2, 3] and c.b.c.shape == (3, 3) and c.b.c[2].tolist() == [1, 1, 1]
+    b1.cat_(b2)
+    assert b1 == c
+    with pytest.raises(ValueError):
+        Batch.cat([Batch(a=[1]), Batch(z=[1])])
+    s = Batch.stack([Batch(a=np.zeros(3), b=Batch(c=1)), Batch(a=np.ones(3), b=Batch(c=2))])
+    assert s.a.shape == (2, 3) and s.b.c.tolist() == [1, 2]
+    s1 = Batch.stack([Batch(a=np.zeros(3)), Batch(a=np.ones(3))], axis=1)
+    assert s1.a.shape == (3, 2)
+    t = Batch.stack([Batch(a=torch.zeros(2)), Batch(a=torch.ones(2))])
+    assert isinstance(t.a, torch.Tensor) and t.a.shape == (2, 2)
+    ragged = Batch.stack([Batch(a=np.zeros(2)), Batch(a=np.zeros(3))])
+    assert ragged.a.dtype == object and len(ragged.a) == 2
+    # key order follows the first batch (never a set): quirk Q5
+    order = Batch.stack([Batch(z=1, a=2, m=3), Batch(m=3, a=2, z=1)])
+    assert list(order.get_keys()) == ["z", "a", "m"]
+
+
+def test_split_merge_last_rule():
+    assert split_bounds(150, 64, merge_last=True) == [(0, 64), (64, 150)]
+    assert split_bounds(150, 64, merge_last=False) == [(0, 64), (64, 128), (128, 150)]
+    assert split_bounds(128, 64, merge_last=True) == [(0, 64), (64, 128)]
+    assert split_bounds(10, -1) == [(0, 10)] and split_bounds(3, 64) == [(0, 3)] and split_bounds(0, 4) == []
+    b = Batch(a=np.arange(10), b=Batch(c=np.arange(10) * 2))
+    parts = list(b.split(4, shuffle=False, merge_last=True))
+    assert [len(p) for p in parts] == [4, 6] and parts[1].b.c.tolist() == [8, 10, 12, 14, 16, 18]
+    parts = list(b.split(4, shuffle=False))
+    assert [len(p) for p in parts] == [4, 4, 2]
+    np.random.seed(0)
+    perm = np.random.permutation(10)
+    np.random.seed(0)
+    got = np.concatenate([p.a for p in b.split(3, shuffle=True)])
+    assert got.tolist() == perm.tolist()  # draws exactly one np.random.permutation (batch.py:1219)
+    assert [len(p) for p in b.split(-1)] == [10]
+
+
+def test_conversions_and_nulls():
+    b = Batch(a=np.arange(3, dtype=np.float64), b=Batch(c=np.array([1, 2, 3])), s=np.array(["x", "y", "z"], dtype=object))
+    t = b.to_torch(dtype=torch.float32)
+    assert t.a.dtype == torch.float32 and t.b.c.dtype == torch.int64 and t.s.dtype == object
+    back = t.to_numpy()
+    assert back.a.dtype == np.float32 and back.b.c.tolist() == [1, 2, 3]
+    b.to_torch_()
+    assert isinstance(b.a, torch.Tensor)
+    b.to_numpy_()
+    assert isinstance(b.a, np.ndarray)
+    assert to_numpy(torch.ones(2)).tolist() == [1, 1] and to_numpy({"k": torch.zeros(1)})["k"].tolist() == [0]
+    assert to_torch(np.ones(2), dtype=torch.float32).dtype == torch.float32
+    assert to_torch_as(np.ones(2), torch.zeros(1, dtype=torch.float64)).dtype == torch.float64
+    with pytest.raises(TypeError):
+        to_torch(np.array(["a"], dtype=object))
+    n = Batch(a=np.array([1.0, np.nan]), b=Batch(c=np.array([None, 1], dtype=object)), i=np.array([1, 2]))
+    assert n.hasnull() and n.isnull().a.tolist() == [False, True] and n.isnull().b.c.tolist() == [True, False]
+    assert not Batch(a=np.zeros(2), t=torch.zeros(2)).hasnull()
+    e = Batch(a=np.ones(3), b=Batch(c=np.ones(3)))
+    e.empty_(1)
+    assert e.a.tolist() == [1, 0, 1] and e.b.c.tolist() == [1, 0, 1]
+    e.empty_()
+    assert e.a.tolist() == [0, 0, 0]
+
+
+def test_equality_update_pickle():
+    import pickle
+
+    a = Batch(x=np.arange(3), y=Batch(z=torch.ones(2)))
+    assert a == Batch(x=np.arange(3), y=Batch(z=torch.ones(2)))
+    assert a != Batch(x=np.arange(3), y=Batch(z=torch.zeros(2))) and a != Batch(x=np.arange(3))
+    a.update(w=[1, 2, 3])
+    a.update({"v": 1})
+    assert a.w.tolist() == [1, 2, 3] and a.v == 1
+    assert pickle.loads(pickle.dumps(a)) == a
+    assert a.pop("v") == 1 and "v" not in a

@@ -1,0 +1,189 @@
+"""Host wrappers: PettingZooEnv (AEC), EnhancedPettingZooEnv (AEC + parallel), DummyVectorEnv.
+
+Modelled on the reference's tests (test/pettingzoo + test/multiagent MinimalEnv mocks): tiny duck-typed
+AEC / Parallel envs, checks of the observation dict formats, reward/flag lists indexed by agent_idx,
+auto mode detection, space validation, vector-env stacking and env_id bookkeeping.
+"""
+import numpy as np
+import pytest
+
+from tianshou_marl_amd.env import DummyVectorEnv, EnhancedPettingZooEnv, PettingZooEnv
+from tianshou_marl_amd.env.enhanced_pettingzoo_env import rows_from_parallel_step
+from tianshou_marl_amd.env.spaces import Box, Discrete
+
+
+class TinyAEC:
+    """Round-robin AEC env: obs = [turn, agent index]; reward of the acting agent = action."""
+
+    def __init__(self, n=3, n_act=4, with_mask=False, horizon=5, uneven_spaces=False):
+        self.possible_agents = [f"agent_{i}" for i in range(n)]
+        self.n_act, self.with_mask, self.horizon, self.uneven = n_act, with_mask, horizon, uneven_spaces
+        self.closed = False
+        self.reset()
+
+    def observation_space(self, agent):
+        if self.uneven and agent == self.possible_agents[-1]:
+            return Box(-1, 1, (3,))
+        return Box(-1, 1, (2,))
+
+    def action_space(self, agent):
+        return Discrete(self.n_act)
+
+    def reset(self, seed=None, **kw):
+        self.t = 0
+        self.k = 0
+        self.agent_selection = self.possible_agents[0]
+        self.rewards = {a: 0.0 for a in self.possible_agents}
+
+    def _obs(self):
+        o = np.array([self.t, self.k], np.float32)
+        if self.with_mask:
+            m = np.zeros(self.n_act, np.int8)
+            m[: self.k + 1] = 1
+            return {"observation": o, "action_mask": m}
+        return o
+
+    def last(self):
+        done = self.t >= self.horizon
+        return self._obs(), self.rewards[self.agent_selection], False, done, {"t": self.t}
+
+    def step(self, action):
+        self.rewards = {a: 0.0 for a in self.possible_agents}
+        self.rewards[self.agent_selection] = float(action)
+        self.k = (self.k + 1) % len(self.possible_agents)
+        if self.k == 0:
+            self.t += 1
+        self.agent_selection = self.possible_agents[self.k]
+
+    def close(self):
+        self.closed = True
+
+    def render(self):
+        return "frame"
+
+
+class TinyParallel:
+    metadata = {"name": "tiny_parallel"}
+
+    def __init__(self, n=3, n_act=4, horizon=3):
+        self.possible_agents = [f"agent_{i}" for i in range(n)]
+        self.observation_spaces = {a: Box(-1, 1, (2,)) for a in self.possible_agents}
+        self.action_spaces = {a: Discrete(n_act) for a in self.possible_agents}
+        self.horizon = horizon
+        self.t = 0
+
+    def reset(self, seed=None, **kw):
+        self.t = 0
+        return {a: np.array([0, i], np.float32) for i, a in enumerate(self.possible_agents)}, {a: {} for a in self.possible_agents}
+
+    def step(self, actions):
+        self.t += 1
+        agents = self.possible_agents
+        # dict order deliberately reversed: consumers must index by agent name, not position (quirk Q5)
+        obs = {a: np.array([self.t, i], np.float32) for i, a in reversed(list(enumerate(agents)))}
+        rew = {a: float(actions[a]) * (i + 1) for i, a in enumerate(agents)}
+        term = {a: False for a in agents}
+        trunc = {a: self.t >= self.horizon for a in agents}
+        if self.t >= self.horizon:  # last agent "dies": no observation any more
+            obs.pop(agents[-1])
+            term[agents[-1]] = True
+        return obs, rew, term, trunc, {a: {} for a in agents}
+
+    def close(self):
+        pass
+
+
+def test_aec_wrapper_formats():
+    env = PettingZooEnv(TinyAEC())
+    assert env.agents == ["agent_0", "agent_1", "agent_2"]
+    assert env.agent_idx == {"agent_0": 0, "agent_1": 1, "agent_2": 2}
+    obs, info = env.reset()
+    assert obs["agent_id"] == "agent_0" and obs["mask"] == [True] * 4
+    np.testing.assert_array_equal(obs["obs"], [0, 0])
+    obs, rew, term, trunc, info = env.step(3)
+    assert obs["agent_id"] == "agent_1"
+    assert rew == [3.0, 0.0, 0.0] and term is False and trunc is False
+    obs, rew, *_ = env.step(2)
+    assert obs["agent_id"] == "agent_2" and rew == [0.0, 2.0, 0.0]
+    env.close()
+    assert env.env.closed and env.render() == "frame"
+
+
+def test_aec_wrapper_action_mask_and_continuous():
+    env = PettingZooEnv(TinyAEC(with_mask=True))
+    obs, _ = env.reset()
+    assert obs["mask"] == [True, False, False, False]
+    obs, *_ = env.step(0)
+    assert obs["mask"] == [True, True, False, False]
+    np.testing.assert_array_equal(obs["obs"], [0, 1])
+
+    class Cont(TinyAEC):
+        def action_space(self, agent):
+            return Box(-1, 1, (2,))
+
+    obs, _ = PettingZooEnv(Cont()).reset()
+    assert set(obs) == {"agent_id", "obs"}  # no mask for non-discrete action spaces
+
+
+def test_aec_wrapper_rejects_uneven_spaces():
+    with pytest.raises(AssertionError, match="Observation spaces"):
+        PettingZooEnv(TinyAEC(uneven_spaces=True))
+
+
+def test_enhanced_auto_detects_mode():
+    assert EnhancedPettingZooEnv(TinyParallel()).mode == "parallel"
+    e = EnhancedPettingZooEnv(TinyAEC())
+    assert e.mode == "aec" and not e.is_parallel and e.num_agents == 3
+    obs, _ = e.reset()
+    assert obs["agent_id"] == "agent_0"  # behaves like the AEC wrapper
+
+
+def test_enhanced_parallel_step_lists_indexed_by_agent():
+    env = EnhancedPettingZooEnv(TinyParallel(), mode="parallel")
+    assert env.is_parallel and env.num_agents == 3 and env.metadata == {"name": "tiny_parallel"}
+    obs, info = env.reset()
+    assert obs["agent_ids"] == env.agents and set(obs["observations"]) == set(env.agents)
+    assert all(obs["masks"][a] == [True] * 4 for a in env.agents)
+    obs, rew, term, trunc, info = env.step(np.array([1, 2, 3]))  # array actions in `agents` order
+    assert rew == [1.0, 4.0, 9.0] and term == [False] * 3 and trunc == [False] * 3
+    rows = rows_from_parallel_step(env.agents, obs)
+    np.testing.assert_array_equal(rows, [[1, 0], [1, 1], [1, 2]])  # agent order, not dict order
+    env.step({"agent_0": 0, "agent_1": 0, "agent_2": 0})
+    obs, rew, term, trunc, _ = env.step([0, 0, 1])
+    assert trunc == [True] * 3 and term == [False, False, True]
+    assert obs["masks"]["agent_2"] == [False] * 4  # dead agent: nothing legal
+    assert "agent_2" not in obs["observations"]
+
+
+def test_dummy_vector_env_contract():
+    venv = DummyVectorEnv([lambda: EnhancedPettingZooEnv(TinyParallel(), mode="parallel") for _ in range(4)])
+    assert len(venv) == 4 and venv.is_async is False
+    assert len(venv.action_space) == 4 and venv.action_space[0] == Discrete(4)
+    obs, info = venv.reset()
+    assert obs.shape == (4,) and obs.dtype == object and info.shape == (4,)
+    act = np.tile(np.array([1, 1, 1]), (4, 1))
+    obs, rew, term, trunc, info = venv.step(act)
+    assert rew.shape == (4, 3) and term.shape == (4, 3) and trunc.dtype == bool
+    assert [i["env_id"] for i in info] == [0, 1, 2, 3]
+    obs, rew, term, trunc, info = venv.step(act[:2], id=[3, 1])
+    assert [i["env_id"] for i in info] == [3, 1]
+    obs, info = venv.reset(env_id=[2])
+    assert obs.shape == (1,)
+    assert venv.get_env_attr("mode", id=1) == ["parallel"]
+    venv.set_env_attr("tag", 7)
+    assert venv.get_env_attr("tag") == [7] * 4
+    assert venv.seed(5) == [None] * 4 and venv.get_env_attr("_seed") == [5, 6, 7, 8]
+    venv.close()
+    with pytest.raises(AssertionError):
+        venv.reset()
+    with pytest.raises(NotImplementedError):
+        DummyVectorEnv([TinyParallel, TinyParallel], wait_num=1)
+
+
+def test_vector_env_aec_rows_stack():
+    venv = DummyVectorEnv([lambda: PettingZooEnv(TinyAEC()) for _ in range(2)])
+    obs, _ = venv.reset()
+    assert [o["agent_id"] for o in obs] == ["agent_0", "agent_0"]
+    obs, rew, term, trunc, info = venv.step([1, 2])
+    assert rew.shape == (2, 3) and rew[:, 0].tolist() == [1.0, 2.0]
+    assert [o["agent_id"] for o in obs] == ["agent_1", "agent_1"]

@@ -1,0 +1,327 @@
+"""Multi-agent training coordination: who learns on which step.
+
+Mirror of /root/reference/tianshou/algorithm/multiagent/training_coordinator.py:
+  `MATrainer`            :19-263   mode switch, sequential round-robin, checkpoint save/load
+  `SimultaneousTrainer`  :266-338  per-agent training frequency, shared-policy handling
+  `SequentialTrainer`    :341-410  explicit agent order / steps per agent, train()/eval() toggling
+  `SelfPlayTrainer`      :413-571  snapshot pool, uniform / latest / prioritized opponent sampling, win-rate EMA
+  `LeaguePlayTrainer`    :574-747  random / elo / win_rate matchmaking, promotion/relegation, Elo update
+All of it is host scheduling -- no numerics live here; every `policy.learn(agent_batch)` it issues lands in
+the HIP update path (algorithm/ppo.py `learn`, algorithm/multiagent/ctde.py `learn`).  `train_step` takes the
+reference's batch format: `batch[agent_id]` = that agent's transitions, optional `global_obs`,
+`global_obs_next` at the top level.  `agent_batches_from_buffer` builds that format straight from the device
+buffer without leaving HBM.
+"""
+from __future__ import annotations
+
+import copy
+from collections import deque
+from typing import Any, Literal
+
+import numpy as np
+import torch
+
+from ...data.batch import Batch
+
+
+def _attach_global(batch: Batch, agent_batch: Batch) -> Batch:
+    for k in ("global_obs", "global_obs_next"):
+        if k in batch:
+            agent_batch[k] = batch[k]
+    return agent_batch
+
+
+class MATrainer:
+    VALID_MODES = ["simultaneous", "sequential", "self_play", "league"]
+
+    def __init__(self, policy_manager, training_mode: Literal["simultaneous", "sequential", "self_play", "league"] = "simultaneous",
+                 **kwargs: Any) -> None:
+        if training_mode not in self.VALID_MODES:
+            raise ValueError(f"Invalid training mode: {training_mode}. Must be one of {self.VALID_MODES}")
+        self.policy_manager = policy_manager
+        self.training_mode = training_mode
+        self.step_count = 0
+        self.kwargs = kwargs
+
+    # ---- shared helpers ----------------------------------------------------------------------------
+    def _policy_of(self, agent_id):
+        pm = self.policy_manager
+        if getattr(pm, "mode", None) == "shared":
+            return pm.policies["shared"]
+        return pm.policies.get(agent_id)
+
+    def _learn(self, agent_id, batch: Batch, with_global: bool = True, set_train: bool = False):
+        agent_batch = batch[agent_id]
+        if with_global:
+            _attach_global(batch, agent_batch)
+        policy = self._policy_of(agent_id)
+        if policy is None:
+            return None
+        if set_train and hasattr(policy, "train"):
+            policy.train()
+        return policy.learn(agent_batch)
+
+    def _init_round_robin(self) -> None:
+        if not hasattr(self, "current_agent_idx"):
+            self.current_agent_idx = 0
+            self.current_agent_steps = 0
+            self.agent_order = sorted(self.policy_manager.policies.keys())
+            self.steps_per_agent = 1
+
+    def _advance_round_robin(self) -> None:
+        self.current_agent_steps += 1
+        if self.current_agent_steps >= self.steps_per_agent:
+            self.current_agent_steps = 0
+            self.current_agent_idx = (self.current_agent_idx + 1) % len(self.agent_order)
+
+    # ---- mode switch (:73-93) ----------------------------------------------------------------------
+    def train_step(self, batch: Batch) -> dict[str, Any]:
+        self.step_count += 1
+        if self.training_mode == "simultaneous":
+            return self._simultaneous_train(batch)
+        if self.training_mode == "sequential":
+            return self._sequential_train(batch)
+        if self.training_mode == "self_play":
+            return self._self_play_train(batch)
+        if self.training_mode == "league":
+            return self._league_train(batch)
+        raise ValueError(f"Unknown training mode: {self.training_mode}")
+
+    def _simultaneous_train(self, batch: Batch) -> dict[str, Any]:
+        losses = {}
+        for agent_id in self.policy_manager.policies:
+            if agent_id in batch:
+                losses[agent_id] = self.policy_manager.policies[agent_id].learn(_attach_global(batch, batch[agent_id]))
+        return losses
+
+    def _sequential_train(self, batch: Batch) -> dict[str, Any]:
+        self._init_round_robin()
+        losses = {}
+        current = self.agent_order[self.current_agent_idx]
+        if current in batch:
+            losses[current] = self.policy_manager.policies[current].learn(_attach_global(batch, batch[current]))
+        self._advance_round_robin()
+        return losses
+
+    def _self_play_train(self, batch: Batch) -> dict[str, Any]:
+        raise NotImplementedError("Use SelfPlayTrainer for self-play training")
+
+    def _league_train(self, batch: Batch) -> dict[str, Any]:
+        raise NotImplementedError("Use LeaguePlayTrainer for league play training")
+
+    def set_training_mode(self, mode: str) -> None:
+        if mode not in self.VALID_MODES:
+            raise ValueError(f"Invalid training mode: {mode}")
+        self.training_mode = mode
+        if mode == "sequential":
+            self._init_round_robin()
+
+    # ---- checkpointing (:205-263) ------------------------------------------------------------------
+    def state_dict(self) -> dict[str, Any]:
+        return {"step_count": self.step_count, "training_mode": self.training_mode}
+
+    def load_state_dict(self, state: dict[str, Any]) -> None:
+        self.step_count = state.get("step_count", 0)
+        self.training_mode = state.get("training_mode", "simultaneous")
+
+    def save_checkpoint(self, path: str) -> None:
+        policies = {a: p.state_dict() for a, p in self.policy_manager.policies.items() if hasattr(p, "state_dict")}
+        torch.save({"trainer_state": self.state_dict(), "policies": policies}, path)
+
+    def load_checkpoint(self, path: str) -> None:
+        ckpt = torch.load(path, weights_only=False)
+        if "trainer_state" in ckpt:
+            self.load_state_dict(ckpt["trainer_state"])
+        for agent_id, sd in ckpt.get("policies", {}).items():
+            policy = self.policy_manager.policies.get(agent_id)
+            if policy is not None and hasattr(policy, "load_state_dict"):
+                policy.load_state_dict(sd)
+
+
+class SimultaneousTrainer(MATrainer):
+    def __init__(self, policy_manager, agent_train_freq: dict[str, int] | None = None,
+                 replay_buffers: dict | None = None, **kwargs: Any) -> None:
+        super().__init__(policy_manager, "simultaneous", **kwargs)
+        self.agent_train_freq = agent_train_freq or {}
+        self.replay_buffers = replay_buffers or {}
+
+    def train_step(self, batch: Batch) -> dict[str, Any]:
+        self.step_count += 1
+        pm = self.policy_manager
+        agents = pm.agents if getattr(pm, "mode", None) == "shared" else list(pm.policies.keys())
+        losses = {}
+        for agent_id in agents:
+            if self.step_count % self.agent_train_freq.get(agent_id, 1) != 0:
+                continue
+            if agent_id in batch:
+                out = self._learn(agent_id, batch, with_global=True, set_train=True)
+                if out is not None:
+                    losses[agent_id] = out
+        return losses
+
+
+class SequentialTrainer(MATrainer):
+    def __init__(self, policy_manager, agent_order: list[str] | None = None, steps_per_agent: int = 1,
+                 **kwargs: Any) -> None:
+        super().__init__(policy_manager, "sequential", **kwargs)
+        self.agent_order = agent_order if agent_order else sorted(policy_manager.policies.keys())
+        self.steps_per_agent = steps_per_agent
+        self.current_agent_idx = 0
+        self.current_agent_steps = 0
+
+    def train_step(self, batch: Batch) -> dict[str, Any]:
+        self.step_count += 1
+        losses = {}
+        current = self.agent_order[self.current_agent_idx]
+        if current in batch:
+            for agent_id, p in self.policy_manager.policies.items():  # learner in train mode, the rest in eval
+                if hasattr(p, "train"):
+                    p.train(agent_id == current)
+            losses[current] = self.policy_manager.policies[current].learn(batch[current])
+        self._advance_round_robin()
+        return losses
+
+
+class SelfPlayTrainer(MATrainer):
+    def __init__(self, policy_manager, main_agent_id: str, snapshot_interval: int = 100, opponent_pool_size: int = 20,
+                 opponent_sampling: Literal["uniform", "prioritized", "latest"] = "uniform", win_rate_window: int = 100,
+                 **kwargs: Any) -> None:
+        super().__init__(policy_manager, "self_play", **kwargs)
+        self.main_agent_id = main_agent_id
+        self.snapshot_interval = snapshot_interval
+        self.opponent_pool_size = opponent_pool_size
+        self.opponent_sampling = opponent_sampling
+        self.win_rate_window = win_rate_window
+        self.opponent_pool: list = []
+        self.opponent_win_rates: dict[int, float] = {}
+        self.win_history: deque = deque(maxlen=win_rate_window)
+
+    def train_step(self, batch: Batch) -> dict[str, Any]:
+        self.step_count += 1
+        losses = {}
+        if self.main_agent_id in batch:
+            policy = self.policy_manager.policies[self.main_agent_id]
+            if hasattr(policy, "train"):
+                policy.train()
+            losses[self.main_agent_id] = policy.learn(batch[self.main_agent_id])
+        if self.step_count % self.snapshot_interval == 0:
+            self._create_snapshot()
+        return losses
+
+    def _create_snapshot(self) -> None:
+        """Frozen copy of the learner joins the opponent pool; the oldest one leaves when the pool is full."""
+        snapshot = copy.deepcopy(self.policy_manager.policies[self.main_agent_id])
+        if hasattr(snapshot, "eval"):
+            snapshot.eval()
+        self.opponent_pool.append(snapshot)
+        if len(self.opponent_pool) > self.opponent_pool_size:
+            self.opponent_win_rates.pop(id(self.opponent_pool.pop(0)), None)
+
+    def _sample_opponent(self):
+        pool = self.opponent_pool
+        if not pool:
+            return None
+        if self.opponent_sampling == "latest":
+            return pool[-1]
+        if self.opponent_sampling == "prioritized" and self.opponent_win_rates:
+            w = np.array([self.opponent_win_rates.get(id(o), 0.5) + 0.1 for o in pool])  # harder = likelier
+            return pool[int(np.random.choice(len(pool), p=w / w.sum()))]
+        return pool[int(np.random.choice(len(pool)))]
+
+    def update_win_rate(self, opponent_id: int, won: bool) -> None:
+        alpha = 0.1  # exponential moving average, start at 0.5
+        prev = self.opponent_win_rates.get(opponent_id, 0.5)
+        self.opponent_win_rates[opponent_id] = alpha * (1.0 if won else 0.0) + (1 - alpha) * prev
+
+    def state_dict(self) -> dict[str, Any]:
+        state = super().state_dict()
+        state.update(opponent_pool_size=len(self.opponent_pool), main_agent_id=self.main_agent_id,
+                     opponent_win_rates=self.opponent_win_rates)
+        return state
+
+    def load_state_dict(self, state: dict[str, Any]) -> None:
+        super().load_state_dict(state)
+        self.main_agent_id = state.get("main_agent_id", self.main_agent_id)
+        self.opponent_win_rates = state.get("opponent_win_rates", {})
+
+
+class LeaguePlayTrainer(MATrainer):
+    def __init__(self, policy_manager, league_size: int = 16, promotion_threshold: float = 0.6,
+                 relegation_threshold: float = 0.4, matchmaking: Literal["random", "elo", "win_rate"] = "random",
+                 games_per_evaluation: int = 10, **kwargs: Any) -> None:
+        super().__init__(policy_manager, "league", **kwargs)
+        self.league_size = league_size
+        self.promotion_threshold = promotion_threshold
+        self.relegation_threshold = relegation_threshold
+        self.matchmaking = matchmaking
+        self.games_per_evaluation = games_per_evaluation
+        self.league = list(policy_manager.policies.keys())
+        self.agent_performance = {agent: 0.5 for agent in self.league}
+        self.elo_ratings = {agent: 1000 for agent in self.league}
+        self.game_count = 0
+        self.match_history: deque = deque(maxlen=100)
+
+    def train_step(self, batch: Batch) -> dict[str, Any]:
+        self.step_count += 1
+        self.game_count += 1
+        losses = {}
+        for agent_id in self._make_match():
+            if agent_id in batch:
+                policy = self.policy_manager.policies[agent_id]
+                if hasattr(policy, "train"):
+                    policy.train()
+                losses[agent_id] = policy.learn(batch[agent_id])
+        if self.game_count % self.games_per_evaluation == 0:
+            self._update_league()
+        return losses
+
+    def _make_match(self) -> list[str]:
+        if len(self.league) < 2:
+            return self.league
+        if self.matchmaking in ("elo", "win_rate"):  # neighbours in the rating order play each other
+            key = self.elo_ratings if self.matchmaking == "elo" else self.agent_performance
+            ranked = sorted(self.league, key=lambda a: key[a])
+            i = np.random.randint(0, len(ranked) - 1)
+            return [ranked[i], ranked[i + 1]]
+        return list(np.random.choice(self.league, size=2, replace=False))
+
+    def _update_league(self) -> tuple[list[str], list[str]]:
+        promoted = [a for a, p in self.agent_performance.items() if p >= self.promotion_threshold]
+        relegated = [a for a, p in self.agent_performance.items()
+                     if p < self.promotion_threshold and p <= self.relegation_threshold]
+        return promoted, relegated
+
+    def update_match_result(self, winner: str, loser: str) -> None:
+        alpha = 0.1
+        self.agent_performance[winner] = alpha + (1 - alpha) * self.agent_performance[winner]
+        self.agent_performance[loser] = (1 - alpha) * self.agent_performance[loser]
+        self._update_elo(winner, loser)
+        self.match_history.append((winner, loser))
+
+    def _update_elo(self, winner: str, loser: str, k: float = 32) -> None:
+        rw, rl = self.elo_ratings[winner], self.elo_ratings[loser]
+        expected_w = 1 / (1 + 10 ** ((rl - rw) / 400))
+        self.elo_ratings[winner] = rw + k * (1 - expected_w)
+        self.elo_ratings[loser] = rl + k * (0 - (1 - expected_w))
+
+
+def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True) -> Batch:
+    """The trainers' batch format straight from the device buffer (no host copy).
+
+    Returns Batch({agent: Batch(obs, act, rew, obs_next, terminated, truncated)}, global_obs, global_obs_next) whose
+    leaves are HBM tensors.  Rows are every stored joint step in env-major order (flat reference index order,
+    `sample_indices(0)`); agent a's rows are column a of the joint rows; the "concatenate" global state of a row
+    is that row's `[N*D]` view (GlobalStateConstructor.build, ctde.py:291-294)."""
+    idx = buffer.index.sample_indices_all()
+    d = buffer.get_device(idx.cpu().numpy())
+    out = Batch()
+    for a, name in enumerate(agents):
+        out[name] = Batch(obs=d["obs"][:, a].contiguous(), act=d["act"][:, a].contiguous().to(torch.int64),
+                          rew=d["rew"][:, a].contiguous(), obs_next=d["obs_next"][:, a].contiguous(),
+                          terminated=d["terminated"][:, a].contiguous().bool(),
+                          truncated=d["truncated"][:, a].contiguous().bool())
+    if global_state:
+        R = d["obs"].shape[0]
+        out["global_obs"] = d["obs"].reshape(R, -1)
+        out["global_obs_next"] = d["obs_next"].reshape(R, -1)
+    return out

@@ -13,6 +13,7 @@ API mirror of the reference's on-policy actor-critic stack:
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Literal
 
@@ -62,6 +63,8 @@ class PPO(nn.Module):
         self._cfg = ops.make_ppo_cfg(eps_clip, dual_clip, value_clip, advantage_normalization, vf_coef, ent_coef)
         self._ws: dict = {}
         self._grad_sync = None  # set by parallel.attach_data_parallel
+        # N>1: capture the per-step gradient all-reduce (RCCL) inside the update hipGraph (TSM_GRAPH_COLLECTIVES=0: eager)
+        self.graph_collectives = os.environ.get("TSM_GRAPH_COLLECTIVES", "1") != "0"
         self.param_version = 0  # bumped whenever the parameters change (stored rollout outputs become stale)
 
     # the reference collector accepts an Algorithm and uses `.policy` (collector.py:358)
@@ -87,7 +90,11 @@ class PPO(nn.Module):
     def forward(self, batch: Batch, state=None, **kwargs) -> Batch:
         """reinforce.py:167-192: Batch(logits, act, state, ...) for `batch.obs` (array [B, D] or Batch(obs=...))."""
         obs = batch.obs
-        if isinstance(obs, Batch) and "obs" in obs:  # MARL wrappers hand over obs.obs (marl.py:157-161)
+        if isinstance(obs, Batch) and "observations" in obs:  # parallel-mode joint rows -> [R, N, D] in agent order
+            from ..data.buffer import _obs_array
+
+            obs = _obs_array(obs)
+        elif isinstance(obs, Batch) and "obs" in obs:  # MARL wrappers hand over obs.obs (marl.py:157-161)
             obs = obs.obs
         obs_t = torch.as_tensor(np.asarray(obs) if not isinstance(obs, torch.Tensor) else obs).to(self.device, torch.float32)
         lead = obs_t.shape[:-1]
@@ -271,7 +278,7 @@ class PPO(nn.Module):
                                            device=dev),
                      agent_off=torch.arange(len(groups), dtype=torch.int64, device=dev).view(-1, 1, 1),
                      step_dev=torch.zeros(1, dtype=torch.int64, device=dev), v_s=f(T, L), v_next=f(T, L),
-                     logp=f(T * L), ret=f(T, L), adv=f(T, L), n_steps=n_steps)
+                     logp=f(T * L), ret=f(T, L), adv=f(T, L), n_steps=n_steps, flat_g=f(P.numel()))
             obs = buffer.obs_store[:T].reshape(T * L, D)
             obs_next = buffer.obs_next_store[:T].reshape(T * L, D)
             act = buffer.act_store[:T].reshape(T * L)
@@ -312,7 +319,12 @@ class PPO(nn.Module):
                                                  v_s_old=w["v_s"].view(-1) if self.value_clip else None, perm=perm[s:e], image=self.net.image,
                                                  M=e - s, n_blocks=nb, slabs=w["slabs"][:nb], partial=w["partial"][k],
                                                  want_scalars=False, opt_step_dev=w["step_dev"])
-                            ops.adam_step(P, w["slabs"][:nb], self.exp_avg, self.exp_avg_sq, 1, lr=self.lr,
+                            grads = w["slabs"][:nb]
+                            if self._grad_sync is not None:  # env-sharded replicas: one captured RCCL all-reduce
+                                ops.reduce_slabs(grads, out=w["flat_g"])
+                                self._grad_sync.all_reduce_mean_(w["flat_g"])
+                                grads = w["flat_g"].view(1, -1)
+                            ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, 1, lr=self.lr,
                                           betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
                                           max_grad_norm=self.max_grad_norm, work=self._adam_work,
                                           step_dev=w["step_dev"], image=self.net.image, image_map=self.net.image_map)
@@ -321,8 +333,21 @@ class PPO(nn.Module):
                 ops.ppo_finalize_many(w["partial"], nb_max * 4, w["nb_dev"], w["M_dev"], self._cfg, w["scal"])
 
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                body()
+            if self._grad_sync is not None:
+                # every rank captures the same collective sequence; a failed capture falls back to eager launches
+                try:
+                    with torch.cuda.graph(graph):
+                        body()
+                except Exception as e:  # noqa: BLE001
+                    import warnings
+
+                    warnings.warn(f"capturing the all-reduce into the update graph failed ({e!r}); using eager launches",
+                                  stacklevel=2)
+                    self.graph_collectives = False
+                    return None
+            else:
+                with torch.cuda.graph(graph):
+                    body()
             w["graph"] = graph
             self._ws[key] = g = w
         # fresh permutations for this update (Batch.split draws one per repeat, batch.py:1219)
@@ -386,7 +411,7 @@ class PPO(nn.Module):
                 "wrap the call in `policy_within_training_step(policy)` (tianshou/utils/torch_utils.py:31-46)")
         t0 = time.time()
         self.net.sync_image()  # `flat` may have been written from outside (load_state_dict, broadcast, tests)
-        if self.use_graph and self._grad_sync is None and not self.return_scaling:
+        if self.use_graph and (self._grad_sync is None or self.graph_collectives) and not self.return_scaling:
             out = self._update_graph(buffer, batch_size, repeat)
             if out is not None:
                 out.train_time = time.time() - t0
@@ -411,7 +436,8 @@ class PPO(nn.Module):
         """One PPO pass on an explicit agent batch holding obs, act, rew, obs_next, terminated[, truncated].
         Rows are one time-ordered lane (the reference's per-agent Batch); GAE treats the last row as end."""
         dev = self.device
-        t = lambda x, dt: torch.as_tensor(np.asarray(x)).to(dev, dt)  # noqa: E731
+        t = lambda x, dt: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))).to(dev, dt).contiguous()  # noqa: E731
+        self.net.sync_image()
         obs = t(batch.obs, torch.float32)
         n = obs.shape[0]
         act = t(batch.act, torch.int32).reshape(n)

@@ -30,6 +30,11 @@ def _parse_value(v):
         return v
     if isinstance(v, dict):
         return Batch(v)
+    if isinstance(v, np.ndarray) and v.dtype == object and v.ndim == 1 and len(v) > 0 and all(
+            isinstance(e, (dict, Batch)) for e in v):
+        # an object array of per-env dicts (what a vector env returns for dict observations / infos,
+        # venvs.py:227-232) becomes one Batch of stacked leaves, as in the reference (batch.py:300-318)
+        return Batch.stack([e if isinstance(e, Batch) else Batch(e) for e in v])
     if isinstance(v, (np.ndarray, torch.Tensor)):
         return v
     if v is None:
@@ -132,7 +137,8 @@ class Batch:
                 else:
                     v[index] = value[k]
             elif isinstance(v, Batch):
-                pass
+                if len(v.__dict__):  # missing nested key: every leaf below is reset at the index
+                    v[index] = Batch()
             else:  # missing key: reset to the "zero" of that leaf (batch.py:795-802)
                 v[index] = None if (isinstance(v, np.ndarray) and v.dtype == object) else 0
 

@@ -19,35 +19,7 @@ import numpy as np
 import torch
 
 from .._abi import call, ptr, stream_ptr, tsm_mpe_cfg
-
-
-class Discrete:
-    """Minimal stand-in for gymnasium.spaces.Discrete (gymnasium is not a dependency of the hot path)."""
-
-    def __init__(self, n: int) -> None:
-        self.n = int(n)
-        self.shape = ()
-        self.dtype = np.int64
-
-    def sample(self) -> int:
-        return int(np.random.randint(self.n))
-
-    def __eq__(self, o) -> bool:
-        return isinstance(o, Discrete) and o.n == self.n
-
-    def __repr__(self) -> str:
-        return f"Discrete({self.n})"
-
-
-class Box:
-    def __init__(self, low, high, shape, dtype=np.float32) -> None:
-        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
-
-    def __eq__(self, o) -> bool:
-        return isinstance(o, Box) and o.shape == self.shape
-
-    def __repr__(self) -> str:
-        return f"Box({self.low}, {self.high}, {self.shape})"
+from .spaces import Box, Discrete
 
 
 class DeviceSimpleSpreadVectorEnv:
