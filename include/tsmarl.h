@@ -354,6 +354,46 @@ int tsm_u64_add(uint64_t *counter, uint64_t inc, void *stream);
 int tsm_global_state(const float *const *obs_by_agent_host, int32_t n_agent, int64_t B, int32_t D,
                      int mode, float *out, void *stream);
 
+/* CTDEPolicy.learn loss head  [a16]
+ * Replaces  the TD target / critic MSE / policy-gradient arithmetic of CTDEPolicy.learn
+ *           (tianshou/algorithm/multiagent/ctde.py:149-185) between the network forwards and `backward()`.
+ * q, q_next [B][n_out]: centralized critic on global_obs / global_obs_next (mean over n_out = the value, :154-157);
+ * logits [B][n_act]: decentralized actor on the local obs; act i64 [B].  The (B,) x (B,1) broadcast of :185 is kept
+ * (actor_loss = -mean(log_probs) * mean(advantage), quirk Q7).  Outputs: dq [B][n_out] = d critic_loss / d q,
+ * dlogits [B][n_act] = d actor_loss / d logits, scalars[2] = {actor_loss, critic_loss}.
+ * partial: tsm_ctde_head_partial_elems(B) doubles of scratch. */
+int64_t tsm_ctde_head_partial_elems(int64_t B);
+int tsm_ctde_td_head(const float *q, const float *q_next, int32_t n_out, const float *rew,
+                     const uint8_t *terminated, float gamma, const float *logits, const int64_t *act,
+                     int32_t n_act, int64_t B, float *dq, float *dlogits, double *partial, float *scalars,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fully-connected networks of arbitrary width (f32 MFMA tiled GEMMs)  [a7, a16]
+ * Replaces  nn.Linear / activation stacks and autograd through them for actor / critic modules that do not fit
+ *           the fused 64-wide kernels: DecentralizedActor.forward (ctde.py:366-379), CentralizedCritic.forward
+ *           (ctde.py:402-414), MLP (tianshou/utils/net/common.py:67-160), and `loss.backward()` (ctde.py:188-194).
+ * params: flat f32 vector in torch `parameters()` order  w0[dims[1]][dims[0]], b0[dims[1]], w1, b1, ...
+ * `act` (1 relu, 2 tanh, 0 none) follows every layer except the last.
+ * tsm_mlp_forward : acts = consecutive blocks [B][dims[1]], [B][dims[2]], ... (the last block is the output);
+ *                   tsm_mlp_act_elems(desc, B) floats.
+ * tsm_mlp_backward: d_out [B][dims[L]] = gradient w.r.t. the output; writes n_split gradient slabs
+ *                   slabs[n_split][n_param] (batch split; sum them with tsm_adam_step / tsm_reduce_slabs);
+ *                   d_acts: workspace of tsm_mlp_act_elems floats (hidden-layer gradients).
+ * ------------------------------------------------------------------------------------------- */
+#define TSM_MLP_MAX_LAYERS 8
+typedef struct tsm_mlp_desc {
+    int32_t n_layers;
+    int32_t act;
+    int32_t dims[TSM_MLP_MAX_LAYERS + 1];
+} tsm_mlp_desc;
+int64_t tsm_mlp_param_count(const tsm_mlp_desc *desc);
+int64_t tsm_mlp_act_elems(const tsm_mlp_desc *desc, int64_t B);
+int tsm_mlp_forward(const tsm_mlp_desc *desc, const float *params, const float *x, int64_t B, float *acts,
+                    void *stream);
+int tsm_mlp_backward(const tsm_mlp_desc *desc, const float *params, const float *x, int64_t B, const float *acts,
+                     const float *d_out, float *d_acts, int32_t n_split, float *slabs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

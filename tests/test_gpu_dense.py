@@ -1,0 +1,235 @@
+"""GPU tests (`-m gpu`) of the generic fully-connected engine (csrc/dense.hip) and the CTDE update built on it.
+
+Forward / dgrad / wgrad are compared with a float64 torch autograd replica of the same network (tolerance 1e-5
+relative to the tensor's scale, the north star's bar); the CTDE step is compared with the reference's own outputs
+(tests/golden/ctde.npz: logits, both losses, every gradient, every post-Adam weight)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.algorithm.multiagent import (
+        CentralizedCritic,
+        CTDEPolicy,
+        DecentralizedActor,
+        GlobalStateConstructor,
+        SimultaneousTrainer,
+        FlexibleMultiAgentPolicyManager,
+        agent_batches_from_buffer,
+    )
+    from tianshou_marl_amd.data import Batch
+    from tianshou_marl_amd.utils.net import FlatAdam, FlatMLP
+
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _torch_replica(net, dtype=torch.float64):
+    layers = []
+    for i in range(net.n_layers):
+        lin = torch.nn.Linear(net.dims[i], net.dims[i + 1]).to(dtype)
+        with torch.no_grad():
+            lin.weight.copy_(net.weight(i).cpu().to(dtype))
+            lin.bias.copy_(net.bias(i).cpu().to(dtype))
+        layers.append(lin)
+        if i + 1 < net.n_layers:
+            layers.append({"relu": torch.nn.ReLU(), "tanh": torch.nn.Tanh()}[net.act])
+    return torch.nn.Sequential(*layers)
+
+
+def _close(got, want, tol=1e-5):
+    want = want.to(torch.float64)
+    scale = max(float(want.abs().max()), 1e-30)
+    err = float((got.cpu().to(torch.float64) - want).abs().max())
+    assert err <= tol * scale, f"max abs err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("dims,act,B,n_split", [
+    ([6, 16, 16, 5], "relu", 32, 1),          # the CTDE fixture's actor
+    ([18, 16, 16, 3], "relu", 32, 2),
+    ([18, 64, 64, 5], "tanh", 100, 0),        # the fused kernels' shape, through the generic path
+    ([48, 128, 128, 5], "relu", 777, 3),      # C3 actor (ragged batch, K not a multiple of 16)
+    ([384, 128, 128, 8], "relu", 1030, 5),    # C3 centralized critic: 8 agents x 48
+    ([7, 33, 5], "tanh", 65, 2),              # odd everything, 2 layers
+    ([5, 3], "relu", 1, 1),                   # single linear layer, single row
+    ([130, 257, 70, 66, 2], "relu", 300, 4),  # 4 layers, dims straddling tile edges
+])
+def test_mlp_forward_backward_match_float64_autograd(dims, act, B, n_split):
+    torch.manual_seed(sum(dims) + B)
+    net = FlatMLP(dims, act=act, device=DEV, seed=1)
+    x = torch.randn(B, dims[0], device=DEV)
+    d_out = torch.randn(B, dims[-1], device=DEV)
+    out = net(x)
+    ref = _torch_replica(net)
+    xr = x.cpu().double()
+    out_ref = ref(xr)
+    _close(out, out_ref.detach())
+    slabs = net.backward(d_out, n_split=n_split)
+    assert slabs.shape[1] == net.flat.numel() and (n_split == 0 or slabs.shape[0] == n_split)
+    (out_ref * d_out.cpu().double()).sum().backward()
+    grad = ops.reduce_slabs(slabs)
+    lins = [m for m in ref if isinstance(m, torch.nn.Linear)]
+    for (gw, gb), lin in zip(net.layer_views(grad), lins):
+        _close(gw, lin.weight.grad)
+        _close(gb, lin.bias.grad)
+    # the forward output is reproducible and independent of what else is in the batch (row-local)
+    out2 = net(x[: max(1, B // 2)], save=False)
+    assert torch.equal(out2, out[: max(1, B // 2)])
+
+
+def test_mlp_large_batch_and_descriptor_checks():
+    net = FlatMLP([18, 64, 64, 1], act="tanh", device=DEV, seed=2)
+    x = torch.randn(76800, 18, device=DEV)  # bench-sized batch: 1200 row tiles
+    out = net(x, save=False)
+    _close(out, _torch_replica(net)(x.cpu().double()).detach())
+    with pytest.raises(ValueError, match="input width"):
+        net(torch.zeros(4, 17, device=DEV))
+    with pytest.raises(ValueError):
+        ops.mlp_desc([4] * 11)
+    with pytest.raises(RuntimeError, match="before forward"):
+        FlatMLP([4, 2], device=DEV).backward(torch.zeros(1, 2, device=DEV))
+
+
+def test_flat_adam_matches_torch_adam():
+    net = FlatMLP([6, 16, 4], device=DEV, seed=3)
+    ref = _torch_replica(net, torch.float32)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=2e-3)
+    opt = FlatAdam(net, lr=2e-3)
+    x = torch.randn(50, 6, device=DEV)
+    for step in range(3):
+        d = torch.randn(50, 4, device=DEV)
+        net(x)
+        opt.step(net.backward(d))
+        opt_ref.zero_grad()
+        (ref(x.cpu()) * d.cpu()).sum().backward()
+        opt_ref.step()
+    lins = [m for m in ref if isinstance(m, torch.nn.Linear)]
+    for i, lin in enumerate(lins):
+        np.testing.assert_allclose(net.weight(i).cpu().numpy(), lin.weight.detach().numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(net.bias(i).cpu().numpy(), lin.bias.detach().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def _fixture_policy(g):
+    actor = DecentralizedActor(6, 5, hidden_dim=16, device=DEV)
+    critic = CentralizedCritic(18, 3, hidden_dim=16, device=DEV)
+    actor.load_layers([(g[f"actor_w{i}"], g[f"actor_b{i}"]) for i in range(3)])
+    critic.load_layers([(g[f"critic_w{i}"], g[f"critic_b{i}"]) for i in range(3)])
+    return CTDEPolicy(actor=actor, critic=critic, optim_actor=FlatAdam(actor, lr=1e-3), optim_critic=FlatAdam(critic, lr=1e-3),
+                      discount_factor=0.99), actor, critic
+
+
+def test_ctde_learn_matches_reference_fixture():
+    g = np.load(os.path.join(GOLD, "ctde.npz"))
+    pol, actor, critic = _fixture_policy(g)
+    fwd = pol(Batch(obs=g["b_obs"]))
+    np.testing.assert_allclose(fwd.act.cpu().numpy(), g["fwd_act_logits"], rtol=1e-5, atol=1e-6)
+    batch = Batch(obs=g["b_obs"], act=g["b_act"], rew=g["b_rew"], obs_next=g["b_obs_next"], terminated=g["b_terminated"],
+                  global_obs=g["b_global_obs"], global_obs_next=g["b_global_obs_next"])
+    # gradients first (same inputs, before the optimizer moves anything)
+    obs = torch.as_tensor(g["b_obs"]).to(DEV)
+    q_next = critic(torch.as_tensor(g["b_global_obs_next"]).to(DEV), save=False)
+    q = critic(torch.as_tensor(g["b_global_obs"]).to(DEV))
+    logits = FlatMLP.forward(actor, obs)
+    dq, dlogits, scal = ops.ctde_td_head(q, q_next, torch.as_tensor(g["b_rew"]).to(DEV),
+                                         torch.as_tensor(g["b_terminated"]).to(DEV, torch.uint8), 0.99, logits,
+                                         torch.as_tensor(g["b_act"]).to(DEV))
+    np.testing.assert_allclose(scal.cpu().numpy(), [g["actor_loss"], g["critic_loss"]], rtol=1e-5)
+    for name, net, d in (("critic", critic, dq), ("actor", actor, dlogits)):
+        grad = ops.reduce_slabs(net.backward(d))
+        for i, (gw, gb) in enumerate(net.layer_views(grad)):
+            ref_w, ref_b = g[f"grad_{name}_w{i}"], g[f"grad_{name}_b{i}"]
+            scale = max(np.abs(ref_w).max(), 1e-12)
+            assert np.abs(gw.cpu().numpy() - ref_w).max() <= 1e-5 * scale, (name, i)
+            assert np.abs(gb.cpu().numpy() - ref_b).max() <= 1e-5 * max(np.abs(ref_b).max(), 1e-12), (name, i)
+    # the whole step: losses and post-Adam weights (Adam's first step is +-lr * sign-ish; compare absolutely)
+    losses = pol.learn(batch)
+    assert losses["actor_loss"] == pytest.approx(float(g["actor_loss"]), rel=1e-5)
+    assert losses["critic_loss"] == pytest.approx(float(g["critic_loss"]), rel=1e-5)
+    for name, net in (("actor", actor), ("critic", critic)):
+        for i in range(3):
+            np.testing.assert_allclose(net.weight(i).cpu().numpy(), g[f"after_{name}_w{i}"], rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(net.bias(i).cpu().numpy(), g[f"after_{name}_b{i}"], rtol=1e-5, atol=2e-6)
+
+
+def test_ctde_head_quirk_q7_and_local_fallback():
+    """actor_loss = -mean(logp) * mean(adv) (the (B,) x (B,1) broadcast), n_out == 1 critics, local-obs fallback."""
+    torch.manual_seed(0)
+    B, A = 300, 4
+    q, qn = torch.randn(B, 1, device=DEV), torch.randn(B, 1, device=DEV)
+    rew, term = torch.randn(B, device=DEV), (torch.rand(B, device=DEV) < 0.2).to(torch.uint8)
+    logits, act = torch.randn(B, A, device=DEV), torch.randint(0, A, (B,), device=DEV)
+    dq, dl, s = ops.ctde_td_head(q, qn, rew, term, 0.9, logits, act)
+    qd, ld = q.double().cpu().requires_grad_(), logits.double().cpu().requires_grad_()
+    td = rew.double().cpu().unsqueeze(-1) + 0.9 * qn.double().cpu() * (1 - term.double().cpu().unsqueeze(-1))
+    critic_loss = torch.nn.functional.mse_loss(qd, td)
+    adv = (td - qd).detach()
+    logp = -torch.nn.functional.cross_entropy(ld, act.cpu(), reduction="none")
+    actor_loss = -(logp * adv).mean()  # (B,) * (B,1) -> (B,B)
+    critic_loss.backward()
+    actor_loss.backward()
+    np.testing.assert_allclose(s.cpu().numpy(), [actor_loss.item(), critic_loss.item()], rtol=1e-5)
+    _close(dq, qd.grad)
+    _close(dl, ld.grad)
+    # no global_obs in the batch -> the critic sees the local observation (ctde.py:144-147)
+    actor, critic = DecentralizedActor(6, A, 32, device=DEV, seed=1), CentralizedCritic(6, 1, 32, device=DEV, seed=2)
+    pol = CTDEPolicy(actor=actor, critic=critic)
+    before = critic.flat.data.clone()
+    out = pol.learn(Batch(obs=np.random.randn(40, 6).astype(np.float32), act=np.random.randint(0, A, 40),
+                          rew=np.random.randn(40).astype(np.float32), obs_next=np.random.randn(40, 6).astype(np.float32),
+                          terminated=np.zeros(40, bool)))
+    assert np.isfinite(out["actor_loss"]) and np.isfinite(out["critic_loss"]) and not torch.equal(before, critic.flat.data)
+    with pytest.raises(TypeError):
+        CTDEPolicy(actor=torch.nn.Linear(2, 2), critic=critic)
+    sd = pol.state_dict()
+    critic.flat.data.zero_()
+    pol.load_state_dict(sd)
+    assert not torch.equal(critic.flat.data, torch.zeros_like(critic.flat.data))
+
+
+def test_global_state_constructor_modes():
+    g = np.load(os.path.join(GOLD, "ctde.npz"))
+    obs = {f"agent_{i}": torch.as_tensor(g["obs_by_agent"][i]) for i in range(3)}
+    np.testing.assert_array_equal(GlobalStateConstructor("concatenate").build(obs).cpu().numpy(), g["global_concatenate"])
+    np.testing.assert_allclose(GlobalStateConstructor("mean", obs_dim=6, n_agents=3).build(obs).cpu().numpy(),
+                               g["global_mean"], rtol=1e-6, atol=1e-7)
+    joint = torch.as_tensor(g["obs_by_agent"]).to(DEV).permute(1, 0, 2).contiguous()  # [B, N, D]
+    np.testing.assert_array_equal(GlobalStateConstructor.from_joint_rows(joint).cpu().numpy(), g["global_concatenate"])
+    assert GlobalStateConstructor("custom", custom_fn=lambda o: 7).build(obs) == 7
+    with pytest.raises(NotImplementedError):
+        GlobalStateConstructor("attention", obs_dim=6, n_agents=3)
+
+
+def test_ctde_policies_train_from_the_device_buffer():
+    """Collector (device rollout) -> agent batches with global state -> SimultaneousTrainer -> CTDEPolicy.learn."""
+    from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+    n_env, N, T = 16, 3, 25
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=1)
+    behaviour = PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=DEV, seed=1))
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=DEV)
+    col = Collector(behaviour, env, buf)
+    col.reset()
+    with policy_within_training_step(behaviour):
+        col.collect(n_step=n_env * T)
+    pols = {a: CTDEPolicy(actor=DecentralizedActor(env.obs_dim, 5, 128, device=DEV, seed=i),
+                          critic=CentralizedCritic(N * env.obs_dim, N, 128, device=DEV, seed=10 + i),
+                          discount_factor=0.0)  # no bootstrapping: the critic regresses the reward, loss must fall
+            for i, a in enumerate(env.agents)}
+    mgr = FlexibleMultiAgentPolicyManager(pols, env, mode="independent")
+    tr = SimultaneousTrainer(mgr)
+    batch = agent_batches_from_buffer(buf, env.agents)
+    first = tr.train_step(batch)
+    for _ in range(30):
+        last = tr.train_step(batch)
+    assert set(first) == set(env.agents)
+    for a in env.agents:  # the centralized critic's regression error shrinks on a fixed batch
+        assert last[a]["critic_loss"] < first[a]["critic_loss"]

@@ -53,6 +53,10 @@ class tsm_rollout_desc(C.Structure):
                 ("ep_len_out", C.c_void_p), ("ep_idx_out", C.c_void_p)]
 
 
+class tsm_mlp_desc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("act", C.c_int32), ("dims", C.c_int32 * 9)]
+
+
 _p, _i64, _i32, _f64, _int, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int, C.c_uint64
 
 # name -> (restype, argtypes); must list every function declared in include/tsmarl.h
@@ -96,6 +100,12 @@ SIGNATURES = {
     "tsm_policy_image_map": (_int, [_i32, _i32, _i32, _p]),
     "tsm_reduce_slabs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
     "tsm_global_state": (_int, [C.POINTER(_p), _i32, _i64, _i32, _int, _p, _p]),
+    "tsm_ctde_head_partial_elems": (_i64, [_i64]),
+    "tsm_ctde_td_head": (_int, [_p, _p, _i32, _p, _p, C.c_float, _p, _p, _i32, _i64, _p, _p, _p, _p, _p]),
+    "tsm_mlp_param_count": (_i64, [C.POINTER(tsm_mlp_desc)]),
+    "tsm_mlp_act_elems": (_i64, [C.POINTER(tsm_mlp_desc), _i64]),
+    "tsm_mlp_forward": (_int, [C.POINTER(tsm_mlp_desc), _p, _p, _i64, _p, _p]),
+    "tsm_mlp_backward": (_int, [C.POINTER(tsm_mlp_desc), _p, _p, _i64, _p, _p, _p, _i32, _p, _p]),
     "tsm_policy_param_count": (_i64, [_i32, _i32, _i32]),
     "tsm_policy_forward": (_int, [_p, _p, _i32, _i32, _i32, _p, _i64, _int, _u64, _u64, _p, _p, _p, _p, _p, _p]),
     "tsm_mpe_spread_reset": (_int, [C.POINTER(tsm_mpe_cfg), _u64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
@@ -110,7 +120,8 @@ SIGNATURES = {
 }
 
 _NO_STATUS = {"tsm_abi_version", "tsm_last_error", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
-              "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems"}
+              "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems",
+              "tsm_mlp_param_count", "tsm_mlp_act_elems", "tsm_ctde_head_partial_elems"}
 
 _lib = None
 

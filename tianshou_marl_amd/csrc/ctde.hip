@@ -48,3 +48,109 @@ TSM_EXPORT int tsm_global_state(const float *const *obs_by_agent_host, int32_t n
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }
+
+// ---- CTDEPolicy.learn loss head (ctde.py:149-185) -----------------------------------------------------------
+// Given the centralized critic's outputs q[B][n_out] on global_obs, q_next on global_obs_next and the actor's
+// logits[B][A]:
+//   values      = q.mean(1),  values_next = q_next.mean(1)              (:154-157; n_out == 1: the value itself)
+//   td_target   = rew + gamma * values_next * (1 - terminated)          (:169)
+//   critic_loss = mean((values - td_target)^2)                          (:172)
+//   advantage   = td_target - values                                    (:181, detached)
+//   log_probs   = -cross_entropy(logits, act, reduction="none")         (:184)
+//   actor_loss  = -(log_probs[B] * advantage[B,1]).mean()               (:185)
+// The product of a (B,) and a (B,1) tensor broadcasts to (B,B), so actor_loss = -mean(log_probs) * mean(advantage)
+// (quirk Q7) -- restated exactly, including its gradient
+//   d actor_loss / d logits[b][a] = -(mean(advantage) / B) * (1[a == act_b] - softmax(logits_b)[a]).
+// Outputs: dq[B][n_out] = 2 (values - td_target) / (B n_out), dlogits[B][A], scalars = {actor_loss, critic_loss}.
+namespace {
+constexpr int kHeadThreads = 256;
+
+__global__ __launch_bounds__(kHeadThreads) void ctde_head_rows(
+    const float *__restrict__ q, const float *__restrict__ q_next, int32_t n_out, const float *__restrict__ rew,
+    const uint8_t *__restrict__ terminated, float gamma, const float *__restrict__ logits,
+    const int64_t *__restrict__ act, int32_t A, int64_t B, float *__restrict__ dq, double *__restrict__ partial) {
+    __shared__ double red[3][kHeadThreads / 64];
+    const int64_t b = (int64_t)blockIdx.x * kHeadThreads + threadIdx.x;
+    double s_adv = 0.0, s_logp = 0.0, s_sq = 0.0;
+    if (b < B) {
+        float v = 0.f, vn = 0.f;
+        for (int j = 0; j < n_out; ++j) {  // torch mean over dim 1: sequential f32 sum / n
+            v += q[b * n_out + j];
+            vn += q_next[b * n_out + j];
+        }
+        v /= (float)n_out;
+        vn /= (float)n_out;
+        const float td = rew[b] + gamma * vn * (terminated[b] ? 0.f : 1.f);
+        const float diff = v - td;
+        const float gq = 2.f * diff / ((float)B * (float)n_out);
+        for (int j = 0; j < n_out; ++j) dq[b * n_out + j] = gq;
+        const float *lg = logits + b * A;
+        float mx = lg[0];
+        for (int a = 1; a < A; ++a) mx = fmaxf(mx, lg[a]);
+        float se = 0.f;
+        for (int a = 0; a < A; ++a) se += expf(lg[a] - mx);
+        const float logp = lg[act[b]] - mx - logf(se);
+        s_adv = (double)(td - v);
+        s_logp = (double)logp;
+        s_sq = (double)diff * (double)diff;
+    }
+    s_adv = wave_sum(s_adv);
+    s_logp = wave_sum(s_logp);
+    s_sq = wave_sum(s_sq);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = s_adv; red[1][w] = s_logp; red[2][w] = s_sq; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0.0;
+        for (int i = 0; i < kHeadThreads / 64; ++i) s += red[threadIdx.x][i];
+        partial[(int64_t)blockIdx.x * 3 + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(kHeadThreads) void ctde_head_actor_grad(
+    const float *__restrict__ logits, const int64_t *__restrict__ act, int32_t A, int64_t B,
+    const double *__restrict__ partial, int32_t n_part, float *__restrict__ dlogits, float *__restrict__ scalars) {
+    __shared__ double tot[3];
+    if (threadIdx.x < 3) {  // every block folds the partials in the same order: identical result everywhere
+        double s = 0.0;
+        for (int i = 0; i < n_part; ++i) s += partial[(int64_t)i * 3 + threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    const double mean_adv = tot[0] / (double)B, mean_logp = tot[1] / (double)B;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scalars[0] = (float)(-mean_logp * mean_adv);
+        scalars[1] = (float)(tot[2] / (double)B);
+    }
+    const int64_t b = (int64_t)blockIdx.x * kHeadThreads + threadIdx.x;
+    if (b >= B) return;
+    const float coef = -(float)mean_adv / (float)B;
+    const float *lg = logits + b * A;
+    float mx = lg[0];
+    for (int a = 1; a < A; ++a) mx = fmaxf(mx, lg[a]);
+    float se = 0.f;
+    for (int a = 0; a < A; ++a) se += expf(lg[a] - mx);
+    const float inv = 1.f / se;
+    const int64_t ab = act[b];
+    for (int a = 0; a < A; ++a) dlogits[b * A + a] = coef * ((a == ab ? 1.f : 0.f) - expf(lg[a] - mx) * inv);
+}
+}  // namespace
+
+TSM_EXPORT int64_t tsm_ctde_head_partial_elems(int64_t B) { return B < 0 ? -1 : 3 * ceil_div(B > 0 ? B : 1, kHeadThreads); }
+
+TSM_EXPORT int tsm_ctde_td_head(const float *q, const float *q_next, int32_t n_out, const float *rew,
+                                const uint8_t *terminated, float gamma, const float *logits, const int64_t *act,
+                                int32_t n_act, int64_t B, float *dq, float *dlogits, double *partial, float *scalars,
+                                void *stream) {
+    TSM_REQUIRE(B >= 1 && n_out >= 1 && n_act >= 1, "tsm_ctde_td_head: bad sizes");
+    TSM_REQUIRE(q && q_next && rew && terminated && logits && act && dq && dlogits && partial && scalars,
+                "tsm_ctde_td_head: null pointer");
+    const unsigned nb = (unsigned)ceil_div(B, kHeadThreads);
+    hipLaunchKernelGGL(ctde_head_rows, dim3(nb), dim3(kHeadThreads), 0, tsm_stream(stream), q, q_next, n_out, rew,
+                       terminated, gamma, logits, act, n_act, B, dq, partial);
+    TSM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ctde_head_actor_grad, dim3(nb), dim3(kHeadThreads), 0, tsm_stream(stream), logits, act, n_act,
+                       B, partial, (int32_t)nb, dlogits, scalars);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}

@@ -123,7 +123,7 @@ class DeviceVectorReplayBuffer:
         dev = self.device
         R = len(batch.rew)
         obs = _obs_array(batch.obs)
-        t = lambda x, dt: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(x))).to(dev, dt).contiguous()  # noqa: E731
+        t = lambda x, dt: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.array(x))).to(dev, dt).contiguous()  # noqa: E731
         N = self.n_agent
         term = np.broadcast_to(np.asarray(batch.terminated, bool).reshape(R, -1), (R, N))
         trunc = np.broadcast_to(np.asarray(batch.truncated, bool).reshape(R, -1), (R, N))

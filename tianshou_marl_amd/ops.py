@@ -400,6 +400,74 @@ def global_state(obs_by_agent, mode: str = "concatenate") -> torch.Tensor:
     return out
 
 
+def ctde_td_head(q, q_next, rew, terminated, gamma: float, logits, act):
+    """CTDEPolicy.learn loss head (ctde.py:149-185) -> (dq, dlogits, scalars[actor_loss, critic_loss])."""
+    q, q_next = _chk(q, torch.float32, "q"), _chk(q_next, torch.float32, "q_next")
+    B, n_out = q.shape
+    logits = _chk(logits, torch.float32, "logits")
+    A = logits.shape[1]
+    dev = q.device
+    dq, dlogits = torch.empty_like(q), torch.empty_like(logits)
+    partial = torch.empty(call("tsm_ctde_head_partial_elems", B), dtype=torch.float64, device=dev)
+    scalars = torch.empty(2, dtype=torch.float32, device=dev)
+    call("tsm_ctde_td_head", ptr(q), ptr(q_next), n_out, ptr(_chk(rew, torch.float32, "rew").reshape(-1)),
+         ptr(_chk(terminated, torch.uint8, "terminated").reshape(-1)), float(gamma), ptr(logits),
+         ptr(_chk(act, torch.int64, "act").reshape(-1)), A, B, ptr(dq), ptr(dlogits), ptr(partial), ptr(scalars),
+         stream_ptr())
+    return dq, dlogits, scalars
+
+
+# --------------------------------------------------------------------------------------------
+# fully-connected networks of arbitrary width (csrc/dense.hip)
+# --------------------------------------------------------------------------------------------
+_ACT = {"none": 0, None: 0, "relu": 1, "tanh": 2}
+
+
+def mlp_desc(dims, act: str = "relu") -> _abi.tsm_mlp_desc:
+    dims = [int(d) for d in dims]
+    if not 2 <= len(dims) <= 9:
+        raise ValueError("mlp_desc: between 1 and 8 layers")
+    d = _abi.tsm_mlp_desc()
+    d.n_layers, d.act = len(dims) - 1, _ACT[act]
+    for i, v in enumerate(dims):
+        d.dims[i] = v
+    return d
+
+
+def mlp_param_count(desc) -> int:
+    return call("tsm_mlp_param_count", C.byref(desc))
+
+
+def mlp_forward(desc, params, x, acts=None):
+    """-> (out [B, dims[-1]] view of the last activation block, acts buffer)."""
+    x = _chk(x, torch.float32, "x")
+    B = x.shape[0]
+    if x.shape[1] != desc.dims[0]:
+        raise ValueError(f"mlp_forward: input width {x.shape[1]} != dims[0] {desc.dims[0]}")
+    n = call("tsm_mlp_act_elems", C.byref(desc), B)
+    if acts is None:
+        acts = torch.empty(n, dtype=torch.float32, device=x.device)
+    call("tsm_mlp_forward", C.byref(desc), ptr(_chk(params, torch.float32, "params")), ptr(x), B, ptr(acts),
+         stream_ptr())
+    O = desc.dims[desc.n_layers]
+    return acts[n - B * O:].view(B, O), acts
+
+
+def mlp_backward(desc, params, x, acts, d_out, n_split: int = 0, slabs=None):
+    """Gradient slabs [n_split, n_param] of sum(out * d_out) w.r.t. the flat parameter vector."""
+    x, d_out = _chk(x, torch.float32, "x"), _chk(d_out, torch.float32, "d_out")
+    B = x.shape[0]
+    if n_split <= 0:
+        n_split = max(1, min(64, -(-B // 256)))
+    n_param = params.numel()
+    if slabs is None:
+        slabs = torch.empty(n_split, n_param, dtype=torch.float32, device=x.device)
+    d_acts = torch.empty_like(acts)
+    call("tsm_mlp_backward", C.byref(desc), ptr(params), ptr(x), B, ptr(acts), ptr(d_out), ptr(d_acts), n_split,
+         ptr(slabs), stream_ptr())
+    return slabs
+
+
 def device_info() -> dict:
     n_cu, wave, hbm = C.c_int(), C.c_int(), C.c_int64()
     name = C.create_string_buffer(64)

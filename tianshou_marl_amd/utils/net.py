@@ -113,6 +113,130 @@ class DiscreteActorCritic(nn.Module):
         self.sync_image()
 
 
+class FlatMLP(nn.Module):
+    """Fully-connected net dims[0] -> ... -> dims[-1] (hidden activation relu | tanh, linear output) whose
+    parameters are ONE flat HBM vector in torch `parameters()` order; forward/backward run in csrc/dense.hip.
+
+    `forward(x)` keeps the activations of the last call so that `backward(d_out)` can produce the gradient slabs
+    (the pair replaces autograd for this module).  Layer views (`weight(i)`, `bias(i)`) alias the flat vector."""
+
+    def __init__(self, dims, act: str = "relu", device: str | torch.device = "cuda", seed: int | None = None) -> None:
+        super().__init__()
+        self.dims = [int(d) for d in dims]
+        self.act = act
+        self.desc = ops.mlp_desc(self.dims, act)
+        self.flat = nn.Parameter(torch.zeros(ops.mlp_param_count(self.desc), dtype=torch.float32, device=device),
+                                 requires_grad=False)
+        self._offsets = []
+        o = 0
+        for i in range(len(self.dims) - 1):
+            k, n = self.dims[i], self.dims[i + 1]
+            self._offsets.append((o, o + n * k))
+            o += n * k + n
+        self._saved = None
+        self.reset_parameters(seed)
+
+    @property
+    def n_layers(self) -> int:
+        return len(self.dims) - 1
+
+    def weight(self, i: int) -> torch.Tensor:
+        o, ob = self._offsets[i]
+        return self.flat.data[o:ob].view(self.dims[i + 1], self.dims[i])
+
+    def bias(self, i: int) -> torch.Tensor:
+        _, ob = self._offsets[i]
+        return self.flat.data[ob:ob + self.dims[i + 1]]
+
+    @torch.no_grad()
+    def reset_parameters(self, seed: int | None = None) -> None:
+        """torch nn.Linear default init (kaiming-uniform weights, uniform bias)."""
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        for i in range(self.n_layers):
+            bound = 1.0 / math.sqrt(self.dims[i])
+            self.weight(i).copy_(torch.empty(self.weight(i).shape).uniform_(-bound, bound, generator=gen))
+            self.bias(i).copy_(torch.empty(self.bias(i).shape).uniform_(-bound, bound, generator=gen))
+
+    @torch.no_grad()
+    def load_layers(self, layers) -> None:
+        """layers: [(W [out, in], b [out])] per layer (numpy or tensors), torch nn.Linear layout."""
+        for i, (W, b) in enumerate(layers):
+            self.weight(i).copy_(torch.as_tensor(np.asarray(W)).to(self.flat.device, torch.float32))
+            self.bias(i).copy_(torch.as_tensor(np.asarray(b)).to(self.flat.device, torch.float32))
+
+    def layer_views(self, flat: torch.Tensor):
+        """[(W, b)] views of any flat vector with this net's layout (e.g. a summed gradient)."""
+        out = []
+        for i, (o, ob) in enumerate(self._offsets):
+            out.append((flat[o:ob].view(self.dims[i + 1], self.dims[i]), flat[ob:ob + self.dims[i + 1]]))
+        return out
+
+    def forward(self, x: torch.Tensor, save: bool = True) -> torch.Tensor:
+        x = x.to(self.flat.device, torch.float32).contiguous()
+        lead = x.shape[:-1]
+        if x.shape[-1] != self.dims[0]:
+            raise ValueError(f"FlatMLP: input width {x.shape[-1]} != {self.dims[0]}")
+        x2 = x.reshape(-1, self.dims[0])
+        out, acts = ops.mlp_forward(self.desc, self.flat.data, x2)
+        if save:
+            self._saved = (x2, acts)
+        return out.view(*lead, self.dims[-1])
+
+    def backward(self, d_out: torch.Tensor, n_split: int = 0) -> torch.Tensor:
+        """Gradient slabs [n_split, n_param] for the inputs of the last `forward(save=True)`."""
+        if self._saved is None:
+            raise RuntimeError("FlatMLP.backward called before forward")
+        x2, acts = self._saved
+        return ops.mlp_backward(self.desc, self.flat.data, x2, acts, d_out.reshape(x2.shape[0], self.dims[-1]).contiguous(),
+                                n_split)
+
+    # reference module key names: fc1/fc2/fc3 (ctde.py:362-364, 398-400)
+    def to_reference_state_dict(self) -> OrderedDict:
+        sd = OrderedDict()
+        for i in range(self.n_layers):
+            sd[f"fc{i + 1}.weight"] = self.weight(i).detach().clone().cpu()
+            sd[f"fc{i + 1}.bias"] = self.bias(i).detach().clone().cpu()
+        return sd
+
+    @torch.no_grad()
+    def load_reference_state_dict(self, sd) -> None:
+        self.load_layers([(sd[f"fc{i + 1}.weight"], sd[f"fc{i + 1}.bias"]) for i in range(self.n_layers)])
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (algorithm_base.py:485-498 wraps it) on one flat parameter vector, executed by
+    `tsm_adam_step` (slab reduction + optional grad-norm clip + Adam in one launch).  Stands where
+    `optim.Adam(module.parameters(), lr=...)` stands in the reference's CTDE constructors (ctde.py:36-37)."""
+
+    def __init__(self, module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 max_grad_norm: float | None = None) -> None:
+        self.param = module.flat.data if hasattr(module, "flat") else module
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.exp_avg = torch.zeros_like(self.param)
+        self.exp_avg_sq = torch.zeros_like(self.param)
+        self.step_count = 0
+        self._work = torch.zeros(ops.call("tsm_adam_work_elems", self.param.numel()), dtype=torch.float32,
+                                 device=self.param.device)
+
+    def zero_grad(self) -> None:  # gradients are produced fresh per step as slabs; nothing accumulates
+        return None
+
+    def step(self, grad_slabs: torch.Tensor) -> None:
+        self.step_count += 1
+        ops.adam_step(self.param, grad_slabs, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr,
+                      betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
+                      work=self._work)
+
+    def state_dict(self) -> dict:
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_count,
+                "lr": self.lr}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count, self.lr = sd["step"], sd["lr"]
+
+
 class RunningMeanStd:
     """tianshou.utils.statistics.RunningMeanStd (statistics.py:68-114), scalar statistics, host f64.
     The batch moments come from a device reduction; only three scalars live on the host."""
