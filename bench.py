@@ -153,6 +153,28 @@ def kernel_rooflines(a, algo, buf):
     fl = torch.zeros(T, L, dtype=torch.uint8, device=dev)
     out = (torch.empty_like(v), torch.empty_like(v))
     gae_s = per_launch(lambda: ops.gae_lanes(v, v, v, fl, fl, out=out))
+    # (3) the HBM-bound kernels at the north star's roofline size (n_env=4096, n_agent=8, T=25: 819 200 samples)
+    grid = []
+    Tg, Lg = 25, 4096 * 8
+    vg = torch.randn(Tg, Lg, device=dev)
+    flg = torch.zeros(Tg, Lg, dtype=torch.uint8, device=dev)
+    outg = (torch.empty_like(vg), torch.empty_like(vg))
+    s_g = per_launch(lambda: ops.gae_lanes(vg, vg, vg, flg, flg, out=outg))
+    grid.append({"kernel": "gae_lanes_kernel", "n_env": 4096, "n_agent": 8, "T": Tg, "bound": "hbm",
+                 "bytes_per_launch": 22 * Tg * Lg, "us_per_launch": s_g * 1e6, "achieved": 22 * Tg * Lg / s_g / 1e9,
+                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 22 * Tg * Lg / s_g / HBM_PEAK})
+    Mg, A = Tg * Lg, net.n_act
+    lg_ = torch.randn(Mg, A, device=dev)
+    vals = [torch.randn(Mg, device=dev) for _ in range(4)]
+    actg = torch.randint(0, A, (Mg,), dtype=torch.int32, device=dev)
+    stg = ops.ppo_adv_stats(vals[2], torch.tensor([0, Mg], device=dev))
+    s_l = per_launch(lambda: ops.ppo_loss_fwd_bwd(lg_, vals[0], actg, vals[1], vals[2], vals[3], algo._cfg,
+                                                  adv_stats=stg[0], finalize=False))
+    loss_bytes = (8 * A + 24) * Mg  # logits + dlogits, value/act/logp_old/adv/ret read, dvalue written (64 B at A=5)
+    grid.append({"kernel": "loss_kernel<5> (PPO clip loss fwd+bwd on given logits/value)", "rows": Mg, "bound": "hbm",
+                 "bytes_per_launch": loss_bytes, "us_per_launch": s_l * 1e6, "achieved": loss_bytes / s_l / 1e9,
+                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": loss_bytes / s_l / HBM_PEAK})
+    del vg, flg, outg, lg_, vals, actg
     H = net.hidden
     fwd_flop = 2 * (2 * D * H + 2 * H * H + H * net.n_act + H)          # actor + critic forward per sample
     upd_flop = 3 * fwd_flop * M                                          # forward + 2x backward (~65 kFLOP)
@@ -169,6 +191,7 @@ def kernel_rooflines(a, algo, buf):
         "roofline_gae": {"bound": "hbm", "kernel": "gae_lanes_kernel", "achieved": gae_bytes / gae_s / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gae_bytes / gae_s / HBM_PEAK, "traffic": None,
                          "bytes_per_launch": gae_bytes, "us_per_launch": gae_s * 1e6},
+        "roofline_grid": grid,
     }
 
 

@@ -19,19 +19,39 @@
 
 namespace {
 
-constexpr int CH = 8;  // steps per thread per super-chunk
+// debug / tuning overrides (tools/bench_kernels.py --gae-sweep): 0 = automatic choice
+int g_force_vec = 0, g_force_ch = 0, g_force_w = 0;
 
-template <bool GENERIC, bool FLAGS_PER_LANE>
+template <int V> __device__ __forceinline__ void ld_f(const float *__restrict__ p, float (&o)[V]) {
+    if constexpr (V == 4) { const float4 q = *reinterpret_cast<const float4 *>(p); o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; }
+    else if constexpr (V == 2) { const float2 q = *reinterpret_cast<const float2 *>(p); o[0] = q.x; o[1] = q.y; }
+    else o[0] = p[0];
+}
+template <int V> __device__ __forceinline__ void st_f(float *__restrict__ p, const float (&v)[V]) {
+    if constexpr (V == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else if constexpr (V == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    else p[0] = v[0];
+}
+template <int V> __device__ __forceinline__ void ld_b(const uint8_t *__restrict__ p, uint8_t (&o)[V]) {
+    if constexpr (V == 4) { const uint32_t q = *reinterpret_cast<const uint32_t *>(p);
+                            o[0] = q & 0xff; o[1] = (q >> 8) & 0xff; o[2] = (q >> 16) & 0xff; o[3] = q >> 24; }
+    else if constexpr (V == 2) { const uint16_t q = *reinterpret_cast<const uint16_t *>(p); o[0] = q & 0xff; o[1] = q >> 8; }
+    else o[0] = p[0];
+}
+
+// A thread owns VEC adjacent lanes (one 4*VEC-byte load per array and step) and CH consecutive steps of a
+// super-chunk.  VEC > 1 requires !GENERIC, FLAGS_PER_LANE, L % VEC == 0 and suitably aligned pointers.
+template <bool GENERIC, bool FLAGS_PER_LANE, int VEC, int CH>
 __global__ __launch_bounds__(1024) void gae_lanes_kernel(
     const float *__restrict__ v_s, const float *__restrict__ v_n, const float *__restrict__ rew,
     const uint8_t *__restrict__ term, const uint8_t *__restrict__ trunc, int64_t T, int64_t L,
     int64_t lanes_per_env, const int32_t *__restrict__ env_start,
     const int32_t *__restrict__ env_len, double gamma, double gl, double v_scale,
     float *__restrict__ ret_out, float *__restrict__ adv_out) {
-    extern __shared__ double lds[];  // [2][W][64][2]
+    extern __shared__ double lds[];  // [2][W][64 * VEC][2]
     const int W = blockDim.y;
     const int lx = threadIdx.x, w = threadIdx.y;
-    const int64_t lane = (int64_t)blockIdx.x * 64 + lx;
+    const int64_t lane = ((int64_t)blockIdx.x * 64 + lx) * VEC;
     const bool live = lane < L;
     const int64_t env = live ? lane / lanes_per_env : 0;
     const int64_t n_env = L / lanes_per_env;
@@ -40,87 +60,115 @@ __global__ __launch_bounds__(1024) void gae_lanes_kernel(
         if (env_len) len = env_len[env];
         if (env_start) start = env_start[env];
     }
-    // the block walks the longest lane length it owns; shorter lanes mask their tail
-    int64_t max_len = T;  // uniform upper bound keeps the barrier structure uniform
     const int64_t SC = (int64_t)W * CH;
-    const int64_t n_sc = (max_len + SC - 1) / SC;
+    const int64_t n_sc = (T + SC - 1) / SC;  // uniform trip count keeps the barrier structure uniform
     const double inv_scale = 1.0 / v_scale;
 
-    double carry_super = 0.0;
+    double carry_super[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) carry_super[j] = 0.0;
     for (int64_t s = n_sc - 1; s >= 0; --s) {
         const int64_t k0 = s * SC + (int64_t)w * CH;
-        double delta[CH];
-        float vs_f[CH];
-        unsigned keep = 0;  // bit k set: discount = gl (no end flag)
+        float a_f[CH][VEC], b_f[CH][VEC], r_f[CH][VEC];
+        uint8_t te_b[CH][VEC], tr_b[CH][VEC];
         unsigned valid = 0;
+        // issue every load of the chunk before the first use (memory-level parallelism)
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const int64_t kk = k0 + k;
-            const bool ok = live && kk < len;
-            delta[k] = 0.0;
-            vs_f[k] = 0.f;
-            if (ok) {
+            if (live && kk < len) {
                 int64_t slot = kk;
                 if (GENERIC) { slot = start + kk; if (slot >= T) slot -= T; }
                 const int64_t i = slot * L + lane;
-                const int64_t fi = FLAGS_PER_LANE ? i : slot * n_env + env;
-                const float a = v_s[i], b = v_n[i], r = rew[i];
-                const uint8_t te = term[fi], tr = trunc[fi];
-                const double vs = (double)a * v_scale;
-                const double vn = te ? 0.0 : (double)b * v_scale;
-                delta[k] = (double)r + vn * gamma - vs;
-                vs_f[k] = a;
-                const bool end = te | tr | (kk == len - 1);
-                keep |= (end ? 0u : 1u) << k;
+                ld_f<VEC>(v_s + i, a_f[k]);
+                ld_f<VEC>(v_n + i, b_f[k]);
+                ld_f<VEC>(rew + i, r_f[k]);
+                if (FLAGS_PER_LANE) { ld_b<VEC>(term + i, te_b[k]); ld_b<VEC>(trunc + i, tr_b[k]); }
+                else { te_b[k][0] = term[slot * n_env + env]; tr_b[k][0] = trunc[slot * n_env + env]; }
                 valid |= 1u << k;
-            } else {
-                keep |= 1u << k;  // masked step: identity map (delta 0, discount 1 handled below)
             }
         }
-        // local scan with carry 0 -> (P, B)
-        double P = 1.0, B = 0.0;
+        double delta[CH][VEC];
+        unsigned keep[VEC];  // bit k set: discount = gl (no end flag)
 #pragma unroll
-        for (int k = CH - 1; k >= 0; --k) {
-            const bool v = (valid >> k) & 1u;
-            const double d = v ? (((keep >> k) & 1u) ? gl : 0.0) : 1.0;
-            B = delta[k] + d * B;
-            P *= d;
+        for (int j = 0; j < VEC; ++j) keep[j] = 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const bool ok = (valid >> k) & 1u;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                delta[k][j] = 0.0;
+                if (ok) {
+                    const uint8_t te = te_b[k][j], tr = tr_b[k][j];
+                    const double vs = (double)a_f[k][j] * v_scale;
+                    const double vn = te ? 0.0 : (double)b_f[k][j] * v_scale;
+                    delta[k][j] = (double)r_f[k][j] + vn * gamma - vs;
+                    const bool end = te | tr | (k0 + k == len - 1);
+                    keep[j] |= (end ? 0u : 1u) << k;
+                }
+            }
         }
-        double *buf = lds + (size_t)(s & 1) * W * 64 * 2;
-        buf[((size_t)w * 64 + lx) * 2 + 0] = P;
-        buf[((size_t)w * 64 + lx) * 2 + 1] = B;
+        // local scan with carry 0 -> affine map carry -> B + P * carry  (masked step: identity)
+        double P[VEC], B[VEC];
+        double *buf = lds + (size_t)(s & 1) * W * 64 * VEC * 2;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            P[j] = 1.0; B[j] = 0.0;
+#pragma unroll
+            for (int k = CH - 1; k >= 0; --k) {
+                const bool v = (valid >> k) & 1u;
+                const double d = v ? (((keep[j] >> k) & 1u) ? gl : 0.0) : 1.0;
+                B[j] = delta[k][j] + d * B[j];
+                P[j] *= d;
+            }
+            buf[(((size_t)w * 64 + lx) * VEC + j) * 2 + 0] = P[j];
+            buf[(((size_t)w * 64 + lx) * VEC + j) * 2 + 1] = B[j];
+        }
         __syncthreads();
-        // fold later chunks (W-1 .. w+1) onto the super-chunk carry
-        double c = carry_super;
-        for (int ww = W - 1; ww > w; --ww) {
-            const double Pw = buf[((size_t)ww * 64 + lx) * 2 + 0];
-            const double Bw = buf[((size_t)ww * 64 + lx) * 2 + 1];
-            c = Bw + Pw * c;
+        // fold the later chunks (W-1 .. w+1) onto the super-chunk carry; continue down to chunk 0 for the next carry
+        double c[VEC], cs[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            double acc = carry_super[j];
+            for (int ww = W - 1; ww > w; --ww) {
+                const double Pw = buf[(((size_t)ww * 64 + lx) * VEC + j) * 2 + 0];
+                const double Bw = buf[(((size_t)ww * 64 + lx) * VEC + j) * 2 + 1];
+                acc = Bw + Pw * acc;
+            }
+            c[j] = acc;
+            acc = B[j] + P[j] * acc;  // own chunk
+            for (int ww = w - 1; ww >= 0; --ww) {
+                const double Pw = buf[(((size_t)ww * 64 + lx) * VEC + j) * 2 + 0];
+                const double Bw = buf[(((size_t)ww * 64 + lx) * VEC + j) * 2 + 1];
+                acc = Bw + Pw * acc;
+            }
+            cs[j] = acc;
         }
         // replay own chunk serially from the true carry-in
-        double g = c;
+        double g[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) g[j] = c[j];
 #pragma unroll
         for (int k = CH - 1; k >= 0; --k) {
-            const bool v = (valid >> k) & 1u;
-            if (v) {
-                const double d = ((keep >> k) & 1u) ? gl : 0.0;
-                g = delta[k] + d * g;
+            if ((valid >> k) & 1u) {
+                float adv_v[VEC], ret_v[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const double d = ((keep[j] >> k) & 1u) ? gl : 0.0;
+                    g[j] = delta[k][j] + d * g[j];
+                    adv_v[j] = (float)g[j];
+                    ret_v[j] = (float)((g[j] + (double)a_f[k][j] * v_scale) * inv_scale);
+                }
                 const int64_t kk = k0 + k;
                 int64_t slot = kk;
                 if (GENERIC) { slot = start + kk; if (slot >= T) slot -= T; }
                 const int64_t i = slot * L + lane;
-                adv_out[i] = (float)g;
-                ret_out[i] = (float)((g + (double)vs_f[k] * v_scale) * inv_scale);
+                st_f<VEC>(adv_out + i, adv_v);
+                st_f<VEC>(ret_out + i, ret_v);
             }
         }
-        // carry for the next (earlier) super-chunk = gae at the first step of chunk 0
-        double cs = carry_super;
-        for (int ww = W - 1; ww >= 0; --ww) {
-            const double Pw = buf[((size_t)ww * 64 + lx) * 2 + 0];
-            const double Bw = buf[((size_t)ww * 64 + lx) * 2 + 1];
-            cs = Bw + Pw * cs;
-        }
-        carry_super = cs;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) carry_super[j] = cs[j];
         // LDS is double-buffered by (s & 1): the next iteration writes the other half, and the
         // barrier of that iteration orders it against this iteration's reads of this half.
     }
@@ -137,17 +185,32 @@ __global__ void mc_return_kernel(const float *__restrict__ rew, int64_t T, int64
     }
 }
 
-int pick_waves(int64_t T, int64_t L) {
+int pick_waves(int64_t T, int64_t L, int vec, int ch) {
     // enough waves to fill 256 CUs x 8, but no more chunks than the series has
-    int64_t blocks = ceil_div(L, 64);
+    int64_t blocks = ceil_div(L, 64 * vec);
     int64_t want = ceil_div(2048, blocks);
-    int64_t max_by_T = ceil_div(T, CH);
+    int64_t max_by_T = ceil_div(T, ch);
     int w = 1;
     while (w < 16 && w < want && w < max_by_T) w <<= 1;
     return w;
 }
 
+template <bool G, bool F, int VEC, int CH>
+void launch_gae(int W, const float *v_s, const float *v_s_next, const float *rew, const uint8_t *terminated,
+                const uint8_t *truncated, int64_t T, int64_t n_lane, int64_t lanes_per_env, const int32_t *env_start,
+                const int32_t *env_len, double gamma, double gl, double v_scale, float *returns_out, float *adv_out,
+                hipStream_t st) {
+    dim3 block(64, W), grid((unsigned)ceil_div(n_lane, 64 * VEC));
+    const size_t shmem = (size_t)2 * W * 64 * VEC * 2 * sizeof(double);
+    hipLaunchKernelGGL((gae_lanes_kernel<G, F, VEC, CH>), grid, block, shmem, st, v_s, v_s_next, rew, terminated,
+                       truncated, T, n_lane, lanes_per_env, env_start, env_len, gamma, gl, v_scale, returns_out, adv_out);
+}
+
 }  // namespace
+
+extern "C" __attribute__((visibility("default"))) void tsm_debug_gae_config(int vec, int ch, int w) {
+    g_force_vec = vec; g_force_ch = ch; g_force_w = w;
+}
 
 TSM_EXPORT int tsm_gae_lanes(const float *v_s, const float *v_s_next, const float *rew,
                              const uint8_t *terminated, const uint8_t *truncated,
@@ -164,19 +227,29 @@ TSM_EXPORT int tsm_gae_lanes(const float *v_s, const float *v_s_next, const floa
                 "tsm_gae_lanes: n_lane=%lld not a multiple of lanes_per_env=%lld",
                 (long long)n_lane, (long long)lanes_per_env);
     TSM_REQUIRE(v_scale > 0.0, "tsm_gae_lanes: v_scale must be > 0");
-    const int W = pick_waves(T, n_lane);
-    dim3 block(64, W), grid((unsigned)ceil_div(n_lane, 64));
-    const size_t shmem = (size_t)2 * W * 64 * 2 * sizeof(double);
     const double gl = gamma * gae_lambda;
     const bool generic = env_start || env_len;
     hipStream_t st = tsm_stream(stream);
-#define LAUNCH(G, F)                                                                             \
-    hipLaunchKernelGGL((gae_lanes_kernel<G, F>), grid, block, shmem, st, v_s, v_s_next, rew,     \
-                       terminated, truncated, T, n_lane, lanes_per_env, env_start, env_len,      \
-                       gamma, gl, v_scale, returns_out, adv_out)
-    if (generic) { if (flags_per_lane) LAUNCH(true, true); else LAUNCH(true, false); }
-    else { if (flags_per_lane) LAUNCH(false, true); else LAUNCH(false, false); }
-#undef LAUNCH
+    // Steps per thread: 4 (measured best on MI355X: 41.7 % of HBM peak at T=25 x 32768 lanes, 67 % at T=2048; 8 steps
+    // per thread and the 8-/16-byte-per-lane variants VEC=2/4 lose to register pressure from the f64 scan state --
+    // profiles/r01_gae_sweep.txt).  VEC stays a template parameter for that experiment; only VEC=1 is instantiated.
+    int ch = 4;
+    if (g_force_ch) ch = g_force_ch;
+    (void)g_force_vec;
+    int W = pick_waves(T, n_lane, 1, ch);
+    if (g_force_w) W = g_force_w;
+#define ARGS W, v_s, v_s_next, rew, terminated, truncated, T, n_lane, lanes_per_env, env_start, env_len, gamma, gl, \
+             v_scale, returns_out, adv_out, st
+#define BY_CH(G, F)                                          \
+    do {                                                     \
+        if (ch == 2) launch_gae<G, F, 1, 2>(ARGS);           \
+        else if (ch == 8) launch_gae<G, F, 1, 8>(ARGS);      \
+        else launch_gae<G, F, 1, 4>(ARGS);                   \
+    } while (0)
+    if (generic) { if (flags_per_lane) BY_CH(true, true); else BY_CH(true, false); }
+    else { if (flags_per_lane) BY_CH(false, true); else BY_CH(false, false); }
+#undef BY_CH
+#undef ARGS
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

@@ -43,6 +43,12 @@ struct Cfg {
 
 constexpr int kLossThreads = 256;
 constexpr int kMaxA = 64;
+constexpr int64_t kMaxLossBlocks = 4096;  // 16 workgroups per CU: enough to saturate HBM, few enough to fold quickly
+
+inline int64_t loss_blocks(int64_t M) {
+    const int64_t n = ceil_div(M, kLossThreads);
+    return n < kMaxLossBlocks ? n : kMaxLossBlocks;
+}
 
 template <int A_T>
 __global__ __launch_bounds__(kLossThreads) void loss_kernel(
@@ -53,9 +59,10 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
     float *__restrict__ dvalue, double *__restrict__ partial) {
     __shared__ double sm[kLossThreads / 64];
     const int A = A_T > 0 ? A_T : A_rt;
-    const int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x;
     double t_clip = 0.0, t_vf = 0.0, t_ent = 0.0;
-    if (i < M) {
+    // a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the grid is capped (kMaxLossBlocks) so that the
+    // finalize pass folds a bounded number of partial sums, in a fixed order (deterministic)
+    for (int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x; i < M; i += (int64_t)gridDim.x * kLossThreads) {
         const int64_t row = perm ? perm[i] : first_row + i;
         const float invM = 1.0f / (float)M;
         float lg[A_T > 0 ? A_T : kMaxA];
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
             const float dent = -p * (l + h);
             dlogits[i * A + j] = g_logp * dlogp - ec * dent;
         }
-        t_clip = obj; t_vf = vf; t_ent = h;
+        t_clip += obj; t_vf += vf; t_ent += h;
     }
     const double b_clip = block_sum<double, kLossThreads>(t_clip, sm);
     const double b_vf = block_sum<double, kLossThreads>(t_vf, sm);
@@ -177,7 +184,7 @@ TSM_EXPORT int tsm_ppo_adv_stats(const float *adv, const int64_t *perm, const in
     return TSM_OK;
 }
 
-TSM_EXPORT int64_t tsm_ppo_loss_partial_elems(int64_t M) { return M <= 0 ? 0 : 4 * ceil_div(M, kLossThreads); }
+TSM_EXPORT int64_t tsm_ppo_loss_partial_elems(int64_t M) { return M <= 0 ? 0 : 4 * loss_blocks(M); }
 
 TSM_EXPORT int tsm_ppo_loss_fwd_bwd(const float *logits, const float *value, const int32_t *act,
                                     const float *logp_old, const float *adv, const float *returns,
@@ -194,7 +201,7 @@ TSM_EXPORT int tsm_ppo_loss_fwd_bwd(const float *logits, const float *value, con
     TSM_REQUIRE(cfg_host->dual_clip <= 0.0 || cfg_host->dual_clip > 1.0,
                 "Dual-clip PPO parameter should greater than 1.0 but got %g", cfg_host->dual_clip);  // ppo.py:124-126
     const Cfg cfg = to_cfg(cfg_host);
-    const dim3 grid((unsigned)ceil_div(M, kLossThreads)), block(kLossThreads);
+    const dim3 grid((unsigned)loss_blocks(M)), block(kLossThreads);
     hipStream_t st = tsm_stream(stream);
 #define LAUNCH(AT)                                                                                         \
     hipLaunchKernelGGL((loss_kernel<AT>), grid, block, 0, st, logits, value, act, logp_old, adv, returns,  \
@@ -210,7 +217,7 @@ TSM_EXPORT int tsm_ppo_loss_finalize(const double *partial, int64_t M, const tsm
                                      float *scalars_out, void *stream) {
     TSM_REQUIRE(M >= 1 && partial && cfg_host && scalars_out, "tsm_ppo_loss_finalize: bad args");
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, tsm_stream(stream), partial,
-                       ceil_div(M, kLossThreads), M, (float)cfg_host->vf_coef, (float)cfg_host->ent_coef,
+                       loss_blocks(M), M, (float)cfg_host->vf_coef, (float)cfg_host->ent_coef,
                        scalars_out);
     TSM_LAUNCH_CHECK();
     return TSM_OK;

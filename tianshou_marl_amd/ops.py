@@ -243,8 +243,10 @@ def ppo_adv_stats(adv, mb_start, perm=None, out=None):
 
 
 def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, returns, cfg: tsm_ppo_cfg, adv_stats=None,
-                     v_s_old=None, perm=None, first_row=0):
-    """One minibatch -> (dlogits[M,A], dvalue[M], scalars[4]={loss, clip, vf, ent})."""
+                     v_s_old=None, perm=None, first_row=0, finalize: bool = True):
+    """One minibatch -> (dlogits[M,A], dvalue[M], scalars[4]={loss, clip, vf, ent}).
+    finalize=False leaves the per-workgroup partial sums unfolded (returned in place of `scalars`): an epoch's
+    statistics can then be folded once, as the fused path does (ppo_finalize_many)."""
     logits = _chk(logits, torch.float32, "logits")
     M, A = logits.shape
     value = _chk(value, torch.float32, "value").reshape(-1)
@@ -258,6 +260,8 @@ def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, returns, cfg: tsm_ppo_cf
          ptr(_chk(logp_old, torch.float32, "logp_old")), ptr(_chk(adv, torch.float32, "adv")),
          ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old), ptr(perm), first_row, M, A,
          ptr(adv_stats), C.byref(cfg), ptr(dlogits), ptr(dvalue), ptr(partial), s)
+    if not finalize:
+        return dlogits, dvalue, partial
     if M > 0:
         call("tsm_ppo_loss_finalize", ptr(partial), M, C.byref(cfg), ptr(scalars), s)
     return dlogits, dvalue, scalars
