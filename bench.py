@@ -96,6 +96,30 @@ def phase_times(a, algo, buf, col, reps=5):
     return t_col / reps, t_upd / reps
 
 
+def pmc_traffic(kernel: str, grid_threads: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
+    (profiles/*pmc_traffic.json, written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes with
+    the guide's gfx950 correction); None when no profile covers that kernel and grid."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    for r in json.load(open(files[-1]))["kernels"]:
+        if kernel in r["kernel"] and r["grid"] == grid_threads and r.get("fetch_KiB") is not None:
+            return r["traffic_B"]
+    return None
+
+
+def gae_grid_threads(T: int, L: int, ch: int = 4) -> int:
+    """Launch shape of tsm_gae_lanes (csrc/gae.hip pick_waves): 64 lanes x W waves per workgroup."""
+    blocks = -(-L // 64)
+    want, max_by_t, w = -(-2048 // blocks), -(-T // ch), 1
+    while w < 16 and w < want and w < max_by_t:
+        w <<= 1
+    return blocks * 64 * w
+
+
 def kernel_rooflines(a, algo, buf):
     """Live per-launch device time of the two kernels that dominate the step, on this job's own buffers:
     graph-batched launches bracketed by HIP events on the launch stream (no host gaps inside the bracket)."""
@@ -149,20 +173,22 @@ def kernel_rooflines(a, algo, buf):
     adam_s = per_launch(lambda: ops.adam_step(p_, slabs, m_, v_, 1, lr=0.0, image=img_, image_map=net.image_map))
     upd_s = step_s - adam_s
     # (2) GAE scan over the rows of this job
-    v = torch.randn(T, L, device=dev)
-    fl = torch.zeros(T, L, dtype=torch.uint8, device=dev)
+    # distinct arrays for every operand: aliased inputs would be served from L2 and flatter the HBM fraction
+    v, v2, v3 = (torch.randn(T, L, device=dev) for _ in range(3))
+    fl, fl2 = (torch.zeros(T, L, dtype=torch.uint8, device=dev) for _ in range(2))
     out = (torch.empty_like(v), torch.empty_like(v))
-    gae_s = per_launch(lambda: ops.gae_lanes(v, v, v, fl, fl, out=out))
+    gae_s = per_launch(lambda: ops.gae_lanes(v, v2, v3, fl, fl2, out=out))
     # (3) the HBM-bound kernels at the north star's roofline size (n_env=4096, n_agent=8, T=25: 819 200 samples)
     grid = []
     Tg, Lg = 25, 4096 * 8
-    vg = torch.randn(Tg, Lg, device=dev)
-    flg = torch.zeros(Tg, Lg, dtype=torch.uint8, device=dev)
+    vg, vg2, vg3 = (torch.randn(Tg, Lg, device=dev) for _ in range(3))
+    flg, flg2 = (torch.zeros(Tg, Lg, dtype=torch.uint8, device=dev) for _ in range(2))
     outg = (torch.empty_like(vg), torch.empty_like(vg))
-    s_g = per_launch(lambda: ops.gae_lanes(vg, vg, vg, flg, flg, out=outg))
+    s_g = per_launch(lambda: ops.gae_lanes(vg, vg2, vg3, flg, flg2, out=outg))
     grid.append({"kernel": "gae_lanes_kernel", "n_env": 4096, "n_agent": 8, "T": Tg, "bound": "hbm",
                  "bytes_per_launch": 22 * Tg * Lg, "us_per_launch": s_g * 1e6, "achieved": 22 * Tg * Lg / s_g / 1e9,
-                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 22 * Tg * Lg / s_g / HBM_PEAK})
+                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 22 * Tg * Lg / s_g / HBM_PEAK,
+                 "traffic": pmc_traffic("gae_lanes_kernel", gae_grid_threads(Tg, Lg))})
     Mg, A = Tg * Lg, net.n_act
     lg_ = torch.randn(Mg, A, device=dev)
     vals = [torch.randn(Mg, device=dev) for _ in range(4)]
@@ -173,8 +199,9 @@ def kernel_rooflines(a, algo, buf):
     loss_bytes = (8 * A + 24) * Mg  # logits + dlogits, value/act/logp_old/adv/ret read, dvalue written (64 B at A=5)
     grid.append({"kernel": "loss_kernel<5> (PPO clip loss fwd+bwd on given logits/value)", "rows": Mg, "bound": "hbm",
                  "bytes_per_launch": loss_bytes, "us_per_launch": s_l * 1e6, "achieved": loss_bytes / s_l / 1e9,
-                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": loss_bytes / s_l / HBM_PEAK})
-    del vg, flg, outg, lg_, vals, actg
+                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": loss_bytes / s_l / HBM_PEAK,
+                 "traffic": pmc_traffic("loss_kernel", 4096 * 256 if Mg > 4096 * 256 else -(-Mg // 256) * 256)})
+    del vg, vg2, vg3, flg, flg2, outg, lg_, vals, actg
     H = net.hidden
     fwd_flop = 2 * (2 * D * H + 2 * H * H + H * net.n_act + H)          # actor + critic forward per sample
     upd_flop = 3 * fwd_flop * M                                          # forward + 2x backward (~65 kFLOP)
@@ -183,13 +210,17 @@ def kernel_rooflines(a, algo, buf):
     return {
         "roofline": {"bound": "mfma", "kernel": "ppo_update_kernel<64> (fused fwd+loss+bwd, f32 MFMA)",
                      "achieved": upd_flop / upd_s / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": upd_flop / upd_s / MFMA_F32_PEAK, "traffic": None, "flop_per_launch": upd_flop,
+                     "frac": upd_flop / upd_s / MFMA_F32_PEAK, "traffic": pmc_traffic("ppo_update_kernel", nb * 256),
+                     "traffic_note": "HBM bytes per launch (PMC): dominated by the per-workgroup gradient slabs "
+                                     "(n_blocks x n_param x 4 B written, read back by adam_kernel)",
+                     "flop_per_launch": upd_flop,
                      "algorithmic_bytes_per_launch": upd_bytes, "hbm_GBps": upd_bytes / upd_s / 1e9,
                      "us_per_launch": upd_s * 1e6, "rows_per_launch": M,
                      "how": "graph of 20 x (ppo_update_kernel, adam_kernel) timed with HIP events, minus the same graph "
                             "of adam_kernel alone", "grad_step_us": step_s * 1e6, "adam_us": adam_s * 1e6},
         "roofline_gae": {"bound": "hbm", "kernel": "gae_lanes_kernel", "achieved": gae_bytes / gae_s / 1e9,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gae_bytes / gae_s / HBM_PEAK, "traffic": None,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gae_bytes / gae_s / HBM_PEAK,
+                         "traffic": pmc_traffic("gae_lanes_kernel", gae_grid_threads(T, L)),
                          "bytes_per_launch": gae_bytes, "us_per_launch": gae_s * 1e6},
         "roofline_grid": grid,
     }

@@ -354,6 +354,16 @@ int tsm_u64_add(uint64_t *counter, uint64_t inc, void *stream);
 int tsm_global_state(const float *const *obs_by_agent_host, int32_t n_agent, int64_t B, int32_t D,
                      int mode, float *out, void *stream);
 
+/* Minibatch permutations  [a14]
+ * Replaces  the np.random.permutation(length) drawn by Batch.split(shuffle=True) once per repeat
+ *           (tianshou/data/batch.py:1219 via ppo.py:179) when shuffling is done on the device.
+ * Writes n_perm pseudo-random permutations of [0, n) in ONE launch (keyed Feistel network + cycle walking, key =
+ * Philox(seed, counter + *counter_dev + p)):  out[p][i] = pi_p(i) * scale + (p / group_size) * offset_mul.
+ * counter_dev (nullable, device u64[1]) lets a captured hipGraph draw fresh permutations on every replay
+ * (advance it with tsm_u64_add). */
+int tsm_random_permutations(int64_t n, int32_t n_perm, uint64_t seed, uint64_t counter, const uint64_t *counter_dev,
+                            int64_t scale, int32_t group_size, int64_t offset_mul, int64_t *out, void *stream);
+
 /* CTDEPolicy.learn loss head  [a16]
  * Replaces  the TD target / critic MSE / policy-gradient arithmetic of CTDEPolicy.learn
  *           (tianshou/algorithm/multiagent/ctde.py:149-185) between the network forwards and `backward()`.

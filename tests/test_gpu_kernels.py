@@ -437,3 +437,47 @@ def test_global_state_fixture(golden_dir):
     np.testing.assert_allclose(ops.global_state(oba, "mean").cpu().numpy(), g["global_mean"], rtol=1e-6, atol=1e-7)
     with pytest.raises(ValueError):
         ops.global_state(oba, "attention")
+
+
+# ------------------------------------------------------------------------------------------------
+# minibatch permutations (batch.py:1219 on the device)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 255, 1000, 25600, 76800, 819200])
+def test_random_permutations_are_permutations(n):
+    n_perm = 5 if n <= 76800 else 2
+    out = ops.random_permutations(n, n_perm, seed=7, counter=11)
+    assert out.shape == (n_perm, n) and out.dtype == torch.int64
+    srt = torch.sort(out, dim=1).values
+    assert torch.equal(srt, torch.arange(n, device=DEV).expand(n_perm, n))  # bijection of [0, n): sortedness property
+    if n >= 64:
+        assert not torch.equal(out[0], out[1])  # different draws
+        assert not torch.equal(out[0], torch.arange(n, device=DEV))
+    again = ops.random_permutations(n, n_perm, seed=7, counter=11)
+    assert torch.equal(out, again)  # counter-based: reproducible
+    if n >= 64:
+        assert not torch.equal(out, ops.random_permutations(n, n_perm, seed=8, counter=11))
+
+
+def test_random_permutations_affine_map_device_counter_and_uniformity():
+    n, N, repeat = 400, 3, 2
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    out = ops.random_permutations(n, N * repeat, seed=3, counter_dev=ctr, scale=N, group_size=repeat, offset_mul=1)
+    for p in range(N * repeat):  # lane ids of agent p // repeat: row * N + agent, each row exactly once
+        a = p // repeat
+        assert torch.equal(torch.sort(out[p]).values, torch.arange(n, device=DEV) * N + a)
+    ops.call("tsm_u64_add", ops.ptr(ctr), N * repeat, ops.stream_ptr())
+    nxt = ops.random_permutations(n, N * repeat, seed=3, counter_dev=ctr, scale=N, group_size=repeat, offset_mul=1)
+    assert not torch.equal(out, nxt)  # the device counter advances the stream (graph replays draw fresh permutations)
+    assert torch.equal(nxt, ops.random_permutations(n, N * repeat, seed=3, counter=N * repeat, scale=N, group_size=repeat,
+                                                    offset_mul=1))
+    # uniformity: where element 0 lands, and which element lands first, over 4000 draws of a 50-permutation
+    m, draws = 50, 4000
+    P = ops.random_permutations(m, draws, seed=5).cpu().numpy()
+    for counts in (np.bincount(P[:, 0], minlength=m), np.bincount(np.argmax(P == 0, axis=1), minlength=m)):
+        chi2 = ((counts - draws / m) ** 2 / (draws / m)).sum()
+        assert chi2 < 100.0, chi2  # 49 dof: mean 49, 99.99th percentile ~ 94
+    # pairs are decorrelated: P(pi(0) < pi(1)) ~ 1/2
+    frac = (P[:, 0] < P[:, 1]).mean()
+    assert abs(frac - 0.5) < 0.04
+    with pytest.raises(ValueError):
+        ops.random_permutations(-1, 1, seed=0)

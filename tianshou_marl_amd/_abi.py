@@ -100,6 +100,7 @@ SIGNATURES = {
     "tsm_policy_image_map": (_int, [_i32, _i32, _i32, _p]),
     "tsm_reduce_slabs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
     "tsm_global_state": (_int, [C.POINTER(_p), _i32, _i64, _i32, _int, _p, _p]),
+    "tsm_random_permutations": (_int, [_i64, _i32, _u64, _u64, _p, _i64, _i32, _i64, _p, _p]),
     "tsm_ctde_head_partial_elems": (_i64, [_i64]),
     "tsm_ctde_td_head": (_int, [_p, _p, _i32, _p, _p, C.c_float, _p, _p, _i32, _i64, _p, _p, _p, _p, _p]),
     "tsm_mlp_param_count": (_i64, [C.POINTER(tsm_mlp_desc)]),

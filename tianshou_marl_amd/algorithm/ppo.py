@@ -60,6 +60,7 @@ class PPO(nn.Module):
         self.opt_step = 0
         self._adam_work = torch.zeros(ops.call("tsm_adam_work_elems", net.flat.numel()), dtype=torch.float32, device=dev)
         self._sample_ctr = 0  # Philox counter base for action sampling
+        self._perm_ctr = torch.zeros(1, dtype=torch.int64, device=dev)  # draw counter of the device-side permutations
         self._cfg = ops.make_ppo_cfg(eps_clip, dual_clip, value_clip, advantage_normalization, vf_coef, ent_coef)
         self._ws: dict = {}
         self._grad_sync = None  # set by parallel.attach_data_parallel
@@ -192,7 +193,8 @@ class PPO(nn.Module):
             if self.shuffle == "numpy":  # Batch.split draws np.random.permutation (batch.py:1219)
                 perm_local = torch.as_tensor(np.random.permutation(n)).to(dev)
             else:
-                perm_local = torch.randperm(n, device=dev)
+                perm_local = ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, device=dev)[0]
+                ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
             perm = perm_local if ids is None else ids[perm_local]
             stats = ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm) if self.advantage_normalization else None
             for j, (s, e) in enumerate(bounds):
@@ -276,7 +278,7 @@ class PPO(nn.Module):
                                             dtype=torch.int32, device=dev),
                      M_dev=torch.as_tensor([e - s for s, e in bounds] * (len(groups) * repeat), dtype=torch.int64,
                                            device=dev),
-                     agent_off=torch.arange(len(groups), dtype=torch.int64, device=dev).view(-1, 1, 1),
+                     perm_ctr=self._perm_ctr,
                      step_dev=torch.zeros(1, dtype=torch.int64, device=dev), v_s=f(T, L), v_next=f(T, L),
                      logp=f(T * L), ret=f(T, L), adv=f(T, L), n_steps=n_steps, flat_g=f(P.numel()))
             obs = buffer.obs_store[:T].reshape(T * L, D)
@@ -284,13 +286,24 @@ class PPO(nn.Module):
             act = buffer.act_store[:T].reshape(T * L)
             rew, term, trunc = (x[:T].reshape(T, L) for x in (buffer.rew_store, buffer.term_store, buffer.trunc_store))
 
+            if stored:
+                w["logp"] = buffer.logp_store[:T].reshape(-1)
+                if not self.recompute_adv:
+                    w["v_s"], w["v_next"] = buffer.vs_store[:T].reshape(T, L), buffer.vnext_store[:T].reshape(T, L)
+            if self.advantage_normalization and not self.recompute_adv:
+                # minibatch k of (group gi, repeat r) covers perm[gi, r][bounds[k]]: one statistics launch for all of them
+                seg = torch.arange(len(groups) * repeat, dtype=torch.int64, device=dev).view(-1, 1) * n_g
+                w["mb_start_all"] = torch.cat([(seg + w["mb_start"][:-1].view(1, -1)).reshape(-1),
+                                               torch.tensor([len(groups) * repeat * n_g], dtype=torch.int64, device=dev)])
+
             def preprocess(recompute: bool = False):
                 if stored and not recompute:
                     # logp_old / v_s / V(obs_next) were produced by the rollout kernel with these very parameters
                     # (bit-identical to recomputing them as a2c.py:121-127 / ppo.py:157-161 do)
-                    w["v_s"].copy_(buffer.vs_store[:T].reshape(T, L))
-                    w["v_next"].copy_(buffer.vnext_store[:T].reshape(T, L))
-                    w["logp"].copy_(buffer.logp_store[:T].reshape(-1))
+                    # the buffer stores are static allocations: the graph reads them in place (w[...] alias them)
+                    if self.recompute_adv:  # later repeats overwrite v_s / v_next: work on copies
+                        w["v_s"].copy_(buffer.vs_store[:T].reshape(T, L))
+                        w["v_next"].copy_(buffer.vnext_store[:T].reshape(T, L))
                 else:
                     # recompute_advantage refreshes the critic values only; logp_old stays (ppo.py:174-178)
                     ops.policy_forward(P, obs, A, H, mode="none" if recompute else "given", act=act,
@@ -303,14 +316,23 @@ class PPO(nn.Module):
                               out=(w["ret"], w["adv"]))
 
             def body():
+                if self.shuffle == "device":
+                    # every permutation of this update (one per agent group and repeat, batch.py:1219) in ONE launch;
+                    # the draw counter is the device-resident optimizer step count (it advances by >= one per permutation
+                    # and update), so each replay of the graph draws fresh permutations without a counter kernel
+                    ops.random_permutations(n_g, len(groups) * repeat, self.seed ^ 0x5DEECE66D, counter_dev=w["step_dev"],
+                                            scale=N if per_agent else 1, group_size=repeat,
+                                            offset_mul=1 if per_agent else 0, out=w["perm"])
                 preprocess()
+                if "mb_start_all" in w:
+                    ops.ppo_adv_stats(w["adv"], w["mb_start_all"], perm=w["perm"].view(-1), out=w["stats"].view(-1, 2))
                 k = 0
                 for gi in range(len(groups)):
                     for r in range(repeat):
                         if self.recompute_adv and r > 0:
                             preprocess(recompute=True)
                         perm = w["perm"][gi, r]
-                        if self.advantage_normalization:
+                        if self.advantage_normalization and "mb_start_all" not in w:
                             ops.ppo_adv_stats(w["adv"], w["mb_start"], perm=perm, out=w["stats"][gi, r])
                         for j, (s, e) in enumerate(bounds):
                             nb = ops.ppo_update_grid(e - s)
@@ -356,16 +378,12 @@ class PPO(nn.Module):
                 for r in range(repeat):
                     pl = torch.as_tensor(np.random.permutation(n_g)).to(dev)
                     g["perm"][gi, r].copy_(pl if a is None else pl * N + a)
-        else:  # all permutations of this update in three launches: keys -> segmented argsort -> lane ids
-            keys = torch.rand(len(groups) * repeat, n_g, device=dev)
-            pl = torch.argsort(keys, dim=1).view(len(groups), repeat, n_g)
-            if per_agent:
-                torch.add(pl * N, g["agent_off"], out=g["perm"])
-            else:
-                g["perm"].copy_(pl)
-        g["step_dev"].fill_(self.opt_step)
+        # shuffle == "device": the permutations are drawn inside the graph (tsm_random_permutations)
+        if g.get("step_host") != self.opt_step:  # the device-side step count is stale (eager updates, a loaded checkpoint)
+            g["step_dev"].fill_(self.opt_step)
         g["graph"].replay()
         self.opt_step += g["n_steps"]
+        g["step_host"] = self.opt_step
         self.param_version += 1
         # loss statistics: async D2H into a pinned ring; the host only blocks when the stats are read
         ring = g.setdefault("ring", [])

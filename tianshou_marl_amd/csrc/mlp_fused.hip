@@ -124,21 +124,21 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
             if (cfg.value_clip) rin.v_old = v_s_old[src];
         }
     };
-    // order matters (vector memory returns in issue order): row ids first, then the weight image, and the
-    // id-dependent gathers last, so that no round trip is serialised behind another
+    // two memory round trips in all: (1) the row ids, (2) the id-dependent gathers together with the weight image,
+    // which goes global -> LDS by DMA.  The DMA is issued LAST: vector memory returns in issue order and, with a DMA
+    // outstanding, hipcc waits for everything at the next use of a load result -- the only such use before the
+    // barrier is that of the row ids, which happens before the DMA is issued.
     int64_t xs[kXRegs];
     int64_t rsrc = -1;
     const bool have_tile = (int64_t)blockIdx.x < n_tiles;
     if (have_tile) {
         prefetch_tile_ids(xs, d, perm, first, (int64_t)blockIdx.x * R, M);
         rsrc = row_id((int64_t)blockIdx.x * R);
-    }
-    if (img) stage_image<H>(lds, ly, img);
-    else stage_weights<H>(lds, ly, d, P);
-    if (have_tile) {
         prefetch_tile_vals(xr, xs, obs);
         prefetch_row(rsrc);
     }
+    if (img) stage_image<H>(lds, ly, img);
+    else stage_weights<H>(lds, ly, d, P);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const float invM = 1.0f / (float)M;

@@ -102,15 +102,18 @@ __host__ __device__ inline int image_f4_padded(int x_floats) {
 // LDS layout W1..B3c incl. zero pads): straight 16-B copies, ~12 independent loads per thread.
 template <int H>
 __device__ __forceinline__ void stage_image(float *lds, const Lay<H> &ly, const float *__restrict__ img) {
-    const float4 *src = reinterpret_cast<const float4 *>(img);
-    float4 *dst = reinterpret_cast<float4 *>(lds);
-    // The image is padded to a whole number of kStageChunk float4 (zeros), so every thread copies full groups of
-    // 4 independent 16-B loads with no tail predicate; the copy may run a few KB past ly.X into the activation
-    // buffers, which are (re)written after staging anyway.  Latency-bound: 4 loads in flight per thread.
+    // LDS-DMA (global_load_lds_dwordx4): the image has exactly the LDS layout, so each wave instruction copies one
+    // contiguous 1-KiB piece (wave-uniform LDS base + lane * 16 B) with no VGPR round trip, and all ~12 pieces of a
+    // wave are in flight at once -- one memory round trip for the whole 48 KB instead of three.  The image is padded
+    // with zeros to a whole number of kStageChunk float4, so there is no tail predicate; the copy may run a few KB
+    // past ly.X into the activation buffers, which only ever receive zeros or are rewritten after the next barrier
+    // (the barrier drains the DMA: hipcc emits vmcnt(0) in front of it).
     const int n4p = image_f4_padded(ly.X);
-    for (int e = threadIdx.x; e < n4p; e += 4 * NT) {
-        const float4 v0 = src[e], v1 = src[e + NT], v2 = src[e + 2 * NT], v3 = src[e + 3 * NT];
-        dst[e] = v0; dst[e + NT] = v1; dst[e + 2 * NT] = v2; dst[e + 3 * NT] = v3;
+    const int wave_base = (threadIdx.x >> 6) * 64;
+    for (int e = 0; e < n4p; e += NT) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(img + (size_t)(e + threadIdx.x) * 4),
+            (__attribute__((address_space(3))) void *)(lds + (size_t)(e + wave_base) * 4), 16, 0, 0);
     }
 }
 

@@ -14,6 +14,11 @@
 namespace {
 
 // ---- advantage statistics: one 1024-thread block per minibatch, two passes in f64 ----
+// The gathered values of the first pass stay in registers (up to kStatRegs per thread = 8192 rows per minibatch), so
+// the second pass costs no memory round trip; longer minibatches re-gather the tail.  Per-thread summation order is
+// the plain strided order in both passes.
+constexpr int kStatRegs = 8;
+
 __global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict__ adv,
                                                          const int64_t *__restrict__ perm,
                                                          const int64_t *__restrict__ mb_start,
@@ -21,11 +26,29 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict
     __shared__ double sm[1024 / 64];
     const int64_t s0 = mb_start[blockIdx.x], s1 = mb_start[blockIdx.x + 1];
     const int64_t M = s1 - s0;
+    int64_t src[kStatRegs];
+    float vals[kStatRegs];
+#pragma unroll
+    for (int k = 0; k < kStatRegs; ++k) {  // all row ids first, then all gathers: two round trips in total
+        const int64_t i = s0 + threadIdx.x + 1024 * (int64_t)k;
+        src[k] = i < s1 ? (perm ? perm[i] : i) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < kStatRegs; ++k) vals[k] = src[k] >= 0 ? adv[src[k]] : 0.f;
     double acc = 0.0;
-    for (int64_t i = s0 + threadIdx.x; i < s1; i += 1024) acc += (double)adv[perm ? perm[i] : i];
+#pragma unroll
+    for (int k = 0; k < kStatRegs; ++k)
+        if (src[k] >= 0) acc += (double)vals[k];
+    for (int64_t i = s0 + threadIdx.x + 1024 * (int64_t)kStatRegs; i < s1; i += 1024) acc += (double)adv[perm ? perm[i] : i];
     const double mean = block_sum<double, 1024>(acc, sm) / (double)M;
     acc = 0.0;
-    for (int64_t i = s0 + threadIdx.x; i < s1; i += 1024) {
+#pragma unroll
+    for (int k = 0; k < kStatRegs; ++k)
+        if (src[k] >= 0) {
+            const double d = (double)vals[k] - mean;
+            acc += d * d;
+        }
+    for (int64_t i = s0 + threadIdx.x + 1024 * (int64_t)kStatRegs; i < s1; i += 1024) {
         const double d = (double)adv[perm ? perm[i] : i] - mean;
         acc += d * d;
     }

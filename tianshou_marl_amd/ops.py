@@ -404,6 +404,21 @@ def global_state(obs_by_agent, mode: str = "concatenate") -> torch.Tensor:
     return out
 
 
+def random_permutations(n: int, n_perm: int, seed: int, counter: int = 0, counter_dev=None, scale: int = 1,
+                        group_size: int = 1, offset_mul: int = 0, out=None, device="cuda"):
+    """n_perm pseudo-random permutations of range(n) in one launch -> i64 [n_perm, n] (batch.py:1219 on device).
+    out[p, i] = pi_p(i) * scale + (p // group_size) * offset_mul."""
+    if n < 0 or n_perm < 0:
+        raise ValueError("random_permutations: negative size")
+    if out is None:
+        out = torch.empty(n_perm, n, dtype=torch.int64, device=device)
+    if out.numel() != n_perm * n:
+        raise ValueError("random_permutations: out has the wrong size")
+    call("tsm_random_permutations", n, n_perm, seed & (2**64 - 1), counter & (2**64 - 1), ptr(counter_dev), scale,
+         group_size, offset_mul, ptr(_chk(out, torch.int64, "out")), stream_ptr())
+    return out
+
+
 def ctde_td_head(q, q_next, rew, terminated, gamma: float, logits, act):
     """CTDEPolicy.learn loss head (ctde.py:149-185) -> (dq, dlogits, scalars[actor_loss, critic_loss])."""
     q, q_next = _chk(q, torch.float32, "q"), _chk(q_next, torch.float32, "q_next")
