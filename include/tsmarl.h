@@ -338,6 +338,12 @@ typedef struct {
     int64_t *ptr_out;
     double *ep_rew_out;
     int64_t *ep_len_out, *ep_idx_out;
+    /* compact record of the episodes finished during the rollout (nullable; what CollectStats needs, collector.py:
+     * 1001-1009, without shipping the dense per-step arrays to the host): i64 words
+     *   [n_env] count | [n_env][max_ep] (step << 32 | length) | [n_env][max_ep][N] f64 episode return.
+     * count may exceed max_ep (records beyond max_ep are dropped): size max_ep for the worst case. */
+    int64_t *ep_rec;
+    int32_t max_ep, _pad2;
 } tsm_rollout_desc;
 
 int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *stream);

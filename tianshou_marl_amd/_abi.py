@@ -50,7 +50,8 @@ class tsm_rollout_desc(C.Structure):
                 ("rew_store", C.c_void_p), ("logp_store", C.c_void_p), ("vs_store", C.c_void_p),
                 ("vnext_store", C.c_void_p), ("act_store", C.c_void_p), ("term_store", C.c_void_p),
                 ("trunc_store", C.c_void_p), ("ptr_out", C.c_void_p), ("ep_rew_out", C.c_void_p),
-                ("ep_len_out", C.c_void_p), ("ep_idx_out", C.c_void_p)]
+                ("ep_len_out", C.c_void_p), ("ep_idx_out", C.c_void_p),
+                ("ep_rec", C.c_void_p), ("max_ep", C.c_int32), ("_pad2", C.c_int32)]
 
 
 class tsm_mlp_desc(C.Structure):

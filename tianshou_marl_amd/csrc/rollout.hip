@@ -53,6 +53,10 @@ struct RolloutArgs {
     int64_t *ptr_out, *ep_len_out, *ep_idx_out;
     double *ep_rew_out;
     int n_steps;
+    // compact record of the episodes finished during this rollout (nullable): i64 words
+    //   [n_env] count | [n_env][max_ep] (step << 32 | length) | [n_env][max_ep][N] f64 return
+    int64_t *ep_rec;
+    int max_ep;
     long long *stamps;  // diagnostic build only (tsm_debug_set_stamps): phase time stamps of workgroup 0
 };
 
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     // sub-buffer bookkeeping of "my" env lives in registers for the whole rollout: the per-step index algebra
     // then has no dependent global loads, only fire-and-forget stores
     int64_t v_ins = 0, v_size = 0, v_eplen = 0, v_epstart = 0, v_last = 0;
+    int n_fin = 0;  // episodes this env finished during the rollout
     double v_epret[kMpeMaxN];
 #pragma unroll
     for (int k = 0; k < kMpeMaxN; ++k) v_epret[k] = 0.0;
@@ -222,14 +227,20 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
             int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
             const int64_t elen = v_eplen + 1;
             if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
+            const bool rec = tr && a.ep_rec && n_fin < a.max_ep;
+            double *rec_rew = rec ? reinterpret_cast<double *>(a.ep_rec + B + (int64_t)B * a.max_ep) +
+                                        ((int64_t)e * a.max_ep + n_fin) * N : nullptr;
 #pragma unroll
             for (int k = 0; k < kMpeMaxN; ++k) {
                 if (k < N) {
                     const double acc = v_epret[k] + (double)s_rew[el * N + k];
                     a.ep_rew_out[o * N + k] = tr ? acc : 0.0;
+                    if (rec) rec_rew[k] = acc;
                     v_epret[k] = tr ? 0.0 : acc;
                 }
             }
+            if (rec) a.ep_rec[B + (int64_t)e * a.max_ep + n_fin] = ((int64_t)t << 32) | elen;
+            n_fin += tr ? 1 : 0;
             a.ep_len_out[o] = tr ? elen : 0;
             a.ptr_out[o] = cur + (int64_t)e * a.S;
             a.ep_idx_out[o] = v_epstart + (int64_t)e * a.S;
@@ -298,6 +309,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         a.steps[e] = s_steps[el];
         vs.ins[e] = v_ins; vs.size[e] = v_size; vs.ep_len[e] = v_eplen; vs.ep_start[e] = v_epstart;
         vs.last_index[e] = v_last; vs.lengths[e] = v_size;
+        if (a.ep_rec) a.ep_rec[e] = n_fin;  // may exceed max_ep: the host treats that as an overflow
 #pragma unroll
         for (int k = 0; k < kMpeMaxN; ++k) if (k < N) vs.ep_return[(int64_t)e * N + k] = v_epret[k];
     }
@@ -340,6 +352,8 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     a.act_store = h.act_store; a.term_store = h.term_store; a.trunc_store = h.trunc_store;
     a.ptr_out = h.ptr_out; a.ep_len_out = h.ep_len_out; a.ep_idx_out = h.ep_idx_out; a.ep_rew_out = h.ep_rew_out;
     a.n_steps = h.n_steps;
+    TSM_REQUIRE(!h.ep_rec || h.max_ep >= 1, "tsm_rollout_spread: ep_rec needs max_ep >= 1");
+    a.ep_rec = h.ep_rec; a.max_ep = h.max_ep;
     a.stamps = g_tsm_stamps;
     const Lay<64> ly(a.d, false);
     const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8;
