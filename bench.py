@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--dispatch", default="per_agent", choices=["per_agent", "pooled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=64)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+                    help="c2 (default, the headline line): simple_spread N=3 shared PPO; c3: N=8 CTDE, 4096 envs")
     return ap.parse_args()
 
 
@@ -234,8 +236,95 @@ def cpu_baseline(a):
                                  repeat=a.repeat, dispatch=a.dispatch, budget_s=15.0)
 
 
+def run_c3(a, device):
+    """BASELINE configs[2] (not the headline line; `--workload c3`): simple_spread N=8 (obs 48), shared decentralized
+    actor 48-128-128-5 and centralized critic 384-128-128-8 (CTDEPolicy), num_envs=4096 on one GPU.  A step = collect
+    T=25 vector steps (actor GEMMs + categorical sampling + env step + buffer add, one hipGraph) + CTDEPolicy.learn on
+    every agent's batch with the concatenated global state (8 TD/policy-gradient steps over 102 400 rows each)."""
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.algorithm.multiagent import (CentralizedCritic, CTDEPolicy, DecentralizedActor,
+                                                        FlexibleMultiAgentPolicyManager, SimultaneousTrainer,
+                                                        agent_batches_from_buffer)
+    from tianshou_marl_amd.algorithm.ppo import policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+
+    n_env, N, T, H = 4096, 8, 25, 128
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=device, seed=1626)
+    D = env.obs_dim
+    pol = CTDEPolicy(actor=DecentralizedActor(D, 5, H, device=device, seed=1),
+                     critic=CentralizedCritic(N * D, N, H, device=device, seed=2), seed=1626)
+    mgr = FlexibleMultiAgentPolicyManager(pol, env, mode="shared")
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=device)
+    col = Collector(mgr, env, buf, async_stats=True)
+    col.reset()
+    trainer = SimultaneousTrainer(mgr)
+
+    def step():
+        with policy_within_training_step(mgr):
+            col.collect(n_step=n_env * T)
+            losses = trainer.train_step(agent_batches_from_buffer(buf, env.agents))
+        col.reset_buffer(keep_statistics=True)
+        return losses
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    e0, e1, e2 = ev(), ev(), ev()
+    with policy_within_training_step(mgr):
+        e0.record()
+        col.collect(n_step=n_env * T)
+        e1.record()
+        trainer.train_step(agent_batches_from_buffer(buf, env.agents))
+        e2.record()
+    torch.cuda.synchronize()
+    col.reset_buffer(keep_statistics=True)
+    # dominant kernel: the 384-wide critic GEMMs (forward on global_obs and global_obs_next, dgrad, wgrad) -- time the
+    # critic forward over one agent batch and price it against the f32-MFMA peak
+    R = n_env * T
+    g = torch.randn(R, N * D, device=device)
+    pol.critic(g, save=False)
+    torch.cuda.synchronize()
+    f0, f1 = ev(), ev()
+    f0.record()
+    for _ in range(10):
+        pol.critic(g, save=False)
+    f1.record()
+    torch.cuda.synchronize()
+    fwd_s = f0.elapsed_time(f1) * 1e-3 / 10
+    fwd_flop = 2 * R * (N * D * H + H * H + H * N)
+    out = {
+        "metric": "env-steps/sec (n_env x n_agent) incl. CTDE update, simple_spread N=8", "value": n_env * N * T / dt,
+        "unit": "env-steps/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "simple_spread_v3 N=8 CTDEPolicy (shared actor 48-128-128-5, centralized critic 384-128-128-8), "
+                               "num_envs=4096, T=25", "learn_calls_per_step": N, "rows_per_learn": R},
+        "collect_ms": e0.elapsed_time(e1), "ctde_update_ms": e1.elapsed_time(e2),
+        "losses_agent_0": {k: float(v) for k, v in losses["agent_0"].items()},
+        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<fwd> x3 (centralized critic forward, 384-128-128-8)",
+                     "achieved": fwd_flop / fwd_s / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": fwd_flop / fwd_s / MFMA_F32_PEAK, "traffic": None, "us_per_forward": fwd_s * 1e6,
+                     "hbm_GBps": (R * N * D * 4 + 2 * R * H * 4 * 2 + R * N * 4) / fwd_s / 1e9},
+    }
+    _ = ops
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
+    if a.workload == "c3":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        torch.cuda.set_device(0)
+        run_c3(a, torch.device("cuda", 0))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

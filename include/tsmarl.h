@@ -156,11 +156,12 @@ int tsm_gather_rows(const void *src, const int64_t *index, int64_t n, int64_t ro
  *           (tianshou/utils/net/discrete.py:22-24; reinforce.py:183-189; ppo.py:160,187,210).
  * logits [B][A] f32 row-major.  Sampling uses a counter-based Philox4x32-10 stream keyed by
  * (seed, offset + row): reproducible, order-independent, NOT bit-identical to torch's CPU RNG.
- * deterministic != 0 -> dist.mode (argmax) (reinforce.py:185-189).
+ * deterministic != 0 -> dist.mode (argmax) (reinforce.py:185-189).  offset_dev (nullable, device u64[1]) is
+ * added to `offset`, so that a captured hipGraph advances the stream from device memory.
  * ------------------------------------------------------------------------------------------- */
 int tsm_categorical_sample(const float *logits, int64_t B, int32_t A, uint64_t seed,
-                           uint64_t offset, int deterministic, int32_t *act_out, float *logp_out,
-                           void *stream);
+                           uint64_t offset, const uint64_t *offset_dev, int deterministic, int32_t *act_out,
+                           float *logp_out, void *stream);
 int tsm_categorical_logp_entropy(const float *logits, const int32_t *act, int64_t B, int32_t A,
                                  float *logp_out, float *ent_out, void *stream);
 

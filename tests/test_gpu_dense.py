@@ -43,7 +43,7 @@ def _torch_replica(net, dtype=torch.float64):
 
 
 def _close(got, want, tol=1e-5):
-    want = want.to(torch.float64)
+    want = want.detach().cpu().to(torch.float64)
     scale = max(float(want.abs().max()), 1e-30)
     err = float((got.cpu().to(torch.float64) - want).abs().max())
     assert err <= tol * scale, f"max abs err {err:.3e} vs scale {scale:.3e}"
@@ -233,3 +233,65 @@ def test_ctde_policies_train_from_the_device_buffer():
     assert set(first) == set(env.agents)
     for a in env.agents:  # the centralized critic's regression error shrinks on a fixed batch
         assert last[a]["critic_loss"] < first[a]["critic_loss"]
+
+
+@pytest.mark.parametrize("n_env", [64, 4096])
+def test_c3_ctde_pipeline_full_size(n_env):
+    """BASELINE configs[2]: simple_spread N=8 (obs 48), shared decentralized actor + centralized critic on the 384-wide
+    concatenated global state, num_envs=4096.  Size-independent properties at full size: episode bookkeeping of the
+    rollout, global-state rows, dense forward vs float64 on a row sample, loss head vs a float64 restatement, and a
+    learn() step that changes both networks."""
+    from tianshou_marl_amd.algorithm.ppo import policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+
+    N, T = 8, 25
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=4)
+    D = env.obs_dim
+    assert D == 48
+    pol = CTDEPolicy(actor=DecentralizedActor(D, 5, 128, device=DEV, seed=1),
+                     critic=CentralizedCritic(N * D, N, 128, device=DEV, seed=2), seed=9)
+    mgr = FlexibleMultiAgentPolicyManager(pol, env, mode="shared")
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=DEV)
+    col = Collector(mgr, env, buf)
+    col.reset()
+    with policy_within_training_step(mgr):
+        st = col.collect(n_step=n_env * T)
+        st2_buf_len = len(buf)
+    assert st.n_collected_episodes == n_env and (st.lens == T).all() and st2_buf_len == n_env * T
+    assert st.returns.shape == (n_env, N) and np.isfinite(st.returns).all()
+    # sampled actions follow the actor's distribution: stored logp == log_softmax(actor(obs))[act]
+    obs_all = buf.obs_store[:T].reshape(-1, D)
+    logits = FlatMLP.forward(pol.actor, obs_all, save=False)
+    ref_lp = torch.log_softmax(logits.double(), -1).gather(1, buf.act_store[:T].reshape(-1, 1).long()).squeeze(1)
+    assert float((buf.logp_store[:T].reshape(-1).double() - ref_lp).abs().max()) < 1e-5
+    counts = torch.bincount(buf.act_store[:T].reshape(-1).long(), minlength=5).double()
+    expect = torch.softmax(logits.double(), -1).sum(0)
+    assert float(((counts - expect) ** 2 / expect).sum()) < 40.0  # chi^2, 4 dof
+    batch = agent_batches_from_buffer(buf, env.agents)
+    R = n_env * T
+    assert batch.global_obs.shape == (R, N * D) and batch.agent_3.obs.shape == (R, D)
+    # the concatenated global state of a row holds every agent's observation of that joint step, in agent order
+    assert torch.equal(batch.global_obs[:, 3 * D:4 * D], batch.agent_3.obs)
+    # dense forward of the 384-wide critic vs float64 on a row sample
+    idx = torch.randint(0, R, (2048,), device=DEV)
+    q_all = pol.critic(batch.global_obs, save=False)
+    ref = _torch_replica(pol.critic)(batch.global_obs[idx].cpu().double())
+    _close(q_all[idx], ref.detach())
+    # loss head at full size vs float64 (same formulas as ctde.py:149-185)
+    ab = batch.agent_0
+    q_next = pol.critic(batch.global_obs_next, save=False)
+    lg = FlatMLP.forward(pol.actor, ab.obs, save=False)
+    dq, dl, s = ops.ctde_td_head(q_all, q_next, ab.rew, ab.terminated.to(torch.uint8), 0.99, lg, ab.act)
+    v, vn = q_all.double().mean(1), q_next.double().mean(1)
+    td = ab.rew.double() + 0.99 * vn * (1 - ab.terminated.double())
+    lp = torch.log_softmax(lg.double(), -1).gather(1, ab.act.view(-1, 1)).squeeze(1)
+    assert float(s[1]) == pytest.approx(float(((v - td) ** 2).mean()), rel=1e-5)
+    assert float(s[0]) == pytest.approx(float(-lp.mean() * (td - v).mean()), rel=1e-4, abs=1e-7)
+    _close(dq, (2 * (v - td) / (R * N)).unsqueeze(1).expand(R, N))
+    # one learn() step per agent batch on the shared policy moves both networks and returns finite losses
+    before = (pol.actor.flat.data.clone(), pol.critic.flat.data.clone())
+    out = SimultaneousTrainer(mgr).train_step(batch)
+    assert set(out) == set(env.agents) and all(np.isfinite(list(v.values())).all() for v in out.values())
+    assert not torch.equal(before[0], pol.actor.flat.data) and not torch.equal(before[1], pol.critic.flat.data)

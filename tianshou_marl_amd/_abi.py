@@ -87,7 +87,7 @@ SIGNATURES = {
     "tsm_agent_index": (_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "tsm_scatter_rows": (_int, [_p, _p, _i64, _i64, _p, _p]),
     "tsm_gather_rows": (_int, [_p, _p, _i64, _i64, _p, _p]),
-    "tsm_categorical_sample": (_int, [_p, _i64, _i32, _u64, _u64, _int, _p, _p, _p]),
+    "tsm_categorical_sample": (_int, [_p, _i64, _i32, _u64, _u64, _p, _int, _p, _p, _p]),
     "tsm_categorical_logp_entropy": (_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "tsm_ppo_adv_stats": (_int, [_p, _p, _p, _i32, _p, _p]),
     "tsm_ppo_loss_partial_elems": (_i64, [_i64]),

@@ -92,6 +92,9 @@ class CTDEPolicy(nn.Module):
         self.enable_global_info = enable_global_info
         self.discount_factor = discount_factor
         self.is_within_training_step = False
+        self.deterministic_eval = bool(kwargs.pop("deterministic_eval", False))
+        self.seed = int(kwargs.pop("seed", 0))
+        self._sample_ctr = 0
 
     @property
     def device(self) -> torch.device:
@@ -105,6 +108,26 @@ class CTDEPolicy(nn.Module):
         """Decentralized execution (ctde.py:85-119): `act` holds the actor's raw output (logits), as upstream."""
         logits, state = self.actor(self._t(batch.obs, torch.float32), state)
         return Batch(act=logits, state=state)
+
+    # ---- device rollout entry (Collector device path) ----------------------------------------------
+    def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None) -> dict:
+        """obs [..., D] in HBM -> dict(act i32, logp, value) per row: actor forward (dense.hip) + Categorical sample /
+        mode (categorical.hip).  The reference leaves turning the actor's logits into an action to the caller
+        (CTDEPolicy.forward returns the raw logits as `act`, ctde.py:119); for a Discrete action space that is a
+        Categorical(logits) draw.  `value` is 0: the centralized critic needs the global state, which only the
+        update sees."""
+        rows = obs.reshape(-1, self.actor.dims[0])
+        logits = FlatMLP.forward(self.actor, rows, save=False)
+        greedy = bool(getattr(self, "deterministic_eval", False) and not self.is_within_training_step)
+        res = (out["act"], out["logp"]) if out is not None else None
+        act, logp = ops.categorical_sample(logits, self.seed, offset=self._sample_ctr, deterministic=greedy,
+                                           offset_dev=offset_dev, out=res)
+        if offset_dev is None:
+            self._sample_ctr += rows.shape[0]
+        if out is not None:
+            out["value"].zero_()
+            return out
+        return dict(act=act, logp=logp, value=torch.zeros_like(logp), logits=logits)
 
     def learn(self, batch: Batch, **kwargs: Any) -> dict[str, float]:
         """One centralized-critic TD step + one policy-gradient step (ctde.py:121-199)."""

@@ -14,10 +14,11 @@ namespace {
 constexpr int kMaxA = 64;
 
 __global__ void sample_kernel(const float *__restrict__ logits, int64_t B, int32_t A, uint64_t seed,
-                              uint64_t offset, int deterministic, int32_t *__restrict__ act_out,
-                              float *__restrict__ logp_out) {
+                              uint64_t offset, const uint64_t *__restrict__ offset_dev, int deterministic,
+                              int32_t *__restrict__ act_out, float *__restrict__ logp_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
+    if (offset_dev) offset += *offset_dev;
     const float *lg = logits + i * A;
     float m = -INFINITY;
     int arg = 0;
@@ -60,12 +61,13 @@ __global__ void logp_ent_kernel(const float *__restrict__ logits, const int32_t 
 }  // namespace
 
 TSM_EXPORT int tsm_categorical_sample(const float *logits, int64_t B, int32_t A, uint64_t seed, uint64_t offset,
-                                      int deterministic, int32_t *act_out, float *logp_out, void *stream) {
+                                      const uint64_t *offset_dev, int deterministic, int32_t *act_out, float *logp_out,
+                                      void *stream) {
     TSM_REQUIRE(B >= 0 && A >= 1 && A <= kMaxA, "tsm_categorical_sample: bad sizes B=%lld A=%d", (long long)B, A);
     if (B == 0) return TSM_OK;
     TSM_REQUIRE(logits && act_out, "tsm_categorical_sample: null pointer");
     hipLaunchKernelGGL(sample_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, tsm_stream(stream), logits, B,
-                       A, seed, offset, deterministic, act_out, logp_out);
+                       A, seed, offset, offset_dev, deterministic, act_out, logp_out);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

@@ -204,12 +204,17 @@ def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 # categorical head (discrete.py:22-24; reinforce.py:183-189)
 # --------------------------------------------------------------------------------------------
-def categorical_sample(logits, seed: int, offset: int = 0, deterministic: bool = False, want_logp: bool = True):
+def categorical_sample(logits, seed: int, offset: int = 0, deterministic: bool = False, want_logp: bool = True,
+                       offset_dev=None, out=None):
+    """Categorical(logits).sample() / .mode + log-prob; `out` = optional preallocated (act i32[B], logp f32[B])."""
     logits = _chk(logits, torch.float32, "logits")
     B, A = logits.shape
-    act = torch.empty(B, dtype=torch.int32, device=logits.device)
-    logp = torch.empty(B, dtype=torch.float32, device=logits.device) if want_logp else None
-    call("tsm_categorical_sample", ptr(logits), B, A, seed & (2**64 - 1), offset & (2**64 - 1),
+    if out is not None:
+        act, logp = out
+    else:
+        act = torch.empty(B, dtype=torch.int32, device=logits.device)
+        logp = torch.empty(B, dtype=torch.float32, device=logits.device) if want_logp else None
+    call("tsm_categorical_sample", ptr(logits), B, A, seed & (2**64 - 1), offset & (2**64 - 1), ptr(offset_dev),
          int(deterministic), ptr(act), ptr(logp), stream_ptr())
     return act, logp
 
