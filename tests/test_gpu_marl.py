@@ -283,3 +283,69 @@ def test_host_collect_loop_with_dummy_vector_env(n_env):
     with policy_within_training_step(algo):
         stats = algo.update(buf, batch_size=64, repeat=1)
     assert np.isfinite(list(stats.get_loss_stats_dict().values())).all()
+
+
+# ---- the reference's own Collector known-answer sequence (test/base/test_collector.py:151-230) -----------------------
+class MoveToRight:
+    """Index walks right by action 1; reaching `size` terminates with reward 1 (reference test/base/env.py)."""
+
+    def __init__(self, size):
+        self.size, self.index = size, 0
+        self.action_space = Discrete(2)
+        self.observation_space = Box(0, size - 1, (1,))
+
+    def reset(self, seed=None, **kw):
+        self.index = 0
+        return np.array([self.index], np.float32), {"key": 1}
+
+    def step(self, action):
+        self.index = self.index + 1 if int(action) == 1 else max(0, self.index - 1)
+        done = self.index == self.size
+        return np.array([self.index], np.float32), int(done), done, False, {"key": 1}
+
+    def close(self):
+        pass
+
+
+class MaxActionPolicy(torch.nn.Module if torch.cuda.is_available() else object):
+    def forward(self, batch, state=None, **kw):
+        return Batch(act=np.ones(len(batch.obs)), state=state)
+
+
+def test_collector_known_answer_layout_of_the_reference():
+    venv = DummyVectorEnv([lambda s=s: MoveToRight(s) for s in (2, 3, 4, 5)])
+    buf = DeviceVectorReplayBuffer(100, 4, n_agent=1, obs_dim=1, device=DEV)
+    col = Collector(MaxActionPolicy(), venv, buf)
+    col.reset()
+    st = col.collect(n_step=8)
+    assert st.n_collected_steps == 8 and st.n_collected_episodes == 1  # env 0 (size 2) finished once
+    obs = np.zeros(100)
+    obs[[0, 1, 25, 26, 50, 51, 75, 76]] = [0, 1, 0, 1, 0, 1, 0, 1]
+    assert np.allclose(buf.obs[:, 0, 0], obs)
+    assert np.allclose(buf[:].obs_next[..., 0, 0], [1, 2, 1, 2, 1, 2, 1, 2])
+    rews = np.zeros(100)
+    rews[[0, 1, 25, 26, 50, 51, 75, 76]] = [0, 1, 0, 0, 0, 0, 0, 0]
+    assert np.allclose(buf.rew[:, 0], rews)
+    # 4 more episodes: env 0 was reset (2 steps), the others finish what they started (1, 2, 3 steps): 8 + 8 rows
+    st = col.collect(n_episode=4)
+    assert st.n_collected_episodes == 4 and len(buf) == 16
+    assert sorted(st.lens.tolist()) == [2, 3, 4, 5] and np.allclose(st.returns, 1.0)
+    obs[[2, 3, 27, 52, 53, 77, 78, 79]] = [0, 1, 2, 2, 3, 2, 3, 4]
+    assert np.allclose(buf.obs[:, 0, 0], obs)
+    assert np.allclose(buf[:].obs_next[..., 0, 0], [1, 2, 1, 2, 1, 2, 3, 1, 2, 3, 4, 1, 2, 3, 4, 5])
+    rews[[2, 3, 27, 52, 53, 77, 78, 79]] = [0, 1, 1, 0, 1, 0, 0, 1]
+    assert np.allclose(buf.rew[:, 0], rews)
+    assert np.array_equal(buf.sample_indices(0), [0, 1, 2, 3, 25, 26, 27, 50, 51, 52, 53, 75, 76, 77, 78, 79])
+    col.collect(n_episode=4, random=True)
+    # fresh start, 8 episodes: the short envs finish more of them (3 + 2 + 2 + 1), 25 rows in all -- the reference's
+    # final obs layout [0..5], [25..30], [50..57], [75..79] (test_collector.py:214-218)
+    col.reset_env()
+    col.reset_buffer()
+    assert col.collect(n_episode=8).n_collected_episodes == 8
+    live = buf[:]
+    per_env = {0: [0, 1, 0, 1, 0, 1], 1: [0, 1, 2, 0, 1, 2], 2: [0, 1, 2, 3, 0, 1, 2, 3], 3: [0, 1, 2, 3, 4]}
+    assert np.allclose(live.obs[..., 0, 0], sum(per_env.values(), []))
+    assert np.array_equal(buf.sample_indices(0), [*range(0, 6), *range(25, 31), *range(50, 58), *range(75, 80)])
+    assert np.allclose(live.rew[:, 0], [0, 1, 0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1])
+    with pytest.raises(ValueError):
+        Collector(MaxActionPolicy(), venv, DeviceVectorReplayBuffer(9, 3, n_agent=1, obs_dim=1, device=DEV))

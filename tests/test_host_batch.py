@@ -71,6 +71,10 @@ def test_cat_and_stack():
     assert isinstance(t.a, torch.Tensor) and t.a.shape == (2, 2)
     ragged = Batch.stack([Batch(a=np.zeros(2)), Batch(a=np.zeros(3))])
     assert ragged.a.dtype == object and len(ragged.a) == 2
+    # partially shared keys: the batch that lacks a key contributes zeros (None for objects), as upstream
+    part = Batch.stack([Batch(a=1), Batch(a=2, b=3.5, c=Batch(d=np.ones(2)), s="x")])
+    assert part.a.tolist() == [1, 2] and part.b.tolist() == [0.0, 3.5] and part.c.d.tolist() == [[0, 0], [1, 1]]
+    assert part.s.tolist() == [None, "x"]
     # key order follows the first batch (never a set): quirk Q5
     order = Batch.stack([Batch(z=1, a=2, m=3), Batch(m=3, a=2, z=1)])
     assert list(order.get_keys()) == ["z", "a", "m"]

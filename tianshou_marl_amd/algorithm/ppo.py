@@ -42,6 +42,11 @@ class PPO(nn.Module):
         assert dual_clip is None or dual_clip > 1.0, f"Dual-clip PPO parameter should greater than 1.0 but got {dual_clip}"
         assert 0.0 <= gae_lambda <= 1.0, f"GAE lambda should be in [0, 1] but got: {gae_lambda}"
         self.net = net
+        # Policy attributes the collector / MARL containers read (algorithm_base.py:159-373, marl.py:79-85)
+        from ..env.spaces import Box, Discrete
+
+        self.action_space = Discrete(net.n_act)
+        self.observation_space = Box(-np.inf, np.inf, (net.obs_dim,))
         self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
         self.eps_clip, self.dual_clip, self.value_clip = eps_clip, dual_clip, value_clip
         self.advantage_normalization, self.recompute_adv = advantage_normalization, recompute_advantage

@@ -276,12 +276,14 @@ class Batch:
         if len(self.__dict__) > 0:
             batches = [Batch(dict(self.__dict__)), *batches]
         # keys are visited in the order of the FIRST batch (never set order, quirk Q5)
-        keys = [k for k in batches[0].get_keys() if all(k in b for b in batches)]
-        extra = {k for b in batches for k in b.get_keys()} - set(keys)
-        if extra:
-            raise ValueError(f"Batch.stack_ with partially shared keys {sorted(extra)} is not supported here")
+        keys = list(batches[0].get_keys())
+        for b in batches[1:]:  # partially shared keys: appended in first-appearance order
+            keys += [k for k in b.get_keys() if k not in keys]
         for k in keys:
-            vals = [b[k] for b in batches]
+            # a batch that lacks the key contributes zeros of the shape the others have (batch.py:1103-1133:
+            # "batches that do not have these keys will be padded by zeros with appropriate shapes")
+            template = next(b[k] for b in batches if k in b)
+            vals = [b[k] if k in b else _zeros_like_value(template) for b in batches]
             if all(isinstance(v, Batch) for v in vals):
                 nb = Batch()
                 nb.stack_(vals, axis)
@@ -353,6 +355,20 @@ class Batch:
             return any(any_true(v) if isinstance(v, Batch) else bool(np.any(v)) for v in b.values())
 
         return any_true(self.isnull())
+
+
+def _zeros_like_value(v):
+    """The "zero" of a leaf: 0 for numbers, None for objects, recursively for nested Batches."""
+    if isinstance(v, Batch):
+        return Batch({k: _zeros_like_value(x) for k, x in v.items()})
+    if isinstance(v, torch.Tensor):
+        return torch.zeros_like(v)
+    a = np.asarray(v)
+    if a.dtype == object:
+        out = np.empty(a.shape, dtype=object)
+        out[...] = None
+        return out
+    return np.zeros_like(a)
 
 
 def _stack_np(arrs: list[np.ndarray], axis: int) -> np.ndarray:
