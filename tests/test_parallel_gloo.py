@@ -75,6 +75,11 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
             m.mul_(0.9).add_(g, alpha=0.1)
             v.mul_(0.999).addcmul_(g, g, value=0.001)
             p.sub_(1e-3 * (m / (1 - 0.9 ** step)) / ((v / (1 - 0.999 ** step)).sqrt() + 1e-8))
+        # pre-scaled contributions + plain sum == mean (the form the update path uses: the 1/world factor is applied
+        # inside the slab-reduction kernel)
+        g = (torch.full((9,), float(rank + 1)) + torch.arange(9)) / world
+        sync.all_reduce_sum_(g)
+        assert torch.allclose(g, torch.full((9,), (1 + world) / 2.0) + torch.arange(9), rtol=0, atol=1e-6)
         np.save(os.path.join(out_dir, f"p{rank}.npy"), p.numpy())
     finally:
         dist.destroy_process_group()

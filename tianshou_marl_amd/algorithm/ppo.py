@@ -213,8 +213,8 @@ class PPO(nn.Module):
                 grads = slabs[:nb]
                 if self._grad_sync is not None:  # env-sharded data parallel: ONE flat all-reduce (parallel.py)
                     flat_g = self._ws.setdefault("flat_grad", torch.empty_like(P))
-                    ops.reduce_slabs(grads, out=flat_g)
-                    self._grad_sync.all_reduce_mean_(flat_g)
+                    ops.reduce_slabs(grads, out=flat_g, scale=1.0 / self._grad_sync.world)  # mean = sum of g_i / world
+                    self._grad_sync.all_reduce_sum_(flat_g)
                     grads = flat_g.view(1, -1)
                 ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr,
                               betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
@@ -348,8 +348,8 @@ class PPO(nn.Module):
                                                  want_scalars=False, opt_step_dev=w["step_dev"])
                             grads = w["slabs"][:nb]
                             if self._grad_sync is not None:  # env-sharded replicas: one captured RCCL all-reduce
-                                ops.reduce_slabs(grads, out=w["flat_g"])
-                                self._grad_sync.all_reduce_mean_(w["flat_g"])
+                                ops.reduce_slabs(grads, out=w["flat_g"], scale=1.0 / self._grad_sync.world)
+                                self._grad_sync.all_reduce_sum_(w["flat_g"])
                                 grads = w["flat_g"].view(1, -1)
                             ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, 1, lr=self.lr,
                                           betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,

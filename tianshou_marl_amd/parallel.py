@@ -34,6 +34,12 @@ class GradSync:
         flat.mul_(1.0 / self.world)
         return flat
 
+    def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
+        """Plain sum (the caller pre-scales its contribution by 1/world inside the slab reduction kernel, which saves
+        an elementwise launch per gradient step)."""
+        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        return flat
+
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         self.dist.broadcast(t, src=src, group=self.group)
         return t
