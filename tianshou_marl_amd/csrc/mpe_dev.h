@@ -67,8 +67,13 @@ __device__ __forceinline__ void mpe_agent_move(const MpeCfg &c, const float *ap,
         // pair force seen from the lower index (a, b) = (min, max): f_a += s*d, f_b -= s*d with d = p_a - p_b
         const int lo = i < j ? i : j, hi = i < j ? j : i;
         const float dx = ap[2 * lo] - ap[2 * hi], dy = ap[2 * lo + 1] - ap[2 * hi + 1];
-        const float dist = sqrtf(dx * dx + dy * dy);
+        const float d2 = dx * dx + dy * dy;
         const float k = c.contact_margin;
+        // far apart (the common case): z < -104, so expf(z) == 0 exactly in f32 and the contact force is exactly 0 --
+        // skip the sqrt / exp / log1p / divide chain.  The bound carries a margin of one contact_margin.
+        const float far = 2.f * c.agent_size + 105.f * k;
+        if (d2 > far * far) continue;
+        const float dist = sqrtf(d2);
         const float z = -(dist - 2.f * c.agent_size) / k;
         const float pen = (z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z))) * k;  // logaddexp(0, z) * k
         const float s = c.contact_force * pen / dist;
