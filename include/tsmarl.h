@@ -348,6 +348,31 @@ typedef struct {
 } tsm_rollout_desc;
 
 int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched simple_tag (predator-prey, two teams)  [(f)1, BASELINE configs[4]]
+ * Same role and call shape as tsm_mpe_spread_*: the vector-env step the reference performs per env through
+ * EnhancedPettingZooEnv (enhanced_pettingzoo_env.py:175-222) under DummyVectorEnv (venvs.py:237-322), for the
+ * grouped-policy / self-play / league configurations (training_coordinator.py:413-747).  Agents are ordered
+ * adversaries first (n_adv), then good agents; observations are zero-padded to the common width
+ * tsm_mpe_tag_obs_dim() = 4 + 2 n_obst + 2 (n_adv + n_good - 1) + 2 n_good (pettingzoo_env.py:55-67 requires
+ * identical spaces).  Dynamics restated from the published MPE spec: parity with pettingzoo unpinned.
+ * State: agent_pos/vel [n_env][NA][2], landmark_pos [n_env][n_obst][2].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_env, n_adv, n_good, n_obst, max_cycles, _pad;
+    double dt, damping, contact_force, contact_margin;          /* 0.1, 0.25, 100, 1e-3 */
+    double adv_size, good_size, obst_size;                       /* 0.075, 0.05, 0.2 */
+    double adv_accel, good_accel, adv_speed, good_speed;        /* 3.0, 4.0, 1.0, 1.3 */
+} tsm_mpe_tag_cfg;
+int tsm_mpe_tag_obs_dim(const tsm_mpe_tag_cfg *cfg_host);
+int tsm_mpe_tag_reset(const tsm_mpe_tag_cfg *cfg_host, uint64_t seed, uint64_t *episode_ctr,
+                      const int64_t *env_ids, int64_t n_ids, float *agent_pos, float *agent_vel,
+                      float *landmark_pos, int32_t *steps, float *obs_out, void *stream);
+int tsm_mpe_tag_step(const tsm_mpe_tag_cfg *cfg_host, uint64_t seed, uint64_t *episode_ctr, const int32_t *act,
+                     float *agent_pos, float *agent_vel, float *landmark_pos, int32_t *steps, float *obs_next_out,
+                     float *obs_cur_out, float *rew_out, uint8_t *terminated_out, uint8_t *truncated_out,
+                     uint8_t *done_env_out, int auto_reset, uint64_t *rng_tick, uint64_t rng_tick_inc, void *stream);
 int tsm_u64_add(uint64_t *counter, uint64_t inc, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

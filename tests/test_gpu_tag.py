@@ -1,0 +1,158 @@
+"""GPU tests (`-m gpu`) of the batched simple_tag env (csrc/mpe_tag.hip) and the two-team configuration built on it
+(BASELINE configs[4]): dynamics vs the numpy float64 oracle (same published spec; parity with pettingzoo itself is
+unpinned), the vector-env contract, grouped policies through the Collector, and the self-play / league trainers
+learning from the device buffer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+
+if torch.cuda.is_available():
+    import mpe_tag_oracle
+
+    from tianshou_marl_amd.algorithm.multiagent import (
+        FlexibleMultiAgentPolicyManager,
+        LeaguePlayTrainer,
+        SelfPlayTrainer,
+        agent_batches_from_buffer,
+    )
+    from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe_tag import DeviceSimpleTagVectorEnv
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("n_env,n_adv,n_good,n_obst", [(33, 3, 1, 2), (8, 2, 2, 1), (5, 1, 1, 0), (64, 4, 2, 3)])
+def test_tag_step_matches_numpy_oracle(n_env, n_adv, n_good, n_obst):
+    T = 12
+    env = DeviceSimpleTagVectorEnv(n_env, n_good, n_adv, n_obst, max_cycles=T, device=DEV, seed=3, auto_reset=False)
+    N = env.n_agent
+    assert env.obs_dim == 4 + 2 * n_obst + 2 * (N - 1) + 2 * n_good
+    assert env.agents[:n_adv] == [f"adversary_{i}" for i in range(n_adv)] and len(env.agents) == N
+    obs0 = env.reset_device().clone()
+    # squeeze the worlds so that contacts (agent-agent, agent-obstacle) and the boundary penalty actually occur
+    env.agent_pos.mul_(0.35)
+    env.agent_pos[: n_env // 2, -1] += 0.8
+    worlds = []
+    for e in range(n_env):
+        w = mpe_tag_oracle.SimpleTagWorld(n_adv, n_good, n_obst, max_cycles=T)
+        w.set_state(env.agent_pos[e].cpu().numpy(), env.agent_vel[e].cpu().numpy(), env.landmark_pos[e, :n_obst].cpu().numpy())
+        worlds.append(w)
+    assert obs0.shape == (n_env, N, env.obs_dim)
+    rng = np.random.default_rng(0)
+    saw_contact = saw_bound = False
+    for t in range(T):
+        act = rng.integers(0, 5, (n_env, N))
+        obs_next, rew, term, trunc, done = env.step_device(torch.as_tensor(act, dtype=torch.int32, device=DEV))
+        exp = [w.step(act[e]) for e, w in enumerate(worlds)]
+        exp_obs = np.stack([x[0] for x in exp])
+        exp_rew = np.stack([x[1] for x in exp])
+        np.testing.assert_allclose(obs_next.cpu().numpy(), exp_obs, rtol=2e-4, atol=2e-5)
+        got_rew = rew.cpu().numpy()
+        # contact / boundary indicators are discontinuous: compare where the float64 world is not on an edge
+        close = np.abs(got_rew - exp_rew) < 1e-3
+        assert close.mean() > 0.995, (t, close.mean())
+        saw_contact |= bool((exp_rew[:, :n_adv] > 0).any())
+        saw_bound |= bool(((exp_rew[:, n_adv:] < 0) & (exp_rew[:, n_adv:] > -10)).any())
+        assert not term.any() and bool(trunc.all()) == (t == T - 1) and bool(done.all()) == (t == T - 1)
+        # adversaries share one reward; padding of the good agents' rows stays zero
+        assert np.allclose(got_rew[:, :n_adv], got_rew[:, :1])
+        assert (obs_next[:, n_adv:, env.obs_dim - 2 * n_good + 2 * (n_good - 1):] == 0).all()
+        np.testing.assert_allclose(env.obs_cur.cpu().numpy(), exp_obs, rtol=2e-4, atol=2e-5)  # no auto reset here
+    assert saw_contact and saw_bound
+
+
+def test_tag_auto_reset_determinism_and_host_api():
+    def run(seed):
+        env = DeviceSimpleTagVectorEnv(16, device=DEV, seed=seed, max_cycles=4)
+        env.reset_device()
+        outs = []
+        for t in range(9):
+            act = torch.full((16, env.n_agent), t % 5, dtype=torch.int32, device=DEV)
+            obs_next, rew, term, trunc, done = env.step_device(act)
+            outs.append((obs_next.clone(), env.obs_cur.clone(), done.clone(), env.steps.clone()))
+        return env, outs
+
+    env, a = run(1)
+    _, b = run(1)
+    _, c = run(2)
+    for x, y in zip(a, b):
+        assert all(torch.equal(p, q) for p, q in zip(x, y))
+    assert not torch.equal(a[0][0], c[0][0])
+    for t, (obs_next, obs_cur, done, steps) in enumerate(a):
+        finished = (t + 1) % 4 == 0
+        assert bool(done.all()) == finished
+        if finished:  # the policy's next input is the reset observation (zero velocities), not the terminal one
+            assert not torch.equal(obs_next, obs_cur) and (obs_cur[:, :, :2] == 0).all() and (steps == 0).all()
+        else:
+            assert torch.equal(obs_next, obs_cur)
+    assert int(env.episode_ctr[0]) == 3  # initial reset + two auto resets
+    # numpy-style vector-env contract (parallel-mode dict layout)
+    obs, info = env.reset()
+    assert obs.shape == (16,) and set(obs[0]["observations"]) == set(env.agents) and info[3]["env_id"] == 3
+    o, r, te, tr, info = env.step(np.zeros((16, env.n_agent), int))
+    assert r.shape == (16, env.n_agent) and te.dtype == bool and o[0]["agent_ids"] == env.agents
+    with pytest.raises(ValueError):
+        DeviceSimpleTagVectorEnv(4, num_good=5, num_adversaries=5, device=DEV)
+
+
+def _team_policies(env, seed=0, **kw):
+    mk = lambda s: PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=DEV, seed=s), seed=s, use_graph=False, **kw)  # noqa: E731
+    return {"adversaries": mk(seed), "good": mk(seed + 1)}
+
+
+def test_grouped_policies_collect_and_train_on_tag():
+    n_env, T = 64, 25
+    env = DeviceSimpleTagVectorEnv(n_env, device=DEV, seed=5, max_cycles=T)
+    teams = _team_policies(env)
+    mgr = FlexibleMultiAgentPolicyManager(teams, env, mode="grouped", agent_groups=env.agent_groups)
+    assert mgr.policy_map["adversary_2"] is teams["adversaries"] and mgr.policy_map["agent_0"] is teams["good"]
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, env.n_agent, env.obs_dim, device=DEV)
+    col = Collector(mgr, env, buf)
+    col.reset()
+    with policy_within_training_step(mgr):
+        st = col.collect(n_step=n_env * T)
+        st2 = col.collect(n_step=n_env * T) if False else None
+    assert st.n_collected_episodes == n_env and st.returns.shape == (n_env, env.n_agent) and st2 is None
+    # team rewards: adversaries share theirs; the prey's is never positive
+    assert np.allclose(st.returns[:, :env.n_adv], st.returns[:, :1]) and (st.returns[:, env.n_adv:] <= 1e-6).all()
+    # every stored action was drawn from the policy of the agent's TEAM
+    from tianshou_marl_amd import ops
+
+    for a, name in enumerate(env.agents):
+        pol = mgr.policy_map[name]
+        rows = buf.obs_store[:T, :, a].reshape(-1, env.obs_dim)
+        ref = ops.policy_forward(pol.net.flat.data, rows, 5, 64, mode="given", act=buf.act_store[:T, :, a].reshape(-1))
+        assert torch.allclose(ref["logp"], buf.logp_store[:T, :, a].reshape(-1), rtol=1e-5, atol=1e-6), name
+    batch = agent_batches_from_buffer(buf, env.agents)
+    # self-play: only the prey learns; snapshots of it join the opponent pool
+    sp = SelfPlayTrainer(mgr, main_agent_id="good", snapshot_interval=2, opponent_pool_size=3)
+    team_batch = batch  # trainers index by policy key: give each team its (first member's) batch under the team name
+    team_batch["good"], team_batch["adversaries"] = batch["agent_0"], batch["adversary_0"]
+    before = {k: p.net.flat.data.clone() for k, p in teams.items()}
+    for _ in range(4):
+        out = sp.train_step(team_batch)
+        assert list(out) == ["good"] and np.isfinite(out["good"]["loss"])
+    assert not torch.equal(before["good"], teams["good"].net.flat.data)
+    assert torch.equal(before["adversaries"], teams["adversaries"].net.flat.data)
+    assert len(sp.opponent_pool) == 2 and sp._sample_opponent() is not teams["good"]
+    # a snapshot acts like the policy it was copied from (deep copy of flat parameters and their LDS image)
+    snap = sp.opponent_pool[-1]
+    obs = torch.randn(32, env.obs_dim, device=DEV)
+    assert torch.equal(ops.policy_forward(snap.net.flat.data, obs, 5, 64, image=snap.net.image, mode="mode")["act"],
+                       ops.policy_forward(teams["good"].net.flat.data, obs, 5, 64, mode="mode")["act"])
+    # league: two matched teams learn per step, ratings move with results
+    lg = LeaguePlayTrainer(mgr, matchmaking="elo", games_per_evaluation=2)
+    out = lg.train_step(team_batch)
+    assert set(out) == {"adversaries", "good"}
+    lg.update_match_result("adversaries", "good")
+    assert lg.elo_ratings["adversaries"] > 1000 > lg.elo_ratings["good"]

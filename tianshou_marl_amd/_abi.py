@@ -54,6 +54,14 @@ class tsm_rollout_desc(C.Structure):
                 ("ep_rec", C.c_void_p), ("max_ep", C.c_int32), ("_pad2", C.c_int32)]
 
 
+class tsm_mpe_tag_cfg(C.Structure):
+    _fields_ = [("n_env", C.c_int32), ("n_adv", C.c_int32), ("n_good", C.c_int32), ("n_obst", C.c_int32),
+                ("max_cycles", C.c_int32), ("_pad", C.c_int32),
+                ("dt", C.c_double), ("damping", C.c_double), ("contact_force", C.c_double), ("contact_margin", C.c_double),
+                ("adv_size", C.c_double), ("good_size", C.c_double), ("obst_size", C.c_double),
+                ("adv_accel", C.c_double), ("good_accel", C.c_double), ("adv_speed", C.c_double), ("good_speed", C.c_double)]
+
+
 class tsm_mlp_desc(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("act", C.c_int32), ("dims", C.c_int32 * 9)]
 
@@ -114,6 +122,10 @@ SIGNATURES = {
     "tsm_mpe_spread_step": (_int, [C.POINTER(tsm_mpe_cfg), _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                    _int, _p, _u64, _p]),
     "tsm_rollout_spread": (_int, [C.POINTER(tsm_rollout_desc), _p]),
+    "tsm_mpe_tag_obs_dim": (_int, [C.POINTER(tsm_mpe_tag_cfg)]),
+    "tsm_mpe_tag_reset": (_int, [C.POINTER(tsm_mpe_tag_cfg), _u64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "tsm_mpe_tag_step": (_int, [C.POINTER(tsm_mpe_tag_cfg), _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                _int, _p, _u64, _p]),
     "tsm_u64_add": (_int, [_p, _u64, _p]),
     "tsm_ppo_update_grid": (_int, [_i64, _i32]),
     "tsm_ppo_finalize_many": (_int, [_p, _i64, _p, _p, _i32, C.POINTER(tsm_ppo_cfg), _p, _p]),
@@ -123,7 +135,7 @@ SIGNATURES = {
 
 _NO_STATUS = {"tsm_abi_version", "tsm_last_error", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
               "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems",
-              "tsm_mlp_param_count", "tsm_mlp_act_elems", "tsm_ctde_head_partial_elems"}
+              "tsm_mlp_param_count", "tsm_mlp_act_elems", "tsm_ctde_head_partial_elems", "tsm_mpe_tag_obs_dim"}
 
 _lib = None
 

@@ -110,7 +110,8 @@ class CTDEPolicy(nn.Module):
         return Batch(act=logits, state=state)
 
     # ---- device rollout entry (Collector device path) ----------------------------------------------
-    def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None) -> dict:
+    def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None,
+                   row_offset: int = 0) -> dict:
         """obs [..., D] in HBM -> dict(act i32, logp, value) per row: actor forward (dense.hip) + Categorical sample /
         mode (categorical.hip).  The reference leaves turning the actor's logits into an action to the caller
         (CTDEPolicy.forward returns the raw logits as `act`, ctde.py:119); for a Discrete action space that is a
@@ -120,7 +121,7 @@ class CTDEPolicy(nn.Module):
         logits = FlatMLP.forward(self.actor, rows, save=False)
         greedy = bool(getattr(self, "deterministic_eval", False) and not self.is_within_training_step)
         res = (out["act"], out["logp"]) if out is not None else None
-        act, logp = ops.categorical_sample(logits, self.seed, offset=self._sample_ctr, deterministic=greedy,
+        act, logp = ops.categorical_sample(logits, self.seed, offset=self._sample_ctr + row_offset, deterministic=greedy,
                                            offset_dev=offset_dev, out=res)
         if offset_dev is None:
             self._sample_ctr += rows.shape[0]

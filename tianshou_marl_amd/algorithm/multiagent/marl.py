@@ -115,7 +115,8 @@ class MultiAgentPolicy(nn.Module):
                        value=torch.empty(E * N, device=dev), logits=None)
         for agent_id, policy in self._agent_policies.items():
             a = self.agent_idx[agent_id]
-            res = policy.act_device(obs[:, a].contiguous(), out=None, offset_dev=offset_dev)
+            # each agent column gets its own sampling-counter range (a policy shared by a team must not reuse draws)
+            res = policy.act_device(obs[:, a].contiguous(), out=None, offset_dev=offset_dev, row_offset=a * E)
             for k in ("act", "logp", "value"):
                 out[k].view(E, N)[:, a].copy_(res[k].view(E))
         return out

@@ -41,6 +41,12 @@ class PPO(nn.Module):
         super().__init__()
         assert dual_clip is None or dual_clip > 1.0, f"Dual-clip PPO parameter should greater than 1.0 but got {dual_clip}"
         assert 0.0 <= gae_lambda <= 1.0, f"GAE lambda should be in [0, 1] but got: {gae_lambda}"
+        self._ctor = dict(lr=lr, betas=betas, adam_eps=adam_eps, weight_decay=weight_decay, eps_clip=eps_clip,
+                          dual_clip=dual_clip, value_clip=value_clip, advantage_normalization=advantage_normalization,
+                          recompute_advantage=recompute_advantage, vf_coef=vf_coef, ent_coef=ent_coef,
+                          max_grad_norm=max_grad_norm, gae_lambda=gae_lambda, max_batchsize=max_batchsize, gamma=gamma,
+                          return_scaling=return_scaling, deterministic_eval=deterministic_eval, dispatch=dispatch,
+                          shuffle=shuffle, seed=seed, use_graph=use_graph, async_stats=async_stats)
         self.net = net
         # Policy attributes the collector / MARL containers read (algorithm_base.py:159-373, marl.py:79-85)
         from ..env.spaces import Box, Discrete
@@ -83,12 +89,15 @@ class PPO(nn.Module):
         return self.net.flat.device
 
     # ---- rollout side -------------------------------------------------------------------------
-    def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None) -> dict:
-        """obs [..., D] in HBM -> dict(act i32, logp, value) for every row (one fused kernel)."""
+    def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None,
+                   row_offset: int = 0) -> dict:
+        """obs [..., D] in HBM -> dict(act i32, logp, value) for every row (one fused kernel).
+        `row_offset` shifts the sampling counter: callers that serve several agents with one policy in separate calls
+        (MultiAgentPolicy) give each call its own counter range so that the draws are independent."""
         rows = obs.reshape(-1, self.net.obs_dim)
         mode = "mode" if (self.deterministic_eval and not self.is_within_training_step) else "sample"
         res = ops.policy_forward(self.net.flat.data, rows, self.net.n_act, self.net.hidden, image=self.net.image, mode=mode, seed=self.seed,
-                                 offset=self._sample_ctr, want_logits=out is None, offset_dev=offset_dev, out=out)
+                                 offset=self._sample_ctr + row_offset, want_logits=out is None, offset_dev=offset_dev, out=out)
         if offset_dev is None:
             self._sample_ctr += rows.shape[0]
         return res
@@ -477,6 +486,17 @@ class PPO(nn.Module):
         st = self._update_with_batch(pb, batch_size, repeat)
         return {"loss": st.loss.mean, "actor_loss": st.actor_loss.mean, "vf_loss": st.vf_loss.mean,
                 "ent_loss": st.ent_loss.mean}
+
+    def __deepcopy__(self, memo):
+        """Snapshot for opponent pools (training_coordinator.py:481-494): parameters, optimizer state and counters are
+        copied; device workspaces (captured graphs, pinned rings) are rebuilt lazily by the copy."""
+        net = DiscreteActorCritic(self.net.obs_dim, self.net.n_act, self.net.hidden, device=self.device)
+        net.flat.data.copy_(self.net.flat.data)
+        net.sync_image()
+        new = PPO(net=net, **self._ctor)
+        new.load_state_dict(self.state_dict())
+        new.train(self.training)
+        return new
 
     # ---- checkpointing (algorithm_base.py:521-541: optimizer state under "_optimizers") ----------
     def state_dict(self, *args, **kwargs):
