@@ -372,7 +372,8 @@ class PPO(nn.Module):
             if self._grad_sync is not None:
                 # every rank captures the same collective sequence; a failed capture falls back to eager launches
                 try:
-                    with torch.cuda.graph(graph):
+                    # thread_local: the process group's watchdog thread may touch the device while this thread captures
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         body()
                 except Exception as e:  # noqa: BLE001
                     import warnings

@@ -111,12 +111,15 @@ __global__ __launch_bounds__(kHeadThreads) void ctde_head_actor_grad(
     const float *__restrict__ logits, const int64_t *__restrict__ act, int32_t A, int64_t B,
     const double *__restrict__ partial, int32_t n_part, float *__restrict__ dlogits, float *__restrict__ scalars) {
     __shared__ double tot[3];
-    if (threadIdx.x < 3) {  // every block folds the partials in the same order: identical result everywhere
+    __shared__ double red[kHeadThreads / 64];
+    // every block folds the partials with the same strided + tree order: identical result everywhere
+    for (int q = 0; q < 3; ++q) {
         double s = 0.0;
-        for (int i = 0; i < n_part; ++i) s += partial[(int64_t)i * 3 + threadIdx.x];
-        tot[threadIdx.x] = s;
+        for (int i = threadIdx.x; i < n_part; i += kHeadThreads) s += partial[(int64_t)i * 3 + q];
+        s = block_sum<double, kHeadThreads>(s, red);
+        if (threadIdx.x == 0) tot[q] = s;
+        __syncthreads();
     }
-    __syncthreads();
     const double mean_adv = tot[0] / (double)B, mean_logp = tot[1] / (double)B;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scalars[0] = (float)(-mean_logp * mean_adv);

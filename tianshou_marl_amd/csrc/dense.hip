@@ -100,14 +100,32 @@ __device__ __forceinline__ void store_kmajor(float *tile, const float (&v)[4], i
     for (int i = 0; i < 4; ++i) tile[(r4 + i) * LDT + k] = v[i];
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+// G > 1: intra-workgroup split-K.  G groups of 4 waves each walk 1/G of the workgroup's k range with their own LDS
+// tiles; their accumulators are then folded through LDS in group order (deterministic) by group 0, which runs the
+// epilogue.  Used for weight gradients of small layers, where (output tiles x slabs) alone cannot fill the chip and the
+// k loop over the batch is latency-bound.
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, int G>
+__global__ __launch_bounds__(NT * G) void gemm_kernel(GemmArgs g) {
+    constexpr int kTile = (BM + BN) * LDT;  // one A tile + one B tile
+    __shared__ __attribute__((aligned(16))) float lds_all[G][2 * kTile];
+    const int grp = threadIdx.x / NT;
+    float *const lds_g = lds_all[grp];  // tile pair `buf` of this group: A at lds_g + buf * kTile, B behind it
+    const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
-    const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+    int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+    int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+    int64_t n_iter = 0;  // identical for every group: the barriers inside the k loop are workgroup-wide
+    if (G > 1) {
+        const int64_t span = kend > kbeg ? kend - kbeg : 0;
+        const int64_t per = (((span + G - 1) / G + BK - 1) / BK) * BK;  // whole tiles per group
+        n_iter = per / BK;
+        const int64_t b2 = kbeg + (int64_t)grp * per;
+        const int64_t e2 = b2 + per < kend ? b2 + per : kend;
+        kbeg = b2 < kend ? b2 : kend;
+        kend = e2 > kbeg ? e2 : kbeg;
+    } else {
+        n_iter = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    }
     const int64_t ones_n = EPI == EPI_WGRAD ? g.N - 1 : -1;
 
     f4 acc[2][2];
@@ -124,21 +142,23 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
         else load_rowmajor(g.B, g.ldb, n0, g.N, k0, kend, vb, tid);
     };
     auto commit = [&](int buf) {
-        if (A_KMAJOR) store_kmajor(As[buf], va, tid); else store_rowmajor(As[buf], va, tid);
-        if (B_KMAJOR) store_kmajor(Bs[buf], vb, tid); else store_rowmajor(Bs[buf], vb, tid);
+        float *at = lds_g + buf * kTile, *bt = at + BM * LDT;
+        if (A_KMAJOR) store_kmajor(at, va, tid); else store_rowmajor(at, va, tid);
+        if (B_KMAJOR) store_kmajor(bt, vb, tid); else store_rowmajor(bt, vb, tid);
     };
 
     int buf = 0;
-    if (kbeg < kend) {
-        fetch(kbeg);
+    if (n_iter > 0) {
+        fetch(kbeg);  // (a group whose share of the range is empty stages zeros)
         commit(0);
     }
     __syncthreads();
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = k0 + BK < kend;
+    for (int64_t it = 0; it < n_iter; ++it) {
+        const int64_t k0 = kbeg + it * BK;
+        const bool more = it + 1 < n_iter;
         if (more) fetch(k0 + BK);  // global loads of the next tile fly while this one is multiplied
-        const float *a_t = As[buf] + (wm * 32 + (lane & 15)) * LDT + (lane >> 4);
-        const float *b_t = Bs[buf] + (wn * 32 + (lane & 15)) * LDT + (lane >> 4);
+        const float *a_t = lds_g + buf * kTile + (wm * 32 + (lane & 15)) * LDT + (lane >> 4);
+        const float *b_t = lds_g + buf * kTile + BM * LDT + (wn * 32 + (lane & 15)) * LDT + (lane >> 4);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             const float a0 = a_t[kk], a1 = a_t[16 * LDT + kk];
@@ -153,6 +173,28 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
         buf ^= 1;
     }
 
+    if (G > 1) {  // fold the groups' accumulators in group order; the staging tiles are free after the last barrier
+        float *mine = lds_all[grp] + tid * 16;
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mine[(i * 2 + j) * 4 + r] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+        for (int q = 1; q < G; ++q) {
+            const float *o = lds_all[q] + tid * 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += o[(i * 2 + j) * 4 + r];
+        }
+    }
     // C fragment: register r of lane l holds C[(l >> 4) * 4 + r][l & 15]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -222,7 +264,7 @@ TSM_EXPORT int tsm_mlp_forward(const tsm_mlp_desc *d, const float *params, const
         dim3 grid((unsigned)ceil_div(O, BN), (unsigned)ceil_div(B, BM), 1);
         TSM_REQUIRE(grid.y <= 65535, "tsm_mlp_forward: batch %lld too large for one launch (max %d rows)",
                     (long long)B, 65535 * BM);
-        hipLaunchKernelGGL((gemm_kernel<false, false, EPI_FWD>), grid, dim3(NT), 0, tsm_stream(stream), g);
+        hipLaunchKernelGGL((gemm_kernel<false, false, EPI_FWD, 1>), grid, dim3(NT), 0, tsm_stream(stream), g);
         TSM_LAUNCH_CHECK();
         p += O * K + O;
         in = out;
@@ -265,7 +307,11 @@ TSM_EXPORT int tsm_mlp_backward(const tsm_mlp_desc *d, const float *params, cons
             g.A = dz; g.lda = O; g.B = in; g.ldb = K; g.M = O; g.N = K + 1; g.K = B; g.k_per_split = k_per;
             g.C = slabs; g.slab_stride = n_param; g.w_off = p_off[l]; g.b_off = p_off[l] + O * K;
             dim3 grid((unsigned)ceil_div(K + 1, BN), (unsigned)ceil_div(O, BM), (unsigned)n_split);
-            hipLaunchKernelGGL((gemm_kernel<true, true, EPI_WGRAD>), grid, dim3(NT), 0, tsm_stream(stream), g);
+            // few output tiles (small layers): 4 wave-groups per workgroup split the batch range once more
+            if ((int64_t)grid.x * grid.y * grid.z < 1024)
+                hipLaunchKernelGGL((gemm_kernel<true, true, EPI_WGRAD, 4>), grid, dim3(NT * 4), 0, tsm_stream(stream), g);
+            else
+                hipLaunchKernelGGL((gemm_kernel<true, true, EPI_WGRAD, 1>), grid, dim3(NT), 0, tsm_stream(stream), g);
             TSM_LAUNCH_CHECK();
         }
         if (l > 0) {  // dgrad, multiplied by the derivative of the previous layer's activation
@@ -274,7 +320,7 @@ TSM_EXPORT int tsm_mlp_backward(const tsm_mlp_desc *d, const float *params, cons
             g.A = dz; g.lda = O; g.B = W; g.ldb = K; g.M = B; g.N = K; g.K = O; g.k_per_split = O;
             g.C = dx; g.ldc = K; g.X = in; g.ldx = K; g.act = d->act;
             dim3 grid((unsigned)ceil_div(K, BN), (unsigned)ceil_div(B, BM), 1);
-            hipLaunchKernelGGL((gemm_kernel<false, true, EPI_DGRAD>), grid, dim3(NT), 0, tsm_stream(stream), g);
+            hipLaunchKernelGGL((gemm_kernel<false, true, EPI_DGRAD, 1>), grid, dim3(NT), 0, tsm_stream(stream), g);
             TSM_LAUNCH_CHECK();
             dz = dx;
         }
