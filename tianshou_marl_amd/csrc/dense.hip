@@ -10,7 +10,7 @@
 // One tiled GEMM kernel on f32-input MFMA (v_mfma_f32_16x16x4_f32: exact f32 products and accumulation, so the
 // 1e-5 parity bar of the north star holds; bf16 inputs would not).  Workgroup = 256 threads = 4 waves in a 2x2
 // arrangement over a 64x64 output tile, each wave 32x32 = 2x2 MFMA accumulators; the K loop stages 64x16 tiles
-// of both operands through LDS (row stride 20 words: conflict-free for the MFMA operand read pattern
+// of both operands through LDS (row stride 18 words = 2 x odd: conflict-free on the 32-bank LDS for the MFMA operand read pattern
 // lane -> [lane & 15][lane >> 4], and 16-B aligned for vector stores), double buffered.
 // Three instantiations cover a layer:
 //   forward   Y[B,O]  = act(X[B,K] . W[O,K]^T + b)                   A row-major, B row-major([N,K])
@@ -24,7 +24,7 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4, NT = 256;  // a k tile = BK / 16 sub-tiles of 16, staged side by side
+constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 2, NT = 256;  // a k tile = BK / 16 sub-tiles of 16, staged side by side
 // (BK = 32 measured slower on MI355X: 29.6 % vs 34.3 % of the f32-MFMA peak on the 384-128-128-8 critic forward)
 constexpr int KS = BK / 16;
 
@@ -54,46 +54,50 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
     return 1.f;
 }
 
-// tile[r][k] <- src[(r0 + r) * ld + k0 + k]   (contiguous along k)
+// tile[r][k] <- src[(r0 + r) * ld + k0 + k]   (contiguous along k).  `fast` is workgroup-uniform: the whole 64x16 piece
+// is in bounds and every row start is 16-B aligned -> one unconditional 16-B load per thread (the compiler can then
+// issue it early and wait for it late); edge pieces take the guarded path.
 __device__ __forceinline__ void load_rowmajor(const float *__restrict__ src, int64_t ld, int64_t r0, int64_t R,
-                                              int64_t k0, int64_t kend, float (&v)[4], int tid) {
+                                              int64_t k0, int64_t kend, float (&v)[4], int tid, bool fast) {
     const int r = tid >> 2, k4 = (tid & 3) * 4;
     const int64_t row = r0 + r, k = k0 + k4;
+    if (fast) {
+        const float4 q = *reinterpret_cast<const float4 *>(src + row * ld + k);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        return;
+    }
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (row >= R) return;
     const float *p = src + row * ld + k;
-    if (k + 3 < kend && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-        const float4 q = *reinterpret_cast<const float4 *>(p);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (k + i < kend) v[i] = p[i];
-    }
+    for (int i = 0; i < 4; ++i)
+        if (k + i < kend) v[i] = p[i];
 }
 __device__ __forceinline__ void store_rowmajor(float *tile, const float (&v)[4], int tid, int koff) {
     const int r = tid >> 2, k4 = (tid & 3) * 4 + koff;
-    *reinterpret_cast<float4 *>(tile + r * LDT + k4) = make_float4(v[0], v[1], v[2], v[3]);
+    // row stride 18 words (2 x odd): conflict-free operand reads on the 32-bank LDS; rows are 8-B aligned only
+    *reinterpret_cast<float2 *>(tile + r * LDT + k4) = make_float2(v[0], v[1]);
+    *reinterpret_cast<float2 *>(tile + r * LDT + k4 + 2) = make_float2(v[2], v[3]);
 }
 
 // tile[r][k] <- src[(k0 + k) * ld + r0 + r]   (contiguous along r); `ones_r` = index of a virtual all-ones row
 __device__ __forceinline__ void load_kmajor(const float *__restrict__ src, int64_t ld, int64_t r0, int64_t R,
-                                            int64_t k0, int64_t kend, int64_t ones_r, float (&v)[4], int tid) {
+                                            int64_t k0, int64_t kend, int64_t ones_r, float (&v)[4], int tid, bool fast) {
     const int k = tid >> 4, r4 = (tid & 15) * 4;
     const int64_t kk = k0 + k, row = r0 + r4;
+    if (fast) {
+        const float4 q = *reinterpret_cast<const float4 *>(src + kk * ld + row);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        return;
+    }
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (kk >= kend) return;
     const float *p = src + kk * ld + row;
     const int64_t Rdata = ones_r >= 0 ? ones_r : R;
-    if (row + 3 < Rdata && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-        const float4 q = *reinterpret_cast<const float4 *>(p);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (row + i < Rdata) v[i] = p[i];
-            else if (row + i == ones_r) v[i] = 1.f;
-        }
+    for (int i = 0; i < 4; ++i) {
+        if (row + i < Rdata) v[i] = p[i];
+        else if (row + i == ones_r) v[i] = 1.f;
     }
 }
 __device__ __forceinline__ void store_kmajor(float *tile, const float (&v)[4], int tid, int koff) {
@@ -136,14 +140,19 @@ __global__ __launch_bounds__(NT * G) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
+    // workgroup-uniform "no edge, aligned" predicates of the two operands (the k extent is checked per tile)
+    const auto al16 = [](const float *p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; };
+    const bool a_in = al16(g.A, g.lda) && m0 + BM <= g.M;
+    const bool b_in = al16(g.B, g.ldb) && n0 + BN <= (ones_n >= 0 ? ones_n : g.N);
     float va[KS][4], vb[KS][4];
     auto fetch = [&](int64_t k0) {
 #pragma unroll
         for (int h = 0; h < KS; ++h) {
-            if (A_KMAJOR) load_kmajor(g.A, g.lda, m0, g.M, k0 + 16 * h, kend, -1, va[h], tid);
-            else load_rowmajor(g.A, g.lda, m0, g.M, k0 + 16 * h, kend, va[h], tid);
-            if (B_KMAJOR) load_kmajor(g.B, g.ldb, n0, g.N, k0 + 16 * h, kend, ones_n, vb[h], tid);
-            else load_rowmajor(g.B, g.ldb, n0, g.N, k0 + 16 * h, kend, vb[h], tid);
+            const bool k_in = k0 + 16 * (h + 1) <= kend;
+            if (A_KMAJOR) load_kmajor(g.A, g.lda, m0, g.M, k0 + 16 * h, kend, -1, va[h], tid, a_in && k_in);
+            else load_rowmajor(g.A, g.lda, m0, g.M, k0 + 16 * h, kend, va[h], tid, a_in && k_in);
+            if (B_KMAJOR) load_kmajor(g.B, g.ldb, n0, g.N, k0 + 16 * h, kend, ones_n, vb[h], tid, b_in && k_in);
+            else load_rowmajor(g.B, g.ldb, n0, g.N, k0 + 16 * h, kend, vb[h], tid, b_in && k_in);
         }
     };
     auto commit = [&](int buf) {
