@@ -250,3 +250,50 @@ def test_graph_replay_equals_eager_launches():
         assert np.array_equal(a, b)
     assert np.array_equal(p_e, p_g)
     assert l_e == l_g
+
+
+def test_wrapped_subbuffers_gae_matches_oracle_and_update_runs(oracle):
+    """Sub-buffers that wrapped around (more rows collected than slots): the stored rows are rotated and the episode
+    the wrap cut in half starts mid-way.  Returns/advantages of the preprocessing pass must equal the oracle's GAE on
+    the time-ordered rows (ragged path of tsm_gae_lanes: env_start / env_len), and update() falls back to explicit
+    index lists."""
+    n_env, N, T, S = 6, 3, 7, 10
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=2)
+    net = DiscreteActorCritic(env.obs_dim, env.n_act, 64, device=DEV, seed=2)
+    algo = PPO(net=net, seed=2, shuffle="numpy", use_graph=True)
+    buf = DeviceVectorReplayBuffer(n_env * S, n_env, N, env.obs_dim, device=DEV)
+    col = Collector(algo, env, buf)
+    col.reset()
+    with policy_within_training_step(algo):
+        col.collect(n_step=n_env * 8)
+        col.collect(n_step=n_env * 5)  # 13 rows per env into 10 slots: wrapped, insertion index 3
+        assert len(buf) == n_env * S and buf.index.insertion_idx.cpu().tolist() == [3] * n_env
+        pb = algo._preprocess_batch(buf)
+        v_s = ops.policy_forward(net.flat.data, buf.obs_store.reshape(-1, env.obs_dim), 5, 64, mode="none")["value"].view(S, n_env, N)
+        v_n = ops.policy_forward(net.flat.data, buf.obs_next_store.reshape(-1, env.obs_dim), 5, 64, mode="none")["value"].view(S, n_env, N)
+        order = (np.arange(S) + 3) % S  # oldest stored row first
+        g = lambda x: x.cpu().numpy()[order]  # noqa: E731
+        ret_o, adv_o = oracle.gae_lanes(g(v_s).reshape(S, -1), g(v_n).reshape(S, -1), g(buf.rew_store).reshape(S, -1),
+                                        g(buf.term_store).reshape(S, -1), g(buf.trunc_store).reshape(S, -1), 0.99, 0.95)
+        back = np.argsort(order)  # time order -> slot order
+        np.testing.assert_allclose(pb["adv"].view(S, -1).cpu().numpy(), adv_o[back], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(pb["ret"].view(S, -1).cpu().numpy(), ret_o[back], rtol=1e-5, atol=1e-6)
+        before = net.flat.data.clone()
+        st = algo.update(buf, batch_size=32, repeat=1)
+    assert all(np.isfinite(v) for v in st.get_loss_stats_dict().values())
+    assert not torch.equal(before, net.flat.data)
+
+
+def test_nan_in_buffer_raises_malformed_buffer_error():
+    from tianshou_marl_amd._abi import MalformedBufferError
+
+    env = DeviceSimpleSpreadVectorEnv(4, 3, max_cycles=5, device=DEV, seed=1)
+    algo = PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=DEV, seed=1))
+    buf = DeviceVectorReplayBuffer(4 * 5, 4, 3, env.obs_dim, device=DEV)
+    col = Collector(algo, env, buf, raise_on_nan_in_buffer=True)
+    col.reset()
+    with policy_within_training_step(algo):
+        col.collect(n_step=8)  # fine
+        env.agent_vel[2, 1, 0] = float("nan")  # a poisoned env state propagates into the stored observations
+        with pytest.raises(MalformedBufferError, match="NaN"):
+            col.collect(n_step=4)
