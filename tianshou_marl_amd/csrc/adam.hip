@@ -20,6 +20,16 @@ namespace {
 
 constexpr int kCols = 64;  // parameters per workgroup
 
+__device__ __forceinline__ double ipow(double b, int64_t e) {
+    double r = 1.0;
+    while (e > 0) {
+        if (e & 1) r *= b;
+        b *= b;
+        e >>= 1;
+    }
+    return r;
+}
+
 __device__ __forceinline__ float slab_sum_block(const float *__restrict__ slabs, int32_t n_slab, int64_t n,
                                                 int64_t i, float *sm /* [4][64] */) {
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -27,7 +37,14 @@ __device__ __forceinline__ float slab_sum_block(const float *__restrict__ slabs,
     if (i < n) {
         int s = sl;
 #pragma unroll 1
-        for (; s + 28 < n_slab; s += 32) {  // 8 independent loads in flight per lane
+        for (; s + 60 < n_slab; s += 64) {  // 16 independent loads in flight per lane (32 measured no faster)
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += t[u];
+        }
+        for (; s + 28 < n_slab; s += 32) {
             float t[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * n + i];
@@ -87,9 +104,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
     if (sl != 0 || i >= n) return;
     // bias corrections from the (host or device-resident) step count, in f64 like torch's python scalars
-    const double step = (double)(step_dev ? *step_dev : step_host);
-    const float step_size = (float)(lr / (1.0 - pow(beta1d, step)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2d, step));
+    // beta^step by repeated squaring in f64 (step is an integer; ~20 multiplies instead of the pow() routine)
+    const int64_t step = step_dev ? *step_dev : step_host;
+    const float step_size = (float)(lr / (1.0 - ipow(beta1d, step)));
+    const float bc2_sqrt = (float)sqrt(1.0 - ipow(beta2d, step));
     const float beta1 = (float)beta1d, beta2 = (float)beta2d;
     const float pi = p[i];
     if (weight_decay != 0.f) g += weight_decay * pi;
