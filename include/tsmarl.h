@@ -434,7 +434,11 @@ int64_t tsm_mlp_act_elems(const tsm_mlp_desc *desc, int64_t B);
 int tsm_mlp_forward(const tsm_mlp_desc *desc, const float *params, const float *x, int64_t B, float *acts,
                     void *stream);
 int tsm_mlp_backward(const tsm_mlp_desc *desc, const float *params, const float *x, int64_t B, const float *acts,
-                     const float *d_out, float *d_acts, int32_t n_split, float *slabs, void *stream);
+                     const float *d_out, float *d_acts, int32_t n_split, float *slabs, int64_t slab_stride,
+                     void *stream);
+/* slab_stride: distance in floats between consecutive slabs (0 = this net's parameter count).  A larger stride lets
+ * several networks write their gradients side by side into the slabs of ONE joint parameter vector (actor + critic
+ * under one optimizer with a global gradient-norm clip, algorithm_base.py:485-498). */
 
 #ifdef __cplusplus
 }

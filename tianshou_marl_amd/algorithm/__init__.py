@@ -1,4 +1,5 @@
 """Algorithms on the device-resident rollout (mirror of tianshou.algorithm for the north-star path)."""
 from .ppo import PPO, policy_within_training_step
+from .ppo_generic import GenericPPO
 
-__all__ = ["PPO", "policy_within_training_step"]
+__all__ = ["PPO", "GenericPPO", "policy_within_training_step"]

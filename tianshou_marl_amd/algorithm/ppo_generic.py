@@ -1,0 +1,204 @@
+"""GenericPPO -- the same PPO as `algorithm/ppo.py`, for actor / critic MLPs of ANY width (and a centralized critic).
+
+`PPO` runs on the fused 64-wide kernels (csrc/mlp_fused.hip: hidden size 64, obs <= 64).  Reference users configure
+`Net(hidden_sizes=[128, 128])`, tanh nets, deeper nets, or a centralized critic over the concatenated global state; for
+those this class composes the general kernels instead:
+    actor / critic forward + backward   csrc/dense.hip      (f32-MFMA tiled GEMMs, `FlatMLP`)
+    Categorical sample / log-prob       csrc/categorical.hip
+    GAE                                 csrc/gae.hip
+    PPO loss forward + backward         csrc/ppo_loss.hip   (on given logits / value -> dlogits, dvalue)
+    clip_grad_norm_ + Adam              csrc/adam.hip       (ONE optimizer over actor + critic, as ActorCritic does)
+Interface, hyper-parameters, per-agent dispatch, statistics and the reference call sites are those of `PPO`
+(ppo.py:17-224, a2c.py:113-151, marl.py:208-268).  Launches are eager (no hipGraph capture yet).
+`critic_input="global"`: the critic sees the env's joint observation `[N * obs_dim]` (GlobalStateConstructor
+"concatenate", ctde.py:291-294) and its single value is shared by the env's agents (centralized-critic PPO).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Literal
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..data.batch import Batch, split_bounds
+from ..data.buffer import DeviceVectorReplayBuffer
+from ..data.stats import A2CTrainingStats, SequenceSummaryStats
+from ..utils.net import FlatMLP, MLPActorCritic
+from .ppo import PPO
+
+
+class GenericPPO(PPO):
+    def __init__(self, *, net: MLPActorCritic, critic_input: Literal["local", "global"] = "local", n_agent: int = 1,
+                 **kwargs) -> None:
+        if not isinstance(net, MLPActorCritic):
+            raise TypeError("GenericPPO needs an MLPActorCritic (use PPO for DiscreteActorCritic)")
+        kwargs["use_graph"] = False
+        super().__init__(net=net, **kwargs)
+        self.critic_input, self.n_agent = critic_input, int(n_agent)
+        want = net.obs_dim * (self.n_agent if critic_input == "global" else 1)
+        if net.critic_obs_dim != want:
+            raise ValueError(f"critic input width {net.critic_obs_dim} != {want} for critic_input={critic_input!r}")
+        self._ctor.update(critic_input=critic_input, n_agent=n_agent)
+
+    # ---- helpers --------------------------------------------------------------------------------------------------
+    def _values(self, obs_rows: torch.Tensor, joint: torch.Tensor | None) -> torch.Tensor:
+        """V for every lane row.  local: critic(row).  global: critic(joint row of the env step), repeated per agent."""
+        if self.critic_input == "local":
+            return FlatMLP.forward(self.net.critic, obs_rows, save=False).reshape(-1)
+        v = FlatMLP.forward(self.net.critic, joint, save=False).reshape(-1, 1)
+        return v.expand(-1, self.n_agent).reshape(-1)
+
+    # ---- rollout side -----------------------------------------------------------------------------------------------
+    def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None,
+                   row_offset: int = 0) -> dict:
+        D = self.net.obs_dim
+        rows = obs.reshape(-1, D)
+        logits = FlatMLP.forward(self.net.actor, rows, save=False)
+        joint = obs.reshape(-1, self.n_agent * D) if self.critic_input == "global" else None
+        value = self._values(rows, joint)
+        greedy = bool(self.deterministic_eval and not self.is_within_training_step)
+        res = (out["act"], out["logp"]) if out is not None else None
+        act, logp = ops.categorical_sample(logits, self.seed, offset=self._sample_ctr + row_offset, deterministic=greedy,
+                                           offset_dev=offset_dev, out=res)
+        if offset_dev is None:
+            self._sample_ctr += rows.shape[0]
+        if out is not None:
+            out["value"].copy_(value)
+            return out
+        return dict(act=act, logp=logp, value=value, logits=logits)
+
+    # ---- update side ------------------------------------------------------------------------------------------------
+    def _preprocess_batch(self, buffer: DeviceVectorReplayBuffer) -> dict:
+        T, rows, env_start, env_len = self._valid_rows(buffer)
+        B, N, D = buffer.buffer_num, buffer.n_agent, buffer.obs_dim
+        if self.critic_input == "global" and N != self.n_agent:
+            raise ValueError(f"buffer holds {N} agents, the centralized critic was built for {self.n_agent}")
+        L = B * N
+        if buffer.obs_next_store is None:
+            raise ValueError("PPO.update needs a buffer that stores obs_next (ignore_obs_next=False)")
+        obs = buffer.obs_store[:T].reshape(T * L, D)
+        obs_next = buffer.obs_next_store[:T].reshape(T * L, D)
+        act = buffer.act_store[:T].reshape(T * L)
+        glob = self.critic_input == "global"
+        joint = buffer.obs_store[:T].reshape(T * B, N * D) if glob else None
+        joint_next = buffer.obs_next_store[:T].reshape(T * B, N * D) if glob else None
+        v_s = self._values(obs, joint).view(T, L)
+        v_next = self._values(obs_next, joint_next).view(T, L)
+        logits = FlatMLP.forward(self.net.actor, obs, save=False)
+        logp_old, _ = ops.categorical_logp_entropy(logits, act)
+        scale = float(np.sqrt(self.ret_rms.var + self._eps)) if self.return_scaling else 1.0
+        ret, adv = ops.gae_lanes(v_s, v_next, buffer.rew_store[:T].reshape(T, L), buffer.term_store[:T].reshape(T, L),
+                                 buffer.trunc_store[:T].reshape(T, L), self.gamma, self.gae_lambda, v_scale=scale,
+                                 lanes_per_env=N, env_start=env_start, env_len=env_len)
+        if self.return_scaling:
+            un = ret * scale
+            self.ret_rms.update(un.view(T * B, N)[rows] if rows is not None else un)
+        return dict(T=T, rows=rows, obs=obs, act=act, v_s=v_s.reshape(-1).contiguous(), ret=ret.reshape(-1),
+                    adv=adv.reshape(-1), logp_old=logp_old, n_env=B, n_agent=N, joint=joint)
+
+    def _grad_step(self, pb: dict, idx: torch.Tensor, adv_stats) -> torch.Tensor:
+        """One minibatch: forward both nets, loss, backward into joint slabs, clip + Adam.  Returns the 4 scalars."""
+        net = self.net
+        x = ops.gather_rows(pb["obs"], idx)
+        cx = x if pb["joint"] is None else ops.gather_rows(pb["joint"], torch.div(idx, pb["n_agent"], rounding_mode="floor"))
+        logits = FlatMLP.forward(net.actor, x, save=True)
+        value = FlatMLP.forward(net.critic, cx, save=True).reshape(-1)
+        dlogits, dvalue, scalars = ops.ppo_loss_fwd_bwd(
+            logits, value, pb["act"], pb["logp_old"], pb["adv"], pb["ret"], self._cfg, adv_stats=adv_stats,
+            v_s_old=pb["v_s"] if self.value_clip else None, perm=idx)
+        M, n_total = idx.numel(), net.flat.numel()
+        n_split = ops.mlp_n_split(M)
+        slabs = self._ws.get(("slabs", n_split))
+        if slabs is None:
+            slabs = self._ws[("slabs", n_split)] = torch.empty(n_split, n_total, dtype=torch.float32, device=self.device)
+        net.actor.backward(dlogits, n_split, slabs=slabs, slab_stride=n_total)
+        net.critic.backward(dvalue.view(M, 1), n_split, slabs=slabs[:, net.n_actor:], slab_stride=n_total)
+        self.opt_step += 1
+        grads = slabs
+        if self._grad_sync is not None:
+            flat_g = self._ws.setdefault("flat_grad", torch.empty_like(net.flat.data))
+            ops.reduce_slabs(grads, out=flat_g, scale=1.0 / self._grad_sync.world)
+            self._grad_sync.all_reduce_sum_(flat_g)
+            grads = flat_g.view(1, -1)
+        ops.adam_step(net.flat.data, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr, betas=self.betas,
+                      eps=self.adam_eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
+                      work=self._adam_work)
+        return scalars
+
+    def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
+                           buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:
+        ids = self._sample_ids(pb, agent)
+        dev = self.device
+        n = ids.numel() if ids is not None else pb["obs"].shape[0]
+        if ids is None:
+            ids = torch.arange(n, dtype=torch.int64, device=dev)
+        bounds = split_bounds(n, batch_size or -1, merge_last=True)
+        mb_start = torch.as_tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=dev)
+        scal = []
+        for step in range(repeat):
+            if self.recompute_adv and step > 0:
+                pb = dict(self._preprocess_batch(buffer), logp_old=pb["logp_old"])
+            if self.shuffle == "numpy":
+                perm_local = torch.as_tensor(np.random.permutation(n)).to(dev)
+            else:
+                perm_local = ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, device=dev)[0]
+                ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
+            perm = ids[perm_local]
+            stats = ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm) if self.advantage_normalization else None
+            for j, (s, e) in enumerate(bounds):
+                scal.append(self._grad_step(pb, perm[s:e].contiguous(), None if stats is None else stats[j]))
+        self.param_version += 1
+        s_h = torch.stack(scal).cpu().numpy()
+        return A2CTrainingStats(
+            loss=SequenceSummaryStats.from_sequence(s_h[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(s_h[:, 1]),
+            vf_loss=SequenceSummaryStats.from_sequence(s_h[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(s_h[:, 3]),
+            gradient_steps=len(scal))
+
+    def learn(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
+        """One PPO pass on an explicit agent batch (training_coordinator.py:336); a centralized critic takes
+        `batch.global_obs` / `batch.global_obs_next`."""
+        dev = self.device
+        t = lambda x, dt: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))).to(dev, dt).contiguous()  # noqa: E731
+        obs, obs_next = t(batch.obs, torch.float32), t(batch.obs_next, torch.float32)
+        n = obs.shape[0]
+        act = t(batch.act, torch.int32).reshape(n)
+        if self.critic_input == "global":
+            if "global_obs" not in batch:
+                raise ValueError("GenericPPO(critic_input='global').learn needs batch.global_obs / global_obs_next")
+            joint, joint_next = t(batch.global_obs, torch.float32), t(batch.global_obs_next, torch.float32)
+            v_s = FlatMLP.forward(self.net.critic, joint, save=False).reshape(n)
+            v_next = FlatMLP.forward(self.net.critic, joint_next, save=False).reshape(n)
+        else:
+            joint = None
+            v_s = FlatMLP.forward(self.net.critic, obs, save=False).reshape(n)
+            v_next = FlatMLP.forward(self.net.critic, obs_next, save=False).reshape(n)
+        logp_old, _ = ops.categorical_logp_entropy(FlatMLP.forward(self.net.actor, obs, save=False), act)
+        term = t(batch.terminated, torch.uint8).reshape(n, 1)
+        trunc = t(batch.truncated, torch.uint8).reshape(n, 1) if "truncated" in batch else torch.zeros_like(term)
+        ret, adv = ops.gae_lanes(v_s.view(n, 1), v_next.view(n, 1), t(batch.rew, torch.float32).view(n, 1), term, trunc,
+                                 self.gamma, self.gae_lambda)
+        pb = dict(T=n, rows=None, obs=obs, act=act, v_s=v_s.contiguous(), ret=ret.reshape(-1), adv=adv.reshape(-1),
+                  logp_old=logp_old, n_env=1, n_agent=1, joint=joint)
+        st = self._update_with_batch(pb, batch_size, repeat)
+        return {"loss": st.loss.mean, "actor_loss": st.actor_loss.mean, "vf_loss": st.vf_loss.mean,
+                "ent_loss": st.ent_loss.mean}
+
+    # ---- checkpoints / snapshots ----------------------------------------------------------------------------------
+    def state_dict(self, *args, **kwargs):
+        return {"net": {"actor": self.net.actor.to_reference_state_dict(), "critic": self.net.critic.to_reference_state_dict()},
+                "flat": self.net.flat.data.clone(),
+                "_optimizers": [{"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                                 "step": self.opt_step, "lr": self.lr}],
+                "ret_rms": (self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count), "sample_ctr": self._sample_ctr}
+
+    def __deepcopy__(self, memo):
+        src = self.net
+        net = MLPActorCritic(src.obs_dim, src.n_act, tuple(src.actor.dims[1:-1]), act=src.actor.act,
+                             critic_obs_dim=src.critic_obs_dim, device=self.device)
+        ctor = copy.copy(self._ctor)
+        new = GenericPPO(net=net, **ctor)
+        new.load_state_dict(self.state_dict())
+        new.train(self.training)
+        return new

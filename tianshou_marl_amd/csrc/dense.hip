@@ -292,7 +292,7 @@ TSM_EXPORT int tsm_mlp_forward(const tsm_mlp_desc *d, const float *params, const
 
 TSM_EXPORT int tsm_mlp_backward(const tsm_mlp_desc *d, const float *params, const float *x, int64_t B,
                                 const float *acts, const float *d_out, float *d_acts, int32_t n_split,
-                                float *slabs, void *stream) {
+                                float *slabs, int64_t slab_stride, void *stream) {
     if (int rc = check_desc(d, "tsm_mlp_backward")) return rc;
     TSM_REQUIRE(B >= 1, "tsm_mlp_backward: batch must be >= 1");
     TSM_REQUIRE(n_split >= 1 && n_split <= 65535, "tsm_mlp_backward: n_split out of range");
@@ -301,6 +301,8 @@ TSM_EXPORT int tsm_mlp_backward(const tsm_mlp_desc *d, const float *params, cons
     TSM_REQUIRE(ceil_div(B, BM) <= 65535, "tsm_mlp_backward: batch too large for one launch");
     const int L = d->n_layers;
     const int64_t n_param = tsm_mlp_param_count(d);
+    TSM_REQUIRE(slab_stride == 0 || slab_stride >= n_param, "tsm_mlp_backward: slab_stride smaller than the parameter count");
+    if (slab_stride == 0) slab_stride = n_param;
     // offsets of each layer's parameters / activation block
     int64_t p_off[TSM_MLP_MAX_LAYERS], a_off[TSM_MLP_MAX_LAYERS + 1];
     {
@@ -322,7 +324,7 @@ TSM_EXPORT int tsm_mlp_backward(const tsm_mlp_desc *d, const float *params, cons
         {   // wgrad + bias grad into every slab
             GemmArgs g{};
             g.A = dz; g.lda = O; g.B = in; g.ldb = K; g.M = O; g.N = K + 1; g.K = B; g.k_per_split = k_per;
-            g.C = slabs; g.slab_stride = n_param; g.w_off = p_off[l]; g.b_off = p_off[l] + O * K;
+            g.C = slabs; g.slab_stride = slab_stride; g.w_off = p_off[l]; g.b_off = p_off[l] + O * K;
             dim3 grid((unsigned)ceil_div(K + 1, BN), (unsigned)ceil_div(O, BM), (unsigned)n_split);
             // few output tiles (small layers): 4 wave-groups per workgroup split the batch range once more
             if ((int64_t)grid.x * grid.y * grid.z < 1024)

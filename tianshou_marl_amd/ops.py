@@ -477,18 +477,24 @@ def mlp_forward(desc, params, x, acts=None):
     return acts[n - B * O:].view(B, O), acts
 
 
-def mlp_backward(desc, params, x, acts, d_out, n_split: int = 0, slabs=None):
-    """Gradient slabs [n_split, n_param] of sum(out * d_out) w.r.t. the flat parameter vector."""
+def mlp_n_split(B: int) -> int:
+    """Default number of gradient slabs for a batch of B rows."""
+    return max(1, min(64, -(-B // 256)))
+
+
+def mlp_backward(desc, params, x, acts, d_out, n_split: int = 0, slabs=None, slab_stride: int = 0):
+    """Gradient slabs [n_split, n_param] of sum(out * d_out) w.r.t. the flat parameter vector.
+    `slabs` may point INTO the slabs of a larger joint parameter vector (slab_stride = its parameter count)."""
     x, d_out = _chk(x, torch.float32, "x"), _chk(d_out, torch.float32, "d_out")
     B = x.shape[0]
     if n_split <= 0:
-        n_split = max(1, min(64, -(-B // 256)))
+        n_split = mlp_n_split(B)
     n_param = params.numel()
     if slabs is None:
         slabs = torch.empty(n_split, n_param, dtype=torch.float32, device=x.device)
     d_acts = torch.empty_like(acts)
     call("tsm_mlp_backward", C.byref(desc), ptr(params), ptr(x), B, ptr(acts), ptr(d_out), ptr(d_acts), n_split,
-         ptr(slabs), stream_ptr())
+         slabs.data_ptr(), slab_stride, stream_ptr())
     return slabs
 
 

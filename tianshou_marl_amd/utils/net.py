@@ -120,13 +120,19 @@ class FlatMLP(nn.Module):
     `forward(x)` keeps the activations of the last call so that `backward(d_out)` can produce the gradient slabs
     (the pair replaces autograd for this module).  Layer views (`weight(i)`, `bias(i)`) alias the flat vector."""
 
-    def __init__(self, dims, act: str = "relu", device: str | torch.device = "cuda", seed: int | None = None) -> None:
+    def __init__(self, dims, act: str = "relu", device: str | torch.device = "cuda", seed: int | None = None,
+                 storage: torch.Tensor | None = None) -> None:
         super().__init__()
         self.dims = [int(d) for d in dims]
         self.act = act
         self.desc = ops.mlp_desc(self.dims, act)
-        self.flat = nn.Parameter(torch.zeros(ops.mlp_param_count(self.desc), dtype=torch.float32, device=device),
-                                 requires_grad=False)
+        n = ops.mlp_param_count(self.desc)
+        if storage is None:
+            storage = torch.zeros(n, dtype=torch.float32, device=device)
+        elif storage.numel() != n or storage.dtype != torch.float32 or not storage.is_contiguous():
+            raise ValueError(f"FlatMLP: storage must be a contiguous f32 vector of {n} elements")
+        # `storage` may be a slice of a larger joint parameter vector (actor + critic under one optimizer)
+        self.flat = nn.Parameter(storage, requires_grad=False)
         self._offsets = []
         o = 0
         for i in range(len(self.dims) - 1):
@@ -182,13 +188,15 @@ class FlatMLP(nn.Module):
             self._saved = (x2, acts)
         return out.view(*lead, self.dims[-1])
 
-    def backward(self, d_out: torch.Tensor, n_split: int = 0) -> torch.Tensor:
-        """Gradient slabs [n_split, n_param] for the inputs of the last `forward(save=True)`."""
+    def backward(self, d_out: torch.Tensor, n_split: int = 0, slabs: torch.Tensor | None = None,
+                 slab_stride: int = 0) -> torch.Tensor:
+        """Gradient slabs [n_split, n_param] for the inputs of the last `forward(save=True)`; `slabs` / `slab_stride`
+        direct them into the slabs of a joint parameter vector."""
         if self._saved is None:
             raise RuntimeError("FlatMLP.backward called before forward")
         x2, acts = self._saved
         return ops.mlp_backward(self.desc, self.flat.data, x2, acts, d_out.reshape(x2.shape[0], self.dims[-1]).contiguous(),
-                                n_split)
+                                n_split, slabs=slabs, slab_stride=slab_stride)
 
     # reference module key names: fc1/fc2/fc3 (ctde.py:362-364, 398-400)
     def to_reference_state_dict(self) -> OrderedDict:
@@ -201,6 +209,49 @@ class FlatMLP(nn.Module):
     @torch.no_grad()
     def load_reference_state_dict(self, sd) -> None:
         self.load_layers([(sd[f"fc{i + 1}.weight"], sd[f"fc{i + 1}.bias"]) for i in range(self.n_layers)])
+
+
+class MLPActorCritic(nn.Module):
+    """Actor and critic MLPs of ARBITRARY widths under one flat parameter vector (`ActorCritic(actor, critic)`,
+    common.py:461-474: one optimizer, one global gradient-norm clip).  Layout = actor parameters then critic parameters,
+    each in torch `parameters()` order; `actor` / `critic` are `FlatMLP` views into it (csrc/dense.hip).  Use with
+    `tianshou_marl_amd.algorithm.ppo_generic.GenericPPO` when the 64-wide fused kernels do not apply (hidden sizes
+    other than 64, more layers, tanh, or a centralized critic: `critic_obs_dim = n_agent * obs_dim`)."""
+
+    def __init__(self, obs_dim: int, n_act: int, hidden_sizes=(128, 128), act: str = "relu",
+                 critic_obs_dim: int | None = None, device: str | torch.device = "cuda", seed: int | None = None,
+                 init: str = "orthogonal") -> None:
+        super().__init__()
+        self.obs_dim, self.n_act, self.hidden = int(obs_dim), int(n_act), int(hidden_sizes[0])
+        self.critic_obs_dim = int(critic_obs_dim or obs_dim)
+        dims_a = [self.obs_dim, *hidden_sizes, self.n_act]
+        dims_c = [self.critic_obs_dim, *hidden_sizes, 1]
+        na = ops.mlp_param_count(ops.mlp_desc(dims_a, act))
+        nc = ops.mlp_param_count(ops.mlp_desc(dims_c, act))
+        self.flat = nn.Parameter(torch.zeros(na + nc, dtype=torch.float32, device=device), requires_grad=False)
+        self.n_actor, self.n_critic = na, nc
+        self.actor = FlatMLP(dims_a, act, device=device, storage=self.flat.data[:na])
+        self.critic = FlatMLP(dims_c, act, device=device, storage=self.flat.data[na:])
+        self.image = self.image_map = None  # no LDS image: the dense kernels stream the weights
+        self.reset_parameters(init, seed)
+
+    def sync_image(self) -> None:
+        return None
+
+    @torch.no_grad()
+    def reset_parameters(self, init: str = "orthogonal", seed: int | None = None) -> None:
+        """orthogonal weights + zero bias (the reference scripts' init) or nn.Linear's default."""
+        if seed is not None:
+            torch.manual_seed(seed)
+        for net in (self.actor, self.critic):
+            if init != "orthogonal":
+                net.reset_parameters(seed)
+                continue
+            for i in range(net.n_layers):
+                w = torch.empty(net.weight(i).shape)
+                nn.init.orthogonal_(w)
+                net.weight(i).copy_(w)
+                net.bias(i).zero_()
 
 
 class FlatAdam:
