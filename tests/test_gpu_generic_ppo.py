@@ -143,3 +143,29 @@ def test_generic_ppo_rollout_and_update_on_device_env(glob, hidden):
     snap = copy.deepcopy(algo)
     assert torch.equal(snap.net.flat.data, net.flat.data) and snap.net.flat.data_ptr() != net.flat.data_ptr()
     assert snap.critic_input == algo.critic_input and snap.opt_step == algo.opt_step
+
+
+def test_generic_ppo_graph_replay_equals_eager_launches():
+    """Capturing the whole update (critic passes, GAE, every gradient step) into one hipGraph changes no bit."""
+    def run(graph):
+        env = DeviceSimpleSpreadVectorEnv(16, 3, max_cycles=25, device=DEV, seed=6)
+        net = MLPActorCritic(env.obs_dim, 5, (96, 96), act="tanh", critic_obs_dim=3 * env.obs_dim, device=DEV, seed=6)
+        algo = GenericPPO(net=net, critic_input="global", n_agent=3, shuffle="numpy", seed=6, graph=graph, max_grad_norm=0.5)
+        buf = DeviceVectorReplayBuffer(16 * 25, 16, 3, env.obs_dim, device=DEV)
+        col = Collector(algo, env, buf, use_graph=False)
+        col.reset()
+        np.random.seed(9)
+        losses = []
+        for _ in range(4):  # graph mode: 1st update eager, 2nd captures + replays, 3rd / 4th replay
+            with policy_within_training_step(algo):
+                col.collect(n_step=16 * 25)
+                ts = algo.update(buf, 128, 2)
+            col.reset_buffer(keep_statistics=True)
+            losses.append(ts.get_loss_stats_dict())
+        return net.flat.data.cpu().numpy(), losses, algo.opt_step
+
+    p_e, l_e, s_e = run(False)
+    p_g, l_g, s_g = run(True)
+    assert s_e == s_g == 4 * 3 * 2 * 3  # 400 rows per agent / 128 -> 3 minibatches, 2 repeats, 3 agents, 4 updates
+    assert np.array_equal(p_e, p_g)
+    assert l_e == l_g

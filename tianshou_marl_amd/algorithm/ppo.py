@@ -276,7 +276,7 @@ class PPO(nn.Module):
         n_g = T * B if per_agent else T * L
         bounds = split_bounds(n_g, batch_size or -1, merge_last=True)
         stored = buffer.vnext_store is not None and buffer.policy_outputs_version == self.param_version
-        key = ("graph", id(buffer), T, batch_size, repeat, self.dispatch, self.lr, self.max_grad_norm, stored)
+        key = ("graph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.lr, self.max_grad_norm, stored)
         g = self._ws.get(key)
         P, A, H = self.net.flat.data, self.net.n_act, self.net.hidden
         if g is None:

@@ -31,16 +31,17 @@ from .ppo import PPO
 
 class GenericPPO(PPO):
     def __init__(self, *, net: MLPActorCritic, critic_input: Literal["local", "global"] = "local", n_agent: int = 1,
-                 **kwargs) -> None:
+                 graph: bool = True, **kwargs) -> None:
         if not isinstance(net, MLPActorCritic):
             raise TypeError("GenericPPO needs an MLPActorCritic (use PPO for DiscreteActorCritic)")
-        kwargs["use_graph"] = False
+        kwargs["use_graph"] = False  # the base class's graph path is the fused-kernel one
         super().__init__(net=net, **kwargs)
+        self.graph = bool(graph)  # capture this class's own update sequence into one hipGraph
         self.critic_input, self.n_agent = critic_input, int(n_agent)
         want = net.obs_dim * (self.n_agent if critic_input == "global" else 1)
         if net.critic_obs_dim != want:
             raise ValueError(f"critic input width {net.critic_obs_dim} != {want} for critic_input={critic_input!r}")
-        self._ctor.update(critic_input=critic_input, n_agent=n_agent)
+        self._ctor.update(critic_input=critic_input, n_agent=n_agent, graph=graph)
 
     # ---- helpers --------------------------------------------------------------------------------------------------
     def _values(self, obs_rows: torch.Tensor, joint: torch.Tensor | None) -> torch.Tensor:
@@ -70,8 +71,10 @@ class GenericPPO(PPO):
         return dict(act=act, logp=logp, value=value, logits=logits)
 
     # ---- update side ------------------------------------------------------------------------------------------------
-    def _preprocess_batch(self, buffer: DeviceVectorReplayBuffer) -> dict:
-        T, rows, env_start, env_len = self._valid_rows(buffer)
+    def _preprocess_batch(self, buffer: DeviceVectorReplayBuffer, uniform_T: int | None = None) -> dict:
+        # uniform_T: every sub-buffer holds exactly T unrotated rows (known on the host): no device round trip, so the
+        # pass can be captured into a hipGraph
+        T, rows, env_start, env_len = (uniform_T, None, None, None) if uniform_T else self._valid_rows(buffer)
         B, N, D = buffer.buffer_num, buffer.n_agent, buffer.obs_dim
         if self.critic_input == "global" and N != self.n_agent:
             raise ValueError(f"buffer holds {N} agents, the centralized critic was built for {self.n_agent}")
@@ -98,8 +101,9 @@ class GenericPPO(PPO):
         return dict(T=T, rows=rows, obs=obs, act=act, v_s=v_s.reshape(-1).contiguous(), ret=ret.reshape(-1),
                     adv=adv.reshape(-1), logp_old=logp_old, n_env=B, n_agent=N, joint=joint)
 
-    def _grad_step(self, pb: dict, idx: torch.Tensor, adv_stats) -> torch.Tensor:
-        """One minibatch: forward both nets, loss, backward into joint slabs, clip + Adam.  Returns the 4 scalars."""
+    def _grad_step(self, pb: dict, idx: torch.Tensor, adv_stats, step_dev: torch.Tensor | None = None) -> torch.Tensor:
+        """One minibatch: forward both nets, loss, backward into joint slabs, clip + Adam.  Returns the 4 scalars.
+        step_dev: device-resident optimizer step count (graph capture); None = the host counter."""
         net = self.net
         x = ops.gather_rows(pb["obs"], idx)
         cx = x if pb["joint"] is None else ops.gather_rows(pb["joint"], torch.div(idx, pb["n_agent"], rounding_mode="floor"))
@@ -115,7 +119,10 @@ class GenericPPO(PPO):
             slabs = self._ws[("slabs", n_split)] = torch.empty(n_split, n_total, dtype=torch.float32, device=self.device)
         net.actor.backward(dlogits, n_split, slabs=slabs, slab_stride=n_total)
         net.critic.backward(dvalue.view(M, 1), n_split, slabs=slabs[:, net.n_actor:], slab_stride=n_total)
-        self.opt_step += 1
+        if step_dev is None:
+            self.opt_step += 1
+        else:
+            ops.call("tsm_u64_add", ops.ptr(step_dev), 1, ops.stream_ptr())
         grads = slabs
         if self._grad_sync is not None:
             flat_g = self._ws.setdefault("flat_grad", torch.empty_like(net.flat.data))
@@ -124,8 +131,92 @@ class GenericPPO(PPO):
             grads = flat_g.view(1, -1)
         ops.adam_step(net.flat.data, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr, betas=self.betas,
                       eps=self.adam_eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
-                      work=self._adam_work)
+                      work=self._adam_work, step_dev=step_dev)
         return scalars
+
+    # ---- hipGraph path: one replay per update() (uniform, unrotated buffers; local advantage statistics) ------------
+    def _update_graph_generic(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
+        from ..data.stats import MapTrainingStats
+
+        T = buffer.host_uniform_len()
+        if not T or buffer.obs_next_store is None:
+            return None
+        B, N = buffer.buffer_num, buffer.n_agent
+        per_agent = self.dispatch == "per_agent"
+        groups = list(range(N)) if per_agent else [None]
+        n_g = T * B if per_agent else T * B * N
+        bounds = split_bounds(n_g, batch_size or -1, merge_last=True)
+        key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.lr, self.max_grad_norm)
+        w = self._ws.get(key)
+        if w is None:  # first update of this shape runs eagerly (one-time kernel attributes, allocator warm-up)
+            self._ws[key] = {}
+            return None
+        dev = self.device
+        n_steps = len(groups) * repeat * len(bounds)
+        if "graph" not in w:
+            w.update(perm=torch.zeros(len(groups), repeat, n_g, dtype=torch.int64, device=dev),
+                     step_dev=torch.zeros(1, dtype=torch.int64, device=dev),
+                     scal=torch.zeros(n_steps, 4, dtype=torch.float32, device=dev),
+                     mb_start=torch.as_tensor([b[0] for b in bounds] + [n_g], dtype=torch.int64, device=dev))
+            seg = torch.arange(len(groups) * repeat, dtype=torch.int64, device=dev).view(-1, 1) * n_g
+            # every tensor a captured kernel reads must outlive the graph: keep it in the workspace
+            w["mb_all"] = mb_all = torch.cat([(seg + w["mb_start"][:-1].view(1, -1)).reshape(-1),
+                                              torch.tensor([len(groups) * repeat * n_g], dtype=torch.int64, device=dev)])
+
+            def body():
+                if self.shuffle == "device":
+                    ops.random_permutations(n_g, len(groups) * repeat, self.seed ^ 0x5DEECE66D, counter_dev=w["step_dev"],
+                                            scale=N if per_agent else 1, group_size=repeat,
+                                            offset_mul=1 if per_agent else 0, out=w["perm"])
+                pb = self._preprocess_batch(buffer, uniform_T=T)
+                stats = None
+                if self.advantage_normalization:
+                    stats = ops.ppo_adv_stats(pb["adv"], mb_all, perm=w["perm"].view(-1)).view(len(groups), repeat, len(bounds), 2)
+                k = 0
+                for gi in range(len(groups)):
+                    for r in range(repeat):
+                        for j, (s, e) in enumerate(bounds):
+                            sc = self._grad_step(pb, w["perm"][gi, r, s:e], None if stats is None else stats[gi, r, j],
+                                                 step_dev=w["step_dev"])
+                            w["scal"][k].copy_(sc)
+                            k += 1
+
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body()
+            w["graph"] = graph
+        if self.shuffle == "numpy":
+            for gi, a in enumerate(groups):
+                for r in range(repeat):
+                    pl = torch.as_tensor(np.random.permutation(n_g)).to(dev)
+                    w["perm"][gi, r].copy_(pl if a is None else pl * N + a)
+        if w.get("step_host") != self.opt_step:
+            w["step_dev"].fill_(self.opt_step)
+        w["graph"].replay()
+        self.opt_step += n_steps
+        w["step_host"] = self.opt_step
+        self.param_version += 1
+        s_h = w["scal"].cpu().numpy()
+        mk = lambda x: A2CTrainingStats(  # noqa: E731
+            loss=SequenceSummaryStats.from_sequence(x[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(x[:, 1]),
+            vf_loss=SequenceSummaryStats.from_sequence(x[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(x[:, 3]),
+            gradient_steps=len(x))
+        if per_agent:
+            per = len(s_h) // N
+            return MapTrainingStats({f"agent_{a}": mk(s_h[a * per:(a + 1) * per]) for a in range(N)})
+        return mk(s_h)
+
+    def update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
+        import time
+
+        if (self.graph and self.is_within_training_step and self._grad_sync is None and not self.return_scaling
+                and not self.recompute_adv):
+            t0 = time.time()
+            out = self._update_graph_generic(buffer, batch_size, repeat)
+            if out is not None:
+                out.train_time = time.time() - t0
+                return out
+        return super().update(buffer, batch_size, repeat)
 
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
                            buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:

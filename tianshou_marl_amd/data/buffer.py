@@ -55,6 +55,13 @@ class DeviceVectorReplayBuffer:
         self._host_rows: int | None = 0
         self._arange = torch.arange(self.maxsize, dtype=torch.int64, device=self.device)
 
+    def storage_key(self) -> tuple:
+        """Identity of the HBM allocations behind this buffer: captured hipGraphs and cached kernel descriptors hold raw
+        pointers into them, so they are keyed by this (an `id()` can be recycled by a new object after this one died)."""
+        stores = (self.obs_store, self.obs_next_store, self.act_store, self.rew_store, self.term_store, self.trunc_store,
+                  self.logp_store, self.vs_store, self.vnext_store, self.index.state, self.index.done_store)
+        return tuple(0 if s is None else s.data_ptr() for s in stores)
+
     # ---- reference attributes ---------------------------------------------------------------
     @property
     def subbuffer_edges(self) -> np.ndarray:
