@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--dispatch", default="per_agent", choices=["per_agent", "pooled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=64)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
-                    help="c2 (default, the headline line): simple_spread N=3 shared PPO; c3: N=8 CTDE, 4096 envs")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ppo"],
+                    help="c2 (default, the headline line): simple_spread N=3 shared PPO; c3: N=8 CTDEPolicy, 4096 envs; "
+                         "c3ppo: N=8 PPO with a centralized critic, 4096 envs")
     return ap.parse_args()
 
 
@@ -317,8 +318,72 @@ def run_c3(a, device):
     print(json.dumps(out))
 
 
+def run_c3ppo(a, device):
+    """`--workload c3ppo`: the north star's roofline configuration with PPO -- simple_spread N=8 (obs 48), 4096 envs,
+    T=25, shared actor 48-128-128-5 and a CENTRALIZED critic 384-128-128-1 on the concatenated global state
+    (GenericPPO on the dense kernels), per-agent dispatch, minibatch 65536 (SURVEY grid), repeat 1.  Reports env-steps/s
+    and the split collect / GAE+PPO update."""
+    from tianshou_marl_amd.algorithm import GenericPPO, policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.utils.net import MLPActorCritic
+
+    n_env, N, T, mb = 4096, 8, 25, 65536
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=device, seed=1626)
+    D = env.obs_dim
+    net = MLPActorCritic(D, 5, (128, 128), critic_obs_dim=N * D, device=device, seed=1626)
+    algo = GenericPPO(net=net, critic_input="global", n_agent=N, lr=3e-4, shuffle="device", seed=1626)
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=device)
+    col = Collector(algo, env, buf, async_stats=True)
+    col.reset()
+
+    def step():
+        with policy_within_training_step(algo):
+            col.collect(n_step=n_env * T)
+            ts = algo.update(buf, mb, 1)
+        col.reset_buffer(keep_statistics=True)
+        return ts
+
+    for _ in range(max(a.warmup, 2)):  # the 2nd update captures the graph
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ts = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    e0, e1, e2 = ev(), ev(), ev()
+    with policy_within_training_step(algo):
+        e0.record()
+        col.collect(n_step=n_env * T)
+        e1.record()
+        algo.update(buf, mb, 1)
+        e2.record()
+    torch.cuda.synchronize()
+    col.reset_buffer(keep_statistics=True)
+    d = ts.get_loss_stats_dict()
+    print(json.dumps({
+        "metric": "env-steps/sec (n_env x n_agent) incl. PPO update, simple_spread N=8, centralized critic",
+        "value": n_env * N * T / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, 2),
+        "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "simple_spread_v3 N=8 PPO, shared actor 48-128-128-5 + centralized critic 384-128-128-1, "
+                               "num_envs=4096, T=25", "minibatch": mb, "repeat": 1, "dispatch": "per_agent"},
+        "collect_ms": e0.elapsed_time(e1), "gae_ppo_update_ms": e1.elapsed_time(e2),
+        "gradient_steps_per_update": sum(int(v) for k, v in d.items() if k.endswith("gradient_steps")),
+        "loss_agent_0": d.get("agent_0/loss")}))
+
+
 def main():
     a = parse()
+    if a.workload == "c3ppo":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        torch.cuda.set_device(0)
+        run_c3ppo(a, torch.device("cuda", 0))
+        return
     if a.workload == "c3":
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
