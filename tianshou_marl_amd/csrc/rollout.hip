@@ -92,6 +92,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     int64_t *s_prev_row = s_row + R;                                 // [EPB]
     uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_prev_row + R);   // [EPB] episode counter of finished envs
 
+    // diagnostics (tsm_debug_set_stamps, >= 1024 slots): [64 + 2b], [65 + 2b] = start / end of workgroup b;
+    // [640 + t] = start of step t in workgroup 0
+    if (a.stamps && threadIdx.x == 0 && blockIdx.x < 256) a.stamps[64 + 2 * blockIdx.x] = (long long)wall_clock64();
     if (a.img) stage_image<H>(lds, ly, a.img);
     else stage_weights<H>(lds, ly, d, a.P);
     for (int i = threadIdx.x; i < R * d.ld1; i += NT) { lds[ly.X + i] = 0.f; XN[i] = 0.f; }
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     for (int t = 0; t <= a.n_steps; ++t) {
         const bool last = t == a.n_steps;  // extra pass: bootstrap value of the final observation only
         STAMP(0);
+        if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 64) a.stamps[640 + t] = (long long)wall_clock64();
         // A. observation rows from the LDS-resident state: one (row, element) per thread
         for (int i = threadIdx.x; i < rows_here * D; i += NT) {
             const int rr = i / D, k = i - rr * D, ee = rr / N;
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     }
     // env state + sub-buffer bookkeeping back to HBM
     __syncthreads();
+    if (a.stamps && threadIdx.x == 0 && blockIdx.x < 256) a.stamps[65 + 2 * blockIdx.x] = (long long)wall_clock64();
     for (int i = threadIdx.x; i < n_here * st; i += NT) {
         a.apos[(int64_t)e0 * st + i] = s_ap[i];
         a.avel[(int64_t)e0 * st + i] = s_av[i];

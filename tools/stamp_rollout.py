@@ -10,14 +10,24 @@ from tianshou_marl_amd.utils.net import DiscreteActorCritic
 dev = "cuda"
 env = DeviceSimpleSpreadVectorEnv(1024, 3, device=dev); net = DiscreteActorCritic(18, 5, 64, device=dev, seed=0)
 algo = PPO(net=net); buf = DeviceVectorReplayBuffer(1024 * 25, 1024, 3, 18, device=dev); col = Collector(algo, env, buf); col.reset()
-st = torch.zeros(64, dtype=torch.int64, device=dev)
+st = torch.zeros(1024, dtype=torch.int64, device=dev)
 lib = _abi.load(); lib.tsm_debug_set_stamps.argtypes = [ctypes.c_void_p]; lib.tsm_debug_set_stamps(st.data_ptr())
 with policy_within_training_step(algo):
     for _ in range(3):
         col.collect(n_step=1024 * 25); col.reset_buffer(keep_statistics=True)
 torch.cuda.synchronize()
-s = st.cpu().numpy().reshape(8, 8)
+full = st.cpu().numpy()
+s = full[:64].reshape(8, 8)
 names = ["A obs", "B fwd", "C head", "D env+idx", "E scatter", "F done", "next"]
 for t in range(1, 4):
     d = [(s[t][k + 1] - s[t][k]) / 100.0 for k in range(6)]  # 100 MHz wall clock -> us
     print("step", t, {names[k]: round(d[k], 2) for k in range(6)}, "total", round((s[t][6] - s[t][0]) / 100.0, 2))
+
+import numpy as np
+blk = full[64:64 + 2 * 205].reshape(-1, 2)
+t0 = blk[:, 0].min()
+print("workgroup start offsets us: min %.2f max %.2f" % ((blk[:, 0].min() - t0) / 100, (blk[:, 0].max() - t0) / 100))
+dur = (blk[:, 1] - blk[:, 0]) / 100.0
+print("workgroup durations us: min %.1f median %.1f max %.1f; kernel span %.1f" % (dur.min(), np.median(dur), dur.max(), (blk[:, 1].max() - t0) / 100))
+steps = full[640:640 + 27]
+print("workgroup 0 step durations us:", [round((steps[i + 1] - steps[i]) / 100.0, 1) for i in range(25)])
