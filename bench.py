@@ -395,18 +395,28 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # Rehearsal switches for a single-GPU box (never used by the real multi-GPU run):
+    #   TSM_FORCE_DIST=1            process group + replica broadcast + captured all-reduce with a world of ONE rank (RCCL)
+    #   TSM_SHARE_GPU=1             every rank uses cuda:0 (RCCL refuses two ranks on one device, so combine it with ...)
+    #   TSM_DIST_BACKEND=gloo       ... the gloo backend: exercises the multi-process logic (env shards, per-step gradient
+    #                               sync, max-over-ranks timing) end to end; its all-reduce cannot be graph-captured, so the
+    #                               update falls back to eager launches on every rank alike
+    if os.environ.get("TSM_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    # TSM_FORCE_DIST=1 rehearses the N>1 code path (process group, replica broadcast, captured all-reduce) with a
-    # world of ONE rank on a single-GPU box
     force_dist = os.environ.get("TSM_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        backend = os.environ.get("TSM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     env, net, algo, buf, col = build_job(a, device, rank)
     if dist is not None:
         from tianshou_marl_amd.parallel import attach_data_parallel
@@ -435,6 +445,14 @@ def main():
         s.gradient_steps for s in getattr(ts, "_agent_id_to_stats", {}).values())
     # every rank runs the phase split: update() contains the gradient all-reduce when N > 1
     t_col_ms, t_upd_ms = phase_times(a, algo, buf, col)
+    replicas_identical = None
+    if dist is not None:  # data-parallel invariant: after any number of synced steps every rank holds the same bits
+        mine = net.flat.data.clone()
+        ref = mine.clone()
+        dist.broadcast(ref, src=0)
+        diff = torch.tensor([0.0 if torch.equal(mine, ref) else 1.0], device=device)
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(diff.item() == 0.0)
     if rank == 0:
         out = {
             "metric": "env-steps/sec (n_env x n_agent) incl. PPO update, simple_spread N=%d" % a.n_agent,
@@ -448,6 +466,8 @@ def main():
             "collect_env_steps_per_s": a.n_env * a.n_agent * a.horizon / (t_col_ms * 1e-3),
             "gradient_steps_per_update": grad_steps,
         }
+        if replicas_identical is not None:
+            out["replicas_identical"] = replicas_identical
         out.update(kernel_rooflines(a, algo, buf))
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a)

@@ -56,6 +56,8 @@ int tsm_mem_h2d(void *dst, const void *src_host, int64_t bytes, void *stream);
 int tsm_mem_d2h(void *dst_host, const void *src, int64_t bytes, void *stream);
 int tsm_mem_set(void *dst, int value, int64_t bytes, void *stream);
 int tsm_stream_sync(void *stream);
+/* Ends a hipGraph capture that failed half-way on `stream` (drops the partial graph); returns 1 if one was ended, else 0. */
+int tsm_stream_abort_capture(void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GAE  [SURVEY 8a: a11, a12]

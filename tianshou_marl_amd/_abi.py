@@ -79,6 +79,7 @@ SIGNATURES = {
     "tsm_mem_d2h": (_int, [_p, _p, _i64, _p]),
     "tsm_mem_set": (_int, [_p, _int, _i64, _p]),
     "tsm_stream_sync": (_int, [_p]),
+    "tsm_stream_abort_capture": (_int, [_p]),
     "tsm_gae_lanes": (_int, [_p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _p, _p, _f64, _f64, _f64, _p, _p, _p]),
     "tsm_mc_return_to_go_lanes": (_int, [_p, _i64, _i64, _f64, _p, _p]),
     "tsm_vrb_state_bytes": (_i64, [_i64, _i64]),
@@ -133,7 +134,7 @@ SIGNATURES = {
                                     C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p, _p]),
 }
 
-_NO_STATUS = {"tsm_abi_version", "tsm_last_error", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
+_NO_STATUS = {"tsm_abi_version", "tsm_last_error", "tsm_stream_abort_capture", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
               "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems",
               "tsm_mlp_param_count", "tsm_mlp_act_elems", "tsm_ctde_head_partial_elems", "tsm_mpe_tag_obs_dim"}
 

@@ -370,17 +370,34 @@ class PPO(nn.Module):
 
             graph = torch.cuda.CUDAGraph()
             if self._grad_sync is not None:
-                # every rank captures the same collective sequence; a failed capture falls back to eager launches
-                try:
-                    # thread_local: the process group's watchdog thread may touch the device while this thread captures
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                # every rank captures the same collective sequence; a failed capture falls back to eager launches.
+                # The capture is driven by hand so that a failure leaves no stream in capture mode and no stream
+                # context entered (torch.cuda.graph's __exit__ skips its clean-up when capture_end raises).
+                # thread_local: the process group's watchdog thread may touch the device while this thread captures.
+                err = None
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    graph.capture_begin(capture_error_mode="thread_local")
+                    try:
                         body()
-                except Exception as e:  # noqa: BLE001
+                    except Exception as e:  # noqa: BLE001
+                        err = e
+                    try:
+                        graph.capture_end()
+                    except Exception as e:  # noqa: BLE001
+                        err = err or e
+                    if err is not None:  # make sure the side stream is out of capture mode whatever state torch left it in
+                        ops.call("tsm_stream_abort_capture", side.cuda_stream)
+                if err is None:
+                    torch.cuda.current_stream().wait_stream(side)
+                if err is not None:
                     import warnings
 
-                    warnings.warn(f"capturing the all-reduce into the update graph failed ({e!r}); using eager launches",
+                    warnings.warn(f"capturing the all-reduce into the update graph failed ({err!r}); using eager launches",
                                   stacklevel=2)
                     self.graph_collectives = False
+                    torch.cuda.synchronize()
                     return None
             else:
                 with torch.cuda.graph(graph):

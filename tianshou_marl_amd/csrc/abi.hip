@@ -61,6 +61,18 @@ TSM_EXPORT int tsm_stream_sync(void *stream) {
     TSM_HIP(hipStreamSynchronize(tsm_stream(stream)));
     return TSM_OK;
 }
+// Take `stream` out of hipGraph capture mode if it is in it (a capture that failed half-way leaves it there, and every
+// later synchronising call on the device then fails); the partial graph is dropped.  Returns 1 if a capture was ended.
+TSM_EXPORT int tsm_stream_abort_capture(void *stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(tsm_stream(stream), &st) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (st == hipStreamCaptureStatusNone) return 0;
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(tsm_stream(stream), &g);  // an invalidated capture reports an error but still ends
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    return 1;
+}
 
 // diagnostic hook (not part of the public ABI header): device buffer of i64 phase time stamps written by
 // workgroup 0 of the rollout / update kernels when set (tools/stamp_*.py)

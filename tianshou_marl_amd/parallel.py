@@ -53,4 +53,10 @@ def attach_data_parallel(algo, dist, group=None) -> GradSync:
     sync.broadcast_(algo.exp_avg)
     sync.broadcast_(algo.exp_avg_sq)
     algo._grad_sync = sync
+    # only RCCL ("nccl") collectives can be captured into a hipGraph; with any other backend the update stays on eager
+    # launches (TSM_GRAPH_COLLECTIVES=force overrides: used to rehearse the failed-capture fallback)
+    import os
+
+    if dist.get_backend(group) != "nccl" and os.environ.get("TSM_GRAPH_COLLECTIVES") != "force":
+        algo.graph_collectives = False
     return sync
