@@ -104,6 +104,8 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
 #define USTAMP(k) do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[k] = (long long)wall_clock64(); } while (0)
     extern __shared__ float lds[];
     USTAMP(0);
+    // diagnostics (>= 1024 slots): [64 + 2b], [65 + 2b] = start / end of workgroup b
+    if (stamps && threadIdx.x == 0 && blockIdx.x < 256) stamps[64 + 2 * blockIdx.x] = (long long)wall_clock64();
     // device-resident optimizer step count (hipGraph replay): bumped here, read by the Adam kernel that follows
     if (opt_step_dev && blockIdx.x == 0 && threadIdx.x == 0) *opt_step_dev += 1;
     const Lay<H> ly(d, true);
@@ -350,28 +352,28 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = kq * 4 + r;
-        if (row < d.A) S[po.aW3 + row * H + 16 * w + colq] = g_W3a[r];
+        if (row < d.A) __builtin_nontemporal_store(g_W3a[r], &S[po.aW3 + row * H + 16 * w + colq]);
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
-            S[po.aW2 + (16 * w + row) * H + 16 * jb + colq] = g_W2a[jb][r];
-            S[po.cW2 + (16 * w + row) * H + 16 * jb + colq] = g_W2c[jb][r];
+            __builtin_nontemporal_store(g_W2a[jb][r], &S[po.aW2 + (16 * w + row) * H + 16 * jb + colq]);
+            __builtin_nontemporal_store(g_W2c[jb][r], &S[po.cW2 + (16 * w + row) * H + 16 * jb + colq]);
         }
 #pragma unroll
         for (int jb = 0; jb < kMaxJ; ++jb) {
             const int c = 16 * jb + colq;
             if (jb < d.nJ && c < d.D) {
-                S[po.aW1 + (16 * w + row) * d.D + c] = g_W1a[jb][r];
-                S[po.cW1 + (16 * w + row) * d.D + c] = g_W1c[jb][r];
+                __builtin_nontemporal_store(g_W1a[jb][r], &S[po.aW1 + (16 * w + row) * d.D + c]);
+                __builtin_nontemporal_store(g_W1c[jb][r], &S[po.cW1 + (16 * w + row) * d.D + c]);
             }
         }
     }
     if (threadIdx.x < 2 * H) {
         const int c = threadIdx.x;
-        if (c < H) { S[po.ab1 + c] = g_b1; S[po.ab2 + c] = g_b2; S[po.cW3 + c] = g_W3c; }
-        else { S[po.cb1 + c - H] = g_b1; S[po.cb2 + c - H] = g_b2; }
+        if (c < H) { __builtin_nontemporal_store(g_b1, &S[po.ab1 + c]); __builtin_nontemporal_store(g_b2, &S[po.ab2 + c]); __builtin_nontemporal_store(g_W3c, &S[po.cW3 + c]); }
+        else { __builtin_nontemporal_store(g_b1, &S[po.cb1 + c - H]); __builtin_nontemporal_store(g_b2, &S[po.cb2 + c - H]); }
     }
-    if (threadIdx.x < d.A) S[po.ab3 + threadIdx.x] = g_b3;
-    if (threadIdx.x == 16) S[po.cb3] = g_b3;
+    if (threadIdx.x < d.A) __builtin_nontemporal_store(g_b3, &S[po.ab3 + threadIdx.x]);
+    if (threadIdx.x == 16) __builtin_nontemporal_store(g_b3, &S[po.cb3]);
     // loss partial sums: row r accumulated in thread 16*r (lane j == 0 of its 16-lane group)
     {
         __shared__ double s_red[3][NT / 64];
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
         }
     }
     USTAMP(6);
+    if (stamps && threadIdx.x == 0 && blockIdx.x < 256) stamps[65 + 2 * blockIdx.x] = (long long)wall_clock64();
 #undef USTAMP
 }
 

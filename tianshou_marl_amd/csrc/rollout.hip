@@ -60,6 +60,7 @@ struct RolloutArgs {
     long long *stamps;  // diagnostic build only (tsm_debug_set_stamps): phase time stamps of workgroup 0
 };
 
+#define XSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[900 + t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 #define STAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 
 template <int H>
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     const int rows_here = n_here * N;         // live tile rows (<= 16): row r = (env el, agent i), r = el*N + i
     const int64_t B = c.n_env;
     // extra LDS behind the forward layout
-    float *XN = lds + ly.total;               // [R][ld1] obs_next rows
-    float *s_ap = XN + R * d.ld1;             // [EPB][N][2]
+    float *XN0 = lds + ly.total;              // [R][ld1] second observation tile (obs_next rows)
+    float *s_ap = XN0 + R * d.ld1;             // [EPB][N][2]
     float *s_av = s_ap + R * 2;
     float *s_lp = s_av + R * 2;
     float *s_rew = s_lp + R * 2;              // [R]
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     if (a.stamps && threadIdx.x == 0 && blockIdx.x < 256) a.stamps[64 + 2 * blockIdx.x] = (long long)wall_clock64();
     if (a.img) stage_image<H>(lds, ly, a.img);
     else stage_weights<H>(lds, ly, d, a.P);
-    for (int i = threadIdx.x; i < R * d.ld1; i += NT) { lds[ly.X + i] = 0.f; XN[i] = 0.f; }
+    for (int i = threadIdx.x; i < R * d.ld1; i += NT) { lds[ly.X + i] = 0.f; XN0[i] = 0.f; }
     const VrbState vs = vrb_view(a.vrb_state, B, N);
     // agent lane r < rows_here <-> (env el, agent i); lane i == 0 additionally owns its env's bookkeeping
     const int r = threadIdx.x, el = r / N, ai = r - el * N;
@@ -127,20 +128,26 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     }
     const uint64_t off0 = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
     __syncthreads();
+    // two observation tiles, swapped every step: obs_next of step t IS obs of step t + 1 (rows of re-initialised
+    // envs are rebuilt in F), so the observation function runs once per step, not twice
+    Lay<H> lyf = ly;
+    int xcur = ly.X, xnxt = ly.total;
+    // A. observation rows from the LDS-resident state: one (row, element) per thread
+    for (int i = threadIdx.x; i < rows_here * D; i += NT) {
+        const int rr = i / D, k = i - rr * D, ee = rr / N;
+        lds[xcur + rr * d.ld1 + k] = mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
+    }
+    __syncthreads();
 
     for (int t = 0; t <= a.n_steps; ++t) {
         const bool last = t == a.n_steps;  // extra pass: bootstrap value of the final observation only
+        float *XN = lds + xnxt;
         STAMP(0);
         if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 64) a.stamps[640 + t] = (long long)wall_clock64();
-        // A. observation rows from the LDS-resident state: one (row, element) per thread
-        for (int i = threadIdx.x; i < rows_here * D; i += NT) {
-            const int rr = i / D, k = i - rr * D, ee = rr / N;
-            lds[ly.X + rr * d.ld1 + k] = mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
-        }
-        __syncthreads();
         STAMP(1);
         // B. actor + critic forward of the 16-row tile
-        tile_forward<H>(lds, ly, d);
+        lyf.X = xcur;
+        tile_forward<H>(lds, lyf, d);
         STAMP(2);
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
             if (a.obs_cur_out)
                 for (int i = threadIdx.x; i < rows_here * D; i += NT) {
                     const int rr = i / D, k = i - rr * D;
-                    a.obs_cur_out[((int64_t)e0 * N + rr) * D + k] = lds[ly.X + rr * d.ld1 + k];
+                    a.obs_cur_out[((int64_t)e0 * N + rr) * D + k] = lds[xcur + rr * d.ld1 + k];
                 }
             break;
         }
@@ -201,24 +208,29 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         float npx = 0.f, npy = 0.f, nvx = 0.f, nvy = 0.f;
         if (lane_live) mpe_agent_move(c, s_ap + el * st, s_av + el * st, ai, s_act[r], npx, npy, nvx, nvy);
         __syncthreads();
+        XSTAMP(0);
         if (lane_live) {
             s_ap[el * st + 2 * ai] = npx; s_ap[el * st + 2 * ai + 1] = npy;
             s_av[el * st + 2 * ai] = nvx; s_av[el * st + 2 * ai + 1] = nvy;
         }
         __syncthreads();
+        XSTAMP(1);
         float local = 0.f;
         if (lane_live) {
             s_m[r] = mpe_landmark_min_dist(c, s_ap + el * st, s_lp + el * st, ai);
             local = mpe_local_penalty(c, s_ap + el * st, ai);
         }
+        XSTAMP(2);
         // obs_next rows (terminal observation for finished episodes) while the reward terms settle
         for (int i = threadIdx.x; i < rows_here * D; i += NT) {
             const int rr = i / D, k = i - rr * D, ee = rr / N;
             XN[rr * d.ld1 + k] = mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
         }
         __syncthreads();
+        XSTAMP(3);
         if (lane_live) s_rew[r] = mpe_reward(c, s_m + el * N, local);
         __syncthreads();
+        XSTAMP(4);
         if (env_lane) {
             const int stp = s_steps[el] + 1;
             const bool tr = stp >= c.max_cycles;
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         for (int i = threadIdx.x; i < rows_here * D; i += NT) {
             const int rr = i / D, k = i - rr * D, ee = rr / N;
             const int64_t dst = (s_row[ee] * N + (rr - ee * N)) * D + k;
-            a.obs_store[dst] = lds[ly.X + rr * d.ld1 + k];
+            a.obs_store[dst] = lds[xcur + rr * d.ld1 + k];
             if (a.obs_next_store) a.obs_next_store[dst] = XN[rr * d.ld1 + k];
         }
         if (lane_live) {
@@ -278,9 +290,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         any_done = __syncthreads_or(any_done);
         if (any_done) {
             if (a.vnext_store) {
-                for (int i = threadIdx.x; i < R * d.ld1; i += NT) lds[ly.X + i] = XN[i];
-                __syncthreads();
-                tile_forward<H>(lds, ly, d);
+                lyf.X = xnxt;
+                tile_forward<H>(lds, lyf, d);
                 if (lane_live && s_done[el]) a.vnext_store[s_row[el] * N + ai] = lds[ly.OUT + r * ly.ldo + 16];
             }
             if (a.auto_reset) {
@@ -293,8 +304,17 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
                 __syncthreads();
                 if (lane_live && s_done[el])
                     mpe_reset_agent(c, e, a.env_seed, s_ep[el], ai, s_ap + el * st, s_av + el * st, s_lp + el * st);
+                __syncthreads();
+                // first observation of the new episodes
+                for (int i = threadIdx.x; i < rows_here * D; i += NT) {
+                    const int rr = i / D, k = i - rr * D, ee = rr / N;
+                    if (s_done[ee])
+                        XN[rr * d.ld1 + k] =
+                            mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
+                }
             }
         }
+        { const int tmp = xcur; xcur = xnxt; xnxt = tmp; }
         if (env_lane) {
             s_prev_done[el] = s_done[el];
             s_prev_row[el] = s_row[el];

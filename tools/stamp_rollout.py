@@ -31,3 +31,7 @@ dur = (blk[:, 1] - blk[:, 0]) / 100.0
 print("workgroup durations us: min %.1f median %.1f max %.1f; kernel span %.1f" % (dur.min(), np.median(dur), dur.max(), (blk[:, 1].max() - t0) / 100))
 steps = full[640:640 + 27]
 print("workgroup 0 step durations us:", [round((steps[i + 1] - steps[i]) / 100.0, 1) for i in range(25)])
+x = full[900:964].reshape(8, 8)
+for t in range(1, 3):
+    seq = [s[t][3]] + [x[t][k] for k in range(5)] + [s[t][4]]
+    print("D sub-phases", [round((seq[i + 1] - seq[i]) / 100.0, 2) for i in range(6)], "(move, publish, min-dist+penalty, obs_next, reward, index algebra)")
