@@ -73,6 +73,16 @@ def one_step(a, algo, buf, col):
     with policy_within_training_step(algo):
         cs = col.collect(n_step=a.n_env * a.horizon)
         ts = algo.update(buf, a.minibatch, a.repeat)
+    # A trainer reads the statistics of every step (trainer.py:1063-1104: collect stats feed the logger and the
+    # stop/test criteria, training stats the logger).  Both objects are lazy: reading the collect statistics here,
+    # after update() has been queued, waits for the rollout only, and the training statistics are read one step late,
+    # so the device never idles while the host looks at numbers -- and the host never queues more than one step
+    # ahead (an unbounded run-ahead makes the HIP runtime drain its queue every ~10 steps, a 2 ms stall each time).
+    cs.resolve()
+    prev = getattr(algo, "_bench_prev_ts", None)
+    if prev is not None:
+        prev.resolve()
+    algo._bench_prev_ts = ts
     col.reset_buffer(keep_statistics=True)  # trainer.py:1104
     return cs, ts
 
@@ -264,8 +274,9 @@ def run_c3(a, device):
 
     def step():
         with policy_within_training_step(mgr):
-            col.collect(n_step=n_env * T)
+            cs = col.collect(n_step=n_env * T)
             losses = trainer.train_step(agent_batches_from_buffer(buf, env.agents))
+        cs.resolve()  # read every step's statistics (see one_step)
         col.reset_buffer(keep_statistics=True)
         return losses
 
@@ -340,8 +351,9 @@ def run_c3ppo(a, device):
 
     def step():
         with policy_within_training_step(algo):
-            col.collect(n_step=n_env * T)
+            cs = col.collect(n_step=n_env * T)
             ts = algo.update(buf, mb, 1)
+        cs.resolve()  # read every step's statistics (see one_step)
         col.reset_buffer(keep_statistics=True)
         return ts
 

@@ -82,8 +82,9 @@ __global__ __launch_bounds__(kStepThreads) void mpe_step_kernel(
     __syncthreads();
     float local = 0.f;
     if (live) {
-        s_m[el * N + i] = mpe_landmark_min_dist(c, s_ap + el * st, s_lp + el * st, i);
-        local = mpe_local_penalty(c, s_ap + el * st, i);
+        const MpePos pos = mpe_load_pos(c, s_ap + el * st);
+        s_m[el * N + i] = mpe_landmark_min_dist(c, pos, s_lp + el * st, i);
+        local = mpe_local_penalty(c, pos, s_ap + el * st, i);
         if (i == 0) {
             const int stp = steps[e] + 1;
             const int tr = stp >= c.max_cycles;

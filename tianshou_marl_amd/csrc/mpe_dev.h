@@ -55,33 +55,50 @@ __device__ __forceinline__ float mpe_obs_elem(const MpeCfg &c, const float *ap, 
     return 0.f;  // communication channel of silent agents
 }
 
+// All N agent positions of one env into registers, branch-free (index clamped to N - 1): the LDS reads issue back
+// to back and cost one round trip instead of one per loop iteration; the loops over them then branch on the
+// wave-uniform N, so only N iterations execute.
+struct MpePos { float x[kMpeMaxN], y[kMpeMaxN]; };
+__device__ __forceinline__ MpePos mpe_load_pos(const MpeCfg &c, const float *ap) {
+    MpePos p;
+#pragma unroll
+    for (int j = 0; j < kMpeMaxN; ++j) {
+        const int jj = j < c.N ? j : c.N - 1;
+        p.x[j] = ap[2 * jj]; p.y[j] = ap[2 * jj + 1];
+    }
+    return p;
+}
+
 // New position / velocity of agent i after one step (action force + soft contact forces, summed over the other
 // agents in increasing index; damping; optional speed clamp; explicit Euler).
 __device__ __forceinline__ void mpe_agent_move(const MpeCfg &c, const float *ap, const float *av, int i, int act,
                                                float &npx, float &npy, float &nvx, float &nvy) {
+    const MpePos p = mpe_load_pos(c, ap);
     const float px = ap[2 * i], py = ap[2 * i + 1];
+    const float vx = av[2 * i], vy = av[2 * i + 1];
     float fx = (act == 1 ? -1.f : (act == 2 ? 1.f : 0.f)) * c.accel;
     float fy = (act == 3 ? -1.f : (act == 4 ? 1.f : 0.f)) * c.accel;
-    for (int j = 0; j < c.N; ++j) {
-        if (j == i) continue;
+    const float k = c.contact_margin;
+    // far apart (the common case): z < -104, so expf(z) == 0 exactly in f32 and the contact force is exactly 0 --
+    // skip the sqrt / exp / log1p / divide chain.  The bound carries a margin of one contact_margin.
+    const float far = 2.f * c.agent_size + 105.f * k;
+#pragma unroll
+    for (int j = 0; j < kMpeMaxN; ++j) {
+        if (j >= c.N) break;  // wave-uniform
         // pair force seen from the lower index (a, b) = (min, max): f_a += s*d, f_b -= s*d with d = p_a - p_b
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        const float dx = ap[2 * lo] - ap[2 * hi], dy = ap[2 * lo + 1] - ap[2 * hi + 1];
+        const float dx = i < j ? px - p.x[j] : p.x[j] - px, dy = i < j ? py - p.y[j] : p.y[j] - py;
         const float d2 = dx * dx + dy * dy;
-        const float k = c.contact_margin;
-        // far apart (the common case): z < -104, so expf(z) == 0 exactly in f32 and the contact force is exactly 0 --
-        // skip the sqrt / exp / log1p / divide chain.  The bound carries a margin of one contact_margin.
-        const float far = 2.f * c.agent_size + 105.f * k;
-        if (d2 > far * far) continue;
-        const float dist = sqrtf(d2);
-        const float z = -(dist - 2.f * c.agent_size) / k;
-        const float pen = (z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z))) * k;  // logaddexp(0, z) * k
-        const float s = c.contact_force * pen / dist;
-        if (i < j) { fx += s * dx; fy += s * dy; }
-        else { fx -= s * dx; fy -= s * dy; }
+        if (j != i && !(d2 > far * far)) {
+            const float dist = sqrtf(d2);
+            const float z = -(dist - 2.f * c.agent_size) / k;
+            const float pen = (z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z))) * k;  // logaddexp(0, z) * k
+            const float s = c.contact_force * pen / dist;
+            if (i < j) { fx += s * dx; fy += s * dy; }
+            else { fx -= s * dx; fy -= s * dy; }
+        }
     }
-    nvx = av[2 * i] * (1.f - c.damping) + fx * c.dt;
-    nvy = av[2 * i + 1] * (1.f - c.damping) + fy * c.dt;
+    nvx = vx * (1.f - c.damping) + fx * c.dt;
+    nvy = vy * (1.f - c.damping) + fy * c.dt;
     if (c.max_speed > 0.f) {
         const float sp = sqrtf(nvx * nvx + nvy * nvy);
         if (sp > c.max_speed) { nvx = nvx / sp * c.max_speed; nvy = nvy / sp * c.max_speed; }
@@ -90,24 +107,35 @@ __device__ __forceinline__ void mpe_agent_move(const MpeCfg &c, const float *ap,
     npy = py + nvy * c.dt;
 }
 
-// min over agents of the distance to landmark l (on the NEW positions)
-__device__ __forceinline__ float mpe_landmark_min_dist(const MpeCfg &c, const float *ap, const float *lp, int l) {
-    float m = INFINITY;
-    for (int i = 0; i < c.N; ++i) {
-        const float dx = ap[2 * i] - lp[2 * l], dy = ap[2 * i + 1] - lp[2 * l + 1];
-        m = fminf(m, sqrtf(dx * dx + dy * dy));
+// min over agents of the distance to landmark l (on the NEW positions).  Correctly rounded sqrt is monotone, so
+// min_i sqrt(d2_i) == sqrt(min_i d2_i) bit for bit: one sqrt instead of N.
+__device__ __forceinline__ float mpe_landmark_min_dist(const MpeCfg &c, const MpePos &p, const float *lp, int l) {
+    float m2 = INFINITY;
+    const float lx = lp[2 * l], ly = lp[2 * l + 1];
+#pragma unroll
+    for (int i = 0; i < kMpeMaxN; ++i) {
+        if (i >= c.N) break;  // wave-uniform
+        const float dx = p.x[i] - lx, dy = p.y[i] - ly;
+        m2 = fminf(m2, dx * dx + dy * dy);
     }
-    return m;
+    return sqrtf(m2);
 }
 
-// -1 per other agent that agent i collides with (on the NEW positions)
-__device__ __forceinline__ float mpe_local_penalty(const MpeCfg &c, const float *ap, int i) {
+// -1 per other agent that agent i collides with (on the NEW positions): sqrt(d2) < 2 * agent_size.  The sqrt is
+// only evaluated inside a +-1 % band around the threshold; outside it the squared comparison decides identically.
+__device__ __forceinline__ float mpe_local_penalty(const MpeCfg &c, const MpePos &p, const float *ap, int i) {
     float local = 0.f;
-    for (int j = 0; j < c.N; ++j) {
-        if (j != i) {
-            const float dx = ap[2 * i] - ap[2 * j], dy = ap[2 * i + 1] - ap[2 * j + 1];
-            if (sqrtf(dx * dx + dy * dy) < 2.f * c.agent_size) local -= 1.f;
-        }
+    const float thr = 2.f * c.agent_size;
+    const float lo2 = (0.99f * thr) * (0.99f * thr), hi2 = (1.01f * thr) * (1.01f * thr);
+    const float px = ap[2 * i], py = ap[2 * i + 1];
+#pragma unroll
+    for (int j = 0; j < kMpeMaxN; ++j) {
+        if (j >= c.N) break;  // wave-uniform
+        const float dx = px - p.x[j], dy = py - p.y[j];
+        const float d2 = dx * dx + dy * dy;
+        bool hit = d2 < lo2;
+        if (!hit && d2 <= hi2) hit = sqrtf(d2) < thr;
+        if (j != i && hit) local -= 1.f;
     }
     return local;
 }

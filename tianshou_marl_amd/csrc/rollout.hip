@@ -100,11 +100,14 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     else stage_weights<H>(lds, ly, d, a.P);
     for (int i = threadIdx.x; i < R * d.ld1; i += NT) { lds[ly.X + i] = 0.f; XN0[i] = 0.f; }
     const VrbState vs = vrb_view(a.vrb_state, B, N);
-    // agent lane r < rows_here <-> (env el, agent i); lane i == 0 additionally owns its env's bookkeeping
+    // agent lane r < rows_here (wave 0) <-> (env el, agent i); env lane 64 + q (wave 1) owns env q's bookkeeping, so
+    // the buffer index algebra runs beside the agent lanes' physics instead of after it
     const int r = threadIdx.x, el = r / N, ai = r - el * N;
     const bool lane_live = r < rows_here;
-    const bool env_lane = lane_live && ai == 0;
     const int e = e0 + el;
+    const int bel = (int)threadIdx.x - 64;  // env lane: local env index
+    const bool env_lane = bel >= 0 && bel < n_here;
+    const int be = e0 + bel;
     // sub-buffer bookkeeping of "my" env lives in registers for the whole rollout: the per-step index algebra
     // then has no dependent global loads, only fire-and-forget stores
     int64_t v_ins = 0, v_size = 0, v_eplen = 0, v_epstart = 0, v_last = 0;
@@ -113,13 +116,13 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
 #pragma unroll
     for (int k = 0; k < kMpeMaxN; ++k) v_epret[k] = 0.0;
     if (env_lane) {
-        v_ins = vs.ins[e]; v_size = vs.size[e]; v_eplen = vs.ep_len[e]; v_epstart = vs.ep_start[e];
-        v_last = vs.last_index[e];
+        v_ins = vs.ins[be]; v_size = vs.size[be]; v_eplen = vs.ep_len[be]; v_epstart = vs.ep_start[be];
+        v_last = vs.last_index[be];
 #pragma unroll
-        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) v_epret[k] = vs.ep_return[(int64_t)e * N + k];
-        s_steps[el] = a.steps[e];
-        s_prev_done[el] = 1;  // "no pending v_next" before the first step
-        s_prev_row[el] = 0;
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) v_epret[k] = vs.ep_return[(int64_t)be * N + k];
+        s_steps[bel] = a.steps[be];
+        s_prev_done[bel] = 1;  // "no pending v_next" before the first step
+        s_prev_row[bel] = 0;
     }
     for (int i = threadIdx.x; i < n_here * st; i += NT) {
         s_ap[i] = a.apos[(int64_t)e0 * st + i];
@@ -204,9 +207,34 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         }
         __syncthreads();
         STAMP(3);
-        // D. env step, one lane per agent (mpe_dev.h): move -> barrier -> publish -> barrier -> reward terms
+        // D. env step, one lane per agent (mpe_dev.h): move -> barrier -> publish -> barrier -> reward terms.
+        //    Beside the move, the env lanes do the buffer index algebra on their register-resident sub-buffer state
+        //    (buffer_base.py:373-410 + manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h).
         float npx = 0.f, npy = 0.f, nvx = 0.f, nvy = 0.f;
         if (lane_live) mpe_agent_move(c, s_ap + el * st, s_av + el * st, ai, s_act[r], npx, npy, nvx, nvy);
+        bool tr = false, rec = false;
+        int64_t o = 0;
+        if (env_lane) {
+            const int stp = s_steps[bel] + 1;
+            tr = stp >= c.max_cycles;
+            s_steps[bel] = stp;
+            o = (int64_t)t * B + be;
+            const int64_t cur = v_ins;
+            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
+            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
+            const int64_t elen = v_eplen + 1;
+            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
+            rec = tr && a.ep_rec && n_fin < a.max_ep;
+            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | elen;
+            a.ep_len_out[o] = tr ? elen : 0;
+            a.ptr_out[o] = cur + (int64_t)be * a.S;
+            a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
+            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
+            v_last = cur + (int64_t)be * a.S;
+            a.done_store[cur * B + be] = tr ? 1 : 0;
+            s_row[bel] = cur * B + be;
+            s_done[bel] = tr ? 1 : 0;
+        }
         __syncthreads();
         XSTAMP(0);
         if (lane_live) {
@@ -217,56 +245,37 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         XSTAMP(1);
         float local = 0.f;
         if (lane_live) {
-            s_m[r] = mpe_landmark_min_dist(c, s_ap + el * st, s_lp + el * st, ai);
-            local = mpe_local_penalty(c, s_ap + el * st, ai);
+            const MpePos pos = mpe_load_pos(c, s_ap + el * st);
+            s_m[r] = mpe_landmark_min_dist(c, pos, s_lp + el * st, ai);
+            local = mpe_local_penalty(c, pos, s_ap + el * st, ai);
         }
         XSTAMP(2);
-        // obs_next rows (terminal observation for finished episodes) while the reward terms settle
-        for (int i = threadIdx.x; i < rows_here * D; i += NT) {
-            const int rr = i / D, k = i - rr * D, ee = rr / N;
-            XN[rr * d.ld1 + k] = mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
-        }
+        // obs_next rows (terminal observation for finished episodes) on waves 1-3 while wave 0 works on the reward terms
+        if (threadIdx.x >= 64)
+            for (int i = threadIdx.x - 64; i < rows_here * D; i += NT - 64) {
+                const int rr = i / D, k = i - rr * D, ee = rr / N;
+                XN[rr * d.ld1 + k] =
+                    mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
+            }
         __syncthreads();
         XSTAMP(3);
         if (lane_live) s_rew[r] = mpe_reward(c, s_m + el * N, local);
         __syncthreads();
         XSTAMP(4);
-        if (env_lane) {
-            const int stp = s_steps[el] + 1;
-            const bool tr = stp >= c.max_cycles;
-            s_steps[el] = stp;
-            // buffer index algebra on the register-resident sub-buffer state
-            // (buffer_base.py:373-410 + manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h)
-            const int64_t o = (int64_t)t * B + e;
-            const int64_t cur = v_ins;
-            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
-            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
-            const int64_t elen = v_eplen + 1;
-            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
-            const bool rec = tr && a.ep_rec && n_fin < a.max_ep;
+        if (env_lane) {  // episode returns (needs the rewards); runs beside the payload scatter below
             double *rec_rew = rec ? reinterpret_cast<double *>(a.ep_rec + B + (int64_t)B * a.max_ep) +
-                                        ((int64_t)e * a.max_ep + n_fin) * N : nullptr;
+                                        ((int64_t)be * a.max_ep + n_fin) * N : nullptr;
 #pragma unroll
             for (int k = 0; k < kMpeMaxN; ++k) {
                 if (k < N) {
-                    const double acc = v_epret[k] + (double)s_rew[el * N + k];
+                    const double acc = v_epret[k] + (double)s_rew[bel * N + k];
                     a.ep_rew_out[o * N + k] = tr ? acc : 0.0;
                     if (rec) rec_rew[k] = acc;
                     v_epret[k] = tr ? 0.0 : acc;
                 }
             }
-            if (rec) a.ep_rec[B + (int64_t)e * a.max_ep + n_fin] = ((int64_t)t << 32) | elen;
             n_fin += tr ? 1 : 0;
-            a.ep_len_out[o] = tr ? elen : 0;
-            a.ptr_out[o] = cur + (int64_t)e * a.S;
-            a.ep_idx_out[o] = v_epstart + (int64_t)e * a.S;
-            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
-            v_last = cur + (int64_t)e * a.S;
-            a.done_store[cur * B + e] = tr ? 1 : 0;
-            s_row[el] = cur * B + e;
-            s_done[el] = tr ? 1 : 0;
         }
-        __syncthreads();
         STAMP(4);
         // E. payload scatter into the time-major SoA store (rows of consecutive envs are adjacent)
         for (int i = threadIdx.x; i < rows_here * D; i += NT) {
@@ -295,11 +304,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
                 if (lane_live && s_done[el]) a.vnext_store[s_row[el] * N + ai] = lds[ly.OUT + r * ly.ldo + 16];
             }
             if (a.auto_reset) {
-                if (env_lane && s_done[el]) {
-                    const uint64_t ep = a.episode_ctr[e];
-                    s_ep[el] = ep;
-                    a.episode_ctr[e] = ep + 1;
-                    s_steps[el] = 0;
+                if (env_lane && s_done[bel]) {
+                    const uint64_t ep = a.episode_ctr[be];
+                    s_ep[bel] = ep;
+                    a.episode_ctr[be] = ep + 1;
+                    s_steps[bel] = 0;
                 }
                 __syncthreads();
                 if (lane_live && s_done[el])
@@ -316,8 +325,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         }
         { const int tmp = xcur; xcur = xnxt; xnxt = tmp; }
         if (env_lane) {
-            s_prev_done[el] = s_done[el];
-            s_prev_row[el] = s_row[el];
+            s_prev_done[bel] = s_done[bel];
+            s_prev_row[bel] = s_row[bel];
         }
         __syncthreads();
         STAMP(6);
@@ -331,12 +340,12 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         a.lpos[(int64_t)e0 * st + i] = s_lp[i];
     }
     if (env_lane) {
-        a.steps[e] = s_steps[el];
-        vs.ins[e] = v_ins; vs.size[e] = v_size; vs.ep_len[e] = v_eplen; vs.ep_start[e] = v_epstart;
-        vs.last_index[e] = v_last; vs.lengths[e] = v_size;
-        if (a.ep_rec) a.ep_rec[e] = n_fin;  // may exceed max_ep: the host treats that as an overflow
+        a.steps[be] = s_steps[bel];
+        vs.ins[be] = v_ins; vs.size[be] = v_size; vs.ep_len[be] = v_eplen; vs.ep_start[be] = v_epstart;
+        vs.last_index[be] = v_last; vs.lengths[be] = v_size;
+        if (a.ep_rec) a.ep_rec[be] = n_fin;  // may exceed max_ep: the host treats that as an overflow
 #pragma unroll
-        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) vs.ep_return[(int64_t)e * N + k] = v_epret[k];
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) vs.ep_return[(int64_t)be * N + k] = v_epret[k];
     }
 }
 
