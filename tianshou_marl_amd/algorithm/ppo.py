@@ -431,6 +431,9 @@ class PPO(nn.Module):
                     slot["pending"].expire("training stats were not read within 4 update() calls (async_stats=True)")
                 else:
                     slot["pending"].resolve()
+            # never queue more than 4 updates ahead of the device: an unbounded run-ahead fills the HIP command queue,
+            # and the runtime then drains it with a ~2 ms stall every ~10 steps (tools/step_jitter.py)
+            slot["event"].synchronize()
         slot["h"].copy_(g["scal"], non_blocking=True)
         slot["event"].record()
 

@@ -32,6 +32,19 @@ def main():
     mode = sys.argv[2] if len(sys.argv) > 2 else "free"
     prev = None
     for i in range(n):
+        if mode.startswith("lib"):  # the library alone: nobody reads any statistics (run-ahead bounded by its rings)
+            from tianshou_marl_amd.algorithm.ppo import policy_within_training_step
+            with policy_within_training_step(algo):
+                cs = col.collect(n_step=a.n_env * a.horizon)
+                ts = algo.update(buf, a.minibatch, a.repeat)
+            col.reset_buffer(keep_statistics=True)
+            if mode == "lib1" and prev is not None:
+                prev[2].synchronize()
+            e = torch.cuda.Event(); e.record()
+            prev = (cs, ts, e)
+            ev[i + 1].record()
+            host[i + 1] = time.perf_counter()
+            continue
         cs, ts = bench.one_step(a, algo, buf, col)
         if mode == "resolve":      # read this step's collect statistics (waits for the rollout, not for the update)
             cs.resolve()
