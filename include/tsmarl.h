@@ -347,6 +347,11 @@ typedef struct {
      * count may exceed max_ep (records beyond max_ep are dropped): size max_ep for the worst case. */
     int64_t *ep_rec;
     int32_t max_ep, _pad2;
+    /* optional: advance the device-resident sampling counter *offset_dev by offset_inc once every workgroup has read
+     * it (done by the last workgroup to finish, counted in *done_ctr: one zero-initialised u32 in HBM that the
+     * kernel leaves at zero).  Saves the separate tsm_u64_add launch per collect().  done_ctr NULL = no advance. */
+    uint64_t offset_inc;
+    uint32_t *done_ctr;
 } tsm_rollout_desc;
 
 int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *stream);

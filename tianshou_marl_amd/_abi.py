@@ -51,7 +51,8 @@ class tsm_rollout_desc(C.Structure):
                 ("vnext_store", C.c_void_p), ("act_store", C.c_void_p), ("term_store", C.c_void_p),
                 ("trunc_store", C.c_void_p), ("ptr_out", C.c_void_p), ("ep_rew_out", C.c_void_p),
                 ("ep_len_out", C.c_void_p), ("ep_idx_out", C.c_void_p),
-                ("ep_rec", C.c_void_p), ("max_ep", C.c_int32), ("_pad2", C.c_int32)]
+                ("ep_rec", C.c_void_p), ("max_ep", C.c_int32), ("_pad2", C.c_int32),
+                ("offset_inc", C.c_uint64), ("done_ctr", C.c_void_p)]
 
 
 class tsm_mpe_tag_cfg(C.Structure):

@@ -287,7 +287,7 @@ class PPO(nn.Module):
             w = dict(perm=torch.zeros(len(groups), repeat, n_g, dtype=torch.int64, device=dev),
                      mb_start=torch.as_tensor([b[0] for b in bounds] + [n_g], dtype=torch.int64, device=dev),
                      stats=f(len(groups), repeat, len(bounds), 2), scal=f(n_steps, 4), slabs=f(nb_max, P.numel()),
-                     partial=torch.zeros(n_steps, nb_max * 4, dtype=torch.float64, device=dev),
+                     partial=torch.zeros(n_steps, nb_max * 4, dtype=torch.float64, device=dev), nb_max=nb_max,
                      nb_dev=torch.as_tensor([ops.ppo_update_grid(e - s) for s, e in bounds] * (len(groups) * repeat),
                                             dtype=torch.int32, device=dev),
                      M_dev=torch.as_tensor([e - s for s, e in bounds] * (len(groups) * repeat), dtype=torch.int64,
@@ -320,11 +320,13 @@ class PPO(nn.Module):
                         w["v_next"].copy_(buffer.vnext_store[:T].reshape(T, L))
                 else:
                     # recompute_advantage refreshes the critic values only; logp_old stays (ppo.py:174-178)
+                    # before the first Adam step of this update the image may be stale: read `flat` (image=None)
+                    img = self.net.image if recompute else None
                     ops.policy_forward(P, obs, A, H, mode="none" if recompute else "given", act=act,
-                                       image=self.net.image,
+                                       image=img,
                                        out=dict(value=w["v_s"].view(-1), logp=None if recompute else w["logp"],
                                                 logits=None))
-                    ops.policy_forward(P, obs_next, A, H, mode="none", image=self.net.image,
+                    ops.policy_forward(P, obs_next, A, H, mode="none", image=img,
                                        out=dict(value=w["v_next"].view(-1), logits=None))
                 ops.gae_lanes(w["v_s"], w["v_next"], rew, term, trunc, self.gamma, self.gae_lambda, lanes_per_env=N,
                               out=(w["ret"], w["adv"]))
@@ -352,7 +354,8 @@ class PPO(nn.Module):
                             nb = ops.ppo_update_grid(e - s)
                             ops.ppo_update_fused(P, obs, act, w["logp"], w["adv"].view(-1), w["ret"].view(-1), self._cfg,
                                                  A, H, adv_stats=w["stats"][gi, r, j] if self.advantage_normalization else None,
-                                                 v_s_old=w["v_s"].view(-1) if self.value_clip else None, perm=perm[s:e], image=self.net.image,
+                                                 v_s_old=w["v_s"].view(-1) if self.value_clip else None, perm=perm[s:e],
+                                                 image=self.net.image if k > 0 else None,  # k == 0: image may be stale
                                                  M=e - s, n_blocks=nb, slabs=w["slabs"][:nb], partial=w["partial"][k],
                                                  want_scalars=False, opt_step_dev=w["step_dev"])
                             grads = w["slabs"][:nb]
@@ -365,8 +368,8 @@ class PPO(nn.Module):
                                           max_grad_norm=self.max_grad_norm, work=self._adam_work,
                                           step_dev=w["step_dev"], image=self.net.image, image_map=self.net.image_map)
                             k += 1
-                # the 4 loss statistics of EVERY gradient step in one launch (reference: 4 .item() per minibatch)
-                ops.ppo_finalize_many(w["partial"], nb_max * 4, w["nb_dev"], w["M_dev"], self._cfg, w["scal"])
+                # (the 4 loss statistics of every gradient step are folded from w["partial"] by ONE launch after the
+                # replay, straight into the pinned slot the host will read)
 
             graph = torch.cuda.CUDAGraph()
             if self._grad_sync is not None:
@@ -417,7 +420,9 @@ class PPO(nn.Module):
         self.opt_step += g["n_steps"]
         g["step_host"] = self.opt_step
         self.param_version += 1
-        # loss statistics: async D2H into a pinned ring; the host only blocks when the stats are read
+        # loss statistics (reference: 4 .item() per minibatch): one launch folds the loss partials of EVERY gradient step
+        # and writes the result straight into a pinned (mapped) host slot -- no D2H copy on the stream; the host only
+        # blocks when the stats are read
         ring = g.setdefault("ring", [])
         if len(ring) < 4:
             ring.append(dict(h=torch.empty(g["scal"].shape, dtype=torch.float32, pin_memory=True),
@@ -434,7 +439,7 @@ class PPO(nn.Module):
             # never queue more than 4 updates ahead of the device: an unbounded run-ahead fills the HIP command queue,
             # and the runtime then drains it with a ~2 ms stall every ~10 steps (tools/step_jitter.py)
             slot["event"].synchronize()
-        slot["h"].copy_(g["scal"], non_blocking=True)
+        ops.ppo_finalize_many(g["partial"], g["nb_max"] * 4, g["nb_dev"], g["M_dev"], self._cfg, slot["h"])
         slot["event"].record()
 
         def build():
@@ -463,12 +468,15 @@ class PPO(nn.Module):
                 "update() was called outside of a training step as signalled by `is_within_training_step=False`; "
                 "wrap the call in `policy_within_training_step(policy)` (tianshou/utils/torch_utils.py:31-46)")
         t0 = time.time()
-        self.net.sync_image()  # `flat` may have been written from outside (load_state_dict, broadcast, tests)
+        # `flat` is the source of truth and may have been written from outside (load_state_dict, broadcast, tests); the
+        # padded image is a cache that the Adam kernel refreshes.  The graph path reads `flat` itself until its first
+        # Adam step has rewritten the image, so it needs no refresh launch; the eager path refreshes it here.
         if self.use_graph and (self._grad_sync is None or self.graph_collectives) and not self.return_scaling:
             out = self._update_graph(buffer, batch_size, repeat)
             if out is not None:
                 out.train_time = time.time() - t0
                 return out
+        self.net.sync_image()
         pb = self._preprocess_batch(buffer)
         if self.dispatch == "per_agent":
             # MARLDispatcher.dispatch_update_with_batch: the (shared) algorithm is updated once per agent id,

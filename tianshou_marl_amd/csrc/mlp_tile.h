@@ -67,16 +67,36 @@ template <int H>
 __device__ void stage_weights(float *lds, const Lay<H> &ly, const Dims &d, const float *__restrict__ P) {
     const POff<H> po(d.D, d.A);
     const int tid = threadIdx.x;
-    for (int e = tid; e < 2 * H * d.ld1; e += NT) {  // W1 actor|critic, zero padded
-        const int row = e / d.ld1, c = e - row * d.ld1;
-        float v = 0.f;
-        if (c < d.D) v = row < H ? P[po.aW1 + row * d.D + c] : P[po.cW1 + (row - H) * d.D + c];
-        lds[ly.W1 + e] = v;
+    // loads are issued in batches of U per thread before any LDS write, so a batch costs one memory round trip
+    constexpr int U = 4;
+    for (int e0 = tid; e0 < 2 * H * d.ld1; e0 += U * NT) {  // W1 actor|critic, zero padded
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * NT;
+            const int row = e / d.ld1, c = e - row * d.ld1;
+            v[u] = 0.f;
+            if (e < 2 * H * d.ld1 && c < d.D) v[u] = row < H ? P[po.aW1 + row * d.D + c] : P[po.cW1 + (row - H) * d.D + c];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (e0 + u * NT < 2 * H * d.ld1) lds[ly.W1 + e0 + u * NT] = v[u];
     }
-    for (int e = tid; e < H * ly.ldh; e += NT) {
-        const int row = e / ly.ldh, c = e - row * ly.ldh;
-        lds[ly.W2a + e] = c < H ? P[po.aW2 + row * H + c] : 0.f;
-        lds[ly.W2c + e] = c < H ? P[po.cW2 + row * H + c] : 0.f;
+    for (int e0 = tid; e0 < H * ly.ldh; e0 += U * NT) {
+        float va[U], vc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * NT;
+            const int row = e / ly.ldh, c = e - row * ly.ldh;
+            const bool on = e < H * ly.ldh && c < H;
+            va[u] = on ? P[po.aW2 + row * H + c] : 0.f;
+            vc[u] = on ? P[po.cW2 + row * H + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * NT;
+            if (e < H * ly.ldh) { lds[ly.W2a + e] = va[u]; lds[ly.W2c + e] = vc[u]; }
+        }
     }
     for (int e = tid; e < 16 * ly.ldh; e += NT) {
         const int row = e / ly.ldh, c = e - row * ly.ldh;

@@ -57,6 +57,9 @@ struct RolloutArgs {
     //   [n_env] count | [n_env][max_ep] (step << 32 | length) | [n_env][max_ep][N] f64 return
     int64_t *ep_rec;
     int max_ep;
+    uint64_t offset_inc;
+    uint64_t *offset_dev_rw;
+    uint32_t *done_ctr;
     long long *stamps;  // diagnostic build only (tsm_debug_set_stamps): phase time stamps of workgroup 0
 };
 
@@ -347,6 +350,13 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
 #pragma unroll
         for (int k = 0; k < kMpeMaxN; ++k) if (k < N) vs.ep_return[(int64_t)be * N + k] = v_epret[k];
     }
+    // the last workgroup to get here advances the sampling counter: every workgroup read it (off0) before finishing
+    if (a.done_ctr && threadIdx.x == 0) {
+        if (atomicAdd(a.done_ctr, 1u) == gridDim.x - 1) {
+            *a.offset_dev_rw += a.offset_inc;
+            *a.done_ctr = 0u;
+        }
+    }
 }
 
 __global__ void u64_add_kernel(uint64_t *p, uint64_t inc) { *p += inc; }
@@ -388,6 +398,9 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     a.n_steps = h.n_steps;
     TSM_REQUIRE(!h.ep_rec || h.max_ep >= 1, "tsm_rollout_spread: ep_rec needs max_ep >= 1");
     a.ep_rec = h.ep_rec; a.max_ep = h.max_ep;
+    TSM_REQUIRE(!h.done_ctr || h.offset_dev, "tsm_rollout_spread: done_ctr needs offset_dev");
+    a.offset_inc = h.offset_inc; a.done_ctr = h.done_ctr;
+    a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
     a.stamps = g_tsm_stamps;
     const Lay<64> ly(a.d, false);
     const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8;

@@ -357,9 +357,16 @@ def scatter_image(params, image, image_map):
 
 
 def ppo_finalize_many(partial, stride_elems: int, n_blocks_dev, M_dev, cfg: tsm_ppo_cfg, scalars_out):
-    """scalars_out[k] = {loss, clip, vf, ent} of gradient step k from its loss partials (one launch for all k)."""
+    """scalars_out[k] = {loss, clip, vf, ent} of gradient step k from its loss partials (one launch for all k).
+    scalars_out may be a pinned host tensor (mapped memory: the kernel writes it directly, no D2H copy)."""
+    if scalars_out.is_cuda:
+        out_p = ptr(scalars_out)
+    elif scalars_out.is_pinned() and scalars_out.is_contiguous() and scalars_out.dtype == torch.float32:
+        out_p = scalars_out.data_ptr()
+    else:
+        raise RuntimeError("ppo_finalize_many: scalars_out must be a device tensor or pinned host memory (f32)")
     call("tsm_ppo_finalize_many", ptr(partial), stride_elems, ptr(_chk(n_blocks_dev, torch.int32, "n_blocks")),
-         ptr(_chk(M_dev, torch.int64, "M")), scalars_out.shape[0], C.byref(cfg), ptr(scalars_out), stream_ptr())
+         ptr(_chk(M_dev, torch.int64, "M")), scalars_out.shape[0], C.byref(cfg), out_p, stream_ptr())
     return scalars_out
 
 
