@@ -67,6 +67,13 @@ def build_job(a, device, rank):
     return env, net, algo, buf, col
 
 
+def _resolve(stats):
+    """Read a statistics object now if it is a lazy one (eager paths return finished objects)."""
+    r = getattr(stats, "resolve", None)
+    if callable(r):
+        r()
+
+
 def one_step(a, algo, buf, col):
     from tianshou_marl_amd.algorithm.ppo import policy_within_training_step
 
@@ -78,10 +85,8 @@ def one_step(a, algo, buf, col):
     # after update() has been queued, waits for the rollout only, and the training statistics are read one step late,
     # so the device never idles while the host looks at numbers -- and the host never queues more than one step
     # ahead (an unbounded run-ahead makes the HIP runtime drain its queue every ~10 steps, a 2 ms stall each time).
-    cs.resolve()
-    prev = getattr(algo, "_bench_prev_ts", None)
-    if prev is not None:
-        prev.resolve()
+    _resolve(cs)
+    _resolve(getattr(algo, "_bench_prev_ts", None))
     algo._bench_prev_ts = ts
     col.reset_buffer(keep_statistics=True)  # trainer.py:1104
     return cs, ts
@@ -276,7 +281,7 @@ def run_c3(a, device):
         with policy_within_training_step(mgr):
             cs = col.collect(n_step=n_env * T)
             losses = trainer.train_step(agent_batches_from_buffer(buf, env.agents))
-        cs.resolve()  # read every step's statistics (see one_step)
+        _resolve(cs)  # read every step's statistics (see one_step)
         col.reset_buffer(keep_statistics=True)
         return losses
 
@@ -353,7 +358,7 @@ def run_c3ppo(a, device):
         with policy_within_training_step(algo):
             cs = col.collect(n_step=n_env * T)
             ts = algo.update(buf, mb, 1)
-        cs.resolve()  # read every step's statistics (see one_step)
+        _resolve(cs)  # read every step's statistics (see one_step)
         col.reset_buffer(keep_statistics=True)
         return ts
 
