@@ -63,6 +63,34 @@ struct RolloutArgs {
     long long *stamps;  // diagnostic build only (tsm_debug_set_stamps): phase time stamps of workgroup 0
 };
 
+// 16-lane rows of a wave are DPP rows: row-wide rotate / broadcast are plain VALU operand modifiers (no LDS crossbar
+// round trip as for ds_bpermute).  dpp_ctrl: row_ror:n = 0x120 + n, row_newbcast:n = 0x150 + n (gfx90a+).
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// s += ex[0] + ex[1] + ... + ex[A - 1] in action order (ex[j] lives in lane j of the 16-lane row)
+template <int J>
+__device__ __forceinline__ void row_prefix_sum(float ex, int A, float &s) {
+    if constexpr (J < 16) {
+        if (J < A) {  // wave-uniform
+            s += row_dpp<0x150 + J>(ex);
+            row_prefix_sum<J + 1>(ex, A, s);
+        }
+    }
+}
+// inverse-CDF pick: first j with u < ex[0] + ... + ex[j] (same running sum as row_prefix_sum)
+template <int J>
+__device__ __forceinline__ void row_cdf_pick(float ex, int A, float u, float &cs, int &act, bool &found) {
+    if constexpr (J < 16) {
+        if (J < A) {
+            cs += row_dpp<0x150 + J>(ex);
+            if (!found && u < cs) { act = J; found = true; }
+            row_cdf_pick<J + 1>(ex, A, u, cs, act, found);
+        }
+    }
+}
+
 #define XSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[900 + t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 #define STAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 
@@ -163,12 +191,14 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
             const bool on = j < d.A;
             const float x = on ? lg[j] : -INFINITY;
             float m = x;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            m = fmaxf(m, row_dpp<0x128>(m));  // row_ror:8, 4, 2, 1: every lane ends with the row maximum
+            m = fmaxf(m, row_dpp<0x124>(m));
+            m = fmaxf(m, row_dpp<0x122>(m));
+            m = fmaxf(m, row_dpp<0x121>(m));
             const float ex = on ? expf(x - m) : 0.f;
             const int gbase = threadIdx.x & 48;  // first lane of this row's 16-lane group inside the wave
             float ssum = 0.f;
-            for (int jj = 0; jj < d.A; ++jj) ssum += __shfl(ex, gbase + jj, 64);
+            row_prefix_sum<0>(ex, d.A, ssum);
             if (j == 0 && hr < rows_here) {
                 const float val = lg[16];
                 const int hel = hr / N;
@@ -184,10 +214,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
                     float cs = 0.f;
                     act = d.A - 1;
                     bool found = false;
-                    for (int jj = 0; jj < d.A; ++jj) {
-                        cs += __shfl(ex, gbase + jj, 64);
-                        if (!found && u < cs) { act = jj; found = true; }
-                    }
+                    row_cdf_pick<0>(ex, d.A, u, cs, act, found);
                 } else {  // dist.mode: first index attaining the maximum
                     const unsigned long long eq = __ballot(on && x == m);
                     act = __ffsll((long long)((eq >> gbase) & 0xFFFFull)) - 1;
