@@ -46,6 +46,24 @@ constexpr int kWave = 64;  // gfx950 wavefront
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- wave / block reductions (64-wide) ----
+// 16-lane rows of a wave are DPP rows: row-wide rotate / broadcast are plain VALU operand modifiers (no LDS crossbar
+// round trip as for ds_bpermute).  dpp_ctrl: row_ror:n = 0x120 + n, row_newbcast:n = 0x150 + n (gfx90a+).
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// All-reduce over the 16 lanes of a row by rotations 8, 4, 2, 1.  After the first step the values have period 8, so
+// every rotation pairs the same operands as the xor butterfly __shfl_xor(v, 8 / 4 / 2 / 1): bit-identical results.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += row_dpp<0x128>(v); v += row_dpp<0x124>(v); v += row_dpp<0x122>(v); v += row_dpp<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, row_dpp<0x128>(v)); v = fmaxf(v, row_dpp<0x124>(v));
+    v = fmaxf(v, row_dpp<0x122>(v)); v = fmaxf(v, row_dpp<0x121>(v));
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

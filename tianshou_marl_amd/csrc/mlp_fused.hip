@@ -181,18 +181,12 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
                 const float *lg = lds + ly.OUT + r * ly.ldo;
                 const bool on = j < d.A;
                 const float x = on ? lg[j] : -INFINITY;
-                float m = x;
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                const float m = row16_max(x);  // (DPP rotations: same operand pairs as the xor butterflies)
                 const float ex = on ? expf(x - m) : 0.f;
-                float s = ex;
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                const float s = row16_sum(ex);
                 const float l = on ? x - (m + logf(s)) : 0.f;   // log-softmax
                 const float p = ex / s;
-                float h = on ? -p * l : 0.f;                     // entropy
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) h += __shfl_xor(h, off, 64);
+                const float h = row16_sum(on ? -p * l : 0.f);   // entropy
                 const int a_idx = cur.a_idx;
                 const float logp = __shfl(l, (threadIdx.x & 48) + a_idx, 64);
                 float a = cur.adv;

@@ -63,12 +63,6 @@ struct RolloutArgs {
     long long *stamps;  // diagnostic build only (tsm_debug_set_stamps): phase time stamps of workgroup 0
 };
 
-// 16-lane rows of a wave are DPP rows: row-wide rotate / broadcast are plain VALU operand modifiers (no LDS crossbar
-// round trip as for ds_bpermute).  dpp_ctrl: row_ror:n = 0x120 + n, row_newbcast:n = 0x150 + n (gfx90a+).
-template <int CTRL>
-__device__ __forceinline__ float row_dpp(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
 // s += ex[0] + ex[1] + ... + ex[A - 1] in action order (ex[j] lives in lane j of the 16-lane row)
 template <int J>
 __device__ __forceinline__ void row_prefix_sum(float ex, int A, float &s) {
@@ -190,11 +184,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
             const float *lg = lds + ly.OUT + hr * ly.ldo;
             const bool on = j < d.A;
             const float x = on ? lg[j] : -INFINITY;
-            float m = x;
-            m = fmaxf(m, row_dpp<0x128>(m));  // row_ror:8, 4, 2, 1: every lane ends with the row maximum
-            m = fmaxf(m, row_dpp<0x124>(m));
-            m = fmaxf(m, row_dpp<0x122>(m));
-            m = fmaxf(m, row_dpp<0x121>(m));
+            const float m = row16_max(x);
             const float ex = on ? expf(x - m) : 0.f;
             const int gbase = threadIdx.x & 48;  // first lane of this row's 16-lane group inside the wave
             float ssum = 0.f;
