@@ -179,6 +179,12 @@ typedef struct {
     double ent_coef;    /* 0.01 */
     int32_t value_clip; /* 0 */
     int32_t adv_norm;   /* 1 */
+    /* 0: PPO clip objective (ppo.py:182-211).  1: plain policy gradient, actor_loss = -mean(log_prob * adv), the
+     * actor term of A2C (a2c.py:260-270: + vf_coef * mse(returns, value) - ent_coef * entropy, no clipping) and, with
+     * vf_coef = ent_coef = 0 and adv = returns, the whole loss of Reinforce (reinforce.py:373-379).  eps_clip,
+     * dual_clip, value_clip and logp_old are ignored for kind 1. */
+    int32_t loss_kind;
+    int32_t _pad;
 } tsm_ppo_cfg;
 
 /* Per-minibatch advantage statistics (ppo.py:185, torch unbiased std).  Minibatch k covers

@@ -287,6 +287,26 @@ def ppo_loss(logits, act, logp_old, adv, returns, value, v_s_old=None, eps_clip=
                 adv_std=sc[5], dlogits=dlogits, dvalue=dvalue)
 
 
+def pg_loss(logits, act, adv, returns=None, value=None, vf_coef=0.5, ent_coef=0.01):
+    """Plain policy-gradient loss of `A2C._update_with_batch` (a2c.py:260-270) and, with value=None and
+    vf_coef = ent_coef = 0, of `Reinforce._update_with_batch` (reinforce.py:373-379; pass adv = returns).
+
+    Returns dict(loss, actor_loss, vf_loss, ent_loss, dlogits[M,A], dvalue[M]).
+    """
+    logits = np.ascontiguousarray(logits, np.float32)
+    M, A = logits.shape
+    act = np.ascontiguousarray(act, np.int64)
+    f = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)  # noqa: E731
+    adv, returns, value = map(f, (adv, returns, value))
+    dlogits = np.zeros((M, A), np.float64)
+    dvalue = np.zeros(M, np.float64)
+    sc = np.zeros(4, np.float64)
+    lib().orc_pg_loss(_p(logits, C.c_float), _p(act, C.c_int64), _p(adv, C.c_float), _p(returns, C.c_float),
+                      _p(value, C.c_float), C.c_int64(M), C.c_int64(A), C.c_double(vf_coef), C.c_double(ent_coef),
+                      _p(dlogits, C.c_double), _p(dvalue, C.c_double), _p(sc, C.c_double))
+    return dict(loss=sc[0], actor_loss=sc[1], vf_loss=sc[2], ent_loss=sc[3], dlogits=dlogits, dvalue=dvalue)
+
+
 class RunningMeanStd:
     """tianshou/utils/statistics.py:68-114 (update only; scalar statistics)."""
 

@@ -11,6 +11,8 @@ Each fixture holds inputs + the reference's outputs for one hot-path function
   gae.npz          Algorithm.compute_episodic_return / _gae            [a12]
   vrb_trace.npz    VectorReplayBuffer.add / sample_indices(0) / prev / next / unfinished_index /
                    get_buffer_indices / reset                           [a8, a9]
+  pg_update.npz    A2C / Reinforce _preprocess_batch + _update_with_batch (returns, loss statistics, post-update
+                   weights, last gradients)                             [(f)4]
   ppo_update.npz   PPO._preprocess_batch + PPO._update_with_batch (loss scalars, gradients,
                    Adam-updated weights, minibatch permutation)         [a7, a11, a13, a14, a15]
   marl_dispatch.npz MultiAgentPolicy.forward scatter + MARLDispatcher per-agent GAE (incl. quirk Q1),
@@ -272,6 +274,77 @@ def make_ppo_update() -> None:
     save("ppo_update.npz", variants=np.array([v["name"] for v in variants]), **out)
 
 
+def make_pg_update() -> None:
+    """A2C._update_with_batch (a2c.py:247-285) and Reinforce._preprocess_batch/_update_with_batch
+    (reinforce.py:273-311, 361-379) on the same buffer contents as ppo_update.npz."""
+    from tianshou.algorithm.modelfree.a2c import A2C
+    from tianshou.algorithm.modelfree.reinforce import Reinforce
+
+    out = {}
+    variants = [
+        dict(name="a2c_default", kind="a2c", kw={}, batch_size=None, repeat=1),
+        dict(name="a2c_mb64", kind="a2c", kw=dict(vf_coef=0.25, ent_coef=0.02, max_grad_norm=0.5), batch_size=64, repeat=2),
+        dict(name="reinforce_default", kind="reinforce", kw={}, batch_size=None, repeat=1),
+        dict(name="reinforce_std_mb50", kind="reinforce", kw=dict(return_standardization=True), batch_size=50, repeat=1),
+    ]
+    n_env, T, obs_dim, n_act = 8, 25, 18, 5
+    for v in variants:
+        rng = np.random.default_rng(7)
+        p = v["name"] + "_"
+        torch.manual_seed(3)
+        actor = DiscreteActor(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[64, 64]), action_shape=n_act,
+                              softmax_output=False)
+        critic = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[64, 64]))
+        for m in list(actor.modules()) + list(critic.modules()):
+            if isinstance(m, torch.nn.Linear):
+                torch.nn.init.orthogonal_(m.weight)
+                torch.nn.init.zeros_(m.bias)
+        policy = DiscreteActorPolicy(actor=actor, action_space=gym.spaces.Discrete(n_act))
+        if v["kind"] == "a2c":
+            algo = A2C(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=3e-4), **v["kw"])
+        else:
+            algo = Reinforce(policy=policy, optim=AdamOptimizerFactory(lr=3e-4), **v["kw"])
+        buf = fill_vector_buffer(rng, n_env, T, obs_dim, p_term=0.03, trunc_at=25, n_act=n_act)
+        batch, indices = buf.sample(0)
+        out.update({p + k: val for k, val in net_params(actor, critic).items()})
+        out.update({p + "obs": batch.obs, p + "obs_next": batch.obs_next, p + "act": batch.act, p + "rew": batch.rew,
+                    p + "terminated": batch.terminated, p + "truncated": batch.truncated, p + "indices": indices,
+                    p + "unfinished": buf.unfinished_index()})
+        if v["kw"].get("return_standardization"):
+            rms = algo.discounted_return_computation.ret_rms
+            rms.update(rng.standard_normal(50) * 3.0 + 1.5)  # non-trivial running stats (mean != 0 bootstraps cut episodes)
+            out[p + "rms_before"] = np.array([rms.mean, rms.var, rms.count], np.float64)
+        with policy_within_training_step(algo.policy):
+            pb = algo._preprocess_batch(batch, buf, indices)
+            out[p + "returns"] = np.asarray(pb.returns if isinstance(pb.returns, np.ndarray) else pb.returns.numpy()).copy()
+            if v["kind"] == "a2c":
+                out.update({p + "v_s": pb.v_s.numpy().copy(), p + "adv": pb.adv.numpy().copy()})
+            if v["kw"].get("return_standardization"):
+                out[p + "rms_after"] = np.array([rms.mean, rms.var, rms.count], np.float64)
+            np.random.seed(11)
+            st = np.random.get_state()
+            out[p + "perms"] = np.stack([np.random.permutation(len(indices)) for _ in range(v["repeat"])])
+            np.random.set_state(st)
+            with torch.enable_grad():
+                algo.train()
+                stats = algo._update_with_batch(pb, v["batch_size"], v["repeat"])
+        out[p + "batch_size"] = -1 if v["batch_size"] is None else v["batch_size"]
+        out[p + "repeat"] = v["repeat"]
+        for k in ("loss", "actor_loss", "vf_loss", "ent_loss"):
+            if hasattr(stats, k):
+                s = getattr(stats, k)
+                out[p + "stat_" + k] = np.array([s.mean, s.std, s.max, s.min], np.float64)
+        out.update({p + "after_" + k: val for k, val in net_params(actor, critic).items()})
+        lin = lambda m: [x for x in m.modules() if isinstance(x, torch.nn.Linear)]  # noqa: E731
+        for i, l in enumerate(lin(actor)):  # gradients of the last gradient step (the critic has none under Reinforce)
+            out[p + f"last_actor_gw{i}"] = l.weight.grad.detach().numpy().copy()
+            out[p + f"last_actor_gb{i}"] = l.bias.grad.detach().numpy().copy()
+        out[p + "cfg"] = np.array([getattr(algo, "vf_coef", 0.0), getattr(algo, "ent_coef", 0.0),
+                                   v["kw"].get("max_grad_norm") or 0.0, 3e-4, 0.99,
+                                   getattr(algo, "gae_lambda", 1.0)], np.float64)
+    save("pg_update.npz", variants=np.array([v["name"] for v in variants]), **out)
+
+
 # ------------------------------------------------------------------------------------------------
 class _FakeAECEnv:
     """Minimal stand-in exposing what MARLDispatcher reads (marl.py:197-203)."""
@@ -445,6 +518,6 @@ def make_misc() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "marl_dispatch", "ctde", "misc"]
+    which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "pg_update", "marl_dispatch", "ctde", "misc"]
     for w in which:
         globals()["make_" + w]()

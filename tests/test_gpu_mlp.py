@@ -54,6 +54,11 @@ def torch_ppo_loss(params64, D, H, A, obs, act, logp_old, adv, ret, v_old, cfg):
     a = torch.from_numpy(adv).double()
     if cfg["adv_norm"]:
         a = (a - a.mean()) / (a.std() + 1e-8)
+    if cfg.get("loss_kind", 0) == 1:  # a2c.py:260-270 (Reinforce: vf_coef = ent_coef = 0, adv = returns)
+        pg_loss = -(dist.log_prob(torch.from_numpy(act)) * a).mean()
+        vf_loss = (torch.from_numpy(ret).double() - value).pow(2).mean()
+        ent = dist.entropy().mean()
+        return pg_loss + cfg["vf_coef"] * vf_loss - cfg["ent_coef"] * ent, pg_loss, vf_loss, ent, logits, value
     ratio = (dist.log_prob(torch.from_numpy(act)) - torch.from_numpy(logp_old).double()).exp()
     s1 = ratio * a
     s2 = ratio.clamp(1 - cfg["eps_clip"], 1 + cfg["eps_clip"]) * a
@@ -131,9 +136,13 @@ CFGS = {
 }
 
 
+CFGS["a2c"] = dict(adv_norm=False, vf_coef=0.5, ent_coef=0.01, loss_kind=1)
+CFGS["reinforce"] = dict(adv_norm=False, vf_coef=0.0, ent_coef=0.0, loss_kind=1)
+
+
 @pytest.mark.parametrize("M,D,A,n_blocks", [(16, 18, 5, 1), (64, 18, 5, 4), (100, 18, 5, 3), (4096, 18, 5, None),
                                             (1000, 48, 5, 7), (257, 33, 9, 2)])
-@pytest.mark.parametrize("variant", ["default", "dual_vclip", "nonorm"])
+@pytest.mark.parametrize("variant", ["default", "dual_vclip", "nonorm", "a2c", "reinforce"])
 def test_ppo_update_fused_gradients(M, D, A, n_blocks, variant):
     rng = np.random.default_rng(M + D)
     H = 64

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(NT) void policy_forward_kernel(
 // ------------------------------------------------------------------------------------------------
 struct LossCfg {
     float eps_clip, dual_clip, vf_coef, ent_coef;
-    int value_clip, adv_norm;
+    int value_clip, adv_norm, kind;
 };
 
 template <int H>
@@ -191,19 +191,23 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
                 const float logp = __shfl(l, (threadIdx.x & 48) + a_idx, 64);
                 float a = cur.adv;
                 if (cfg.adv_norm) a = (a - a_mean) / (a_std + 1e-8f);
-                const float ratio = expf(logp - cur.logp_old);
-                const float lo = 1.0f - cfg.eps_clip, hi = 1.0f + cfg.eps_clip;
-                const float rc = fminf(fmaxf(ratio, lo), hi);
-                const float s1 = ratio * a, s2 = rc * a;
-                const bool in_range = ratio >= lo && ratio <= hi;
-                float obj, g_ratio;
-                if (s1 < s2) { obj = s1; g_ratio = a; }
-                else if (s1 > s2) { obj = s2; g_ratio = in_range ? a : 0.f; }
-                else { obj = s1; g_ratio = 0.5f * a + (in_range ? 0.5f * a : 0.f); }
-                if (cfg.dual_clip > 0.f && a < 0.f) {
-                    const float c = cfg.dual_clip * a;
-                    if (c > obj) { obj = c; g_ratio = 0.f; }
-                    else if (c == obj) g_ratio *= 0.5f;
+                float ratio, obj, g_ratio;  // d obj / d logp = g_ratio * ratio
+                if (cfg.kind == 1) {  // plain policy gradient (a2c.py:263-264, reinforce.py:375-376): obj = logp * adv
+                    ratio = 1.f; obj = logp * a; g_ratio = a;
+                } else {
+                    ratio = expf(logp - cur.logp_old);
+                    const float lo = 1.0f - cfg.eps_clip, hi = 1.0f + cfg.eps_clip;
+                    const float rc = fminf(fmaxf(ratio, lo), hi);
+                    const float s1 = ratio * a, s2 = rc * a;
+                    const bool in_range = ratio >= lo && ratio <= hi;
+                    if (s1 < s2) { obj = s1; g_ratio = a; }
+                    else if (s1 > s2) { obj = s2; g_ratio = in_range ? a : 0.f; }
+                    else { obj = s1; g_ratio = 0.5f * a + (in_range ? 0.5f * a : 0.f); }
+                    if (cfg.dual_clip > 0.f && a < 0.f) {
+                        const float c = cfg.dual_clip * a;
+                        if (c > obj) { obj = c; g_ratio = 0.f; }
+                        else if (c == obj) g_ratio *= 0.5f;
+                    }
                 }
                 const float v = lg[16], ret = cur.ret;
                 float vf, g_v;
@@ -535,6 +539,7 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
                 "tsm_ppo_update_fused: null pointer");
     TSM_REQUIRE(!cfg_host->value_clip || v_s_old, "tsm_ppo_update_fused: value_clip needs v_s_old");
     TSM_REQUIRE(!cfg_host->adv_norm || adv_stats, "tsm_ppo_update_fused: adv_norm needs adv_stats");
+    TSM_REQUIRE(cfg_host->loss_kind == 0 || cfg_host->loss_kind == 1, "tsm_ppo_update_fused: loss_kind must be 0 or 1");
     TSM_REQUIRE(cfg_host->dual_clip <= 0.0 || cfg_host->dual_clip > 1.0,
                 "Dual-clip PPO parameter should greater than 1.0 but got %g", cfg_host->dual_clip);
     TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(M, R), "tsm_ppo_update_fused: n_blocks=%d out of range",
@@ -546,6 +551,7 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
     cfg.ent_coef = (float)cfg_host->ent_coef;
     cfg.value_clip = cfg_host->value_clip;
     cfg.adv_norm = cfg_host->adv_norm;
+    cfg.kind = cfg_host->loss_kind;
     const Lay<64> ly(d, true);
     const size_t shmem = (size_t)ly.total * sizeof(float);
     static bool attr_set = false;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict
 
 struct Cfg {
     float eps_clip, dual_clip, vf_coef, ent_coef;
-    int value_clip, adv_norm;
+    int value_clip, adv_norm, kind;
 };
 
 constexpr int kLossThreads = 256;
@@ -107,19 +107,23 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
             h -= expf(l) * l;
             if (j == a_idx) logp = l;
         }
-        const float ratio = expf(logp - logp_old[row]);
-        const float lo = 1.0f - cfg.eps_clip, hi = 1.0f + cfg.eps_clip;
-        const float rc = fminf(fmaxf(ratio, lo), hi);
-        const float s1 = ratio * a, s2 = rc * a;
-        const bool in_range = ratio >= lo && ratio <= hi;
-        float obj, g_ratio;
-        if (s1 < s2) { obj = s1; g_ratio = a; }
-        else if (s1 > s2) { obj = s2; g_ratio = in_range ? a : 0.f; }
-        else { obj = s1; g_ratio = 0.5f * a + (in_range ? 0.5f * a : 0.f); }
-        if (cfg.dual_clip > 0.f && a < 0.f) {
-            const float c = cfg.dual_clip * a;
-            if (c > obj) { obj = c; g_ratio = 0.f; }
-            else if (c == obj) g_ratio *= 0.5f;
+        float ratio, obj, g_ratio;  // d obj / d logp = g_ratio * ratio
+        if (cfg.kind == 1) {  // plain policy gradient (a2c.py:263-264, reinforce.py:375-376): obj = logp * adv
+            ratio = 1.f; obj = logp * a; g_ratio = a;
+        } else {
+            ratio = expf(logp - logp_old[row]);
+            const float lo = 1.0f - cfg.eps_clip, hi = 1.0f + cfg.eps_clip;
+            const float rc = fminf(fmaxf(ratio, lo), hi);
+            const float s1 = ratio * a, s2 = rc * a;
+            const bool in_range = ratio >= lo && ratio <= hi;
+            if (s1 < s2) { obj = s1; g_ratio = a; }
+            else if (s1 > s2) { obj = s2; g_ratio = in_range ? a : 0.f; }
+            else { obj = s1; g_ratio = 0.5f * a + (in_range ? 0.5f * a : 0.f); }
+            if (cfg.dual_clip > 0.f && a < 0.f) {
+                const float c = cfg.dual_clip * a;
+                if (c > obj) { obj = c; g_ratio = 0.f; }
+                else if (c == obj) g_ratio *= 0.5f;
+            }
         }
         const float v = value[i], ret = returns[row];
         float vf, g_v;
@@ -191,6 +195,7 @@ Cfg to_cfg(const tsm_ppo_cfg *c) {
     k.ent_coef = (float)c->ent_coef;
     k.value_clip = c->value_clip;
     k.adv_norm = c->adv_norm;
+    k.kind = c->loss_kind;
     return k;
 }
 
@@ -221,6 +226,7 @@ TSM_EXPORT int tsm_ppo_loss_fwd_bwd(const float *logits, const float *value, con
                 "tsm_ppo_loss_fwd_bwd: null pointer");
     TSM_REQUIRE(!cfg_host->value_clip || v_s_old, "tsm_ppo_loss_fwd_bwd: value_clip needs v_s_old");
     TSM_REQUIRE(!cfg_host->adv_norm || adv_stats, "tsm_ppo_loss_fwd_bwd: adv_norm needs adv_stats");
+    TSM_REQUIRE(cfg_host->loss_kind == 0 || cfg_host->loss_kind == 1, "tsm_ppo_loss_fwd_bwd: loss_kind must be 0 or 1");
     TSM_REQUIRE(cfg_host->dual_clip <= 0.0 || cfg_host->dual_clip > 1.0,
                 "Dual-clip PPO parameter should greater than 1.0 but got %g", cfg_host->dual_clip);  // ppo.py:124-126
     const Cfg cfg = to_cfg(cfg_host);

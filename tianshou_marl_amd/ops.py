@@ -232,9 +232,13 @@ def categorical_logp_entropy(logits, act):
 # --------------------------------------------------------------------------------------------
 # PPO loss (ppo.py:182-211)
 # --------------------------------------------------------------------------------------------
-def make_ppo_cfg(eps_clip=0.2, dual_clip=None, value_clip=False, adv_norm=True, vf_coef=0.5, ent_coef=0.01):
+def make_ppo_cfg(eps_clip=0.2, dual_clip=None, value_clip=False, adv_norm=True, vf_coef=0.5, ent_coef=0.01,
+                 loss_kind=0):
+    """loss_kind 0: PPO clip objective; 1: plain policy gradient -mean(logp * adv) (A2C / Reinforce)."""
+    if loss_kind not in (0, 1):
+        raise ValueError(f"loss_kind must be 0 (PPO clip) or 1 (policy gradient), got {loss_kind}")
     return tsm_ppo_cfg(float(eps_clip), float(dual_clip or 0.0), float(vf_coef), float(ent_coef),
-                       int(bool(value_clip)), int(bool(adv_norm)))
+                       int(bool(value_clip)), int(bool(adv_norm)), int(loss_kind), 0)
 
 
 def ppo_adv_stats(adv, mb_start, perm=None, out=None):

@@ -14,12 +14,13 @@ stats = ops.ppo_adv_stats(adv, torch.tensor([0, M], device=dev), perm=perm)
 cfg = ops.make_ppo_cfg()
 st = torch.zeros(1024, dtype=torch.int64, device=dev)
 lib = _abi.load(); lib.tsm_debug_set_stamps.argtypes = [ctypes.c_void_p]; lib.tsm_debug_set_stamps(st.data_ptr())
-for _ in range(5):
-    ops.ppo_update_fused(P, obs, act, logp, adv, ret, cfg, A, H, adv_stats=stats[0], perm=perm, M=M, image=net.image)
-torch.cuda.synchronize()
-s = st.cpu().numpy()
 names = ["stage", "gather X", "forward", "loss head", "backward", "slab write"]
-print({names[k]: round((s[k + 1] - s[k]) / 100.0, 2) for k in range(6)}, "total", round((s[6] - s[0]) / 100.0, 2))
+for label, pm in (("perm gather", perm), ("contiguous rows", None)):
+    for _ in range(5):
+        ops.ppo_update_fused(P, obs, act, logp, adv, ret, cfg, A, H, adv_stats=stats[0], perm=pm, M=M, image=net.image)
+    torch.cuda.synchronize()
+    s = st.cpu().numpy()
+    print(label, {names[k]: round((s[k + 1] - s[k]) / 100.0, 2) for k in range(6)}, "total", round((s[6] - s[0]) / 100.0, 2))
 import numpy as np
 b = s[64:64 + 512].reshape(256, 2).astype(np.float64) / 100.0
 t0 = b[:, 0].min()
