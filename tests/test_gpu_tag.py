@@ -105,6 +105,25 @@ def test_tag_auto_reset_determinism_and_host_api():
         DeviceSimpleTagVectorEnv(4, num_good=5, num_adversaries=5, device=DEV)
 
 
+@pytest.mark.parametrize("n_adv,n_good,n_obst", [(3, 1, 2), (1, 1, 4), (5, 3, 0)])
+def test_tag_auto_reset_draws_the_same_worlds_as_the_reset_kernel(n_adv, n_good, n_obst):
+    """The step kernel re-initialises finished envs lane-wise (agent lane i draws agent i and obstacles i, i + NA, ...);
+    the stand-alone reset kernel does it one thread per env.  Same Philox counters => the same worlds, bit for bit."""
+    E, T = 21, 3
+    a = DeviceSimpleTagVectorEnv(E, n_good, n_adv, n_obst, max_cycles=T, device=DEV, seed=9)
+    b = DeviceSimpleTagVectorEnv(E, n_good, n_adv, n_obst, max_cycles=T, device=DEV, seed=9)
+    a.reset_device()
+    act = torch.zeros(E, a.n_agent, dtype=torch.int32, device=DEV)
+    for _ in range(T):
+        a.step_device(act)  # the last step truncates and auto-resets (episode 1)
+    b.reset_device()
+    obs_b = b.reset_device().clone()  # second reset: episode 1
+    assert torch.equal(a.agent_pos, b.agent_pos) and torch.equal(a.agent_vel, b.agent_vel)
+    if n_obst:
+        assert torch.equal(a.landmark_pos[:, :n_obst], b.landmark_pos[:, :n_obst])
+    assert torch.equal(a.obs_cur, obs_b)
+
+
 def _team_policies(env, seed=0, **kw):
     mk = lambda s: PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=DEV, seed=s), seed=s, use_graph=False, **kw)  # noqa: E731
     return {"adversaries": mk(seed), "good": mk(seed + 1)}

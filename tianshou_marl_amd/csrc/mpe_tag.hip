@@ -18,7 +18,7 @@
 //   (others only) 2 each]; adversaries see 2 n_good more numbers than good agents do, so rows are zero-padded to
 //   the common width obs_dim = 4 + 2 n_obst + 2 (NA - 1) + 2 n_good (PettingZooEnv requires identical spaces,
 //   pettingzoo_env.py:55-67).  Truncation at max_cycles; never terminates.
-// One thread per env: this env family is a functional row, not a tuned one (4096 envs = 4096 threads).
+// The step kernel runs one lane per (env, agent) on LDS-staged state (16 envs per workgroup); reset: one thread per env.
 #include "common.h"
 #include "philox.h"
 
@@ -85,81 +85,170 @@ __global__ void tag_reset_kernel(TagCfg c, uint64_t seed, uint64_t *episode_ctr,
     for (int i = 0; i < NA; ++i) tag_obs(c, ap, av, lp, i, obs + ((int64_t)e * NA + i) * c.obs_dim);
 }
 
-__global__ void tag_step_kernel(TagCfg c, uint64_t seed, uint64_t *episode_ctr, const int32_t *__restrict__ act,
-                                float *apos, float *avel, float *lpos, int32_t *steps, float *obs_next, float *obs_cur,
-                                float *rew, uint8_t *term, uint8_t *trunc, uint8_t *done_env, int auto_reset,
-                                uint64_t *tick, uint64_t tick_inc) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e == 0 && tick) *tick += tick_inc;  // sampling counter of the NEXT policy call (graph-replay safe)
-    if (e >= c.n_env) return;
-    const int NA = c.n_adv + c.n_good, NE = NA + c.n_obst;
-    float px[kMaxAgents + kMaxObst], py[kMaxAgents + kMaxObst], fx[kMaxAgents], fy[kMaxAgents], sz[kMaxAgents + kMaxObst];
-    float *ap = apos + (int64_t)e * NA * 2, *av = avel + (int64_t)e * NA * 2, *lp = lpos + (int64_t)e * c.n_obst * 2;
-    for (int i = 0; i < NA; ++i) {
-        px[i] = ap[2 * i]; py[i] = ap[2 * i + 1];
-        sz[i] = i < c.n_adv ? c.adv_size : c.good_size;
-        const float accel = i < c.n_adv ? c.adv_accel : c.good_accel;
-        const int a = act[(int64_t)e * NA + i];
-        fx[i] = (a == 1 ? -1.f : (a == 2 ? 1.f : 0.f)) * accel;
-        fy[i] = (a == 3 ? -1.f : (a == 4 ? 1.f : 0.f)) * accel;
+// Element k of agent i's (zero-padded) observation -- the element-wise form of tag_obs for coalesced row writes.
+__device__ __forceinline__ float tag_obs_elem(const TagCfg &c, const float *ap, const float *av, const float *lp, int i,
+                                              int k) {
+    const int NA = c.n_adv + c.n_good;
+    if (k < 2) return av[2 * i + k];
+    if (k < 4) return ap[2 * i + k - 2];
+    k -= 4;
+    if (k < 2 * c.n_obst) { const int l = k >> 1, x = k & 1; return lp[2 * l + x] - ap[2 * i + x]; }
+    k -= 2 * c.n_obst;
+    if (k < 2 * (NA - 1)) {
+        int j = k >> 1;
+        const int x = k & 1;
+        if (j >= i) ++j;  // the other agents in increasing index
+        return ap[2 * j + x] - ap[2 * i + x];
     }
-    for (int l = 0; l < c.n_obst; ++l) { px[NA + l] = lp[2 * l]; py[NA + l] = lp[2 * l + 1]; sz[NA + l] = c.obst_size; }
-    // soft contact forces over entity pairs a < b (agents first, then obstacles); only agents move
-    for (int a = 0; a < NA; ++a)
-        for (int b = a + 1; b < NE; ++b) {
-            const float dx = px[a] - px[b], dy = py[a] - py[b];
-            const float dmin = sz[a] + sz[b];
+    k -= 2 * (NA - 1);
+    const int n_seen = c.n_good - (i >= c.n_adv ? 1 : 0);  // velocities of the good agents other than oneself
+    if (k < 2 * n_seen) {
+        int j = c.n_adv + (k >> 1);
+        if (i >= c.n_adv && j >= i) ++j;
+        return av[2 * j + (k & 1)];
+    }
+    return 0.f;  // padding of the good agents' rows
+}
+
+constexpr int kTagEnvPerBlock = 16;
+constexpr int kTagThreads = kTagEnvPerBlock * kMaxAgents;  // one lane per (env, agent)
+
+// One joint step of every env, one lane per agent (same structure as mpe_step_kernel in mpe.hip): the env state of
+// 16 envs is staged in LDS, every agent lane sums the soft contact forces it receives from the other entities in
+// increasing entity index -- the order in which the serial pair loop (a < b) accumulates into f[i] -- so the result
+// is bit-identical to the pair formulation; observation rows leave through LDS as coalesced writes.
+__global__ __launch_bounds__(kTagThreads) void tag_step_kernel(
+    TagCfg c, uint64_t seed, uint64_t *episode_ctr, const int32_t *__restrict__ act, float *apos, float *avel,
+    float *lpos, int32_t *steps, float *obs_next, float *obs_cur, float *rew, uint8_t *term, uint8_t *trunc,
+    uint8_t *done_env, int auto_reset, uint64_t *tick, uint64_t tick_inc) {
+    extern __shared__ float sm[];
+    const int NA = c.n_adv + c.n_good, NE = NA + c.n_obst;
+    const int st = 2 * NA, lst = 2 * c.n_obst, row = NA * c.obs_dim;
+    float *s_ap = sm;                                   // [16][NA][2]
+    float *s_av = s_ap + kTagEnvPerBlock * st;
+    float *s_lp = s_av + kTagEnvPerBlock * st;          // [16][n_obst][2]
+    float *s_hit = s_lp + kTagEnvPerBlock * (lst > 0 ? lst : 2);  // [16][NA] 10 * (adversaries touching good agent g)
+    int *s_tr = reinterpret_cast<int *>(s_hit + kTagEnvPerBlock * NA);  // [16]
+    uint64_t *s_ep = reinterpret_cast<uint64_t *>(
+        (reinterpret_cast<uintptr_t>(s_tr + kTagEnvPerBlock) + 7) & ~(uintptr_t)7);  // [16]
+    float *s_next = reinterpret_cast<float *>(s_ep + kTagEnvPerBlock);  // [16][row]
+    const int e0 = blockIdx.x * kTagEnvPerBlock;
+    const int n_here = min(kTagEnvPerBlock, c.n_env - e0);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && tick) *tick += tick_inc;  // sampling counter of the NEXT policy call
+    for (int k = threadIdx.x; k < n_here * st; k += kTagThreads) {
+        s_ap[k] = apos[(int64_t)e0 * st + k];
+        s_av[k] = avel[(int64_t)e0 * st + k];
+    }
+    for (int k = threadIdx.x; k < n_here * lst; k += kTagThreads) s_lp[k] = lpos[(int64_t)e0 * lst + k];
+    __syncthreads();
+    const int el = threadIdx.x / NA, i = threadIdx.x - el * NA;  // agent lane -> (env, agent)
+    const bool live = threadIdx.x < n_here * NA;
+    const int e = e0 + el;
+    const float *ap = s_ap + el * st, *av = s_av + el * st, *lp = s_lp + el * lst;
+    const bool is_adv = i < c.n_adv;
+    const float my_size = is_adv ? c.adv_size : c.good_size;
+    float npx = 0.f, npy = 0.f, nvx = 0.f, nvy = 0.f;
+    if (live) {
+        const int a = act[(int64_t)e * NA + i];
+        const float accel = is_adv ? c.adv_accel : c.good_accel;
+        float fx = (a == 1 ? -1.f : (a == 2 ? 1.f : 0.f)) * accel;
+        float fy = (a == 3 ? -1.f : (a == 4 ? 1.f : 0.f)) * accel;
+        const float px = ap[2 * i], py = ap[2 * i + 1];
+        for (int j = 0; j < NE; ++j) {  // wave-uniform trip count
+            if (j == i) continue;
+            const float qx = j < NA ? ap[2 * j] : lp[2 * (j - NA)], qy = j < NA ? ap[2 * j + 1] : lp[2 * (j - NA) + 1];
+            const float sj = j < NA ? (j < c.n_adv ? c.adv_size : c.good_size) : c.obst_size;
+            // pair (lo, hi) = (min, max) of (i, j): d = p_lo - p_hi; f_lo += s d, f_hi -= s d
+            const float dx = i < j ? px - qx : qx - px, dy = i < j ? py - qy : qy - py;
+            const float dmin = i < j ? my_size + sj : sj + my_size;
             const float d2 = dx * dx + dy * dy;
             const float far = dmin + 105.f * c.contact_margin;  // beyond it expf underflows: the force is exactly 0
             if (d2 > far * far) continue;
             const float dist = sqrtf(d2);
             const float pen = softplus_k(-(dist - dmin) / c.contact_margin, c.contact_margin);
             const float s = c.contact_force * pen / dist;
-            fx[a] += s * dx; fy[a] += s * dy;
-            if (b < NA) { fx[b] -= s * dx; fy[b] -= s * dy; }
+            if (i < j) { fx += s * dx; fy += s * dy; }
+            else { fx -= s * dx; fy -= s * dy; }
         }
-    for (int i = 0; i < NA; ++i) {
-        float vx = av[2 * i] * (1.f - c.damping) + fx[i] * c.dt;
-        float vy = av[2 * i + 1] * (1.f - c.damping) + fy[i] * c.dt;
-        const float vmax = i < c.n_adv ? c.adv_speed : c.good_speed;
-        const float sp = sqrtf(vx * vx + vy * vy);
-        if (sp > vmax) { vx = vx / sp * vmax; vy = vy / sp * vmax; }
-        av[2 * i] = vx; av[2 * i + 1] = vy;
-        px[i] += vx * c.dt; py[i] += vy * c.dt;
-        ap[2 * i] = px[i]; ap[2 * i + 1] = py[i];
+        nvx = av[2 * i] * (1.f - c.damping) + fx * c.dt;
+        nvy = av[2 * i + 1] * (1.f - c.damping) + fy * c.dt;
+        const float vmax = is_adv ? c.adv_speed : c.good_speed;
+        const float sp = sqrtf(nvx * nvx + nvy * nvy);
+        if (sp > vmax) { nvx = nvx / sp * vmax; nvy = nvy / sp * vmax; }
+        npx = px + nvx * c.dt;
+        npy = py + nvy * c.dt;
     }
-    // rewards on the new positions
-    float adv_rew = 0.f;
-    float good_rew[kMaxAgents];
-    for (int g = c.n_adv; g < NA; ++g) {
-        float r = 0.f;
-        for (int a = 0; a < c.n_adv; ++a) {
-            const float dx = px[a] - px[g], dy = py[a] - py[g];
-            if (sqrtf(dx * dx + dy * dy) < sz[a] + sz[g]) { r -= 10.f; adv_rew += 10.f; }
+    __syncthreads();
+    if (live) {
+        s_ap[el * st + 2 * i] = npx; s_ap[el * st + 2 * i + 1] = npy;
+        s_av[el * st + 2 * i] = nvx; s_av[el * st + 2 * i + 1] = nvy;
+    }
+    __syncthreads();
+    // rewards on the new positions: a good agent counts the adversaries touching it (multiples of 10: exact in f32)
+    float my_rew = 0.f;
+    if (live) {
+        float hit = 0.f;
+        if (!is_adv) {
+            for (int a = 0; a < c.n_adv; ++a) {
+                const float dx = ap[2 * a] - npx, dy = ap[2 * a + 1] - npy;
+                if (sqrtf(dx * dx + dy * dy) < c.adv_size + c.good_size) { my_rew -= 10.f; hit += 10.f; }
+            }
+            my_rew -= bound_pen(fabsf(npx));
+            my_rew -= bound_pen(fabsf(npy));
         }
-        r -= bound_pen(fabsf(px[g]));
-        r -= bound_pen(fabsf(py[g]));
-        good_rew[g] = r;
+        s_hit[el * NA + i] = hit;
+        if (i == 0) {
+            const int stp = steps[e] + 1;
+            const int tr = stp >= c.max_cycles;
+            s_tr[el] = tr;
+            steps[e] = (tr && auto_reset) ? 0 : stp;
+            done_env[e] = (uint8_t)tr;
+        }
     }
-    const int stp = steps[e] + 1;
-    const bool tr = stp >= c.max_cycles;
-    for (int i = 0; i < NA; ++i) {
-        const int64_t o = (int64_t)e * NA + i;
-        rew[o] = i < c.n_adv ? adv_rew : good_rew[i];
-        term[o] = 0;
-        trunc[o] = tr ? 1 : 0;
-        tag_obs(c, ap, av, lp, i, obs_next + o * c.obs_dim);
+    __syncthreads();
+    if (live) {
+        if (is_adv) for (int g = c.n_adv; g < NA; ++g) my_rew += s_hit[el * NA + g];  // shared by the team
+        const int64_t li = (int64_t)e * NA + i;
+        rew[li] = my_rew;
+        term[li] = 0;
+        trunc[li] = (uint8_t)s_tr[el];
     }
-    done_env[e] = tr ? 1 : 0;
-    if (tr && auto_reset) {
-        const uint64_t ep = episode_ctr[e]++;
-        tag_reset_env(c, e, seed, ep, ap, av, lp);
-        steps[e] = 0;
-    } else {
-        steps[e] = stp;
+    for (int k = threadIdx.x; k < n_here * row; k += kTagThreads) {
+        const int r = k / c.obs_dim, kk = k - r * c.obs_dim, ee = r / NA;
+        s_next[k] = tag_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * lst, r - ee * NA, kk);
     }
-    if (obs_cur)
-        for (int i = 0; i < NA; ++i) tag_obs(c, ap, av, lp, i, obs_cur + ((int64_t)e * NA + i) * c.obs_dim);
+    if (live && i == 0 && s_tr[el] && auto_reset) {
+        const uint64_t ep = episode_ctr[e];
+        s_ep[el] = ep;
+        episode_ctr[e] = ep + 1;
+    }
+    __syncthreads();
+    if (live && s_tr[el] && auto_reset) {  // re-initialise: agent lane i draws agent i (and obstacles i, i + NA, ...)
+        uint32_t r4[4];
+        const uint64_t base = (s_ep[el] * (uint64_t)c.n_env + (uint64_t)e) * 16ull;
+        tsm_philox4(seed, base + (uint64_t)i, r4);
+        s_ap[el * st + 2 * i] = uni(r4[0], -1.f, 1.f); s_ap[el * st + 2 * i + 1] = uni(r4[1], -1.f, 1.f);
+        s_av[el * st + 2 * i] = 0.f; s_av[el * st + 2 * i + 1] = 0.f;
+        for (int l = i; l < c.n_obst; l += NA) {
+            tsm_philox4(seed, base + (uint64_t)(NA + l), r4);
+            s_lp[el * lst + 2 * l] = uni(r4[0], -0.9f, 0.9f); s_lp[el * lst + 2 * l + 1] = uni(r4[1], -0.9f, 0.9f);
+        }
+    }
+    __syncthreads();
+    float *g_next = obs_next + (int64_t)e0 * row;
+    for (int k = threadIdx.x; k < n_here * row; k += kTagThreads) g_next[k] = s_next[k];
+    if (obs_cur) {
+        float *g_cur = obs_cur + (int64_t)e0 * row;
+        for (int k = threadIdx.x; k < n_here * row; k += kTagThreads) {
+            const int r = k / c.obs_dim, kk = k - r * c.obs_dim, ee = r / NA;
+            g_cur[k] = tag_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * lst, r - ee * NA, kk);
+        }
+    }
+    for (int k = threadIdx.x; k < n_here * st; k += kTagThreads) {
+        apos[(int64_t)e0 * st + k] = s_ap[k];
+        avel[(int64_t)e0 * st + k] = s_av[k];
+    }
+    for (int k = threadIdx.x; k < n_here * lst; k += kTagThreads) lpos[(int64_t)e0 * lst + k] = s_lp[k];
 }
 
 int check_cfg(const tsm_mpe_tag_cfg *h, TagCfg *c) {
@@ -209,7 +298,11 @@ TSM_EXPORT int tsm_mpe_tag_step(const tsm_mpe_tag_cfg *cfg_host, uint64_t seed, 
     TSM_REQUIRE(episode_ctr && act && agent_pos && agent_vel && landmark_pos && steps && obs_next_out && rew_out &&
                     terminated_out && truncated_out && done_env_out,
                 "tsm_mpe_tag_step: null pointer");
-    hipLaunchKernelGGL(tag_step_kernel, dim3((unsigned)ceil_div(c.n_env, 64)), dim3(64), 0, tsm_stream(stream), c, seed,
+    const int NA = c.n_adv + c.n_good;
+    const size_t shmem = sizeof(float) * (size_t)kTagEnvPerBlock * (4 * NA + (c.n_obst > 0 ? 2 * c.n_obst : 2) + NA + 1 +
+                                                                     NA * c.obs_dim) + sizeof(uint64_t) * (kTagEnvPerBlock + 1);
+    hipLaunchKernelGGL(tag_step_kernel, dim3((unsigned)ceil_div(c.n_env, kTagEnvPerBlock)), dim3(kTagThreads), shmem,
+                       tsm_stream(stream), c, seed,
                        episode_ctr, act, agent_pos, agent_vel, landmark_pos, steps, obs_next_out, obs_cur_out, rew_out,
                        terminated_out, truncated_out, done_env_out, auto_reset, rng_tick, rng_tick_inc);
     TSM_LAUNCH_CHECK();
