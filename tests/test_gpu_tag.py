@@ -129,6 +129,27 @@ def _team_policies(env, seed=0, **kw):
     return {"adversaries": mk(seed), "good": mk(seed + 1)}
 
 
+def test_team_members_are_served_by_one_forward_call_with_the_same_draws():
+    """Consecutive agent columns that share a policy go through ONE fused forward on agent-major rows; counters (and
+    therefore sampled actions, log-probs, values) are identical to column-by-column calls."""
+    E = 37
+    env = DeviceSimpleTagVectorEnv(E, device=DEV, seed=1)
+    teams = _team_policies(env)
+    mgr = FlexibleMultiAgentPolicyManager(teams, env, mode="grouped", agent_groups=env.agent_groups)
+    assert [(a, k) for a, k, _ in mgr._policy_runs()] == [(0, env.n_adv), (env.n_adv, env.n_good)]
+    obs = torch.randn(E, env.n_agent, env.obs_dim, device=DEV)
+    tick = torch.tensor([12345], dtype=torch.int64, device=DEV)
+    with policy_within_training_step(mgr):
+        got = mgr.act_device(obs, offset_dev=tick)
+        for a, name in enumerate(env.agents):
+            ref = mgr.policy_map[name].act_device(obs[:, a].contiguous(), offset_dev=tick, row_offset=a * E)
+            for f in ("act", "logp", "value"):
+                assert torch.equal(got[f].view(E, env.n_agent)[:, a], ref[f].view(E)), (name, f)
+    # a map with the same policy on NON-adjacent columns falls back to separate calls for them
+    mgr.policy_map["adversary_1"] = teams["good"]
+    assert [(a, k) for a, k, _ in mgr._policy_runs()] == [(0, 1), (1, 1), (2, 1), (3, 1)]
+
+
 def test_grouped_policies_collect_and_train_on_tag():
     n_env, T = 64, 25
     env = DeviceSimpleTagVectorEnv(n_env, device=DEV, seed=5, max_cycles=T)

@@ -113,13 +113,32 @@ class MultiAgentPolicy(nn.Module):
             dev = obs.device
             out = dict(act=torch.empty(E * N, dtype=torch.int32, device=dev), logp=torch.empty(E * N, device=dev),
                        value=torch.empty(E * N, device=dev), logits=None)
-        for agent_id, policy in self._agent_policies.items():
-            a = self.agent_idx[agent_id]
-            # each agent column gets its own sampling-counter range (a policy shared by a team must not reuse draws)
-            res = policy.act_device(obs[:, a].contiguous(), out=None, offset_dev=offset_dev, row_offset=a * E)
-            for k in ("act", "logp", "value"):
-                out[k].view(E, N)[:, a].copy_(res[k].view(E))
+        # Each agent column gets its own sampling-counter range [a * E, (a + 1) * E) (a policy shared by a team must not
+        # reuse draws).  Consecutive columns served by the same policy object go through ONE call on agent-major rows
+        # (row j * E + e -> counter (a0 + j) * E + e: the same counters, hence the same draws, as column-by-column calls).
+        for a0, k, policy in self._policy_runs():
+            if k == 1:
+                res = policy.act_device(obs[:, a0].contiguous(), out=None, offset_dev=offset_dev, row_offset=a0 * E)
+                for f in ("act", "logp", "value"):
+                    out[f].view(E, N)[:, a0].copy_(res[f].view(E))
+            else:
+                rows = obs[:, a0:a0 + k].transpose(0, 1).contiguous().view(k * E, -1)
+                res = policy.act_device(rows, out=None, offset_dev=offset_dev, row_offset=a0 * E)
+                for f in ("act", "logp", "value"):
+                    out[f].view(E, N)[:, a0:a0 + k].copy_(res[f].view(k, E).transpose(0, 1))
         return out
+
+    def _policy_runs(self) -> list:
+        """[(first agent column, run length, policy)] for maximal runs of consecutive columns sharing a policy object."""
+        # recomputed per call: trainers swap entries of the policy map (self-play opponents, league snapshots)
+        by_col = sorted(((self.agent_idx[aid], pol) for aid, pol in self._agent_policies.items()), key=lambda t: t[0])
+        runs: list = []
+        for a, pol in by_col:
+            if runs and runs[-1][2] is pol and runs[-1][0] + runs[-1][1] == a:
+                runs[-1] = (runs[-1][0], runs[-1][1] + 1, pol)
+            else:
+                runs.append((a, 1, pol))
+        return runs
 
     # ---- reference forward -------------------------------------------------------------------------
     def forward(self, batch: Batch, state: dict | Batch | None = None, **kwargs: Any) -> Batch:
