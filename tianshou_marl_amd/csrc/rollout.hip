@@ -112,11 +112,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     int *s_act = reinterpret_cast<int *>(s_m + R);          // [R]
     int *s_steps = s_act + R;                               // [EPB]
     int *s_done = s_steps + R;                              // [EPB] done flag of the step just taken
-    int *s_prev_done = s_done + R;                          // [EPB]
     int64_t *s_row = reinterpret_cast<int64_t *>(                    // [EPB] slot*B + env of the step just added
-        (reinterpret_cast<uintptr_t>(s_prev_done + R) + 7) & ~(uintptr_t)7);
-    int64_t *s_prev_row = s_row + R;                                 // [EPB]
-    uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_prev_row + R);   // [EPB] episode counter of finished envs
+        (reinterpret_cast<uintptr_t>(s_done + R) + 7) & ~(uintptr_t)7);
+    uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + R);        // [EPB] episode counter of finished envs
+    // s_done / s_row keep the values of step t until phase D of step t + 1 overwrites them, so phase C of step t + 1
+    // reads them as "the previous step" (pending V(obs_next) stores) without a copy
 
     // diagnostics (tsm_debug_set_stamps, >= 1024 slots): [64 + 2b], [65 + 2b] = start / end of workgroup b;
     // [640 + t] = start of step t in workgroup 0
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
 #pragma unroll
         for (int k = 0; k < kMpeMaxN; ++k) if (k < N) v_epret[k] = vs.ep_return[(int64_t)be * N + k];
         s_steps[bel] = a.steps[be];
-        s_prev_done[bel] = 1;  // "no pending v_next" before the first step
-        s_prev_row[bel] = 0;
+        s_done[bel] = 1;  // "no pending v_next" before the first step
+        s_row[bel] = 0;
     }
     for (int i = threadIdx.x; i < n_here * st; i += NT) {
         s_ap[i] = a.apos[(int64_t)e0 * st + i];
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
             if (j == 0 && hr < rows_here) {
                 const float val = lg[16];
                 const int hel = hr / N;
-                if (!s_prev_done[hel] && a.vnext_store)  // V(obs_next) of the previous step == V(obs) of this one
-                    a.vnext_store[s_prev_row[hel] * N + (hr - hel * N)] = val;
+                if (!s_done[hel] && a.vnext_store)  // V(obs_next) of the previous step == V(obs) of this one
+                    a.vnext_store[s_row[hel] * N + (hr - hel * N)] = val;
                 if (!last) s_val[hr] = val;
             }
             if (!last) {
@@ -341,14 +341,12 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
                         XN[rr * d.ld1 + k] =
                             mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
                 }
+                __syncthreads();  // the next forward reads these rows at once
             }
         }
+        // no barrier at the end of a step: nothing written above is read before the first barrier inside the next
+        // step's forward pass, and that barrier also separates this step's LDS reads from the next step's writes
         { const int tmp = xcur; xcur = xnxt; xnxt = tmp; }
-        if (env_lane) {
-            s_prev_done[bel] = s_done[bel];
-            s_prev_row[bel] = s_row[bel];
-        }
-        __syncthreads();
         STAMP(6);
     }
     // env state + sub-buffer bookkeeping back to HBM
