@@ -390,6 +390,433 @@ __global__ __launch_bounds__(NT) void ppo_update_kernel(
 #undef USTAMP
 }
 
+// ------------------------------------------------------------------------------------------------
+// update, one NET per workgroup: grid (n_blocks, 2), blockIdx.y = 0 actor | 1 critic
+// ------------------------------------------------------------------------------------------------
+// The PPO / policy-gradient loss is separable: the clip (or policy-gradient) and entropy terms depend on the actor
+// only, the value term on the critic only.  A workgroup therefore carries ONE net through forward + loss + backward for
+// its 16-row tiles: half the MFMA chain per wave (one accumulator chain per layer instead of two interleaved ones),
+// half the gradient registers and half the slab stores on the critical path, 52 KB of LDS instead of 86 KB -- and the
+// actor and the critic workgroup of a tile run side by side on one CU (or on two).  Per net the arithmetic is the same
+// instruction sequence as in ppo_update_kernel (same k order, same reduction trees): results are bit-identical.
+template <int H>
+struct LayN {  // LDS layout in floats of one net
+    static constexpr int ldh = H + 2;  // 66 = 2 * 33
+    static constexpr int ldo = 18;     // logits(16) | value | pad
+    int W1, W2, W3, B1, B2, B3, X, H1, H2, OUT, D3, D2, D1, total;
+    __host__ __device__ explicit LayN(const Dims &d) {
+        int o = 0;
+        W1 = o; o += H * d.ld1;
+        W2 = o; o += H * ldh;
+        W3 = o; o += 16 * ldh;  // actor: [16][ldh], rows >= A zero; critic: the first H floats hold W3c
+        B1 = o; o += H;
+        B2 = o; o += H;
+        B3 = o; o += 16;
+        o = (o + 3) & ~3;
+        X = o; o += R * d.ld1;
+        H1 = o; o += R * ldh;
+        H2 = o; o += R * ldh;
+        OUT = o; o += R * ldo;
+        D3 = o; o += R * ldo;
+        D2 = o; o += R * ldh;
+        D1 = o; o += R * ldh;
+        total = o;
+    }
+};
+
+// weights of one net from the padded image (csrc/adam.hip keeps it current): every piece is a contiguous, 16-B aligned
+// run of the image; all loads are issued before the first LDS write (one memory round trip)
+template <int H, int NET>
+__device__ __forceinline__ void stage_net_image(float *lds, const LayN<H> &ln, const Lay<H> &ly, const Dims &d,
+                                                const float *__restrict__ img) {
+    constexpr int kIt1 = (H * (16 * kMaxJ + 2) / 4 + NT - 1) / NT, kIt2 = (H * LayN<H>::ldh / 4 + NT - 1) / NT;
+    constexpr int kIt3 = (16 * LayN<H>::ldh / 4 + NT - 1) / NT;
+    const f4 *s1 = reinterpret_cast<const f4 *>(img + ly.W1 + NET * H * d.ld1);
+    const f4 *s2 = reinterpret_cast<const f4 *>(img + (NET ? ly.W2c : ly.W2a));
+    const f4 *s3 = reinterpret_cast<const f4 *>(img + (NET ? ly.W3c : ly.W3a));
+    const int n1 = H * d.ld1 / 4, n2 = H * LayN<H>::ldh / 4, n3 = NET ? H / 4 : 16 * LayN<H>::ldh / 4;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    f4 r1[kIt1], r2[kIt2], r3[kIt3];
+#pragma unroll
+    for (int it = 0; it < kIt1; ++it) { const int i = threadIdx.x + it * NT; r1[it] = i < n1 ? s1[i] : zero; }
+#pragma unroll
+    for (int it = 0; it < kIt2; ++it) { const int i = threadIdx.x + it * NT; r2[it] = i < n2 ? s2[i] : zero; }
+#pragma unroll
+    for (int it = 0; it < kIt3; ++it) { const int i = threadIdx.x + it * NT; r3[it] = i < n3 ? s3[i] : zero; }
+    float b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (threadIdx.x < H) { b1 = img[ly.B1 + NET * H + threadIdx.x]; b2 = img[ly.B2 + NET * H + threadIdx.x]; }
+    if (threadIdx.x < 16) b3 = NET ? (threadIdx.x == 0 ? img[ly.B3c] : 0.f) : img[ly.B3a + threadIdx.x];
+    f4 *d1 = reinterpret_cast<f4 *>(lds + ln.W1), *d2 = reinterpret_cast<f4 *>(lds + ln.W2);
+    f4 *d3 = reinterpret_cast<f4 *>(lds + ln.W3);
+#pragma unroll
+    for (int it = 0; it < kIt1; ++it) { const int i = threadIdx.x + it * NT; if (i < n1) d1[i] = r1[it]; }
+#pragma unroll
+    for (int it = 0; it < kIt2; ++it) { const int i = threadIdx.x + it * NT; if (i < n2) d2[i] = r2[it]; }
+#pragma unroll
+    for (int it = 0; it < kIt3; ++it) { const int i = threadIdx.x + it * NT; if (i < n3) d3[i] = r3[it]; }
+    if (threadIdx.x < H) { lds[ln.B1 + threadIdx.x] = b1; lds[ln.B2 + threadIdx.x] = b2; }
+    if (threadIdx.x < 16) lds[ln.B3 + threadIdx.x] = b3;
+}
+
+// ... or from the flat parameter vector (first gradient step of an update: the image may be stale)
+template <int H, int NET>
+__device__ void stage_net_flat(float *lds, const LayN<H> &ln, const Dims &d, const float *__restrict__ P) {
+    const POff<H> po(d.D, d.A);
+    const int oW1 = NET ? po.cW1 : po.aW1, oW2 = NET ? po.cW2 : po.aW2, oW3 = NET ? po.cW3 : po.aW3;
+    const int ob1 = NET ? po.cb1 : po.ab1, ob2 = NET ? po.cb2 : po.ab2, ob3 = NET ? po.cb3 : po.ab3;
+    constexpr int U = 4;
+    for (int e0 = threadIdx.x; e0 < H * d.ld1; e0 += U * NT) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * NT, row = e / d.ld1, c = e - row * d.ld1;
+            v[u] = (e < H * d.ld1 && c < d.D) ? P[oW1 + row * d.D + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (e0 + u * NT < H * d.ld1) lds[ln.W1 + e0 + u * NT] = v[u];
+    }
+    for (int e0 = threadIdx.x; e0 < H * ln.ldh; e0 += U * NT) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * NT, row = e / ln.ldh, c = e - row * ln.ldh;
+            v[u] = (e < H * ln.ldh && c < H) ? P[oW2 + row * H + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (e0 + u * NT < H * ln.ldh) lds[ln.W2 + e0 + u * NT] = v[u];
+    }
+    for (int e = threadIdx.x; e < 16 * ln.ldh; e += NT) {
+        const int row = e / ln.ldh, c = e - row * ln.ldh;
+        float v = 0.f;
+        if (NET) { if (e < H) v = P[oW3 + e]; }
+        else if (row < d.A && c < H) v = P[oW3 + row * H + c];
+        lds[ln.W3 + e] = v;
+    }
+    if (threadIdx.x < H) { lds[ln.B1 + threadIdx.x] = P[ob1 + threadIdx.x]; lds[ln.B2 + threadIdx.x] = P[ob2 + threadIdx.x]; }
+    if (threadIdx.x < 16) lds[ln.B3 + threadIdx.x] = threadIdx.x < (NET ? 1 : d.A) ? P[ob3 + threadIdx.x] : 0.f;
+}
+
+template <int H, int NET>
+__device__ __forceinline__ void ppo_update_net(
+    float *lds, const float *__restrict__ P, const float *__restrict__ img, const Dims &d, const float *__restrict__ obs,
+    const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
+    const float *__restrict__ returns, const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first,
+    int64_t M, const float *__restrict__ adv_stats, const LossCfg &cfg, float *__restrict__ slabs,
+    double *__restrict__ loss_partial) {
+    const LayN<H> ln(d);
+    const POff<H> po(d.D, d.A);
+    const int64_t n_tiles = (M + R - 1) / R;
+    float xr[kXRegs];
+    struct RowIn { int a_idx; float adv, logp_old, ret, v_old; } rin;
+    auto row_id = [&](int64_t row0) -> int64_t {
+        const int64_t i = row0 + (threadIdx.x >> 4);
+        return i < M ? (perm ? perm[i] : first + i) : -1;
+    };
+    auto prefetch_row = [&](int64_t src) {
+        rin.a_idx = 0; rin.adv = 0.f; rin.logp_old = 0.f; rin.ret = 0.f; rin.v_old = 0.f;
+        if (src >= 0) {
+            if (NET == 0) { rin.a_idx = act[src]; rin.adv = adv[src]; rin.logp_old = logp_old[src]; }
+            else { rin.ret = returns[src]; if (cfg.value_clip) rin.v_old = v_s_old[src]; }
+        }
+    };
+    int64_t xs[kXRegs];
+    if ((int64_t)blockIdx.x < n_tiles) {
+        prefetch_tile_ids(xs, d, perm, first, (int64_t)blockIdx.x * R, M);
+        const int64_t rsrc = row_id((int64_t)blockIdx.x * R);
+        prefetch_tile_vals(xr, xs, obs);
+        prefetch_row(rsrc);
+    }
+    if (img) { const Lay<H> ly(d, true); stage_net_image<H, NET>(lds, ln, ly, d, img); }
+    else stage_net_flat<H, NET>(lds, ln, d, P);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const float invM = 1.0f / (float)M;
+    float a_mean = 0.f, a_std = 1.f;
+    if (NET == 0 && cfg.adv_norm) { a_mean = adv_stats[0]; a_std = adv_stats[1]; }
+
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    f4 g_W3 = zero;             // actor: rows i (A pad 16) x cols 16w..
+    f4 g_W2[4], g_W1[kMaxJ];    // rows 16w.. x col block jb
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g_W2[j] = zero;
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) g_W1[j] = zero;
+    float g_b1 = 0.f, g_b2 = 0.f;  // threads 0..H-1
+    float g_W3c = 0.f;             // critic, threads 0..H-1
+    float g_b3 = 0.f;              // actor: threads 0..A-1; critic: thread 0
+    double s_a = 0.0, s_b = 0.0;   // threads 16*r: actor (clip objective, entropy) | critic (value loss, -)
+
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t row0 = t * R;
+        __syncthreads();
+        commit_tile_x(lds, ln.X, d, xr);
+        const RowIn cur = rin;
+        __syncthreads();
+        // ---- forward ----
+        {
+            f4 acc = zero;
+            const float *xa = lds + ln.X + r16 * d.ld1 + kq;
+            const float *wa = lds + ln.W1 + (16 * w + r16) * d.ld1 + kq;
+            for (int k0 = 0; k0 < d.Kp1; k0 += 4) acc = mfma(xa[k0], wa[k0], acc);
+            const int col = 16 * w + r16;
+            const float b = lds[ln.B1 + col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[ln.H1 + (kq * 4 + r) * ln.ldh + col] = fmaxf(acc[r] + b, 0.f);
+        }
+        __syncthreads();
+        {
+            f4 acc = zero;
+            const float *ha = lds + ln.H1 + r16 * ln.ldh + kq;
+            const float *wa = lds + ln.W2 + (16 * w + r16) * ln.ldh + kq;
+#pragma unroll
+            for (int k0 = 0; k0 < H; k0 += 4) acc = mfma(ha[k0], wa[k0], acc);
+            const int col = 16 * w + r16;
+            const float b = lds[ln.B2 + col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[ln.H2 + (kq * 4 + r) * ln.ldh + col] = fmaxf(acc[r] + b, 0.f);
+        }
+        __syncthreads();
+        if (NET == 0) {
+            if (w == 0) {
+                f4 acc = zero;
+                const float *ha = lds + ln.H2 + r16 * ln.ldh + kq;
+                const float *wa = lds + ln.W3 + r16 * ln.ldh + kq;
+#pragma unroll
+                for (int k0 = 0; k0 < H; k0 += 4) acc = mfma(ha[k0], wa[k0], acc);
+                const float b = lds[ln.B3 + r16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[ln.OUT + (kq * 4 + r) * ln.ldo + r16] = acc[r] + b;
+            }
+        } else if (threadIdx.x < R) {
+            const float *hc = lds + ln.H2 + threadIdx.x * ln.ldh;
+            float sv = 0.f;
+            for (int j = 0; j < H; ++j) sv = fmaf(hc[j], lds[ln.W3 + j], sv);
+            lds[ln.OUT + threadIdx.x * ln.ldo + 16] = sv + lds[ln.B3];
+        }
+        __syncthreads();
+
+        // ---- loss head: 16 lanes per row ----
+        {
+            const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
+            const int64_t i = row0 + r;
+            float *d3 = lds + ln.D3 + r * ln.ldo;
+            float dl = 0.f, dv = 0.f;
+            if (i < M) {
+                const float *lg = lds + ln.OUT + r * ln.ldo;
+                if (NET == 0) {
+                    const bool on = j < d.A;
+                    const float x = on ? lg[j] : -INFINITY;
+                    const float m = row16_max(x);
+                    const float ex = on ? expf(x - m) : 0.f;
+                    const float s = row16_sum(ex);
+                    const float l = on ? x - (m + logf(s)) : 0.f;
+                    const float p = ex / s;
+                    const float h = row16_sum(on ? -p * l : 0.f);
+                    const int a_idx = cur.a_idx;
+                    const float logp = __shfl(l, (threadIdx.x & 48) + a_idx, 64);
+                    float a = cur.adv;
+                    if (cfg.adv_norm) a = (a - a_mean) / (a_std + 1e-8f);
+                    float ratio, obj, g_ratio;
+                    if (cfg.kind == 1) {
+                        ratio = 1.f; obj = logp * a; g_ratio = a;
+                    } else {
+                        ratio = expf(logp - cur.logp_old);
+                        const float lo = 1.0f - cfg.eps_clip, hi = 1.0f + cfg.eps_clip;
+                        const float rc = fminf(fmaxf(ratio, lo), hi);
+                        const float s1 = ratio * a, s2 = rc * a;
+                        const bool in_range = ratio >= lo && ratio <= hi;
+                        if (s1 < s2) { obj = s1; g_ratio = a; }
+                        else if (s1 > s2) { obj = s2; g_ratio = in_range ? a : 0.f; }
+                        else { obj = s1; g_ratio = 0.5f * a + (in_range ? 0.5f * a : 0.f); }
+                        if (cfg.dual_clip > 0.f && a < 0.f) {
+                            const float c = cfg.dual_clip * a;
+                            if (c > obj) { obj = c; g_ratio = 0.f; }
+                            else if (c == obj) g_ratio *= 0.5f;
+                        }
+                    }
+                    const float g_logp = -g_ratio * ratio * invM, ec = cfg.ent_coef * invM;
+                    if (on) dl = g_logp * ((j == a_idx ? 1.f : 0.f) - p) + ec * p * (l + h);
+                    if (j == 0) { s_a += (double)obj; s_b += (double)h; }
+                } else if (j == 0) {
+                    const float v = lg[16], ret = cur.ret;
+                    float vf, g_v;
+                    if (cfg.value_clip) {
+                        const float vs = cur.v_old;
+                        const float dd = v - vs;
+                        const float dc = fminf(fmaxf(dd, -cfg.eps_clip), cfg.eps_clip);
+                        const bool v_in = dd >= -cfg.eps_clip && dd <= cfg.eps_clip;
+                        const float vclip = vs + dc;
+                        const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vclip) * (ret - vclip);
+                        const float g1 = 2.f * (v - ret), g2 = v_in ? 2.f * (vclip - ret) : 0.f;
+                        if (vf1 > vf2) { vf = vf1; g_v = g1; }
+                        else if (vf1 < vf2) { vf = vf2; g_v = g2; }
+                        else { vf = vf1; g_v = 0.5f * g1 + 0.5f * g2; }
+                    } else {
+                        vf = (ret - v) * (ret - v);
+                        g_v = 2.f * (v - ret);
+                    }
+                    dv = cfg.vf_coef * g_v * invM;
+                    s_a += (double)vf;
+                }
+            }
+            if (NET == 0) d3[j] = dl;
+            else if (j == 0) d3[16] = dv;
+        }
+        __syncthreads();
+
+        if (t + gridDim.x < n_tiles) {  // next tile's gathers fly under this tile's backward pass
+            prefetch_tile_x(xr, d, obs, perm, first, (t + gridDim.x) * R, M);
+            prefetch_row(row_id((t + gridDim.x) * R));
+        }
+        // ---- output-layer gradients + dh2 ----
+        if (NET == 0) {
+            const float *dA = lds + ln.D3 + kq * ln.ldo + r16;
+            const float *hB = lds + ln.H2 + kq * ln.ldh + 16 * w + r16;
+#pragma unroll
+            for (int k0 = 0; k0 < R; k0 += 4) g_W3 = mfma(dA[k0 * ln.ldo], hB[k0 * ln.ldh], g_W3);
+            f4 acc = zero;
+            const float *dR = lds + ln.D3 + r16 * ln.ldo + kq;
+            const float *wB = lds + ln.W3 + kq * ln.ldh + 16 * w + r16;
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4) acc = mfma(dR[k0], wB[k0 * ln.ldh], acc);
+            const int col = 16 * w + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kq * 4 + r;
+                lds[ln.D2 + row * ln.ldh + col] = lds[ln.H2 + row * ln.ldh + col] > 0.f ? acc[r] : 0.f;
+            }
+            if (threadIdx.x < 16) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += lds[ln.D3 + r * ln.ldo + threadIdx.x];
+                g_b3 += s;
+            }
+        } else {
+            for (int e = threadIdx.x; e < R * H; e += NT) {
+                const int r = e / H, j = e - r * H;
+                const float hv = lds[ln.H2 + r * ln.ldh + j];
+                lds[ln.D2 + r * ln.ldh + j] = hv > 0.f ? lds[ln.D3 + r * ln.ldo + 16] * lds[ln.W3 + j] : 0.f;
+            }
+            if (threadIdx.x < H) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s = fmaf(lds[ln.D3 + r * ln.ldo + 16], lds[ln.H2 + r * ln.ldh + threadIdx.x], s);
+                g_W3c += s;
+            }
+            if (threadIdx.x == 0) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += lds[ln.D3 + r * ln.ldo + 16];
+                g_b3 += s;
+            }
+        }
+        __syncthreads();
+        // ---- hidden layer 2 gradients + dh1 ----
+        {
+            const float *dA = lds + ln.D2 + kq * ln.ldh + 16 * w + r16;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const float *hB = lds + ln.H1 + kq * ln.ldh + 16 * jb + r16;
+#pragma unroll
+                for (int k0 = 0; k0 < R; k0 += 4) g_W2[jb] = mfma(dA[k0 * ln.ldh], hB[k0 * ln.ldh], g_W2[jb]);
+            }
+            if (threadIdx.x < H) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += lds[ln.D2 + r * ln.ldh + threadIdx.x];
+                g_b2 += s;
+            }
+            f4 acc = zero;
+            const float *dR = lds + ln.D2 + r16 * ln.ldh + kq;
+            const float *wB = lds + ln.W2 + kq * ln.ldh + 16 * w + r16;
+#pragma unroll
+            for (int k0 = 0; k0 < H; k0 += 4) acc = mfma(dR[k0], wB[k0 * ln.ldh], acc);
+            const int col = 16 * w + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kq * 4 + r;
+                lds[ln.D1 + row * ln.ldh + col] = lds[ln.H1 + row * ln.ldh + col] > 0.f ? acc[r] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- layer 1 gradients ----
+        {
+            const float *dA = lds + ln.D1 + kq * ln.ldh + 16 * w + r16;
+#pragma unroll
+            for (int jb = 0; jb < kMaxJ; ++jb) {
+                if (jb < d.nJ) {
+                    const float *xB = lds + ln.X + kq * d.ld1 + 16 * jb + r16;
+#pragma unroll
+                    for (int k0 = 0; k0 < R; k0 += 4) g_W1[jb] = mfma(dA[k0 * ln.ldh], xB[k0 * d.ld1], g_W1[jb]);
+                }
+            }
+            if (threadIdx.x < H) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += lds[ln.D1 + r * ln.ldh + threadIdx.x];
+                g_b1 += s;
+            }
+        }
+    }
+
+    // ---- this net's half of the workgroup's gradient slab ----
+    float *S = slabs + (int64_t)blockIdx.x * po.total;
+    const int oW1 = NET ? po.cW1 : po.aW1, oW2 = NET ? po.cW2 : po.aW2;
+    const int colq = r16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kq * 4 + r;
+        if (NET == 0 && row < d.A) __builtin_nontemporal_store(g_W3[r], &S[po.aW3 + row * H + 16 * w + colq]);
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+            __builtin_nontemporal_store(g_W2[jb][r], &S[oW2 + (16 * w + row) * H + 16 * jb + colq]);
+#pragma unroll
+        for (int jb = 0; jb < kMaxJ; ++jb) {
+            const int c = 16 * jb + colq;
+            if (jb < d.nJ && c < d.D) __builtin_nontemporal_store(g_W1[jb][r], &S[oW1 + (16 * w + row) * d.D + c]);
+        }
+    }
+    if (threadIdx.x < H) {
+        const int c = threadIdx.x;
+        __builtin_nontemporal_store(g_b1, &S[(NET ? po.cb1 : po.ab1) + c]);
+        __builtin_nontemporal_store(g_b2, &S[(NET ? po.cb2 : po.ab2) + c]);
+        if (NET) __builtin_nontemporal_store(g_W3c, &S[po.cW3 + c]);
+    }
+    if (NET == 0 && threadIdx.x < d.A) __builtin_nontemporal_store(g_b3, &S[po.ab3 + threadIdx.x]);
+    if (NET == 1 && threadIdx.x == 0) __builtin_nontemporal_store(g_b3, &S[po.cb3]);
+    // loss partial sums: actor -> clip objective [0], entropy [2]; critic -> value loss [1]
+    {
+        __shared__ double s_red[2][NT / 64];
+        const double a = wave_sum(s_a), b = wave_sum(s_b);
+        if (lane == 0) { s_red[0][w] = a; s_red[1][w] = b; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double ta = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+            const double tb = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+            if (NET == 0) {
+                loss_partial[4 * blockIdx.x + 0] = ta;
+                loss_partial[4 * blockIdx.x + 2] = tb;
+                loss_partial[4 * blockIdx.x + 3] = 0.0;
+            } else {
+                loss_partial[4 * blockIdx.x + 1] = ta;
+            }
+        }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(NT) void ppo_update_split_kernel(
+    const float *__restrict__ P, const float *__restrict__ img, Dims d, const float *__restrict__ obs,
+    const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
+    const float *__restrict__ returns, const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first,
+    int64_t M, const float *__restrict__ adv_stats, LossCfg cfg, float *__restrict__ slabs,
+    double *__restrict__ loss_partial, int64_t *__restrict__ opt_step_dev) {
+    extern __shared__ float lds[];
+    // device-resident optimizer step count (hipGraph replay): bumped here, read by the Adam kernel that follows
+    if (opt_step_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *opt_step_dev += 1;
+    if (blockIdx.y == 0)
+        ppo_update_net<H, 0>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
+                             loss_partial);
+    else
+        ppo_update_net<H, 1>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
+                             loss_partial);
+}
+
 __global__ __launch_bounds__(256) void update_finalize_kernel(const double *__restrict__ partial, int n_blocks,
                                                               int64_t M, float vf_coef, float ent_coef,
                                                               float *__restrict__ scalars) {
@@ -517,6 +944,10 @@ TSM_EXPORT int tsm_policy_forward(const float *params, const float *param_image,
     return TSM_OK;
 }
 
+// diagnostics (not in the public header): 0 = one net per workgroup (default), 1 = both nets in one workgroup
+static int g_update_variant = 0;
+extern "C" __attribute__((visibility("default"))) void tsm_debug_set_update_variant(int v) { g_update_variant = v; }
+
 TSM_EXPORT int tsm_ppo_update_grid(int64_t M, int32_t max_blocks) {
     const int64_t n_tiles = ceil_div(M > 0 ? M : 1, R);
     int64_t g = n_tiles < 256 ? n_tiles : 256;
@@ -562,10 +993,18 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
         attr_set = true;
     }
     hipStream_t st = tsm_stream(stream);
-    hipLaunchKernelGGL((ppo_update_kernel<64>), dim3((unsigned)n_blocks), dim3(NT), shmem, st, params, param_image, d,
-                       obs, act,
-                       logp_old, adv, returns, v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out,
-                       loss_partial_out, opt_step_dev, g_tsm_stamps);
+    if (g_update_variant == 0 && !g_tsm_stamps) {
+        // one net per workgroup (grid.y = actor | critic): see ppo_update_split_kernel
+        const LayN<64> ln(d);
+        hipLaunchKernelGGL((ppo_update_split_kernel<64>), dim3((unsigned)n_blocks, 2), dim3(NT),
+                           (size_t)ln.total * sizeof(float), st, params, param_image, d, obs, act, logp_old, adv, returns,
+                           v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out, loss_partial_out, opt_step_dev);
+    } else {  // both nets in one workgroup (kept for the phase stamps of tools/stamp_update.py and as an A/B reference)
+        hipLaunchKernelGGL((ppo_update_kernel<64>), dim3((unsigned)n_blocks), dim3(NT), shmem, st, params, param_image, d,
+                           obs, act,
+                           logp_old, adv, returns, v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out,
+                           loss_partial_out, opt_step_dev, g_tsm_stamps);
+    }
     TSM_LAUNCH_CHECK();
     if (scalars_out) {
         hipLaunchKernelGGL(update_finalize_kernel, dim3(1), dim3(256), 0, st, loss_partial_out, n_blocks, M,
