@@ -242,7 +242,7 @@ def kernel_rooflines(a, algo, buf):
         s_u = per_launch(lambda: ops.ppo_update_fused(p_, obsG, actG, lpG, advG, retG, algo._cfg, net.n_act, Hn,
                                                       adv_stats=stG[0], perm=permG, M=MG, n_blocks=nbG, slabs=slabsG,
                                                       partial=partG, want_scalars=False, image=img_), n=10)
-        grid.append({"kernel": "ppo_update_kernel<64> (fused fwd+loss+bwd) at a pooled minibatch", "rows": MG, "bound": "mfma",
+        grid.append({"kernel": "ppo_update_split_kernel<64> (fused fwd+loss+bwd) at a pooled minibatch", "rows": MG, "bound": "mfma",
                      "flop_per_launch": 3 * fwd_flop_row * MG, "us_per_launch": s_u * 1e6,
                      "achieved": 3 * fwd_flop_row * MG / s_u / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": 3 * fwd_flop_row * MG / s_u / MFMA_F32_PEAK, "n_blocks": nbG, "traffic": None})
@@ -253,9 +253,11 @@ def kernel_rooflines(a, algo, buf):
     upd_bytes = (4 * D + 16 + 8) * M                                     # obs + act/logp/adv/ret + perm (88 B)
     gae_bytes = 22 * T * L                                               # 22 B / sample
     return {
-        "roofline": {"bound": "mfma", "kernel": "ppo_update_kernel<64> (fused fwd+loss+bwd, f32 MFMA)",
+        "roofline": {"bound": "mfma", "kernel": "ppo_update_split_kernel<64> (fused fwd+loss+bwd, f32 MFMA; one net per "
+                                                "workgroup: grid n_blocks x 2)",
                      "achieved": upd_flop / upd_s / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": upd_flop / upd_s / MFMA_F32_PEAK, "traffic": pmc_traffic("ppo_update_kernel", nb * 256),
+                     "frac": upd_flop / upd_s / MFMA_F32_PEAK,
+                     "traffic": pmc_traffic("ppo_update_split_kernel", nb * 2 * 256),
                      "traffic_note": "HBM bytes per launch (PMC): dominated by the per-workgroup gradient slabs "
                                      "(n_blocks x n_param x 4 B written, read back by adam_kernel)",
                      "flop_per_launch": upd_flop,
