@@ -219,3 +219,36 @@ def test_fused_mlp_rejects_unsupported_dims():
         ops.policy_forward(P, torch.zeros(4, 100, device=DEV), 5, 64)
     with pytest.raises(ValueError):
         ops.policy_param_count(18, 128, 5)
+
+
+@pytest.mark.parametrize("M,D,A,kw", [(4096, 18, 5, {}), (1000, 48, 5, dict(dual_clip=2.0, value_clip=True)),
+                                      (257, 33, 9, dict(adv_norm=False)), (300, 18, 5, dict(adv_norm=False, loss_kind=1))])
+def test_one_net_per_workgroup_update_is_bit_identical_to_the_joint_kernel(M, D, A, kw):
+    """`ppo_update_split_kernel` (grid.y = actor | critic, the default) runs the same per-net instruction sequence as
+    `ppo_update_kernel` (both nets in one workgroup): slabs and loss statistics must agree bit for bit."""
+    import ctypes
+
+    from tianshou_marl_amd import _abi
+
+    lib = _abi.load()
+    lib.tsm_debug_set_update_variant.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(M)
+    actor, critic = rand_nets(rng, D, 64, A)
+    P = torch.from_numpy(pack(actor, critic)).to(DEV)
+    n = M + 77
+    d = lambda x, dt=None: torch.from_numpy(np.ascontiguousarray(x)).to(DEV, dt)  # noqa: E731
+    obs, act = d(rng.standard_normal((n, D)).astype(np.float32)), d(rng.integers(0, A, n), torch.int32)
+    lp, adv, ret, vo = (d(rng.standard_normal(n).astype(np.float32)) for _ in range(4))
+    perm = d(rng.permutation(n)[:M])
+    stats = ops.ppo_adv_stats(adv, d(np.array([0, M], np.int64)), perm=perm)
+    cfg = ops.make_ppo_cfg(**kw)
+    out = []
+    try:
+        for variant in (0, 1):
+            lib.tsm_debug_set_update_variant(variant)
+            slabs, sc = ops.ppo_update_fused(P, obs, act, lp, adv, ret, cfg, A, 64, adv_stats=stats[0], perm=perm,
+                                             v_s_old=vo if kw.get("value_clip") else None)
+            out.append((slabs.clone(), sc.clone()))
+    finally:
+        lib.tsm_debug_set_update_variant(0)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
