@@ -297,3 +297,38 @@ def test_nan_in_buffer_raises_malformed_buffer_error():
         env.agent_vel[2, 1, 0] = float("nan")  # a poisoned env state propagates into the stored observations
         with pytest.raises(MalformedBufferError, match="NaN"):
             col.collect(n_step=4)
+
+
+def test_update_grid_is_not_monotone_and_slabs_are_sized_for_the_largest_grid():
+    """tsm_ppo_update_grid gives a merged last minibatch (320 tiles) FEWER workgroups than a regular one (256 tiles), so
+    workspaces must be sized by the largest grid over the minibatches, not by the grid of the largest minibatch.
+    9216 rows per agent with batch_size 4096 split into [4096, 5120] (Batch.split merge_last): graph replay and eager
+    launches must both run (ops.ppo_update_fused refuses a slab buffer that is too small) and agree bit for bit."""
+    assert ops.ppo_update_grid(5120) < ops.ppo_update_grid(4096)
+    for M in (1, 15, 16, 17, 4096, 5120, 8192, 16384, 65536, 10**6):
+        g = ops.ppo_update_grid(M)
+        assert 1 <= g <= -(-M // 16)
+    with pytest.raises(ValueError):  # capacity check
+        P = torch.zeros(ops.policy_param_count(18, 64, 5), device=DEV)
+        z = torch.zeros(4096, device=DEV)
+        ops.ppo_update_fused(P, torch.zeros(4096, 18, device=DEV), torch.zeros(4096, dtype=torch.int32, device=DEV), z, z, z,
+                             ops.make_ppo_cfg(adv_norm=False), 5, 64, slabs=torch.zeros(8, P.numel(), device=DEV))
+    finals = []
+    for use_graph in (True, False):
+        np.random.seed(5)
+        n_env, T = 384, 24
+        env = DeviceSimpleSpreadVectorEnv(n_env, 3, max_cycles=T, device=DEV, seed=2)
+        net = DiscreteActorCritic(18, 5, 64, device=DEV, seed=1)
+        algo = PPO(net=net, lr=1e-3, seed=3, use_graph=use_graph, dispatch="per_agent")
+        buf = DeviceVectorReplayBuffer(n_env * T, n_env, 3, 18, device=DEV)
+        col = Collector(algo, env, buf)
+        col.reset()
+        assert [e - s for s, e in split_bounds(n_env * T, 4096)] == [4096, 5120]
+        for _ in range(3):
+            with policy_within_training_step(algo):
+                col.collect(n_step=n_env * T)
+                st = algo.update(buf, 4096, 1)
+            col.reset_buffer(keep_statistics=True)
+        assert np.isfinite(st.get_loss_stats_dict()["agent_0/loss"])
+        finals.append(net.flat.data.clone())
+    assert torch.equal(finals[0], finals[1])

@@ -193,8 +193,8 @@ class PPO(nn.Module):
         P, A, H = self.net.flat.data, self.net.n_act, self.net.hidden
         n_steps = repeat * len(bounds)
         scal = torch.zeros(n_steps, 4, dtype=torch.float32, device=dev)
-        max_M = max(e - s for s, e in bounds)
-        n_blk_max = ops.ppo_update_grid(max_M)
+        # the grid is not monotone in the minibatch size (ops.ppo_update_grid): size the slabs for the largest grid
+        n_blk_max = max(ops.ppo_update_grid(e - s) for s, e in bounds)
         slabs = self._ws.get(("slabs", n_blk_max))
         if slabs is None:
             slabs = torch.empty(n_blk_max, P.numel(), dtype=torch.float32, device=dev)
@@ -282,7 +282,8 @@ class PPO(nn.Module):
         if g is None:
             self._warm_kernels(buffer)
             n_steps = len(groups) * repeat * len(bounds)
-            nb_max = ops.ppo_update_grid(max(e - s for s, e in bounds))
+            # the grid is not monotone in the minibatch size: size the slabs / partials for the largest grid
+            nb_max = max(ops.ppo_update_grid(e - s) for s, e in bounds)
             f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
             w = dict(perm=torch.zeros(len(groups), repeat, n_g, dtype=torch.int64, device=dev),
                      mb_start=torch.as_tensor([b[0] for b in bounds] + [n_g], dtype=torch.int64, device=dev),

@@ -949,12 +949,17 @@ static int g_update_variant = 0;
 extern "C" __attribute__((visibility("default"))) void tsm_debug_set_update_variant(int v) { g_update_variant = v; }
 
 TSM_EXPORT int tsm_ppo_update_grid(int64_t M, int32_t max_blocks) {
-    // one-net workgroups need 52 KB of LDS: three fit on a CU (768 on the chip).  Measured (tools/ab_update_variant.py,
-    // gradient step = update + Adam): up to 384 tiles one tile per workgroup pair is fastest (5120 rows: 22.4 us vs 23.6
-    // at 256); beyond that the extra slabs cost more than the second wave of tiles (8192 rows: 24.8 us at 256 vs 25.5
-    // at 384) until there are many tiles per workgroup (65 536 rows: 88 us at 384 vs 103 at 256).
+    // One-net workgroups need 52 KB of LDS: three fit on a CU (768 on the chip).  The rule comes from a sweep of the
+    // gradient step (update + Adam, us) over the slab count n_blocks -- every slab is 45 KB written here and read back
+    // by Adam, so fewer slabs pay for a second tile per workgroup once the chip is full:
+    //   tiles  128: 14.8 @128 | 18.3 @64        256: 19.4 @256 | 19.3 @128      320: 22.0 @160 | 22.2 @320 | 24.9 @107
+    //          384: 22.4 @192 | 25.1 @384       512: 24.8 @256 | 25.5 @384     1024: 34.3 @384 | 35.7 @256 | 44.7 @512
+    //         4096: 88 @384 | 103 @256 | 112 @512
     const int64_t n_tiles = ceil_div(M > 0 ? M : 1, R);
-    int64_t g = n_tiles <= 384 ? n_tiles : (n_tiles < 1024 ? 256 : 384);
+    int64_t g;
+    if (n_tiles <= 256) g = n_tiles;
+    else if (n_tiles < 1024) g = (n_tiles + 1) / 2 < 256 ? (n_tiles + 1) / 2 : 256;
+    else g = 384;
     if (max_blocks > 0 && g > max_blocks) g = max_blocks;
     return (int)g;
 }

@@ -392,8 +392,14 @@ def ppo_update_fused(params, obs, act, logp_old, adv, returns, cfg: tsm_ppo_cfg,
     dev = obs.device
     if slabs is None:
         slabs = torch.empty(n_blocks, P, dtype=torch.float32, device=dev)
+    elif slabs.numel() < n_blocks * P:  # the kernel writes n_blocks slabs of P floats: never launch into a smaller buffer
+        raise ValueError(f"ppo_update_fused: slabs holds {slabs.numel()} floats, {n_blocks} slabs of {P} need {n_blocks * P}")
     if partial is None:
         partial = torch.empty(n_blocks * 4, dtype=torch.float64, device=dev)
+    elif partial.numel() < n_blocks * 4:
+        raise ValueError(f"ppo_update_fused: partial holds {partial.numel()} values, {n_blocks} workgroups need {n_blocks * 4}")
+    if perm is not None and perm.numel() < M:
+        raise ValueError(f"ppo_update_fused: perm holds {perm.numel()} row ids, M = {M}")
     if scalars is None and want_scalars:
         scalars = torch.empty(4, dtype=torch.float32, device=dev)
     call("tsm_ppo_update_fused", ptr(_chk(params, torch.float32, "params")), ptr(image), D, hidden, n_act, ptr(obs),
