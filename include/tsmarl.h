@@ -266,7 +266,11 @@ int tsm_policy_forward(const float *params, const float *param_image, int32_t ob
                        const float *obs, int64_t B, int mode, uint64_t seed, uint64_t offset,
                        const uint64_t *offset_dev, float *logits_out, float *value_out, int32_t *act_io, float *logp_out,
                        void *stream);
-/* recommended number of workgroups (= gradient slabs) for a minibatch of M rows */
+/* recommended n_blocks (= number of gradient slabs; the launch is n_blocks x 2 workgroups, one net each) for a
+ * minibatch of M rows.  NOT monotone in M (a slab is 45 KB written here and read back by tsm_adam_step, so past a full
+ * chip fewer slabs with two tiles each are faster): when one workspace serves minibatches of several sizes, size
+ * grad_slabs_out / loss_partial_out by the LARGEST value over those sizes, not by the value at the largest size.
+ * tsm_ppo_update_fused writes n_blocks * n_param floats and n_blocks * 4 doubles. */
 int tsm_ppo_update_grid(int64_t M, int32_t max_blocks);
 int tsm_ppo_update_fused(const float *params, const float *param_image, int32_t obs_dim, int32_t hidden,
                          int32_t n_act,
