@@ -204,6 +204,53 @@ __device__ __forceinline__ void tile_forward(float *lds, const Lay<H> &ly, const
     __syncthreads();
 }
 
+// The same forward for a workgroup of EIGHT waves (rollout.hip): waves 0-3 carry the actor, waves 4-7 the critic, one
+// accumulator chain per wave and layer instead of two interleaved ones.  Same chains, same k order as tile_forward:
+// bit-identical outputs.  All 512 threads must call it (three barriers inside).
+template <int H>
+__device__ __forceinline__ void tile_forward_split(float *lds, const Lay<H> &ly, const Dims &d) {
+    const int lane = threadIdx.x & 63, w8 = threadIdx.x >> 6, net = w8 >> 2, w = w8 & 3;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int col = 16 * w + r16;
+    {   // L1
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float *xa = lds + ly.X + r16 * d.ld1 + kq;
+        const float *wp = lds + ly.W1 + (net * H + col) * d.ld1 + kq;
+        for (int k0 = 0; k0 < d.Kp1; k0 += 4) acc = mfma(xa[k0], wp[k0], acc);
+        const float b = lds[ly.B1 + net * H + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[ly.H1 + (kq * 4 + r) * ly.ld2 + net * H + col] = fmaxf(acc[r] + b, 0.f);
+    }
+    __syncthreads();
+    {   // L2
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float *ha = lds + ly.H1 + r16 * ly.ld2 + net * H + kq;
+        const float *wp = lds + (net ? ly.W2c : ly.W2a) + col * ly.ldh + kq;
+#pragma unroll
+        for (int k0 = 0; k0 < H; k0 += 4) acc = mfma(ha[k0], wp[k0], acc);
+        const float b = lds[ly.B2 + net * H + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[ly.H2 + (kq * 4 + r) * ly.ld2 + net * H + col] = fmaxf(acc[r] + b, 0.f);
+    }
+    __syncthreads();
+    if (w8 == 0) {  // logits (MFMA, A padded to 16)
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float *ha = lds + ly.H2 + r16 * ly.ld2 + kq;
+        const float *wa = lds + ly.W3a + r16 * ly.ldh + kq;
+#pragma unroll
+        for (int k0 = 0; k0 < H; k0 += 4) acc = mfma(ha[k0], wa[k0], acc);
+        const float b = lds[ly.B3a + r16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[ly.OUT + (kq * 4 + r) * ly.ldo + r16] = acc[r] + b;
+    } else if (w8 == 4 && lane < R) {  // value (VALU dot)
+        const float *hc = lds + ly.H2 + lane * ly.ld2 + H;
+        float s = 0.f;
+        for (int j = 0; j < H; ++j) s = fmaf(hc[j], lds[ly.W3c + j], s);
+        lds[ly.OUT + lane * ly.ldo + 16] = s + lds[ly.B3c];
+    }
+    __syncthreads();
+}
+
 constexpr int kXRegs = (R * (16 * kMaxJ + 2) + NT - 1) / NT;  // X tile elements per thread (worst case)
 
 // Gather one X tile into registers in two phases so that other loads can be issued in between:

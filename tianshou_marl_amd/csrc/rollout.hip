@@ -88,8 +88,13 @@ __device__ __forceinline__ void row_cdf_pick(float ex, int A, float u, float &cs
 #define XSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[900 + t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 #define STAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 
+// The workgroup has EIGHT waves: in the forward pass waves 0-3 carry the actor and waves 4-7 the critic (one MFMA chain
+// per wave and layer: the forward is 0.9 us shorter than with both chains on four waves); the element-wise loops
+// (observation build, payload scatter) spread over all 512 threads; everything else runs on threads 0..255 as before.
+constexpr int NT2 = 2 * NT;
+
 template <int H>
-__global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
+__global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     extern __shared__ float lds[];
     const Dims d = a.d;
     const MpeCfg c = a.c;
@@ -121,9 +126,12 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     // diagnostics (tsm_debug_set_stamps, >= 1024 slots): [64 + 2b], [65 + 2b] = start / end of workgroup b;
     // [640 + t] = start of step t in workgroup 0
     if (a.stamps && threadIdx.x == 0 && blockIdx.x < 256) a.stamps[64 + 2 * blockIdx.x] = (long long)wall_clock64();
-    if (a.img) stage_image<H>(lds, ly, a.img);
-    else stage_weights<H>(lds, ly, d, a.P);
-    for (int i = threadIdx.x; i < R * d.ld1; i += NT) { lds[ly.X + i] = 0.f; XN0[i] = 0.f; }
+    const bool main_t = threadIdx.x < NT;  // waves 0-3
+    if (main_t) {
+        if (a.img) stage_image<H>(lds, ly, a.img);
+        else stage_weights<H>(lds, ly, d, a.P);
+    }
+    for (int i = threadIdx.x; i < R * d.ld1; i += NT2) { lds[ly.X + i] = 0.f; XN0[i] = 0.f; }
     const VrbState vs = vrb_view(a.vrb_state, B, N);
     // agent lane r < rows_here (wave 0) <-> (env el, agent i); env lane 64 + q (wave 1) owns env q's bookkeeping, so
     // the buffer index algebra runs beside the agent lanes' physics instead of after it
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         s_done[bel] = 1;  // "no pending v_next" before the first step
         s_row[bel] = 0;
     }
-    for (int i = threadIdx.x; i < n_here * st; i += NT) {
+    for (int i = threadIdx.x; i < n_here * st; i += NT2) {
         s_ap[i] = a.apos[(int64_t)e0 * st + i];
         s_av[i] = a.avel[(int64_t)e0 * st + i];
         s_lp[i] = a.lpos[(int64_t)e0 * st + i];
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     Lay<H> lyf = ly;
     int xcur = ly.X, xnxt = ly.total;
     // A. observation rows from the LDS-resident state: one (row, element) per thread
-    for (int i = threadIdx.x; i < rows_here * D; i += NT) {
+    for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
         const int rr = i / D, k = i - rr * D, ee = rr / N;
         lds[xcur + rr * d.ld1 + k] = mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
     }
@@ -175,11 +183,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         STAMP(1);
         // B. actor + critic forward of the 16-row tile
         lyf.X = xcur;
-        tile_forward<H>(lds, lyf, d);
+        tile_forward_split<H>(lds, lyf, d);
         STAMP(2);
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
-        {
+        if (main_t) {
             const int hr = threadIdx.x >> 4, j = threadIdx.x & 15;
             const float *lg = lds + ly.OUT + hr * ly.ldo;
             const bool on = j < d.A;
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         if (last) {
             // the observation of the next collect() call
             if (a.obs_cur_out)
-                for (int i = threadIdx.x; i < rows_here * D; i += NT) {
+                for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
                     const int rr = i / D, k = i - rr * D;
                     a.obs_cur_out[((int64_t)e0 * N + rr) * D + k] = lds[xcur + rr * d.ld1 + k];
                 }
@@ -270,9 +278,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
             local = mpe_local_penalty(c, pos, s_ap + el * st, ai);
         }
         XSTAMP(2);
-        // obs_next rows (terminal observation for finished episodes) on waves 1-3 while wave 0 works on the reward terms
+        // obs_next rows (terminal observation for finished episodes) on waves 1-7 while wave 0 works on the reward terms
         if (threadIdx.x >= 64)
-            for (int i = threadIdx.x - 64; i < rows_here * D; i += NT - 64) {
+            for (int i = threadIdx.x - 64; i < rows_here * D; i += NT2 - 64) {
                 const int rr = i / D, k = i - rr * D, ee = rr / N;
                 XN[rr * d.ld1 + k] =
                     mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         }
         STAMP(4);
         // E. payload scatter into the time-major SoA store (rows of consecutive envs are adjacent)
-        for (int i = threadIdx.x; i < rows_here * D; i += NT) {
+        for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
             const int rr = i / D, k = i - rr * D, ee = rr / N;
             const int64_t dst = (s_row[ee] * N + (rr - ee * N)) * D + k;
             a.obs_store[dst] = lds[xcur + rr * d.ld1 + k];
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
         if (any_done) {
             if (a.vnext_store) {
                 lyf.X = xnxt;
-                tile_forward<H>(lds, lyf, d);
+                tile_forward_split<H>(lds, lyf, d);
                 if (lane_live && s_done[el]) a.vnext_store[s_row[el] * N + ai] = lds[ly.OUT + r * ly.ldo + 16];
             }
             if (a.auto_reset) {
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
                     mpe_reset_agent(c, e, a.env_seed, s_ep[el], ai, s_ap + el * st, s_av + el * st, s_lp + el * st);
                 __syncthreads();
                 // first observation of the new episodes
-                for (int i = threadIdx.x; i < rows_here * D; i += NT) {
+                for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
                     const int rr = i / D, k = i - rr * D, ee = rr / N;
                     if (s_done[ee])
                         XN[rr * d.ld1 + k] =
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(RolloutArgs a) {
     // env state + sub-buffer bookkeeping back to HBM
     __syncthreads();
     if (a.stamps && threadIdx.x == 0 && blockIdx.x < 256) a.stamps[65 + 2 * blockIdx.x] = (long long)wall_clock64();
-    for (int i = threadIdx.x; i < n_here * st; i += NT) {
+    for (int i = threadIdx.x; i < n_here * st; i += NT2) {
         a.apos[(int64_t)e0 * st + i] = s_ap[i];
         a.avel[(int64_t)e0 * st + i] = s_av[i];
         a.lpos[(int64_t)e0 * st + i] = s_lp[i];
@@ -427,7 +435,7 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
         attr_set = true;
     }
     const int EPB = R / a.c.N;
-    hipLaunchKernelGGL((rollout_kernel<64>), dim3((unsigned)ceil_div(a.c.n_env, EPB)), dim3(NT), shmem,
+    hipLaunchKernelGGL((rollout_kernel<64>), dim3((unsigned)ceil_div(a.c.n_env, EPB)), dim3(NT2), shmem,
                        tsm_stream(stream), a);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
