@@ -28,8 +28,10 @@ def _job(n_env, N, T, fused, seed=3, slots=None, **ppo_kw):
     return env, net, algo, buf, col
 
 
+# (1024, 3): 205 workgroups -> the eight-wave form of the kernel; (1400, 3): 280 workgroups of 70 KB LDS -> the four-wave
+# form (two workgroups per CU); (600, 8): 300 workgroups of 91 KB LDS -> eight waves again
 @pytest.mark.parametrize("n_env,N,T,steps", [(64, 3, 25, 25), (7, 3, 6, 15), (33, 8, 5, 12), (5, 1, 4, 9), (10, 2, 7, 7),
-                                             (1024, 3, 25, 25)])
+                                             (1024, 3, 25, 25), (1400, 3, 5, 7), (600, 8, 4, 6)])
 def test_fused_rollout_is_bit_identical_to_unfused(n_env, N, T, steps):
     slots = steps + 3 + 1  # both collects fit without wrap-around
     outs = []

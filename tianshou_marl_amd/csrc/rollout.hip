@@ -88,14 +88,14 @@ __device__ __forceinline__ void row_cdf_pick(float ex, int A, float u, float &cs
 #define XSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[900 + t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 #define STAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 
-// The workgroup has EIGHT waves: in the forward pass waves 0-3 carry the actor and waves 4-7 the critic (one MFMA chain
+// With NT2 = 512 the workgroup has EIGHT waves: in the forward pass waves 0-3 carry the actor and waves 4-7 the critic (one MFMA chain
 // per wave and layer); the element-wise loops (observation build, payload scatter) spread over all 512 threads;
 // everything else runs on threads 0..255.  Measured: forward 2.2 -> 2.1 us, scatter 0.7 -> 0.5 us per vector step.  The
 // forward gains little because the two chains of a SIMD share its matrix pipe wherever they sit (dropping the critic
 // chains altogether, as an experiment, gave 1.3 us): the tile forward is MFMA-issue bound at 16 rows per CU.
-constexpr int NT2 = 2 * NT;
-
-template <int H>
+// NT2 = 256 is the four-wave form (both chains on every wave, tile_forward): its workgroups need half the registers, so
+// two of them share a CU when their LDS fits twice -- the better choice once there are more workgroups than CUs.
+template <int H, int NT2>
 __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     extern __shared__ float lds[];
     const Dims d = a.d;
@@ -185,7 +185,8 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         STAMP(1);
         // B. actor + critic forward of the 16-row tile
         lyf.X = xcur;
-        tile_forward_split<H>(lds, lyf, d);
+        if constexpr (NT2 == 2 * NT) tile_forward_split<H>(lds, lyf, d);
+        else tile_forward<H>(lds, lyf, d);
         STAMP(2);
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         if (any_done) {
             if (a.vnext_store) {
                 lyf.X = xnxt;
-                tile_forward_split<H>(lds, lyf, d);
+                if constexpr (NT2 == 2 * NT) tile_forward_split<H>(lds, lyf, d);
+                else tile_forward<H>(lds, lyf, d);
                 if (lane_live && s_done[el]) a.vnext_store[s_row[el] * N + ai] = lds[ly.OUT + r * ly.ldo + 16];
             }
             if (a.auto_reset) {
@@ -432,13 +434,20 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     const size_t shmem = ((size_t)ly.total + extra) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_kernel<64>),
+        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_kernel<64, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_kernel<64, 2 * NT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set = true;
     }
     const int EPB = R / a.c.N;
-    hipLaunchKernelGGL((rollout_kernel<64>), dim3((unsigned)ceil_div(a.c.n_env, EPB)), dim3(NT2), shmem,
-                       tsm_stream(stream), a);
+    const unsigned n_wg = (unsigned)ceil_div(a.c.n_env, EPB);
+    // Eight waves when a CU holds one workgroup anyway (no more workgroups than CUs, or an LDS footprint above half a
+    // CU); four waves otherwise, so that two workgroups fit the register file of a CU.  Measured (us per 25-step
+    // collect, 4 / 8 waves): 1024 envs x 3 agents 242 / 234; 4096 x 3: 505 / 775; 4096 x 8 (91 KB of LDS): 7100 / 2250.
+    const bool eight = n_wg <= 256 || shmem > 80 * 1024;
+    if (eight) hipLaunchKernelGGL((rollout_kernel<64, 2 * NT>), dim3(n_wg), dim3(2 * NT), shmem, tsm_stream(stream), a);
+    else hipLaunchKernelGGL((rollout_kernel<64, NT>), dim3(n_wg), dim3(NT), shmem, tsm_stream(stream), a);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }
