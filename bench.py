@@ -201,15 +201,18 @@ def kernel_rooflines(a, algo, buf):
     gae_s = per_launch(lambda: ops.gae_lanes(v, v2, v3, fl, fl2, out=out))
     # (3) the HBM-bound kernels at the north star's roofline size (n_env=4096, n_agent=8, T=25: 819 200 samples)
     grid = []
-    Tg, Lg = 25, 4096 * 8
-    vg, vg2, vg3 = (torch.randn(Tg, Lg, device=dev) for _ in range(3))
-    flg, flg2 = (torch.zeros(Tg, Lg, dtype=torch.uint8, device=dev) for _ in range(2))
-    outg = (torch.empty_like(vg), torch.empty_like(vg))
-    s_g = per_launch(lambda: ops.gae_lanes(vg, vg2, vg3, flg, flg2, out=outg))
-    grid.append({"kernel": "gae_lanes_kernel", "n_env": 4096, "n_agent": 8, "T": Tg, "bound": "hbm",
-                 "bytes_per_launch": 22 * Tg * Lg, "us_per_launch": s_g * 1e6, "achieved": 22 * Tg * Lg / s_g / 1e9,
-                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 22 * Tg * Lg / s_g / HBM_PEAK,
-                 "traffic": pmc_traffic("gae_lanes_kernel", gae_grid_threads(Tg, Lg))})
+    Lg = 4096 * 8
+    for Tg in (2048, 256, 25):  # SURVEY 8d roofline grid: synthetic horizons 2048 and 256, then the env's own T = 25
+        vg, vg2, vg3 = (torch.randn(Tg, Lg, device=dev) for _ in range(3))
+        flg, flg2 = (torch.zeros(Tg, Lg, dtype=torch.uint8, device=dev) for _ in range(2))
+        outg = (torch.empty_like(vg), torch.empty_like(vg))
+        s_g = per_launch(lambda: ops.gae_lanes(vg, vg2, vg3, flg, flg2, out=outg), n=20 if Tg <= 256 else 4, reps=3)
+        grid.append({"kernel": "gae_lanes_kernel", "n_env": 4096, "n_agent": 8, "T": Tg, "bound": "hbm",
+                     "bytes_per_launch": 22 * Tg * Lg, "us_per_launch": s_g * 1e6, "achieved": 22 * Tg * Lg / s_g / 1e9,
+                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 22 * Tg * Lg / s_g / HBM_PEAK,
+                     "traffic": pmc_traffic("gae_lanes_kernel", gae_grid_threads(Tg, Lg))})
+        del vg, vg2, vg3, flg, flg2, outg
+    Tg = 25
     Mg, A = Tg * Lg, net.n_act
     lg_ = torch.randn(Mg, A, device=dev)
     vals = [torch.randn(Mg, device=dev) for _ in range(4)]
@@ -222,7 +225,7 @@ def kernel_rooflines(a, algo, buf):
                  "bytes_per_launch": loss_bytes, "us_per_launch": s_l * 1e6, "achieved": loss_bytes / s_l / 1e9,
                  "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": loss_bytes / s_l / HBM_PEAK,
                  "traffic": pmc_traffic("loss_kernel", 4096 * 256 if Mg > 4096 * 256 else -(-Mg // 256) * 256)})
-    del vg, vg2, vg3, flg, flg2, outg, lg_, vals, actg
+    del lg_, vals, actg
     # (4) the fused gradient step when the workload hands it more than one 16-row tile per workgroup: pooled minibatch
     # of 65 536 rows (SURVEY 8d grid) out of 819 200 buffer rows of this job's observation width.  Opt-in
     # (--pooled-grid): its launches would otherwise mix into the per-kernel averages of the committed rocprofv3 summary,
