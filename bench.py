@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--dispatch", default="per_agent", choices=["per_agent", "pooled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pooled-grid", action="store_true",
-                    help="also time the fused gradient step at a pooled 65 536-row minibatch (roofline_grid entry)")
+                    help="extended roofline_grid: the fused gradient step at a pooled 65 536-row minibatch and GAE at the "
+                         "synthetic horizons T = 2048 and 256")
     ap.add_argument("--cpu-envs", type=int, default=64)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ppo"],
                     help="c2 (default, the headline line): simple_spread N=3 shared PPO; c3: N=8 CTDEPolicy, 4096 envs; "
@@ -202,7 +203,9 @@ def kernel_rooflines(a, algo, buf):
     # (3) the HBM-bound kernels at the north star's roofline size (n_env=4096, n_agent=8, T=25: 819 200 samples)
     grid = []
     Lg = 4096 * 8
-    for Tg in (2048, 256, 25):  # SURVEY 8d roofline grid: synthetic horizons 2048 and 256, then the env's own T = 25
+    # SURVEY 8d roofline grid: the env's own T = 25; the synthetic horizons 2048 and 256 only with --pooled-grid (their
+    # launches have the same kernel name and grid as the T = 25 one and would blur the committed per-kernel summaries)
+    for Tg in ((2048, 256, 25) if getattr(a, "pooled_grid", False) else (25,)):
         vg, vg2, vg3 = (torch.randn(Tg, Lg, device=dev) for _ in range(3))
         flg, flg2 = (torch.zeros(Tg, Lg, dtype=torch.uint8, device=dev) for _ in range(2))
         outg = (torch.empty_like(vg), torch.empty_like(vg))
