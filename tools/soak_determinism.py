@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Soak + determinism check of the headline job: run N training steps (collect + update) and print a hash of the final
+parameters, optimizer state and buffer contents.  Two runs with the same seeds must print the same line: every kernel
+on the path is deterministic (fixed-order reductions, counter-based RNG), so a data race would show up as a mismatch.
+
+    python tools/soak_determinism.py [n_steps]
+"""
+import hashlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+class A:
+    n_env, n_agent, horizon, minibatch, repeat, dispatch = 1024, 3, 25, 4096, 1, "per_agent"
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+    a = A()
+    env, net, algo, buf, col = bench.build_job(a, torch.device("cuda"), 0)
+    ret = 0.0
+    for i in range(n):
+        cs, ts = bench.one_step(a, algo, buf, col)
+        if i % 500 == 0:
+            ret = float(cs.returns.mean()) if len(cs.returns) else ret
+            print(f"step {i}: mean episode return {ret:.3f}", flush=True)
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for t in (net.flat.data, algo.exp_avg, algo.exp_avg_sq, buf.obs_store, buf.act_store, buf.rew_store, buf.logp_store,
+              buf.vs_store, env.agent_pos):
+        h.update(t.detach().cpu().contiguous().numpy().tobytes())
+    print(f"steps {n} opt_step {algo.opt_step} sha256 {h.hexdigest()}")
+
+
+if __name__ == "__main__":
+    main()
