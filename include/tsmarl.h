@@ -78,6 +78,21 @@ int tsm_gae_lanes(const float *v_s, const float *v_s_next, const float *rew,
                   int64_t T, int64_t n_lane, int64_t lanes_per_env, const int32_t *env_start,
                   const int32_t *env_len, double gamma, double gae_lambda, double v_scale,
                   float *returns_out, float *adv_out, void *stream);
+/* The same with `return_scaling` statistics that live in HBM (a2c.py:132-146): rms = f64 {mean, var, count} of
+ * the reference's RunningMeanStd (utils/statistics.py:68-114); v_scale = sqrt(rms[1] + rms_eps) is read by the
+ * kernel, so a captured hipGraph follows the statistics from update to update. */
+int tsm_gae_lanes_rms(const float *v_s, const float *v_s_next, const float *rew,
+                      const uint8_t *terminated, const uint8_t *truncated, int flags_per_lane,
+                      int64_t T, int64_t n_lane, int64_t lanes_per_env, const int32_t *env_start,
+                      const int32_t *env_len, double gamma, double gae_lambda, const double *rms,
+                      double rms_eps, float *returns_out, float *adv_out, void *stream);
+/* RunningMeanStd.update (utils/statistics.py:97-114) with the UNNORMALISED returns of a2c.py:144-146:
+ * x[i] = returns[ids ? ids[i] : i] * sqrt(rms[1] + rms_eps), i < n; batch mean / population variance in f64
+ * (two-level fixed-order sums), then the parallel-variance merge into rms = {mean, var, count} in place.
+ * work: f64[tsm_rms_update_work_elems(n)]. */
+int64_t tsm_rms_update_work_elems(int64_t n);
+int tsm_rms_update(const float *returns, const int64_t *ids, int64_t n, double *rms, double rms_eps,
+                   double *work, void *stream);
 
 /* `episode_mc_return_to_go` (algorithm_base.py:1137-1151) over n_lane independent episodes
  * stored [T][n_lane]; out f32. */
@@ -192,6 +207,12 @@ typedef struct {
  * stats_out [n_mb][2] f32 = {mean, std}.  One launch serves every minibatch of an epoch. */
 int tsm_ppo_adv_stats(const float *adv, const int64_t *perm, const int64_t *mb_start,
                       int32_t n_mb, float *stats_out, void *stream);
+/* The same statistics for long minibatches: every 8192-row chunk of a minibatch is reduced by its own workgroup
+ * (shifted f64 sums), a second launch folds the chunks in chunk order (deterministic; independent of the grid).
+ * max_rows >= the longest minibatch (host knowledge: mb_start lives in HBM); work: f64[tsm_ppo_adv_stats_work_elems]. */
+int64_t tsm_ppo_adv_stats_work_elems(int32_t n_mb, int64_t max_rows);
+int tsm_ppo_adv_stats_wide(const float *adv, const int64_t *perm, const int64_t *mb_start, int32_t n_mb,
+                           int64_t max_rows, double *work, float *stats_out, void *stream);
 
 /* One minibatch of M samples: sample i is row perm[i] of the full-batch arrays (perm == NULL:
  * row first_row + i).  logits [M][A] and value [M] are minibatch-contiguous network outputs.
@@ -217,6 +238,8 @@ int tsm_ppo_loss_finalize(const double *partial, int64_t M, const tsm_ppo_cfg *c
  * param_image / image_map (nullable): padded LDS-layout copy of the parameters kept in sync for the fused
  * MLP kernels (tsm_policy_image_elems / tsm_policy_image_map).
  * step: 1-based Adam step count; when step_dev (device i64[1]) is given it overrides `step`.
+ * lr_dev (nullable, device f64[1]) overrides `lr`: the learning rate an LR scheduler steps after every update
+ * (algorithm_base.py:626-627, optim.py:22-46) lives in HBM, so a captured hipGraph follows the schedule.
  * ------------------------------------------------------------------------------------------- */
 /* out[i] = scale * sum_s grad_slabs[s][i]: the flat gradient handed to the RCCL all-reduce of the
  * env-sharded data-parallel path (no reference counterpart: the reference has no distributed backend). */
@@ -224,9 +247,9 @@ int tsm_reduce_slabs(const float *grad_slabs, int32_t n_slab, int64_t n, double 
                      void *stream);
 int64_t tsm_adam_work_elems(int64_t n);
 int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
-                  float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, double beta1, double beta2,
-                  double eps, double weight_decay, double max_grad_norm, float *work, float *param_image,
-                  const int32_t *image_map, void *stream);
+                  float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, const double *lr_dev,
+                  double beta1, double beta2, double eps, double weight_decay, double max_grad_norm, float *work,
+                  float *param_image, const int32_t *image_map, void *stream);
 /* param_image[image_map[i]] = param[i]  (initial fill of the padded image; pads must already be zero) */
 int tsm_scatter_image(const float *param, int64_t n, const int32_t *image_map, float *param_image,
                       void *stream);

@@ -158,7 +158,8 @@ def _replica_update(net_params, obs, obs_next, act, rew, term, trunc, T, n_env, 
     ret, adv = ret.reshape(-1).astype(np.float32), adv.reshape(-1).astype(np.float32)
     losses = []
     for a in range(N):
-        ids = np.arange(T * n_env) * N + a
+        # the agent's rows in the reference's sample(0) order (env-major, time-ordered) as lane ids of the time-major stores
+        ids = (np.arange(T)[None, :] * n_env + np.arange(n_env)[:, None]).reshape(-1) * N + a
         n = len(ids)
         for _ in range(repeat):
             perm = ids[np.random.permutation(n)]

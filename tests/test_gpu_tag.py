@@ -196,3 +196,57 @@ def test_grouped_policies_collect_and_train_on_tag():
     assert set(out) == {"adversaries", "good"}
     lg.update_match_result("adversaries", "good")
     assert lg.elo_ratings["adversaries"] > 1000 > lg.elo_ratings["good"]
+
+
+def test_configs4_at_full_size_4096_envs():
+    """BASELINE configs[4] at its stated per-job size: 4096 simple_tag worlds (3 adversaries v 1 prey, 2 obstacles),
+    grouped policies, one collect of 25 vector steps, then one self-play and one league training step on the device
+    rows.  The env kernel is spot-checked against the numpy oracle on a 64-env slice of the SAME 4096-env launches."""
+    n_env, T, chk = 4096, 25, 64
+    env = DeviceSimpleTagVectorEnv(n_env, device=DEV, seed=7, max_cycles=T, auto_reset=False)
+    N = env.n_agent
+    env.reset_device()
+    env.agent_pos.mul_(0.5)  # denser worlds: contacts inside the checked slice
+    worlds = []
+    for e in range(chk):
+        w = mpe_tag_oracle.SimpleTagWorld(env.n_adv, env.n_good, env.n_obst, max_cycles=T)
+        w.set_state(env.agent_pos[e].cpu().numpy(), env.agent_vel[e].cpu().numpy(),
+                    env.landmark_pos[e, :env.n_obst].cpu().numpy())
+        worlds.append(w)
+    rng = np.random.default_rng(1)
+    for t in range(6):
+        act = rng.integers(0, 5, (n_env, N))
+        obs_next, rew, term, trunc, done = env.step_device(torch.as_tensor(act, dtype=torch.int32, device=DEV))
+        exp = [w.step(act[e]) for e, w in enumerate(worlds)]
+        np.testing.assert_allclose(obs_next[:chk].cpu().numpy(), np.stack([x[0] for x in exp]), rtol=2e-4, atol=2e-5)
+        close = np.abs(rew[:chk].cpu().numpy() - np.stack([x[1] for x in exp])) < 1e-3
+        assert close.mean() > 0.99
+        assert torch.isfinite(obs_next).all() and torch.isfinite(rew).all()
+    # the training job at this size
+    env = DeviceSimpleTagVectorEnv(n_env, device=DEV, seed=5, max_cycles=T)
+    teams = _team_policies(env)
+    mgr = FlexibleMultiAgentPolicyManager(teams, env, mode="grouped", agent_groups=env.agent_groups)
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=DEV)
+    col = Collector(mgr, env, buf)
+    col.reset()
+    with policy_within_training_step(mgr):
+        st = col.collect(n_step=n_env * T)
+    assert st.n_collected_steps == n_env * T and st.n_collected_episodes == n_env
+    assert st.returns.shape == (n_env, N) and np.isfinite(st.returns).all()
+    assert np.allclose(st.returns[:, :env.n_adv], st.returns[:, :1]) and (st.returns[:, env.n_adv:] <= 1e-6).all()
+    assert len(buf) == n_env * T and not buf.hasnull()
+    batch = agent_batches_from_buffer(buf, env.agents)
+    batch["good"], batch["adversaries"] = batch["agent_0"], batch["adversary_0"]
+    assert len(batch["good"].obs) == n_env * T
+    before = {k: p.net.flat.data.clone() for k, p in teams.items()}
+    sp = SelfPlayTrainer(mgr, main_agent_id="good", snapshot_interval=1, opponent_pool_size=2)
+    out = sp.train_step(batch)
+    assert list(out) == ["good"] and np.isfinite(out["good"]["loss"])
+    assert not torch.equal(before["good"], teams["good"].net.flat.data)
+    assert torch.equal(before["adversaries"], teams["adversaries"].net.flat.data) and len(sp.opponent_pool) == 1
+    lg = LeaguePlayTrainer(mgr, matchmaking="elo", games_per_evaluation=2)
+    out = lg.train_step(batch)
+    assert set(out) == {"adversaries", "good"} and all(np.isfinite(v["loss"]) for v in out.values())
+    assert not torch.equal(before["adversaries"], teams["adversaries"].net.flat.data)
+    for p in teams.values():
+        assert torch.isfinite(p.net.flat.data).all()

@@ -80,6 +80,14 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         g = (torch.full((9,), float(rank + 1)) + torch.arange(9)) / world
         sync.all_reduce_sum_(g)
         assert torch.allclose(g, torch.full((9,), (1 + world) / 2.0) + torch.arange(9), rtol=0, atol=1e-6)
+        # every rank must take the same number of gradient steps per update (unequal env shards can split into a
+        # different number of minibatches -> a different number of all-reduces -> deadlock): agreed values pass (and are
+        # checked once), a disagreement raises on EVERY rank instead of hanging
+        sync.require_equal(18, "the number of gradient steps per update")
+        sync.require_equal(18, "the number of gradient steps per update")
+        assert ("the number of gradient steps per update", 18) in sync._checked
+        with pytest.raises(ValueError, match="disagree"):
+            sync.require_equal(30 + rank, "the number of gradient steps per update")
         np.save(os.path.join(out_dir, f"p{rank}.npy"), p.numpy())
     finally:
         dist.destroy_process_group()

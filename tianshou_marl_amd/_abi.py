@@ -83,6 +83,9 @@ SIGNATURES = {
     "tsm_stream_sync": (_int, [_p]),
     "tsm_stream_abort_capture": (_int, [_p]),
     "tsm_gae_lanes": (_int, [_p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _p, _p, _f64, _f64, _f64, _p, _p, _p]),
+    "tsm_gae_lanes_rms": (_int, [_p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _p, _p, _f64, _f64, _p, _f64, _p, _p, _p]),
+    "tsm_rms_update_work_elems": (_i64, [_i64]),
+    "tsm_rms_update": (_int, [_p, _p, _i64, _p, _f64, _p, _p]),
     "tsm_mc_return_to_go_lanes": (_int, [_p, _i64, _i64, _f64, _p, _p]),
     "tsm_vrb_state_bytes": (_i64, [_i64, _i64]),
     "tsm_vrb_init": (_int, [_p, _i64, _i64, _i64, _p]),
@@ -101,12 +104,14 @@ SIGNATURES = {
     "tsm_categorical_sample": (_int, [_p, _i64, _i32, _u64, _u64, _p, _int, _p, _p, _p]),
     "tsm_categorical_logp_entropy": (_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "tsm_ppo_adv_stats": (_int, [_p, _p, _p, _i32, _p, _p]),
+    "tsm_ppo_adv_stats_work_elems": (_i64, [_i32, _i64]),
+    "tsm_ppo_adv_stats_wide": (_int, [_p, _p, _p, _i32, _i64, _p, _p, _p]),
     "tsm_ppo_loss_partial_elems": (_i64, [_i64]),
     "tsm_ppo_loss_fwd_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p,
                                     C.POINTER(tsm_ppo_cfg), _p, _p, _p, _p]),
     "tsm_ppo_loss_finalize": (_int, [_p, _i64, C.POINTER(tsm_ppo_cfg), _p, _p]),
     "tsm_adam_work_elems": (_i64, [_i64]),
-    "tsm_adam_step": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _p, _f64, _f64, _f64, _f64, _f64, _f64, _p, _p, _p, _p]),
+    "tsm_adam_step": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _p, _f64, _p, _f64, _f64, _f64, _f64, _f64, _p, _p, _p, _p]),
     "tsm_scatter_image": (_int, [_p, _i64, _p, _p, _p]),
     "tsm_policy_image_elems": (_i64, [_i32, _i32, _i32]),
     "tsm_policy_image_map": (_int, [_i32, _i32, _i32, _p]),
@@ -136,7 +141,7 @@ SIGNATURES = {
                                     C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p, _p]),
 }
 
-_NO_STATUS = {"tsm_abi_version", "tsm_last_error", "tsm_stream_abort_capture", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
+_NO_STATUS = {"tsm_rms_update_work_elems", "tsm_ppo_adv_stats_work_elems", "tsm_abi_version", "tsm_last_error", "tsm_stream_abort_capture", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
               "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems",
               "tsm_mlp_param_count", "tsm_mlp_act_elems", "tsm_ctde_head_partial_elems", "tsm_mpe_tag_obs_dim"}
 

@@ -25,7 +25,7 @@ from .. import ops
 from ..data.batch import Batch, split_bounds
 from ..data.buffer import DeviceVectorReplayBuffer
 from ..data.stats import A2CTrainingStats, LazyStats, MapTrainingStats, SequenceSummaryStats
-from ..utils.net import DiscreteActorCritic, RunningMeanStd
+from ..utils.net import DeviceRunningMeanStd, DiscreteActorCritic
 
 
 class PPO(nn.Module):
@@ -53,12 +53,17 @@ class PPO(nn.Module):
 
         self.action_space = Discrete(net.n_act)
         self.observation_space = Box(-np.inf, np.inf, (net.obs_dim,))
-        self.lr, self.betas, self.adam_eps, self.weight_decay = lr, betas, adam_eps, weight_decay
+        # the learning rate lives in HBM too (`_lr_dev`): LR schedulers move it between updates and the captured update
+        # graph reads it in place (algorithm_base.py:626-627)
+        self._lr_dev = torch.tensor([float(lr)], dtype=torch.float64, device=net.flat.device)
+        self._lr = float(lr)
+        self.lr_schedulers: list = []
+        self.betas, self.adam_eps, self.weight_decay = betas, adam_eps, weight_decay
         self.eps_clip, self.dual_clip, self.value_clip = eps_clip, dual_clip, value_clip
         self.advantage_normalization, self.recompute_adv = advantage_normalization, recompute_advantage
         self.vf_coef, self.ent_coef, self.max_grad_norm = vf_coef, ent_coef, max_grad_norm
         self.gae_lambda, self.gamma, self.max_batchsize = gae_lambda, gamma, max_batchsize
-        self.return_scaling, self.ret_rms, self._eps = return_scaling, RunningMeanStd(), 1e-8
+        self.return_scaling, self.ret_rms, self._eps = return_scaling, DeviceRunningMeanStd(net.flat.device), 1e-8
         self.deterministic_eval = deterministic_eval
         self.is_within_training_step = False
         self.dispatch, self.shuffle = dispatch, shuffle
@@ -87,6 +92,15 @@ class PPO(nn.Module):
     @property
     def device(self) -> torch.device:
         return self.net.flat.device
+
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float) -> None:
+        self._lr = float(value)
+        self._lr_dev.fill_(self._lr)
 
     # ---- rollout side -------------------------------------------------------------------------
     def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None,
@@ -138,9 +152,12 @@ class PPO(nn.Module):
         if uniform and (start_h == 0).all():
             T = int(lens_h[0])
             return T, None, None, None
-        slot = (start_h[None, :] + np.arange(S)[:, None]) % S
-        valid = np.arange(S)[:, None] < lens_h[None, :]
-        rows = (slot * B + np.arange(B)[None, :])[valid]
+        # joint-row ids (slot * B + env) in the reference's sample(0) order: env-major, time-ordered inside a
+        # sub-buffer (manager.py:224-229, buffer_base.py:511-514)
+        k = np.arange(S)[None, :]
+        slot = (start_h[:, None] + k) % S
+        valid = k < lens_h[:, None]
+        rows = (slot * B + np.arange(B)[:, None])[valid]
         dev = self.device
         return S, torch.as_tensor(rows).to(dev), torch.as_tensor(start_h.astype(np.int32)).to(dev), \
             torch.as_tensor(lens_h.astype(np.int32)).to(dev)
@@ -160,24 +177,54 @@ class PPO(nn.Module):
         nxt = ops.policy_forward(P, buffer.obs_next_store[:T].reshape(T * L, D), self.net.n_act, self.net.hidden,
                                  mode="none", want_logits=False)
         v_s, v_next, logp_old = cur["value"].view(T, L), nxt["value"].view(T, L), cur["logp"]
-        scale = float(np.sqrt(self.ret_rms.var + self._eps)) if self.return_scaling else 1.0
-        ret, adv = ops.gae_lanes(v_s, v_next, buffer.rew_store[:T].reshape(T, L), buffer.term_store[:T].reshape(T, L),
-                                 buffer.trunc_store[:T].reshape(T, L), self.gamma, self.gae_lambda, v_scale=scale,
-                                 lanes_per_env=N, env_start=env_start, env_len=env_len)
-        if self.return_scaling:  # a2c.py:144-146: update with the UNNORMALISED returns
-            un = ret * scale
-            sel = un.view(T * B, N)[rows] if rows is not None else un
-            self.ret_rms.update(sel)
+        ret, adv = self._gae(v_s, v_next, buffer.rew_store[:T].reshape(T, L), buffer.term_store[:T].reshape(T, L),
+                             buffer.trunc_store[:T].reshape(T, L), N, env_start=env_start, env_len=env_len, rows=rows)
         return dict(T=T, rows=rows, obs=obs, act=act, v_s=v_s.reshape(-1), ret=ret.reshape(-1), adv=adv.reshape(-1),
                     logp_old=logp_old, n_env=B, n_agent=N)
+
+    def _gae(self, v_s, v_next, rew, term, trunc, N: int, env_start=None, env_len=None, rows=None, out=None):
+        """compute_episodic_return on [T, L] lanes, with the return_scaling arithmetic of a2c.py:132-146 when enabled:
+        the critic values are un-normalised by sqrt(ret_rms.var + eps), the returns divided by it, and ret_rms is then
+        updated with the unnormalised returns -- all on device (statistics in HBM), so the pass can be captured."""
+        if not self.return_scaling:
+            return ops.gae_lanes(v_s, v_next, rew, term, trunc, self.gamma, self.gae_lambda, lanes_per_env=N,
+                                 env_start=env_start, env_len=env_len, out=out)
+        rms = self.ret_rms.dev
+        T, L = v_s.shape
+        if self.dispatch == "per_agent" and N > 1:
+            # MARLDispatcher preprocesses agent after agent with the SAME algorithm object (marl.py:208-249): the running
+            # statistics advance between the agents, so agent a + 1 is scaled with what agent a left behind
+            B = L // N
+            ret, adv = out if out is not None else (torch.empty_like(v_s), torch.empty_like(v_s))
+            lane = lambda x, a: x.view(T, B, N)[:, :, a].contiguous()  # noqa: E731
+            for a in range(N):
+                r, ad = ops.gae_lanes(lane(v_s, a), lane(v_next, a), lane(rew, a), lane(term, a), lane(trunc, a),
+                                      self.gamma, self.gae_lambda, lanes_per_env=1, env_start=env_start, env_len=env_len,
+                                      rms=rms, rms_eps=self._eps)
+                self.ret_rms.update_scaled_returns(r, self._eps, ids=rows)  # rows index the [T, B] lane array
+                ret.view(T, B, N)[:, :, a].copy_(r)
+                adv.view(T, B, N)[:, :, a].copy_(ad)
+            return ret, adv
+        ret, adv = ops.gae_lanes(v_s, v_next, rew, term, trunc, self.gamma, self.gae_lambda, lanes_per_env=N,
+                                 env_start=env_start, env_len=env_len, out=out, rms=rms, rms_eps=self._eps)
+        ids = None if rows is None else (rows[:, None] * N + torch.arange(N, device=rows.device)[None, :]).reshape(-1)
+        self.ret_rms.update_scaled_returns(ret, self._eps, ids=ids)
+        return ret, adv
 
     def _sample_ids(self, pb: dict, agent: int | None) -> torch.Tensor | None:
         """Flat sample ids ((slot*B+env)*N + agent) of the rows to train on; None = all, contiguous."""
         T, B, N, rows = pb["T"], pb["n_env"], pb["n_agent"], pb["rows"]
         dev = self.device
-        if rows is None and agent is None:
+        if rows is None and agent is None and self.shuffle != "numpy":
             return None
-        base = rows if rows is not None else torch.arange(T * B, device=dev)
+        if rows is not None:
+            base = rows
+        elif self.shuffle == "numpy":
+            # parity mode: position p of the reference batch (env-major, time-ordered: sample(0)) -> joint row id,
+            # so that np.random.permutation picks the very rows Batch.split would (batch.py:1219)
+            base = ref_order_rows(T, B, dev)
+        else:
+            base = torch.arange(T * B, device=dev)
         if agent is None:
             return (base[:, None] * N + torch.arange(N, device=dev)[None, :]).reshape(-1)
         return base * N + agent
@@ -192,6 +239,8 @@ class PPO(nn.Module):
         mb_start = torch.as_tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=dev)
         P, A, H = self.net.flat.data, self.net.n_act, self.net.hidden
         n_steps = repeat * len(bounds)
+        if self._grad_sync is not None:
+            self._grad_sync.require_equal(n_steps, "the number of gradient steps per update")
         scal = torch.zeros(n_steps, 4, dtype=torch.float32, device=dev)
         # the grid is not monotone in the minibatch size (ops.ppo_update_grid): size the slabs for the largest grid
         n_blk_max = max(ops.ppo_update_grid(e - s) for s, e in bounds)
@@ -210,7 +259,8 @@ class PPO(nn.Module):
                 perm_local = ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, device=dev)[0]
                 ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
             perm = perm_local if ids is None else ids[perm_local]
-            stats = ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm) if self.advantage_normalization else None
+            stats = (ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm, max_rows=max(e - s for s, e in bounds))
+                     if self.advantage_normalization else None)
             for j, (s, e) in enumerate(bounds):
                 M = e - s
                 nb = ops.ppo_update_grid(M)
@@ -225,7 +275,7 @@ class PPO(nn.Module):
                     ops.reduce_slabs(grads, out=flat_g, scale=1.0 / self._grad_sync.world)  # mean = sum of g_i / world
                     self._grad_sync.all_reduce_sum_(flat_g)
                     grads = flat_g.view(1, -1)
-                ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr,
+                ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr, lr_dev=self._lr_dev,
                               betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
                               max_grad_norm=self.max_grad_norm, work=self._adam_work, image=self.net.image,
                               image_map=self.net.image_map)
@@ -276,12 +326,14 @@ class PPO(nn.Module):
         n_g = T * B if per_agent else T * L
         bounds = split_bounds(n_g, batch_size or -1, merge_last=True)
         stored = buffer.vnext_store is not None and buffer.policy_outputs_version == self.param_version
-        key = ("graph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.lr, self.max_grad_norm, stored)
+        key = ("graph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored)
         g = self._ws.get(key)
         P, A, H = self.net.flat.data, self.net.n_act, self.net.hidden
         if g is None:
             self._warm_kernels(buffer)
             n_steps = len(groups) * repeat * len(bounds)
+            if self._grad_sync is not None:
+                self._grad_sync.require_equal(n_steps, "the number of gradient steps per update")
             # the grid is not monotone in the minibatch size: size the slabs / partials for the largest grid
             nb_max = max(ops.ppo_update_grid(e - s) for s, e in bounds)
             f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
@@ -329,8 +381,7 @@ class PPO(nn.Module):
                                                 logits=None))
                     ops.policy_forward(P, obs_next, A, H, mode="none", image=img,
                                        out=dict(value=w["v_next"].view(-1), logits=None))
-                ops.gae_lanes(w["v_s"], w["v_next"], rew, term, trunc, self.gamma, self.gae_lambda, lanes_per_env=N,
-                              out=(w["ret"], w["adv"]))
+                self._gae(w["v_s"], w["v_next"], rew, term, trunc, N, out=(w["ret"], w["adv"]))
 
             def body():
                 if self.shuffle == "device":
@@ -342,7 +393,8 @@ class PPO(nn.Module):
                                             offset_mul=1 if per_agent else 0, out=w["perm"])
                 preprocess()
                 if "mb_start_all" in w:
-                    ops.ppo_adv_stats(w["adv"], w["mb_start_all"], perm=w["perm"].view(-1), out=w["stats"].view(-1, 2))
+                    ops.ppo_adv_stats(w["adv"], w["mb_start_all"], perm=w["perm"].view(-1), out=w["stats"].view(-1, 2),
+                                      max_rows=max(e - s for s, e in bounds))
                 k = 0
                 for gi in range(len(groups)):
                     for r in range(repeat):
@@ -350,7 +402,8 @@ class PPO(nn.Module):
                             preprocess(recompute=True)
                         perm = w["perm"][gi, r]
                         if self.advantage_normalization and "mb_start_all" not in w:
-                            ops.ppo_adv_stats(w["adv"], w["mb_start"], perm=perm, out=w["stats"][gi, r])
+                            ops.ppo_adv_stats(w["adv"], w["mb_start"], perm=perm, out=w["stats"][gi, r],
+                                              max_rows=max(e - s for s, e in bounds))
                         for j, (s, e) in enumerate(bounds):
                             nb = ops.ppo_update_grid(e - s)
                             ops.ppo_update_fused(P, obs, act, w["logp"], w["adv"].view(-1), w["ret"].view(-1), self._cfg,
@@ -364,7 +417,7 @@ class PPO(nn.Module):
                                 ops.reduce_slabs(grads, out=w["flat_g"], scale=1.0 / self._grad_sync.world)
                                 self._grad_sync.all_reduce_sum_(w["flat_g"])
                                 grads = w["flat_g"].view(1, -1)
-                            ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, 1, lr=self.lr,
+                            ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, 1, lr=self.lr, lr_dev=self._lr_dev,
                                           betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
                                           max_grad_norm=self.max_grad_norm, work=self._adam_work,
                                           step_dev=w["step_dev"], image=self.net.image, image_map=self.net.image_map)
@@ -374,10 +427,12 @@ class PPO(nn.Module):
 
             graph = torch.cuda.CUDAGraph()
             if self._grad_sync is not None:
-                # every rank captures the same collective sequence; a failed capture falls back to eager launches.
-                # The capture is driven by hand so that a failure leaves no stream in capture mode and no stream
-                # context entered (torch.cuda.graph's __exit__ skips its clean-up when capture_end raises).
-                # thread_local: the process group's watchdog thread may touch the device while this thread captures.
+                # Every rank captures the same collective sequence.  Whether a backend CAN be captured is decided before
+                # this point (parallel.attach_data_parallel: only RCCL; anything else runs the eager path from the
+                # start).  A capture that fails all the same is fatal: the process group's own stream has joined the
+                # capture, HIP leaves it invalidated, and every later collective on it dies
+                # (hipErrorStreamCaptureInvalidated) -- so there is no in-process fall-back; the job is re-started with
+                # eager collectives instead.  thread_local: the watchdog thread may touch the device meanwhile.
                 err = None
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream())
@@ -391,29 +446,31 @@ class PPO(nn.Module):
                         graph.capture_end()
                     except Exception as e:  # noqa: BLE001
                         err = err or e
-                    if err is not None:  # make sure the side stream is out of capture mode whatever state torch left it in
+                    if err is not None:
                         ops.call("tsm_stream_abort_capture", side.cuda_stream)
-                if err is None:
-                    torch.cuda.current_stream().wait_stream(side)
                 if err is not None:
-                    import warnings
-
-                    warnings.warn(f"capturing the all-reduce into the update graph failed ({err!r}); using eager launches",
-                                  stacklevel=2)
-                    self.graph_collectives = False
-                    torch.cuda.synchronize()
-                    return None
+                    raise RuntimeError(
+                        "capturing the gradient all-reduce into the update hipGraph failed "
+                        f"({type(err).__name__}: {err}).  Streams behind an invalidated capture are not usable, so this "
+                        "process cannot continue: start the job again with TSM_GRAPH_COLLECTIVES=0 (eager collectives)."
+                    ) from err
+                torch.cuda.current_stream().wait_stream(side)
             else:
                 with torch.cuda.graph(graph):
                     body()
             w["graph"] = graph
+            if self.shuffle == "numpy":
+                base = ref_order_rows(T, B, dev)
+                w["ref_ids"] = [base * N + a if a is not None else
+                                (base[:, None] * N + torch.arange(N, device=dev)[None, :]).reshape(-1) for a in groups]
             self._ws[key] = g = w
         # fresh permutations for this update (Batch.split draws one per repeat, batch.py:1219)
         if self.shuffle == "numpy":
             for gi, a in enumerate(groups):
                 for r in range(repeat):
                     pl = torch.as_tensor(np.random.permutation(n_g)).to(dev)
-                    g["perm"][gi, r].copy_(pl if a is None else pl * N + a)
+                    # positions of the reference batch (sample(0) order) -> lane ids of the time-major stores
+                    g["perm"][gi, r].copy_(g["ref_ids"][gi][pl])
         # shuffle == "device": the permutations are drawn inside the graph (tsm_random_permutations)
         if g.get("step_host") != self.opt_step:  # the device-side step count is stale (eager updates, a loaded checkpoint)
             g["step_dev"].fill_(self.opt_step)
@@ -463,19 +520,26 @@ class PPO(nn.Module):
         return out
 
     def update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
-        """OnPolicyAlgorithm.update (algorithm_base.py:852-863): raises outside a training step (:610-615)."""
+        """OnPolicyAlgorithm.update -> Algorithm._update (algorithm_base.py:852-863, 584-629): raises outside a training
+        step (:610-615); steps every LR scheduler once per update (:626-627)."""
         if not self.is_within_training_step:
             raise RuntimeError(
                 "update() was called outside of a training step as signalled by `is_within_training_step=False`; "
                 "wrap the call in `policy_within_training_step(policy)` (tianshou/utils/torch_utils.py:31-46)")
         t0 = time.time()
+        out = self._update(buffer, batch_size, repeat, t0)
+        for sched in self.lr_schedulers:
+            sched.step()
+        out.train_time = time.time() - t0
+        return out
+
+    def _update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int, t0: float):
         # `flat` is the source of truth and may have been written from outside (load_state_dict, broadcast, tests); the
         # padded image is a cache that the Adam kernel refreshes.  The graph path reads `flat` itself until its first
         # Adam step has rewritten the image, so it needs no refresh launch; the eager path refreshes it here.
-        if self.use_graph and (self._grad_sync is None or self.graph_collectives) and not self.return_scaling:
+        if self.use_graph and (self._grad_sync is None or self.graph_collectives):
             out = self._update_graph(buffer, batch_size, repeat)
             if out is not None:
-                out.train_time = time.time() - t0
                 return out
         self.net.sync_image()
         pb = self._preprocess_batch(buffer)
@@ -487,11 +551,8 @@ class PPO(nn.Module):
                 st = self._update_with_batch(pb, batch_size, repeat, agent=a, buffer=buffer)
                 st.train_time = time.time() - t0
                 per_agent[f"agent_{a}"] = st
-            out = MapTrainingStats(per_agent)
-        else:
-            out = self._update_with_batch(pb, batch_size, repeat, agent=None, buffer=buffer)
-        out.train_time = time.time() - t0
-        return out
+            return MapTrainingStats(per_agent)
+        return self._update_with_batch(pb, batch_size, repeat, agent=None, buffer=buffer)
 
     # ---- `.learn(batch)` for the MARL trainers (training_coordinator.py:336) ----------------------
     def learn(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
@@ -545,6 +606,12 @@ class PPO(nn.Module):
         self.opt_step, self.lr = o["step"], o["lr"]
         self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = sd["ret_rms"]
         self._sample_ctr = sd.get("sample_ctr", 0)
+
+
+def ref_order_rows(T: int, B: int, device) -> torch.Tensor:
+    """Joint-row ids (slot * B + env) of a uniformly filled buffer listed in the reference's sample(0) order:
+    sub-buffer after sub-buffer, time-ordered inside each (manager.py:224-229)."""
+    return (torch.arange(T, device=device)[None, :] * B + torch.arange(B, device=device)[:, None]).reshape(-1)
 
 
 class policy_within_training_step:

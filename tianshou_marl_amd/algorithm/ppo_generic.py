@@ -26,7 +26,7 @@ from ..data.batch import Batch, split_bounds
 from ..data.buffer import DeviceVectorReplayBuffer
 from ..data.stats import A2CTrainingStats, SequenceSummaryStats
 from ..utils.net import FlatMLP, MLPActorCritic
-from .ppo import PPO
+from .ppo import PPO, ref_order_rows
 
 
 class GenericPPO(PPO):
@@ -91,13 +91,8 @@ class GenericPPO(PPO):
         v_next = self._values(obs_next, joint_next).view(T, L)
         logits = FlatMLP.forward(self.net.actor, obs, save=False)
         logp_old, _ = ops.categorical_logp_entropy(logits, act)
-        scale = float(np.sqrt(self.ret_rms.var + self._eps)) if self.return_scaling else 1.0
-        ret, adv = ops.gae_lanes(v_s, v_next, buffer.rew_store[:T].reshape(T, L), buffer.term_store[:T].reshape(T, L),
-                                 buffer.trunc_store[:T].reshape(T, L), self.gamma, self.gae_lambda, v_scale=scale,
-                                 lanes_per_env=N, env_start=env_start, env_len=env_len)
-        if self.return_scaling:
-            un = ret * scale
-            self.ret_rms.update(un.view(T * B, N)[rows] if rows is not None else un)
+        ret, adv = self._gae(v_s, v_next, buffer.rew_store[:T].reshape(T, L), buffer.term_store[:T].reshape(T, L),
+                             buffer.trunc_store[:T].reshape(T, L), N, env_start=env_start, env_len=env_len, rows=rows)
         return dict(T=T, rows=rows, obs=obs, act=act, v_s=v_s.reshape(-1).contiguous(), ret=ret.reshape(-1),
                     adv=adv.reshape(-1), logp_old=logp_old, n_env=B, n_agent=N, joint=joint)
 
@@ -129,7 +124,8 @@ class GenericPPO(PPO):
             ops.reduce_slabs(grads, out=flat_g, scale=1.0 / self._grad_sync.world)
             self._grad_sync.all_reduce_sum_(flat_g)
             grads = flat_g.view(1, -1)
-        ops.adam_step(net.flat.data, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr, betas=self.betas,
+        ops.adam_step(net.flat.data, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr, lr_dev=self._lr_dev,
+                      betas=self.betas,
                       eps=self.adam_eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
                       work=self._adam_work, step_dev=step_dev)
         return scalars
@@ -146,7 +142,7 @@ class GenericPPO(PPO):
         groups = list(range(N)) if per_agent else [None]
         n_g = T * B if per_agent else T * B * N
         bounds = split_bounds(n_g, batch_size or -1, merge_last=True)
-        key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.lr, self.max_grad_norm)
+        key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm)
         w = self._ws.get(key)
         if w is None:  # first update of this shape runs eagerly (one-time kernel attributes, allocator warm-up)
             self._ws[key] = {}
@@ -171,7 +167,8 @@ class GenericPPO(PPO):
                 pb = self._preprocess_batch(buffer, uniform_T=T)
                 stats = None
                 if self.advantage_normalization:
-                    stats = ops.ppo_adv_stats(pb["adv"], mb_all, perm=w["perm"].view(-1)).view(len(groups), repeat, len(bounds), 2)
+                    stats = ops.ppo_adv_stats(pb["adv"], mb_all, perm=w["perm"].view(-1),
+                                              max_rows=max(e - s for s, e in bounds)).view(len(groups), repeat, len(bounds), 2)
                 k = 0
                 for gi in range(len(groups)):
                     for r in range(repeat):
@@ -185,11 +182,15 @@ class GenericPPO(PPO):
             with torch.cuda.graph(graph):
                 body()
             w["graph"] = graph
+            if self.shuffle == "numpy":
+                base = ref_order_rows(T, B, dev)
+                w["ref_ids"] = [base * N + a if a is not None else
+                                (base[:, None] * N + torch.arange(N, device=dev)[None, :]).reshape(-1) for a in groups]
         if self.shuffle == "numpy":
             for gi, a in enumerate(groups):
                 for r in range(repeat):
                     pl = torch.as_tensor(np.random.permutation(n_g)).to(dev)
-                    w["perm"][gi, r].copy_(pl if a is None else pl * N + a)
+                    w["perm"][gi, r].copy_(w["ref_ids"][gi][pl])  # reference batch position -> lane id (ppo.ref_order_rows)
         if w.get("step_host") != self.opt_step:
             w["step_dev"].fill_(self.opt_step)
         w["graph"].replay()
@@ -206,17 +207,12 @@ class GenericPPO(PPO):
             return MapTrainingStats({f"agent_{a}": mk(s_h[a * per:(a + 1) * per]) for a in range(N)})
         return mk(s_h)
 
-    def update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
-        import time
-
-        if (self.graph and self.is_within_training_step and self._grad_sync is None and not self.return_scaling
-                and not self.recompute_adv):
-            t0 = time.time()
+    def _update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int, t0: float):
+        if self.graph and self._grad_sync is None and not self.recompute_adv:
             out = self._update_graph_generic(buffer, batch_size, repeat)
             if out is not None:
-                out.train_time = time.time() - t0
                 return out
-        return super().update(buffer, batch_size, repeat)
+        return super()._update(buffer, batch_size, repeat, t0)
 
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
                            buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:
@@ -237,7 +233,8 @@ class GenericPPO(PPO):
                 perm_local = ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, device=dev)[0]
                 ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
             perm = ids[perm_local]
-            stats = ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm) if self.advantage_normalization else None
+            stats = (ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm, max_rows=max(e - s for s, e in bounds))
+                     if self.advantage_normalization else None)
             for j, (s, e) in enumerate(bounds):
                 scal.append(self._grad_step(pb, perm[s:e].contiguous(), None if stats is None else stats[j]))
         self.param_version += 1

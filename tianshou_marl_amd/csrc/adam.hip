@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void reduce_norm_kernel(const float *__restric
 
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ slabs,
                                                    int32_t n_slab, int64_t n, float *__restrict__ m,
-                                                   float *__restrict__ v, double lr, double beta1d, double beta2d,
+                                                   float *__restrict__ v, double lr_host,
+                                                   const double *__restrict__ lr_dev, double beta1d, double beta2d,
                                                    int64_t step_host, const int64_t *__restrict__ step_dev,
                                                    float eps, float weight_decay, float max_norm,
                                                    const float *__restrict__ work, float *__restrict__ img,
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     // bias corrections from the (host or device-resident) step count, in f64 like torch's python scalars
     // beta^step by repeated squaring in f64 (step is an integer; ~20 multiplies instead of the pow() routine)
     const int64_t step = step_dev ? *step_dev : step_host;
+    // the learning rate may live in HBM (LR schedulers, algorithm_base.py:626-627): a captured graph then follows it
+    const double lr = lr_dev ? *lr_dev : lr_host;
     const float step_size = (float)(lr / (1.0 - ipow(beta1d, step)));
     const float bc2_sqrt = (float)sqrt(1.0 - ipow(beta2d, step));
     const float beta1 = (float)beta1d, beta2 = (float)beta2d;
@@ -154,8 +157,8 @@ TSM_EXPORT int tsm_reduce_slabs(const float *grad_slabs, int32_t n_slab, int64_t
 TSM_EXPORT int64_t tsm_adam_work_elems(int64_t n) { return n < 0 ? -1 : n + ceil_div(n > 0 ? n : 1, kCols); }
 
 TSM_EXPORT int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
-                             float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, double beta1,
-                             double beta2, double eps, double weight_decay, double max_grad_norm, float *work,
+                             float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, const double *lr_dev,
+                             double beta1, double beta2, double eps, double weight_decay, double max_grad_norm, float *work,
                              float *param_image, const int32_t *image_map, void *stream) {
     TSM_REQUIRE(n >= 0 && n_slab >= 1 && (step >= 1 || step_dev), "tsm_adam_step: bad sizes n=%lld n_slab=%d step=%lld",
                 (long long)n, n_slab, (long long)step);
@@ -170,7 +173,7 @@ TSM_EXPORT int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_sl
         TSM_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, st, param, grad_slabs, n_slab, n, exp_avg, exp_avg_sq, lr,
-                       beta1, beta2, step, step_dev, (float)eps, (float)weight_decay, (float)max_grad_norm, work,
+                       lr_dev, beta1, beta2, step, step_dev, (float)eps, (float)weight_decay, (float)max_grad_norm, work,
                        param_image, image_map);
     TSM_LAUNCH_CHECK();
     return TSM_OK;

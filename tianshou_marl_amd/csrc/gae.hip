@@ -46,8 +46,8 @@ __global__ __launch_bounds__(1024) void gae_lanes_kernel(
     const float *__restrict__ v_s, const float *__restrict__ v_n, const float *__restrict__ rew,
     const uint8_t *__restrict__ term, const uint8_t *__restrict__ trunc, int64_t T, int64_t L,
     int64_t lanes_per_env, const int32_t *__restrict__ env_start,
-    const int32_t *__restrict__ env_len, double gamma, double gl, double v_scale,
-    float *__restrict__ ret_out, float *__restrict__ adv_out) {
+    const int32_t *__restrict__ env_len, double gamma, double gl, double v_scale_arg,
+    const double *__restrict__ rms, double rms_eps, float *__restrict__ ret_out, float *__restrict__ adv_out) {
     extern __shared__ double lds[];  // [2][W][64 * VEC][2]
     const int W = blockDim.y;
     const int lx = threadIdx.x, w = threadIdx.y;
@@ -62,6 +62,9 @@ __global__ __launch_bounds__(1024) void gae_lanes_kernel(
     }
     const int64_t SC = (int64_t)W * CH;
     const int64_t n_sc = (T + SC - 1) / SC;  // uniform trip count keeps the barrier structure uniform
+    // return_scaling with device-resident running statistics (a2c.py:132-134): scale = sqrt(var + eps), read from HBM
+    // so that a captured graph follows the statistics from update to update
+    const double v_scale = rms ? sqrt(rms[1] + rms_eps) : v_scale_arg;
     const double inv_scale = 1.0 / v_scale;
 
     double carry_super[VEC];
@@ -185,6 +188,49 @@ __global__ void mc_return_kernel(const float *__restrict__ rew, int64_t T, int64
     }
 }
 
+// ---- RunningMeanStd.update on the unnormalised returns (a2c.py:144-146, utils/statistics.py:97-114) ----
+// level 1: one workgroup per 8192 elements -> {sum x, sum x^2} f64 (x = returns * scale, scale from the OLD var);
+// level 2: one workgroup folds the partials in index order and merges the batch moments into rms in place.
+constexpr int kRmsThreads = 1024, kRmsPer = 8;
+constexpr int64_t kRmsChunk = (int64_t)kRmsThreads * kRmsPer;
+
+__global__ __launch_bounds__(kRmsThreads) void rms_partial_kernel(const float *__restrict__ x, const int64_t *__restrict__ ids,
+                                                                  int64_t n, const double *__restrict__ rms, double eps,
+                                                                  double *__restrict__ work) {
+    __shared__ double sm[kRmsThreads / 64];
+    const double scale = sqrt(rms[1] + eps);
+    const int64_t base = (int64_t)blockIdx.x * kRmsChunk;
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kRmsPer; ++k) {
+        const int64_t i = base + threadIdx.x + (int64_t)kRmsThreads * k;
+        if (i < n) {
+            const double v = (double)x[ids ? ids[i] : i] * scale;
+            a1 += v;
+            a2 += v * v;
+        }
+    }
+    a1 = block_sum<double, kRmsThreads>(a1, sm);
+    a2 = block_sum<double, kRmsThreads>(a2, sm);
+    if (threadIdx.x == 0) { work[2 * blockIdx.x] = a1; work[2 * blockIdx.x + 1] = a2; }
+}
+
+__global__ __launch_bounds__(64) void rms_merge_kernel(const double *__restrict__ work, int64_t n_part, int64_t n,
+                                                       double *__restrict__ rms) {
+    if (threadIdx.x != 0) return;
+    double a1 = 0.0, a2 = 0.0;
+    for (int64_t b = 0; b < n_part; ++b) { a1 += work[2 * b]; a2 += work[2 * b + 1]; }
+    const double bm = a1 / (double)n;
+    double bv = a2 / (double)n - bm * bm;  // np.var (population)
+    if (bv < 0.0) bv = 0.0;
+    const double mean = rms[0], var = rms[1], count = rms[2];
+    const double delta = bm - mean, total = count + (double)n;
+    const double m2 = var * count + bv * (double)n + delta * delta * count * (double)n / total;
+    rms[0] = mean + delta * (double)n / total;
+    rms[1] = m2 / total;
+    rms[2] = total;
+}
+
 int pick_waves(int64_t T, int64_t L, int vec, int ch) {
     // enough waves to fill 256 CUs x 8, but no more chunks than the series has
     int64_t blocks = ceil_div(L, 64 * vec);
@@ -198,12 +244,13 @@ int pick_waves(int64_t T, int64_t L, int vec, int ch) {
 template <bool G, bool F, int VEC, int CH>
 void launch_gae(int W, const float *v_s, const float *v_s_next, const float *rew, const uint8_t *terminated,
                 const uint8_t *truncated, int64_t T, int64_t n_lane, int64_t lanes_per_env, const int32_t *env_start,
-                const int32_t *env_len, double gamma, double gl, double v_scale, float *returns_out, float *adv_out,
-                hipStream_t st) {
+                const int32_t *env_len, double gamma, double gl, double v_scale, const double *rms, double rms_eps,
+                float *returns_out, float *adv_out, hipStream_t st) {
     dim3 block(64, W), grid((unsigned)ceil_div(n_lane, 64 * VEC));
     const size_t shmem = (size_t)2 * W * 64 * VEC * 2 * sizeof(double);
     hipLaunchKernelGGL((gae_lanes_kernel<G, F, VEC, CH>), grid, block, shmem, st, v_s, v_s_next, rew, terminated,
-                       truncated, T, n_lane, lanes_per_env, env_start, env_len, gamma, gl, v_scale, returns_out, adv_out);
+                       truncated, T, n_lane, lanes_per_env, env_start, env_len, gamma, gl, v_scale, rms, rms_eps, returns_out,
+                       adv_out);
 }
 
 }  // namespace
@@ -212,12 +259,10 @@ extern "C" __attribute__((visibility("default"))) void tsm_debug_gae_config(int 
     g_force_vec = vec; g_force_ch = ch; g_force_w = w;
 }
 
-TSM_EXPORT int tsm_gae_lanes(const float *v_s, const float *v_s_next, const float *rew,
-                             const uint8_t *terminated, const uint8_t *truncated,
-                             int flags_per_lane, int64_t T, int64_t n_lane, int64_t lanes_per_env,
-                             const int32_t *env_start, const int32_t *env_len, double gamma,
-                             double gae_lambda, double v_scale, float *returns_out, float *adv_out,
-                             void *stream) {
+static int gae_impl(const float *v_s, const float *v_s_next, const float *rew, const uint8_t *terminated,
+                    const uint8_t *truncated, int flags_per_lane, int64_t T, int64_t n_lane, int64_t lanes_per_env,
+                    const int32_t *env_start, const int32_t *env_len, double gamma, double gae_lambda, double v_scale,
+                    const double *rms, double rms_eps, float *returns_out, float *adv_out, void *stream) {
     TSM_REQUIRE(T >= 0 && n_lane >= 0, "tsm_gae_lanes: negative size T=%lld n_lane=%lld",
                 (long long)T, (long long)n_lane);
     if (T == 0 || n_lane == 0) return TSM_OK;
@@ -226,7 +271,7 @@ TSM_EXPORT int tsm_gae_lanes(const float *v_s, const float *v_s_next, const floa
     TSM_REQUIRE(lanes_per_env >= 1 && n_lane % lanes_per_env == 0,
                 "tsm_gae_lanes: n_lane=%lld not a multiple of lanes_per_env=%lld",
                 (long long)n_lane, (long long)lanes_per_env);
-    TSM_REQUIRE(v_scale > 0.0, "tsm_gae_lanes: v_scale must be > 0");
+    TSM_REQUIRE(rms || v_scale > 0.0, "tsm_gae_lanes: v_scale must be > 0");
     const double gl = gamma * gae_lambda;
     const bool generic = env_start || env_len;
     hipStream_t st = tsm_stream(stream);
@@ -239,7 +284,7 @@ TSM_EXPORT int tsm_gae_lanes(const float *v_s, const float *v_s_next, const floa
     int W = pick_waves(T, n_lane, 1, ch);
     if (g_force_w) W = g_force_w;
 #define ARGS W, v_s, v_s_next, rew, terminated, truncated, T, n_lane, lanes_per_env, env_start, env_len, gamma, gl, \
-             v_scale, returns_out, adv_out, st
+             v_scale, rms, rms_eps, returns_out, adv_out, st
 #define BY_CH(G, F)                                          \
     do {                                                     \
         if (ch == 2) launch_gae<G, F, 1, 2>(ARGS);           \
@@ -254,6 +299,27 @@ TSM_EXPORT int tsm_gae_lanes(const float *v_s, const float *v_s_next, const floa
     return TSM_OK;
 }
 
+TSM_EXPORT int tsm_gae_lanes(const float *v_s, const float *v_s_next, const float *rew,
+                             const uint8_t *terminated, const uint8_t *truncated,
+                             int flags_per_lane, int64_t T, int64_t n_lane, int64_t lanes_per_env,
+                             const int32_t *env_start, const int32_t *env_len, double gamma,
+                             double gae_lambda, double v_scale, float *returns_out, float *adv_out,
+                             void *stream) {
+    return gae_impl(v_s, v_s_next, rew, terminated, truncated, flags_per_lane, T, n_lane, lanes_per_env, env_start,
+                    env_len, gamma, gae_lambda, v_scale, nullptr, 0.0, returns_out, adv_out, stream);
+}
+
+TSM_EXPORT int tsm_gae_lanes_rms(const float *v_s, const float *v_s_next, const float *rew,
+                                 const uint8_t *terminated, const uint8_t *truncated,
+                                 int flags_per_lane, int64_t T, int64_t n_lane, int64_t lanes_per_env,
+                                 const int32_t *env_start, const int32_t *env_len, double gamma,
+                                 double gae_lambda, const double *rms, double rms_eps, float *returns_out,
+                                 float *adv_out, void *stream) {
+    TSM_REQUIRE(rms, "tsm_gae_lanes_rms: rms is null");
+    return gae_impl(v_s, v_s_next, rew, terminated, truncated, flags_per_lane, T, n_lane, lanes_per_env, env_start,
+                    env_len, gamma, gae_lambda, 1.0, rms, rms_eps, returns_out, adv_out, stream);
+}
+
 TSM_EXPORT int tsm_mc_return_to_go_lanes(const float *rew, int64_t T, int64_t n_lane, double gamma,
                                          float *out, void *stream) {
     TSM_REQUIRE(T >= 0 && n_lane >= 0, "tsm_mc_return_to_go_lanes: negative size");
@@ -261,6 +327,22 @@ TSM_EXPORT int tsm_mc_return_to_go_lanes(const float *rew, int64_t T, int64_t n_
     TSM_REQUIRE(rew && out, "tsm_mc_return_to_go_lanes: null pointer");
     hipLaunchKernelGGL(mc_return_kernel, dim3((unsigned)ceil_div(n_lane, 256)), dim3(256), 0,
                        tsm_stream(stream), rew, T, n_lane, gamma, out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+TSM_EXPORT int64_t tsm_rms_update_work_elems(int64_t n) { return n < 0 ? -1 : 2 * ceil_div(n > 0 ? n : 1, kRmsChunk); }
+
+TSM_EXPORT int tsm_rms_update(const float *returns, const int64_t *ids, int64_t n, double *rms, double rms_eps,
+                              double *work, void *stream) {
+    TSM_REQUIRE(n >= 0, "tsm_rms_update: negative n");
+    if (n == 0) return TSM_OK;
+    TSM_REQUIRE(returns && rms && work, "tsm_rms_update: null pointer");
+    const int64_t n_part = ceil_div(n, kRmsChunk);
+    hipLaunchKernelGGL(rms_partial_kernel, dim3((unsigned)n_part), dim3(kRmsThreads), 0, tsm_stream(stream), returns, ids,
+                       n, rms, rms_eps, work);
+    TSM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rms_merge_kernel, dim3(1), dim3(64), 0, tsm_stream(stream), work, n_part, n, rms);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

@@ -59,6 +59,65 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float *__restrict
     }
 }
 
+// ---- the same statistics for LONG minibatches (> 8192 rows): chunks of a minibatch on separate workgroups ----
+// One 1024-thread workgroup per 8192-row chunk writes {sum(x - c), sum((x - c)^2)} in f64, c = the minibatch's first
+// gathered value (shifted data: no cancellation between the two sums); a second launch folds the chunks of each
+// minibatch in chunk order.  Chunk boundaries depend on the minibatch bounds only, so results do not depend on the
+// grid.  (The one-workgroup kernel above took 324 us for a single 819 200-row minibatch.)
+constexpr int64_t kStatChunk = 1024 * kStatRegs;
+
+__global__ __launch_bounds__(1024) void adv_stats_chunk_kernel(const float *__restrict__ adv,
+                                                               const int64_t *__restrict__ perm,
+                                                               const int64_t *__restrict__ mb_start, int32_t n_chunk,
+                                                               double *__restrict__ work) {
+    __shared__ double sm[1024 / 64];
+    const int64_t s0 = mb_start[blockIdx.x], s1 = mb_start[blockIdx.x + 1];
+    const int64_t c0 = s0 + (int64_t)blockIdx.y * kStatChunk;
+    double *out = work + ((int64_t)blockIdx.x * n_chunk + blockIdx.y) * 2;
+    if (c0 >= s1) {  // uniform per workgroup
+        if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; }
+        return;
+    }
+    const int64_t c1 = c0 + kStatChunk < s1 ? c0 + kStatChunk : s1;
+    const float shift = adv[perm ? perm[s0] : s0];
+    int64_t src[kStatRegs];
+#pragma unroll
+    for (int k = 0; k < kStatRegs; ++k) {
+        const int64_t i = c0 + threadIdx.x + 1024 * (int64_t)k;
+        src[k] = i < c1 ? (perm ? perm[i] : i) : -1;
+    }
+    float vals[kStatRegs];
+#pragma unroll
+    for (int k = 0; k < kStatRegs; ++k) vals[k] = src[k] >= 0 ? adv[src[k]] : shift;
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kStatRegs; ++k) {
+        const double d = (double)vals[k] - (double)shift;
+        a1 += d;
+        a2 += d * d;
+    }
+    a1 = block_sum<double, 1024>(a1, sm);
+    a2 = block_sum<double, 1024>(a2, sm);
+    if (threadIdx.x == 0) { out[0] = a1; out[1] = a2; }
+}
+
+__global__ __launch_bounds__(64) void adv_stats_fold_kernel(const float *__restrict__ adv, const int64_t *__restrict__ perm,
+                                                            const int64_t *__restrict__ mb_start, int32_t n_chunk,
+                                                            const double *__restrict__ work, float *__restrict__ stats_out) {
+    const int64_t s0 = mb_start[blockIdx.x], M = mb_start[blockIdx.x + 1] - s0;
+    if (threadIdx.x != 0) return;
+    double a1 = 0.0, a2 = 0.0;
+    for (int c = 0; c < n_chunk; ++c) {
+        a1 += work[((int64_t)blockIdx.x * n_chunk + c) * 2 + 0];
+        a2 += work[((int64_t)blockIdx.x * n_chunk + c) * 2 + 1];
+    }
+    const double shift = M > 0 ? (double)adv[perm ? perm[s0] : s0] : 0.0;
+    const double mean_s = M > 0 ? a1 / (double)M : 0.0;
+    stats_out[2 * blockIdx.x + 0] = (float)(shift + mean_s);
+    const double ss = a2 - a1 * mean_s;  // sum (x - mean)^2
+    stats_out[2 * blockIdx.x + 1] = M > 1 ? (float)sqrt((ss > 0.0 ? ss : 0.0) / (double)(M - 1)) : NAN;
+}
+
 struct Cfg {
     float eps_clip, dual_clip, vf_coef, ent_coef;
     int value_clip, adv_norm, kind;
@@ -208,6 +267,27 @@ TSM_EXPORT int tsm_ppo_adv_stats(const float *adv, const int64_t *perm, const in
     TSM_REQUIRE(adv && mb_start && stats_out, "tsm_ppo_adv_stats: null pointer");
     hipLaunchKernelGGL(adv_stats_kernel, dim3((unsigned)n_mb), dim3(1024), 0, tsm_stream(stream), adv, perm,
                        mb_start, stats_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+TSM_EXPORT int64_t tsm_ppo_adv_stats_work_elems(int32_t n_mb, int64_t max_rows) {
+    if (n_mb < 0 || max_rows < 0) return -1;
+    return 2 * (int64_t)n_mb * ceil_div(max_rows > 0 ? max_rows : 1, kStatChunk);
+}
+
+TSM_EXPORT int tsm_ppo_adv_stats_wide(const float *adv, const int64_t *perm, const int64_t *mb_start, int32_t n_mb,
+                                      int64_t max_rows, double *work, float *stats_out, void *stream) {
+    TSM_REQUIRE(n_mb >= 0 && max_rows >= 0, "tsm_ppo_adv_stats_wide: negative size");
+    if (n_mb == 0) return TSM_OK;
+    TSM_REQUIRE(adv && mb_start && stats_out && work, "tsm_ppo_adv_stats_wide: null pointer");
+    const int64_t n_chunk = ceil_div(max_rows > 0 ? max_rows : 1, kStatChunk);
+    TSM_REQUIRE(n_chunk <= 65535, "tsm_ppo_adv_stats_wide: minibatch of %lld rows is too long", (long long)max_rows);
+    hipLaunchKernelGGL(adv_stats_chunk_kernel, dim3((unsigned)n_mb, (unsigned)n_chunk), dim3(1024), 0, tsm_stream(stream),
+                       adv, perm, mb_start, (int32_t)n_chunk, work);
+    TSM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adv_stats_fold_kernel, dim3((unsigned)n_mb), dim3(64), 0, tsm_stream(stream), adv, perm, mb_start,
+                       (int32_t)n_chunk, work, stats_out);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

@@ -23,10 +23,11 @@ def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
 # GAE  (algorithm_base.py:651-717,1079-1134; a2c.py:132-146)
 # --------------------------------------------------------------------------------------------
 def gae_lanes(v_s, v_s_next, rew, terminated, truncated, gamma=0.99, gae_lambda=0.95, v_scale=1.0,
-              lanes_per_env=1, env_start=None, env_len=None, out=None):
+              lanes_per_env=1, env_start=None, env_len=None, out=None, rms=None, rms_eps=1e-8):
     """Per-lane GAE on time-major tensors [T, ...lanes]; returns (returns, adv) f32 tensors.
 
     terminated/truncated: u8/bool, either the lane shape [T, n_lane] or env-level [T, n_env].
+    rms: device f64[3] {mean, var, count} of the return statistics -> v_scale = sqrt(var + rms_eps) read on device.
     """
     v_s = _chk(v_s, torch.float32, "v_s")
     T = v_s.shape[0]
@@ -46,10 +47,26 @@ def gae_lanes(v_s, v_s_next, rew, terminated, truncated, gamma=0.99, gae_lambda=
         ret, adv = torch.empty_like(v_s), torch.empty_like(v_s)
     else:
         ret, adv = out
+    if rms is not None:
+        call("tsm_gae_lanes_rms", ptr(v_s), ptr(v_s_next), ptr(rew), ptr(term), ptr(trunc), flags_per_lane, T, L,
+             lanes_per_env, ptr(env_start), ptr(env_len), float(gamma), float(gae_lambda),
+             ptr(_chk(rms, torch.float64, "rms")), float(rms_eps), ptr(ret), ptr(adv), stream_ptr())
+        return ret, adv
     call("tsm_gae_lanes", ptr(v_s), ptr(v_s_next), ptr(rew), ptr(term), ptr(trunc), flags_per_lane, T, L,
          lanes_per_env, ptr(env_start), ptr(env_len), float(gamma), float(gae_lambda), float(v_scale),
          ptr(ret), ptr(adv), stream_ptr())
     return ret, adv
+
+
+def rms_update(returns, rms, rms_eps=1e-8, ids=None, work=None):
+    """RunningMeanStd.update(returns * sqrt(var + eps)) on device (a2c.py:144-146); rms f64[3] is updated in place."""
+    returns = _chk(returns, torch.float32, "returns").reshape(-1)
+    n = returns.numel() if ids is None else ids.numel()
+    if work is None:
+        work = torch.empty(call("tsm_rms_update_work_elems", n), dtype=torch.float64, device=returns.device)
+    call("tsm_rms_update", ptr(returns), ptr(ids), n, ptr(_chk(rms, torch.float64, "rms")), float(rms_eps), ptr(work),
+         stream_ptr())
+    return rms
 
 
 def mc_return_to_go_lanes(rew, gamma=0.99):
@@ -241,12 +258,20 @@ def make_ppo_cfg(eps_clip=0.2, dual_clip=None, value_clip=False, adv_norm=True, 
                        int(bool(value_clip)), int(bool(adv_norm)), int(loss_kind), 0)
 
 
-def ppo_adv_stats(adv, mb_start, perm=None, out=None):
-    """Per-minibatch (mean, unbiased std) of adv[perm[mb_start[k]:mb_start[k+1]]] -> [n_mb, 2] f32."""
+def ppo_adv_stats(adv, mb_start, perm=None, out=None, max_rows: int = 0, work=None):
+    """Per-minibatch (mean, unbiased std) of adv[perm[mb_start[k]:mb_start[k+1]]] -> [n_mb, 2] f32.
+    max_rows: host knowledge of the longest minibatch; above 8192 rows the chunks of a minibatch are reduced by separate
+    workgroups (tsm_ppo_adv_stats_wide, work = f64 scratch kept alive by the caller when captured in a graph)."""
     adv = _chk(adv, torch.float32, "adv").reshape(-1)
     mb_start = _chk(mb_start, torch.int64, "mb_start")
     n_mb = mb_start.numel() - 1
     stats = out if out is not None else torch.empty(n_mb, 2, dtype=torch.float32, device=adv.device)
+    if max_rows > 8192:
+        if work is None:
+            work = torch.empty(call("tsm_ppo_adv_stats_work_elems", n_mb, max_rows), dtype=torch.float64, device=adv.device)
+        call("tsm_ppo_adv_stats_wide", ptr(adv), ptr(perm), ptr(mb_start), n_mb, int(max_rows), ptr(work), ptr(stats),
+             stream_ptr())
+        return stats
     call("tsm_ppo_adv_stats", ptr(adv), ptr(perm), ptr(mb_start), n_mb, ptr(stats), stream_ptr())
     return stats
 
@@ -280,14 +305,14 @@ def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, returns, cfg: tsm_ppo_cf
 # optimizer (algorithm_base.py:485-498; optim.py:91-111)
 # --------------------------------------------------------------------------------------------
 def adam_step(param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-              weight_decay=0.0, max_grad_norm=None, work=None, step_dev=None, image=None, image_map=None):
+              weight_decay=0.0, max_grad_norm=None, work=None, step_dev=None, image=None, image_map=None, lr_dev=None):
     """In-place Adam on a flat f32 vector; grad_slabs [n_slab, n] are summed in slab order."""
     n = param.numel()
     grad_slabs = _chk(grad_slabs, torch.float32, "grad_slabs").reshape(-1, n)
     if max_grad_norm and work is None:
         work = torch.empty(call("tsm_adam_work_elems", n), dtype=torch.float32, device=param.device)
     call("tsm_adam_step", ptr(param), ptr(grad_slabs), grad_slabs.shape[0], n, ptr(exp_avg), ptr(exp_avg_sq),
-         int(step), ptr(step_dev), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+         int(step), ptr(step_dev), float(lr), ptr(lr_dev), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
          float(max_grad_norm or 0.0), ptr(work), ptr(image), ptr(image_map), stream_ptr())
     return param
 

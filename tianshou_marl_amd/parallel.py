@@ -28,6 +28,8 @@ class GradSync:
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self._checked: set = set()
+        self._probe_device = torch.device("cpu")  # attach_data_parallel points it at the replica's device for RCCL
 
     def all_reduce_mean_(self, flat: torch.Tensor) -> torch.Tensor:
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -39,6 +41,23 @@ class GradSync:
         an elementwise launch per gradient step)."""
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
         return flat
+
+    def require_equal(self, value: int, what: str) -> None:
+        """Every rank must issue the same number of gradient all-reduces per update, or the job deadlocks: env shards of
+        different sizes can split into a different number of minibatches (Batch.split merge-last rule).  Checked once per
+        distinct value (one tiny all-reduce), before any capture."""
+        key = (what, int(value))
+        if key in self._checked:
+            return
+        t = torch.tensor([int(value), -int(value)], dtype=torch.int64, device=self._probe_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        hi, lo = int(t[0].item()), -int(t[1].item())
+        if hi != lo:
+            raise ValueError(
+                f"data-parallel ranks disagree on {what}: between {lo} and {hi} (this rank: {value}).  Give every rank the "
+                "same number of environments (and the same batch_size / repeat) so that all replicas take the same "
+                "number of gradient steps.")
+        self._checked.add(key)
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         self.dist.broadcast(t, src=src, group=self.group)
@@ -53,6 +72,8 @@ def attach_data_parallel(algo, dist, group=None) -> GradSync:
     sync.broadcast_(algo.exp_avg)
     sync.broadcast_(algo.exp_avg_sq)
     algo._grad_sync = sync
+    if dist.get_backend(group) == "nccl":
+        sync._probe_device = algo.net.flat.device
     # only RCCL ("nccl") collectives can be captured into a hipGraph; with any other backend the update stays on eager
     # launches (TSM_GRAPH_COLLECTIVES=force overrides: used to rehearse the failed-capture fallback)
     import os

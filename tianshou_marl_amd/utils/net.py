@@ -311,3 +311,26 @@ class RunningMeanStd:
         else:
             a = np.asarray(x, np.float64)
             self.update_from_moments(float(a.mean()), float(a.var()), a.size)
+
+
+class DeviceRunningMeanStd(RunningMeanStd):
+    """The same statistics with their state in HBM: `dev` = f64 {mean, var, count}.  The GAE kernel reads the scale
+    sqrt(var + eps) from it and `tsm_rms_update` merges a batch of unnormalised returns into it (a2c.py:132-146), so
+    `return_scaling` needs no host round trip and survives hipGraph replays.  `mean` / `var` / `count` read (and
+    write) the device state; reading synchronises."""
+
+    def __init__(self, device, mean: float = 0.0, std: float = 1.0, clip_max: float | None = 10.0,
+                 epsilon: float = float(np.finfo(np.float32).eps)) -> None:
+        self.dev = torch.tensor([mean, std, 0.0], dtype=torch.float64, device=device)
+        self.clip_max, self.eps = clip_max, epsilon
+
+    def _get(self, i: int) -> float:
+        return float(self.dev[i].item())
+
+    mean = property(lambda s: s._get(0), lambda s, v: s.dev[0:1].fill_(float(v)))
+    var = property(lambda s: s._get(1), lambda s, v: s.dev[1:2].fill_(float(v)))
+    count = property(lambda s: int(s._get(2)), lambda s, v: s.dev[2:3].fill_(float(v)))
+
+    def update_scaled_returns(self, returns: torch.Tensor, rms_eps: float, ids: torch.Tensor | None = None) -> None:
+        """update(returns * sqrt(var + rms_eps)) entirely on device (a2c.py:144-146)."""
+        ops.rms_update(returns, self.dev, rms_eps, ids=ids)
