@@ -199,7 +199,10 @@ typedef struct {
      * vf_coef = ent_coef = 0 and adv = returns, the whole loss of Reinforce (reinforce.py:373-379).  eps_clip,
      * dual_clip, value_clip and logp_old are ignored for kind 1. */
     int32_t loss_kind;
-    int32_t _pad;
+    /* <= 1: one critic value per sample.  N > 1 (tsm_ppo_loss_fwd_bwd only): centralized critic -- samples
+     * i = r * N + a of a minibatch are the N agents of joint row r, `value` holds one entry per ROW (value[i / N]) and
+     * dvalue_out [M / N] receives the sum of the row's N per-sample gradients (M % N == 0). */
+    int32_t value_group;
 } tsm_ppo_cfg;
 
 /* Per-minibatch advantage statistics (ppo.py:185, torch unbiased std).  Minibatch k covers

@@ -118,7 +118,7 @@ def make_api_surface() -> None:
             "LeaguePlayTrainer.train_step": sig(tc.LeaguePlayTrainer.train_step),
             "MATrainer.save_checkpoint": sig(tc.MATrainer.save_checkpoint),
             "MATrainer.load_checkpoint": sig(tc.MATrainer.load_checkpoint),
-            "policy_within_training_step.__init__": sig(policy_within_training_step.__init__),
+            "policy_within_training_step": sig(inspect.unwrap(policy_within_training_step)),
         },
         "dataclass_fields": {
             "CollectStats": fields(CollectStats),
@@ -148,12 +148,12 @@ def make_api_surface() -> None:
         },
     }
     # verify the hand-listed attributes against the reference classes
-    probe = {"algorithm": Algorithm, "train_collector": Collector, "buffer": VectorReplayBuffer, "collect_stats": CollectStats,
+    probe = {"algorithm": OnPolicyAlgorithm, "train_collector": Collector, "buffer": VectorReplayBuffer, "collect_stats": CollectStats,
              "training_stats": TrainingStats}
     for who, cls in probe.items():
         for attr in api["trainer_touches"][who]:
             ok = hasattr(cls, attr) or attr in getattr(cls, "__dataclass_fields__", {}) or \
-                attr in ("buffer", "collect_step", "collect_episode", "collect_time")  # instance attributes set in __init__
+                attr in ("policy", "buffer", "collect_step", "collect_episode", "collect_time")  # instance attributes set in __init__
             assert ok, (who, attr)
     path = os.path.join(HERE, "api_surface.json")
     with open(path, "w") as f:
@@ -203,7 +203,8 @@ def make_checkpoint() -> None:
     act = DecentralizedActor(obs_dim=6, action_dim=3, hidden_dim=16)
     cri = CentralizedCritic(global_obs_dim=12, n_agents=2, hidden_dim=16)
     pol = CTDEPolicy(actor=act, critic=cri, optim_actor=torch.optim.Adam(act.parameters(), lr=1e-3),
-                     optim_critic=torch.optim.Adam(cri.parameters(), lr=1e-3), action_space=mf.gym.spaces.Discrete(3))
+                     optim_critic=torch.optim.Adam(cri.parameters(), lr=1e-3),
+                     observation_space=mf.gym.spaces.Box(-np.inf, np.inf, (6,)), action_space=mf.gym.spaces.Discrete(3))
     csd = pol.state_dict()
     out["ctde_keys"] = np.array(list(csd))
     out["ctde_shapes"] = np.array([json.dumps(list(v.shape)) for v in csd.values()])

@@ -214,7 +214,7 @@ def test_ppo_update_pooled_and_options_run_and_learn():
     assert not torch.equal(p0, net.flat.data) and torch.isfinite(net.flat.data).all()
     assert algo.ret_rms.count == 3 * 32 * 25 * 3  # one ret_rms.update per _preprocess_batch call (1 + 2 recomputes)
     sd = algo.state_dict()
-    assert "_optimizers" in sd and sd["_optimizers"][0]["step"] == st.gradient_steps
+    assert "_optimizers" in sd and float(sd["_optimizers"][0]["state"][0]["step"]) == st.gradient_steps
     # MARL-trainer entry point: .learn(batch) on one agent's lane (training_coordinator.py:336)
     b = Batch(obs=np.random.randn(50, 18).astype(np.float32), act=np.random.randint(0, 5, 50),
               rew=np.random.randn(50).astype(np.float32), obs_next=np.random.randn(50, 18).astype(np.float32),

@@ -29,7 +29,7 @@ class tsm_field(C.Structure):
 class tsm_ppo_cfg(C.Structure):
     _fields_ = [("eps_clip", C.c_double), ("dual_clip", C.c_double), ("vf_coef", C.c_double),
                 ("ent_coef", C.c_double), ("value_clip", C.c_int32), ("adv_norm", C.c_int32),
-                ("loss_kind", C.c_int32), ("_pad", C.c_int32)]
+                ("loss_kind", C.c_int32), ("value_group", C.c_int32)]
 
 
 class tsm_mpe_cfg(C.Structure):

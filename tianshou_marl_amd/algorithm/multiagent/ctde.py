@@ -164,11 +164,18 @@ class CTDEPolicy(nn.Module):
         return batch.global_obs if "global_obs" in batch else batch.obs
 
     def state_dict(self, *args, **kwargs):
-        return {"actor": self.actor.flat.data.clone(), "critic": self.critic.flat.data.clone(),
-                "_optimizers": [self.optim_actor.state_dict(), self.optim_critic.state_dict()]}
+        """The reference's CTDEPolicy is a plain nn.Module over `actor` and `critic` (ctde.py:346-414: fc1..fc3), so its
+        state_dict is `actor.fc{i}.weight|bias`, `critic.fc{i}.weight|bias` and nothing else; the two optimizers are
+        saved by their owner (`optim_actor.state_dict()`: torch-Adam layout, utils/net.FlatAdam).  Key names and shapes
+        are pinned by tests/golden/checkpoint.npz."""
+        from collections import OrderedDict
+
+        sd = OrderedDict()
+        for name, net in (("actor", self.actor), ("critic", self.critic)):
+            for k, v in net.to_reference_state_dict().items():
+                sd[f"{name}.{k}"] = v
+        return sd
 
     def load_state_dict(self, sd, *args, **kwargs):
-        self.actor.flat.data.copy_(sd["actor"])
-        self.critic.flat.data.copy_(sd["critic"])
-        self.optim_actor.load_state_dict(sd["_optimizers"][0])
-        self.optim_critic.load_state_dict(sd["_optimizers"][1])
+        for name, net in (("actor", self.actor), ("critic", self.critic)):
+            net.load_reference_state_dict({k[len(name) + 1:]: v for k, v in sd.items() if k.startswith(name + ".")})

@@ -30,14 +30,14 @@ from .ppo import PPO
 class A2C(PPO):
     """Synchronous advantage actor-critic (a2c.py:152-285) with the reference's constructor arguments."""
 
-    def __init__(self, *, net: DiscreteActorCritic, vf_coef: float = 0.5, ent_coef: float = 0.01,
+    def __init__(self, *, policy=None, critic=None, optim=None, vf_coef: float = 0.5, ent_coef: float = 0.01,
                  max_grad_norm: float | None = None, gae_lambda: float = 0.95, max_batchsize: int = 256,
-                 gamma: float = 0.99, return_scaling: bool = False, **kw) -> None:
+                 gamma: float = 0.99, return_scaling: bool = False, net: DiscreteActorCritic | None = None, **kw) -> None:
         for banned in ("eps_clip", "dual_clip", "value_clip", "advantage_normalization", "recompute_advantage"):
             if banned in kw:
                 raise TypeError(f"A2C has no `{banned}` (that is a PPO option)")
-        super().__init__(net=net, vf_coef=vf_coef, ent_coef=ent_coef, max_grad_norm=max_grad_norm,
-                         gae_lambda=gae_lambda, max_batchsize=max_batchsize, gamma=gamma, return_scaling=return_scaling,
+        super().__init__(policy=policy, critic=critic, optim=optim, net=net, vf_coef=vf_coef, ent_coef=ent_coef,
+                         max_grad_norm=max_grad_norm, gae_lambda=gae_lambda, max_batchsize=max_batchsize, gamma=gamma, return_scaling=return_scaling,
                          advantage_normalization=False, recompute_advantage=False, value_clip=False, dual_clip=None, **kw)
         self._cfg = ops.make_ppo_cfg(adv_norm=False, vf_coef=vf_coef, ent_coef=ent_coef, loss_kind=1)
         self._a2c_ctor = dict(vf_coef=vf_coef, ent_coef=ent_coef, max_grad_norm=max_grad_norm, gae_lambda=gae_lambda,
@@ -47,6 +47,7 @@ class A2C(PPO):
         net = DiscreteActorCritic(self.net.obs_dim, self.net.n_act, self.net.hidden, device=self.device)
         net.flat.data.copy_(self.net.flat.data)
         net.sync_image()
+        net._ref_keys = getattr(self.net, "_ref_keys", None)
         new = type(self)(net=net, **self._a2c_ctor)
         new.load_state_dict(self.state_dict())
         new.train(self.training)
@@ -68,15 +69,16 @@ class Reinforce(PPO):
     """Vanilla policy gradient (reinforce.py:313-379).  `return_standardization` as in
     DiscountedReturnComputation (reinforce.py:240-311)."""
 
-    def __init__(self, *, net: DiscreteActorCritic, gamma: float = 0.99, return_standardization: bool = False,
-                 **kw) -> None:
+    def __init__(self, *, policy=None, gamma: float = 0.99, return_standardization: bool = False, optim=None,
+                 net: DiscreteActorCritic | None = None, **kw) -> None:
         for banned in ("eps_clip", "dual_clip", "value_clip", "advantage_normalization", "recompute_advantage",
                        "vf_coef", "ent_coef", "gae_lambda", "return_scaling", "max_grad_norm"):
             if banned in kw:
                 raise TypeError(f"Reinforce has no `{banned}`")
         kw.pop("use_graph", None)
         # the return standardisation keeps running statistics on the host: the update stays on eager launches
-        super().__init__(net=net, gamma=gamma, gae_lambda=1.0, vf_coef=0.0, ent_coef=0.0, advantage_normalization=False,
+        super().__init__(policy=policy, critic=None, optim=optim, net=net, gamma=gamma, gae_lambda=1.0, vf_coef=0.0,
+                         ent_coef=0.0, advantage_normalization=False,
                          recompute_advantage=False, value_clip=False, dual_clip=None, return_scaling=False,
                          use_graph=False, **kw)
         self.return_standardization = bool(return_standardization)
@@ -136,6 +138,7 @@ class Reinforce(PPO):
         net = DiscreteActorCritic(self.net.obs_dim, self.net.n_act, self.net.hidden, device=self.device)
         net.flat.data.copy_(self.net.flat.data)
         net.sync_image()
+        net._ref_keys = getattr(self.net, "_ref_keys", None)
         new = type(self)(net=net, **self._r_ctor)
         new.load_state_dict(self.state_dict())
         new.train(self.training)

@@ -29,24 +29,56 @@ from ..utils.net import DeviceRunningMeanStd, DiscreteActorCritic
 
 
 class PPO(nn.Module):
-    def __init__(self, *, net: DiscreteActorCritic, lr: float = 3e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8,
-                 weight_decay: float = 0.0, eps_clip: float = 0.2, dual_clip: float | None = None,
-                 value_clip: bool = False, advantage_normalization: bool = True,
-                 recompute_advantage: bool = False, vf_coef: float = 0.5, ent_coef: float = 0.01,
-                 max_grad_norm: float | None = None, gae_lambda: float = 0.95, max_batchsize: int = 256,
-                 gamma: float = 0.99, return_scaling: bool = False, deterministic_eval: bool = False,
-                 dispatch: Literal["per_agent", "pooled"] = "per_agent",
+    def __new__(cls, *args, **kw):
+        # reference-style construction `PPO(policy=..., critic=..., optim=...)`: nets the fused 64-wide kernels do not
+        # cover (other widths / depths, tanh, a wider critic input) run on the general kernels of GenericPPO
+        if cls is PPO and kw.get("policy") is not None and kw.get("net") is None:
+            from ..utils.net import MLPActorCritic, net_from_reference_modules
+
+            if isinstance(net_from_reference_modules(kw["policy"], kw.get("critic"), kw.get("device", "cuda")), MLPActorCritic):
+                from .ppo_generic import GenericPPO
+
+                return super().__new__(GenericPPO)
+        return super().__new__(cls)
+
+    def __init__(self, *, policy=None, critic=None, optim=None, eps_clip: float = 0.2, dual_clip: float | None = None,
+                 value_clip: bool = False, advantage_normalization: bool = True, recompute_advantage: bool = False,
+                 vf_coef: float = 0.5, ent_coef: float = 0.01, max_grad_norm: float | None = None,
+                 gae_lambda: float = 0.95, max_batchsize: int = 256, gamma: float = 0.99, return_scaling: bool = False,
+                 net: DiscreteActorCritic | None = None, lr: float = 3e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8,
+                 weight_decay: float = 0.0, deterministic_eval: bool = False,
+                 dispatch: Literal["per_agent", "pooled"] | None = None,
                  shuffle: Literal["numpy", "device"] = "numpy", seed: int = 0, use_graph: bool = True,
-                 async_stats: bool = False) -> None:
+                 async_stats: bool = False, device: str | torch.device = "cuda") -> None:
+        """Either the reference's arguments (ppo.py:17-60: `policy` = DiscreteActorPolicy, `critic` = DiscreteCritic,
+        `optim` = AdamOptimizerFactory -- utils/ref_nets.py, algorithm/optim.py) or the engine's own (`net` = a flat
+        HBM network + Adam hyper-parameters).  Hyper-parameter names and defaults are the reference's."""
         super().__init__()
         assert dual_clip is None or dual_clip > 1.0, f"Dual-clip PPO parameter should greater than 1.0 but got {dual_clip}"
         assert 0.0 <= gae_lambda <= 1.0, f"GAE lambda should be in [0, 1] but got: {gae_lambda}"
+        sched_factory = None
+        if net is None:
+            if policy is None:
+                raise TypeError("PPO needs `policy=` (+ `critic=`, `optim=`) or `net=`")
+            from ..utils.net import net_from_reference_modules
+
+            net = net_from_reference_modules(policy, critic, device)
+            deterministic_eval = bool(getattr(policy, "deterministic_eval", deterministic_eval))
+            # a reference PPO object updates on the whole batch it is handed (ppo.py:164-224); the per-agent sequence of
+            # MARLDispatcher (marl.py:251-268) is what `dispatch="per_agent"` reproduces for a shared algorithm
+            dispatch = dispatch or "pooled"
+        dispatch = dispatch or "per_agent"
+        if optim is not None:  # AdamOptimizerFactory (optim.py:91-111), optionally with an LR scheduler factory
+            kw_o = optim.adam_kwargs()
+            lr, betas, adam_eps, weight_decay = kw_o["lr"], kw_o["betas"], kw_o["adam_eps"], kw_o["weight_decay"]
+            sched_factory = getattr(optim, "lr_scheduler_factory", None)
         self._ctor = dict(lr=lr, betas=betas, adam_eps=adam_eps, weight_decay=weight_decay, eps_clip=eps_clip,
                           dual_clip=dual_clip, value_clip=value_clip, advantage_normalization=advantage_normalization,
                           recompute_advantage=recompute_advantage, vf_coef=vf_coef, ent_coef=ent_coef,
                           max_grad_norm=max_grad_norm, gae_lambda=gae_lambda, max_batchsize=max_batchsize, gamma=gamma,
                           return_scaling=return_scaling, deterministic_eval=deterministic_eval, dispatch=dispatch,
                           shuffle=shuffle, seed=seed, use_graph=use_graph, async_stats=async_stats)
+        self._sched_factory = sched_factory
         self.net = net
         # Policy attributes the collector / MARL containers read (algorithm_base.py:159-373, marl.py:79-85)
         from ..env.spaces import Box, Discrete
@@ -58,6 +90,8 @@ class PPO(nn.Module):
         self._lr_dev = torch.tensor([float(lr)], dtype=torch.float64, device=net.flat.device)
         self._lr = float(lr)
         self.lr_schedulers: list = []
+        if sched_factory is not None:  # Algorithm._create_optimizer (algorithm_base.py:506-519)
+            self.lr_schedulers.append(sched_factory.create_scheduler(self))
         self.betas, self.adam_eps, self.weight_decay = betas, adam_eps, weight_decay
         self.eps_clip, self.dual_clip, self.value_clip = eps_clip, dual_clip, value_clip
         self.advantage_normalization, self.recompute_adv = advantage_normalization, recompute_advantage
@@ -584,28 +618,89 @@ class PPO(nn.Module):
         net = DiscreteActorCritic(self.net.obs_dim, self.net.n_act, self.net.hidden, device=self.device)
         net.flat.data.copy_(self.net.flat.data)
         net.sync_image()
+        net._ref_keys = getattr(self.net, "_ref_keys", None)
         new = PPO(net=net, **self._ctor)
         new.load_state_dict(self.state_dict())
         new.train(self.training)
         return new
 
-    # ---- checkpointing (algorithm_base.py:521-541: optimizer state under "_optimizers") ----------
+    # ---- checkpointing: the reference's layout (algorithm_base.py:521-541) --------------------------------------
     def state_dict(self, *args, **kwargs):
-        return {"net": self.net.to_reference_state_dict(), "flat": self.net.flat.data.clone(),
-                "_optimizers": [{"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                                 "step": self.opt_step, "lr": self.lr}],
-                "ret_rms": (self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count), "sample_ctr": self._sample_ctr}
+        """`Algorithm.state_dict()` of the reference: the nn.Module parameters under their module paths
+        (`policy.actor.preprocess.model.model.0.weight` ... `critic.last.model.0.bias`) plus `_optimizers` = a list with
+        ONE torch-Adam `state_dict()` (`state[i] = {step, exp_avg, exp_avg_sq}` per parameter in
+        ActorCritic.parameters() order, `param_groups`), so checkpoints move between the reference and this engine in both
+        directions (pinned by tests/golden/checkpoint.npz).  What the engine needs beyond that to resume bit-identically
+        (return statistics, sampling / permutation counters, scheduler epochs) rides in `_optimizers[0]["tsm_engine"]`,
+        a key torch's `Optimizer.load_state_dict` ignores."""
+        from collections import OrderedDict
+
+        views = self.net.reference_named_views()
+        sd = OrderedDict((k, v.detach().clone()) for k, v in views)
+        state, o = {}, 0
+        for i, (_, v) in enumerate(views):
+            n = v.numel()
+            if self.opt_step > 0:  # torch creates the per-parameter state at the first step
+                state[i] = {"step": torch.tensor(float(self.opt_step)),
+                            "exp_avg": self.exp_avg[o:o + n].view(v.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + n].view(v.shape).clone()}
+            o += n
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.adam_eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(views)))}
+        if self.lr_schedulers:
+            group["initial_lr"] = self.lr_schedulers[0].base_lr  # torch's LambdaLR stores it in the group
+        engine = {"ret_rms": self.ret_rms.dev.detach().cpu().clone(), "sample_ctr": int(self._sample_ctr),
+                  "perm_ctr": int(self._perm_ctr.item()), "opt_step": int(self.opt_step),
+                  "lr_schedulers": [s.state_dict() for s in self.lr_schedulers]}
+        sd["_optimizers"] = [{"state": state, "param_groups": [group], "tsm_engine": engine}]
+        return sd
 
     def load_state_dict(self, sd, *args, **kwargs):
-        self.net.flat.data.copy_(sd["flat"])
+        views = self.net.reference_named_views()
+        missing = [k for k, _ in views if k not in sd]
+        if missing:
+            raise KeyError(f"state_dict lacks {missing[:3]}{' ...' if len(missing) > 3 else ''}")
+        with torch.no_grad():
+            for k, v in views:
+                v.copy_(torch.as_tensor(sd[k]).to(v.device, v.dtype).reshape(v.shape))
         self.net.sync_image()
         self.param_version += 1
-        o = sd["_optimizers"][0]
-        self.exp_avg.copy_(o["exp_avg"])
-        self.exp_avg_sq.copy_(o["exp_avg_sq"])
-        self.opt_step, self.lr = o["step"], o["lr"]
-        self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = sd["ret_rms"]
-        self._sample_ctr = sd.get("sample_ctr", 0)
+        opt = sd["_optimizers"][0]
+        st, o, step = opt["state"], 0, 0
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, (_, v) in enumerate(views):
+            n = v.numel()
+            e = st.get(i, st.get(str(i)))
+            if e is not None:
+                self.exp_avg[o:o + n].copy_(torch.as_tensor(e["exp_avg"]).reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(torch.as_tensor(e["exp_avg_sq"]).reshape(-1))
+                step = int(float(e["step"]))
+            o += n
+        self.opt_step = step
+        g = opt["param_groups"][0]
+        self.lr = float(g["lr"])
+        hyper = (tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"]))
+        if hyper != (tuple(self.betas), self.adam_eps, self.weight_decay):
+            self._ws = {}  # captured graphs hold the old Adam constants as kernel arguments
+        self.betas, self.adam_eps, self.weight_decay = hyper
+        eng = opt.get("tsm_engine")
+        if eng is not None:
+            self.ret_rms.dev.copy_(torch.as_tensor(eng["ret_rms"]))
+            self._sample_ctr = int(eng["sample_ctr"])
+            self._perm_ctr.fill_(int(eng["perm_ctr"]))
+            for s, s_sd in zip(self.lr_schedulers, eng.get("lr_schedulers", [])):
+                s.load_state_dict(s_sd)
+
+    # ---- the reference's training entry points (algorithm_base.py:543-582) ------------------------------------------
+    def create_trainer(self, params):
+        from ..trainer import OnPolicyTrainer
+
+        return OnPolicyTrainer(self, params)
+
+    def run_training(self, params):
+        return self.create_trainer(params).run()
 
 
 def ref_order_rows(T: int, B: int, device) -> torch.Tensor:

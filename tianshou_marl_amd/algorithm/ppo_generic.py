@@ -30,10 +30,18 @@ from .ppo import PPO, ref_order_rows
 
 
 class GenericPPO(PPO):
-    def __init__(self, *, net: MLPActorCritic, critic_input: Literal["local", "global"] = "local", n_agent: int = 1,
-                 graph: bool = True, **kwargs) -> None:
+    def __init__(self, *, net: MLPActorCritic | None = None, critic_input: Literal["local", "global"] | None = None,
+                 n_agent: int | None = None, graph: bool = True, **kwargs) -> None:
+        if net is None and kwargs.get("policy") is not None:  # reference-style construction (see PPO.__new__)
+            from ..utils.net import net_from_reference_modules
+
+            net = net_from_reference_modules(kwargs["policy"], kwargs.get("critic"), kwargs.get("device", "cuda"))
         if not isinstance(net, MLPActorCritic):
             raise TypeError("GenericPPO needs an MLPActorCritic (use PPO for DiscreteActorCritic)")
+        if critic_input is None:  # a critic that is wider than the actor's observation sees the env's joint observation
+            critic_input = "local" if net.critic_obs_dim == net.obs_dim else "global"
+        if n_agent is None:
+            n_agent = max(1, net.critic_obs_dim // net.obs_dim) if critic_input == "global" else 1
         kwargs["use_graph"] = False  # the base class's graph path is the fused-kernel one
         super().__init__(net=net, **kwargs)
         self.graph = bool(graph)  # capture this class's own update sequence into one hipGraph
@@ -42,8 +50,18 @@ class GenericPPO(PPO):
         if net.critic_obs_dim != want:
             raise ValueError(f"critic input width {net.critic_obs_dim} != {want} for critic_input={critic_input!r}")
         self._ctor.update(critic_input=critic_input, n_agent=n_agent, graph=graph)
+        self._cfg_rows = ops.make_ppo_cfg(self.eps_clip, self.dual_clip, self.value_clip, self.advantage_normalization,
+                                          self.vf_coef, self.ent_coef, value_group=self.n_agent)
 
     # ---- helpers --------------------------------------------------------------------------------------------------
+    @property
+    def row_minibatches(self) -> bool:
+        """Centralized critic + pooled dispatch: a minibatch is a set of JOINT ROWS (one env step = the reference's buffer
+        row, all N agents of it) instead of a set of lanes.  The actor then runs on the row's N observations and the
+        critic ONCE on their concatenation -- the same 4 * N * D bytes serve both nets, and the critic costs 1 / N of the
+        per-lane form.  `batch_size` still counts samples (lanes) and must be a multiple of N."""
+        return self.critic_input == "global" and self.dispatch == "pooled"
+
     def _values(self, obs_rows: torch.Tensor, joint: torch.Tensor | None) -> torch.Tensor:
         """V for every lane row.  local: critic(row).  global: critic(joint row of the env step), repeated per agent."""
         if self.critic_input == "local":
@@ -96,24 +114,35 @@ class GenericPPO(PPO):
         return dict(T=T, rows=rows, obs=obs, act=act, v_s=v_s.reshape(-1).contiguous(), ret=ret.reshape(-1),
                     adv=adv.reshape(-1), logp_old=logp_old, n_env=B, n_agent=N, joint=joint)
 
-    def _grad_step(self, pb: dict, idx: torch.Tensor, adv_stats, step_dev: torch.Tensor | None = None) -> torch.Tensor:
+    def _grad_step(self, pb: dict, idx: torch.Tensor, adv_stats, step_dev: torch.Tensor | None = None,
+                   rows: torch.Tensor | None = None) -> torch.Tensor:
         """One minibatch: forward both nets, loss, backward into joint slabs, clip + Adam.  Returns the 4 scalars.
-        step_dev: device-resident optimizer step count (graph capture); None = the host counter."""
+        idx: lane (sample) ids of the minibatch; rows: its joint-row ids when the minibatch is made of whole rows
+        (`row_minibatches`: idx == rows * N + agent, row-major).  step_dev: device-resident optimizer step count (graph
+        capture); None = the host counter."""
         net = self.net
-        x = ops.gather_rows(pb["obs"], idx)
-        cx = x if pb["joint"] is None else ops.gather_rows(pb["joint"], torch.div(idx, pb["n_agent"], rounding_mode="floor"))
+        if rows is not None:
+            N = pb["n_agent"]
+            cx = ops.gather_rows(pb["joint"], rows)                    # [Mr, N * D]: read once ...
+            x = cx.view(-1, net.obs_dim)                               # ... the same bytes are the actor's N rows
+            cfg = self._cfg_rows
+        else:
+            x = ops.gather_rows(pb["obs"], idx)
+            cx = x if pb["joint"] is None else ops.gather_rows(pb["joint"], torch.div(idx, pb["n_agent"], rounding_mode="floor"))
+            cfg = self._cfg
         logits = FlatMLP.forward(net.actor, x, save=True)
         value = FlatMLP.forward(net.critic, cx, save=True).reshape(-1)
         dlogits, dvalue, scalars = ops.ppo_loss_fwd_bwd(
-            logits, value, pb["act"], pb["logp_old"], pb["adv"], pb["ret"], self._cfg, adv_stats=adv_stats,
+            logits, value, pb["act"], pb["logp_old"], pb["adv"], pb["ret"], cfg, adv_stats=adv_stats,
             v_s_old=pb["v_s"] if self.value_clip else None, perm=idx)
         M, n_total = idx.numel(), net.flat.numel()
+        Mc = value.numel()  # critic rows: M, or M / N with row minibatches
         n_split = ops.mlp_n_split(M)
         slabs = self._ws.get(("slabs", n_split))
         if slabs is None:
             slabs = self._ws[("slabs", n_split)] = torch.empty(n_split, n_total, dtype=torch.float32, device=self.device)
         net.actor.backward(dlogits, n_split, slabs=slabs, slab_stride=n_total)
-        net.critic.backward(dvalue.view(M, 1), n_split, slabs=slabs[:, net.n_actor:], slab_stride=n_total)
+        net.critic.backward(dvalue.view(Mc, 1), n_split, slabs=slabs[:, net.n_actor:], slab_stride=n_total)
         if step_dev is None:
             self.opt_step += 1
         else:
@@ -130,6 +159,20 @@ class GenericPPO(PPO):
                       work=self._adam_work, step_dev=step_dev)
         return scalars
 
+    # ---- minibatch plan shared by the graph and the eager path -----------------------------------------------------
+    def _plan(self, n_rows: int, N: int, batch_size: int | None):
+        """-> (groups, n_g, bounds, unit): `n_g` permuted units per group, `bounds` over units, `unit` = lanes per unit.
+        per_agent: units are one agent's lanes; pooled: all lanes; row minibatches: joint rows of N lanes each."""
+        if self.dispatch == "per_agent":
+            return list(range(N)), n_rows, split_bounds(n_rows, batch_size or -1, merge_last=True), 1
+        if self.row_minibatches:
+            if batch_size and batch_size > 0 and batch_size % N:
+                raise ValueError(f"batch_size={batch_size} must be a multiple of the {N} agents of a joint row "
+                                 "(centralized critic, pooled dispatch: minibatches are made of whole rows)")
+            return [None], n_rows, split_bounds(n_rows, (batch_size // N) if batch_size and batch_size > 0 else -1,
+                                                merge_last=True), N
+        return [None], n_rows * N, split_bounds(n_rows * N, batch_size or -1, merge_last=True), 1
+
     # ---- hipGraph path: one replay per update() (uniform, unrotated buffers; local advantage statistics) ------------
     def _update_graph_generic(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
         from ..data.stats import MapTrainingStats
@@ -139,9 +182,8 @@ class GenericPPO(PPO):
             return None
         B, N = buffer.buffer_num, buffer.n_agent
         per_agent = self.dispatch == "per_agent"
-        groups = list(range(N)) if per_agent else [None]
-        n_g = T * B if per_agent else T * B * N
-        bounds = split_bounds(n_g, batch_size or -1, merge_last=True)
+        groups, n_g, bounds, unit = self._plan(T * B, N, batch_size)
+        row_mode = unit > 1
         key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm)
         w = self._ws.get(key)
         if w is None:  # first update of this shape runs eagerly (one-time kernel attributes, allocator warm-up)
@@ -153,28 +195,32 @@ class GenericPPO(PPO):
             w.update(perm=torch.zeros(len(groups), repeat, n_g, dtype=torch.int64, device=dev),
                      step_dev=torch.zeros(1, dtype=torch.int64, device=dev),
                      scal=torch.zeros(n_steps, 4, dtype=torch.float32, device=dev),
-                     mb_start=torch.as_tensor([b[0] for b in bounds] + [n_g], dtype=torch.int64, device=dev))
-            seg = torch.arange(len(groups) * repeat, dtype=torch.int64, device=dev).view(-1, 1) * n_g
+                     mb_start=torch.as_tensor([b[0] * unit for b in bounds] + [n_g * unit], dtype=torch.int64, device=dev))
+            seg = torch.arange(len(groups) * repeat, dtype=torch.int64, device=dev).view(-1, 1) * (n_g * unit)
             # every tensor a captured kernel reads must outlive the graph: keep it in the workspace
             w["mb_all"] = mb_all = torch.cat([(seg + w["mb_start"][:-1].view(1, -1)).reshape(-1),
-                                              torch.tensor([len(groups) * repeat * n_g], dtype=torch.int64, device=dev)])
+                                              torch.tensor([len(groups) * repeat * n_g * unit], dtype=torch.int64, device=dev)])
+            w["lane_of_row"] = torch.arange(N, dtype=torch.int64, device=dev).view(1, 1, 1, N)
 
             def body():
                 if self.shuffle == "device":
                     ops.random_permutations(n_g, len(groups) * repeat, self.seed ^ 0x5DEECE66D, counter_dev=w["step_dev"],
                                             scale=N if per_agent else 1, group_size=repeat,
                                             offset_mul=1 if per_agent else 0, out=w["perm"])
+                # lane ids of every minibatch: the permuted units themselves, or the N lanes of each permuted joint row
+                lanes = (w["perm"].unsqueeze(-1) * N + w["lane_of_row"]).reshape(len(groups), repeat, n_g * N) \
+                    if row_mode else w["perm"]
                 pb = self._preprocess_batch(buffer, uniform_T=T)
                 stats = None
                 if self.advantage_normalization:
-                    stats = ops.ppo_adv_stats(pb["adv"], mb_all, perm=w["perm"].view(-1),
-                                              max_rows=max(e - s for s, e in bounds)).view(len(groups), repeat, len(bounds), 2)
+                    stats = ops.ppo_adv_stats(pb["adv"], mb_all, perm=lanes.reshape(-1),
+                                              max_rows=max(e - s for s, e in bounds) * unit).view(len(groups), repeat, len(bounds), 2)
                 k = 0
                 for gi in range(len(groups)):
                     for r in range(repeat):
                         for j, (s, e) in enumerate(bounds):
-                            sc = self._grad_step(pb, w["perm"][gi, r, s:e], None if stats is None else stats[gi, r, j],
-                                                 step_dev=w["step_dev"])
+                            sc = self._grad_step(pb, lanes[gi, r, s * unit:e * unit], None if stats is None else stats[gi, r, j],
+                                                 step_dev=w["step_dev"], rows=w["perm"][gi, r, s:e] if row_mode else None)
                             w["scal"][k].copy_(sc)
                             k += 1
 
@@ -184,7 +230,7 @@ class GenericPPO(PPO):
             w["graph"] = graph
             if self.shuffle == "numpy":
                 base = ref_order_rows(T, B, dev)
-                w["ref_ids"] = [base * N + a if a is not None else
+                w["ref_ids"] = [base if row_mode else base * N + a if a is not None else
                                 (base[:, None] * N + torch.arange(N, device=dev)[None, :]).reshape(-1) for a in groups]
         if self.shuffle == "numpy":
             for gi, a in enumerate(groups):
@@ -216,13 +262,28 @@ class GenericPPO(PPO):
 
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
                            buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:
-        ids = self._sample_ids(pb, agent)
         dev = self.device
-        n = ids.numel() if ids is not None else pb["obs"].shape[0]
-        if ids is None:
-            ids = torch.arange(n, dtype=torch.int64, device=dev)
-        bounds = split_bounds(n, batch_size or -1, merge_last=True)
-        mb_start = torch.as_tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=dev)
+        N = pb["n_agent"]
+        row_mode = agent is None and self.row_minibatches and pb.get("joint") is not None and N > 1
+        if row_mode:  # units = joint rows in the reference's sample(0) order (or the ragged row list)
+            if pb["rows"] is not None:
+                ids = pb["rows"]
+            elif self.shuffle == "numpy":
+                ids = ref_order_rows(pb["T"], pb["n_env"], dev)
+            else:
+                ids = torch.arange(pb["T"] * pb["n_env"], dtype=torch.int64, device=dev)
+            if batch_size and batch_size > 0 and batch_size % N:
+                raise ValueError(f"batch_size={batch_size} must be a multiple of the {N} agents of a joint row")
+            unit, size = N, (batch_size // N) if batch_size and batch_size > 0 else -1
+        else:
+            ids = self._sample_ids(pb, agent)
+            if ids is None:
+                ids = torch.arange(pb["obs"].shape[0], dtype=torch.int64, device=dev)
+            unit, size = 1, batch_size or -1
+        n = ids.numel()
+        bounds = split_bounds(n, size, merge_last=True)
+        mb_start = torch.as_tensor([b[0] * unit for b in bounds] + [n * unit], dtype=torch.int64, device=dev)
+        lane_of_row = torch.arange(N, dtype=torch.int64, device=dev).view(1, N)
         scal = []
         for step in range(repeat):
             if self.recompute_adv and step > 0:
@@ -233,10 +294,12 @@ class GenericPPO(PPO):
                 perm_local = ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, device=dev)[0]
                 ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
             perm = ids[perm_local]
-            stats = (ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm, max_rows=max(e - s for s, e in bounds))
+            lanes = (perm.view(-1, 1) * N + lane_of_row).reshape(-1) if row_mode else perm
+            stats = (ops.ppo_adv_stats(pb["adv"], mb_start, perm=lanes, max_rows=max(e - s for s, e in bounds) * unit)
                      if self.advantage_normalization else None)
             for j, (s, e) in enumerate(bounds):
-                scal.append(self._grad_step(pb, perm[s:e].contiguous(), None if stats is None else stats[j]))
+                scal.append(self._grad_step(pb, lanes[s * unit:e * unit].contiguous(), None if stats is None else stats[j],
+                                            rows=perm[s:e].contiguous() if row_mode else None))
         self.param_version += 1
         s_h = torch.stack(scal).cpu().numpy()
         return A2CTrainingStats(
@@ -273,18 +336,12 @@ class GenericPPO(PPO):
         return {"loss": st.loss.mean, "actor_loss": st.actor_loss.mean, "vf_loss": st.vf_loss.mean,
                 "ent_loss": st.ent_loss.mean}
 
-    # ---- checkpoints / snapshots ----------------------------------------------------------------------------------
-    def state_dict(self, *args, **kwargs):
-        return {"net": {"actor": self.net.actor.to_reference_state_dict(), "critic": self.net.critic.to_reference_state_dict()},
-                "flat": self.net.flat.data.clone(),
-                "_optimizers": [{"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                                 "step": self.opt_step, "lr": self.lr}],
-                "ret_rms": (self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count), "sample_ctr": self._sample_ctr}
-
+    # ---- snapshots (checkpoints: PPO.state_dict / load_state_dict on the reference key names) ------------------
     def __deepcopy__(self, memo):
         src = self.net
         net = MLPActorCritic(src.obs_dim, src.n_act, tuple(src.actor.dims[1:-1]), act=src.actor.act,
                              critic_obs_dim=src.critic_obs_dim, device=self.device)
+        net._ref_keys = getattr(src, "_ref_keys", None)
         ctor = copy.copy(self._ctor)
         new = GenericPPO(net=net, **ctor)
         new.load_state_dict(self.state_dict())

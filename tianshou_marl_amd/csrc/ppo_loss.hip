@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void adv_stats_fold_kernel(const float *__restr
 
 struct Cfg {
     float eps_clip, dual_clip, vf_coef, ent_coef;
-    int value_clip, adv_norm, kind;
+    int value_clip, adv_norm, kind, vg;
 };
 
 constexpr int kLossThreads = 256;
@@ -142,9 +142,9 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
     __shared__ double sm[kLossThreads / 64];
     const int A = A_T > 0 ? A_T : A_rt;
     double t_clip = 0.0, t_vf = 0.0, t_ent = 0.0;
-    // a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the grid is capped (kMaxLossBlocks) so that the
-    // finalize pass folds a bounded number of partial sums, in a fixed order (deterministic)
-    for (int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x; i < M; i += (int64_t)gridDim.x * kLossThreads) {
+    // one sample: loss terms into the running sums, d loss / d logits stored, d loss / d value returned.  `v` is the
+    // sample's value (value_group > 1: the value of its joint row, shared by the row's agents)
+    auto sample = [&](int64_t i, float v) -> float {
         const int64_t row = perm ? perm[i] : first_row + i;
         const float invM = 1.0f / (float)M;
         float lg[A_T > 0 ? A_T : kMaxA];
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
                 else if (c == obj) g_ratio *= 0.5f;
             }
         }
-        const float v = value[i], ret = returns[row];
+        const float ret = returns[row];
         float vf, g_v;
         if (cfg.value_clip) {
             const float vs = v_s_old[row];
@@ -201,7 +201,6 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
             vf = (ret - v) * (ret - v);
             g_v = 2.f * (v - ret);
         }
-        dvalue[i] = cfg.vf_coef * g_v * invM;
         const float g_logp = -g_ratio * ratio * invM;
         const float ec = cfg.ent_coef * invM;
 #pragma unroll
@@ -212,6 +211,31 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
             dlogits[i * A + j] = g_logp * dlogp - ec * dent;
         }
         t_clip += obj; t_vf += vf; t_ent += h;
+        return cfg.vf_coef * g_v * invM;
+    };
+    // a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the grid is capped (kMaxLossBlocks) so that the
+    // finalize pass folds a bounded number of partial sums, in a fixed order (deterministic)
+    const int vg = cfg.vg;
+    if (vg == 1) {
+        for (int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x; i < M; i += (int64_t)gridDim.x * kLossThreads)
+            dvalue[i] = sample(i, value[i]);
+    } else if ((vg & (vg - 1)) == 0 && vg <= 64) {
+        // centralized critic: the vg samples of a joint row are adjacent lanes of one wave (vg | 64, M % vg == 0, so a
+        // group is never split by the loop bound); d value of the row = xor-butterfly sum over its lanes (symmetric:
+        // the same bits on every lane), stored by the row's first lane
+        for (int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x; i < M; i += (int64_t)gridDim.x * kLossThreads) {
+            float dv = sample(i, value[i / vg]);
+            for (int off = 1; off < vg; off <<= 1) dv += __shfl_xor(dv, off, 64);
+            if (i % vg == 0) dvalue[i / vg] = dv;
+        }
+    } else {  // any group size: one thread walks the samples of a joint row
+        const int64_t G = M / vg;
+        for (int64_t gi = (int64_t)blockIdx.x * kLossThreads + threadIdx.x; gi < G; gi += (int64_t)gridDim.x * kLossThreads) {
+            const float v = value[gi];
+            float dv = 0.f;
+            for (int a = 0; a < vg; ++a) dv += sample(gi * vg + a, v);
+            dvalue[gi] = dv;
+        }
     }
     const double b_clip = block_sum<double, kLossThreads>(t_clip, sm);
     const double b_vf = block_sum<double, kLossThreads>(t_vf, sm);
@@ -255,6 +279,7 @@ Cfg to_cfg(const tsm_ppo_cfg *c) {
     k.value_clip = c->value_clip;
     k.adv_norm = c->adv_norm;
     k.kind = c->loss_kind;
+    k.vg = c->value_group > 1 ? c->value_group : 1;
     return k;
 }
 
@@ -310,6 +335,7 @@ TSM_EXPORT int tsm_ppo_loss_fwd_bwd(const float *logits, const float *value, con
     TSM_REQUIRE(cfg_host->dual_clip <= 0.0 || cfg_host->dual_clip > 1.0,
                 "Dual-clip PPO parameter should greater than 1.0 but got %g", cfg_host->dual_clip);  // ppo.py:124-126
     const Cfg cfg = to_cfg(cfg_host);
+    TSM_REQUIRE(M % cfg.vg == 0, "tsm_ppo_loss_fwd_bwd: M = %lld is not a multiple of value_group = %d", (long long)M, cfg.vg);
     const dim3 grid((unsigned)loss_blocks(M)), block(kLossThreads);
     hipStream_t st = tsm_stream(stream);
 #define LAUNCH(AT)                                                                                         \

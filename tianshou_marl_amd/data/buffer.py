@@ -250,6 +250,87 @@ class DeviceVectorReplayBuffer:
         return bool(bad.item())
 
 
+    def isnull(self) -> Batch:
+        """buffer_base.py:649-650: boolean masks (same shapes as `self[:]`) of missing values; computed on device."""
+        idx = torch.as_tensor(self.sample_indices(0), dtype=torch.int64, device=self.device)
+        d = self.get_device(idx)
+        out = Batch()
+        for k, v in d.items():
+            if k in ("logp", "v_s"):
+                continue
+            out[k] = (torch.isnan(v) if v.is_floating_point() else torch.zeros_like(v, dtype=torch.bool)).cpu().numpy()
+        return out
+
+    _KEY_STORES = {"obs": "obs_store", "obs_next": "obs_next_store", "act": "act_store", "rew": "rew_store",
+                   "terminated": "term_store", "truncated": "trunc_store", "done": "done_store"}
+
+    def set_array_at_key(self, seq, key: str, index=None, default_value: float | None = None) -> None:
+        """buffer_base.py:637-644 -> Batch.set_array_at_key (batch.py:1269-1305) for the stored (reserved) keys: write
+        `seq` at the flat reference indices `index` (None: every slot, len(seq) == maxsize).  New keys cannot be
+        created: the vector buffer keeps reserved keys only (manager.py:146-149)."""
+        if key not in self._KEY_STORES or getattr(self, self._KEY_STORES[key]) is None:
+            raise ValueError(f"Cannot set sequence at key {key}: the device buffer stores {sorted(self._KEY_STORES)} only")
+        store = getattr(self, self._KEY_STORES[key])
+        idx = np.arange(self.maxsize) if index is None else np.atleast_1d(np.asarray(index))
+        if idx.dtype == bool:
+            idx = np.nonzero(idx)[0]
+        seq = np.asarray(seq)
+        if len(seq) != len(idx):
+            raise ValueError(f"Length of the sequence ({len(seq)}) must match the number of indices ({len(idx)})")
+        idx_d = torch.as_tensor(idx % self.maxsize, dtype=torch.int64, device=self.device)
+        env, slot = idx_d // self.sub_size, idx_d % self.sub_size
+        store[slot, env] = torch.as_tensor(seq).to(self.device, store.dtype).reshape(len(idx), *store.shape[2:])
+
+
+class VectorReplayBuffer(DeviceVectorReplayBuffer):
+    """`VectorReplayBuffer(total_size, buffer_num)` with the reference's constructor (vecbuf.py:15-37): like the
+    reference (manager.py:187-192) the stores are allocated lazily -- here when a Collector binds the buffer to its env
+    (agent count, observation width) or at the first `add`.  Everything else is DeviceVectorReplayBuffer."""
+
+    def __init__(self, total_size: int, buffer_num: int, n_agent: int | None = None, obs_dim: int | None = None,
+                 device: str | torch.device = "cuda", **kwargs) -> None:
+        self._lazy = dict(total_size=int(total_size), buffer_num=int(buffer_num), device=device, kwargs=kwargs)
+        self.buffer_num = int(buffer_num)
+        self.sub_size = -(-int(total_size) // self.buffer_num)
+        self.maxsize = self.sub_size * self.buffer_num
+        if n_agent is not None and obs_dim is not None:
+            self.bind(n_agent, obs_dim)
+
+    @property
+    def allocated(self) -> bool:
+        return "index" in self.__dict__
+
+    def bind(self, n_agent: int, obs_dim: int) -> "VectorReplayBuffer":
+        if self.allocated:
+            if (self.n_agent, self.obs_dim) != (int(n_agent), int(obs_dim)):
+                raise ValueError(f"buffer holds rows of {self.n_agent} agents x {self.obs_dim} floats, "
+                                 f"asked to bind {n_agent} x {obs_dim}")
+            return self
+        lz = self._lazy
+        DeviceVectorReplayBuffer.__init__(self, lz["total_size"], lz["buffer_num"], int(n_agent), int(obs_dim),
+                                          device=lz["device"], **lz["kwargs"])
+        return self
+
+    def add(self, batch: Batch, buffer_ids=None):
+        if not self.allocated:
+            obs = _obs_array(batch.obs)
+            obs = obs.reshape(len(batch.rew), -1, obs.shape[-1]) if obs.ndim > 2 else obs.reshape(len(batch.rew), 1, -1)
+            self.bind(obs.shape[1], obs.shape[2])
+        return super().add(batch, buffer_ids)
+
+    def __len__(self) -> int:
+        return super().__len__() if self.allocated else 0
+
+    def reset(self, keep_statistics: bool = False) -> None:
+        if self.allocated:
+            super().reset(keep_statistics)
+
+    def __getattr__(self, key: str):
+        if key in ("index", "obs_store") or key.endswith("_store"):
+            raise AttributeError(f"{key}: the buffer is not allocated yet (bind it to an env through a Collector, or add a row)")
+        return super().__getattr__(key)
+
+
 def _obs_array(obs) -> np.ndarray:
     """Accept the reference's observation containers: plain array, Batch(obs=...), or the parallel-mode
     Batch(observations=Batch(agent_i=...)) (enhanced_pettingzoo_env.py:202-205) -> [R, N, D] in agent order."""

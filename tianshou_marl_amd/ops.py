@@ -250,12 +250,12 @@ def categorical_logp_entropy(logits, act):
 # PPO loss (ppo.py:182-211)
 # --------------------------------------------------------------------------------------------
 def make_ppo_cfg(eps_clip=0.2, dual_clip=None, value_clip=False, adv_norm=True, vf_coef=0.5, ent_coef=0.01,
-                 loss_kind=0):
+                 loss_kind=0, value_group=1):
     """loss_kind 0: PPO clip objective; 1: plain policy gradient -mean(logp * adv) (A2C / Reinforce)."""
     if loss_kind not in (0, 1):
         raise ValueError(f"loss_kind must be 0 (PPO clip) or 1 (policy gradient), got {loss_kind}")
     return tsm_ppo_cfg(float(eps_clip), float(dual_clip or 0.0), float(vf_coef), float(ent_coef),
-                       int(bool(value_clip)), int(bool(adv_norm)), int(loss_kind), 0)
+                       int(bool(value_clip)), int(bool(adv_norm)), int(loss_kind), int(value_group))
 
 
 def ppo_adv_stats(adv, mb_start, perm=None, out=None, max_rows: int = 0, work=None):
@@ -285,8 +285,11 @@ def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, returns, cfg: tsm_ppo_cf
     M, A = logits.shape
     value = _chk(value, torch.float32, "value").reshape(-1)
     dev = logits.device
+    vg = max(1, int(cfg.value_group))
+    if value.numel() * vg != M:
+        raise ValueError(f"ppo_loss_fwd_bwd: {value.numel()} values for {M} samples with value_group={vg}")
     dlogits = torch.empty_like(logits)
-    dvalue = torch.empty(M, dtype=torch.float32, device=dev)
+    dvalue = torch.empty(M // vg, dtype=torch.float32, device=dev)
     partial = torch.empty(max(1, call("tsm_ppo_loss_partial_elems", M)), dtype=torch.float64, device=dev)
     scalars = torch.empty(4, dtype=torch.float32, device=dev)
     s = stream_ptr()

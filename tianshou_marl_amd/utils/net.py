@@ -88,6 +88,21 @@ class DiscreteActorCritic(nn.Module):
         "w2": "last.model.0.weight", "b2": "last.model.0.bias",
     }
 
+    def reference_named_views(self) -> list[tuple[str, torch.Tensor]]:
+        """[(key, view)] in ActorCritic.parameters() order with the key names `Algorithm.state_dict()` gives the
+        reference's PPO over DiscreteActor/DiscreteCritic(Net(hidden_sizes=[H, H])): `policy.actor.<...>`, `critic.<...>`
+        (algorithm_base.py:521-541; verified by tests/golden/checkpoint.npz)."""
+        keys = getattr(self, "_ref_keys", None)
+        out = []
+        for i, (name, v) in enumerate(self.named_views()):
+            net, layer = name.split(".")
+            if keys is not None:
+                k = keys[net][int(layer[1])][0 if layer[0] == "w" else 1]
+            else:
+                k = self._REF_KEYS[layer]
+            out.append((("policy.actor." if net == "actor" else "critic.") + k, v))
+        return out
+
     def to_reference_state_dict(self) -> dict[str, OrderedDict]:
         """{'actor': ..., 'critic': ...} with the key names of DiscreteActor/DiscreteCritic over Net."""
         out = {"actor": OrderedDict(), "critic": OrderedDict()}
@@ -238,6 +253,21 @@ class MLPActorCritic(nn.Module):
     def sync_image(self) -> None:
         return None
 
+    def reference_named_views(self) -> list[tuple[str, torch.Tensor]]:
+        """As DiscreteActorCritic.reference_named_views, for Net(hidden_sizes=[...]) of any depth: hidden layer i is
+        `preprocess.model.model.{2 i}` (Linear, activation, Linear, ...), the output layer `last.model.0`."""
+        keys = getattr(self, "_ref_keys", None)
+        out = []
+        for net_name, net, prefix in (("actor", self.actor, "policy.actor."), ("critic", self.critic, "critic.")):
+            for i in range(net.n_layers):
+                if keys is not None:
+                    kw, kb = keys[net_name][i]
+                else:
+                    stem = f"preprocess.model.model.{2 * i}" if i < net.n_layers - 1 else "last.model.0"
+                    kw, kb = stem + ".weight", stem + ".bias"
+                out += [(prefix + kw, net.weight(i)), (prefix + kb, net.bias(i))]
+        return out
+
     @torch.no_grad()
     def reset_parameters(self, init: str = "orthogonal", seed: int | None = None) -> None:
         """orthogonal weights + zero bias (the reference scripts' init) or nn.Linear's default."""
@@ -262,6 +292,7 @@ class FlatAdam:
     def __init__(self, module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  max_grad_norm: float | None = None) -> None:
         self.param = module.flat.data if hasattr(module, "flat") else module
+        self._module = module
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.exp_avg = torch.zeros_like(self.param)
         self.exp_avg_sq = torch.zeros_like(self.param)
@@ -278,14 +309,43 @@ class FlatAdam:
                       betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
                       work=self._work)
 
+    def _shapes(self) -> list[tuple[int, ...]]:
+        m = self._module
+        if isinstance(m, FlatMLP):
+            return [s for i in range(m.n_layers) for s in ((m.dims[i + 1], m.dims[i]), (m.dims[i + 1],))]
+        return [tuple(self.param.shape)]
+
     def state_dict(self) -> dict:
-        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_count,
-                "lr": self.lr}
+        """torch.optim.Adam.state_dict() layout (per-parameter `state`, one `param_groups` entry), parameters in the
+        module's `parameters()` order -- what `optim_actor.state_dict()` gives in the reference (ctde.py:36-37)."""
+        state, o = {}, 0
+        shapes = self._shapes()
+        for i, shp in enumerate(shapes):
+            n = int(np.prod(shp))
+            if self.step_count > 0:
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[o:o + n].view(shp).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + n].view(shp).clone()}
+            o += n
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(shapes)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd: dict) -> None:
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.step_count, self.lr = sd["step"], sd["lr"]
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        o, step = 0, 0
+        for i, shp in enumerate(self._shapes()):
+            n = int(np.prod(shp))
+            e = sd["state"].get(i, sd["state"].get(str(i)))
+            if e is not None:
+                self.exp_avg[o:o + n].copy_(torch.as_tensor(e["exp_avg"]).reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(torch.as_tensor(e["exp_avg_sq"]).reshape(-1))
+                step = int(float(e["step"]))
+            o += n
+        g = sd["param_groups"][0]
+        self.step_count, self.lr = step, float(g["lr"])
+        self.betas, self.eps, self.weight_decay = tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
 
 
 class RunningMeanStd:
@@ -334,3 +394,51 @@ class DeviceRunningMeanStd(RunningMeanStd):
     def update_scaled_returns(self, returns: torch.Tensor, rms_eps: float, ids: torch.Tensor | None = None) -> None:
         """update(returns * sqrt(var + rms_eps)) entirely on device (a2c.py:144-146)."""
         ops.rms_update(returns, self.dev, rms_eps, ids=ids)
+
+
+def net_from_reference_modules(policy, critic, device="cuda"):
+    """Build the flat HBM network from reference-shaped torch modules (`utils/ref_nets.py` mirrors or the reference's
+    own `DiscreteActorPolicy` / `DiscreteCritic`): parameters are copied once, the key names of the modules'
+    `state_dict()` are remembered for checkpoints.  64-64 ReLU nets on observations of at most 64 floats run on the
+    fused kernels (DiscreteActorCritic); everything else on the general MLP kernels (MLPActorCritic).
+    critic=None (Reinforce): the fused layout always carries a critic trunk; it stays untouched."""
+    from .ref_nets import activation_of, linear_layers, reference_key_names
+
+    cached = getattr(policy, "_tsm_net", None)
+    if cached is not None and cached[0] is critic and str(cached[1].flat.device).startswith(str(device).split(":")[0]):
+        return cached[1]
+    actor_mod = getattr(policy, "actor", policy)
+    la = linear_layers(actor_mod)
+    act = activation_of(actor_mod)
+    obs_dim, n_act = la[0][0].shape[1], la[-1][0].shape[0]
+    hidden = [w.shape[0] for w, _ in la[:-1]]
+    if critic is not None:
+        lc = linear_layers(critic)
+        if activation_of(critic) != act and len(lc) > 1:
+            raise ValueError("actor and critic must use the same activation")
+        if [w.shape[0] for w, _ in lc[:-1]] != hidden or lc[-1][0].shape[0] != 1:
+            raise ValueError("actor and critic must have the same hidden sizes and the critic a single output")
+        critic_obs = lc[0][0].shape[1]
+    else:
+        lc, critic_obs = None, obs_dim
+    if len(la) == 3 and hidden == [64, 64] and obs_dim <= 64 and n_act <= 16 and act == "relu" and critic_obs == obs_dim:
+        net = DiscreteActorCritic(obs_dim, n_act, 64, device=device)
+        if lc is None:
+            lc = [(np.zeros_like(net.view(f"critic.w{i}").cpu().numpy()), np.zeros_like(net.view(f"critic.b{i}").cpu().numpy()))
+                  for i in range(3)]
+        net.load_layers(la, lc)
+    else:
+        if lc is None:
+            raise ValueError("Reinforce without a critic runs on the fused 64-64 layout only")
+        net = MLPActorCritic(obs_dim, n_act, tuple(hidden), act=act, critic_obs_dim=critic_obs, device=device)
+        net.actor.load_layers(la)
+        net.critic.load_layers(lc)
+    net._ref_keys = {"actor": reference_key_names(actor_mod),
+                     "critic": reference_key_names(critic) if critic is not None else None}
+    if net._ref_keys["critic"] is None:
+        net._ref_keys = None
+    try:
+        policy._tsm_net = (critic, net)
+    except Exception:  # noqa: BLE001  (objects without attribute assignment: no cache)
+        pass
+    return net
