@@ -44,11 +44,13 @@ def parse():
     ap.add_argument("--minibatch", type=int, default=4096)
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--dispatch", default="per_agent", choices=["per_agent", "pooled"])
+    ap.add_argument("--c3-dispatch", default="pooled", choices=["per_agent", "pooled"],
+                    help="c3ppo: pooled = minibatches of joint rows (critic once per row); per_agent = MARLDispatcher order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pooled-grid", action="store_true",
                     help="extended roofline_grid: the fused gradient step at a pooled 65 536-row minibatch and GAE at the "
                          "synthetic horizons T = 2048 and 256")
-    ap.add_argument("--cpu-envs", type=int, default=64)
+    ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU baseline sample (0 = the GPU job's --n-env)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ppo"],
                     help="c2 (default, the headline line): simple_spread N=3 shared PPO; c3: N=8 CTDEPolicy, 4096 envs; "
                          "c3ppo: N=8 PPO with a centralized critic, 4096 envs")
@@ -283,8 +285,12 @@ def cpu_baseline(a):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cpu_path  # test/benchmark infrastructure: the CPU port of the same step
 
-    return cpu_path.run_baseline(n_env=a.cpu_envs, n_agent=a.n_agent, horizon=a.horizon, minibatch=a.minibatch,
-                                 repeat=a.repeat, dispatch=a.dispatch, budget_s=15.0)
+    # the GPU job's own per-GPU size (n_env = 1024 by default): a handful of ~4 s steps inside the 20 s budget, then the
+    # separate legs SURVEY 8(d) lists: the scan alone (serial / all cores) and the reference-default batch-64 update
+    out = cpu_path.run_baseline(n_env=a.cpu_envs or a.n_env, n_agent=a.n_agent, horizon=a.horizon, minibatch=a.minibatch,
+                                repeat=a.repeat, dispatch=a.dispatch, budget_s=20.0, ref_default_leg=True)
+    out.update(cpu_path.gae_legs(shapes=((a.horizon, a.n_env * a.n_agent), (25, 4096 * 8)), budget_s=4.0))
+    return out
 
 
 def run_c3(a, device):
@@ -384,7 +390,7 @@ def run_c3ppo(a, device):
     env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=device, seed=1626)
     D = env.obs_dim
     net = MLPActorCritic(D, 5, (128, 128), critic_obs_dim=N * D, device=device, seed=1626)
-    algo = GenericPPO(net=net, critic_input="global", n_agent=N, lr=3e-4, shuffle="device", seed=1626)
+    algo = GenericPPO(net=net, critic_input="global", n_agent=N, lr=3e-4, shuffle="device", seed=1626, dispatch=a.c3_dispatch)
     buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=device)
     col = Collector(algo, env, buf, async_stats=True)
     col.reset()
@@ -422,10 +428,10 @@ def run_c3ppo(a, device):
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "simple_spread_v3 N=8 PPO, shared actor 48-128-128-5 + centralized critic 384-128-128-1, "
-                               "num_envs=4096, T=25", "minibatch": mb, "repeat": 1, "dispatch": "per_agent"},
+                               "num_envs=4096, T=25", "minibatch": mb, "repeat": 1, "dispatch": a.c3_dispatch},
         "collect_ms": e0.elapsed_time(e1), "gae_ppo_update_ms": e1.elapsed_time(e2),
         "gradient_steps_per_update": sum(int(v) for k, v in d.items() if k.endswith("gradient_steps")),
-        "loss_agent_0": d.get("agent_0/loss")}))
+        "loss": d.get("agent_0/loss", d.get("loss"))}))
 
 
 def main():

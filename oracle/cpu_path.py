@@ -38,7 +38,7 @@ def _mlp(d_in, h, d_out):
 
 
 def run_baseline(n_env=64, n_agent=3, horizon=25, minibatch=4096, repeat=1, dispatch="per_agent", budget_s=15.0,
-                 seed=1626):
+                 seed=1626, ref_default_leg=False):
     torch.manual_seed(seed)
     np.random.seed(seed)
     torch.set_num_threads(min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU; tiny GEMMs do not scale further
@@ -56,8 +56,11 @@ def run_baseline(n_env=64, n_agent=3, horizon=25, minibatch=4096, repeat=1, disp
     index = oracle.VectorReplayBufferIndex(n_env * S, n_env, N)
     last_obs = np.stack([e.reset() for e in envs]).astype(np.float32)
 
-    def one_step():
+    def one_step(minibatch=minibatch, dispatch=dispatch, collect=True):
         nonlocal last_obs
+        if not collect:  # update only, on the rows of the last collect (the reference-default leg below)
+            t_c1 = time.perf_counter()
+            return (0.0, *update(minibatch, dispatch, t_c1)[1:])
         t_c0 = time.perf_counter()
         index.reset(keep_statistics=True)
         for _ in range(T):
@@ -77,7 +80,9 @@ def run_baseline(n_env=64, n_agent=3, horizon=25, minibatch=4096, repeat=1, disp
             for i in np.where(done)[0]:
                 last_obs[i] = envs[i].reset()
         t_c1 = time.perf_counter()
-        # ---- update ----
+        return (t_c1 - t_c0, *update(minibatch, dispatch, t_c1)[1:])
+
+    def update(minibatch, dispatch, t_c1):
         idx = index.sample_indices_all()                                   # env-major, time-ordered
         ob, obn = torch.from_numpy(obs_buf[idx]), torch.from_numpy(obs_next_buf[idx])
         with torch.no_grad():
@@ -118,7 +123,7 @@ def run_baseline(n_env=64, n_agent=3, horizon=25, minibatch=4096, repeat=1, disp
                     _ = (clip_loss.item(), vf_loss.item(), ent.item(), loss.item())
                     n_grad += 1
         t_u1 = time.perf_counter()
-        return t_c1 - t_c0, t_u1 - t_c1, n_grad
+        return 0.0, t_u1 - t_c1, n_grad
 
     one_step()  # warm-up (allocator, torch thread pool)
     t_col = t_upd = 0.0
@@ -132,13 +137,59 @@ def run_baseline(n_env=64, n_agent=3, horizon=25, minibatch=4096, repeat=1, disp
         if time.perf_counter() - t0 >= budget_s:
             break
     per_step = (t_col + t_upd) / n_steps
+    extra = {}
+    if ref_default_leg:
+        # the reference's own defaults for the update (trainer.py:287,295: batch_size=64, repeat=1) on the same rows,
+        # through the dispatcher's per-agent sequence: ONE timed update (thousands of 64-row gradient steps)
+        _, u64, n64 = one_step(minibatch=64, dispatch=dispatch, collect=False)
+        extra["update_reference_default_batch64"] = {"ms": u64 * 1e3, "gradient_steps": n64, "batch_size": 64, "repeat": repeat,
+                                                     "rows": n_env * T * N, "updates_timed": 1}
     return {
+        **extra,
         "value": n_env * N * T / per_step, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{n_steps} steps of n_env={n_env} (GPU job: per-GPU n_env is larger), N={N}, T={T}, minibatch={minibatch}, "
+        "sample": f"{n_steps} steps of n_env={n_env}, N={N}, T={T}, minibatch={minibatch}, "
                   f"repeat={repeat}, dispatch={dispatch}; python per-env loop + torch-CPU MLP/Adam + single-thread C GAE",
         "collect_env_steps_per_s": n_env * N * T / (t_col / n_steps), "ppo_update_ms": t_upd / n_steps * 1e3,
-        "gradient_steps_per_update": n_grad, "host_cpus": os.cpu_count(),
+        "gradient_steps_per_update": n_grad, "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+        "torch_threads": torch.get_num_threads(),
     }
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def gae_legs(shapes=((25, 3072), (25, 32768)), budget_s=3.0, seed=0):
+    """SURVEY 8(d) CPU legs for the scan alone, on the layouts the GPU kernel is timed on:
+      serial     -- one thread walks every lane's series: the faithful analogue of the reference's single-core numba
+                    `_gae` (algorithm_base.py:1079-1134);
+      all_cores  -- the same C loop with OpenMP over lanes on every host core (baseline-best).
+    22 B per (lane, step) as for the GPU roofline (f32 in, f64 accumulate)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    n_thr = os.cpu_count() or 1
+    for T, L in shapes:
+        v_s, v_n, rew = (rng.standard_normal((T, L)).astype(np.float32) for _ in range(3))
+        term = rng.random((T, L)) < 0.01
+        trunc = np.zeros((T, L), bool)
+        trunc[-1] = True
+        for name, thr in (("serial", 1), ("all_cores", n_thr)):
+            oracle.gae_lanes(v_s, v_n, rew, term, trunc, 0.99, 0.95, threads=thr)  # warm-up
+            n, t0 = 0, time.perf_counter()
+            while True:
+                oracle.gae_lanes(v_s, v_n, rew, term, trunc, 0.99, 0.95, threads=thr)
+                n += 1
+                if time.perf_counter() - t0 >= budget_s / (2 * len(shapes)):
+                    break
+            dt = (time.perf_counter() - t0) / n
+            out[f"gae_{name}_T{T}_L{L}"] = {"us": dt * 1e6, "GBps": 22.0 * T * L / dt / 1e9, "threads": thr, "calls_timed": n}
+    return out
 
 
 if __name__ == "__main__":

@@ -169,3 +169,88 @@ def test_generic_ppo_graph_replay_equals_eager_launches():
     assert s_e == s_g == 4 * 3 * 2 * 3  # 400 rows per agent / 128 -> 3 minibatches, 2 repeats, 3 agents, 4 updates
     assert np.array_equal(p_e, p_g)
     assert l_e == l_g
+
+
+@pytest.mark.parametrize("N,graph", [(3, False), (8, True), (4, False)])
+def test_row_minibatches_with_centralized_critic_match_float64_autograd(oracle, N, graph):
+    """Pooled dispatch + centralized critic: a minibatch is a set of joint rows; the critic runs once per row on the
+    concatenated observations and its value / gradient is shared by the row's N agents (value_group in the loss kernel:
+    wave-shuffle sum for N = 4 / 8, one thread per row for N = 3).  Whole update vs a float64 autograd replica that uses
+    the same permutations (reference sample(0) order)."""
+    from tianshou_marl_amd.data.batch import split_bounds
+
+    torch.manual_seed(1)
+    B, T, D, A, H = 12, 6, 5, 4, 32
+    net = MLPActorCritic(D, A, (H, H), critic_obs_dim=N * D, device=DEV, seed=2)
+    algo = GenericPPO(net=net, critic_input="global", n_agent=N, dispatch="pooled", shuffle="numpy", lr=1e-3, graph=graph,
+                      max_grad_norm=0.7, value_clip=True)
+    assert algo.row_minibatches
+    buf = DeviceVectorReplayBuffer(B * T, B, N, D, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for t in range(T):
+        r = lambda *s: torch.randn(*s, device=DEV, generator=gen)  # noqa: E731
+        term = (torch.rand(B, N, device=DEV, generator=gen) < 0.1).to(torch.uint8)
+        buf.add_device(r(B, N, D), torch.randint(0, A, (B, N), device=DEV, generator=gen, dtype=torch.int32), r(B, N), term,
+                       torch.full((B, N), int(t == T - 1), dtype=torch.uint8, device=DEV), obs_next=r(B, N, D))
+    actor, critic = _replica(net)
+    params = list(actor.parameters()) + list(critic.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3)
+    c = lambda x: x.cpu().numpy()  # noqa: E731
+    obs, obs_next = torch.as_tensor(c(buf.obs_store)).double(), torch.as_tensor(c(buf.obs_next_store)).double()   # [T, B, N, D]
+    act = torch.as_tensor(c(buf.act_store)).long()
+    with torch.no_grad():
+        v_s = critic(obs.reshape(T * B, N * D)).reshape(T, B, 1).expand(T, B, N)
+        v_n = critic(obs_next.reshape(T * B, N * D)).reshape(T, B, 1).expand(T, B, N)
+        logp_old = torch.log_softmax(actor(obs), -1).gather(-1, act.unsqueeze(-1)).squeeze(-1)
+    L = B * N
+    ret, adv = oracle.gae_lanes(v_s.numpy().astype(np.float32).reshape(T, L), v_n.numpy().astype(np.float32).reshape(T, L),
+                                c(buf.rew_store).reshape(T, L), c(buf.term_store).reshape(T, L).astype(bool),
+                                c(buf.trunc_store).reshape(T, L).astype(bool), 0.99, 0.95)
+    ret = torch.as_tensor(ret.astype(np.float32)).double().reshape(T * B, N)
+    adv = torch.as_tensor(adv.astype(np.float32)).double().reshape(T * B, N)
+    v_old = v_s.reshape(T * B, N).float().double()
+    ref_rows = (np.arange(T)[None, :] * B + np.arange(B)[:, None]).reshape(-1)  # sample(0) order -> joint-row id
+    batch_size, repeat = 20 * N, 2
+    np.random.seed(4)
+    losses = []
+    for _ in range(repeat):
+        perm = ref_rows[np.random.permutation(T * B)]
+        for s, e in split_bounds(T * B, batch_size // N, True):
+            rows = torch.as_tensor(perm[s:e])
+            x = obs.reshape(T * B, N, D)[rows]
+            a = adv[rows]
+            a = (a - a.mean()) / (a.std() + 1e-8)
+            lsm = torch.log_softmax(actor(x), -1)
+            logp = lsm.gather(-1, act.reshape(T * B, N)[rows].unsqueeze(-1)).squeeze(-1)
+            ratio = (logp - logp_old.reshape(T * B, N)[rows]).exp()
+            clip_loss = -torch.min(ratio * a, ratio.clamp(0.8, 1.2) * a).mean()
+            value = critic(x.reshape(len(rows), N * D)).expand(len(rows), N)
+            v_clip = v_old[rows] + (value - v_old[rows]).clamp(-0.2, 0.2)
+            vf_loss = torch.max((ret[rows] - value) ** 2, (ret[rows] - v_clip) ** 2).mean()
+            ent = -(lsm.exp() * lsm).sum(-1).mean()
+            loss = clip_loss + 0.5 * vf_loss - 0.01 * ent
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 0.7)
+            opt.step()
+            losses.append(float(loss))
+    np.random.seed(4)
+    with policy_within_training_step(algo):
+        if graph:  # the first update of a shape runs eagerly, the second captures: replay the same update twice on copies
+            p0 = net.flat.data.clone()
+            algo.update(buf, batch_size, repeat)
+            net.flat.data.copy_(p0)
+            algo.exp_avg.zero_()
+            algo.exp_avg_sq.zero_()
+            algo.opt_step = 0
+            np.random.seed(4)
+        st = algo.update(buf, batch_size, repeat)
+    assert st.gradient_steps == len(losses) == 2 * len(split_bounds(T * B, 20, True))
+    assert st.loss.mean == pytest.approx(np.mean(losses), rel=2e-5, abs=2e-6)
+    for f, ref in ((net.actor, actor), (net.critic, critic)):
+        for i, lin in enumerate([m for m in ref if isinstance(m, torch.nn.Linear)]):
+            np.testing.assert_allclose(f.weight(i).cpu().numpy(), lin.weight.detach().numpy(), rtol=5e-5, atol=5e-6)
+            np.testing.assert_allclose(f.bias(i).cpu().numpy(), lin.bias.detach().numpy(), rtol=5e-5, atol=5e-6)
+    with pytest.raises(ValueError):
+        with policy_within_training_step(algo):
+            algo.update(buf, batch_size + 1, 1)
