@@ -197,7 +197,10 @@ typedef struct {
     /* 0: PPO clip objective (ppo.py:182-211).  1: plain policy gradient, actor_loss = -mean(log_prob * adv), the
      * actor term of A2C (a2c.py:260-270: + vf_coef * mse(returns, value) - ent_coef * entropy, no clipping) and, with
      * vf_coef = ent_coef = 0 and adv = returns, the whole loss of Reinforce (reinforce.py:373-379).  eps_clip,
-     * dual_clip, value_clip and logp_old are ignored for kind 1. */
+     * dual_clip, value_clip and logp_old are ignored for kind 1.
+     * 2 (tsm_ppo_loss_fwd_bwd only): the VALUE term alone -- vf_coef * value loss, d loss / d value; logits, act,
+     * logp_old, adv, adv_stats and dlogits_out may be NULL (the policy terms of the same samples come from
+     * tsm_ppo_actor_rows_update). */
     int32_t loss_kind;
     /* <= 1: one critic value per sample.  N > 1 (tsm_ppo_loss_fwd_bwd only): centralized critic -- samples
      * i = r * N + a of a minibatch are the N agents of joint row r, `value` holds one entry per ROW (value[i / N]) and
@@ -417,6 +420,27 @@ int tsm_mpe_tag_step(const tsm_mpe_tag_cfg *cfg_host, uint64_t seed, uint64_t *e
                      float *obs_cur_out, float *rew_out, uint8_t *terminated_out, uint8_t *truncated_out,
                      uint8_t *done_env_out, int auto_reset, uint64_t *rng_tick, uint64_t rng_tick_inc, void *stream);
 int tsm_u64_add(uint64_t *counter, uint64_t inc, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 128-wide actor, one gradient step in one launch  [a7, a14 at BASELINE configs[2]: actor obs-128-128-A]
+ * Replaces the actor half of PPO._update_with_batch (ppo.py:182-212): policy(minibatch).dist, advantage
+ * normalisation, ratio / clip / dual-clip surrogate, entropy and the actor's backward pass.  The loss is separable
+ * (clip + entropy: actor; value term: critic), so the critic runs beside it: tsm_mlp_forward ->
+ * tsm_ppo_loss_fwd_bwd(loss_kind = 2) -> tsm_mlp_backward, and the gradient halves meet in tsm_adam_step.
+ * actor_params: w0[H][D] b0[H] w1[H][H] b1[H] w2[A][H] b2[A] (torch parameters() order), H == 128, D <= 64, A <= 16.
+ * Sample i of the minibatch is row perm[i] (NULL: first_row + i) of obs [n][D], act, logp_old, adv.
+ * n_blocks = tsm_ppo_actor_rows_grid(M) persistent workgroups, each writes ONE gradient slab:
+ * grad_slabs_out [n_blocks][tsm_ppo_actor_rows_param_count]; loss_partial_out f64 [n_blocks][4] =
+ * {sum clip objective, 0, sum entropy, 0} (the layout tsm_ppo_finalize_many folds).
+ * ------------------------------------------------------------------------------------------- */
+int tsm_ppo_actor_rows_supported(int32_t obs_dim, int32_t hidden, int32_t n_act);
+int64_t tsm_ppo_actor_rows_param_count(int32_t obs_dim, int32_t hidden, int32_t n_act);
+int tsm_ppo_actor_rows_grid(int64_t M);
+int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+                              const float *obs, const int32_t *act, const float *logp_old, const float *adv,
+                              const int64_t *perm, int64_t first_row, int64_t M, const float *adv_stats,
+                              const tsm_ppo_cfg *cfg, int32_t n_blocks, float *grad_slabs_out,
+                              double *loss_partial_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CTDE global state  [a16]

@@ -171,20 +171,21 @@ def test_generic_ppo_graph_replay_equals_eager_launches():
     assert l_e == l_g
 
 
-@pytest.mark.parametrize("N,graph", [(3, False), (8, True), (4, False)])
-def test_row_minibatches_with_centralized_critic_match_float64_autograd(oracle, N, graph):
+@pytest.mark.parametrize("N,graph,H", [(3, False, 32), (8, True, 32), (4, False, 32), (8, True, 128), (3, False, 128)])
+def test_row_minibatches_with_centralized_critic_match_float64_autograd(oracle, N, graph, H):
     """Pooled dispatch + centralized critic: a minibatch is a set of joint rows; the critic runs once per row on the
     concatenated observations and its value / gradient is shared by the row's N agents (value_group in the loss kernel:
     wave-shuffle sum for N = 4 / 8, one thread per row for N = 3).  Whole update vs a float64 autograd replica that uses
-    the same permutations (reference sample(0) order)."""
+    the same permutations (reference sample(0) order).  H = 128: the actor runs in the one-launch kernel of
+    csrc/ppo_rows.hip, the critic beside it with the value term alone."""
     from tianshou_marl_amd.data.batch import split_bounds
 
     torch.manual_seed(1)
-    B, T, D, A, H = 12, 6, 5, 4, 32
+    B, T, D, A = 12, 6, 5, 4
     net = MLPActorCritic(D, A, (H, H), critic_obs_dim=N * D, device=DEV, seed=2)
     algo = GenericPPO(net=net, critic_input="global", n_agent=N, dispatch="pooled", shuffle="numpy", lr=1e-3, graph=graph,
                       max_grad_norm=0.7, value_clip=True)
-    assert algo.row_minibatches
+    assert algo.row_minibatches and algo.fused_actor == (H == 128)
     buf = DeviceVectorReplayBuffer(B * T, B, N, D, device=DEV)
     gen = torch.Generator(device=DEV).manual_seed(3)
     for t in range(T):
@@ -254,3 +255,67 @@ def test_row_minibatches_with_centralized_critic_match_float64_autograd(oracle, 
     with pytest.raises(ValueError):
         with policy_within_training_step(algo):
             algo.update(buf, batch_size + 1, 1)
+
+
+@pytest.mark.parametrize("D,A,M,variant", [(48, 5, 1000, "default"), (18, 3, 32, "dual"), (64, 16, 4103, "nonorm"),
+                                           (5, 4, 70, "pg"), (48, 5, 65536, "default")])
+def test_actor_rows_kernel_matches_float64_autograd(D, A, M, variant):
+    """csrc/ppo_rows.hip: forward + policy loss + backward of a D-128-128-A actor in one launch vs float64 autograd of
+    the reference's arithmetic (ppo.py:183-196, 210): gradient slabs (summed), clip objective and entropy sums."""
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.utils.net import FlatMLP
+
+    H = 128
+    rng = np.random.default_rng(D + A + M)
+    f = FlatMLP([D, H, H, A], device=DEV, seed=3)
+    n = M + 37
+    obs = rng.standard_normal((n, D)).astype(np.float32)
+    act = rng.integers(0, A, n)
+    logp_old = (rng.standard_normal(n) * 0.3 - 1.3).astype(np.float32)
+    adv = (rng.standard_normal(n) * 2 + 0.3).astype(np.float32)
+    perm = rng.permutation(n)[:M]
+    kw = dict(default={}, dual=dict(dual_clip=2.0, eps_clip=0.1), nonorm=dict(adv_norm=False, ent_coef=0.03),
+              pg=dict(loss_kind=1, adv_norm=False))[variant]
+    cfg = ops.make_ppo_cfg(**kw)
+    d = lambda x, dt=None: torch.from_numpy(np.ascontiguousarray(x)).to(DEV, dt)  # noqa: E731
+    adv_d, perm_d = d(adv), d(perm)
+    stats = ops.ppo_adv_stats(adv_d, d(np.array([0, M], np.int64)), perm=perm_d, max_rows=M) if kw.get("adv_norm", True) else None
+    slabs, partial = ops.ppo_actor_rows_update(f.flat.data, d(obs), d(act, torch.int32), d(logp_old), adv_d, cfg, A, H,
+                                               adv_stats=None if stats is None else stats[0], perm=perm_d)
+    assert slabs.shape[0] == min(-(-M // 32), ops.device_info()["n_cu"])
+    # float64 replica
+    lins = []
+    for i in range(3):
+        lin = torch.nn.Linear(f.dims[i], f.dims[i + 1]).double()
+        with torch.no_grad():
+            lin.weight.copy_(f.weight(i).cpu().double())
+            lin.bias.copy_(f.bias(i).cpu().double())
+        lins.append(lin)
+    x = torch.as_tensor(obs[perm]).double()
+    lsm = torch.log_softmax(lins[2](torch.relu(lins[1](torch.relu(lins[0](x))))), -1)
+    logp = lsm.gather(1, torch.as_tensor(act[perm]).view(-1, 1)).flatten()
+    a = torch.as_tensor(adv[perm]).double()
+    if kw.get("adv_norm", True):
+        a = (a - a.mean()) / (a.std() + 1e-8)
+    ent = -(lsm.exp() * lsm).sum(-1)
+    if variant == "pg":
+        obj = logp * a
+    else:
+        eps = kw.get("eps_clip", 0.2)
+        ratio = (logp - torch.as_tensor(logp_old[perm]).double()).exp()
+        obj = torch.min(ratio * a, ratio.clamp(1 - eps, 1 + eps) * a)
+        if kw.get("dual_clip"):
+            obj = torch.where(a < 0, torch.max(obj, kw["dual_clip"] * a), obj)
+    loss = -obj.mean() - kw.get("ent_coef", 0.01) * ent.mean()
+    loss.backward()
+    g_ref = torch.cat([t.grad.flatten() for lin in lins for t in (lin.weight, lin.bias)]).numpy()
+    g = slabs.double().sum(0).cpu().numpy()
+    assert np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref) < 2e-5
+    np.testing.assert_allclose(g, g_ref, rtol=1e-3, atol=2e-4 * np.abs(g_ref).max())
+    p = partial.view(-1, 4).sum(0).cpu().numpy()
+    np.testing.assert_allclose([p[0], p[2]], [float(obj.sum()), float(ent.sum())], rtol=2e-5)
+    assert p[1] == 0 and p[3] == 0
+    # deterministic: the same launch twice gives the same bits
+    slabs2, _ = ops.ppo_actor_rows_update(f.flat.data, d(obs), d(act, torch.int32), d(logp_old), adv_d, cfg, A, H,
+                                          adv_stats=None if stats is None else stats[0], perm=perm_d)
+    assert torch.equal(slabs, slabs2)

@@ -31,7 +31,7 @@ from .ppo import PPO, ref_order_rows
 
 class GenericPPO(PPO):
     def __init__(self, *, net: MLPActorCritic | None = None, critic_input: Literal["local", "global"] | None = None,
-                 n_agent: int | None = None, graph: bool = True, **kwargs) -> None:
+                 n_agent: int | None = None, graph: bool = True, fused_actor: bool = True, **kwargs) -> None:
         if net is None and kwargs.get("policy") is not None:  # reference-style construction (see PPO.__new__)
             from ..utils.net import net_from_reference_modules
 
@@ -52,6 +52,12 @@ class GenericPPO(PPO):
         self._ctor.update(critic_input=critic_input, n_agent=n_agent, graph=graph)
         self._cfg_rows = ops.make_ppo_cfg(self.eps_clip, self.dual_clip, self.value_clip, self.advantage_normalization,
                                           self.vf_coef, self.ent_coef, value_group=self.n_agent)
+        # value term alone (the actor's terms come from the one-launch actor step, csrc/ppo_rows.hip)
+        self._cfg_value = {vg: ops.make_ppo_cfg(self.eps_clip, self.dual_clip, self.value_clip, False, self.vf_coef,
+                                                self.ent_coef, loss_kind=2, value_group=vg) for vg in (1, self.n_agent)}
+        self.fused_actor = bool(fused_actor) and ops.ppo_actor_rows_supported(net.obs_dim, net.actor.dims[1:-1], net.n_act,
+                                                                              net.actor.act)
+        self._ctor.update(fused_actor=fused_actor)
 
     # ---- helpers --------------------------------------------------------------------------------------------------
     @property
@@ -121,6 +127,8 @@ class GenericPPO(PPO):
         (`row_minibatches`: idx == rows * N + agent, row-major).  step_dev: device-resident optimizer step count (graph
         capture); None = the host counter."""
         net = self.net
+        if self.fused_actor:
+            return self._grad_step_fused_actor(pb, idx, adv_stats, step_dev, rows)
         if rows is not None:
             N = pb["n_agent"]
             cx = ops.gather_rows(pb["joint"], rows)                    # [Mr, N * D]: read once ...
@@ -158,6 +166,52 @@ class GenericPPO(PPO):
                       eps=self.adam_eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
                       work=self._adam_work, step_dev=step_dev)
         return scalars
+
+    def _grad_step_fused_actor(self, pb: dict, idx: torch.Tensor, adv_stats, step_dev, rows) -> torch.Tensor:
+        """The same gradient step with the 128-wide actor in ONE launch (forward, policy loss, backward:
+        csrc/ppo_rows.hip) and the critic beside it on the dense GEMMs with the value term alone; the two gradient halves
+        are folded into one flat gradient for the (jointly clipped) Adam step.  Loss statistics: one finalize launch over
+        the actor's and the value kernel's partial sums."""
+        net, dev = self.net, self.device
+        M, P_a, P_c = idx.numel(), net.n_actor, net.n_critic
+        na, nv = ops.ppo_actor_rows_grid(M), ops.ppo_loss_partial_elems(M) // 4
+        n_split = ops.mlp_n_split(M if rows is None else rows.numel())
+        w = self._ws.get(("rows", M, n_split))
+        if w is None:
+            w = self._ws[("rows", M, n_split)] = dict(
+                slabs_a=torch.empty(na, P_a, dtype=torch.float32, device=dev),
+                slabs_c=torch.empty(n_split, P_c, dtype=torch.float32, device=dev),
+                partial=torch.zeros((na + nv) * 4, dtype=torch.float64, device=dev),
+                nb=torch.tensor([na + nv], dtype=torch.int32, device=dev), M=torch.tensor([M], dtype=torch.int64, device=dev),
+                flat_g=torch.empty(P_a + P_c, dtype=torch.float32, device=dev))
+        ops.ppo_actor_rows_update(net.actor.flat.data, pb["obs"], pb["act"], pb["logp_old"], pb["adv"], self._cfg, net.n_act,
+                                  net.actor.dims[1], adv_stats=adv_stats, perm=idx, M=M, n_blocks=na, slabs=w["slabs_a"],
+                                  partial=w["partial"][:na * 4])
+        if rows is not None:
+            cx, vg = ops.gather_rows(pb["joint"], rows), pb["n_agent"]
+        elif pb["joint"] is not None:
+            cx, vg = ops.gather_rows(pb["joint"], torch.div(idx, pb["n_agent"], rounding_mode="floor")), 1
+        else:
+            cx, vg = ops.gather_rows(pb["obs"], idx), 1
+        value = FlatMLP.forward(net.critic, cx, save=True).reshape(-1)
+        dvalue, _ = ops.ppo_value_loss(value, pb["ret"], self._cfg_value[vg], M, v_s_old=pb["v_s"] if self.value_clip else None,
+                                       perm=idx, partial=w["partial"][na * 4:])
+        net.critic.backward(dvalue.view(-1, 1), n_split, slabs=w["slabs_c"], slab_stride=P_c)
+        scale = 1.0 / self._grad_sync.world if self._grad_sync is not None else 1.0
+        ops.reduce_slabs(w["slabs_a"], out=w["flat_g"][:P_a], scale=scale)
+        ops.reduce_slabs(w["slabs_c"], out=w["flat_g"][P_a:], scale=scale)
+        if self._grad_sync is not None:
+            self._grad_sync.all_reduce_sum_(w["flat_g"])
+        if step_dev is None:
+            self.opt_step += 1
+        else:
+            ops.call("tsm_u64_add", ops.ptr(step_dev), 1, ops.stream_ptr())
+        ops.adam_step(net.flat.data, w["flat_g"].view(1, -1), self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr,
+                      lr_dev=self._lr_dev, betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
+                      max_grad_norm=self.max_grad_norm, work=self._adam_work, step_dev=step_dev)
+        scal = torch.empty(1, 4, dtype=torch.float32, device=dev)
+        ops.ppo_finalize_many(w["partial"], (na + nv) * 4, w["nb"], w["M"], self._cfg, scal)
+        return scal[0]
 
     # ---- minibatch plan shared by the graph and the eager path -----------------------------------------------------
     def _plan(self, n_rows: int, N: int, batch_size: int | None):

@@ -142,9 +142,36 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
     __shared__ double sm[kLossThreads / 64];
     const int A = A_T > 0 ? A_T : A_rt;
     double t_clip = 0.0, t_vf = 0.0, t_ent = 0.0;
+    // value term of one sample (ppo.py:198-208): vf = loss term, g_v = d vf / d value
+    auto value_terms = [&](int64_t row, float v, float &vf, float &g_v) {
+        const float ret = returns[row];
+        if (cfg.value_clip) {
+            const float vs = v_s_old[row];
+            const float d = v - vs;
+            const float dc = fminf(fmaxf(d, -cfg.eps_clip), cfg.eps_clip);
+            const bool v_in = d >= -cfg.eps_clip && d <= cfg.eps_clip;
+            const float vclip = vs + dc;
+            const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vclip) * (ret - vclip);
+            const float g1 = 2.f * (v - ret), g2 = v_in ? 2.f * (vclip - ret) : 0.f;
+            if (vf1 > vf2) { vf = vf1; g_v = g1; }
+            else if (vf1 < vf2) { vf = vf2; g_v = g2; }
+            else { vf = vf1; g_v = 0.5f * g1 + 0.5f * g2; }
+        } else {
+            vf = (ret - v) * (ret - v);
+            g_v = 2.f * (v - ret);
+        }
+    };
+    // loss_kind 2: the value term alone (the policy terms of these samples are produced elsewhere, csrc/ppo_rows.hip)
+    auto sample_value_only = [&](int64_t i, float v) -> float {
+        const int64_t row = perm ? perm[i] : first_row + i;
+        float vf, g_v;
+        value_terms(row, v, vf, g_v);
+        t_vf += vf;
+        return cfg.vf_coef * g_v * (1.0f / (float)M);
+    };
     // one sample: loss terms into the running sums, d loss / d logits stored, d loss / d value returned.  `v` is the
     // sample's value (value_group > 1: the value of its joint row, shared by the row's agents)
-    auto sample = [&](int64_t i, float v) -> float {
+    auto sample_full = [&](int64_t i, float v) -> float {
         const int64_t row = perm ? perm[i] : first_row + i;
         const float invM = 1.0f / (float)M;
         float lg[A_T > 0 ? A_T : kMaxA];
@@ -184,23 +211,8 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
                 else if (c == obj) g_ratio *= 0.5f;
             }
         }
-        const float ret = returns[row];
         float vf, g_v;
-        if (cfg.value_clip) {
-            const float vs = v_s_old[row];
-            const float d = v - vs;
-            const float dc = fminf(fmaxf(d, -cfg.eps_clip), cfg.eps_clip);
-            const bool v_in = d >= -cfg.eps_clip && d <= cfg.eps_clip;
-            const float vclip = vs + dc;
-            const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vclip) * (ret - vclip);
-            const float g1 = 2.f * (v - ret), g2 = v_in ? 2.f * (vclip - ret) : 0.f;
-            if (vf1 > vf2) { vf = vf1; g_v = g1; }
-            else if (vf1 < vf2) { vf = vf2; g_v = g2; }
-            else { vf = vf1; g_v = 0.5f * g1 + 0.5f * g2; }
-        } else {
-            vf = (ret - v) * (ret - v);
-            g_v = 2.f * (v - ret);
-        }
+        value_terms(row, v, vf, g_v);
         const float g_logp = -g_ratio * ratio * invM;
         const float ec = cfg.ent_coef * invM;
 #pragma unroll
@@ -215,6 +227,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
     };
     // a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the grid is capped (kMaxLossBlocks) so that the
     // finalize pass folds a bounded number of partial sums, in a fixed order (deterministic)
+    auto sample = [&](int64_t i, float v) -> float { return cfg.kind == 2 ? sample_value_only(i, v) : sample_full(i, v); };
     const int vg = cfg.vg;
     if (vg == 1) {
         for (int64_t i = (int64_t)blockIdx.x * kLossThreads + threadIdx.x; i < M; i += (int64_t)gridDim.x * kLossThreads)
@@ -327,11 +340,12 @@ TSM_EXPORT int tsm_ppo_loss_fwd_bwd(const float *logits, const float *value, con
     TSM_REQUIRE(M >= 0 && A >= 1 && A <= kMaxA, "tsm_ppo_loss_fwd_bwd: bad sizes M=%lld A=%d", (long long)M, A);
     if (M == 0) return TSM_OK;
     TSM_REQUIRE(cfg_host, "tsm_ppo_loss_fwd_bwd: null cfg");
-    TSM_REQUIRE(logits && value && act && logp_old && adv && returns && dlogits_out && dvalue_out && partial_out,
-                "tsm_ppo_loss_fwd_bwd: null pointer");
+    const bool value_only = cfg_host->loss_kind == 2;
+    TSM_REQUIRE(value && returns && dvalue_out && partial_out, "tsm_ppo_loss_fwd_bwd: null pointer");
+    TSM_REQUIRE(value_only || (logits && act && logp_old && adv && dlogits_out), "tsm_ppo_loss_fwd_bwd: null pointer");
     TSM_REQUIRE(!cfg_host->value_clip || v_s_old, "tsm_ppo_loss_fwd_bwd: value_clip needs v_s_old");
-    TSM_REQUIRE(!cfg_host->adv_norm || adv_stats, "tsm_ppo_loss_fwd_bwd: adv_norm needs adv_stats");
-    TSM_REQUIRE(cfg_host->loss_kind == 0 || cfg_host->loss_kind == 1, "tsm_ppo_loss_fwd_bwd: loss_kind must be 0 or 1");
+    TSM_REQUIRE(value_only || !cfg_host->adv_norm || adv_stats, "tsm_ppo_loss_fwd_bwd: adv_norm needs adv_stats");
+    TSM_REQUIRE(cfg_host->loss_kind >= 0 && cfg_host->loss_kind <= 2, "tsm_ppo_loss_fwd_bwd: loss_kind must be 0, 1 or 2");
     TSM_REQUIRE(cfg_host->dual_clip <= 0.0 || cfg_host->dual_clip > 1.0,
                 "Dual-clip PPO parameter should greater than 1.0 but got %g", cfg_host->dual_clip);  // ppo.py:124-126
     const Cfg cfg = to_cfg(cfg_host);

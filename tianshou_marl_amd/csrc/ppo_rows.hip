@@ -1,0 +1,431 @@
+// ppo_rows.hip -- one PPO gradient step of a 128-wide ACTOR (obs -> 128 -> 128 -> A logits) in a single launch:
+// forward, Categorical log-prob / entropy, clip objective, and the whole backward pass, for the north star's roofline
+// configuration (simple_spread N = 8: actor 48-128-128-5 next to a centralized critic, BASELINE configs[2]).
+//
+// Replaces, for the actor half of `PPO._update_with_batch` (/root/reference/tianshou/algorithm/modelfree/ppo.py:182-212):
+//   dist = policy(minibatch).dist; advantage normalisation; ratio / clip / dual-clip surrogate; dist.entropy();
+//   the actor's share of loss.backward().
+// The PPO loss is separable -- the clip and entropy terms need the actor only, the value term the critic only (DESIGN.md
+// section 4) -- so the critic of this configuration runs beside it on the dense GEMMs (csrc/dense.hip) with
+// `tsm_ppo_loss_fwd_bwd(loss_kind = 2)` for the value term, and the two gradient halves meet in the Adam step.
+//
+// gfx950 mapping.  One persistent workgroup (512 threads = 8 waves, 2 per SIMD) per CU walks 32-sample tiles of the
+// minibatch (tile t, t + grid, ...).  The actor's weights stay in LDS for the lifetime of the workgroup (W1 | W2 | W3:
+// ~100 KB of the CU's 160 KB), a tile's activations next to them; every layer product is v_mfma_f32_16x16x4_f32 (exact
+// f32, DESIGN.md "Why f32 MFMA").  Wave w owns output columns [16 w, 16 w + 16) of a layer and both 16-row halves of the
+// tile, so a weight fragment read from LDS serves two MFMAs.  Weight gradients never leave registers between tiles:
+// wave w accumulates the 16 x 128 block dW2[16 w ..][:] (8 accumulator tiles), dW1[16 w ..][:] and one tile of dW3
+// across all tiles of its workgroup and writes them ONCE, as the workgroup's gradient slab (deterministic: tiles are
+// assigned statically, slabs are summed in order by tsm_reduce_slabs / tsm_adam_step).
+// Algorithmic HBM traffic per sample and step: obs 4 D + act 4 + logp_old 4 + adv 4 + id 8; activations
+// never touch HBM (the dense path writes and re-reads 4 x 512 B per sample).
+#include "common.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kH = 128;        // hidden width
+constexpr int kRows = 32;      // samples per tile (two 16-row MFMA tiles)
+constexpr int kThreads = 512;  // 8 waves
+constexpr int kLdh = kH + 2;   // 130 = 2 x odd: conflict-free [lane & 15][lane >> 4] operand reads
+constexpr int kLdo = 18;
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+struct RowsLay {  // LDS layout in floats
+    int nJ, ld1, W1, W2, W3, B1, B2, B3, X, H1, H2, LG, total;
+    __host__ __device__ explicit RowsLay(int D) {
+        nJ = (D + 15) / 16;
+        ld1 = 16 * nJ + 2;
+        int o = 0;
+        W1 = o; o += kH * ld1;
+        W2 = o; o += kH * kLdh;
+        W3 = o; o += 16 * kLdh;
+        B1 = o; o += kH;
+        B2 = o; o += kH;
+        B3 = o; o += 16;
+        X = o; o += kRows * ld1;
+        H1 = o; o += kRows * kLdh;
+        H2 = o; o += kRows * kLdh;
+        LG = o; o += kRows * kLdo;
+        total = o;
+    }
+};
+
+struct ActorArgs {
+    const float *P;          // actor parameters: w0[H][D] b0[H] w1[H][H] b1[H] w2[A][H] b2[A]
+    const float *obs;        // [n][D]
+    const int32_t *act;
+    const float *logp_old, *adv;
+    const int64_t *perm;     // sample ids of the minibatch (nullable: first_row + i)
+    int64_t first_row, M;
+    const float *adv_stats;  // {mean, std} of the minibatch (adv_norm)
+    int D, A;
+    float eps_clip, dual_clip, ent_coef;
+    int adv_norm, kind;
+    float *slabs;            // [grid][P]
+    double *partial;         // [grid][4] = {sum clip objective, 0, sum entropy, 0}
+};
+
+template <int NJ>
+__global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const RowsLay ly(g.D);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+    const int D = g.D, A = g.A, ld1 = ly.ld1;
+    const int64_t n_tiles = (g.M + kRows - 1) / kRows;
+
+    // ---- stage the weights once (zero pads: W1 columns >= D, W3 rows >= A) ----
+    const int oW1 = 0, oB1 = kH * D, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + A * kH;
+    for (int e = tid; e < kH * ld1; e += kThreads) {
+        const int r = e / ld1, c = e - r * ld1;
+        lds[ly.W1 + e] = c < D ? g.P[oW1 + r * D + c] : 0.f;
+    }
+    for (int e = tid; e < kH * kLdh; e += kThreads) {
+        const int r = e / kLdh, c = e - r * kLdh;
+        lds[ly.W2 + e] = c < kH ? g.P[oW2 + r * kH + c] : 0.f;
+    }
+    for (int e = tid; e < 16 * kLdh; e += kThreads) {
+        const int r = e / kLdh, c = e - r * kLdh;
+        lds[ly.W3 + e] = (r < A && c < kH) ? g.P[oW3 + r * kH + c] : 0.f;
+    }
+    if (tid < kH) { lds[ly.B1 + tid] = g.P[oB1 + tid]; lds[ly.B2 + tid] = g.P[oB2 + tid]; }
+    if (tid < 16) lds[ly.B3 + tid] = tid < A ? g.P[oB3 + tid] : 0.f;
+
+    // ---- persistent gradient accumulators ----
+    f4 gW2[8], gW1[NJ], gW3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gW2[i] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) gW1[i] = f4{0.f, 0.f, 0.f, 0.f};
+    gW3 = f4{0.f, 0.f, 0.f, 0.f};
+    float gB = 0.f;               // threads 0..127: db1[tid]; 128..255: db2[tid - 128]; 256..271: db3[tid - 256]
+    double t_clip = 0.0, t_ent = 0.0;  // wave 0, lanes < 32
+
+    // X tile of a tile: 32 samples x (4 nJ) float4 pieces; thread -> (sample, piece); prefetched one tile ahead
+    const int n_piece = 4 * NJ;   // float4 pieces per padded row (16 nJ floats)
+    const int xr = tid / n_piece, xp = tid - xr * n_piece;
+    const bool x_thread = tid < kRows * n_piece;
+    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch_x = [&](int64_t tile) {
+        xv[0] = xv[1] = xv[2] = xv[3] = 0.f;
+        if (!x_thread) return;
+        const int64_t i = tile * kRows + xr;
+        if (i >= g.M) return;
+        const int64_t s = g.perm ? g.perm[i] : g.first_row + i;
+        const float *src = g.obs + s * D + 4 * xp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * xp + j < D) xv[j] = src[j];
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) fetch_x(tile);
+    __syncthreads();  // weights staged
+
+    for (; tile < n_tiles; tile += gridDim.x) {
+        // ---- P0: commit the prefetched X tile (the previous tile's readers are behind the loop-end barrier) ----
+        if (x_thread) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lds[ly.X + xr * ld1 + 4 * xp + j] = xv[j];
+        }
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch_x(tile + gridDim.x);  // flies during the whole tile
+
+        const int col = 16 * w + c16;
+        // ---- P1: H1 = relu(X W1^T + b1) ----
+        {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            const float *a = lds + ly.X + c16 * ld1 + kq;
+            const float *b = lds + ly.W1 + col * ld1 + kq;
+#pragma unroll
+            for (int k0 = 0; k0 < 16 * NJ; k0 += 4) {
+                const float bv = b[k0];
+                acc[0] = mfma4(a[k0], bv, acc[0]);
+                acc[1] = mfma4(a[16 * ld1 + k0], bv, acc[1]);
+            }
+            const float bb = lds[ly.B1 + col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[ly.H1 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
+        }
+        __syncthreads();
+        // ---- P2: H2 = relu(H1 W2^T + b2) ----
+        {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            const float *a = lds + ly.H1 + c16 * kLdh + kq;
+            const float *b = lds + ly.W2 + col * kLdh + kq;
+#pragma unroll
+            for (int k0 = 0; k0 < kH; k0 += 4) {
+                const float bv = b[k0];
+                acc[0] = mfma4(a[k0], bv, acc[0]);
+                acc[1] = mfma4(a[16 * kLdh + k0], bv, acc[1]);
+            }
+            const float bb = lds[ly.B2 + col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[ly.H2 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
+        }
+        __syncthreads();
+        // ---- P3: logits = H2 W3^T + b3 (A padded to 16): waves 0 / 1 take the two row halves ----
+        if (w < 2) {
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            const float *a = lds + ly.H2 + (16 * w + c16) * kLdh + kq;
+            const float *b = lds + ly.W3 + c16 * kLdh + kq;
+#pragma unroll
+            for (int k0 = 0; k0 < kH; k0 += 4) acc = mfma4(a[k0], b[k0], acc);
+            const float bb = lds[ly.B3 + c16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[ly.LG + (16 * w + kq * 4 + r) * kLdo + c16] = acc[r] + bb;
+        }
+        __syncthreads();
+        // ---- P4: loss head, one lane per sample (ppo.py:183-196, 210); logits -> d loss / d logits in place ----
+        if (w == 0 && lane < kRows) {
+            float *lg = lds + ly.LG + lane * kLdo;
+            const int64_t i = tile * kRows + lane;
+            if (i < g.M) {
+                const int64_t s = g.perm ? g.perm[i] : g.first_row + i;
+                const float invM = 1.0f / (float)g.M;
+                float m = -INFINITY;
+                for (int j = 0; j < A; ++j) m = fmaxf(m, lg[j]);
+                float sum = 0.f;
+                for (int j = 0; j < A; ++j) sum += expf(lg[j] - m);
+                const float lse = m + logf(sum);
+                const int a_idx = g.act[s];
+                float a = g.adv[s];
+                if (g.adv_norm) a = (a - g.adv_stats[0]) / (g.adv_stats[1] + 1e-8f);
+                float logp = 0.f, h = 0.f;
+                for (int j = 0; j < A; ++j) {
+                    const float l = lg[j] - lse;
+                    lg[j] = l;
+                    h -= expf(l) * l;
+                    if (j == a_idx) logp = l;
+                }
+                float ratio, obj, g_ratio;
+                if (g.kind == 1) {
+                    ratio = 1.f; obj = logp * a; g_ratio = a;
+                } else {
+                    ratio = expf(logp - g.logp_old[s]);
+                    const float lo = 1.0f - g.eps_clip, hi = 1.0f + g.eps_clip;
+                    const float rc = fminf(fmaxf(ratio, lo), hi);
+                    const float s1 = ratio * a, s2 = rc * a;
+                    const bool in_range = ratio >= lo && ratio <= hi;
+                    if (s1 < s2) { obj = s1; g_ratio = a; }
+                    else if (s1 > s2) { obj = s2; g_ratio = in_range ? a : 0.f; }
+                    else { obj = s1; g_ratio = 0.5f * a + (in_range ? 0.5f * a : 0.f); }
+                    if (g.dual_clip > 0.f && a < 0.f) {
+                        const float c = g.dual_clip * a;
+                        if (c > obj) { obj = c; g_ratio = 0.f; }
+                        else if (c == obj) g_ratio *= 0.5f;
+                    }
+                }
+                const float g_logp = -g_ratio * ratio * invM;
+                const float ec = g.ent_coef * invM;
+                for (int j = 0; j < A; ++j) {
+                    const float l = lg[j], p = expf(l);
+                    lg[j] = g_logp * ((j == a_idx ? 1.f : 0.f) - p) + ec * p * (l + h);
+                }
+                t_clip += obj;
+                t_ent += h;
+            } else {
+                for (int j = 0; j < A; ++j) lg[j] = 0.f;
+            }
+            for (int j = A; j < 16; ++j) lg[j] = 0.f;
+        }
+        __syncthreads();
+        // ---- P5: dW3 += dLG^T H2 ; db3 ; dH2 = (dLG W3) * relu'(H2) ----
+        {
+            const float *a = lds + ly.LG + kq * kLdo + c16;            // A[i = a][k = row]
+            const float *b = lds + ly.H2 + kq * kLdh + col;            // B[k = row][j = hidden col]
+#pragma unroll
+            for (int r0 = 0; r0 < kRows; r0 += 4) gW3 = mfma4(a[r0 * kLdo], b[r0 * kLdh], gW3);
+        }
+        if (tid >= 256 && tid < 272) {
+            float s = 0.f;
+            for (int r = 0; r < kRows; ++r) s += lds[ly.LG + r * kLdo + (tid - 256)];
+            gB += s;
+        }
+        f4 d2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        {
+            const float *a = lds + ly.LG + c16 * kLdo + kq;            // A[i = row][k = a]
+            const float *b = lds + ly.W3 + kq * kLdh + col;            // B[k = a][j = hidden col]
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4) {
+                const float bv = b[k0 * kLdh];
+                d2[0] = mfma4(a[k0], bv, d2[0]);
+                d2[1] = mfma4(a[16 * kLdo + k0], bv, d2[1]);
+            }
+        }
+        __syncthreads();  // every wave has read H2 for dW3
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float *p = lds + ly.H2 + (mt * 16 + kq * 4 + r) * kLdh + col;
+                *p = *p > 0.f ? d2[mt][r] : 0.f;
+            }
+        __syncthreads();
+        // ---- P6: dW2 += dH2^T H1 ; db2 ; dH1 = (dH2 W2) * relu'(H1) ----
+        {
+            const float *a = lds + ly.H2 + kq * kLdh + col;            // A[i = out o][k = row]
+            const float *b = lds + ly.H1 + kq * kLdh + c16;            // B[k = row][j = in col]
+#pragma unroll
+            for (int r0 = 0; r0 < kRows; r0 += 4) {
+                const float av = a[r0 * kLdh];
+#pragma unroll
+                for (int ti = 0; ti < 8; ++ti) gW2[ti] = mfma4(av, b[r0 * kLdh + 16 * ti], gW2[ti]);
+            }
+        }
+        if (tid >= 128 && tid < 256) {
+            float s = 0.f;
+            for (int r = 0; r < kRows; ++r) s += lds[ly.H2 + r * kLdh + (tid - 128)];
+            gB += s;
+        }
+        f4 d1[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        {
+            const float *a = lds + ly.H2 + c16 * kLdh + kq;            // A[i = row][k = o]
+            const float *b = lds + ly.W2 + kq * kLdh + col;            // B[k = o][j = in col]
+#pragma unroll
+            for (int k0 = 0; k0 < kH; k0 += 4) {
+                const float bv = b[k0 * kLdh];
+                d1[0] = mfma4(a[k0], bv, d1[0]);
+                d1[1] = mfma4(a[16 * kLdh + k0], bv, d1[1]);
+            }
+        }
+        __syncthreads();  // every wave has read H1 for dW2
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float *p = lds + ly.H1 + (mt * 16 + kq * 4 + r) * kLdh + col;
+                *p = *p > 0.f ? d1[mt][r] : 0.f;
+            }
+        __syncthreads();
+        // ---- P7: dW1 += dH1^T X ; db1 ----
+        {
+            const float *a = lds + ly.H1 + kq * kLdh + col;            // A[i = out o][k = row]
+            const float *b = lds + ly.X + kq * ld1 + c16;              // B[k = row][j = obs col]
+#pragma unroll
+            for (int r0 = 0; r0 < kRows; r0 += 4) {
+                const float av = a[r0 * kLdh];
+#pragma unroll
+                for (int ti = 0; ti < NJ; ++ti) gW1[ti] = mfma4(av, b[r0 * ld1 + 16 * ti], gW1[ti]);
+            }
+        }
+        if (tid < 128) {
+            float s = 0.f;
+            for (int r = 0; r < kRows; ++r) s += lds[ly.H1 + r * kLdh + tid];
+            gB += s;
+        }
+        __syncthreads();  // X / H1 / H2 / LG are free for the next tile
+    }
+
+    // ---- the workgroup's gradient slab: written once, streamed (consumed once, by the reduction kernel) ----
+    float *slab = g.slabs + (size_t)blockIdx.x * (size_t)(oB3 + A);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 16 * w + kq * 4 + r;
+#pragma unroll
+        for (int ti = 0; ti < NJ; ++ti) {
+            const int i = 16 * ti + c16;
+            if (i < D) __builtin_nontemporal_store(gW1[ti][r], slab + oW1 + o * D + i);
+        }
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + oW2 + o * kH + 16 * ti + c16);
+        const int a = kq * 4 + r;
+        if (a < A) __builtin_nontemporal_store(gW3[r], slab + oW3 + a * kH + 16 * w + c16);
+    }
+    if (tid < 128) __builtin_nontemporal_store(gB, slab + oB1 + tid);
+    else if (tid < 256) __builtin_nontemporal_store(gB, slab + oB2 + tid - 128);
+    else if (tid < 256 + A) __builtin_nontemporal_store(gB, slab + oB3 + tid - 256);
+    if (w == 0) {
+        const double c = wave_sum(t_clip), e = wave_sum(t_ent);
+        if (lane == 0) {
+            g.partial[4 * blockIdx.x + 0] = c;
+            g.partial[4 * blockIdx.x + 1] = 0.0;
+            g.partial[4 * blockIdx.x + 2] = e;
+            g.partial[4 * blockIdx.x + 3] = 0.0;
+        }
+    }
+}
+
+int rows_supported(int32_t D, int32_t H, int32_t A) { return H == kH && D >= 1 && D <= 64 && A >= 1 && A <= 16; }
+
+int n_cu() {
+    static int cached = 0;
+    if (!cached) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cached = p.multiProcessorCount;
+        if (cached <= 0) cached = 256;
+    }
+    return cached;
+}
+
+}  // namespace
+
+TSM_EXPORT int tsm_ppo_actor_rows_supported(int32_t obs_dim, int32_t hidden, int32_t n_act) {
+    return rows_supported(obs_dim, hidden, n_act);
+}
+
+TSM_EXPORT int64_t tsm_ppo_actor_rows_param_count(int32_t obs_dim, int32_t hidden, int32_t n_act) {
+    if (!rows_supported(obs_dim, hidden, n_act)) return -1;
+    return (int64_t)hidden * obs_dim + hidden + (int64_t)hidden * hidden + hidden + (int64_t)n_act * hidden + n_act;
+}
+
+// workgroups (= gradient slabs) for a minibatch of M samples: one per CU, never more than there are tiles
+TSM_EXPORT int tsm_ppo_actor_rows_grid(int64_t M) {
+    if (M <= 0) return 0;
+    const int64_t tiles = ceil_div(M, kRows);
+    const int cu = n_cu();
+    return (int)(tiles < cu ? tiles : cu);
+}
+
+TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_dim, int32_t hidden, int32_t n_act,
+                                         const float *obs, const int32_t *act, const float *logp_old, const float *adv,
+                                         const int64_t *perm, int64_t first_row, int64_t M, const float *adv_stats,
+                                         const tsm_ppo_cfg *cfg, int32_t n_blocks, float *grad_slabs_out,
+                                         double *loss_partial_out, void *stream) {
+    TSM_REQUIRE(rows_supported(obs_dim, hidden, n_act),
+                "tsm_ppo_actor_rows_update supports hidden == 128, obs_dim <= 64, n_act <= 16 (got %d / %d / %d)", hidden,
+                obs_dim, n_act);
+    TSM_REQUIRE(M >= 1 && cfg, "tsm_ppo_actor_rows_update: empty minibatch or null cfg");
+    TSM_REQUIRE(actor_params && obs && act && logp_old && adv && grad_slabs_out && loss_partial_out,
+                "tsm_ppo_actor_rows_update: null pointer");
+    TSM_REQUIRE(!cfg->adv_norm || adv_stats, "tsm_ppo_actor_rows_update: adv_norm needs adv_stats");
+    TSM_REQUIRE(cfg->loss_kind == 0 || cfg->loss_kind == 1, "tsm_ppo_actor_rows_update: loss_kind must be 0 or 1");
+    TSM_REQUIRE(cfg->dual_clip <= 0.0 || cfg->dual_clip > 1.0,
+                "Dual-clip PPO parameter should greater than 1.0 but got %g", cfg->dual_clip);
+    TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(M, kRows), "tsm_ppo_actor_rows_update: n_blocks = %d out of range", n_blocks);
+    ActorArgs g{};
+    g.P = actor_params; g.obs = obs; g.act = act; g.logp_old = logp_old; g.adv = adv; g.perm = perm;
+    g.first_row = first_row; g.M = M; g.adv_stats = adv_stats; g.D = obs_dim; g.A = n_act;
+    g.eps_clip = (float)cfg->eps_clip; g.dual_clip = (float)cfg->dual_clip; g.ent_coef = (float)cfg->ent_coef;
+    g.adv_norm = cfg->adv_norm; g.kind = cfg->loss_kind;
+    g.slabs = grad_slabs_out; g.partial = loss_partial_out;
+    const RowsLay ly(obs_dim);
+    const size_t shmem = (size_t)ly.total * sizeof(float);
+    TSM_REQUIRE(shmem <= 160 * 1024, "tsm_ppo_actor_rows_update: LDS layout of %zu bytes does not fit", shmem);
+    static bool attr_set[4] = {false, false, false, false};
+    hipStream_t st = tsm_stream(stream);
+#define LAUNCH(NJ)                                                                                                     \
+    do {                                                                                                               \
+        if (!attr_set[NJ - 1]) {                                                                                       \
+            TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ppo_actor_rows_kernel<NJ>),                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
+            attr_set[NJ - 1] = true;                                                                                   \
+        }                                                                                                              \
+        hipLaunchKernelGGL((ppo_actor_rows_kernel<NJ>), dim3((unsigned)n_blocks), dim3(kThreads), shmem, st, g);       \
+    } while (0)
+    switch (ly.nJ) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}

@@ -251,9 +251,10 @@ def categorical_logp_entropy(logits, act):
 # --------------------------------------------------------------------------------------------
 def make_ppo_cfg(eps_clip=0.2, dual_clip=None, value_clip=False, adv_norm=True, vf_coef=0.5, ent_coef=0.01,
                  loss_kind=0, value_group=1):
-    """loss_kind 0: PPO clip objective; 1: plain policy gradient -mean(logp * adv) (A2C / Reinforce)."""
-    if loss_kind not in (0, 1):
-        raise ValueError(f"loss_kind must be 0 (PPO clip) or 1 (policy gradient), got {loss_kind}")
+    """loss_kind 0: PPO clip objective; 1: plain policy gradient -mean(logp * adv) (A2C / Reinforce); 2: the value term
+    alone (ppo_value_loss).  value_group N > 1: one critic value per joint row of N agents (centralized critic)."""
+    if loss_kind not in (0, 1, 2):
+        raise ValueError(f"loss_kind must be 0 (PPO clip), 1 (policy gradient) or 2 (value term only), got {loss_kind}")
     return tsm_ppo_cfg(float(eps_clip), float(dual_clip or 0.0), float(vf_coef), float(ent_coef),
                        int(bool(value_clip)), int(bool(adv_norm)), int(loss_kind), int(value_group))
 
@@ -436,6 +437,72 @@ def ppo_update_fused(params, obs, act, logp_old, adv, returns, cfg: tsm_ppo_cfg,
          ptr(perm), first_row, M, ptr(adv_stats), C.byref(cfg), n_blocks, ptr(slabs), ptr(partial), ptr(scalars),
          ptr(opt_step_dev), stream_ptr())
     return slabs, scalars
+
+
+def ppo_actor_rows_supported(obs_dim: int, hidden_sizes, n_act: int, act: str = "relu") -> bool:
+    """Does the one-launch actor step (csrc/ppo_rows.hip) cover this actor?  obs -> 128 -> 128 -> n_act, ReLU."""
+    hs = list(hidden_sizes)
+    return act == "relu" and len(hs) == 2 and hs[0] == hs[1] and bool(call("tsm_ppo_actor_rows_supported", obs_dim, hs[0], n_act))
+
+
+def ppo_actor_rows_grid(M: int) -> int:
+    return call("tsm_ppo_actor_rows_grid", M)
+
+
+def ppo_actor_rows_update(actor_params, obs, act, logp_old, adv, cfg: tsm_ppo_cfg, n_act: int, hidden: int = 128,
+                          adv_stats=None, perm=None, first_row=0, M=None, n_blocks=None, slabs=None, partial=None):
+    """Actor half of one PPO gradient step in one launch -> (grad_slabs [n_blocks, P_actor], loss partials f64
+    [n_blocks, 4] = {sum clip objective, 0, sum entropy, 0})."""
+    obs = _chk(obs, torch.float32, "obs")
+    D = obs.shape[-1]
+    if M is None:
+        M = perm.numel() if perm is not None else obs.shape[0] - first_row
+    if n_blocks is None:
+        n_blocks = ppo_actor_rows_grid(M)
+    P = actor_params.numel()
+    if P != call("tsm_ppo_actor_rows_param_count", D, hidden, n_act):
+        raise ValueError(f"ppo_actor_rows_update: {P} actor parameters do not match obs {D} -> {hidden} -> {hidden} -> {n_act}")
+    dev = obs.device
+    if slabs is None:
+        slabs = torch.empty(n_blocks, P, dtype=torch.float32, device=dev)
+    elif slabs.numel() < n_blocks * P:
+        raise ValueError(f"ppo_actor_rows_update: slabs holds {slabs.numel()} floats, {n_blocks} slabs of {P} need {n_blocks * P}")
+    if partial is None:
+        partial = torch.empty(n_blocks * 4, dtype=torch.float64, device=dev)
+    elif partial.numel() < n_blocks * 4:
+        raise ValueError("ppo_actor_rows_update: partial is too small")
+    if perm is not None and perm.numel() < M:
+        raise ValueError(f"ppo_actor_rows_update: perm holds {perm.numel()} sample ids, M = {M}")
+    call("tsm_ppo_actor_rows_update", ptr(_chk(actor_params, torch.float32, "actor_params")), D, hidden, n_act, ptr(obs),
+         ptr(_chk(act, torch.int32, "act")), ptr(_chk(logp_old, torch.float32, "logp_old")),
+         ptr(_chk(adv, torch.float32, "adv")), ptr(perm), first_row, M, ptr(adv_stats), C.byref(cfg), n_blocks, ptr(slabs),
+         ptr(partial), stream_ptr())
+    return slabs, partial
+
+
+def ppo_value_loss(value, returns, cfg: tsm_ppo_cfg, M: int, v_s_old=None, perm=None, first_row=0, partial=None):
+    """Value term of the PPO loss alone (loss_kind = 2) for M samples whose values are `value` (one per sample, or one
+    per joint row with cfg.value_group = N) -> (dvalue [len(value)], loss partials f64 [blocks, 4] = {0, sum vf, 0, 0})."""
+    value = _chk(value, torch.float32, "value").reshape(-1)
+    vg = max(1, int(cfg.value_group))
+    if value.numel() * vg != M:
+        raise ValueError(f"ppo_value_loss: {value.numel()} values for {M} samples with value_group={vg}")
+    if cfg.loss_kind != 2:
+        raise ValueError("ppo_value_loss needs a cfg with loss_kind = 2")
+    dev = value.device
+    dvalue = torch.empty(value.numel(), dtype=torch.float32, device=dev)
+    n_part = call("tsm_ppo_loss_partial_elems", M)
+    if partial is None:
+        partial = torch.empty(n_part, dtype=torch.float64, device=dev)
+    elif partial.numel() < n_part:
+        raise ValueError("ppo_value_loss: partial is too small")
+    call("tsm_ppo_loss_fwd_bwd", None, ptr(value), None, None, None, ptr(_chk(returns, torch.float32, "returns")),
+         ptr(v_s_old), ptr(perm), first_row, M, 1, None, C.byref(cfg), None, ptr(dvalue), ptr(partial), stream_ptr())
+    return dvalue, partial
+
+
+def ppo_loss_partial_elems(M: int) -> int:
+    return call("tsm_ppo_loss_partial_elems", M)
 
 
 # --------------------------------------------------------------------------------------------
