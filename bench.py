@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--c3-dispatch", default="pooled", choices=["per_agent", "pooled"],
                     help="c3ppo: pooled = minibatches of joint rows (critic once per row); per_agent = MARLDispatcher order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c3-grid", action="store_true", help="skip the roofline_grid entries of the 4096 x 8 configuration")
     ap.add_argument("--pooled-grid", action="store_true",
                     help="extended roofline_grid: the fused gradient step at a pooled 65 536-row minibatch and GAE at the "
                          "synthetic horizons T = 2048 and 256")
@@ -279,6 +280,94 @@ def kernel_rooflines(a, algo, buf):
                          "bytes_per_launch": gae_bytes, "us_per_launch": gae_s * 1e6},
         "roofline_grid": grid,
     }
+
+
+def c3_rooflines(device):
+    """roofline_grid entries for the north star's roofline configuration (BASELINE configs[2]: simple_spread N = 8,
+    4096 envs, T = 25, shared actor 48-128-128-5 + centralized critic 384-128-128-1, minibatch 65 536 samples of whole
+    joint rows): (i) the WHOLE GAE + PPO update as `GenericPPO.update` runs it (one hipGraph replay), priced against the
+    f32-MFMA peak with the flops it actually executes; (ii) its dominant kernel, the one-launch actor step."""
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.algorithm import GenericPPO, policy_within_training_step
+    from tianshou_marl_amd.data.batch import split_bounds
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.utils.net import MLPActorCritic
+
+    n_env, N, T, mb, H, A = 4096, 8, 25, 65536, 128, 5
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=device, seed=1626)
+    D = env.obs_dim
+    net = MLPActorCritic(D, A, (H, H), critic_obs_dim=N * D, device=device, seed=1626)
+    algo = GenericPPO(net=net, critic_input="global", n_agent=N, lr=3e-4, shuffle="device", seed=1626, dispatch="pooled")
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=device)
+    col = Collector(algo, env, buf)
+    col.reset()
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    t_col = t_upd = 0.0
+    reps, warm = 5, 3  # (the 2nd update captures the graph)
+    for i in range(warm + reps):
+        e0, e1, e2 = ev(), ev(), ev()
+        with policy_within_training_step(algo):
+            e0.record()
+            col.collect(n_step=n_env * T)
+            e1.record()
+            ts = algo.update(buf, mb, 1)
+            e2.record()
+        torch.cuda.synchronize()
+        col.reset_buffer(keep_statistics=True)
+        if i >= warm:
+            t_col += e0.elapsed_time(e1) / reps
+            t_upd += e1.elapsed_time(e2) / reps
+    rows, samples = n_env * T, n_env * T * N
+    f_actor = 2 * (D * H + H * H + H * A)             # forward flops per sample
+    f_critic = 2 * (N * D * H + H * H + H)            # forward flops per joint row
+    # executed: V(obs_next) for every row (logp_old / v_s come from the rollout) + forward and backward (2x) of every
+    # sample through the actor and of every joint row through the critic, once per epoch
+    flop = rows * f_critic + 3 * (samples * f_actor + rows * f_critic)
+    steps = len(split_bounds(rows, mb // N, True))
+    out = [{"kernel": "C3 whole GAE + PPO update (GenericPPO.update: V(obs_next), GAE, advantage statistics, %d gradient "
+                      "steps of actor-rows kernel + critic GEMMs + Adam; one hipGraph replay)" % steps,
+            "n_env": n_env, "n_agent": N, "T": T, "minibatch": mb, "bound": "mfma", "ms_per_update": t_upd,
+            "flop_per_update": flop, "achieved": flop / (t_upd * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+            "unit": "TFLOP/s", "frac": flop / (t_upd * 1e-3) / MFMA_F32_PEAK, "collect_ms": t_col,
+            "env_steps_per_s": samples / ((t_col + t_upd) * 1e-3), "gradient_steps": ts.gradient_steps,
+            "note": "flops as executed (the critic runs once per joint row); the per-lane critic of round 1 executed "
+                    "%.0f GFLOP for the same update" % ((2 * rows * f_critic + samples * f_actor + 3 * samples * (f_actor + f_critic)) / 1e9)}]
+    # (ii) the actor step alone, graph-batched launches on the job's own rows
+    n = samples
+    obs, act = buf.obs_store[:T].reshape(n, D), buf.act_store[:T].reshape(n)
+    lp, adv = buf.logp_store[:T].reshape(n), torch.randn(n, device=device)
+    perm = torch.randperm(n, device=device)[:mb].contiguous()
+    st = ops.ppo_adv_stats(adv, torch.tensor([0, mb], device=device), perm=perm, max_rows=mb)
+    nb = ops.ppo_actor_rows_grid(mb)
+    slabs = torch.empty(nb, net.n_actor, device=device)
+    part = torch.empty(nb * 4, dtype=torch.float64, device=device)
+    fn = lambda: ops.ppo_actor_rows_update(net.actor.flat.data, obs, act, lp, adv, algo._cfg, A, H, adv_stats=st[0],  # noqa: E731
+                                           perm=perm, M=mb, n_blocks=nb, slabs=slabs, partial=part)
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(10):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    tot = 0.0
+    for _ in range(5):
+        e0, e1 = ev(), ev()
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1) * 1e-3 / 10 / 5
+    a_flop, a_bytes = 3 * f_actor * mb, (4 * D + 4 + 4 + 4 + 8) * mb
+    out.append({"kernel": "ppo_actor_rows_kernel<3> (actor 48-128-128-5: forward + policy loss + backward in one launch)",
+                "rows": mb, "bound": "mfma", "flop_per_launch": a_flop, "us_per_launch": tot * 1e6,
+                "achieved": a_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": a_flop / tot / MFMA_F32_PEAK, "n_blocks": nb, "algorithmic_bytes_per_launch": a_bytes,
+                "slab_bytes_per_launch": nb * net.n_actor * 4, "traffic": pmc_traffic("ppo_actor_rows_kernel", nb * 512)})
+    return out
 
 
 def cpu_baseline(a):
@@ -527,6 +616,9 @@ def main():
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
         out.update(kernel_rooflines(a, algo, buf))
+        if world == 1 and not a.no_c3_grid:
+            del algo, buf, col, env  # (free the headline job's graphs before the 4096-env job is built)
+            out["roofline_grid"] += c3_rooflines(device)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))

@@ -394,6 +394,13 @@ typedef struct {
 } tsm_rollout_desc;
 
 int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *stream);
+/* The same collect loop for a 128-wide ACTOR (obs -> 128 -> 128 -> 5, e.g. BASELINE configs[2]: N = 8, actor
+ * 48-128-128-5 next to a centralized critic that does not fit a CU's LDS): desc.params = the actor's parameters
+ * (w0 b0 w1 b1 w2 b2), desc.hidden = 128, param_image unused; vs_store / vnext_store are NOT written -- the update
+ * computes V(obs) / V(obs_next) for all rows in two batched passes (a2c.py:121-127).  Everything else as
+ * tsm_rollout_spread; results are bit-identical to tsm_mlp_forward -> tsm_categorical_sample -> tsm_mpe_spread_step ->
+ * tsm_vrb_add step by step. */
+int tsm_rollout_spread_actor(const tsm_rollout_desc *desc, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched simple_tag (predator-prey, two teams)  [(f)1, BASELINE configs[4]]

@@ -119,7 +119,9 @@ def test_generic_ppo_rollout_and_update_on_device_env(glob, hidden):
     algo = GenericPPO(net=net, critic_input="global" if glob else "local", n_agent=N, shuffle="device", seed=2)
     buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=DEV)
     col = Collector(algo, env, buf)
-    assert not col._can_fuse()  # hidden 64 here too: the fused rollout is for the DiscreteActorCritic layout only
+    # a 128-wide actor rolls out in the actor-only persistent kernel (csrc/rollout_rows.hip); the 64-wide MLPActorCritic
+    # here does not (the 64-wide fused rollout is for the DiscreteActorCritic layout only)
+    assert col._can_fuse() == (hidden == (128, 128))
     col.reset()
     losses = []
     for _ in range(3):

@@ -83,3 +83,68 @@ def test_update_from_stored_rollout_outputs_equals_recomputed():
         res.append((net.flat.data.clone(), st.get_loss_stats_dict()))
     assert torch.equal(res[0][0], res[1][0])
     assert res[0][1] == res[1][1]
+
+
+# ---- the actor-only persistent rollout for 128-wide actors (csrc/rollout_rows.hip) ----
+def _job128(n_env, N, T, fused, glob, seed=3, slots=None):
+    from tianshou_marl_amd.algorithm import GenericPPO
+    from tianshou_marl_amd.utils.net import MLPActorCritic
+
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=seed)
+    net = MLPActorCritic(env.obs_dim, 5, (128, 128), critic_obs_dim=N * env.obs_dim if glob else None, device=DEV, seed=seed)
+    algo = GenericPPO(net=net, critic_input="global" if glob else "local", n_agent=N, seed=seed, shuffle="numpy",
+                      dispatch="pooled")
+    buf = DeviceVectorReplayBuffer(n_env * (slots or T), n_env, N, env.obs_dim, device=DEV)
+    col = Collector(algo, env, buf, fused_rollout=fused, use_graph=False)
+    col.reset()
+    return env, net, algo, buf, col
+
+
+# (600, 8): 38 workgroups of 16 envs; (50, 3): 42 envs per workgroup, 126 live rows (partial last tile); (4096, 8): the
+# BASELINE configs[2] size, one workgroup per CU
+@pytest.mark.parametrize("n_env,N,T,steps,glob", [(600, 8, 4, 6, True), (50, 3, 6, 15, False), (5, 1, 4, 9, False),
+                                                  (33, 8, 25, 25, True), (4096, 8, 25, 25, True)])
+def test_actor_rollout_is_bit_identical_to_unfused(n_env, N, T, steps, glob):
+    slots = steps + 3 + 1
+    outs = []
+    for fused in (False, True):
+        env, net, algo, buf, col = _job128(n_env, N, T, fused, glob, slots=slots)
+        assert col._can_fuse() == fused and col._can_fuse_actor() == fused
+        with policy_within_training_step(algo):
+            st1 = col.collect(n_step=n_env * steps)
+            st2 = col.collect(n_step=n_env * 3)
+        outs.append(dict(
+            obs=buf.obs_store.clone(), obs_next=buf.obs_next_store.clone(), act=buf.act_store.clone(),
+            rew=buf.rew_store.clone(), trunc=buf.trunc_store.clone(), term=buf.term_store.clone(),
+            logp=buf.logp_store.clone(), done=buf.done_store.clone(), state=buf.index.state.clone(),
+            apos=env.agent_pos.clone(), avel=env.agent_vel.clone(), lpos=env.landmark_pos.clone(), steps=env.steps.clone(),
+            ep=env.episode_ctr.clone(), obs_cur=env.obs_cur.clone(), tick=env.rng_tick.clone(), ret1=st1.returns,
+            len1=st1.lens, n1=st1.n_collected_episodes, ret2=st2.returns, n2=st2.n_collected_episodes))
+        # logp is the acting policy's in both paths; only the unfused path also stored V(obs)
+        assert buf.logp_outputs_version == algo.param_version
+        assert buf.behaviour_outputs_version == (None if fused else algo.param_version)
+    a, b = outs
+    for k in a:
+        if isinstance(a[k], torch.Tensor):
+            assert torch.equal(a[k], b[k]), k
+        elif isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+
+
+def test_update_after_actor_rollout_equals_update_after_unfused_collect():
+    """The update recomputes V(obs) itself after the actor-only rollout and takes logp_old from the buffer: same weights
+    as after the unfused collect (which stored both)."""
+    res = []
+    for fused in (False, True):
+        env, net, algo, buf, col = _job128(64, 8, 25, fused, True)
+        np.random.seed(2)
+        for _ in range(3):
+            with policy_within_training_step(algo):
+                col.collect(n_step=64 * 25)
+                st = algo.update(buf, 512 * 8, 2)
+            col.reset_buffer(keep_statistics=True)
+        res.append((net.flat.data.clone(), st.get_loss_stats_dict()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1]

@@ -130,6 +130,7 @@ SIGNATURES = {
     "tsm_mpe_spread_step": (_int, [C.POINTER(tsm_mpe_cfg), _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                    _int, _p, _u64, _p]),
     "tsm_rollout_spread": (_int, [C.POINTER(tsm_rollout_desc), _p]),
+    "tsm_rollout_spread_actor": (_int, [C.POINTER(tsm_rollout_desc), _p]),
     "tsm_mpe_tag_obs_dim": (_int, [C.POINTER(tsm_mpe_tag_cfg)]),
     "tsm_mpe_tag_reset": (_int, [C.POINTER(tsm_mpe_tag_cfg), _u64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "tsm_mpe_tag_step": (_int, [C.POINTER(tsm_mpe_tag_cfg), _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,

@@ -31,7 +31,8 @@ from .ppo import PPO, ref_order_rows
 
 class GenericPPO(PPO):
     def __init__(self, *, net: MLPActorCritic | None = None, critic_input: Literal["local", "global"] | None = None,
-                 n_agent: int | None = None, graph: bool = True, fused_actor: bool = True, **kwargs) -> None:
+                 n_agent: int | None = None, graph: bool = True, fused_actor: bool = True,
+                 reuse_rollout_outputs: bool = True, **kwargs) -> None:
         if net is None and kwargs.get("policy") is not None:  # reference-style construction (see PPO.__new__)
             from ..utils.net import net_from_reference_modules
 
@@ -57,7 +58,8 @@ class GenericPPO(PPO):
                                                 self.ent_coef, loss_kind=2, value_group=vg) for vg in (1, self.n_agent)}
         self.fused_actor = bool(fused_actor) and ops.ppo_actor_rows_supported(net.obs_dim, net.actor.dims[1:-1], net.n_act,
                                                                               net.actor.act)
-        self._ctor.update(fused_actor=fused_actor)
+        self.reuse_rollout_outputs = bool(reuse_rollout_outputs)
+        self._ctor.update(fused_actor=fused_actor, reuse_rollout_outputs=reuse_rollout_outputs)
 
     # ---- helpers --------------------------------------------------------------------------------------------------
     @property
@@ -95,7 +97,8 @@ class GenericPPO(PPO):
         return dict(act=act, logp=logp, value=value, logits=logits)
 
     # ---- update side ------------------------------------------------------------------------------------------------
-    def _preprocess_batch(self, buffer: DeviceVectorReplayBuffer, uniform_T: int | None = None) -> dict:
+    def _preprocess_batch(self, buffer: DeviceVectorReplayBuffer, uniform_T: int | None = None,
+                          allow_stored: bool = True) -> dict:
         # uniform_T: every sub-buffer holds exactly T unrotated rows (known on the host): no device round trip, so the
         # pass can be captured into a hipGraph
         T, rows, env_start, env_len = (uniform_T, None, None, None) if uniform_T else self._valid_rows(buffer)
@@ -111,10 +114,18 @@ class GenericPPO(PPO):
         glob = self.critic_input == "global"
         joint = buffer.obs_store[:T].reshape(T * B, N * D) if glob else None
         joint_next = buffer.obs_next_store[:T].reshape(T * B, N * D) if glob else None
-        v_s = self._values(obs, joint).view(T, L)
+        reuse = allow_stored and self.reuse_rollout_outputs and rows is None and buffer.logp_store is not None
+        # logp_old / v_s produced by the rollout with these very parameters (same kernels, row-wise arithmetic: the same bits
+        # as recomputing them, a2c.py:121-127 / ppo.py:157-161) are taken from the buffer
+        if reuse and buffer.behaviour_outputs_version == self.param_version:
+            v_s = buffer.vs_store[:T].reshape(T, L)
+        else:
+            v_s = self._values(obs, joint).view(T, L)
+        if reuse and buffer.logp_outputs_version == self.param_version:
+            logp_old = buffer.logp_store[:T].reshape(T * L)
+        else:
+            logp_old, _ = ops.categorical_logp_entropy(FlatMLP.forward(self.net.actor, obs, save=False), act)
         v_next = self._values(obs_next, joint_next).view(T, L)
-        logits = FlatMLP.forward(self.net.actor, obs, save=False)
-        logp_old, _ = ops.categorical_logp_entropy(logits, act)
         ret, adv = self._gae(v_s, v_next, buffer.rew_store[:T].reshape(T, L), buffer.term_store[:T].reshape(T, L),
                              buffer.trunc_store[:T].reshape(T, L), N, env_start=env_start, env_len=env_len, rows=rows)
         return dict(T=T, rows=rows, obs=obs, act=act, v_s=v_s.reshape(-1).contiguous(), ret=ret.reshape(-1),
@@ -238,7 +249,9 @@ class GenericPPO(PPO):
         per_agent = self.dispatch == "per_agent"
         groups, n_g, bounds, unit = self._plan(T * B, N, batch_size)
         row_mode = unit > 1
-        key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm)
+        stored = (self.reuse_rollout_outputs, buffer.behaviour_outputs_version == self.param_version,
+                  buffer.logp_outputs_version == self.param_version)
+        key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored)
         w = self._ws.get(key)
         if w is None:  # first update of this shape runs eagerly (one-time kernel attributes, allocator warm-up)
             self._ws[key] = {}
@@ -341,7 +354,7 @@ class GenericPPO(PPO):
         scal = []
         for step in range(repeat):
             if self.recompute_adv and step > 0:
-                pb = dict(self._preprocess_batch(buffer), logp_old=pb["logp_old"])
+                pb = dict(self._preprocess_batch(buffer, allow_stored=False), logp_old=pb["logp_old"])
             if self.shuffle == "numpy":
                 perm_local = torch.as_tensor(np.random.permutation(n)).to(dev)
             else:

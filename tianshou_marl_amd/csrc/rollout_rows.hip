@@ -1,0 +1,427 @@
+// rollout_rows.hip -- persistent rollout for a 128-wide ACTOR on batched simple_spread: the whole Collector loop of one
+// collect(n_step) call in ONE launch (BASELINE configs[2]: N = 8 agents, actor 48-128-128-5, 4096 envs).
+//
+// Same job as rollout.hip (policy forward + Categorical sample / log-prob, env.step of every env + reset of finished
+// envs, buffer.add index algebra + payload scatter: /root/reference/tianshou/data/collector.py:854-1069,
+// modelfree/reinforce.py:167-192, env/venvs.py:237-322, data/buffer/manager.py:131-193), for policies whose nets do not
+// fit the 64-wide actor+critic tile of rollout.hip.  Only the ACTOR runs inside the rollout: a centralized critic's
+// first layer alone (384 x 128 f32 = 192 KB) exceeds a CU's LDS, and the update needs the critic values of all rows in
+// one batch anyway (a2c.py:121-127), so V(obs) / V(obs_next) are computed there by two large GEMM passes instead of 2 x 25
+// small ones here.
+//
+// gfx950 mapping.  A workgroup (512 threads, one per CU) owns EPB = 128 / N whole environments for all T steps: the
+// actor's weights are staged in LDS once (~100 KB), the env state (positions, velocities, landmarks) lives in LDS, and
+// only buffer rows travel to HBM.  Per vector step the workgroup's rows are processed as tiles of 32 samples through the
+// three layers on v_mfma_f32_16x16x4_f32 with the k order of csrc/dense.hip, so logits -- hence sampled actions and
+// log-probs (Philox counter = offset + step * n_env * N + env * N + agent, arithmetic of categorical.hip) -- are
+// bit-identical to the unfused sequence tsm_mlp_forward -> tsm_categorical_sample -> tsm_mpe_spread_step -> tsm_vrb_add.
+#include "common.h"
+#include "mpe_dev.h"
+#include "philox.h"
+#include "vrb_dev.h"
+
+int tsm_mpe_check_cfg(const tsm_mpe_cfg *h, MpeCfg *c);  // mpe.hip
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kH = 128, kTile = 32, kThreads = 512, kLdh = kH + 2, kLdo = 18, kRowsWg = 128;
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+struct RrLay {  // LDS layout in floats
+    int nJ, ld1, W1, W2, W3, B1, B2, B3, X, H1, H2, LG, AP, AV, LP, REW, LOGP, MIN, ACT, STEPS, DONE, ROW, EP, total;
+    __host__ __device__ explicit RrLay(int D) {
+        nJ = (D + 15) / 16;
+        ld1 = 16 * nJ + 2;
+        int o = 0;
+        W1 = o; o += kH * ld1;
+        W2 = o; o += kH * kLdh;
+        W3 = o; o += 16 * kLdh;
+        B1 = o; o += kH;
+        B2 = o; o += kH;
+        B3 = o; o += 16;
+        X = o; o += kTile * ld1;
+        H1 = o; o += kTile * kLdh;
+        H2 = o; o += kTile * kLdh;
+        LG = o; o += kTile * kLdo;
+        AP = o; o += kRowsWg * 2;
+        AV = o; o += kRowsWg * 2;
+        LP = o; o += kRowsWg * 2;
+        REW = o; o += kRowsWg;
+        LOGP = o; o += kRowsWg;
+        MIN = o; o += kRowsWg;
+        ACT = o; o += kRowsWg;      // int
+        STEPS = o; o += kRowsWg;    // int  [EPB]
+        DONE = o; o += kRowsWg;     // int  [EPB]
+        o = (o + 1) & ~1;
+        ROW = o; o += 2 * kRowsWg;  // int64 [EPB]
+        EP = o; o += 2 * kRowsWg;   // uint64 [EPB]
+        total = o;
+    }
+};
+
+struct RrArgs {
+    const float *P;  // actor parameters w0[H][D] b0[H] w1[H][H] b1[H] w2[A][H] b2[A]
+    int D, A, mode;
+    uint64_t pol_seed, offset;
+    const uint64_t *offset_dev;
+    MpeCfg c;
+    uint64_t env_seed;
+    uint64_t *episode_ctr;
+    float *apos, *avel, *lpos;
+    int32_t *steps;
+    int auto_reset;
+    float *obs_cur_out;
+    void *vrb_state;
+    int64_t S;
+    uint8_t *done_store;
+    float *obs_store, *obs_next_store, *rew_store, *logp_store;
+    int32_t *act_store;
+    uint8_t *term_store, *trunc_store;
+    int64_t *ptr_out, *ep_len_out, *ep_idx_out;
+    double *ep_rew_out;
+    int n_steps;
+    int64_t *ep_rec;
+    int max_ep;
+    uint64_t offset_inc;
+    uint64_t *offset_dev_rw;
+    uint32_t *done_ctr;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MpeCfg c = a.c;
+    const RrLay ly(a.D);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+    const int N = c.N, D = a.D, A = a.A, ld1 = ly.ld1, st = 2 * N;
+    const int EPB = kRowsWg / N;
+    const int e0 = blockIdx.x * EPB;
+    const int n_here = min(EPB, c.n_env - e0);
+    const int rows_here = n_here * N;
+    const int n_tiles = (rows_here + kTile - 1) / kTile;
+    const int64_t B = c.n_env;
+    float *s_ap = lds + ly.AP, *s_av = lds + ly.AV, *s_lp = lds + ly.LP, *s_rew = lds + ly.REW, *s_logp = lds + ly.LOGP,
+          *s_m = lds + ly.MIN;
+    int *s_act = reinterpret_cast<int *>(lds + ly.ACT), *s_steps = reinterpret_cast<int *>(lds + ly.STEPS),
+        *s_done = reinterpret_cast<int *>(lds + ly.DONE);
+    int64_t *s_row = reinterpret_cast<int64_t *>(lds + ly.ROW);
+    uint64_t *s_ep = reinterpret_cast<uint64_t *>(lds + ly.EP);
+
+    // ---- weights into LDS once (zero pads: W1 columns >= D, W3 rows >= A) ----
+    const int oB1 = kH * D, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + A * kH;
+    for (int e = tid; e < kH * ld1; e += kThreads) {
+        const int r = e / ld1, cc = e - r * ld1;
+        lds[ly.W1 + e] = cc < D ? a.P[r * D + cc] : 0.f;
+    }
+    for (int e = tid; e < kH * kLdh; e += kThreads) {
+        const int r = e / kLdh, cc = e - r * kLdh;
+        lds[ly.W2 + e] = cc < kH ? a.P[oW2 + r * kH + cc] : 0.f;
+    }
+    for (int e = tid; e < 16 * kLdh; e += kThreads) {
+        const int r = e / kLdh, cc = e - r * kLdh;
+        lds[ly.W3 + e] = (r < A && cc < kH) ? a.P[oW3 + r * kH + cc] : 0.f;
+    }
+    if (tid < kH) { lds[ly.B1 + tid] = a.P[oB1 + tid]; lds[ly.B2 + tid] = a.P[oB2 + tid]; }
+    if (tid < 16) lds[ly.B3 + tid] = tid < A ? a.P[oB3 + tid] : 0.f;
+    for (int i = tid; i < kTile * ld1; i += kThreads) lds[ly.X + i] = 0.f;
+
+    const VrbState vs = vrb_view(a.vrb_state, B, N);
+    // agent lane r (threads 0..127) <-> (env el, agent ai); env lane (threads 128..128+EPB) owns env bel's bookkeeping
+    const int r = tid, el = r / N, ai = r - el * N;
+    const bool lane_live = r < rows_here;
+    const int e = e0 + el;
+    const int bel = tid - kRowsWg;
+    const bool env_lane = bel >= 0 && bel < n_here;
+    const int be = e0 + bel;
+    int64_t v_ins = 0, v_size = 0, v_eplen = 0, v_epstart = 0, v_last = 0;
+    int n_fin = 0;
+    double v_epret[kMpeMaxN];
+#pragma unroll
+    for (int k = 0; k < kMpeMaxN; ++k) v_epret[k] = 0.0;
+    if (env_lane) {
+        v_ins = vs.ins[be]; v_size = vs.size[be]; v_eplen = vs.ep_len[be]; v_epstart = vs.ep_start[be];
+        v_last = vs.last_index[be];
+#pragma unroll
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) v_epret[k] = vs.ep_return[(int64_t)be * N + k];
+        s_steps[bel] = a.steps[be];
+        s_done[bel] = 0;
+        s_row[bel] = 0;
+    }
+    for (int i = tid; i < n_here * st; i += kThreads) {
+        s_ap[i] = a.apos[(int64_t)e0 * st + i];
+        s_av[i] = a.avel[(int64_t)e0 * st + i];
+        s_lp[i] = a.lpos[(int64_t)e0 * st + i];
+    }
+    const uint64_t off0 = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
+    __syncthreads();
+
+    for (int t = 0; t < a.n_steps; ++t) {
+        // ---- A. buffer index algebra of this step on the env lanes (buffer_base.py:373-410 + manager.py:170-177; same
+        //         arithmetic as vrb_add_row): the slot of the row is known before the payload exists ----
+        bool tr = false, rec = false;
+        int64_t o = 0;
+        if (env_lane) {
+            const int stp = s_steps[bel] + 1;
+            tr = stp >= c.max_cycles;
+            s_steps[bel] = stp;
+            o = (int64_t)t * B + be;
+            const int64_t cur = v_ins;
+            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
+            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
+            const int64_t elen = v_eplen + 1;
+            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
+            rec = tr && a.ep_rec && n_fin < a.max_ep;
+            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | elen;
+            a.ep_len_out[o] = tr ? elen : 0;
+            a.ptr_out[o] = cur + (int64_t)be * a.S;
+            a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
+            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
+            v_last = cur + (int64_t)be * a.S;
+            a.done_store[cur * B + be] = tr ? 1 : 0;
+            s_row[bel] = cur * B + be;
+            s_done[bel] = tr ? 1 : 0;
+        }
+        __syncthreads();
+        // ---- B. per 32-row tile: observation rows from the LDS-resident state (also the buffer's obs rows), actor
+        //         forward, Categorical head ----
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const int r0 = tile * kTile;
+            for (int i = tid; i < kTile * D; i += kThreads) {
+                const int rr = i / D, k = i - rr * D, gr = r0 + rr;
+                float v = 0.f;
+                if (gr < rows_here) {
+                    const int ee = gr / N;
+                    v = mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, gr - ee * N, k);
+                    a.obs_store[(s_row[ee] * N + (gr - ee * N)) * D + k] = v;
+                }
+                lds[ly.X + rr * ld1 + k] = v;
+            }
+            __syncthreads();
+            const int col = 16 * w + c16;
+            {   // H1 = relu(X W1^T + b1)
+                f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+                const float *pa = lds + ly.X + c16 * ld1 + kq;
+                const float *pb = lds + ly.W1 + col * ld1 + kq;
+#pragma unroll
+                for (int k0 = 0; k0 < 16 * NJ; k0 += 4) {
+                    const float bv = pb[k0];
+                    acc[0] = mfma4(pa[k0], bv, acc[0]);
+                    acc[1] = mfma4(pa[16 * ld1 + k0], bv, acc[1]);
+                }
+                const float bb = lds[ly.B1 + col];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = acc[mt][q] + bb;
+                        lds[ly.H1 + (mt * 16 + kq * 4 + q) * kLdh + col] = v > 0.f ? v : 0.f;
+                    }
+            }
+            __syncthreads();
+            {   // H2 = relu(H1 W2^T + b2)
+                f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+                const float *pa = lds + ly.H1 + c16 * kLdh + kq;
+                const float *pb = lds + ly.W2 + col * kLdh + kq;
+#pragma unroll
+                for (int k0 = 0; k0 < kH; k0 += 4) {
+                    const float bv = pb[k0];
+                    acc[0] = mfma4(pa[k0], bv, acc[0]);
+                    acc[1] = mfma4(pa[16 * kLdh + k0], bv, acc[1]);
+                }
+                const float bb = lds[ly.B2 + col];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = acc[mt][q] + bb;
+                        lds[ly.H2 + (mt * 16 + kq * 4 + q) * kLdh + col] = v > 0.f ? v : 0.f;
+                    }
+            }
+            __syncthreads();
+            if (w < 2) {  // logits (A padded to 16): waves 0 / 1 take the two row halves
+                f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+                const float *pa = lds + ly.H2 + (16 * w + c16) * kLdh + kq;
+                const float *pb = lds + ly.W3 + c16 * kLdh + kq;
+#pragma unroll
+                for (int k0 = 0; k0 < kH; k0 += 4) acc = mfma4(pa[k0], pb[k0], acc);
+                const float bb = lds[ly.B3 + c16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lds[ly.LG + (16 * w + kq * 4 + q) * kLdo + c16] = acc[q] + bb;
+            }
+            __syncthreads();
+            if (tid < kTile && r0 + tid < rows_here) {  // head: one lane per row, the arithmetic of categorical.hip
+                const float *lg = lds + ly.LG + tid * kLdo;
+                float m = -INFINITY;
+                int arg = 0;
+                for (int j = 0; j < A; ++j) { const float v = lg[j]; if (v > m) { m = v; arg = j; } }
+                float s = 0.f;
+                for (int j = 0; j < A; ++j) s += expf(lg[j] - m);
+                const float lse = m + logf(s);
+                int act = arg;
+                if (a.mode == 1) {
+                    const uint64_t gi = (uint64_t)e0 * N + (uint64_t)(r0 + tid);  // global row env * N + agent
+                    const float u = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)t * B * N + gi) * s;
+                    float cs = 0.f;
+                    act = A - 1;
+                    for (int j = 0; j < A; ++j) {
+                        cs += expf(lg[j] - m);
+                        if (u < cs) { act = j; break; }
+                    }
+                }
+                s_act[r0 + tid] = act;
+                s_logp[r0 + tid] = lg[act] - lse;
+            }
+            // (the barrier after the next tile's observation build, or the one below, orders LG / X reuse)
+            __syncthreads();
+        }
+        // ---- C. env step, one lane per agent (mpe_dev.h): move -> publish -> reward terms ----
+        float npx = 0.f, npy = 0.f, nvx = 0.f, nvy = 0.f;
+        if (lane_live) mpe_agent_move(c, s_ap + el * st, s_av + el * st, ai, s_act[r], npx, npy, nvx, nvy);
+        __syncthreads();
+        if (lane_live) {
+            s_ap[el * st + 2 * ai] = npx; s_ap[el * st + 2 * ai + 1] = npy;
+            s_av[el * st + 2 * ai] = nvx; s_av[el * st + 2 * ai + 1] = nvy;
+        }
+        __syncthreads();
+        float local = 0.f;
+        if (lane_live) {
+            const MpePos pos = mpe_load_pos(c, s_ap + el * st);
+            s_m[r] = mpe_landmark_min_dist(c, pos, s_lp + el * st, ai);
+            local = mpe_local_penalty(c, pos, s_ap + el * st, ai);
+        }
+        // obs_next rows (the terminal observation for finished episodes) straight into the buffer
+        if (a.obs_next_store)
+            for (int i = tid; i < rows_here * D; i += kThreads) {
+                const int rr = i / D, k = i - rr * D, ee = rr / N;
+                a.obs_next_store[(s_row[ee] * N + (rr - ee * N)) * D + k] =
+                    mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
+            }
+        __syncthreads();
+        if (lane_live) s_rew[r] = mpe_reward(c, s_m + el * N, local);
+        __syncthreads();
+        if (env_lane) {  // episode returns
+            double *rec_rew = rec ? reinterpret_cast<double *>(a.ep_rec + B + (int64_t)B * a.max_ep) +
+                                        ((int64_t)be * a.max_ep + n_fin) * N : nullptr;
+#pragma unroll
+            for (int k = 0; k < kMpeMaxN; ++k) {
+                if (k < N) {
+                    const double acc = v_epret[k] + (double)s_rew[bel * N + k];
+                    a.ep_rew_out[o * N + k] = tr ? acc : 0.0;
+                    if (rec) rec_rew[k] = acc;
+                    v_epret[k] = tr ? 0.0 : acc;
+                }
+            }
+            n_fin += tr ? 1 : 0;
+        }
+        if (lane_live) {
+            const int64_t dst = s_row[el] * N + ai;
+            a.act_store[dst] = s_act[r];
+            a.rew_store[dst] = s_rew[r];
+            a.term_store[dst] = 0;
+            a.trunc_store[dst] = (uint8_t)s_done[el];
+            if (a.logp_store) a.logp_store[dst] = s_logp[r];
+        }
+        // ---- D. finished episodes: re-initialise the env (the next step's observation build sees the new state) ----
+        if (a.auto_reset) {
+            if (env_lane && s_done[bel]) {
+                const uint64_t ep = a.episode_ctr[be];
+                s_ep[bel] = ep;
+                a.episode_ctr[be] = ep + 1;
+                s_steps[bel] = 0;
+            }
+            __syncthreads();
+            if (lane_live && s_done[el])
+                mpe_reset_agent(c, e, a.env_seed, s_ep[el], ai, s_ap + el * st, s_av + el * st, s_lp + el * st);
+        }
+        __syncthreads();
+    }
+    // the observation of the next collect() call, env state and sub-buffer bookkeeping back to HBM
+    if (a.obs_cur_out)
+        for (int i = tid; i < rows_here * D; i += kThreads) {
+            const int rr = i / D, k = i - rr * D, ee = rr / N;
+            a.obs_cur_out[((int64_t)e0 * N + rr) * D + k] =
+                mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
+        }
+    for (int i = tid; i < n_here * st; i += kThreads) {
+        a.apos[(int64_t)e0 * st + i] = s_ap[i];
+        a.avel[(int64_t)e0 * st + i] = s_av[i];
+        a.lpos[(int64_t)e0 * st + i] = s_lp[i];
+    }
+    if (env_lane) {
+        a.steps[be] = s_steps[bel];
+        vs.ins[be] = v_ins; vs.size[be] = v_size; vs.ep_len[be] = v_eplen; vs.ep_start[be] = v_epstart;
+        vs.last_index[be] = v_last; vs.lengths[be] = v_size;
+        if (a.ep_rec) a.ep_rec[be] = n_fin;
+#pragma unroll
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) vs.ep_return[(int64_t)be * N + k] = v_epret[k];
+    }
+    if (a.done_ctr && tid == 0) {  // the last workgroup advances the sampling counter (every one has read it)
+        if (atomicAdd(a.done_ctr, 1u) == gridDim.x - 1) {
+            *a.offset_dev_rw += a.offset_inc;
+            *a.done_ctr = 0u;
+        }
+    }
+}
+
+}  // namespace
+
+// Same descriptor as tsm_rollout_spread; `params` = the ACTOR's parameters (hidden == 128), vs_store / vnext_store are
+// not written (the critic does not run inside this rollout).
+TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void *stream) {
+    TSM_REQUIRE(desc_host, "tsm_rollout_spread_actor: null descriptor");
+    const tsm_rollout_desc &h = *desc_host;
+    RrArgs a{};
+    if (int rc = tsm_mpe_check_cfg(&h.env, &a.c)) return rc;
+    TSM_REQUIRE(h.hidden == kH, "tsm_rollout_spread_actor: hidden must be 128 (got %d)", h.hidden);
+    TSM_REQUIRE(a.c.obs_dim == h.obs_dim && h.obs_dim <= 64, "tsm_rollout_spread_actor: obs_dim %d != 6 * n_agent (<= 64)", h.obs_dim);
+    TSM_REQUIRE(h.n_act == 5, "tsm_rollout_spread_actor: simple_spread has 5 discrete actions");
+    TSM_REQUIRE(a.c.N >= 1 && a.c.N <= kMpeMaxN, "tsm_rollout_spread_actor: n_agent out of range");
+    TSM_REQUIRE(h.n_steps >= 1 && h.sub_size >= 1, "tsm_rollout_spread_actor: bad n_steps / sub_size");
+    TSM_REQUIRE(h.mode == 1 || h.mode == 2, "tsm_rollout_spread_actor: mode must be 1 (sample) or 2 (argmax)");
+    TSM_REQUIRE(h.params && h.episode_ctr && h.agent_pos && h.agent_vel && h.landmark_pos && h.steps && h.vrb_state &&
+                    h.done_store && h.obs_store && h.act_store && h.rew_store && h.term_store && h.trunc_store && h.ptr_out &&
+                    h.ep_rew_out && h.ep_len_out && h.ep_idx_out,
+                "tsm_rollout_spread_actor: null pointer");
+    TSM_REQUIRE(!h.ep_rec || h.max_ep >= 1, "tsm_rollout_spread_actor: ep_rec needs max_ep >= 1");
+    TSM_REQUIRE(!h.done_ctr || h.offset_dev, "tsm_rollout_spread_actor: done_ctr needs offset_dev");
+    a.P = h.params; a.D = h.obs_dim; a.A = h.n_act; a.mode = h.mode;
+    a.pol_seed = h.policy_seed; a.offset = h.offset; a.offset_dev = h.offset_dev;
+    a.env_seed = h.env_seed; a.episode_ctr = h.episode_ctr;
+    a.apos = h.agent_pos; a.avel = h.agent_vel; a.lpos = h.landmark_pos; a.steps = h.steps;
+    a.auto_reset = h.auto_reset; a.obs_cur_out = h.obs_cur_out;
+    a.vrb_state = h.vrb_state; a.S = h.sub_size; a.done_store = h.done_store;
+    a.obs_store = h.obs_store; a.obs_next_store = h.obs_next_store; a.rew_store = h.rew_store; a.logp_store = h.logp_store;
+    a.act_store = h.act_store; a.term_store = h.term_store; a.trunc_store = h.trunc_store;
+    a.ptr_out = h.ptr_out; a.ep_len_out = h.ep_len_out; a.ep_idx_out = h.ep_idx_out; a.ep_rew_out = h.ep_rew_out;
+    a.n_steps = h.n_steps; a.ep_rec = h.ep_rec; a.max_ep = h.max_ep;
+    a.offset_inc = h.offset_inc; a.done_ctr = h.done_ctr;
+    a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
+    const RrLay ly(h.obs_dim);
+    const size_t shmem = (size_t)ly.total * sizeof(float);
+    TSM_REQUIRE(shmem <= 160 * 1024, "tsm_rollout_spread_actor: LDS layout of %zu bytes does not fit", shmem);
+    const int EPB = kRowsWg / a.c.N;
+    const unsigned n_wg = (unsigned)ceil_div(a.c.n_env, EPB);
+    static bool attr_set[4] = {false, false, false, false};
+    hipStream_t st = tsm_stream(stream);
+#define LAUNCH(NJ)                                                                                                     \
+    do {                                                                                                               \
+        if (!attr_set[NJ - 1]) {                                                                                       \
+            TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_rows_kernel<NJ>),                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
+            attr_set[NJ - 1] = true;                                                                                   \
+        }                                                                                                              \
+        hipLaunchKernelGGL((rollout_rows_kernel<NJ>), dim3(n_wg), dim3(kThreads), shmem, st, a);                       \
+    } while (0)
+    switch (ly.nJ) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}

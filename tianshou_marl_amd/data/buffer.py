@@ -52,6 +52,9 @@ class DeviceVectorReplayBuffer:
         # parameter version the stored logp / v_s / v_next of EVERY row were computed with:
         # "empty" (nothing stored yet), an int version, or None (mixed / incomplete -> the update recomputes them)
         self.policy_outputs_version = "empty"
+        # the same for logp / v_s alone (rows added by the unfused device collect path carry them but no V(obs_next))
+        self.behaviour_outputs_version = "empty"
+        self.logp_outputs_version = "empty"  # ... and for logp alone (the actor-only persistent rollout)
         self._host_rows: int | None = 0
         self._arange = torch.arange(self.maxsize, dtype=torch.int64, device=self.device)
 
@@ -77,6 +80,8 @@ class DeviceVectorReplayBuffer:
     def reset(self, keep_statistics: bool = False) -> None:
         self.index.reset(keep_statistics)
         self.policy_outputs_version = "empty"
+        self.behaviour_outputs_version = "empty"
+        self.logp_outputs_version = "empty"
         self._host_rows = 0
 
     # host-side mirror of "every sub-buffer received the same number of rows since reset" (saves the update a
@@ -91,6 +96,17 @@ class DeviceVectorReplayBuffer:
         if h is None or (h > self.sub_size and h % self.sub_size != 0):
             return None
         return min(h, self.sub_size)
+
+    def mark_behaviour_outputs(self, version) -> None:
+        """Called by a collect path whose every added row carried logp / v_s of the acting policy at `version`
+        (None: unknown / not stored)."""
+        cur = self.behaviour_outputs_version
+        self.behaviour_outputs_version = version if (version is not None and cur in ("empty", version)) else None
+        self.mark_logp_outputs(version)
+
+    def mark_logp_outputs(self, version) -> None:
+        cur = self.logp_outputs_version
+        self.logp_outputs_version = version if (version is not None and cur in ("empty", version)) else None
 
     def mark_policy_outputs(self, version: int) -> None:
         """Called by the fused rollout after it stored logp / v_s / v_next for every row it added."""
@@ -116,6 +132,10 @@ class DeviceVectorReplayBuffer:
         if v_s is not None and self.vs_store is not None:
             fields.append((v_s, self.vs_store))
         self.policy_outputs_version = None  # rows added without V(obs_next): the update recomputes critic passes
+        if logp is None or v_s is None or self.logp_store is None:
+            self.behaviour_outputs_version = None
+        if logp is None or self.logp_store is None:
+            self.logp_outputs_version = None
         if buffer_ids is None and rew.shape[0] == self.buffer_num:
             self.note_uniform_rows(1)
         else:

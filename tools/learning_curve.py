@@ -34,13 +34,22 @@ CONFIGS = {
     "retscale": dict(return_scaling=True),
     "vclip": dict(value_clip=True, max_grad_norm=0.5),
     "retscale_gradclip": dict(return_scaling=True, max_grad_norm=0.5),
+    "lr1e-4": dict(lr=1e-4),
+    "lr1e-4_gradclip": dict(lr=1e-4, max_grad_norm=0.5),
+    "lr1e-4_vclip_gradclip": dict(lr=1e-4, max_grad_norm=0.5, value_clip=True),
+    "lr5e-5_gradclip": dict(lr=5e-5, max_grad_norm=0.5),
+    "gamma095": dict(gamma=0.95),
+    "gamma095_gradclip": dict(gamma=0.95, max_grad_norm=0.5),
+    "gamma095_lr1e-4_gradclip": dict(gamma=0.95, lr=1e-4, max_grad_norm=0.5),
+    "retscale_lr1e-4_gradclip": dict(return_scaling=True, lr=1e-4, max_grad_norm=0.5),
 }
 
 
 def engine_curve(n_updates: int, every: int, **kw) -> list:
     env = DeviceSimpleSpreadVectorEnv(E, N, device=DEV, seed=1626)
     net = DiscreteActorCritic(env.obs_dim, 5, 64, device=DEV, seed=1626)
-    algo = PPO(net=net, lr=3e-4, dispatch="per_agent", shuffle="device", seed=1626, **kw)
+    kw = dict(kw)
+    algo = PPO(net=net, lr=kw.pop("lr", 3e-4), dispatch="per_agent", shuffle="device", seed=1626, **kw)
     buf = DeviceVectorReplayBuffer(E * T, E, N, env.obs_dim, device=DEV)
     col = Collector(algo, env, buf)
     col.reset()
@@ -67,12 +76,12 @@ def _mlp(d_in, d_out, seed):
     return net
 
 
-def replica_curve(n_updates: int, every: int, return_scaling=False, max_grad_norm=None, **_) -> list:
+def replica_curve(n_updates: int, every: int, return_scaling=False, max_grad_norm=None, lr=3e-4, gamma=0.99, **_) -> list:
     env = DeviceSimpleSpreadVectorEnv(E, N, device=DEV, seed=1626)
     D = env.obs_dim
     actor, critic = _mlp(D, 5, 1), _mlp(D, 1, 2)
     params = list(actor.parameters()) + list(critic.parameters())
-    opt = torch.optim.Adam(params, lr=3e-4)
+    opt = torch.optim.Adam(params, lr=lr)
     gen = torch.Generator(device=DEV).manual_seed(7)
     obs = env.reset_device().clone()
     ep_ret = torch.zeros(E, N, device=DEV, dtype=torch.float64)
@@ -83,7 +92,11 @@ def replica_curve(n_updates: int, every: int, return_scaling=False, max_grad_nor
         finished = []
         for _ in range(T):
             with torch.no_grad():
-                act = torch.multinomial(torch.softmax(actor(obs), -1).reshape(E * N, 5), 1, generator=gen).reshape(E, N)
+                probs = torch.softmax(actor(obs), -1).reshape(E * N, 5)
+                if not bool(torch.isfinite(probs).all()):  # the run has diverged to NaN: stop (multinomial would assert)
+                    out.append((i, float("nan"), float("nan"), float("nan")))
+                    return out
+                act = torch.multinomial(probs, 1, generator=gen).reshape(E, N)
             obs_next, rew, term, trunc, done = env.step_device(act.to(torch.int32))
             O.append(obs.clone()); O2.append(obs_next.clone()); Ac.append(act); R.append(rew.clone())  # noqa: E702
             Te.append(term.bool().clone()); Tr.append(trunc.bool().clone())  # noqa: E702
@@ -101,11 +114,11 @@ def replica_curve(n_updates: int, every: int, return_scaling=False, max_grad_nor
         v_s, v_n = v_s * scale, v_n * scale * (~Te)
         end = Te | Tr
         end[-1] = True                                                                # unfinished_index forcing
-        delta = R.double() + 0.99 * v_n - v_s
+        delta = R.double() + gamma * v_n - v_s
         adv = torch.zeros_like(delta)
         g = torch.zeros(E, N, device=DEV, dtype=torch.float64)
         for t in range(T - 1, -1, -1):
-            g = delta[t] + 0.99 * 0.95 * (~end[t]) * g
+            g = delta[t] + gamma * 0.95 * (~end[t]) * g
             adv[t] = g
         unnorm = adv + v_s
         ret = (unnorm / scale).float()
