@@ -301,24 +301,26 @@ def c3_rooflines(device):
     net = MLPActorCritic(D, A, (H, H), critic_obs_dim=N * D, device=device, seed=1626)
     algo = GenericPPO(net=net, critic_input="global", n_agent=N, lr=3e-4, shuffle="device", seed=1626, dispatch="pooled")
     buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=device)
-    col = Collector(algo, env, buf)
+    col = Collector(algo, env, buf, async_stats=True)
     col.reset()
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-    t_col = t_upd = 0.0
-    reps, warm = 5, 3  # (the 2nd update captures the graph)
+    cols, upds = [], []
+    reps, warm = 7, 4  # (the 2nd update captures the graph; the median keeps one-off runtime hiccups out of the figure)
     for i in range(warm + reps):
         e0, e1, e2 = ev(), ev(), ev()
         with policy_within_training_step(algo):
             e0.record()
-            col.collect(n_step=n_env * T)
+            cs = col.collect(n_step=n_env * T)
             e1.record()
             ts = algo.update(buf, mb, 1)
             e2.record()
         torch.cuda.synchronize()
+        _resolve(cs)
         col.reset_buffer(keep_statistics=True)
         if i >= warm:
-            t_col += e0.elapsed_time(e1) / reps
-            t_upd += e1.elapsed_time(e2) / reps
+            cols.append(e0.elapsed_time(e1))
+            upds.append(e1.elapsed_time(e2))
+    t_col, t_upd = sorted(cols)[reps // 2], sorted(upds)[reps // 2]
     rows, samples = n_env * T, n_env * T * N
     f_actor = 2 * (D * H + H * H + H * A)             # forward flops per sample
     f_critic = 2 * (N * D * H + H * H + H)            # forward flops per joint row
@@ -331,6 +333,7 @@ def c3_rooflines(device):
             "n_env": n_env, "n_agent": N, "T": T, "minibatch": mb, "bound": "mfma", "ms_per_update": t_upd,
             "flop_per_update": flop, "achieved": flop / (t_upd * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
             "unit": "TFLOP/s", "frac": flop / (t_upd * 1e-3) / MFMA_F32_PEAK, "collect_ms": t_col,
+            "ms_per_update_all": [round(x, 3) for x in upds],
             "env_steps_per_s": samples / ((t_col + t_upd) * 1e-3), "gradient_steps": ts.gradient_steps,
             "note": "flops as executed (the critic runs once per joint row); the per-lane critic of round 1 executed "
                     "%.0f GFLOP for the same update" % ((2 * rows * f_critic + samples * f_actor + 3 * samples * (f_actor + f_critic)) / 1e9)}]

@@ -169,11 +169,11 @@ def gae_legs(shapes=((25, 3072), (25, 32768)), budget_s=3.0, seed=0):
     """SURVEY 8(d) CPU legs for the scan alone, on the layouts the GPU kernel is timed on:
       serial     -- one thread walks every lane's series: the faithful analogue of the reference's single-core numba
                     `_gae` (algorithm_base.py:1079-1134);
-      all_cores  -- the same C loop with OpenMP over lanes on every host core (baseline-best).
+      all_cores  -- the same C loop with OpenMP over lanes on the host cores of one GPU's share (16; baseline-best).
     22 B per (lane, step) as for the GPU roofline (f32 in, f64 accumulate)."""
     rng = np.random.default_rng(seed)
     out = {}
-    n_thr = os.cpu_count() or 1
+    n_thr = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU (more threads than that only add fork/join cost)
     for T, L in shapes:
         v_s, v_n, rew = (rng.standard_normal((T, L)).astype(np.float32) for _ in range(3))
         term = rng.random((T, L)) < 0.01

@@ -1,0 +1,144 @@
+"""GPU tests (`-m gpu`) of the env-sharded data-parallel update with TWO real processes (`gloo` backend, both ranks on
+cuda:0 -- RCCL refuses two ranks on one device; the collective itself is the backend's business, everything around it is
+the product's): the real `PPO._update_with_batch` reduction order, `PPO.update` on two env shards, and the packed
+per-step all-reduce of two policy groups (`parallel.learn_lockstep`)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+D, A, H = 18, 5, 64
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _synthetic_pb(seed, n_env, T):
+    """A preprocessed batch as `_preprocess_batch` builds it, from seeded noise."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    n = n_env * T
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    return dict(T=T, rows=None, obs=r(n, D), act=torch.randint(0, A, (n,), device=DEV, generator=g, dtype=torch.int32), v_s=r(n),
+                ret=r(n), adv=r(n) * 2 + 0.3, logp_old=r(n) * 0.3 - 1.5, n_env=n_env, n_agent=1)
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import torch.distributed as dist
+
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.algorithm.multiagent import FlexibleMultiAgentPolicyManager, LeaguePlayTrainer
+    from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
+    from tianshou_marl_amd.data.batch import Batch
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.parallel import attach_data_parallel
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # ---- (1) one full-batch gradient step through the REAL update loop vs the averaged gradient by hand ----
+        net = DiscreteActorCritic(D, A, H, device=DEV, seed=10 + rank)  # replicas start different: attach broadcasts rank 0
+        algo = PPO(net=net, lr=1e-3, max_grad_norm=0.5, dispatch="pooled", shuffle="numpy", use_graph=False, seed=3)
+        attach_data_parallel(algo, dist)
+        assert algo.graph_collectives is False  # gloo: eager collectives, decided before any capture
+        p0 = net.flat.data.clone()
+        np.random.seed(5)
+        st = algo._update_with_batch(_synthetic_pb(100 + rank, 8, 25), None, 1)
+        assert st.gradient_steps == 1
+        if rank == 0:  # both shards' gradients on one process, mean, one Adam step
+            ref = DiscreteActorCritic(D, A, H, device=DEV, seed=10)
+            assert torch.equal(ref.flat.data, p0)
+            halves = []
+            for rk in range(world):
+                pb = _synthetic_pb(100 + rk, 8, 25)
+                np.random.seed(5)
+                perm = torch.as_tensor(np.random.permutation(200)).to(DEV)
+                ids = algo._sample_ids(pb, None)[perm]
+                stats = ops.ppo_adv_stats(pb["adv"], torch.tensor([0, 200], device=DEV), perm=ids)
+                slabs, _ = ops.ppo_update_fused(p0, pb["obs"], pb["act"], pb["logp_old"], pb["adv"], pb["ret"], algo._cfg, A, H,
+                                                adv_stats=stats[0], perm=ids)
+                halves.append(ops.reduce_slabs(slabs, scale=1.0 / world))
+            g = halves[0] + halves[1]
+            p_ref = p0.clone()
+            ops.adam_step(p_ref, g.view(1, -1), torch.zeros_like(p0), torch.zeros_like(p0), 1, lr=1e-3, max_grad_norm=0.5)
+            assert torch.equal(p_ref, net.flat.data)  # bit for bit: the update on the averaged gradient
+        # ---- (2) PPO.update on two env shards: replicas stay bit-identical over synced updates ----
+        env = DeviceSimpleSpreadVectorEnv(32, 3, device=DEV, seed=50 + rank)  # this rank's shard
+        buf = DeviceVectorReplayBuffer(32 * 25, 32, 3, D, device=DEV)
+        algo2 = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=20 + rank), lr=1e-3, dispatch="per_agent",
+                    shuffle="device", seed=7 + rank)
+        attach_data_parallel(algo2, dist)
+        col = Collector(algo2, env, buf)
+        col.reset()
+        for _ in range(3):
+            with policy_within_training_step(algo2):
+                col.collect(n_step=32 * 25)
+                ts = algo2.update(buf, 256, 2)
+            col.reset_buffer(keep_statistics=True)
+        assert all(np.isfinite(v) for v in ts.get_loss_stats_dict().values())
+        # ---- (3) two policy groups trained in one step: their gradients travel in ONE packed all-reduce per step ----
+        teams = {"adversaries": PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=30 + rank), use_graph=False, seed=1),
+                 "good": PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=40 + rank), use_graph=False, seed=2)}
+
+        class _Env:
+            agents = ["adversary_0", "adversary_1", "agent_0"]
+
+        mgr = FlexibleMultiAgentPolicyManager(teams, _Env(), mode="grouped",
+                                              agent_groups={"adversaries": _Env.agents[:2], "good": _Env.agents[2:]})
+        sync = attach_data_parallel(mgr, dist)
+        calls = []
+        orig = sync.all_reduce_sum_
+        sync.all_reduce_sum_ = lambda t: (calls.append(t.numel()), orig(t))[1]
+        g = torch.Generator().manual_seed(60 + rank)
+        mk = lambda n: Batch(obs=torch.randn(n, D, generator=g).numpy(), act=torch.randint(0, A, (n,), generator=g).numpy(),  # noqa: E731
+                             rew=torch.randn(n, generator=g).numpy(), obs_next=torch.randn(n, D, generator=g).numpy(),
+                             terminated=np.zeros(n, bool))
+        batch = Batch(adversaries=mk(300), good=mk(300))
+        lg = LeaguePlayTrainer(mgr, matchmaking="random")
+        np.random.seed(9)
+        out = lg.train_step(batch)
+        assert set(out) == {"adversaries", "good"} and all(np.isfinite(v["loss"]) for v in out.values())
+        P = teams["good"].net.flat.numel()
+        assert calls == [2 * P], calls  # one gradient step per group (full batch), ONE packed reduce for both
+        flats = torch.cat([net.flat.data, algo2.net.flat.data, teams["adversaries"].net.flat.data, teams["good"].net.flat.data])
+        np.save(os.path.join(out_dir, f"p{rank}.npy"), flats.cpu().numpy())
+        # ---- (4) unequal shards are refused instead of deadlocking ----
+        algo3 = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=1), dispatch="pooled", shuffle="numpy", use_graph=False)
+        attach_data_parallel(algo3, dist)
+        with pytest.raises(ValueError, match="disagree"):
+            algo3._update_with_batch(_synthetic_pb(1, 8 + 8 * rank, 25), 64, 1)  # 200 vs 400 rows -> 3 vs 6 minibatches
+    except BaseException:
+        import traceback
+
+        with open(os.path.join(out_dir, f"err{rank}.txt"), "w") as f:
+            traceback.print_exc(file=f)
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_data_parallel_update_on_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+
+    try:
+        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    except Exception:
+        for r in range(2):
+            f = tmp_path / f"err{r}.txt"
+            if f.exists():
+                print(f"---- rank {r} ----\n{f.read_text()}")
+        raise
+    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
+    assert np.array_equal(p0, p1) and np.isfinite(p0).all()  # every replica of every policy: the same bits on both ranks

@@ -61,6 +61,30 @@ class MATrainer:
             policy.train()
         return policy.learn(agent_batch)
 
+    def _learn_many(self, agent_ids, batch: Batch, with_global: bool = True) -> dict[str, Any]:
+        """`policy.learn(agent_batch)` for several agents / groups.  Data-parallel replicas whose policies share one
+        GradSync (parallel.attach_data_parallel(manager, dist)) run their updates in lock step so that the gradients of
+        all groups that train this step travel in ONE packed all-reduce per gradient step; otherwise one after the
+        other, exactly as the reference does (training_coordinator.py:118,154,336)."""
+        pairs = []
+        for agent_id in agent_ids:
+            policy = self._policy_of(agent_id)
+            if policy is None or agent_id not in batch:
+                continue
+            agent_batch = batch[agent_id]
+            if with_global:
+                _attach_global(batch, agent_batch)
+            pairs.append((agent_id, policy, agent_batch))
+        sync = getattr(self.policy_manager, "_grad_sync", None)
+        distinct = len({id(p) for _, p, _ in pairs}) == len(pairs)
+        if sync is not None and len(pairs) > 1 and distinct and all(
+                getattr(p, "_grad_sync", None) is sync and callable(getattr(p, "learn_steps", None)) for _, p, _ in pairs):
+            from ...parallel import learn_lockstep
+
+            out = learn_lockstep([p.learn_steps(b) for _, p, b in pairs], sync)
+            return {a: r for (a, _, _), r in zip(pairs, out)}
+        return {a: p.learn(b) for a, p, b in pairs}
+
     def _init_round_robin(self) -> None:
         if not hasattr(self, "current_agent_idx"):
             self.current_agent_idx = 0
@@ -88,11 +112,7 @@ class MATrainer:
         raise ValueError(f"Unknown training mode: {self.training_mode}")
 
     def _simultaneous_train(self, batch: Batch) -> dict[str, Any]:
-        losses = {}
-        for agent_id in self.policy_manager.policies:
-            if agent_id in batch:
-                losses[agent_id] = self.policy_manager.policies[agent_id].learn(_attach_global(batch, batch[agent_id]))
-        return losses
+        return self._learn_many([a for a in self.policy_manager.policies if a in batch], batch)
 
     def _sequential_train(self, batch: Batch) -> dict[str, Any]:
         self._init_round_robin()
@@ -149,15 +169,12 @@ class SimultaneousTrainer(MATrainer):
         self.step_count += 1
         pm = self.policy_manager
         agents = pm.agents if getattr(pm, "mode", None) == "shared" else list(pm.policies.keys())
-        losses = {}
-        for agent_id in agents:
-            if self.step_count % self.agent_train_freq.get(agent_id, 1) != 0:
-                continue
-            if agent_id in batch:
-                out = self._learn(agent_id, batch, with_global=True, set_train=True)
-                if out is not None:
-                    losses[agent_id] = out
-        return losses
+        due = [a for a in agents if self.step_count % self.agent_train_freq.get(a, 1) == 0 and a in batch]
+        for agent_id in due:
+            policy = self._policy_of(agent_id)
+            if policy is not None and hasattr(policy, "train"):
+                policy.train()
+        return self._learn_many(due, batch, with_global=True)
 
 
 class SequentialTrainer(MATrainer):
@@ -264,13 +281,13 @@ class LeaguePlayTrainer(MATrainer):
     def train_step(self, batch: Batch) -> dict[str, Any]:
         self.step_count += 1
         self.game_count += 1
-        losses = {}
-        for agent_id in self._make_match():
-            if agent_id in batch:
-                policy = self.policy_manager.policies[agent_id]
-                if hasattr(policy, "train"):
-                    policy.train()
-                losses[agent_id] = policy.learn(batch[agent_id])
+        match = [a for a in self._make_match() if a in batch]
+        for agent_id in match:
+            policy = self.policy_manager.policies[agent_id]
+            if hasattr(policy, "train"):
+                policy.train()
+        # the matched agents learn (training_coordinator.py:641); data-parallel replicas reduce them together
+        losses = self._learn_many(match, batch, with_global=False)
         if self.game_count % self.games_per_evaluation == 0:
             self._update_league()
         return losses

@@ -266,6 +266,15 @@ class PPO(nn.Module):
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
                            buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:
         """ppo.py:164-224 for one sample set (all lanes, or one agent's lanes under per-agent dispatch)."""
+        return drive_steps(self._update_steps(pb, batch_size, repeat, agent=agent, buffer=buffer), self._grad_sync)
+
+    def _update_steps(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
+                      buffer: DeviceVectorReplayBuffer | None = None):
+        """The minibatch loop as a generator: with data-parallel replicas it YIELDS the flat gradient of each gradient
+        step (already scaled by 1 / world) at the point where it has to be summed over the ranks, and continues with the
+        Adam step once the caller has reduced it in place.  `drive_steps` does that with one all-reduce per step;
+        `parallel.learn_lockstep` advances several policy groups together and packs their gradients into ONE buffer per
+        step.  Returns (StopIteration.value) the training statistics."""
         ids = self._sample_ids(pb, agent)
         n = ids.numel() if ids is not None else pb["obs"].shape[0]
         dev = self.device
@@ -307,7 +316,7 @@ class PPO(nn.Module):
                 if self._grad_sync is not None:  # env-sharded data parallel: ONE flat all-reduce (parallel.py)
                     flat_g = self._ws.setdefault("flat_grad", torch.empty_like(P))
                     ops.reduce_slabs(grads, out=flat_g, scale=1.0 / self._grad_sync.world)  # mean = sum of g_i / world
-                    self._grad_sync.all_reduce_sum_(flat_g)
+                    yield flat_g  # summed over the ranks by the driver, in place
                     grads = flat_g.view(1, -1)
                 ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr, lr_dev=self._lr_dev,
                               betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
@@ -589,9 +598,8 @@ class PPO(nn.Module):
         return self._update_with_batch(pb, batch_size, repeat, agent=None, buffer=buffer)
 
     # ---- `.learn(batch)` for the MARL trainers (training_coordinator.py:336) ----------------------
-    def learn(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
-        """One PPO pass on an explicit agent batch holding obs, act, rew, obs_next, terminated[, truncated].
-        Rows are one time-ordered lane (the reference's per-agent Batch); GAE treats the last row as end."""
+    def learn_steps(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs):
+        """`learn` as a generator of gradient synchronisation points (see `_update_steps`)."""
         dev = self.device
         t = lambda x, dt: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))).to(dev, dt).contiguous()  # noqa: E731
         self.net.sync_image()
@@ -608,9 +616,14 @@ class PPO(nn.Module):
                                  term, trunc, self.gamma, self.gae_lambda)
         pb = dict(T=n, rows=None, obs=obs, act=act, v_s=cur["value"], ret=ret.reshape(-1), adv=adv.reshape(-1),
                   logp_old=cur["logp"], n_env=1, n_agent=1)
-        st = self._update_with_batch(pb, batch_size, repeat)
+        st = yield from self._update_steps(pb, batch_size, repeat)
         return {"loss": st.loss.mean, "actor_loss": st.actor_loss.mean, "vf_loss": st.vf_loss.mean,
                 "ent_loss": st.ent_loss.mean}
+
+    def learn(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
+        """One PPO pass on an explicit agent batch holding obs, act, rew, obs_next, terminated[, truncated].
+        Rows are one time-ordered lane (the reference's per-agent Batch); GAE treats the last row as end."""
+        return drive_steps(self.learn_steps(batch, batch_size, repeat, **kwargs), self._grad_sync)
 
     def __deepcopy__(self, memo):
         """Snapshot for opponent pools (training_coordinator.py:481-494): parameters, optimizer state and counters are
@@ -701,6 +714,17 @@ class PPO(nn.Module):
 
     def run_training(self, params):
         return self.create_trainer(params).run()
+
+
+def drive_steps(gen, grad_sync):
+    """Run an `_update_steps` / `learn_steps` generator to its end: every yielded flat gradient is summed over the
+    data-parallel ranks in place (one all-reduce per gradient step).  Single-process jobs never yield."""
+    try:
+        while True:
+            flat_g = next(gen)
+            grad_sync.all_reduce_sum_(flat_g)
+    except StopIteration as stop:
+        return stop.value
 
 
 def ref_order_rows(T: int, B: int, device) -> torch.Tensor:

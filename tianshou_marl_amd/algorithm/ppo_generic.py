@@ -30,6 +30,8 @@ from .ppo import PPO, ref_order_rows
 
 
 class GenericPPO(PPO):
+    learn_steps = None  # (its gradient steps reduce inside `_grad_step`; no lock-step generator form)
+
     def __init__(self, *, net: MLPActorCritic | None = None, critic_input: Literal["local", "global"] | None = None,
                  n_agent: int | None = None, graph: bool = True, fused_actor: bool = True,
                  reuse_rollout_outputs: bool = True, **kwargs) -> None:

@@ -64,13 +64,65 @@ class GradSync:
         return t
 
 
+def learn_lockstep(jobs, sync: "GradSync") -> list:
+    """Advance several policies' updates (generators from `PPO.learn_steps` / `_update_steps`) gradient step by gradient
+    step.  The flat gradients that fall due at the same step -- one per policy GROUP that trains this step -- are packed
+    into ONE buffer and summed over the ranks with ONE all-reduce ("one reduce per policy group
+    that trained this step, packed in one buffer"), then handed back so that each group applies its own Adam step.
+    Every rank must submit the same groups in the same order.  Returns the generators' results in job order."""
+    results = [None] * len(jobs)
+    alive = dict(enumerate(jobs))
+    while alive:
+        due = {}
+        for i, g in list(alive.items()):
+            try:
+                due[i] = next(g)
+            except StopIteration as stop:
+                results[i] = stop.value
+                del alive[i]
+        if not due:
+            continue
+        flats = list(due.values())
+        if len(flats) == 1:
+            sync.all_reduce_sum_(flats[0])
+            continue
+        packed = torch.cat([f.reshape(-1) for f in flats])
+        sync.all_reduce_sum_(packed)
+        o = 0
+        for f in flats:
+            f.copy_(packed[o:o + f.numel()].view_as(f))
+            o += f.numel()
+    return results
+
+
 def attach_data_parallel(algo, dist, group=None) -> GradSync:
-    """Make `algo` (tianshou_marl_amd.algorithm.ppo.PPO) a data-parallel replica: parameters and optimizer
-    state are broadcast from rank 0, and every gradient step all-reduces the flat gradient."""
+    """Make `algo` a data-parallel replica: parameters and optimizer state are broadcast from rank 0, and every gradient
+    step all-reduces the flat gradient.  `algo` is a PPO-family algorithm, or a policy manager
+    (FlexibleMultiAgentPolicyManager: every distinct policy of `.policies` is attached to ONE shared GradSync, and the
+    MARL trainers then reduce the groups that train in a step together, `learn_lockstep`)."""
     sync = GradSync(dist, group)
+    if hasattr(algo, "policies") and not hasattr(algo, "net"):
+        seen = []
+        for pol in algo.policies.values():
+            if any(pol is q for q in seen) or not hasattr(pol, "net"):
+                continue
+            seen.append(pol)
+            sync.broadcast_(pol.net.flat.data)
+            sync.broadcast_(pol.exp_avg)
+            sync.broadcast_(pol.exp_avg_sq)
+            pol._grad_sync = sync
+            if hasattr(pol.net, "sync_image"):
+                pol.net.sync_image()
+            pol.graph_collectives = False  # the packed reduction is driven from the host: eager launches
+        if dist.get_backend(group) == "nccl" and seen:
+            sync._probe_device = seen[0].net.flat.device
+        algo._grad_sync = sync
+        return sync
     sync.broadcast_(algo.net.flat.data)
     sync.broadcast_(algo.exp_avg)
     sync.broadcast_(algo.exp_avg_sq)
+    if hasattr(algo.net, "sync_image"):
+        algo.net.sync_image()  # the padded LDS image is a cache of `flat`: refresh it behind the broadcast
     algo._grad_sync = sync
     if dist.get_backend(group) == "nccl":
         sync._probe_device = algo.net.flat.device
