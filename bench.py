@@ -52,7 +52,8 @@ def parse():
                     help="extended roofline_grid: the fused gradient step at a pooled 65 536-row minibatch and GAE at the "
                          "synthetic horizons T = 2048 and 256")
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU baseline sample (0 = the GPU job's --n-env)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ppo"],
+    ap.add_argument("--tag-envs", type=int, default=512, help="tag: simple_tag envs per GPU (BASELINE configs[4]: 4096 over 8 GPUs)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c3ppo", "tag"],
                     help="c2 (default, the headline line): simple_spread N=3 shared PPO; c3: N=8 CTDEPolicy, 4096 envs; "
                          "c3ppo: N=8 PPO with a centralized critic, 4096 envs")
     return ap.parse_args()
@@ -526,6 +527,83 @@ def run_c3ppo(a, device):
         "loss": d.get("agent_0/loss", d.get("loss"))}))
 
 
+def run_tag(a, device, rank, world, dist):
+    """`--workload tag` (BASELINE configs[4]): simple_tag (3 adversaries v 1 prey, 2 obstacles), grouped policies (one PPO
+    per team), league trainer -- per GPU `--tag-envs` worlds (512: 4096 over 8 GPUs), T = 25.  A step = collect + one
+    `LeaguePlayTrainer.train_step` in which both teams learn; with N > 1 the two teams' gradients travel in ONE packed
+    all-reduce per gradient step (parallel.learn_lockstep).  Weak scaling; value = env-steps/s over all ranks."""
+    from tianshou_marl_amd.algorithm.multiagent import FlexibleMultiAgentPolicyManager, LeaguePlayTrainer, agent_batches_from_buffer
+    from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe_tag import DeviceSimpleTagVectorEnv
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+    n_env, T = a.tag_envs, a.horizon
+    env = DeviceSimpleTagVectorEnv(n_env, device=device, seed=1626 + rank, max_cycles=T)
+    N = env.n_agent
+    mk = lambda s: PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=device, seed=s), seed=s + rank, lr=3e-4,  # noqa: E731
+                       shuffle="device", use_graph=False)
+    teams = {"adversaries": mk(1626), "good": mk(1627)}
+    mgr = FlexibleMultiAgentPolicyManager(teams, env, mode="grouped", agent_groups=env.agent_groups)
+    if dist is not None:
+        from tianshou_marl_amd.parallel import attach_data_parallel
+
+        attach_data_parallel(mgr, dist)
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=device)
+    col = Collector(mgr, env, buf)
+    col.reset()
+    trainer = LeaguePlayTrainer(mgr, matchmaking="random")
+    np.random.seed(1626)  # matchmaking draws must agree on every rank
+
+    def step():
+        with policy_within_training_step(mgr):
+            cs = col.collect(n_step=n_env * T)
+            batch = agent_batches_from_buffer(buf, env.agents)
+            batch["good"], batch["adversaries"] = batch["agent_0"], batch["adversary_0"]
+            losses = trainer.train_step(batch)
+        col.reset_buffer(keep_statistics=True)
+        return cs, losses
+
+    for _ in range(a.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cs, losses = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    replicas_identical = None
+    if dist is not None:
+        diff = torch.zeros(1, device=device)
+        for p in teams.values():
+            ref = p.net.flat.data.clone()
+            dist.broadcast(ref, src=0)
+            diff += 0.0 if torch.equal(ref, p.net.flat.data) else 1.0
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(diff.item() == 0.0)
+    if rank == 0:
+        out = {"metric": "env-steps/sec (n_env x n_agent) incl. league PPO update, simple_tag 3v1",
+               "value": n_env * N * T * world / (dt / a.steps), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "simple_tag_v3 3 adversaries + 1 prey, 2 obstacles, grouped PPO (one policy per team), "
+                                      "LeaguePlayTrainer, num_envs=%d per GPU, T=%d" % (n_env, T),
+                          "parallelism": "env-shard x%d, one packed gradient all-reduce per step for both teams" % world},
+               "losses": {k: float(v["loss"]) for k, v in losses.items()}}
+        if replicas_identical is not None:
+            out["replicas_identical"] = replicas_identical
+        print(json.dumps(out))
+
+
 def main():
     a = parse()
     if a.workload == "c3ppo":
@@ -567,6 +645,12 @@ def main():
             dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if a.workload == "tag":
+        run_tag(a, device, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     env, net, algo, buf, col = build_job(a, device, rank)
     if dist is not None:
         from tianshou_marl_amd.parallel import attach_data_parallel

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tianshou_marl_amd.parallel import GradSync, attach_data_parallel, shard_range
+from tianshou_marl_amd.parallel import GradSync, attach_data_parallel, learn_lockstep, shard_range
 
 
 def test_shard_range_partitions_every_env_once():
@@ -80,6 +80,29 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         g = (torch.full((9,), float(rank + 1)) + torch.arange(9)) / world
         sync.all_reduce_sum_(g)
         assert torch.allclose(g, torch.full((9,), (1 + world) / 2.0) + torch.arange(9), rtol=0, atol=1e-6)
+        # lock-step training of two policy groups (parallel.learn_lockstep): the flat gradients that fall due at the same
+        # gradient step are packed into ONE all-reduce; a group with more steps goes on alone.  Generators stand in for
+        # PPO.learn_steps: they yield rank-local gradients (pre-scaled by 1 / world) and read them back reduced.
+        reduces = []
+        orig = sync.all_reduce_sum_
+        sync.all_reduce_sum_ = lambda t: (reduces.append(t.numel()), orig(t))[1]
+
+        def group(n_param, n_steps, base):
+            seen = []
+            for k in range(n_steps):
+                g = torch.full((n_param,), (base + k) * (rank + 1) / world)
+                yield g
+                seen.append(g.clone())
+            return seen
+
+        got_a, got_b = learn_lockstep([group(5, 2, 1.0), group(7, 3, 10.0)], sync)
+        sync.all_reduce_sum_ = orig
+        assert reduces == [12, 12, 7]  # steps 1-2: both groups in one packed buffer; step 3: group b alone
+        mean_rank = (1 + world) / 2.0  # sum over ranks of (rank + 1) / world
+        for k, g in enumerate(got_a):
+            assert torch.allclose(g, torch.full((5,), (1.0 + k) * mean_rank))
+        for k, g in enumerate(got_b):
+            assert torch.allclose(g, torch.full((7,), (10.0 + k) * mean_rank))
         # every rank must take the same number of gradient steps per update (unequal env shards can split into a
         # different number of minibatches -> a different number of all-reduces -> deadlock): agreed values pass (and are
         # checked once), a disagreement raises on EVERY rank instead of hanging

@@ -81,6 +81,8 @@ class MATrainer:
                 getattr(p, "_grad_sync", None) is sync and callable(getattr(p, "learn_steps", None)) for _, p, _ in pairs):
             from ...parallel import learn_lockstep
 
+            pairs.sort(key=lambda t: str(t[0]))  # the packing order must not depend on a rank's matchmaking draw
+            sync.check_same([a for a, _, _ in pairs], "the policy groups that train in this step")
             out = learn_lockstep([p.learn_steps(b) for _, p, b in pairs], sync)
             return {a: r for (a, _, _), r in zip(pairs, out)}
         return {a: p.learn(b) for a, p, b in pairs}

@@ -59,6 +59,19 @@ class GradSync:
                 "number of gradient steps.")
         self._checked.add(key)
 
+    def check_same(self, names: list, what: str) -> None:
+        """Every rank must train the same policy groups in a step (random matchmaking has to be seeded identically on
+        all ranks): a stable 31-bit hash of the names is compared with one tiny all-reduce, every call (not cached -- a
+        rank that skipped the collective would hang the others)."""
+        import zlib
+
+        h = zlib.crc32("|".join(str(n) for n in names).encode()) & 0x7FFFFFFF
+        t = torch.tensor([h, -h], dtype=torch.int64, device=self._probe_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        if int(t[0].item()) != -int(t[1].item()):
+            raise ValueError(f"data-parallel ranks disagree on {what} (this rank: {list(names)}): seed the trainers' "
+                             "matchmaking identically on every rank")
+
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         self.dist.broadcast(t, src=src, group=self.group)
         return t
