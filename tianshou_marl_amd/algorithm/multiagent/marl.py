@@ -225,12 +225,74 @@ class MARLDispatcher:
         The reference slices the rows of each agent out of the flat buffer and temporarily swaps `buffer.rew`
         for that agent's reward column (:227-248); with joint-step lanes every agent's lane already carries
         its own reward/value stream, so one pass per distinct algorithm object covers all of its agents."""
+        if getattr(buffer, "aec", False):
+            return self._dispatch_process_aec(buffer)
         done: dict[int, dict] = {}
         results = {}
         for agent, algorithm in self.algorithms.items():
             if id(algorithm) not in done:
                 done[id(algorithm)] = algorithm._preprocess_batch(buffer)
             results[agent] = done[id(algorithm)]
+        return results
+
+    # ---- AEC rows (DeviceAECReplayBuffer): the reference's own flat semantics, quirks included -------------------
+    @staticmethod
+    def aec_partition(buffer):
+        """(indices i64 [n] = sample_indices(0), positions grouped by agent, host offsets [N + 1]):
+        `np.nonzero(batch.obs.agent_id == agent)` of marl.py:233 for every agent, by one stable counting sort on device."""
+        idx_all = buffer.index.sample_indices_all()
+        codes = buffer._gather(buffer.agent_store.unsqueeze(-1), idx_all).view(-1)
+        pos, offs = ops.agent_index(codes, len(buffer.agents))
+        return idx_all, pos, offs.cpu().numpy()
+
+    @staticmethod
+    def aec_returns(buffer, tind: torch.Tensor, k: int, v_s: torch.Tensor, v_next: torch.Tensor, gamma: float,
+                    gae_lambda: float, algorithm=None):
+        """`compute_episodic_return` (algorithm_base.py:651-717) on ONE agent's rows `tind` (flat indices in sample(0)
+        order) with that agent's reward column (marl.py:231,240): the filtered rows form one flat series whose end flags
+        are terminated | truncated | isin(index, unfinished_index()) -- i.e. quirk Q1 is kept:
+        a row that is the last of ITS agent in a sub-buffer but not the sub-buffer's last row carries the GAE of the next
+        sub-buffer.  value_mask = ~terminated.  -> (returns, adv) f32 [n]."""
+        n = tind.numel()
+        g = lambda store: buffer._gather(store, tind)  # noqa: E731
+        rew = g(buffer.rew_store)[:, k].contiguous().view(n, 1)
+        term = g(buffer.term_store).view(n, 1)
+        trunc = g(buffer.trunc_store).view(n, 1)
+        forced = torch.zeros(buffer.maxsize, dtype=torch.uint8, device=tind.device)
+        forced[buffer.index.unfinished_index()] = 1
+        end = (trunc | forced[tind].view(n, 1)).contiguous()
+        if algorithm is not None:  # through the algorithm: return_scaling statistics included (a2c.py:132-146)
+            ret, adv = algorithm._gae(v_s.view(n, 1), v_next.view(n, 1), rew, term, end, 1)
+        else:
+            ret, adv = ops.gae_lanes(v_s.view(n, 1), v_next.view(n, 1), rew, term, end, gamma, gae_lambda)
+        return ret.view(n), adv.view(n)
+
+    def _dispatch_process_aec(self, buffer) -> dict:
+        """marl.py:208-249 on AEC rows: per agent, slice its rows (and their flat indices) out of the batch, take its
+        reward column, and run the sub-algorithm's `_preprocess_batch` arithmetic on them (critic on obs and on obs_next
+        -- the NEXT AGENT's observation, quirk Q2 --, GAE, logp_old).  Results are lane batches of one agent each."""
+        idx_all, pos, offs = self.aec_partition(buffer)
+        results = {}
+        for agent, algorithm in self.algorithms.items():
+            k = self.agent_idx[agent]
+            lo, hi = int(offs[k]), int(offs[k + 1])
+            if hi == lo:
+                results[agent] = None
+                continue
+            net = getattr(algorithm, "net", None)
+            if net is None or getattr(net, "image_map", None) is None:
+                raise NotImplementedError("AEC rows are preprocessed for the fused 64-wide PPO family (DiscreteActorCritic)")
+            tind = idx_all[pos[lo:hi]].contiguous()
+            n = hi - lo
+            obs = buffer._gather(buffer.obs_store, tind).view(n, buffer.obs_dim)
+            nxt = buffer.get_device(tind)["obs_next"].view(n, buffer.obs_dim)
+            act = buffer._gather(buffer.act_store, tind).view(n)
+            P = net.flat.data
+            cur = ops.policy_forward(P, obs, net.n_act, net.hidden, image=net.image, mode="given", act=act, want_logits=False)
+            v_next = ops.policy_forward(P, nxt, net.n_act, net.hidden, image=net.image, mode="none", want_logits=False)["value"]
+            ret, adv = self.aec_returns(buffer, tind, k, cur["value"], v_next, algorithm.gamma, algorithm.gae_lambda, algorithm)
+            results[agent] = dict(T=n, rows=None, obs=obs, act=act, v_s=cur["value"], ret=ret.contiguous(), adv=adv.contiguous(),
+                                  logp_old=cur["logp"], n_env=1, n_agent=1, aec=True)
         return results
 
     def dispatch_update_with_batch(self, batch: dict, algorithm_update_with_batch_fn: Callable) -> MapTrainingStats:
@@ -267,6 +329,8 @@ class MultiAgentOnPolicyAlgorithm(nn.Module):
 
     def _update_with_batch(self, batch: dict, batch_size: int | None, repeat: int, buffer=None) -> MapTrainingStats:
         def update(algorithm, data, agent_col):
+            if data.get("aec"):  # one agent's own rows already: no column to select
+                return algorithm._update_with_batch(data, batch_size, repeat, agent=None, buffer=None)
             return algorithm._update_with_batch(data, batch_size, repeat, agent=agent_col, buffer=buffer)
 
         return self._dispatcher.dispatch_update_with_batch(batch, update)
@@ -274,7 +338,7 @@ class MultiAgentOnPolicyAlgorithm(nn.Module):
     def update(self, buffer, batch_size: int | None, repeat: int):
         """OnPolicyAlgorithm.update (algorithm_base.py:852-863) through the dispatcher."""
         algos = _unique(self._dispatcher.algorithms.values())
-        if len(algos) == 1 and getattr(algos[0], "dispatch", None) == "per_agent":
+        if len(algos) == 1 and getattr(algos[0], "dispatch", None) == "per_agent" and not getattr(buffer, "aec", False):
             return algos[0].update(buffer, batch_size, repeat)  # shared parameters: the fused/graph path
         if not self.is_within_training_step:
             raise RuntimeError("update() was called outside of a training step as signalled by "

@@ -216,7 +216,7 @@ class DeviceVectorReplayBuffer:
 
     def get_device(self, index) -> dict[str, torch.Tensor]:
         """Rows by flat reference index as device tensors (ReplayBuffer.__getitem__, buffer_base.py:591-635)."""
-        idx = torch.as_tensor(np.asarray(index), dtype=torch.int64).to(self.device).reshape(-1)
+        idx = (index if isinstance(index, torch.Tensor) else torch.as_tensor(np.asarray(index))).to(self.device, torch.int64).reshape(-1)
         out = {
             "obs": self._gather(self.obs_store, idx), "act": self._gather(self.act_store, idx),
             "rew": self._gather(self.rew_store, idx), "terminated": self._gather(self.term_store, idx),
@@ -300,6 +300,115 @@ class DeviceVectorReplayBuffer:
         idx_d = torch.as_tensor(idx % self.maxsize, dtype=torch.int64, device=self.device)
         env, slot = idx_d // self.sub_size, idx_d % self.sub_size
         store[slot, env] = torch.as_tensor(seq).to(self.device, store.dtype).reshape(len(idx), *store.shape[2:])
+
+
+class DeviceAECReplayBuffer(DeviceVectorReplayBuffer):
+    """The same HBM-resident vector buffer for AEC rows -- the rows `PettingZooEnv` emits and the reference's only runnable
+    Collector pipeline stores (pettingzoo_env.py:97-120, SURVEY.md headline fact 6): ONE agent's turn per row,
+    `obs = Batch(agent_id, obs[, mask])`, `rew` = the per-agent reward vector, scalar terminated / truncated.
+    Per row the buffer keeps the acting agent's index (and the next observation's) next to the payload, so
+    `sample(0)` / `__getitem__` hand back the reference's Batch layout (agent ids as strings) while the MARL
+    dispatcher partitions rows by agent on the device (`tsm_agent_index`).  Index algebra and episode statistics are the
+    shared kernels (csrc/vrb.hip); flat index <-> (env, slot) as for joint rows."""
+
+    aec = True
+
+    def __init__(self, total_size: int, buffer_num: int, agents, obs_dim: int, n_act: int | None = None,
+                 device: str | torch.device = "cuda", ignore_obs_next: bool = False) -> None:
+        super().__init__(total_size, buffer_num, 1, obs_dim, device=device, ignore_obs_next=ignore_obs_next,
+                         store_policy_outputs=False)
+        self.agents = list(agents)
+        self.agent_idx = {a: i for i, a in enumerate(self.agents)}
+        self.rew_dim = len(self.agents)
+        S, B = self.sub_size, self.buffer_num
+        self.index = ops.VrbState(total_size, buffer_num, rew_dim=self.rew_dim, device=self.device)
+        self.rew_store = torch.zeros(S, B, self.rew_dim, dtype=torch.float32, device=self.device)
+        self.agent_store = torch.zeros(S, B, dtype=torch.int32, device=self.device)
+        self.agent_next_store = torch.zeros(S, B, dtype=torch.int32, device=self.device) if self._save_obs_next else None
+        self.n_act = n_act
+        self.mask_store = torch.ones(S, B, n_act, dtype=torch.uint8, device=self.device) if n_act else None
+        self._names = np.array(self.agents, dtype=object)
+
+    def storage_key(self) -> tuple:
+        return super().storage_key() + (self.agent_store.data_ptr(),)
+
+    def _codes(self, agent_id) -> torch.Tensor:
+        ids = np.asarray(agent_id)
+        codes = np.empty(ids.shape, np.int32)
+        for i, a in enumerate(ids.reshape(-1)):
+            if a not in self.agent_idx:
+                raise ValueError(f"unknown agent id {a!r} (buffer was built for {self.agents})")
+            codes.reshape(-1)[i] = self.agent_idx[a]
+        return torch.as_tensor(codes).to(self.device)
+
+    def add(self, batch: Batch, buffer_ids=None):
+        """manager.py:131-193 for AEC rows: host Batch in (obs / obs_next = Batch(agent_id, obs[, mask])), numpy 4-tuple out."""
+        keys = set(batch.get_keys())
+        if not {"obs", "act", "rew", "terminated", "truncated"}.issubset(keys):
+            raise ValueError("Input batch must have the keys obs, act, rew, terminated, truncated")
+        obs = batch.obs
+        if not (isinstance(obs, Batch) and "agent_id" in obs and "obs" in obs):
+            raise ValueError("AEC rows carry obs = Batch(agent_id, obs[, mask]) (pettingzoo_env.py:76-93)")
+        dev = self.device
+        R = len(np.asarray(batch.terminated).reshape(-1))
+        t = lambda x, dt: torch.as_tensor(np.ascontiguousarray(x)).to(dev, dt).contiguous()  # noqa: E731
+        rew = np.asarray(batch.rew, np.float32).reshape(R, -1)
+        if rew.shape[1] != self.rew_dim:
+            raise ValueError(f"rew has {rew.shape[1]} entries per row, the env has {self.rew_dim} agents")
+        term_h = np.asarray(batch.terminated, bool).reshape(R)
+        trunc_h = np.asarray(batch.truncated, bool).reshape(R)
+        term, trunc = t(term_h.reshape(R, 1), torch.uint8), t(trunc_h.reshape(R, 1), torch.uint8)
+        fields = [(t(np.asarray(obs.obs, np.float32).reshape(R, 1, self.obs_dim), torch.float32), self.obs_store),
+                  (t(np.asarray(batch.act).reshape(R, 1), torch.int32), self.act_store),
+                  (t(rew, torch.float32), self.rew_store), (term, self.term_store), (trunc, self.trunc_store),
+                  (self._codes(obs.agent_id).reshape(R), self.agent_store)]
+        if self.mask_store is not None and "mask" in obs:
+            fields.append((t(np.asarray(obs.mask, bool).reshape(R, self.n_act), torch.uint8), self.mask_store))
+        if self._save_obs_next and "obs_next" in keys:
+            nxt = batch.obs_next
+            fields.append((t(np.asarray(nxt.obs, np.float32).reshape(R, 1, self.obs_dim), torch.float32), self.obs_next_store))
+            fields.append((self._codes(nxt.agent_id).reshape(R), self.agent_next_store))
+        ids = None if buffer_ids is None else t(np.asarray(buffer_ids, np.int64), torch.int64)
+        if ids is None and R == self.buffer_num:
+            self.note_uniform_rows(1)
+        else:
+            self._host_rows = None
+        done = t(term_h | trunc_h, torch.uint8)
+        out = self.index.add(t(rew, torch.float32), done, ids, fields=fields)
+        return tuple(x.cpu().numpy() for x in out)
+
+    def add_device(self, *args, **kwargs):
+        raise NotImplementedError("AEC rows are added through add(batch, buffer_ids) (host Collector loop)")
+
+    def get_device(self, index) -> dict[str, torch.Tensor]:
+        idx = (index if isinstance(index, torch.Tensor) else torch.as_tensor(np.asarray(index))).to(self.device, torch.int64).reshape(-1)
+        out = super().get_device(idx)
+        out["agent"] = self._gather(self.agent_store.unsqueeze(-1), idx).view(-1)
+        if self._save_obs_next:
+            out["agent_next"] = self._gather(self.agent_next_store.unsqueeze(-1), idx).view(-1)
+        else:
+            out["agent_next"] = self._gather(self.agent_store.unsqueeze(-1), self.index.next(idx)).view(-1)
+        if self.mask_store is not None:
+            out["mask"] = self._gather(self.mask_store, idx)
+        return out
+
+    def __getitem__(self, index) -> Batch:
+        if isinstance(index, slice):
+            indices = self.sample_indices(0) if index == slice(None) else np.arange(len(self))[index]
+        else:
+            indices = index
+        d = {k: v.cpu().numpy() for k, v in self.get_device(indices).items()}
+        n = len(d["agent"])
+        obs = Batch(agent_id=self._names[d["agent"]], obs=d["obs"].reshape(n, self.obs_dim))
+        obs_next = Batch(agent_id=self._names[d["agent_next"]], obs=d["obs_next"].reshape(n, self.obs_dim))
+        if "mask" in d:
+            obs.mask = d["mask"].astype(bool)
+        b = Batch(obs=obs, act=d["act"].reshape(n).astype(np.int64), rew=d["rew"].astype(np.float64),
+                  terminated=d["terminated"].reshape(n).astype(bool), truncated=d["truncated"].reshape(n).astype(bool),
+                  done=d["done"].astype(bool), obs_next=obs_next)
+        b.info = Batch()
+        b.policy = Batch()
+        return b
 
 
 class VectorReplayBuffer(DeviceVectorReplayBuffer):
