@@ -227,7 +227,20 @@ def make_checkpoint() -> None:
     print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")
 
 
+def make_batch_ops() -> None:
+    """The reference's `Batch` run through tests/golden/batch_cases.py -> batch_ops.npz (row a18)."""
+    import batch_cases
+
+    out = {}
+    for name, res in batch_cases.cases(Batch).items():
+        for path, arr in batch_cases.flatten(res).items():
+            out[f"{name}::{path}"] = arr
+    path = os.path.join(HERE, "batch_ops.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["api_surface", "checkpoint"]
+    which = sys.argv[1:] or ["api_surface", "checkpoint", "batch_ops"]
     for w in which:
         globals()["make_" + w]()

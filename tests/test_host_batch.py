@@ -2,6 +2,8 @@
 test/base/test_batch.py that the hot path relies on: construction from dicts / lists of dicts, attribute and
 key access, numpy-style indexing and assignment of every leaf, cat / stack (incl. nested), split with the
 merge_last rule, conversions, emptiness and null checks."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -101,9 +103,12 @@ def test_split_merge_last_rule():
 def test_conversions_and_nulls():
     b = Batch(a=np.arange(3, dtype=np.float64), b=Batch(c=np.array([1, 2, 3])), s=np.array(["x", "y", "z"], dtype=object))
     t = b.to_torch(dtype=torch.float32)
-    assert t.a.dtype == torch.float32 and t.b.c.dtype == torch.int64 and t.s.dtype == object
+    # as in the reference (batch.py:899-901, pinned by batch_ops.npz): numpy leaves keep their own dtype; `dtype` only
+    # converts leaves that already are tensors
+    assert t.a.dtype == torch.float64 and t.b.c.dtype == torch.int64 and t.s.dtype == object
+    assert t.to_torch(dtype=torch.float32).a.dtype == torch.float32
     back = t.to_numpy()
-    assert back.a.dtype == np.float32 and back.b.c.tolist() == [1, 2, 3]
+    assert back.a.dtype == np.float64 and back.b.c.tolist() == [1, 2, 3]
     b.to_torch_()
     assert isinstance(b.a, torch.Tensor)
     b.to_numpy_()
@@ -134,3 +139,36 @@ def test_equality_update_pickle():
     assert a.w.tolist() == [1, 2, 3] and a.v == 1
     assert pickle.loads(pickle.dumps(a)) == a
     assert a.pop("v") == 1 and "v" not in a
+
+
+# ---- the reference's own Batch, case by case (tests/golden/batch_ops.npz; row a18) ------------------------------------
+def _reference_cases():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "batch_ops.npz"), allow_pickle=False)
+
+
+def test_batch_operations_match_the_reference_case_by_case():
+    """tests/golden/batch_cases.py was run on `tianshou.data.Batch` by make_api_fixtures.py; the same script on the
+    product's Batch must give the same key paths, shapes, dtypes (kind and width) and values for every operation the hot
+    path uses: stacking of per-env dicts, get / set item, cat, stack, split incl. merge_last and the shuffled draw,
+    to_torch / to_numpy, empty_, update, len / shape."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import batch_cases
+
+    ref = _reference_cases()
+    ours = {}
+    for name, res in batch_cases.cases(Batch).items():
+        for path, arr in batch_cases.flatten(res).items():
+            ours[f"{name}::{path}"] = arr
+    assert sorted(ours) == sorted(ref.files), (sorted(set(ref.files) - set(ours))[:5], sorted(set(ours) - set(ref.files))[:5])
+    for k in ref.files:
+        a, b = ours[k], ref[k]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        assert a.dtype.kind == b.dtype.kind and (a.dtype.kind in "US" or a.dtype == b.dtype), (k, a.dtype, b.dtype)
+        if a.dtype.kind in "US":
+            assert a.tolist() == b.tolist(), k
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=k)

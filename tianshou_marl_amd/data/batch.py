@@ -224,8 +224,8 @@ class Batch:
             elif isinstance(v, torch.Tensor):
                 out.__dict__[k] = v.to(device=device, dtype=dtype or v.dtype)
             elif isinstance(v, np.ndarray) and v.dtype != object:
-                t = torch.from_numpy(np.ascontiguousarray(v)).to(device)
-                out.__dict__[k] = t.to(dtype) if dtype is not None and t.is_floating_point() else t
+                # as the reference (batch.py:899-901): a numpy leaf keeps ITS dtype, `dtype` converts torch leaves only
+                out.__dict__[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device)
             else:
                 out.__dict__[k] = v
         return out
