@@ -449,6 +449,21 @@ int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_dim, int32_
                               const tsm_ppo_cfg *cfg, int32_t n_blocks, float *grad_slabs_out,
                               double *loss_partial_out, void *stream);
 
+/* The critic of the same configuration in one launch: value = MLP(row) with in_dim = n_agent * obs_dim inputs (centralized
+ * critic over the joint row, ctde.py:291-294 "concatenate"; n_agent = 1: a local critic on the sample's own observation),
+ * the value term of the PPO loss (ppo.py:198-208) for the n_agent samples row * n_agent + a of every row, and the critic's
+ * backward pass.  critic_params: w0[H][in_dim] b0[H] w1[H][H] b1[H] w2[1][H] b2[1], H == 128, in_dim <= 384.
+ * Row i of the minibatch is joint row rows[i] (NULL: first_row + i) of obs_rows [n][in_dim]; returns / v_s_old are
+ * per-sample arrays.  grad_slabs_out [n_blocks][tsm_ppo_critic_rows_param_count]; loss_partial_out f64 [n_blocks][4] =
+ * {0, sum of the value-loss terms, 0, 0}; the mean is over Mr * n_agent samples. */
+int tsm_ppo_critic_rows_supported(int32_t in_dim, int32_t hidden, int32_t n_agent);
+int64_t tsm_ppo_critic_rows_param_count(int32_t in_dim, int32_t hidden);
+int tsm_ppo_critic_rows_grid(int64_t Mr);
+int tsm_ppo_critic_rows_update(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_agent,
+                               const float *obs_rows, const float *returns, const float *v_s_old, const int64_t *rows,
+                               int64_t first_row, int64_t Mr, const tsm_ppo_cfg *cfg, int32_t n_blocks,
+                               float *grad_slabs_out, double *loss_partial_out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * CTDE global state  [a16]
  * Replaces  GlobalStateConstructor.build("concatenate" | "mean")

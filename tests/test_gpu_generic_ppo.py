@@ -321,3 +321,51 @@ def test_actor_rows_kernel_matches_float64_autograd(D, A, M, variant):
     slabs2, _ = ops.ppo_actor_rows_update(f.flat.data, d(obs), d(act, torch.int32), d(logp_old), adv_d, cfg, A, H,
                                           adv_stats=None if stats is None else stats[0], perm=perm_d)
     assert torch.equal(slabs, slabs2)
+
+
+@pytest.mark.parametrize("D,N,Mr,vclip", [(48, 8, 1000, True), (18, 1, 300, False), (18, 3, 77, True), (48, 8, 8192, False),
+                                          (6, 2, 32, False)])
+def test_critic_rows_kernel_matches_float64_autograd(D, N, Mr, vclip):
+    """csrc/ppo_rows.hip, critic: value = MLP(joint row), value term (with / without clipping) for the row's N agents and
+    the critic's backward pass in one launch vs float64 autograd; layer-1 weights streamed in 32-column slices."""
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.utils.net import FlatMLP
+
+    H, K1 = 128, N * D
+    rng = np.random.default_rng(D + N + Mr)
+    f = FlatMLP([K1, H, H, 1], device=DEV, seed=4)
+    n_rows = Mr + 13
+    obs = rng.standard_normal((n_rows, K1)).astype(np.float32)
+    ret = (rng.standard_normal(n_rows * N) * 2).astype(np.float32)
+    v_old = rng.standard_normal(n_rows * N).astype(np.float32)
+    rows = rng.permutation(n_rows)[:Mr]
+    cfg = ops.make_ppo_cfg(value_clip=vclip, vf_coef=0.7, eps_clip=0.3)
+    d = lambda x, dt=None: torch.from_numpy(np.ascontiguousarray(x)).to(DEV, dt)  # noqa: E731
+    slabs, partial = ops.ppo_critic_rows_update(f.flat.data, d(obs), d(ret), cfg, N, H, v_s_old=d(v_old) if vclip else None,
+                                                rows=d(rows))
+    lins = []
+    for i in range(3):
+        lin = torch.nn.Linear(f.dims[i], f.dims[i + 1]).double()
+        with torch.no_grad():
+            lin.weight.copy_(f.weight(i).cpu().double())
+            lin.bias.copy_(f.bias(i).cpu().double())
+        lins.append(lin)
+    x = torch.as_tensor(obs[rows]).double()
+    v = lins[2](torch.relu(lins[1](torch.relu(lins[0](x))))).expand(Mr, N)
+    sid = rows[:, None] * N + np.arange(N)[None, :]
+    r_t, vo = torch.as_tensor(ret[sid]).double(), torch.as_tensor(v_old[sid]).double()
+    if vclip:
+        v_clip = vo + (v - vo).clamp(-0.3, 0.3)
+        vf = torch.max((r_t - v) ** 2, (r_t - v_clip) ** 2)
+    else:
+        vf = (r_t - v) ** 2
+    (0.7 * vf.mean()).backward()
+    g_ref = torch.cat([t.grad.flatten() for lin in lins for t in (lin.weight, lin.bias)]).numpy()
+    g = slabs.double().sum(0).cpu().numpy()
+    assert np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref) < 2e-5
+    np.testing.assert_allclose(g, g_ref, rtol=1e-3, atol=2e-4 * np.abs(g_ref).max())
+    p = partial.view(-1, 4).sum(0).cpu().numpy()
+    np.testing.assert_allclose(p[1], float(vf.sum()), rtol=2e-5)
+    assert p[0] == 0 and p[2] == 0
+    slabs2, _ = ops.ppo_critic_rows_update(f.flat.data, d(obs), d(ret), cfg, N, H, v_s_old=d(v_old) if vclip else None, rows=d(rows))
+    assert torch.equal(slabs, slabs2)

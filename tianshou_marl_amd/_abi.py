@@ -136,6 +136,10 @@ SIGNATURES = {
     "tsm_mpe_tag_step": (_int, [C.POINTER(tsm_mpe_tag_cfg), _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                 _int, _p, _u64, _p]),
     "tsm_u64_add": (_int, [_p, _u64, _p]),
+    "tsm_ppo_critic_rows_supported": (_int, [_i32, _i32, _i32]),
+    "tsm_ppo_critic_rows_param_count": (_i64, [_i32, _i32]),
+    "tsm_ppo_critic_rows_grid": (_int, [_i64]),
+    "tsm_ppo_critic_rows_update": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i64, C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p]),
     "tsm_ppo_actor_rows_supported": (_int, [_i32, _i32, _i32]),
     "tsm_ppo_actor_rows_param_count": (_i64, [_i32, _i32, _i32]),
     "tsm_ppo_actor_rows_grid": (_int, [_i64]),
@@ -147,7 +151,8 @@ SIGNATURES = {
                                     C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p, _p]),
 }
 
-_NO_STATUS = {"tsm_ppo_actor_rows_supported", "tsm_ppo_actor_rows_param_count", "tsm_ppo_actor_rows_grid",
+_NO_STATUS = {"tsm_ppo_critic_rows_supported", "tsm_ppo_critic_rows_param_count", "tsm_ppo_critic_rows_grid",
+              "tsm_ppo_actor_rows_supported", "tsm_ppo_actor_rows_param_count", "tsm_ppo_actor_rows_grid",
               "tsm_rms_update_work_elems", "tsm_ppo_adv_stats_work_elems", "tsm_abi_version", "tsm_last_error", "tsm_stream_abort_capture", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
               "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems",
               "tsm_mlp_param_count", "tsm_mlp_act_elems", "tsm_ctde_head_partial_elems", "tsm_mpe_tag_obs_dim"}

@@ -60,6 +60,11 @@ class GenericPPO(PPO):
                                                 self.ent_coef, loss_kind=2, value_group=vg) for vg in (1, self.n_agent)}
         self.fused_actor = bool(fused_actor) and ops.ppo_actor_rows_supported(net.obs_dim, net.actor.dims[1:-1], net.n_act,
                                                                               net.actor.act)
+        # ... and the critic in its own single launch when it is in_dim -> 128 -> 128 -> 1 (row minibatches or a local
+        # critic: the samples of a row are adjacent lanes)
+        self.fused_critic = self.fused_actor and ops.ppo_critic_rows_supported(
+            net.critic_obs_dim, net.critic.dims[1:-1], self.n_agent if critic_input == "global" else 1, net.critic.act) \
+            and net.critic.dims[-1] == 1
         self.reuse_rollout_outputs = bool(reuse_rollout_outputs)
         self._ctor.update(fused_actor=fused_actor, reuse_rollout_outputs=reuse_rollout_outputs)
 
@@ -187,11 +192,15 @@ class GenericPPO(PPO):
         the actor's and the value kernel's partial sums."""
         net, dev = self.net, self.device
         M, P_a, P_c = idx.numel(), net.n_actor, net.n_critic
-        na, nv = ops.ppo_actor_rows_grid(M), ops.ppo_loss_partial_elems(M) // 4
-        n_split = ops.mlp_n_split(M if rows is None else rows.numel())
-        w = self._ws.get(("rows", M, n_split))
+        # the critic in one launch too when the minibatch is made of whole joint rows (or the critic is local)
+        crit_rows = self.fused_critic and (rows is not None or pb["joint"] is None)
+        Mr = rows.numel() if rows is not None else M
+        na = ops.ppo_actor_rows_grid(M)
+        nv = ops.ppo_critic_rows_grid(Mr) if crit_rows else ops.ppo_loss_partial_elems(M) // 4
+        n_split = nv if crit_rows else ops.mlp_n_split(Mr)
+        w = self._ws.get(("rows", M, n_split, crit_rows))
         if w is None:
-            w = self._ws[("rows", M, n_split)] = dict(
+            w = self._ws[("rows", M, n_split, crit_rows)] = dict(
                 slabs_a=torch.empty(na, P_a, dtype=torch.float32, device=dev),
                 slabs_c=torch.empty(n_split, P_c, dtype=torch.float32, device=dev),
                 partial=torch.zeros((na + nv) * 4, dtype=torch.float64, device=dev),
@@ -200,16 +209,22 @@ class GenericPPO(PPO):
         ops.ppo_actor_rows_update(net.actor.flat.data, pb["obs"], pb["act"], pb["logp_old"], pb["adv"], self._cfg, net.n_act,
                                   net.actor.dims[1], adv_stats=adv_stats, perm=idx, M=M, n_blocks=na, slabs=w["slabs_a"],
                                   partial=w["partial"][:na * 4])
-        if rows is not None:
-            cx, vg = ops.gather_rows(pb["joint"], rows), pb["n_agent"]
-        elif pb["joint"] is not None:
-            cx, vg = ops.gather_rows(pb["joint"], torch.div(idx, pb["n_agent"], rounding_mode="floor")), 1
+        if crit_rows:
+            src, N_c = (pb["joint"], pb["n_agent"]) if rows is not None else (pb["obs"], 1)
+            ops.ppo_critic_rows_update(net.critic.flat.data, src, pb["ret"], self._cfg, N_c, net.critic.dims[1],
+                                       v_s_old=pb["v_s"] if self.value_clip else None, rows=rows if rows is not None else idx,
+                                       Mr=Mr, n_blocks=nv, slabs=w["slabs_c"], partial=w["partial"][na * 4:])
         else:
-            cx, vg = ops.gather_rows(pb["obs"], idx), 1
-        value = FlatMLP.forward(net.critic, cx, save=True).reshape(-1)
-        dvalue, _ = ops.ppo_value_loss(value, pb["ret"], self._cfg_value[vg], M, v_s_old=pb["v_s"] if self.value_clip else None,
-                                       perm=idx, partial=w["partial"][na * 4:])
-        net.critic.backward(dvalue.view(-1, 1), n_split, slabs=w["slabs_c"], slab_stride=P_c)
+            if rows is not None:
+                cx, vg = ops.gather_rows(pb["joint"], rows), pb["n_agent"]
+            elif pb["joint"] is not None:
+                cx, vg = ops.gather_rows(pb["joint"], torch.div(idx, pb["n_agent"], rounding_mode="floor")), 1
+            else:
+                cx, vg = ops.gather_rows(pb["obs"], idx), 1
+            value = FlatMLP.forward(net.critic, cx, save=True).reshape(-1)
+            dvalue, _ = ops.ppo_value_loss(value, pb["ret"], self._cfg_value[vg], M, v_s_old=pb["v_s"] if self.value_clip else None,
+                                           perm=idx, partial=w["partial"][na * 4:])
+            net.critic.backward(dvalue.view(-1, 1), n_split, slabs=w["slabs_c"], slab_stride=P_c)
         scale = 1.0 / self._grad_sync.world if self._grad_sync is not None else 1.0
         ops.reduce_slabs(w["slabs_a"], out=w["flat_g"][:P_a], scale=scale)
         ops.reduce_slabs(w["slabs_c"], out=w["flat_g"][P_a:], scale=scale)

@@ -351,6 +351,334 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
     }
 }
 
+// ================================================================================================================
+// The critic of the same configuration in one launch: value = MLP(joint row) with K1 = N * D inputs (centralized critic,
+// 384 for simple_spread N = 8; K1 = D for a local critic), value term of the PPO loss (ppo.py:198-208) for the N agents of
+// the row, and the critic's backward pass.
+//
+// The first layer's weights (128 x 384 f32 = 192 KB) exceed a CU's LDS, so layer 1 streams K-slices of 32 columns of W1
+// and of the 32-row observation block through a double buffer (global -> registers -> LDS, one barrier per slice) while the
+// layer's accumulators stay in registers; W2 stays resident like the actor's.  The weight gradient of layer 1 streams the
+// observation slices a second time (they are L2-hot) against dH1 kept in LDS: wave w accumulates dW1[16 w ..][32 s .. 32 s + 32)
+// for every slice s in registers (2 tiles x NS slices), across all blocks of its workgroup, and writes them once.
+// ================================================================================================================
+constexpr int kKs = 32, kLds = kKs + 2;
+
+struct CritLay {
+    int W2, W3, B1, B2, H1, H2, WS, XS, V, DV, total;
+    __host__ __device__ CritLay() {
+        int o = 0;
+        W2 = o; o += kH * kLdh;
+        W3 = o; o += kH;
+        B1 = o; o += kH;
+        B2 = o; o += kH;
+        H1 = o; o += kRows * kLdh;
+        H2 = o; o += kRows * kLdh;
+        WS = o; o += 2 * kH * kLds;      // W1 slice, double buffered
+        XS = o; o += 2 * kRows * kLds;   // observation slice, double buffered
+        V = o; o += kRows;
+        DV = o; o += kRows * 16;         // per-sample d loss / d value of a row's agents (N <= 16)
+        total = o;
+    }
+};
+
+struct CriticArgs {
+    const float *P;          // critic parameters: w0[H][K1] b0[H] w1[H][H] b1[H] w2[1][H] b2[1]
+    const float *obs;        // joint rows [n_rows][K1]
+    const float *returns, *v_s_old;   // per SAMPLE (lane id = row * N + agent)
+    const int64_t *rows;     // joint-row ids of the minibatch (nullable: first_row + i)
+    int64_t first_row, Mr;   // rows in the minibatch
+    int K1, N;
+    float eps_clip, vf_coef;
+    int value_clip;
+    float *slabs;            // [grid][P]
+    double *partial;         // [grid][4] = {0, sum vf, 0, 0}
+};
+
+template <int NS>
+__global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const CritLay ly;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+    const int K1 = g.K1, N = g.N;
+    const int64_t n_blocks = (g.Mr + kRows - 1) / kRows;
+    const int oB1 = kH * K1, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + kH;
+    for (int e = tid; e < kH * kLdh; e += kThreads) {
+        const int r = e / kLdh, c = e - r * kLdh;
+        lds[ly.W2 + e] = c < kH ? g.P[oW2 + r * kH + c] : 0.f;
+    }
+    if (tid < kH) { lds[ly.W3 + tid] = g.P[oW3 + tid]; lds[ly.B1 + tid] = g.P[oB1 + tid]; lds[ly.B2 + tid] = g.P[oB2 + tid]; }
+    const float b3 = g.P[oB3];
+
+    // dW2 lives in registers for the whole launch; dW1 (2 NS tiles per wave: 96 registers at K1 = 384) only during a
+    // block's layer-1 weight-gradient phase -- it is folded into the workgroup's slab (plain store for the first block,
+    // read-add-store by the same lanes afterwards: fixed order) so that the other phases keep their registers
+    f4 gW2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gW2[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float *slab = g.slabs + (size_t)blockIdx.x * (size_t)(oB3 + 1);
+    float gB = 0.f;   // threads 0..127: db1; 128..255: db2; 256..383: dW3[tid - 256]; 384: db3
+    double t_vf = 0.0;
+
+    // slice staging: W1 slice = 128 rows x 8 float4 (two per thread), observation slice = 32 rows x 8 float4 (threads < 256)
+    const int wr0 = tid >> 3, wp = tid & 7;          // W1 rows wr0 and wr0 + 64, float4 piece wp
+    const int xr = tid >> 3;                          // observation row (tid < 256)
+    f4 rw[2], rx;
+    int64_t x_row = -1;
+    auto fetch_slice = [&](int s, bool with_w) {
+        const int k = kKs * s + 4 * wp;
+        if (with_w) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float *src = g.P + (size_t)(wr0 + 64 * h) * K1 + k;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rw[h][j] = k + j < K1 ? src[j] : 0.f;
+            }
+        }
+        if (tid < 256) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rx[j] = (x_row >= 0 && k + j < K1) ? g.obs[x_row * K1 + k + j] : 0.f;
+        }
+    };
+    auto commit_slice = [&](int buf, bool with_w) {
+        if (with_w) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lds[ly.WS + buf * kH * kLds + (wr0 + 64 * h) * kLds + 4 * wp + j] = rw[h][j];
+        }
+        if (tid < 256) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lds[ly.XS + buf * kRows * kLds + xr * kLds + 4 * wp + j] = rx[j];
+        }
+    };
+    __syncthreads();
+
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int col = 16 * w + c16;
+        {
+            const int64_t i = blk * kRows + xr;
+            x_row = (tid < 256 && i < g.Mr) ? (g.rows ? g.rows[i] : g.first_row + i) : -1;
+        }
+        // ---- L1: H1 = relu(X W1^T + b1), K-slices through the double buffer ----
+        {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            fetch_slice(0, true);
+            commit_slice(0, true);
+            __syncthreads();
+#pragma unroll 1
+            for (int s = 0; s < NS; ++s) {
+                if (s + 1 < NS) fetch_slice(s + 1, true);
+                const float *pa = lds + ly.XS + (s & 1) * kRows * kLds + c16 * kLds + kq;
+                const float *pb = lds + ly.WS + (s & 1) * kH * kLds + col * kLds + kq;
+#pragma unroll
+                for (int k0 = 0; k0 < kKs; k0 += 4) {
+                    const float bv = pb[k0];
+                    acc[0] = mfma4(pa[k0], bv, acc[0]);
+                    acc[1] = mfma4(pa[16 * kLds + k0], bv, acc[1]);
+                }
+                if (s + 1 < NS) commit_slice((s + 1) & 1, true);
+                __syncthreads();
+            }
+            const float bb = lds[ly.B1 + col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[mt][r] + bb;
+                    lds[ly.H1 + (mt * 16 + kq * 4 + r) * kLdh + col] = v > 0.f ? v : 0.f;
+                }
+        }
+        __syncthreads();
+        // ---- L2 ----
+        {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            const float *pa = lds + ly.H1 + c16 * kLdh + kq;
+            const float *pb = lds + ly.W2 + col * kLdh + kq;
+#pragma unroll
+            for (int k0 = 0; k0 < kH; k0 += 4) {
+                const float bv = pb[k0];
+                acc[0] = mfma4(pa[k0], bv, acc[0]);
+                acc[1] = mfma4(pa[16 * kLdh + k0], bv, acc[1]);
+            }
+            const float bb = lds[ly.B2 + col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[mt][r] + bb;
+                    lds[ly.H2 + (mt * 16 + kq * 4 + r) * kLdh + col] = v > 0.f ? v : 0.f;
+                }
+        }
+        __syncthreads();
+        // ---- L3: value of every row (one lane per row, k-ordered fma chain) ----
+        if (tid < kRows) {
+            const float *h = lds + ly.H2 + tid * kLdh;
+            float sacc = 0.f;
+            for (int j = 0; j < kH; ++j) sacc = fmaf(h[j], lds[ly.W3 + j], sacc);
+            lds[ly.V + tid] = sacc + b3;
+        }
+        __syncthreads();
+        // ---- value term for the N agents of every row (ppo.py:198-208) ----
+        if (tid < kRows * N) {
+            const int r = tid / N, a = tid - r * N;
+            const int64_t i = blk * kRows + r;
+            float dv = 0.f;
+            if (i < g.Mr) {
+                const int64_t row = g.rows ? g.rows[i] : g.first_row + i;
+                const int64_t sidx = row * N + a;
+                const float v = lds[ly.V + r], ret = g.returns[sidx];
+                float vf, g_v;
+                if (g.value_clip) {
+                    const float vs = g.v_s_old[sidx];
+                    const float d = v - vs;
+                    const float dc = fminf(fmaxf(d, -g.eps_clip), g.eps_clip);
+                    const bool v_in = d >= -g.eps_clip && d <= g.eps_clip;
+                    const float vclip = vs + dc;
+                    const float vf1 = (ret - v) * (ret - v), vf2 = (ret - vclip) * (ret - vclip);
+                    const float g1 = 2.f * (v - ret), g2 = v_in ? 2.f * (vclip - ret) : 0.f;
+                    if (vf1 > vf2) { vf = vf1; g_v = g1; }
+                    else if (vf1 < vf2) { vf = vf2; g_v = g2; }
+                    else { vf = vf1; g_v = 0.5f * g1 + 0.5f * g2; }
+                } else {
+                    vf = (ret - v) * (ret - v);
+                    g_v = 2.f * (v - ret);
+                }
+                dv = g.vf_coef * g_v * (1.0f / (float)(g.Mr * N));
+                t_vf += vf;
+            }
+            lds[ly.DV + r * 16 + a] = dv;
+        }
+        __syncthreads();
+        if (tid < kRows) {  // d loss / d value of the row = sum over its agents, in agent order
+            float sacc = 0.f;
+            for (int a = 0; a < N; ++a) sacc += lds[ly.DV + tid * 16 + a];
+            lds[ly.V + tid] = sacc;
+        }
+        __syncthreads();
+        // ---- backward: dW3, db3 (VALU), dH2 = dv (x) w3 * relu'(H2) in place ----
+        if (tid >= 256 && tid < 256 + kH) {
+            const int j = tid - 256;
+            float sacc = 0.f;
+            for (int r = 0; r < kRows; ++r) sacc = fmaf(lds[ly.V + r], lds[ly.H2 + r * kLdh + j], sacc);
+            gB += sacc;
+        } else if (tid == 384) {
+            float sacc = 0.f;
+            for (int r = 0; r < kRows; ++r) sacc += lds[ly.V + r];
+            gB += sacc;
+        }
+        __syncthreads();
+        for (int e = tid; e < kRows * kH; e += kThreads) {
+            const int r = e >> 7, j = e & (kH - 1);
+            float *p = lds + ly.H2 + r * kLdh + j;
+            *p = *p > 0.f ? lds[ly.V + r] * lds[ly.W3 + j] : 0.f;
+        }
+        __syncthreads();
+        // ---- dW2 += dH2^T H1 ; db2 ; dH1 = (dH2 W2) * relu'(H1) ----
+        {
+            const float *pa = lds + ly.H2 + kq * kLdh + col;
+            const float *pb = lds + ly.H1 + kq * kLdh + c16;
+#pragma unroll
+            for (int r0 = 0; r0 < kRows; r0 += 4) {
+                const float av = pa[r0 * kLdh];
+#pragma unroll
+                for (int ti = 0; ti < 8; ++ti) gW2[ti] = mfma4(av, pb[r0 * kLdh + 16 * ti], gW2[ti]);
+            }
+        }
+        if (tid >= 128 && tid < 256) {
+            float sacc = 0.f;
+            for (int r = 0; r < kRows; ++r) sacc += lds[ly.H2 + r * kLdh + (tid - 128)];
+            gB += sacc;
+        }
+        f4 d1[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        {
+            const float *pa = lds + ly.H2 + c16 * kLdh + kq;
+            const float *pb = lds + ly.W2 + kq * kLdh + col;
+#pragma unroll
+            for (int k0 = 0; k0 < kH; k0 += 4) {
+                const float bv = pb[k0 * kLdh];
+                d1[0] = mfma4(pa[k0], bv, d1[0]);
+                d1[1] = mfma4(pa[16 * kLdh + k0], bv, d1[1]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float *p = lds + ly.H1 + (mt * 16 + kq * 4 + r) * kLdh + col;
+                *p = *p > 0.f ? d1[mt][r] : 0.f;
+            }
+        __syncthreads();
+        if (tid < 128) {
+            float sacc = 0.f;
+            for (int r = 0; r < kRows; ++r) sacc += lds[ly.H1 + r * kLdh + tid];
+            gB += sacc;
+        }
+        // ---- dW1[:, slice s] += dH1^T X[:, slice s]: the observation slices once more (L2-hot) ----
+        // slices in groups of GS: a group's 2 GS accumulator tiles live in registers, then go to the slab
+        constexpr int GS = NS > 4 ? 4 : NS;
+        const bool first_blk = blk == (int64_t)blockIdx.x;
+        fetch_slice(0, false);
+        commit_slice(0, false);
+        __syncthreads();
+#pragma unroll
+        for (int g0 = 0; g0 < NS; g0 += GS) {
+            f4 gW1[2 * GS];
+#pragma unroll
+            for (int i = 0; i < 2 * GS; ++i) gW1[i] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < GS; ++q) {
+                const int s = g0 + q;
+                if (s < NS) {
+                    if (s + 1 < NS) fetch_slice(s + 1, false);
+                    const float *pa = lds + ly.H1 + kq * kLdh + col;                            // A[i = out o][k = row]
+                    const float *pb = lds + ly.XS + (s & 1) * kRows * kLds + kq * kLds + c16;   // B[k = row][j = slice col]
+#pragma unroll
+                    for (int r0 = 0; r0 < kRows; r0 += 4) {
+                        const float av = pa[r0 * kLdh];
+                        gW1[2 * q] = mfma4(av, pb[r0 * kLds], gW1[2 * q]);
+                        gW1[2 * q + 1] = mfma4(av, pb[r0 * kLds + 16], gW1[2 * q + 1]);
+                    }
+                    if (s + 1 < NS) commit_slice((s + 1) & 1, false);
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * w + kq * 4 + r;
+#pragma unroll
+                for (int t2 = 0; t2 < 2 * GS; ++t2) {
+                    const int k = kKs * g0 + 16 * t2 + c16;
+                    if (k < K1) {
+                        float *dst = slab + (size_t)o * K1 + k;
+                        *dst = first_blk ? gW1[t2][r] : *dst + gW1[t2][r];
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 16 * w + kq * 4 + r;
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + oW2 + o * kH + 16 * ti + c16);
+    }
+    if (tid < 128) __builtin_nontemporal_store(gB, slab + oB1 + tid);
+    else if (tid < 256) __builtin_nontemporal_store(gB, slab + oB2 + tid - 128);
+    else if (tid < 384) __builtin_nontemporal_store(gB, slab + oW3 + tid - 256);
+    else if (tid == 384) __builtin_nontemporal_store(gB, slab + oB3);
+    __shared__ double sm[kThreads / 64];
+    const double tot = block_sum<double, kThreads>(t_vf, sm);
+    if (tid == 0) {
+        g.partial[4 * blockIdx.x + 0] = 0.0;
+        g.partial[4 * blockIdx.x + 1] = tot;
+        g.partial[4 * blockIdx.x + 2] = 0.0;
+        g.partial[4 * blockIdx.x + 3] = 0.0;
+    }
+}
+
 int rows_supported(int32_t D, int32_t H, int32_t A) { return H == kH && D >= 1 && D <= 64 && A >= 1 && A <= 16; }
 
 int n_cu() {
@@ -426,6 +754,67 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
         default: LAUNCH(4); break;
     }
 #undef LAUNCH
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+// ---- critic ----
+TSM_EXPORT int tsm_ppo_critic_rows_supported(int32_t in_dim, int32_t hidden, int32_t n_agent) {
+    return hidden == kH && in_dim >= 1 && in_dim <= 12 * kKs && n_agent >= 1 && n_agent <= 16;
+}
+
+TSM_EXPORT int64_t tsm_ppo_critic_rows_param_count(int32_t in_dim, int32_t hidden) {
+    if (hidden != kH || in_dim < 1) return -1;
+    return (int64_t)hidden * in_dim + hidden + (int64_t)hidden * hidden + hidden + hidden + 1;
+}
+
+// workgroups (= gradient slabs) for Mr joint rows: one block of 32 rows at a time; half the CUs by default (a slab is
+// 264 KB for the 384-wide critic: fewer, longer-running workgroups keep the slab traffic below the compute time)
+TSM_EXPORT int tsm_ppo_critic_rows_grid(int64_t Mr) {
+    if (Mr <= 0) return 0;
+    const int64_t blocks = ceil_div(Mr, kRows);
+    const int cap = n_cu() / 2 > 0 ? n_cu() / 2 : 1;
+    return (int)(blocks < cap ? blocks : cap);
+}
+
+TSM_EXPORT int tsm_ppo_critic_rows_update(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_agent,
+                                          const float *obs_rows, const float *returns, const float *v_s_old,
+                                          const int64_t *rows, int64_t first_row, int64_t Mr, const tsm_ppo_cfg *cfg,
+                                          int32_t n_blocks, float *grad_slabs_out, double *loss_partial_out, void *stream) {
+    TSM_REQUIRE(tsm_ppo_critic_rows_supported(in_dim, hidden, n_agent),
+                "tsm_ppo_critic_rows_update supports hidden == 128, in_dim <= 384, n_agent <= 16 (got %d / %d / %d)", hidden,
+                in_dim, n_agent);
+    TSM_REQUIRE(Mr >= 1 && cfg, "tsm_ppo_critic_rows_update: empty minibatch or null cfg");
+    TSM_REQUIRE(critic_params && obs_rows && returns && grad_slabs_out && loss_partial_out,
+                "tsm_ppo_critic_rows_update: null pointer");
+    TSM_REQUIRE(!cfg->value_clip || v_s_old, "tsm_ppo_critic_rows_update: value_clip needs v_s_old");
+    TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(Mr, kRows), "tsm_ppo_critic_rows_update: n_blocks = %d out of range", n_blocks);
+    CriticArgs g{};
+    g.P = critic_params; g.obs = obs_rows; g.returns = returns; g.v_s_old = v_s_old; g.rows = rows;
+    g.first_row = first_row; g.Mr = Mr; g.K1 = in_dim; g.N = n_agent;
+    g.eps_clip = (float)cfg->eps_clip; g.vf_coef = (float)cfg->vf_coef; g.value_clip = cfg->value_clip;
+    g.slabs = grad_slabs_out; g.partial = loss_partial_out;
+    const CritLay ly;
+    const size_t shmem = (size_t)ly.total * sizeof(float);
+    const int ns = (in_dim + kKs - 1) / kKs;
+    static bool attr_set[13] = {false};
+    hipStream_t st = tsm_stream(stream);
+#define LAUNCHC(NS)                                                                                                    \
+    case NS:                                                                                                           \
+        if (!attr_set[NS]) {                                                                                           \
+            TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ppo_critic_rows_kernel<NS>),                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                      \
+            attr_set[NS] = true;                                                                                       \
+        }                                                                                                              \
+        hipLaunchKernelGGL((ppo_critic_rows_kernel<NS>), dim3((unsigned)n_blocks), dim3(kThreads), shmem, st, g);      \
+        break;
+    switch (ns) {
+        LAUNCHC(1) LAUNCHC(2) LAUNCHC(3) LAUNCHC(4) LAUNCHC(6) LAUNCHC(8) LAUNCHC(12)
+        default:
+            TSM_REQUIRE(false, "tsm_ppo_critic_rows_update: in_dim = %d needs %d slices of 32 (instantiated: 1, 2, 3, 4, 6, 8, 12)",
+                        in_dim, ns);
+    }
+#undef LAUNCHC
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

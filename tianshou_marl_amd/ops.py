@@ -480,6 +480,48 @@ def ppo_actor_rows_update(actor_params, obs, act, logp_old, adv, cfg: tsm_ppo_cf
     return slabs, partial
 
 
+def ppo_critic_rows_supported(in_dim: int, hidden_sizes, n_agent: int, act: str = "relu") -> bool:
+    """Does the one-launch critic step (csrc/ppo_rows.hip) cover this critic?  in_dim -> 128 -> 128 -> 1, ReLU."""
+    hs = list(hidden_sizes)
+    n_slice = -(-in_dim // 32)
+    return (act == "relu" and len(hs) == 2 and hs[0] == hs[1] and n_slice in (1, 2, 3, 4, 6, 8, 12)
+            and bool(call("tsm_ppo_critic_rows_supported", in_dim, hs[0], n_agent)))
+
+
+def ppo_critic_rows_grid(Mr: int) -> int:
+    return call("tsm_ppo_critic_rows_grid", Mr)
+
+
+def ppo_critic_rows_update(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n_agent: int, hidden: int = 128, v_s_old=None,
+                           rows=None, first_row=0, Mr=None, n_blocks=None, slabs=None, partial=None):
+    """Critic half of one PPO gradient step in one launch -> (grad_slabs [n_blocks, P_critic], loss partials f64
+    [n_blocks, 4] = {0, sum vf, 0, 0}).  obs_rows [n, in_dim]: the joint rows (in_dim = n_agent * obs_dim)."""
+    obs_rows = _chk(obs_rows, torch.float32, "obs_rows")
+    K1 = obs_rows.shape[-1]
+    if Mr is None:
+        Mr = rows.numel() if rows is not None else obs_rows.shape[0] - first_row
+    if n_blocks is None:
+        n_blocks = ppo_critic_rows_grid(Mr)
+    P = critic_params.numel()
+    if P != call("tsm_ppo_critic_rows_param_count", K1, hidden):
+        raise ValueError(f"ppo_critic_rows_update: {P} critic parameters do not match {K1} -> {hidden} -> {hidden} -> 1")
+    dev = obs_rows.device
+    if slabs is None:
+        slabs = torch.empty(n_blocks, P, dtype=torch.float32, device=dev)
+    elif slabs.numel() < n_blocks * P:
+        raise ValueError("ppo_critic_rows_update: slabs is too small")
+    if partial is None:
+        partial = torch.empty(n_blocks * 4, dtype=torch.float64, device=dev)
+    elif partial.numel() < n_blocks * 4:
+        raise ValueError("ppo_critic_rows_update: partial is too small")
+    if rows is not None and rows.numel() < Mr:
+        raise ValueError("ppo_critic_rows_update: rows holds fewer ids than Mr")
+    call("tsm_ppo_critic_rows_update", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_agent,
+         ptr(obs_rows), ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old), ptr(rows), first_row, Mr, C.byref(cfg),
+         n_blocks, ptr(slabs), ptr(partial), stream_ptr())
+    return slabs, partial
+
+
 def ppo_value_loss(value, returns, cfg: tsm_ppo_cfg, M: int, v_s_old=None, perm=None, first_row=0, partial=None):
     """Value term of the PPO loss alone (loss_kind = 2) for M samples whose values are `value` (one per sample, or one
     per joint row with cfg.value_group = N) -> (dvalue [len(value)], loss partials f64 [blocks, 4] = {0, sum vf, 0, 0})."""
