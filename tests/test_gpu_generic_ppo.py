@@ -185,8 +185,9 @@ def test_row_minibatches_with_centralized_critic_match_float64_autograd(oracle, 
     torch.manual_seed(1)
     B, T, D, A = 12, 6, 5, 4
     net = MLPActorCritic(D, A, (H, H), critic_obs_dim=N * D, device=DEV, seed=2)
+    gn = None if (H == 128 and not graph) else 0.7  # without clipping each half's slabs feed its own Adam launch
     algo = GenericPPO(net=net, critic_input="global", n_agent=N, dispatch="pooled", shuffle="numpy", lr=1e-3, graph=graph,
-                      max_grad_norm=0.7, value_clip=True)
+                      max_grad_norm=gn, value_clip=True)
     assert algo.row_minibatches and algo.fused_actor == (H == 128)
     buf = DeviceVectorReplayBuffer(B * T, B, N, D, device=DEV)
     gen = torch.Generator(device=DEV).manual_seed(3)
@@ -234,7 +235,8 @@ def test_row_minibatches_with_centralized_critic_match_float64_autograd(oracle, 
             loss = clip_loss + 0.5 * vf_loss - 0.01 * ent
             opt.zero_grad()
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(params, 0.7)
+            if gn:
+                torch.nn.utils.clip_grad_norm_(params, gn)
             opt.step()
             losses.append(float(loss))
     np.random.seed(4)

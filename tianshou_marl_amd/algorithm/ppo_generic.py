@@ -225,18 +225,26 @@ class GenericPPO(PPO):
             dvalue, _ = ops.ppo_value_loss(value, pb["ret"], self._cfg_value[vg], M, v_s_old=pb["v_s"] if self.value_clip else None,
                                            perm=idx, partial=w["partial"][na * 4:])
             net.critic.backward(dvalue.view(-1, 1), n_split, slabs=w["slabs_c"], slab_stride=P_c)
-        scale = 1.0 / self._grad_sync.world if self._grad_sync is not None else 1.0
-        ops.reduce_slabs(w["slabs_a"], out=w["flat_g"][:P_a], scale=scale)
-        ops.reduce_slabs(w["slabs_c"], out=w["flat_g"][P_a:], scale=scale)
-        if self._grad_sync is not None:
-            self._grad_sync.all_reduce_sum_(w["flat_g"])
         if step_dev is None:
             self.opt_step += 1
         else:
             ops.call("tsm_u64_add", ops.ptr(step_dev), 1, ops.stream_ptr())
-        ops.adam_step(net.flat.data, w["flat_g"].view(1, -1), self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr,
-                      lr_dev=self._lr_dev, betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
-                      max_grad_norm=self.max_grad_norm, work=self._adam_work, step_dev=step_dev)
+        adam = lambda p, g, m, v, **kw: ops.adam_step(  # noqa: E731
+            p, g, m, v, self.opt_step, lr=self.lr, lr_dev=self._lr_dev, betas=self.betas, eps=self.adam_eps,
+            weight_decay=self.weight_decay, step_dev=step_dev, **kw)
+        if self._grad_sync is None and not self.max_grad_norm:
+            # no joint norm and nothing to exchange: each half's slabs go straight into its own Adam launch (the slab sum
+            # is part of tsm_adam_step), two launches instead of two reductions + one Adam
+            adam(net.flat.data[:P_a], w["slabs_a"], self.exp_avg[:P_a], self.exp_avg_sq[:P_a])
+            adam(net.flat.data[P_a:], w["slabs_c"][:n_split], self.exp_avg[P_a:], self.exp_avg_sq[P_a:])
+        else:
+            scale = 1.0 / self._grad_sync.world if self._grad_sync is not None else 1.0
+            ops.reduce_slabs(w["slabs_a"], out=w["flat_g"][:P_a], scale=scale)
+            ops.reduce_slabs(w["slabs_c"], out=w["flat_g"][P_a:], scale=scale)
+            if self._grad_sync is not None:
+                self._grad_sync.all_reduce_sum_(w["flat_g"])
+            adam(net.flat.data, w["flat_g"].view(1, -1), self.exp_avg, self.exp_avg_sq, max_grad_norm=self.max_grad_norm,
+                 work=self._adam_work)
         scal = torch.empty(1, 4, dtype=torch.float32, device=dev)
         ops.ppo_finalize_many(w["partial"], (na + nv) * 4, w["nb"], w["M"], self._cfg, scal)
         return scal[0]

@@ -33,6 +33,25 @@ constexpr int kLdo = 18;
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// W2 [128][128] -> LDS rows of kLdh floats: 16-B global loads (8 per thread, all in flight), 8-B LDS stores
+__device__ __forceinline__ void stage_w2(float *dst, const float *__restrict__ src, bool aligned) {
+    if (aligned) {
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = reinterpret_cast<const float4 *>(src)[threadIdx.x + u * kThreads];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e4 = threadIdx.x + u * kThreads, r = e4 >> 5, c = (e4 & 31) * 4;
+            float *p = dst + r * kLdh + c;
+            *reinterpret_cast<float2 *>(p) = make_float2(q[u].x, q[u].y);
+            *reinterpret_cast<float2 *>(p + 2) = make_float2(q[u].z, q[u].w);
+        }
+    } else {
+        for (int e = threadIdx.x; e < kH * kH; e += kThreads) dst[(e >> 7) * kLdh + (e & 127)] = src[e];
+    }
+    for (int e = threadIdx.x; e < kH * 2; e += kThreads) dst[(e >> 1) * kLdh + kH + (e & 1)] = 0.f;  // the two pad columns
+}
+
 struct RowsLay {  // LDS layout in floats
     int nJ, ld1, W1, W2, W3, B1, B2, B3, X, H1, H2, LG, total;
     __host__ __device__ explicit RowsLay(int D) {
@@ -82,10 +101,7 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
         const int r = e / ld1, c = e - r * ld1;
         lds[ly.W1 + e] = c < D ? g.P[oW1 + r * D + c] : 0.f;
     }
-    for (int e = tid; e < kH * kLdh; e += kThreads) {
-        const int r = e / kLdh, c = e - r * kLdh;
-        lds[ly.W2 + e] = c < kH ? g.P[oW2 + r * kH + c] : 0.f;
-    }
+    stage_w2(lds + ly.W2, g.P + oW2, (oW2 & 3) == 0);
     for (int e = tid; e < 16 * kLdh; e += kThreads) {
         const int r = e / kLdh, c = e - r * kLdh;
         lds[ly.W3 + e] = (r < A && c < kH) ? g.P[oW3 + r * kH + c] : 0.f;
@@ -403,10 +419,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
     const int K1 = g.K1, N = g.N;
     const int64_t n_blocks = (g.Mr + kRows - 1) / kRows;
     const int oB1 = kH * K1, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + kH;
-    for (int e = tid; e < kH * kLdh; e += kThreads) {
-        const int r = e / kLdh, c = e - r * kLdh;
-        lds[ly.W2 + e] = c < kH ? g.P[oW2 + r * kH + c] : 0.f;
-    }
+    stage_w2(lds + ly.W2, g.P + oW2, (oW2 & 3) == 0);
     if (tid < kH) { lds[ly.W3 + tid] = g.P[oW3 + tid]; lds[ly.B1 + tid] = g.P[oB1 + tid]; lds[ly.B2 + tid] = g.P[oB2 + tid]; }
     const float b3 = g.P[oB3];
 
@@ -423,33 +436,49 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
     // slice staging: W1 slice = 128 rows x 8 float4 (two per thread), observation slice = 32 rows x 8 float4 (threads < 256)
     const int wr0 = tid >> 3, wp = tid & 7;          // W1 rows wr0 and wr0 + 64, float4 piece wp
     const int xr = tid >> 3;                          // observation row (tid < 256)
-    f4 rw[2], rx;
+    // three register sets: slice s + 3 is requested while slice s is multiplied, so a slice has ~3 compute phases to
+    // arrive (one phase is ~0.4 us of MFMA work, an L2 round trip 1-2 us)
+    f4 rw[3][2], rx[3];
     int64_t x_row = -1;
-    auto fetch_slice = [&](int s, bool with_w) {
+    auto fetch_slice = [&](int s, int set, bool with_w) {
         const int k = kKs * s + 4 * wp;
+        const bool whole = k + 3 < K1 && (K1 & 3) == 0;  // 16-B aligned, inside the row
         if (with_w) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float *src = g.P + (size_t)(wr0 + 64 * h) * K1 + k;
+                if (whole) {
+                    const float4 q = *reinterpret_cast<const float4 *>(src);
+                    rw[set][h] = f4{q.x, q.y, q.z, q.w};
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rw[h][j] = k + j < K1 ? src[j] : 0.f;
+                    for (int j = 0; j < 4; ++j) rw[set][h][j] = k + j < K1 ? src[j] : 0.f;
+                }
             }
         }
         if (tid < 256) {
+            if (x_row >= 0 && whole) {
+                const float4 q = *reinterpret_cast<const float4 *>(g.obs + x_row * K1 + k);
+                rx[set] = f4{q.x, q.y, q.z, q.w};
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rx[j] = (x_row >= 0 && k + j < K1) ? g.obs[x_row * K1 + k + j] : 0.f;
+                for (int j = 0; j < 4; ++j) rx[set][j] = (x_row >= 0 && k + j < K1) ? g.obs[x_row * K1 + k + j] : 0.f;
+            }
         }
     };
-    auto commit_slice = [&](int buf, bool with_w) {
+    auto commit_slice = [&](int buf, int set, bool with_w) {
         if (with_w) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) lds[ly.WS + buf * kH * kLds + (wr0 + 64 * h) * kLds + 4 * wp + j] = rw[h][j];
+            for (int h = 0; h < 2; ++h) {
+                float *dst = lds + ly.WS + buf * kH * kLds + (wr0 + 64 * h) * kLds + 4 * wp;  // 8-B aligned (34 = 2 x 17)
+                *reinterpret_cast<float2 *>(dst) = make_float2(rw[set][h][0], rw[set][h][1]);
+                *reinterpret_cast<float2 *>(dst + 2) = make_float2(rw[set][h][2], rw[set][h][3]);
+            }
         }
         if (tid < 256) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) lds[ly.XS + buf * kRows * kLds + xr * kLds + 4 * wp + j] = rx[j];
+            float *dst = lds + ly.XS + buf * kRows * kLds + xr * kLds + 4 * wp;
+            *reinterpret_cast<float2 *>(dst) = make_float2(rx[set][0], rx[set][1]);
+            *reinterpret_cast<float2 *>(dst + 2) = make_float2(rx[set][2], rx[set][3]);
         }
     };
     __syncthreads();
@@ -463,12 +492,14 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
         // ---- L1: H1 = relu(X W1^T + b1), K-slices through the double buffer ----
         {
             f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-            fetch_slice(0, true);
-            commit_slice(0, true);
+            fetch_slice(0, 0, true);
+            if (NS > 1) fetch_slice(1, 1, true);
+            if (NS > 2) fetch_slice(2, 2, true);
+            commit_slice(0, 0, true);
             __syncthreads();
-#pragma unroll 1
+#pragma unroll
             for (int s = 0; s < NS; ++s) {
-                if (s + 1 < NS) fetch_slice(s + 1, true);
+                if (s + 3 < NS) fetch_slice(s + 3, s % 3, true);  // (set s % 3 went to LDS before slice s was multiplied)
                 const float *pa = lds + ly.XS + (s & 1) * kRows * kLds + c16 * kLds + kq;
                 const float *pb = lds + ly.WS + (s & 1) * kH * kLds + col * kLds + kq;
 #pragma unroll
@@ -477,7 +508,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
                     acc[0] = mfma4(pa[k0], bv, acc[0]);
                     acc[1] = mfma4(pa[16 * kLds + k0], bv, acc[1]);
                 }
-                if (s + 1 < NS) commit_slice((s + 1) & 1, true);
+                if (s + 1 < NS) commit_slice((s + 1) & 1, (s + 1) % 3, true);
                 __syncthreads();
             }
             const float bb = lds[ly.B1 + col];
@@ -619,8 +650,10 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
         // slices in groups of GS: a group's 2 GS accumulator tiles live in registers, then go to the slab
         constexpr int GS = NS > 4 ? 4 : NS;
         const bool first_blk = blk == (int64_t)blockIdx.x;
-        fetch_slice(0, false);
-        commit_slice(0, false);
+        fetch_slice(0, 0, false);
+        if (NS > 1) fetch_slice(1, 1, false);
+        if (NS > 2) fetch_slice(2, 2, false);
+        commit_slice(0, 0, false);
         __syncthreads();
 #pragma unroll
         for (int g0 = 0; g0 < NS; g0 += GS) {
@@ -631,7 +664,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
             for (int q = 0; q < GS; ++q) {
                 const int s = g0 + q;
                 if (s < NS) {
-                    if (s + 1 < NS) fetch_slice(s + 1, false);
+                    if (s + 3 < NS) fetch_slice(s + 3, s % 3, false);
                     const float *pa = lds + ly.H1 + kq * kLdh + col;                            // A[i = out o][k = row]
                     const float *pb = lds + ly.XS + (s & 1) * kRows * kLds + kq * kLds + c16;   // B[k = row][j = slice col]
 #pragma unroll
@@ -640,7 +673,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
                         gW1[2 * q] = mfma4(av, pb[r0 * kLds], gW1[2 * q]);
                         gW1[2 * q + 1] = mfma4(av, pb[r0 * kLds + 16], gW1[2 * q + 1]);
                     }
-                    if (s + 1 < NS) commit_slice((s + 1) & 1, false);
+                    if (s + 1 < NS) commit_slice((s + 1) & 1, (s + 1) % 3, false);
                     __syncthreads();
                 }
             }
@@ -768,12 +801,13 @@ TSM_EXPORT int64_t tsm_ppo_critic_rows_param_count(int32_t in_dim, int32_t hidde
     return (int64_t)hidden * in_dim + hidden + (int64_t)hidden * hidden + hidden + hidden + 1;
 }
 
-// workgroups (= gradient slabs) for Mr joint rows: one block of 32 rows at a time; half the CUs by default (a slab is
-// 264 KB for the 384-wide critic: fewer, longer-running workgroups keep the slab traffic below the compute time)
+// workgroups (= gradient slabs) for Mr joint rows: blocks of 32 rows, one workgroup per CU (a block is a latency-bound
+// chain of phases: measured 68 us with 256 workgroups x 1 block against 123 us with 128 x 2 at 8192 rows, although every
+// workgroup writes a 264 KB slab for the 384-wide critic)
 TSM_EXPORT int tsm_ppo_critic_rows_grid(int64_t Mr) {
     if (Mr <= 0) return 0;
     const int64_t blocks = ceil_div(Mr, kRows);
-    const int cap = n_cu() / 2 > 0 ? n_cu() / 2 : 1;
+    const int cap = n_cu();
     return (int)(blocks < cap ? blocks : cap);
 }
 
