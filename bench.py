@@ -330,7 +330,7 @@ def c3_rooflines(device):
     flop = rows * f_critic + 3 * (samples * f_actor + rows * f_critic)
     steps = len(split_bounds(rows, mb // N, True))
     out = [{"kernel": "C3 whole GAE + PPO update (GenericPPO.update: V(obs_next), GAE, advantage statistics, %d gradient "
-                      "steps of actor-rows kernel + critic GEMMs + Adam; one hipGraph replay)" % steps,
+                      "steps of actor-rows kernel + critic-rows kernel + 2 Adam; one hipGraph replay)" % steps,
             "n_env": n_env, "n_agent": N, "T": T, "minibatch": mb, "bound": "mfma", "ms_per_update": t_upd,
             "flop_per_update": flop, "achieved": flop / (t_upd * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
             "unit": "TFLOP/s", "frac": flop / (t_upd * 1e-3) / MFMA_F32_PEAK, "collect_ms": t_col,
@@ -371,6 +371,39 @@ def c3_rooflines(device):
                 "achieved": a_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": a_flop / tot / MFMA_F32_PEAK, "n_blocks": nb, "algorithmic_bytes_per_launch": a_bytes,
                 "slab_bytes_per_launch": nb * net.n_actor * 4, "traffic": pmc_traffic("ppo_actor_rows_kernel", nb * 512)})
+    # (iii) the critic step alone: the same minibatch as whole joint rows (mb / N rows of N * D floats)
+    mr = mb // N
+    joint, ret = buf.obs_store[:T].reshape(rows, N * D), torch.randn(n, device=device)
+    rid = torch.randperm(rows, device=device)[:mr].contiguous()
+    nbc = ops.ppo_critic_rows_grid(mr)
+    cslabs = torch.empty(nbc, net.critic.flat.numel(), device=device)
+    cpart = torch.empty(nbc * 4, dtype=torch.float64, device=device)
+    fc = lambda: ops.ppo_critic_rows_update(net.critic.flat.data, joint, ret, algo._cfg, N, H, rows=rid, Mr=mr, n_blocks=nbc,  # noqa: E731
+                                            slabs=cslabs, partial=cpart)
+    fc()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(10):
+            fc()
+    g.replay()
+    torch.cuda.synchronize()
+    tot = 0.0
+    for _ in range(5):
+        e0, e1 = ev(), ev()
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1) * 1e-3 / 10 / 5
+    c_flop, c_bytes = 3 * f_critic * mr, (4 * N * D + 8 + 4 * N) * mr
+    out.append({"kernel": "ppo_critic_rows_kernel<12> (centralized critic 384-128-128-1 on joint rows: forward + value loss of "
+                          "the row's 8 agents + backward in one launch)",
+                "rows": mr, "samples": mb, "bound": "mfma", "flop_per_launch": c_flop, "us_per_launch": tot * 1e6,
+                "achieved": c_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": c_flop / tot / MFMA_F32_PEAK, "n_blocks": nbc, "algorithmic_bytes_per_launch": c_bytes,
+                "slab_bytes_per_launch": nbc * net.critic.flat.numel() * 4,
+                "traffic": pmc_traffic("ppo_critic_rows_kernel", nbc * 512)})
     return out
 
 
@@ -556,13 +589,20 @@ def run_tag(a, device, rank, world, dist):
     trainer = LeaguePlayTrainer(mgr, matchmaking="random")
     np.random.seed(1626)  # matchmaking draws must agree on every rank
 
+    marks = []
+
     def step():
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         with policy_within_training_step(mgr):
+            e[0].record()
             cs = col.collect(n_step=n_env * T)
+            e[1].record()
             batch = agent_batches_from_buffer(buf, env.agents)
             batch["good"], batch["adversaries"] = batch["agent_0"], batch["adversary_0"]
             losses = trainer.train_step(batch)
+            e[2].record()
         col.reset_buffer(keep_statistics=True)
+        marks.append(e)
         return cs, losses
 
     for _ in range(a.warmup):
@@ -598,6 +638,8 @@ def run_tag(a, device, rank, world, dist):
                "config": {"workload": "simple_tag_v3 3 adversaries + 1 prey, 2 obstacles, grouped PPO (one policy per team), "
                                       "LeaguePlayTrainer, num_envs=%d per GPU, T=%d" % (n_env, T),
                           "parallelism": "env-shard x%d, one packed gradient all-reduce per step for both teams" % world},
+               "collect_ms": float(np.median([e[0].elapsed_time(e[1]) for e in marks[-a.steps:]])),
+               "league_train_step_ms": float(np.median([e[1].elapsed_time(e[2]) for e in marks[-a.steps:]])),
                "losses": {k: float(v["loss"]) for k, v in losses.items()}}
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical

@@ -59,20 +59,32 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         if rank == 0:  # both shards' gradients on one process, mean, one Adam step
             ref = DiscreteActorCritic(D, A, H, device=DEV, seed=10)
             assert torch.equal(ref.flat.data, p0)
-            halves = []
+            halves, shards, pack = [], [], 0.0
             for rk in range(world):
                 pb = _synthetic_pb(100 + rk, 8, 25)
                 np.random.seed(5)
                 perm = torch.as_tensor(np.random.permutation(200)).to(DEV)
                 ids = algo._sample_ids(pb, None)[perm]
-                stats = ops.ppo_adv_stats(pb["adv"], torch.tensor([0, 200], device=DEV), perm=ids)
+                st = ops.ppo_adv_stats(pb["adv"], torch.tensor([0, 200], device=DEV), perm=ids).double()
+                n = torch.tensor([200.0], dtype=torch.float64, device=DEV)
+                mean, var = st[:, 0], st[:, 1] * st[:, 1]  # (n, sum x, sum x^2) as GradSync.merge_adv_stats_ packs them
+                pack = pack + torch.stack([n, n * mean, (n - 1.0) * var + n * mean * mean], dim=1)
+                shards.append((pb, ids))
+            gmean = pack[:, 1] / pack[:, 0]
+            gstd = ((pack[:, 2] - pack[:, 0] * gmean * gmean) / (pack[:, 0] - 1.0)).sqrt()
+            stats = torch.stack([gmean, gstd], dim=1).float()  # statistics of the GLOBAL minibatch (both shards)
+            union = torch.cat([pb["adv"][ids] for pb, ids in shards]).double()
+            assert float(stats[0, 0]) == pytest.approx(float(union.mean()), abs=1e-6)
+            assert float(stats[0, 1]) == pytest.approx(float(union.std()), rel=1e-6)
+            for pb, ids in shards:
                 slabs, _ = ops.ppo_update_fused(p0, pb["obs"], pb["act"], pb["logp_old"], pb["adv"], pb["ret"], algo._cfg, A, H,
                                                 adv_stats=stats[0], perm=ids)
                 halves.append(ops.reduce_slabs(slabs, scale=1.0 / world))
             g = halves[0] + halves[1]
             p_ref = p0.clone()
             ops.adam_step(p_ref, g.view(1, -1), torch.zeros_like(p0), torch.zeros_like(p0), 1, lr=1e-3, max_grad_norm=0.5)
-            assert torch.equal(p_ref, net.flat.data)  # bit for bit: the update on the averaged gradient
+            assert torch.equal(p_ref, net.flat.data)  # bit for bit: the single-GPU update on the union minibatch's statistics
+            #                                           and the averaged gradient
         # ---- (2) PPO.update on two env shards: replicas stay bit-identical over synced updates ----
         env = DeviceSimpleSpreadVectorEnv(32, 3, device=DEV, seed=50 + rank)  # this rank's shard
         buf = DeviceVectorReplayBuffer(32 * 25, 32, 3, D, device=DEV)

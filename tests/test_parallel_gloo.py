@@ -111,6 +111,24 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         assert ("the number of gradient steps per update", 18) in sync._checked
         with pytest.raises(ValueError, match="disagree"):
             sync.require_equal(30 + rank, "the number of gradient steps per update")
+        # advantage statistics of the GLOBAL minibatch: every rank holds (mean, unbiased std) of its own
+        # part of each minibatch; one all-reduce turns them into the statistics of the union, identical on every rank
+        gen = torch.Generator().manual_seed(7)
+        parts = [[torch.randn(n, generator=gen) * (1 + k) + k for n in (40, 64)] for k in range(world)]  # [rank][minibatch]
+        mine = torch.tensor([[float(x.mean()), float(x.std())] for x in parts[rank]], dtype=torch.float32)
+        counts = torch.tensor([x.numel() for x in parts[rank]])
+        sync.merge_adv_stats_(mine, counts)
+        for j in range(2):
+            union = torch.cat([parts[k][j] for k in range(world)]).double()
+            assert mine[j, 0].item() == pytest.approx(float(union.mean()), rel=1e-6, abs=1e-6)
+            assert mine[j, 1].item() == pytest.approx(float(union.std()), rel=1e-6)
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert all(torch.equal(both[0], b) for b in both)  # bit-identical on every rank
+        sync.global_adv_stats = False                       # rank-local statistics: no collective, untouched
+        local = torch.tensor([[1.0, 2.0]])
+        assert torch.equal(sync.merge_adv_stats_(local, torch.tensor([5])), torch.tensor([[1.0, 2.0]]))
+        sync.global_adv_stats = True
         np.save(os.path.join(out_dir, f"p{rank}.npy"), p.numpy())
     finally:
         dist.destroy_process_group()

@@ -263,6 +263,14 @@ class PPO(nn.Module):
             return (base[:, None] * N + torch.arange(N, device=dev)[None, :]).reshape(-1)
         return base * N + agent
 
+    def _global_adv_stats(self, stats, mb_start):
+        """Data-parallel replicas normalise with the statistics of the GLOBAL minibatch (the union over the ranks):
+        one small all-reduce for all minibatches in `stats` (parallel.GradSync.merge_adv_stats_); no-op on one GPU."""
+        gs = self._grad_sync
+        if gs is not None and stats is not None and gs.global_adv_stats:
+            gs.merge_adv_stats_(stats, mb_start[1:] - mb_start[:-1])
+        return stats
+
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
                            buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:
         """ppo.py:164-224 for one sample set (all lanes, or one agent's lanes under per-agent dispatch)."""
@@ -304,6 +312,7 @@ class PPO(nn.Module):
             perm = perm_local if ids is None else ids[perm_local]
             stats = (ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm, max_rows=max(e - s for s, e in bounds))
                      if self.advantage_normalization else None)
+            self._global_adv_stats(stats, mb_start)
             for j, (s, e) in enumerate(bounds):
                 M = e - s
                 nb = ops.ppo_update_grid(M)
@@ -438,6 +447,7 @@ class PPO(nn.Module):
                 if "mb_start_all" in w:
                     ops.ppo_adv_stats(w["adv"], w["mb_start_all"], perm=w["perm"].view(-1), out=w["stats"].view(-1, 2),
                                       max_rows=max(e - s for s, e in bounds))
+                    self._global_adv_stats(w["stats"].view(-1, 2), w["mb_start_all"])
                 k = 0
                 for gi in range(len(groups)):
                     for r in range(repeat):
@@ -447,6 +457,7 @@ class PPO(nn.Module):
                         if self.advantage_normalization and "mb_start_all" not in w:
                             ops.ppo_adv_stats(w["adv"], w["mb_start"], perm=perm, out=w["stats"][gi, r],
                                               max_rows=max(e - s for s, e in bounds))
+                            self._global_adv_stats(w["stats"][gi, r], w["mb_start"])
                         for j, (s, e) in enumerate(bounds):
                             nb = ops.ppo_update_grid(e - s)
                             ops.ppo_update_fused(P, obs, act, w["logp"], w["adv"].view(-1), w["ret"].view(-1), self._cfg,

@@ -306,7 +306,8 @@ class GenericPPO(PPO):
                 stats = None
                 if self.advantage_normalization:
                     stats = ops.ppo_adv_stats(pb["adv"], mb_all, perm=lanes.reshape(-1),
-                                              max_rows=max(e - s for s, e in bounds) * unit).view(len(groups), repeat, len(bounds), 2)
+                                              max_rows=max(e - s for s, e in bounds) * unit)
+                    stats = self._global_adv_stats(stats, mb_all).view(len(groups), repeat, len(bounds), 2)
                 k = 0
                 for gi in range(len(groups)):
                     for r in range(repeat):
@@ -389,6 +390,7 @@ class GenericPPO(PPO):
             lanes = (perm.view(-1, 1) * N + lane_of_row).reshape(-1) if row_mode else perm
             stats = (ops.ppo_adv_stats(pb["adv"], mb_start, perm=lanes, max_rows=max(e - s for s, e in bounds) * unit)
                      if self.advantage_normalization else None)
+            self._global_adv_stats(stats, mb_start)
             for j, (s, e) in enumerate(bounds):
                 scal.append(self._grad_step(pb, lanes[s * unit:e * unit].contiguous(), None if stats is None else stats[j],
                                             rows=perm[s:e].contiguous() if row_mode else None))

@@ -496,7 +496,15 @@ __device__ void stage_net_flat(float *lds, const LayN<H> &ln, const Dims &d, con
     if (threadIdx.x < 16) lds[ln.B3 + threadIdx.x] = threadIdx.x < (NET ? 1 : d.A) ? P[ob3 + threadIdx.x] : 0.f;
 }
 
-template <int H, int NET>
+// slab store flavour (diagnostics, tools/sweep_slab.py): 0 = non-temporal (default: consumed once, by the next kernel),
+// 1 = plain write-back, 2 = agent-scope relaxed atomic store (sc1 write-through)
+template <int ST>
+__device__ __forceinline__ void slab_store(float v, float *p) {
+    if (ST == 0) __builtin_nontemporal_store(v, p);
+    else if (ST == 1) *p = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int H, int NET, int ST>
 __device__ __forceinline__ void ppo_update_net(
     float *lds, const float *__restrict__ P, const float *__restrict__ img, const Dims &d, const float *__restrict__ obs,
     const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
@@ -761,24 +769,24 @@ __device__ __forceinline__ void ppo_update_net(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = kq * 4 + r;
-        if (NET == 0 && row < d.A) __builtin_nontemporal_store(g_W3[r], &S[po.aW3 + row * H + 16 * w + colq]);
+        if (NET == 0 && row < d.A) slab_store<ST>(g_W3[r], &S[po.aW3 + row * H + 16 * w + colq]);
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
-            __builtin_nontemporal_store(g_W2[jb][r], &S[oW2 + (16 * w + row) * H + 16 * jb + colq]);
+            slab_store<ST>(g_W2[jb][r], &S[oW2 + (16 * w + row) * H + 16 * jb + colq]);
 #pragma unroll
         for (int jb = 0; jb < kMaxJ; ++jb) {
             const int c = 16 * jb + colq;
-            if (jb < d.nJ && c < d.D) __builtin_nontemporal_store(g_W1[jb][r], &S[oW1 + (16 * w + row) * d.D + c]);
+            if (jb < d.nJ && c < d.D) slab_store<ST>(g_W1[jb][r], &S[oW1 + (16 * w + row) * d.D + c]);
         }
     }
     if (threadIdx.x < H) {
         const int c = threadIdx.x;
-        __builtin_nontemporal_store(g_b1, &S[(NET ? po.cb1 : po.ab1) + c]);
-        __builtin_nontemporal_store(g_b2, &S[(NET ? po.cb2 : po.ab2) + c]);
-        if (NET) __builtin_nontemporal_store(g_W3c, &S[po.cW3 + c]);
+        slab_store<ST>(g_b1, &S[(NET ? po.cb1 : po.ab1) + c]);
+        slab_store<ST>(g_b2, &S[(NET ? po.cb2 : po.ab2) + c]);
+        if (NET) slab_store<ST>(g_W3c, &S[po.cW3 + c]);
     }
-    if (NET == 0 && threadIdx.x < d.A) __builtin_nontemporal_store(g_b3, &S[po.ab3 + threadIdx.x]);
-    if (NET == 1 && threadIdx.x == 0) __builtin_nontemporal_store(g_b3, &S[po.cb3]);
+    if (NET == 0 && threadIdx.x < d.A) slab_store<ST>(g_b3, &S[po.ab3 + threadIdx.x]);
+    if (NET == 1 && threadIdx.x == 0) slab_store<ST>(g_b3, &S[po.cb3]);
     // loss partial sums: actor -> clip objective [0], entropy [2]; critic -> value loss [1]
     {
         __shared__ double s_red[2][NT / 64];
@@ -799,7 +807,7 @@ __device__ __forceinline__ void ppo_update_net(
     }
 }
 
-template <int H>
+template <int H, int ST>
 __global__ __launch_bounds__(NT) void ppo_update_split_kernel(
     const float *__restrict__ P, const float *__restrict__ img, Dims d, const float *__restrict__ obs,
     const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
@@ -810,10 +818,10 @@ __global__ __launch_bounds__(NT) void ppo_update_split_kernel(
     // device-resident optimizer step count (hipGraph replay): bumped here, read by the Adam kernel that follows
     if (opt_step_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *opt_step_dev += 1;
     if (blockIdx.y == 0)
-        ppo_update_net<H, 0>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
+        ppo_update_net<H, 0, ST>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
                              loss_partial);
     else
-        ppo_update_net<H, 1>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
+        ppo_update_net<H, 1, ST>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
                              loss_partial);
 }
 
@@ -946,18 +954,22 @@ TSM_EXPORT int tsm_policy_forward(const float *params, const float *param_image,
 
 // diagnostics (not in the public header): 0 = one net per workgroup (default), 1 = both nets in one workgroup
 static int g_update_variant = 0;
+static int g_slab_store = 0;
+extern "C" __attribute__((visibility("default"))) void tsm_debug_set_slab_store(int v) { g_slab_store = v; }
 extern "C" __attribute__((visibility("default"))) void tsm_debug_set_update_variant(int v) { g_update_variant = v; }
 
 TSM_EXPORT int tsm_ppo_update_grid(int64_t M, int32_t max_blocks) {
-    // One-net workgroups need 52 KB of LDS: three fit on a CU (768 on the chip).  The rule comes from a sweep of the
+    // One-net workgroups need 52 KB of LDS: three fit on a CU (768 on the chip).  The rule comes from sweeps of the
     // gradient step (update + Adam, us) over the slab count n_blocks -- every slab is 45 KB written here and read back
     // by Adam, so fewer slabs pay for a second tile per workgroup once the chip is full:
-    //   tiles  128: 14.8 @128 | 18.3 @64        256: 19.4 @256 | 19.3 @128      320: 22.0 @160 | 22.2 @320 | 24.9 @107
-    //          384: 22.4 @192 | 25.1 @384       512: 24.8 @256 | 25.5 @384     1024: 34.3 @384 | 35.7 @256 | 44.7 @512
-    //         4096: 88 @384 | 103 @256 | 112 @512
+    //   tiles  128: 14.8 @128 | 18.3 @64        256: 19.8 @256 | 19.2 @128 | 25.2 @86 | 27.0 @64 (tools/sweep_slab.py)
+    //          320: 22.0 @160 | 22.2 @320 | 24.9 @107                       384: 22.4 @192 | 25.1 @384
+    //          512: 24.8 @256 | 25.5 @384     1024: 34.3 @384 | 35.7 @256 | 44.7 @512     4096: 88 @384 | 103 @256 | 112 @512
+    // 256 tiles (the headline minibatch of 4096 rows) therefore run as 128 pairs of 2 tiles: the same time within noise
+    // and half the slab traffic (5.7 MB written + 5.7 MB read back per gradient step instead of 11.4 + 11.4).
     const int64_t n_tiles = ceil_div(M > 0 ? M : 1, R);
     int64_t g;
-    if (n_tiles <= 256) g = n_tiles;
+    if (n_tiles < 256) g = n_tiles;
     else if (n_tiles < 1024) g = (n_tiles + 1) / 2 < 256 ? (n_tiles + 1) / 2 : 256;
     else g = 384;
     if (max_blocks > 0 && g > max_blocks) g = max_blocks;
@@ -1005,7 +1017,9 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
     if (g_update_variant == 0 && !g_tsm_stamps) {
         // one net per workgroup (grid.y = actor | critic): see ppo_update_split_kernel
         const LayN<64> ln(d);
-        hipLaunchKernelGGL((ppo_update_split_kernel<64>), dim3((unsigned)n_blocks, 2), dim3(NT),
+        auto kern = g_slab_store == 1 ? ppo_update_split_kernel<64, 1>
+                    : g_slab_store == 2 ? ppo_update_split_kernel<64, 2> : ppo_update_split_kernel<64, 0>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks, 2), dim3(NT),
                            (size_t)ln.total * sizeof(float), st, params, param_image, d, obs, act, logp_old, adv, returns,
                            v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out, loss_partial_out, opt_step_dev);
     } else {  // both nets in one workgroup (kept for the phase stamps of tools/stamp_update.py and as an A/B reference)

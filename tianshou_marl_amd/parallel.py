@@ -7,7 +7,10 @@ data-path collective; only the shared-policy update exchanges data -- the flat g
 actor+critic vector (~11 k f32 = 45 KB: latency-bound over xGMI) is summed with one
 `torch.distributed.all_reduce` (backend "nccl" == RCCL on ROCm; "gloo" on CPU for tests) per
 gradient step, after which every rank applies the identical Adam step, keeping replicas bit-identical.
-Advantage normalisation uses the rank-local minibatch statistics (ppo.py:184-186 applied per shard).
+Advantage normalisation (ppo.py:184-186) uses the statistics of the GLOBAL minibatch -- the union of the ranks'
+minibatches of one gradient step: the per-minibatch (n, sum, sum of squares) of all minibatches of an update travel in
+ONE small f64 all-reduce per update (`GradSync.merge_adv_stats_`), so the sharded update is the single-GPU update on the
+union minibatch; `global_adv_stats=False` keeps the rank-local statistics and saves that collective.
 """
 from __future__ import annotations
 
@@ -29,6 +32,7 @@ class GradSync:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._checked: set = set()
+        self.global_adv_stats = True  # minibatch advantage statistics over all ranks (merge_adv_stats_)
         self._probe_device = torch.device("cpu")  # attach_data_parallel points it at the replica's device for RCCL
 
     def all_reduce_mean_(self, flat: torch.Tensor) -> torch.Tensor:
@@ -72,6 +76,28 @@ class GradSync:
             raise ValueError(f"data-parallel ranks disagree on {what} (this rank: {list(names)}): seed the trainers' "
                              "matchmaking identically on every rank")
 
+    def merge_adv_stats_(self, stats: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+        """stats [..., 2] = rank-local (mean, unbiased std) of the advantages of each minibatch, counts [...] = its rows on
+        this rank -> in place, the (mean, unbiased std) of the union of all ranks' minibatch ("the
+        advantage statistics make the sharded minibatch normalisation identical to a single global minibatch").  One f64
+        all-reduce of (n, sum x, sum x^2) per minibatch, every minibatch of the update in one message; every rank ends
+        with bit-identical statistics."""
+        import os
+
+        # (a one-rank group skips it, except in the single-GPU rehearsal of the captured multi-GPU path, TSM_FORCE_DIST)
+        if not self.global_adv_stats or (self.world == 1 and not os.environ.get("TSM_FORCE_DIST")):
+            return stats
+        st = stats.reshape(-1, 2).to(torch.float64)
+        n = counts.reshape(-1).to(torch.float64)
+        mean, var = st[:, 0], st[:, 1] * st[:, 1]
+        pack = torch.stack([n, n * mean, (n - 1.0).clamp_min(0.0) * var + n * mean * mean], dim=1).contiguous()
+        self.dist.all_reduce(pack, op=self.dist.ReduceOp.SUM, group=self.group)
+        N, S1, S2 = pack[:, 0], pack[:, 1], pack[:, 2]
+        gmean = S1 / N
+        gvar = ((S2 - N * gmean * gmean) / (N - 1.0).clamp_min(1.0)).clamp_min(0.0)
+        stats.reshape(-1, 2).copy_(torch.stack([gmean, gvar.sqrt()], dim=1).to(stats.dtype))
+        return stats
+
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         self.dist.broadcast(t, src=src, group=self.group)
         return t
@@ -108,12 +134,13 @@ def learn_lockstep(jobs, sync: "GradSync") -> list:
     return results
 
 
-def attach_data_parallel(algo, dist, group=None) -> GradSync:
+def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) -> GradSync:
     """Make `algo` a data-parallel replica: parameters and optimizer state are broadcast from rank 0, and every gradient
     step all-reduces the flat gradient.  `algo` is a PPO-family algorithm, or a policy manager
     (FlexibleMultiAgentPolicyManager: every distinct policy of `.policies` is attached to ONE shared GradSync, and the
     MARL trainers then reduce the groups that train in a step together, `learn_lockstep`)."""
     sync = GradSync(dist, group)
+    sync.global_adv_stats = bool(global_adv_stats)
     if hasattr(algo, "policies") and not hasattr(algo, "net"):
         seen = []
         for pol in algo.policies.values():
