@@ -597,7 +597,7 @@ def run_tag(a, device, rank, world, dist):
             e[0].record()
             cs = col.collect(n_step=n_env * T)
             e[1].record()
-            batch = agent_batches_from_buffer(buf, env.agents)
+            batch = agent_batches_from_buffer(buf, env.agents, only=["agent_0", "adversary_0"])  # one learner per team
             batch["good"], batch["adversaries"] = batch["agent_0"], batch["adversary_0"]
             losses = trainer.train_step(batch)
             e[2].record()

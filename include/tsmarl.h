@@ -220,6 +220,13 @@ int64_t tsm_ppo_adv_stats_work_elems(int32_t n_mb, int64_t max_rows);
 int tsm_ppo_adv_stats_wide(const float *adv, const int64_t *perm, const int64_t *mb_start, int32_t n_mb,
                            int64_t max_rows, double *work, float *stats_out, void *stream);
 
+/* Env-sharded replicas: the advantage normalisation of ppo.py:184-186 over the GLOBAL minibatch (the union
+ * of the ranks' parts).  pack: stats [n_mb][2] = this rank's {mean, unbiased std} and its row counts mb_start[k+1] -
+ * mb_start[k] -> pack_out f64 [n_mb][3] = {n, sum x, sum x^2}; the caller sums pack over the ranks (one all-reduce
+ * for every minibatch of the update); unpack: summed pack -> stats_out [n_mb][2] = {mean, unbiased std} of the union. */
+int tsm_ppo_adv_stats_pack(const float *stats, const int64_t *mb_start, int32_t n_mb, double *pack_out, void *stream);
+int tsm_ppo_adv_stats_unpack(const double *pack, int32_t n_mb, float *stats_out, void *stream);
+
 /* One minibatch of M samples: sample i is row perm[i] of the full-batch arrays (perm == NULL:
  * row first_row + i).  logits [M][A] and value [M] are minibatch-contiguous network outputs.
  * Outputs: dlogits [M][A], dvalue [M] (already scaled by 1/M and the coefficients, i.e. d loss),
@@ -427,6 +434,46 @@ int tsm_mpe_tag_step(const tsm_mpe_tag_cfg *cfg_host, uint64_t seed, uint64_t *e
                      float *obs_cur_out, float *rew_out, uint8_t *terminated_out, uint8_t *truncated_out,
                      uint8_t *done_env_out, int auto_reset, uint64_t *rng_tick, uint64_t rng_tick_inc, void *stream);
 int tsm_u64_add(uint64_t *counter, uint64_t inc, void *stream);
+
+/* Persistent rollout for simple_tag under GROUPED policies  [a4 + a6 + a7 + a8 fused for BASELINE configs[4]]
+ * One launch == one Collector.collect(n_step = n_steps * n_env) on the batched simple_tag env with ONE 64-wide
+ * actor/critic per team (FlexibleMultiAgentPolicyManager(mode="grouped"), flexible_policy.py:96-98; collector loop
+ * data/collector.py:854-1069): params[0] serves the adversaries (agent columns [0, n_adv)), params[1] the good agents
+ * (both flat vectors as for tsm_policy_forward; pass the same pointer twice for one shared policy).  Bit-identical to,
+ * per step, tsm_policy_forward on each team's agent-major rows (sampling counter of step t, column a, env e:
+ * offset[team] + *offset_dev + t n_env NA + a n_env + e, as MultiAgentPolicy hands a team's columns to its policy)
+ * -> tsm_mpe_tag_step -> tsm_vrb_add.  logp_store / vs_store receive each row's own policy outputs (nullable);
+ * V(obs_next) is not produced.  Everything else as tsm_rollout_spread. */
+typedef struct {
+    const float *params[2];
+    uint64_t policy_seed[2], offset[2];
+    int32_t mode[2]; /* per team: 1 sample, 2 dist.mode */
+    int32_t obs_dim, hidden, n_act;
+    int32_t env_major_counter; /* 0: counter a n_env + e inside a step (grouped policies); 1: e NA + a (ONE shared policy
+                                * called on the [n_env][NA] rows, params[0] == params[1]) */
+    const uint64_t *offset_dev;
+    tsm_mpe_tag_cfg env;
+    uint64_t env_seed;
+    uint64_t *episode_ctr;
+    float *agent_pos, *agent_vel, *landmark_pos;
+    int32_t *steps;
+    int32_t auto_reset, n_steps;
+    float *obs_cur_out;
+    void *vrb_state;
+    int64_t sub_size;
+    uint8_t *done_store;
+    float *obs_store, *obs_next_store, *rew_store, *logp_store, *vs_store;
+    int32_t *act_store;
+    uint8_t *term_store, *trunc_store;
+    int64_t *ptr_out;
+    double *ep_rew_out;
+    int64_t *ep_len_out, *ep_idx_out;
+    int64_t *ep_rec; /* compact episode record, layout as in tsm_rollout_desc (nullable) */
+    int32_t max_ep, _pad2;
+    uint64_t offset_inc; /* added to *offset_dev by the last workgroup to finish (done_ctr: zeroed u32 in HBM; NULL = off) */
+    uint32_t *done_ctr;
+} tsm_rollout_tag_desc;
+int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 128-wide actor, one gradient step in one launch  [a7, a14 at BASELINE configs[2]: actor obs-128-128-A]

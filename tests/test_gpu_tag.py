@@ -250,3 +250,84 @@ def test_configs4_at_full_size_4096_envs():
     assert not torch.equal(before["adversaries"], teams["adversaries"].net.flat.data)
     for p in teams.values():
         assert torch.isfinite(p.net.flat.data).all()
+
+
+def _tag_job(n_env, n_adv, n_good, n_obst, T, fused, slots, shared=False, deterministic=False):
+    env = DeviceSimpleTagVectorEnv(n_env, n_good, n_adv, n_obst, max_cycles=T, device=DEV, seed=11)
+    mk = lambda s: PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=DEV, seed=s), seed=s, deterministic_eval=deterministic)  # noqa: E731
+    if shared:
+        mgr = FlexibleMultiAgentPolicyManager(mk(21), env, mode="shared")
+    else:
+        mgr = FlexibleMultiAgentPolicyManager({"adversaries": mk(21), "good": mk(22)}, env, mode="grouped",
+                                              agent_groups=env.agent_groups)
+    buf = DeviceVectorReplayBuffer(n_env * slots, n_env, env.n_agent, env.obs_dim, device=DEV)
+    col = Collector(mgr, env, buf, fused_rollout=fused, use_graph=False)
+    col.reset()
+    return env, mgr, buf, col
+
+
+# (512, 3, 1, 2): the configs[4] shard (128 workgroups); (300, 2, 2, 1): two good agents; (9, 1, 1, 0): no obstacles, a
+# ragged last workgroup; (40, 4, 2, 3): six agents -> two worlds per workgroup, four dead tile rows
+@pytest.mark.parametrize("n_env,n_adv,n_good,n_obst,T,steps,shared", [
+    (512, 3, 1, 2, 25, 25, False), (300, 2, 2, 1, 5, 12, False), (9, 1, 1, 0, 4, 9, False), (40, 4, 2, 3, 6, 7, False),
+    (64, 3, 1, 2, 7, 10, True)])
+def test_fused_tag_rollout_is_bit_identical_to_unfused(n_env, n_adv, n_good, n_obst, T, steps, shared):
+    """csrc/rollout_tag.hip: ONE launch per collect() must reproduce, bit for bit, the unfused Collector loop under grouped
+    policies (per team policy_forward on agent-major rows -> tag step -> buffer add), across episode ends / re-initialised
+    worlds and across two consecutive collects."""
+    slots = steps + 3 + 1
+    outs = []
+    for fused in (False, True):
+        env, mgr, buf, col = _tag_job(n_env, n_adv, n_good, n_obst, T, fused, slots, shared=shared)
+        assert col._can_fuse() == fused
+        with policy_within_training_step(mgr):
+            st1 = col.collect(n_step=n_env * steps)
+            st2 = col.collect(n_step=n_env * 3)  # continues mid-episode
+        outs.append(dict(
+            obs=buf.obs_store.clone(), obs_next=buf.obs_next_store.clone(), act=buf.act_store.clone(),
+            rew=buf.rew_store.clone(), trunc=buf.trunc_store.clone(), term=buf.term_store.clone(),
+            logp=buf.logp_store.clone(), vs=buf.vs_store.clone(), done=buf.done_store.clone(),
+            state=buf.index.state.clone(), apos=env.agent_pos.clone(), avel=env.agent_vel.clone(),
+            lpos=env.landmark_pos.clone(), steps=env.steps.clone(), ep=env.episode_ctr.clone(), obs_cur=env.obs_cur.clone(),
+            tick=env.rng_tick.clone(), ret1=st1.returns, len1=st1.lens, n1=st1.n_collected_episodes,
+            ret2=st2.returns, n2=st2.n_collected_episodes))
+    a, b = outs
+    assert a["n1"] == n_env * (steps // T) and a["n1"] + a["n2"] == n_env * ((steps + 3) // T)
+    for k in a:
+        if isinstance(a[k], torch.Tensor):
+            assert torch.equal(a[k], b[k]), k
+        elif isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+
+
+def test_fused_tag_rollout_takes_the_mode_outside_training_steps():
+    """deterministic_eval policies act with dist.mode outside a training step (reinforce.py:167-192): the fused kernel
+    must switch per policy exactly as the unfused calls do."""
+    outs = []
+    for fused in (False, True):
+        env, mgr, buf, col = _tag_job(32, 3, 1, 2, 6, fused, 12, deterministic=True)
+        col.collect(n_step=32 * 8)  # not within a training step: argmax actions
+        outs.append((buf.act_store.clone(), buf.logp_store.clone(), buf.obs_store.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
+def test_agent_batches_fast_path_equals_the_indexed_gather():
+    """agent_batches_from_buffer reads equally filled sub-buffers as strided views; the general path gathers by
+    sample_indices(0).  Same rows, same order, same dtypes; `only` restricts the agents built."""
+    env, mgr, buf, col = _tag_job(48, 3, 1, 2, 6, True, 10)
+    with policy_within_training_step(mgr):
+        col.collect(n_step=48 * 10)
+    assert buf.host_uniform_len() == 10
+    fast = agent_batches_from_buffer(buf, env.agents)
+    some = agent_batches_from_buffer(buf, env.agents, only=["agent_0"])
+    assert "agent_0" in some and "adversary_0" not in some
+    buf._host_rows = None  # fill level unknown on the host: the indexed path
+    slow = agent_batches_from_buffer(buf, env.agents)
+    for name in env.agents:
+        for k in ("obs", "act", "rew", "obs_next", "terminated", "truncated"):
+            assert fast[name][k].dtype == slow[name][k].dtype and torch.equal(fast[name][k], slow[name][k]), (name, k)
+    assert torch.equal(fast["global_obs"], slow["global_obs"]) and torch.equal(fast["global_obs_next"], slow["global_obs_next"])
+    assert torch.equal(some["agent_0"].obs, slow["agent_0"].obs)

@@ -112,12 +112,25 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         with pytest.raises(ValueError, match="disagree"):
             sync.require_equal(30 + rank, "the number of gradient steps per update")
         # advantage statistics of the GLOBAL minibatch: every rank holds (mean, unbiased std) of its own
-        # part of each minibatch; one all-reduce turns them into the statistics of the union, identical on every rank
+        # part of each minibatch; pack -> ONE all-reduce -> unpack turns them into the statistics of the union, identical
+        # on every rank.  The pack / unpack arithmetic is a pair of HIP kernels in the product (checked bit for bit in
+        # tests/test_gpu_parallel.py); here the same formulas in torch stand in for them and the PROTOCOL is under test.
+        def pack_fn(stats, mb_start):
+            n = (mb_start[1:] - mb_start[:-1]).double()
+            m, sd = stats[:, 0].double(), stats[:, 1].double()
+            return torch.stack([n, n * m, (n - 1.0) * (sd * sd) + n * m * m], dim=1).contiguous()
+
+        def unpack_fn(pack, stats):
+            m = pack[:, 1] / pack[:, 0]
+            var = (pack[:, 2] - pack[:, 0] * m * m) / (pack[:, 0] - 1.0)
+            stats.copy_(torch.stack([m, var.clamp_min(0.0).sqrt()], dim=1).float())
+
+        sync._stat_codec = (pack_fn, unpack_fn)
         gen = torch.Generator().manual_seed(7)
-        parts = [[torch.randn(n, generator=gen) * (1 + k) + k for n in (40, 64)] for k in range(world)]  # [rank][minibatch]
+        parts = [[torch.randn(n, generator=gen) * (1 + k) + k for n in (40 + 8 * k, 64)] for k in range(world)]  # [rank][minibatch]
         mine = torch.tensor([[float(x.mean()), float(x.std())] for x in parts[rank]], dtype=torch.float32)
-        counts = torch.tensor([x.numel() for x in parts[rank]])
-        sync.merge_adv_stats_(mine, counts)
+        mb_start = torch.tensor([0, parts[rank][0].numel(), parts[rank][0].numel() + parts[rank][1].numel()])
+        sync.merge_adv_stats_(mine, mb_start)
         for j in range(2):
             union = torch.cat([parts[k][j] for k in range(world)]).double()
             assert mine[j, 0].item() == pytest.approx(float(union.mean()), rel=1e-6, abs=1e-6)
@@ -127,7 +140,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         assert all(torch.equal(both[0], b) for b in both)  # bit-identical on every rank
         sync.global_adv_stats = False                       # rank-local statistics: no collective, untouched
         local = torch.tensor([[1.0, 2.0]])
-        assert torch.equal(sync.merge_adv_stats_(local, torch.tensor([5])), torch.tensor([[1.0, 2.0]]))
+        assert torch.equal(sync.merge_adv_stats_(local, torch.tensor([0, 5])), torch.tensor([[1.0, 2.0]]))
         sync.global_adv_stats = True
         np.save(os.path.join(out_dir, f"p{rank}.npy"), p.numpy())
     finally:

@@ -64,6 +64,21 @@ class tsm_mpe_tag_cfg(C.Structure):
                 ("adv_accel", C.c_double), ("good_accel", C.c_double), ("adv_speed", C.c_double), ("good_speed", C.c_double)]
 
 
+class tsm_rollout_tag_desc(C.Structure):
+    _fields_ = [("params", C.c_void_p * 2), ("policy_seed", C.c_uint64 * 2), ("offset", C.c_uint64 * 2),
+                ("mode", C.c_int32 * 2), ("obs_dim", C.c_int32), ("hidden", C.c_int32), ("n_act", C.c_int32),
+                ("env_major_counter", C.c_int32), ("offset_dev", C.c_void_p), ("env", tsm_mpe_tag_cfg), ("env_seed", C.c_uint64),
+                ("episode_ctr", C.c_void_p), ("agent_pos", C.c_void_p), ("agent_vel", C.c_void_p),
+                ("landmark_pos", C.c_void_p), ("steps", C.c_void_p), ("auto_reset", C.c_int32), ("n_steps", C.c_int32),
+                ("obs_cur_out", C.c_void_p), ("vrb_state", C.c_void_p), ("sub_size", C.c_int64),
+                ("done_store", C.c_void_p), ("obs_store", C.c_void_p), ("obs_next_store", C.c_void_p),
+                ("rew_store", C.c_void_p), ("logp_store", C.c_void_p), ("vs_store", C.c_void_p),
+                ("act_store", C.c_void_p), ("term_store", C.c_void_p), ("trunc_store", C.c_void_p),
+                ("ptr_out", C.c_void_p), ("ep_rew_out", C.c_void_p), ("ep_len_out", C.c_void_p),
+                ("ep_idx_out", C.c_void_p), ("ep_rec", C.c_void_p), ("max_ep", C.c_int32), ("_pad2", C.c_int32),
+                ("offset_inc", C.c_uint64), ("done_ctr", C.c_void_p)]
+
+
 class tsm_mlp_desc(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("act", C.c_int32), ("dims", C.c_int32 * 9)]
 
@@ -105,6 +120,8 @@ SIGNATURES = {
     "tsm_categorical_logp_entropy": (_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "tsm_ppo_adv_stats": (_int, [_p, _p, _p, _i32, _p, _p]),
     "tsm_ppo_adv_stats_work_elems": (_i64, [_i32, _i64]),
+    "tsm_ppo_adv_stats_pack": (_int, [_p, _p, _i32, _p, _p]),
+    "tsm_ppo_adv_stats_unpack": (_int, [_p, _i32, _p, _p]),
     "tsm_ppo_adv_stats_wide": (_int, [_p, _p, _p, _i32, _i64, _p, _p, _p]),
     "tsm_ppo_loss_partial_elems": (_i64, [_i64]),
     "tsm_ppo_loss_fwd_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p,
@@ -131,6 +148,7 @@ SIGNATURES = {
                                    _int, _p, _u64, _p]),
     "tsm_rollout_spread": (_int, [C.POINTER(tsm_rollout_desc), _p]),
     "tsm_rollout_spread_actor": (_int, [C.POINTER(tsm_rollout_desc), _p]),
+    "tsm_rollout_tag": (_int, [C.POINTER(tsm_rollout_tag_desc), _p]),
     "tsm_mpe_tag_obs_dim": (_int, [C.POINTER(tsm_mpe_tag_cfg)]),
     "tsm_mpe_tag_reset": (_int, [C.POINTER(tsm_mpe_tag_cfg), _u64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "tsm_mpe_tag_step": (_int, [C.POINTER(tsm_mpe_tag_cfg), _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,

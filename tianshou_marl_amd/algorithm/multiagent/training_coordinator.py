@@ -324,23 +324,43 @@ class LeaguePlayTrainer(MATrainer):
         self.elo_ratings[loser] = rl + k * (0 - (1 - expected_w))
 
 
-def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True) -> Batch:
+def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, only: list | None = None) -> Batch:
     """The trainers' batch format straight from the device buffer (no host copy).
 
     Returns Batch({agent: Batch(obs, act, rew, obs_next, terminated, truncated)}, global_obs, global_obs_next) whose
     leaves are HBM tensors.  Rows are every stored joint step in env-major order (flat reference index order,
     `sample_indices(0)`); agent a's rows are column a of the joint rows; the "concatenate" global state of a row
-    is that row's `[N*D]` view (GlobalStateConstructor.build, ctde.py:291-294)."""
-    idx = buffer.index.sample_indices_all()
-    d = buffer.get_device(idx.cpu().numpy())
+    is that row's `[N*D]` view (GlobalStateConstructor.build, ctde.py:291-294).  `only`: build the batches of these
+    agents alone (a league / self-play step trains one agent per team).
+    Equally filled sub-buffers that start at slot 0 (what `collect(n_step)` leaves behind a `reset_buffer`) are read as
+    strided views of the time-major store -- one copy per field and agent, no index kernel and no host round trip."""
+    T = buffer.host_uniform_len()
+    if T is not None:
+        E = buffer.buffer_num
+        em = lambda x: x[:T].transpose(0, 1)  # noqa: E731  [E, T, ...] view: env-major rows without a copy
+        d = {"obs": em(buffer.obs_store), "act": em(buffer.act_store), "rew": em(buffer.rew_store),
+             "obs_next": em(buffer.obs_next_store) if buffer.obs_next_store is not None else None,
+             "terminated": em(buffer.term_store), "truncated": em(buffer.trunc_store)}
+        if d["obs_next"] is None:
+            d = None
+        else:
+            col = lambda x, a: x[:, :, a].reshape(E * T, *x.shape[3:])  # noqa: E731  (the reshape is the one copy)
+            full = lambda x: x.reshape(E * T, -1)  # noqa: E731
+    else:
+        d = None
+    if d is None:
+        idx = buffer.index.sample_indices_all()
+        d = buffer.get_device(idx.cpu().numpy())
+        col = lambda x, a: x[:, a].contiguous()  # noqa: E731
+        full = lambda x: x.reshape(x.shape[0], -1)  # noqa: E731
     out = Batch()
     for a, name in enumerate(agents):
-        out[name] = Batch(obs=d["obs"][:, a].contiguous(), act=d["act"][:, a].contiguous().to(torch.int64),
-                          rew=d["rew"][:, a].contiguous(), obs_next=d["obs_next"][:, a].contiguous(),
-                          terminated=d["terminated"][:, a].contiguous().bool(),
-                          truncated=d["truncated"][:, a].contiguous().bool())
+        if only is not None and name not in only:
+            continue
+        out[name] = Batch(obs=col(d["obs"], a), act=col(d["act"], a).to(torch.int64),
+                          rew=col(d["rew"], a), obs_next=col(d["obs_next"], a),
+                          terminated=col(d["terminated"], a).bool(), truncated=col(d["truncated"], a).bool())
     if global_state:
-        R = d["obs"].shape[0]
-        out["global_obs"] = d["obs"].reshape(R, -1)
-        out["global_obs_next"] = d["obs_next"].reshape(R, -1)
+        out["global_obs"] = full(d["obs"])
+        out["global_obs_next"] = full(d["obs_next"])
     return out

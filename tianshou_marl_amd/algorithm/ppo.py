@@ -268,7 +268,7 @@ class PPO(nn.Module):
         one small all-reduce for all minibatches in `stats` (parallel.GradSync.merge_adv_stats_); no-op on one GPU."""
         gs = self._grad_sync
         if gs is not None and stats is not None and gs.global_adv_stats:
-            gs.merge_adv_stats_(stats, mb_start[1:] - mb_start[:-1])
+            gs.merge_adv_stats_(stats.view(-1, 2), mb_start)
         return stats
 
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,

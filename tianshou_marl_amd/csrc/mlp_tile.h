@@ -64,9 +64,9 @@ struct POff {
 };
 
 template <int H>
-__device__ void stage_weights(float *lds, const Lay<H> &ly, const Dims &d, const float *__restrict__ P) {
+__device__ void stage_weights(float *lds, const Lay<H> &ly, const Dims &d, const float *__restrict__ P, int tid_in = -1) {
     const POff<H> po(d.D, d.A);
-    const int tid = threadIdx.x;
+    const int tid = tid_in < 0 ? (int)threadIdx.x : tid_in;  // NT threads take part (rollout_tag.hip: waves 4-7 pass tid - NT)
     // loads are issued in batches of U per thread before any LDS write, so a batch costs one memory round trip
     constexpr int U = 4;
     for (int e0 = tid; e0 < 2 * H * d.ld1; e0 += U * NT) {  // W1 actor|critic, zero padded

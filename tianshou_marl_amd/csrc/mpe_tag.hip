@@ -20,57 +20,11 @@
 //   pettingzoo_env.py:55-67).  Truncation at max_cycles; never terminates.
 // The step kernel runs one lane per (env, agent) on LDS-staged state (16 envs per workgroup); reset: one thread per env.
 #include "common.h"
-#include "philox.h"
+#include "mpe_tag_dev.h"
 
 namespace {
 
-constexpr int kMaxAgents = 8, kMaxObst = 4;
-
-struct TagCfg {
-    int n_env, n_adv, n_good, n_obst, max_cycles, obs_dim;
-    float dt, damping, contact_force, contact_margin;
-    float adv_size, good_size, obst_size, adv_accel, good_accel, adv_speed, good_speed;
-};
-
-__device__ __forceinline__ float uni(uint32_t bits, float lo, float hi) { return lo + (hi - lo) * tsm_u01(bits); }
-
-// positions ~ U(-1, 1)^2 for agents, U(-0.9, 0.9)^2 for obstacles; Philox counter (episode * n_env + e) * 16 + entity
-__device__ void tag_reset_env(const TagCfg &c, int e, uint64_t seed, uint64_t episode, float *ap, float *av, float *lp) {
-    const int NA = c.n_adv + c.n_good;
-    for (int i = 0; i < NA + c.n_obst; ++i) {
-        uint32_t r[4];
-        tsm_philox4(seed, (episode * (uint64_t)c.n_env + (uint64_t)e) * 16ull + (uint64_t)i, r);
-        if (i < NA) {
-            ap[2 * i] = uni(r[0], -1.f, 1.f); ap[2 * i + 1] = uni(r[1], -1.f, 1.f);
-            av[2 * i] = 0.f; av[2 * i + 1] = 0.f;
-        } else {
-            lp[2 * (i - NA)] = uni(r[0], -0.9f, 0.9f); lp[2 * (i - NA) + 1] = uni(r[1], -0.9f, 0.9f);
-        }
-    }
-}
-
-__device__ void tag_obs(const TagCfg &c, const float *ap, const float *av, const float *lp, int i, float *o) {
-    const int NA = c.n_adv + c.n_good;
-    int k = 0;
-    o[k++] = av[2 * i]; o[k++] = av[2 * i + 1];
-    o[k++] = ap[2 * i]; o[k++] = ap[2 * i + 1];
-    for (int l = 0; l < c.n_obst; ++l) { o[k++] = lp[2 * l] - ap[2 * i]; o[k++] = lp[2 * l + 1] - ap[2 * i + 1]; }
-    for (int j = 0; j < NA; ++j)
-        if (j != i) { o[k++] = ap[2 * j] - ap[2 * i]; o[k++] = ap[2 * j + 1] - ap[2 * i + 1]; }
-    for (int j = c.n_adv; j < NA; ++j)
-        if (j != i) { o[k++] = av[2 * j]; o[k++] = av[2 * j + 1]; }
-    while (k < c.obs_dim) o[k++] = 0.f;  // good agents: padded to the adversaries' width
-}
-
-__device__ __forceinline__ float softplus_k(float z, float k) {  // logaddexp(0, z) * k
-    return (z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z))) * k;
-}
-
-__device__ __forceinline__ float bound_pen(float x) {
-    if (x < 0.9f) return 0.f;
-    if (x < 1.0f) return (x - 0.9f) * 10.f;
-    return fminf(expf(2.f * x - 2.f), 10.f);
-}
+constexpr int kMaxAgents = kTagMaxAgents, kMaxObst = kTagMaxObst;
 
 __global__ void tag_reset_kernel(TagCfg c, uint64_t seed, uint64_t *episode_ctr, const int64_t *env_ids, int64_t n,
                                  float *apos, float *avel, float *lpos, int32_t *steps, float *obs) {
@@ -85,31 +39,6 @@ __global__ void tag_reset_kernel(TagCfg c, uint64_t seed, uint64_t *episode_ctr,
     for (int i = 0; i < NA; ++i) tag_obs(c, ap, av, lp, i, obs + ((int64_t)e * NA + i) * c.obs_dim);
 }
 
-// Element k of agent i's (zero-padded) observation -- the element-wise form of tag_obs for coalesced row writes.
-__device__ __forceinline__ float tag_obs_elem(const TagCfg &c, const float *ap, const float *av, const float *lp, int i,
-                                              int k) {
-    const int NA = c.n_adv + c.n_good;
-    if (k < 2) return av[2 * i + k];
-    if (k < 4) return ap[2 * i + k - 2];
-    k -= 4;
-    if (k < 2 * c.n_obst) { const int l = k >> 1, x = k & 1; return lp[2 * l + x] - ap[2 * i + x]; }
-    k -= 2 * c.n_obst;
-    if (k < 2 * (NA - 1)) {
-        int j = k >> 1;
-        const int x = k & 1;
-        if (j >= i) ++j;  // the other agents in increasing index
-        return ap[2 * j + x] - ap[2 * i + x];
-    }
-    k -= 2 * (NA - 1);
-    const int n_seen = c.n_good - (i >= c.n_adv ? 1 : 0);  // velocities of the good agents other than oneself
-    if (k < 2 * n_seen) {
-        int j = c.n_adv + (k >> 1);
-        if (i >= c.n_adv && j >= i) ++j;
-        return av[2 * j + (k & 1)];
-    }
-    return 0.f;  // padding of the good agents' rows
-}
-
 constexpr int kTagEnvPerBlock = 16;
 constexpr int kTagThreads = kTagEnvPerBlock * kMaxAgents;  // one lane per (env, agent)
 
@@ -122,7 +51,7 @@ __global__ __launch_bounds__(kTagThreads) void tag_step_kernel(
     float *lpos, int32_t *steps, float *obs_next, float *obs_cur, float *rew, uint8_t *term, uint8_t *trunc,
     uint8_t *done_env, int auto_reset, uint64_t *tick, uint64_t tick_inc) {
     extern __shared__ float sm[];
-    const int NA = c.n_adv + c.n_good, NE = NA + c.n_obst;
+    const int NA = c.n_adv + c.n_good;
     const int st = 2 * NA, lst = 2 * c.n_obst, row = NA * c.obs_dim;
     float *s_ap = sm;                                   // [16][NA][2]
     float *s_av = s_ap + kTagEnvPerBlock * st;
@@ -146,38 +75,8 @@ __global__ __launch_bounds__(kTagThreads) void tag_step_kernel(
     const int e = e0 + el;
     const float *ap = s_ap + el * st, *av = s_av + el * st, *lp = s_lp + el * lst;
     const bool is_adv = i < c.n_adv;
-    const float my_size = is_adv ? c.adv_size : c.good_size;
     float npx = 0.f, npy = 0.f, nvx = 0.f, nvy = 0.f;
-    if (live) {
-        const int a = act[(int64_t)e * NA + i];
-        const float accel = is_adv ? c.adv_accel : c.good_accel;
-        float fx = (a == 1 ? -1.f : (a == 2 ? 1.f : 0.f)) * accel;
-        float fy = (a == 3 ? -1.f : (a == 4 ? 1.f : 0.f)) * accel;
-        const float px = ap[2 * i], py = ap[2 * i + 1];
-        for (int j = 0; j < NE; ++j) {  // wave-uniform trip count
-            if (j == i) continue;
-            const float qx = j < NA ? ap[2 * j] : lp[2 * (j - NA)], qy = j < NA ? ap[2 * j + 1] : lp[2 * (j - NA) + 1];
-            const float sj = j < NA ? (j < c.n_adv ? c.adv_size : c.good_size) : c.obst_size;
-            // pair (lo, hi) = (min, max) of (i, j): d = p_lo - p_hi; f_lo += s d, f_hi -= s d
-            const float dx = i < j ? px - qx : qx - px, dy = i < j ? py - qy : qy - py;
-            const float dmin = i < j ? my_size + sj : sj + my_size;
-            const float d2 = dx * dx + dy * dy;
-            const float far = dmin + 105.f * c.contact_margin;  // beyond it expf underflows: the force is exactly 0
-            if (d2 > far * far) continue;
-            const float dist = sqrtf(d2);
-            const float pen = softplus_k(-(dist - dmin) / c.contact_margin, c.contact_margin);
-            const float s = c.contact_force * pen / dist;
-            if (i < j) { fx += s * dx; fy += s * dy; }
-            else { fx -= s * dx; fy -= s * dy; }
-        }
-        nvx = av[2 * i] * (1.f - c.damping) + fx * c.dt;
-        nvy = av[2 * i + 1] * (1.f - c.damping) + fy * c.dt;
-        const float vmax = is_adv ? c.adv_speed : c.good_speed;
-        const float sp = sqrtf(nvx * nvx + nvy * nvy);
-        if (sp > vmax) { nvx = nvx / sp * vmax; nvy = nvy / sp * vmax; }
-        npx = px + nvx * c.dt;
-        npy = py + nvy * c.dt;
-    }
+    if (live) tag_agent_move(c, ap, av, lp, i, act[(int64_t)e * NA + i], npx, npy, nvx, nvy);
     __syncthreads();
     if (live) {
         s_ap[el * st + 2 * i] = npx; s_ap[el * st + 2 * i + 1] = npy;
@@ -187,15 +86,8 @@ __global__ __launch_bounds__(kTagThreads) void tag_step_kernel(
     // rewards on the new positions: a good agent counts the adversaries touching it (multiples of 10: exact in f32)
     float my_rew = 0.f;
     if (live) {
-        float hit = 0.f;
-        if (!is_adv) {
-            for (int a = 0; a < c.n_adv; ++a) {
-                const float dx = ap[2 * a] - npx, dy = ap[2 * a + 1] - npy;
-                if (sqrtf(dx * dx + dy * dy) < c.adv_size + c.good_size) { my_rew -= 10.f; hit += 10.f; }
-            }
-            my_rew -= bound_pen(fabsf(npx));
-            my_rew -= bound_pen(fabsf(npy));
-        }
+        float hit;
+        my_rew = tag_own_reward(c, ap, i, npx, npy, hit);
         s_hit[el * NA + i] = hit;
         if (i == 0) {
             const int stp = steps[e] + 1;
@@ -223,17 +115,8 @@ __global__ __launch_bounds__(kTagThreads) void tag_step_kernel(
         episode_ctr[e] = ep + 1;
     }
     __syncthreads();
-    if (live && s_tr[el] && auto_reset) {  // re-initialise: agent lane i draws agent i (and obstacles i, i + NA, ...)
-        uint32_t r4[4];
-        const uint64_t base = (s_ep[el] * (uint64_t)c.n_env + (uint64_t)e) * 16ull;
-        tsm_philox4(seed, base + (uint64_t)i, r4);
-        s_ap[el * st + 2 * i] = uni(r4[0], -1.f, 1.f); s_ap[el * st + 2 * i + 1] = uni(r4[1], -1.f, 1.f);
-        s_av[el * st + 2 * i] = 0.f; s_av[el * st + 2 * i + 1] = 0.f;
-        for (int l = i; l < c.n_obst; l += NA) {
-            tsm_philox4(seed, base + (uint64_t)(NA + l), r4);
-            s_lp[el * lst + 2 * l] = uni(r4[0], -0.9f, 0.9f); s_lp[el * lst + 2 * l + 1] = uni(r4[1], -0.9f, 0.9f);
-        }
-    }
+    if (live && s_tr[el] && auto_reset)  // re-initialise: agent lane i draws agent i (and obstacles i, i + NA, ...)
+        tag_reset_lane(c, e, seed, s_ep[el], i, s_ap + el * st, s_av + el * st, s_lp + el * lst);
     __syncthreads();
     float *g_next = obs_next + (int64_t)e0 * row;
     for (int k = threadIdx.x; k < n_here * row; k += kTagThreads) g_next[k] = s_next[k];
@@ -251,7 +134,9 @@ __global__ __launch_bounds__(kTagThreads) void tag_step_kernel(
     for (int k = threadIdx.x; k < n_here * lst; k += kTagThreads) lpos[(int64_t)e0 * lst + k] = s_lp[k];
 }
 
-int check_cfg(const tsm_mpe_tag_cfg *h, TagCfg *c) {
+}  // namespace
+
+int tsm_mpe_tag_check_cfg(const tsm_mpe_tag_cfg *h, TagCfg *c) {
     TSM_REQUIRE(h, "simple_tag: null config");
     TSM_REQUIRE(h->n_env >= 1 && h->n_adv >= 1 && h->n_good >= 1 && h->n_adv + h->n_good <= kMaxAgents &&
                     h->n_obst >= 0 && h->n_obst <= kMaxObst && h->max_cycles >= 1,
@@ -267,18 +152,16 @@ int check_cfg(const tsm_mpe_tag_cfg *h, TagCfg *c) {
     return TSM_OK;
 }
 
-}  // namespace
-
 TSM_EXPORT int tsm_mpe_tag_obs_dim(const tsm_mpe_tag_cfg *cfg_host) {
     TagCfg c;
-    return check_cfg(cfg_host, &c) == TSM_OK ? c.obs_dim : -1;
+    return tsm_mpe_tag_check_cfg(cfg_host, &c) == TSM_OK ? c.obs_dim : -1;
 }
 
 TSM_EXPORT int tsm_mpe_tag_reset(const tsm_mpe_tag_cfg *cfg_host, uint64_t seed, uint64_t *episode_ctr,
                                  const int64_t *env_ids, int64_t n_ids, float *agent_pos, float *agent_vel,
                                  float *landmark_pos, int32_t *steps, float *obs_out, void *stream) {
     TagCfg c;
-    if (int rc = check_cfg(cfg_host, &c)) return rc;
+    if (int rc = tsm_mpe_tag_check_cfg(cfg_host, &c)) return rc;
     const int64_t n = env_ids ? n_ids : c.n_env;
     if (n == 0) return TSM_OK;
     TSM_REQUIRE(episode_ctr && agent_pos && agent_vel && landmark_pos && steps && obs_out, "tsm_mpe_tag_reset: null pointer");
@@ -294,7 +177,7 @@ TSM_EXPORT int tsm_mpe_tag_step(const tsm_mpe_tag_cfg *cfg_host, uint64_t seed, 
                                 uint8_t *terminated_out, uint8_t *truncated_out, uint8_t *done_env_out, int auto_reset,
                                 uint64_t *rng_tick, uint64_t rng_tick_inc, void *stream) {
     TagCfg c;
-    if (int rc = check_cfg(cfg_host, &c)) return rc;
+    if (int rc = tsm_mpe_tag_check_cfg(cfg_host, &c)) return rc;
     TSM_REQUIRE(episode_ctr && act && agent_pos && agent_vel && landmark_pos && steps && obs_next_out && rew_out &&
                     terminated_out && truncated_out && done_env_out,
                 "tsm_mpe_tag_step: null pointer");

@@ -296,6 +296,33 @@ Cfg to_cfg(const tsm_ppo_cfg *c) {
     return k;
 }
 
+// Data-parallel replicas: (mean, unbiased std) of a rank's part of each minibatch <-> the additive form (n, sum x,
+// sum x^2) in f64 that ONE all-reduce sums over the ranks.  Every operation is rounded on its own (no fma contraction),
+// so the pair is bit-reproducible from plain f64 arithmetic in any language (tests/test_gpu_parallel.py).
+__global__ void adv_stats_pack_kernel(const float *__restrict__ stats, const int64_t *__restrict__ mb_start, int32_t n_mb,
+                                      double *__restrict__ pack) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_mb) return;
+    const double n = (double)(mb_start[k + 1] - mb_start[k]);
+    const double m = (double)stats[2 * k], sd = (double)stats[2 * k + 1];
+    const double nm1 = n > 1.0 ? __dsub_rn(n, 1.0) : 0.0;
+    pack[3 * k] = n;
+    pack[3 * k + 1] = __dmul_rn(n, m);
+    pack[3 * k + 2] = __dadd_rn(__dmul_rn(nm1, __dmul_rn(sd, sd)), __dmul_rn(__dmul_rn(n, m), m));
+}
+
+__global__ void adv_stats_unpack_kernel(const double *__restrict__ pack, int32_t n_mb, float *__restrict__ stats) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_mb) return;
+    const double N = pack[3 * k], S1 = pack[3 * k + 1], S2 = pack[3 * k + 2];
+    const double m = __ddiv_rn(S1, N);
+    const double den = N > 1.0 ? __dsub_rn(N, 1.0) : 1.0;
+    double var = __ddiv_rn(__dsub_rn(S2, __dmul_rn(__dmul_rn(N, m), m)), den);
+    if (!(var > 0.0)) var = 0.0;
+    stats[2 * k] = (float)m;
+    stats[2 * k + 1] = (float)__dsqrt_rn(var);
+}
+
 }  // namespace
 
 TSM_EXPORT int tsm_ppo_adv_stats(const float *adv, const int64_t *perm, const int64_t *mb_start,
@@ -326,6 +353,27 @@ TSM_EXPORT int tsm_ppo_adv_stats_wide(const float *adv, const int64_t *perm, con
     TSM_LAUNCH_CHECK();
     hipLaunchKernelGGL(adv_stats_fold_kernel, dim3((unsigned)n_mb), dim3(64), 0, tsm_stream(stream), adv, perm, mb_start,
                        (int32_t)n_chunk, work, stats_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+TSM_EXPORT int tsm_ppo_adv_stats_pack(const float *stats, const int64_t *mb_start, int32_t n_mb, double *pack_out,
+                                      void *stream) {
+    TSM_REQUIRE(n_mb >= 0, "tsm_ppo_adv_stats_pack: negative n_mb");
+    if (n_mb == 0) return TSM_OK;
+    TSM_REQUIRE(stats && mb_start && pack_out, "tsm_ppo_adv_stats_pack: null pointer");
+    hipLaunchKernelGGL(adv_stats_pack_kernel, dim3((unsigned)ceil_div(n_mb, 64)), dim3(64), 0, tsm_stream(stream), stats,
+                       mb_start, n_mb, pack_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+TSM_EXPORT int tsm_ppo_adv_stats_unpack(const double *pack, int32_t n_mb, float *stats_out, void *stream) {
+    TSM_REQUIRE(n_mb >= 0, "tsm_ppo_adv_stats_unpack: negative n_mb");
+    if (n_mb == 0) return TSM_OK;
+    TSM_REQUIRE(pack && stats_out, "tsm_ppo_adv_stats_unpack: null pointer");
+    hipLaunchKernelGGL(adv_stats_unpack_kernel, dim3((unsigned)ceil_div(n_mb, 64)), dim3(64), 0, tsm_stream(stream), pack,
+                       n_mb, stats_out);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

@@ -1,0 +1,402 @@
+// rollout_tag.hip -- persistent rollout kernel for the two-team env (simple_tag): the whole Collector loop of one
+// collect(n_step) call under GROUPED policies (one policy per team) in ONE launch.
+//
+// BASELINE configs[4] (/root/reference paths): FlexibleMultiAgentPolicyManager(mode="grouped") forwards every team's
+// agents through that team's policy (algorithm/multiagent/flexible_policy.py:96-98, marl.py:137-190), the vector env
+// steps every world (env/venvs.py:237-322 over enhanced_pettingzoo_env.py:175-222) and the buffer manager adds the joint
+// rows (data/buffer/manager.py:131-193) -- data/collector.py:854-1069 per vector step.  Fused exactly as rollout.hip
+// fuses the shared-policy loop, with two differences:
+//   * TWO parameter sets live in LDS (team 0 = adversaries = agent columns [0, n_adv), team 1 = good agents); both
+//     nets run on the workgroup's 16-row tile and every row takes the outputs of its own team's net.  A tile row's
+//     result does not depend on the other rows of the tile, so logits / values are bit-identical to tsm_policy_forward
+//     on the team's own rows;
+//   * the sampling counter of (step t, agent column a, env e) is  offset[team] + *offset_dev + t n_env NA + a n_env + e:
+//     agent-major inside a step, as MultiAgentPolicy.act_device hands the columns of a team to its policy (one shared
+//     policy sees the [n_env][NA] rows in one call instead: env_major_counter, e NA + a).
+// A workgroup owns EPB = 16 / NA whole worlds for all T steps: weights staged once, env state in LDS, only the buffer
+// rows travel to HBM.  Results are bit-identical to the unfused sequence (per team: tsm_policy_forward) ->
+// tsm_mpe_tag_step -> tsm_vrb_add (tests/test_gpu_tag.py).  V(obs_next) is not produced (the league / self-play trainers
+// learn from per-agent batches and run their own critic passes: training_coordinator.py:160-179).
+#include "common.h"
+#include "mlp_tile.h"
+#include "mpe_tag_dev.h"
+#include "philox.h"
+#include "vrb_dev.h"
+
+int tsm_mpe_tag_check_cfg(const tsm_mpe_tag_cfg *h, TagCfg *c);  // mpe_tag.hip
+
+namespace {
+
+struct TagRolloutArgs {
+    // policies: [0] adversaries, [1] good agents
+    const float *P[2];
+    uint64_t pol_seed[2], offset[2];
+    int mode[2];  // 1 sample, 2 argmax
+    int env_major;  // sampling counter inside a step: 0 column * n_env + env (grouped), 1 env * NA + column (one shared policy)
+    Dims d;
+    const uint64_t *offset_dev;
+    // env
+    TagCfg c;
+    uint64_t env_seed;
+    uint64_t *episode_ctr;
+    float *apos, *avel, *lpos;
+    int32_t *steps;
+    int auto_reset;
+    float *obs_cur_out;  // [n_env][NA][D] next policy input after the rollout
+    // buffer
+    void *vrb_state;
+    int64_t S;
+    uint8_t *done_store;
+    float *obs_store, *obs_next_store, *rew_store, *logp_store, *vs_store;
+    int32_t *act_store;
+    uint8_t *term_store, *trunc_store;
+    // per-step outputs [n_steps][n_env]...
+    int64_t *ptr_out, *ep_len_out, *ep_idx_out;
+    double *ep_rew_out;
+    int n_steps;
+    // compact record of the episodes finished during this rollout (nullable), layout as in rollout.hip
+    int64_t *ep_rec;
+    int max_ep;
+    uint64_t offset_inc;
+    uint64_t *offset_dev_rw;
+    uint32_t *done_ctr;
+};
+
+// s += ex[0] + ex[1] + ... + ex[A - 1] in action order (ex[j] lives in lane j of the 16-lane row)
+template <int J>
+__device__ __forceinline__ void row_prefix_sum(float ex, int A, float &s) {
+    if constexpr (J < 16) {
+        if (J < A) {  // wave-uniform
+            s += row_dpp<0x150 + J>(ex);
+            row_prefix_sum<J + 1>(ex, A, s);
+        }
+    }
+}
+// inverse-CDF pick: first j with u < ex[0] + ... + ex[j] (same running sum as row_prefix_sum)
+template <int J>
+__device__ __forceinline__ void row_cdf_pick(float ex, int A, float u, float &cs, int &act, bool &found) {
+    if constexpr (J < 16) {
+        if (J < A) {
+            cs += row_dpp<0x150 + J>(ex);
+            if (!found && u < cs) { act = J; found = true; }
+            row_cdf_pick<J + 1>(ex, A, u, cs, act, found);
+        }
+    }
+}
+
+constexpr int NT2 = 2 * NT;  // eight waves: actor chains on waves 0-3, critic chains on waves 4-7 (tile_forward_split)
+
+template <int H>
+__global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
+    extern __shared__ float lds[];
+    const Dims d = a.d;
+    const TagCfg c = a.c;
+    const Lay<H> ly(d, false);                    // team 0: weights + the shared activation buffers
+    const int wB = ly.total;                      // team 1: weights only, the image layout of [0, ly.X) behind team 0
+    const int w_size = (ly.X + 3) & ~3;
+    Lay<H> lyB = ly;
+    lyB.W1 += wB; lyB.W2a += wB; lyB.W2c += wB; lyB.W3a += wB; lyB.W3c += wB;
+    lyB.B1 += wB; lyB.B2 += wB; lyB.B3a += wB; lyB.B3c += wB;
+    lyB.OUT = wB + w_size;                        // [R][ldo] team 1's logits | value
+    const int xn0 = lyB.OUT + R * ly.ldo;         // [R][ld1] second observation tile
+    const int NA = c.n_adv + c.n_good, D = d.D, st = 2 * NA, lst = 2 * c.n_obst;
+    const int EPB = R / NA;                       // worlds per workgroup
+    const int e0 = blockIdx.x * EPB;
+    const int n_here = min(EPB, c.n_env - e0);
+    const int rows_here = n_here * NA;            // live tile rows (<= 16): row r = (env el, agent i), r = el*NA + i
+    const int64_t B = c.n_env;
+    float *s_ap = lds + xn0 + R * d.ld1;          // [EPB][NA][2]
+    float *s_av = s_ap + R * 2;
+    float *s_lp = s_av + R * 2;                   // [EPB][n_obst][2]  (EPB * n_obst <= 8 * 4)
+    float *s_hit = s_lp + 2 * 8 * kTagMaxObst;    // [R] 10 * (adversaries touching the good agent of this row)
+    float *s_rew = s_hit + R;                     // [R]
+    float *s_logp = s_rew + R;                    // [R]
+    float *s_val = s_logp + R;                    // [R]
+    int *s_act = reinterpret_cast<int *>(s_val + R);        // [R]
+    int *s_steps = s_act + R;                               // [EPB]
+    int *s_done = s_steps + R;                              // [EPB] done flag of the step just taken
+    int64_t *s_row = reinterpret_cast<int64_t *>(                    // [EPB] slot*B + env of the step just added
+        (reinterpret_cast<uintptr_t>(s_done + R) + 7) & ~(uintptr_t)7);
+    uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + R);        // [EPB] episode counter of finished envs
+
+    // waves 0-3 stage team 0's weights, waves 4-7 team 1's (batches of 4 loads per thread: ~1 us per workgroup)
+    if (threadIdx.x < NT) stage_weights<H>(lds, ly, d, a.P[0]);
+    else stage_weights<H>(lds + wB, ly, d, a.P[1], (int)threadIdx.x - NT);
+    for (int i = threadIdx.x; i < R * d.ld1; i += NT2) { lds[ly.X + i] = 0.f; lds[xn0 + i] = 0.f; }
+    const VrbState vs = vrb_view(a.vrb_state, B, NA);
+    // agent lane r < rows_here (wave 0) <-> (env el, agent ai); env lane 64 + q (wave 1) owns env q's bookkeeping
+    const int r = threadIdx.x, el = r / NA, ai = r - el * NA;
+    const bool lane_live = r < rows_here;
+    const int e = e0 + el;
+    const int bel = (int)threadIdx.x - 64;  // env lane: local env index
+    const bool env_lane = bel >= 0 && bel < n_here;
+    const int be = e0 + bel;
+    int64_t v_ins = 0, v_size = 0, v_eplen = 0, v_epstart = 0, v_last = 0;
+    int n_fin = 0;  // episodes this env finished during the rollout
+    double v_epret[kTagMaxAgents];
+#pragma unroll
+    for (int k = 0; k < kTagMaxAgents; ++k) v_epret[k] = 0.0;
+    if (env_lane) {
+        v_ins = vs.ins[be]; v_size = vs.size[be]; v_eplen = vs.ep_len[be]; v_epstart = vs.ep_start[be];
+        v_last = vs.last_index[be];
+#pragma unroll
+        for (int k = 0; k < kTagMaxAgents; ++k) if (k < NA) v_epret[k] = vs.ep_return[(int64_t)be * NA + k];
+        s_steps[bel] = a.steps[be];
+        s_done[bel] = 0;
+        s_row[bel] = 0;
+    }
+    for (int i = threadIdx.x; i < n_here * st; i += NT2) {
+        s_ap[i] = a.apos[(int64_t)e0 * st + i];
+        s_av[i] = a.avel[(int64_t)e0 * st + i];
+    }
+    for (int i = threadIdx.x; i < n_here * lst; i += NT2) s_lp[i] = a.lpos[(int64_t)e0 * lst + i];
+    const uint64_t off0 = a.offset_dev ? *a.offset_dev : 0ull;
+    __syncthreads();
+    // two observation tiles, swapped every step: obs_next of step t IS obs of step t + 1 (rows of re-initialised
+    // envs are rebuilt in F), so the observation function runs once per step, not twice
+    Lay<H> lyf = ly, lyg = lyB;
+    int xcur = ly.X, xnxt = xn0;
+    // A. observation rows from the LDS-resident state: one (row, element) per thread
+    for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
+        const int rr = i / D, k = i - rr * D, ee = rr / NA;
+        lds[xcur + rr * d.ld1 + k] = tag_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * lst, rr - ee * NA, k);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < a.n_steps; ++t) {
+        float *XN = lds + xnxt;
+        // B. both teams' actor + critic forward of the 16-row tile (same X, separate OUT)
+        lyf.X = xcur; lyg.X = xcur;
+        tile_forward_split<H>(lds, lyf, d);
+        tile_forward_split<H>(lds, lyg, d);
+        // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
+        //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
+        if (threadIdx.x < NT) {
+            const int hr = threadIdx.x >> 4, j = threadIdx.x & 15;
+            const int hel = hr / NA, hai = hr - hel * NA;
+            const int team = hai >= c.n_adv ? 1 : 0;
+            const float *lg = lds + (team ? lyB.OUT : ly.OUT) + hr * ly.ldo;
+            const bool on = j < d.A;
+            const float x = on ? lg[j] : -INFINITY;
+            const float m = row16_max(x);
+            const float ex = on ? expf(x - m) : 0.f;
+            const int gbase = threadIdx.x & 48;  // first lane of this row's 16-lane group inside the wave
+            float ssum = 0.f;
+            row_prefix_sum<0>(ex, d.A, ssum);
+            int act = 0;
+            if (a.mode[team] == 1) {
+                const uint64_t gi = a.env_major ? (uint64_t)(e0 + hel) * NA + hai  // one policy call over [n_env][NA] rows
+                                                : (uint64_t)hai * B + (uint64_t)(e0 + hel);  // column * n_env + env
+                const float u = tsm_philox_uniform(a.pol_seed[team], a.offset[team] + off0 + (uint64_t)t * B * NA + gi) * ssum;
+                float cs = 0.f;
+                act = d.A - 1;
+                bool found = false;
+                row_cdf_pick<0>(ex, d.A, u, cs, act, found);
+            } else {  // dist.mode: first index attaining the maximum
+                const unsigned long long eq = __ballot(on && x == m);
+                act = __ffsll((long long)((eq >> gbase) & 0xFFFFull)) - 1;
+            }
+            const float la = __shfl(x, gbase + act, 64);
+            if (j == 0 && hr < rows_here) {
+                s_val[hr] = lg[16];
+                s_act[hr] = act;
+                s_logp[hr] = la - (m + logf(ssum));
+            }
+        }
+        __syncthreads();
+        // D. env step, one lane per agent (mpe_tag_dev.h): move -> barrier -> publish -> barrier -> reward terms.
+        //    Beside the move, the env lanes do the buffer index algebra on their register-resident sub-buffer state
+        //    (buffer_base.py:373-410 + manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h).
+        float npx = 0.f, npy = 0.f, nvx = 0.f, nvy = 0.f;
+        if (lane_live) tag_agent_move(c, s_ap + el * st, s_av + el * st, s_lp + el * lst, ai, s_act[r], npx, npy, nvx, nvy);
+        bool tr = false, rec = false;
+        int64_t o = 0;
+        if (env_lane) {
+            const int stp = s_steps[bel] + 1;
+            tr = stp >= c.max_cycles;
+            s_steps[bel] = stp;
+            o = (int64_t)t * B + be;
+            const int64_t cur = v_ins;
+            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
+            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
+            const int64_t elen = v_eplen + 1;
+            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
+            rec = tr && a.ep_rec && n_fin < a.max_ep;
+            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | elen;
+            a.ep_len_out[o] = tr ? elen : 0;
+            a.ptr_out[o] = cur + (int64_t)be * a.S;
+            a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
+            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
+            v_last = cur + (int64_t)be * a.S;
+            a.done_store[cur * B + be] = tr ? 1 : 0;
+            s_row[bel] = cur * B + be;
+            s_done[bel] = tr ? 1 : 0;
+        }
+        __syncthreads();
+        if (lane_live) {
+            s_ap[el * st + 2 * ai] = npx; s_ap[el * st + 2 * ai + 1] = npy;
+            s_av[el * st + 2 * ai] = nvx; s_av[el * st + 2 * ai + 1] = nvy;
+        }
+        __syncthreads();
+        float my_rew = 0.f;
+        if (lane_live) {
+            float hit;
+            my_rew = tag_own_reward(c, s_ap + el * st, ai, npx, npy, hit);
+            s_hit[r] = hit;
+        }
+        // obs_next rows (terminal observation for finished episodes) on waves 1-7 while wave 0 works on the reward terms
+        if (threadIdx.x >= 64)
+            for (int i = threadIdx.x - 64; i < rows_here * D; i += NT2 - 64) {
+                const int rr = i / D, k = i - rr * D, ee = rr / NA;
+                XN[rr * d.ld1 + k] = tag_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * lst, rr - ee * NA, k);
+            }
+        __syncthreads();
+        if (lane_live) {
+            if (ai < c.n_adv) for (int g = c.n_adv; g < NA; ++g) my_rew += s_hit[el * NA + g];  // shared by the team
+            s_rew[r] = my_rew;
+        }
+        __syncthreads();
+        if (env_lane) {  // episode returns (needs the rewards); runs beside the payload scatter below
+            double *rec_rew = rec ? reinterpret_cast<double *>(a.ep_rec + B + (int64_t)B * a.max_ep) +
+                                        ((int64_t)be * a.max_ep + n_fin) * NA : nullptr;
+#pragma unroll
+            for (int k = 0; k < kTagMaxAgents; ++k) {
+                if (k < NA) {
+                    const double acc = v_epret[k] + (double)s_rew[bel * NA + k];
+                    a.ep_rew_out[o * NA + k] = tr ? acc : 0.0;
+                    if (rec) rec_rew[k] = acc;
+                    v_epret[k] = tr ? 0.0 : acc;
+                }
+            }
+            n_fin += tr ? 1 : 0;
+        }
+        // E. payload scatter into the time-major SoA store (rows of consecutive envs are adjacent)
+        for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
+            const int rr = i / D, k = i - rr * D, ee = rr / NA;
+            const int64_t dst = (s_row[ee] * NA + (rr - ee * NA)) * D + k;
+            a.obs_store[dst] = lds[xcur + rr * d.ld1 + k];
+            if (a.obs_next_store) a.obs_next_store[dst] = XN[rr * d.ld1 + k];
+        }
+        if (lane_live) {
+            const int64_t dst = s_row[el] * NA + ai;
+            a.act_store[dst] = s_act[r];
+            a.rew_store[dst] = s_rew[r];
+            a.term_store[dst] = 0;
+            a.trunc_store[dst] = (uint8_t)s_done[el];
+            if (a.logp_store) a.logp_store[dst] = s_logp[r];
+            if (a.vs_store) a.vs_store[dst] = s_val[r];
+        }
+        // F. finished episodes: re-initialise the env, first observation of the new episode
+        if (a.auto_reset) {
+            int any_done = lane_live ? s_done[el] : 0;
+            any_done = __syncthreads_or(any_done);
+            if (any_done) {
+                if (env_lane && s_done[bel]) {
+                    const uint64_t ep = a.episode_ctr[be];
+                    s_ep[bel] = ep;
+                    a.episode_ctr[be] = ep + 1;
+                    s_steps[bel] = 0;
+                }
+                __syncthreads();
+                if (lane_live && s_done[el])
+                    tag_reset_lane(c, e, a.env_seed, s_ep[el], ai, s_ap + el * st, s_av + el * st, s_lp + el * lst);
+                __syncthreads();
+                for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
+                    const int rr = i / D, k = i - rr * D, ee = rr / NA;
+                    if (s_done[ee])
+                        XN[rr * d.ld1 + k] =
+                            tag_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * lst, rr - ee * NA, k);
+                }
+            }
+        }
+        __syncthreads();  // the next forward (or the epilogue) reads the tile at once; s_* of this step are free again
+        { const int tmp = xcur; xcur = xnxt; xnxt = tmp; }
+    }
+    // the observation of the next collect() call
+    if (a.obs_cur_out)
+        for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
+            const int rr = i / D, k = i - rr * D;
+            a.obs_cur_out[((int64_t)e0 * NA + rr) * D + k] = lds[xcur + rr * d.ld1 + k];
+        }
+    // env state + sub-buffer bookkeeping back to HBM
+    for (int i = threadIdx.x; i < n_here * st; i += NT2) {
+        a.apos[(int64_t)e0 * st + i] = s_ap[i];
+        a.avel[(int64_t)e0 * st + i] = s_av[i];
+    }
+    for (int i = threadIdx.x; i < n_here * lst; i += NT2) a.lpos[(int64_t)e0 * lst + i] = s_lp[i];
+    if (env_lane) {
+        a.steps[be] = s_steps[bel];
+        vs.ins[be] = v_ins; vs.size[be] = v_size; vs.ep_len[be] = v_eplen; vs.ep_start[be] = v_epstart;
+        vs.last_index[be] = v_last; vs.lengths[be] = v_size;
+        if (a.ep_rec) a.ep_rec[be] = n_fin;  // may exceed max_ep: the host treats that as an overflow
+#pragma unroll
+        for (int k = 0; k < kTagMaxAgents; ++k) if (k < NA) vs.ep_return[(int64_t)be * NA + k] = v_epret[k];
+    }
+    // the last workgroup to get here advances the sampling counter: every workgroup read it (off0) before finishing
+    if (a.done_ctr && threadIdx.x == 0) {
+        if (atomicAdd(a.done_ctr, 1u) == gridDim.x - 1) {
+            *a.offset_dev_rw += a.offset_inc;
+            *a.done_ctr = 0u;
+        }
+    }
+}
+
+size_t tag_rollout_lds_floats(const Dims &d) {
+    const Lay<64> ly(d, false);
+    const size_t w_size = (size_t)((ly.X + 3) & ~3);
+    return (size_t)ly.total + w_size + (size_t)R * ly.ldo + (size_t)R * d.ld1 + 2 * R * 2 + 2 * 8 * kTagMaxObst + 4 * R +
+           3 * R + 2 * 2 * R + 8;
+}
+
+}  // namespace
+
+TSM_EXPORT int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stream) {
+    TSM_REQUIRE(desc_host, "tsm_rollout_tag: null descriptor");
+    const tsm_rollout_tag_desc &h = *desc_host;
+    TagRolloutArgs a;
+    if (int rc = make_dims(h.obs_dim, h.hidden, h.n_act, &a.d)) return rc;
+    if (int rc = tsm_mpe_tag_check_cfg(&h.env, &a.c)) return rc;
+    const int NA = a.c.n_adv + a.c.n_good;
+    TSM_REQUIRE(a.c.obs_dim == h.obs_dim, "tsm_rollout_tag: obs_dim %d != the env's padded width %d", h.obs_dim, a.c.obs_dim);
+    TSM_REQUIRE(h.n_act == 5, "tsm_rollout_tag: simple_tag has 5 discrete actions");
+    TSM_REQUIRE(NA <= R && R / NA <= 8, "tsm_rollout_tag: %d agents do not fit the row tile", NA);
+    TSM_REQUIRE(h.n_steps >= 1 && h.sub_size >= 1, "tsm_rollout_tag: bad n_steps / sub_size");
+    for (int k = 0; k < 2; ++k) {
+        TSM_REQUIRE(h.mode[k] == 1 || h.mode[k] == 2, "tsm_rollout_tag: mode must be 1 (sample) or 2 (argmax)");
+        TSM_REQUIRE(h.params[k], "tsm_rollout_tag: null parameters");
+        a.P[k] = h.params[k]; a.pol_seed[k] = h.policy_seed[k]; a.offset[k] = h.offset[k]; a.mode[k] = h.mode[k];
+    }
+    TSM_REQUIRE(h.episode_ctr && h.agent_pos && h.agent_vel && h.landmark_pos && h.steps && h.vrb_state && h.done_store &&
+                    h.obs_store && h.act_store && h.rew_store && h.term_store && h.trunc_store && h.ptr_out &&
+                    h.ep_rew_out && h.ep_len_out && h.ep_idx_out,
+                "tsm_rollout_tag: null pointer");
+    a.offset_dev = h.offset_dev;
+    a.env_major = h.env_major_counter ? 1 : 0;
+    a.env_seed = h.env_seed; a.episode_ctr = h.episode_ctr;
+    a.apos = h.agent_pos; a.avel = h.agent_vel; a.lpos = h.landmark_pos; a.steps = h.steps;
+    a.auto_reset = h.auto_reset; a.obs_cur_out = h.obs_cur_out;
+    a.vrb_state = h.vrb_state; a.S = h.sub_size; a.done_store = h.done_store;
+    a.obs_store = h.obs_store; a.obs_next_store = h.obs_next_store; a.rew_store = h.rew_store;
+    a.logp_store = h.logp_store; a.vs_store = h.vs_store;
+    a.act_store = h.act_store; a.term_store = h.term_store; a.trunc_store = h.trunc_store;
+    a.ptr_out = h.ptr_out; a.ep_len_out = h.ep_len_out; a.ep_idx_out = h.ep_idx_out; a.ep_rew_out = h.ep_rew_out;
+    a.n_steps = h.n_steps;
+    TSM_REQUIRE(!h.ep_rec || h.max_ep >= 1, "tsm_rollout_tag: ep_rec needs max_ep >= 1");
+    a.ep_rec = h.ep_rec; a.max_ep = h.max_ep;
+    TSM_REQUIRE(!h.done_ctr || h.offset_dev, "tsm_rollout_tag: done_ctr needs offset_dev");
+    a.offset_inc = h.offset_inc; a.done_ctr = h.done_ctr;
+    a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
+    const size_t shmem = tag_rollout_lds_floats(a.d) * sizeof(float);
+    TSM_REQUIRE(shmem <= 156 * 1024, "tsm_rollout_tag: %zu bytes of LDS needed", shmem);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_tag_kernel<64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        attr_set = true;
+    }
+    const int EPB = R / NA;
+    const unsigned n_wg = (unsigned)ceil_div(a.c.n_env, EPB);
+    hipLaunchKernelGGL((rollout_tag_kernel<64>), dim3(n_wg), dim3(NT2), shmem, tsm_stream(stream), a);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}

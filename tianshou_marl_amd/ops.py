@@ -277,6 +277,29 @@ def ppo_adv_stats(adv, mb_start, perm=None, out=None, max_rows: int = 0, work=No
     return stats
 
 
+def ppo_adv_stats_pack(stats, mb_start, out=None):
+    """This rank's per-minibatch (mean, unbiased std) + row counts -> f64 [n_mb, 3] = (n, sum x, sum x^2): the additive
+    form one all-reduce sums over data-parallel ranks (parallel.GradSync.merge_adv_stats_)."""
+    stats = _chk(stats, torch.float32, "stats").reshape(-1, 2)
+    mb_start = _chk(mb_start, torch.int64, "mb_start")
+    n_mb = mb_start.numel() - 1
+    if stats.shape[0] != n_mb:
+        raise ValueError(f"ppo_adv_stats_pack: {stats.shape[0]} statistics rows for {n_mb} minibatches")
+    pack = out if out is not None else torch.empty(n_mb, 3, dtype=torch.float64, device=stats.device)
+    call("tsm_ppo_adv_stats_pack", ptr(stats), ptr(mb_start), n_mb, ptr(_chk(pack, torch.float64, "pack")), stream_ptr())
+    return pack
+
+
+def ppo_adv_stats_unpack(pack, stats):
+    """Summed (n, sum x, sum x^2) -> (mean, unbiased std) of the union, written into `stats` [n_mb, 2] f32 in place."""
+    pack = _chk(pack, torch.float64, "pack").reshape(-1, 3)
+    st = _chk(stats, torch.float32, "stats")
+    if st.numel() != 2 * pack.shape[0]:
+        raise ValueError("ppo_adv_stats_unpack: stats and pack disagree on the number of minibatches")
+    call("tsm_ppo_adv_stats_unpack", ptr(pack), pack.shape[0], ptr(st), stream_ptr())
+    return stats
+
+
 def ppo_loss_fwd_bwd(logits, value, act, logp_old, adv, returns, cfg: tsm_ppo_cfg, adv_stats=None,
                      v_s_old=None, perm=None, first_row=0, finalize: bool = True):
     """One minibatch -> (dlogits[M,A], dvalue[M], scalars[4]={loss, clip, vf, ent}).

@@ -33,6 +33,7 @@ class GradSync:
         self.rank = dist.get_rank(group)
         self._checked: set = set()
         self.global_adv_stats = True  # minibatch advantage statistics over all ranks (merge_adv_stats_)
+        self._stat_codec = None       # (pack, unpack) callables; None = the HIP kernels (ops.ppo_adv_stats_pack / _unpack)
         self._probe_device = torch.device("cpu")  # attach_data_parallel points it at the replica's device for RCCL
 
     def all_reduce_mean_(self, flat: torch.Tensor) -> torch.Tensor:
@@ -76,27 +77,28 @@ class GradSync:
             raise ValueError(f"data-parallel ranks disagree on {what} (this rank: {list(names)}): seed the trainers' "
                              "matchmaking identically on every rank")
 
-    def merge_adv_stats_(self, stats: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
-        """stats [..., 2] = rank-local (mean, unbiased std) of the advantages of each minibatch, counts [...] = its rows on
-        this rank -> in place, the (mean, unbiased std) of the union of all ranks' minibatch ("the
-        advantage statistics make the sharded minibatch normalisation identical to a single global minibatch").  One f64
-        all-reduce of (n, sum x, sum x^2) per minibatch, every minibatch of the update in one message; every rank ends
-        with bit-identical statistics."""
+    def merge_adv_stats_(self, stats: torch.Tensor, mb_start: torch.Tensor) -> torch.Tensor:
+        """stats [n_mb, 2] = rank-local (mean, unbiased std) of the advantages of each minibatch (its rows on this rank:
+        mb_start[k+1] - mb_start[k]) -> in place, the (mean, unbiased std) of the union of all ranks' minibatch (SURVEY.md
+        section 8e: "the advantage statistics make the sharded minibatch normalisation identical to a single global
+        minibatch").  Three launches: pack to f64 (n, sum x, sum x^2) (`tsm_ppo_adv_stats_pack`), ONE all-reduce for every
+        minibatch of the update, unpack; every rank ends with bit-identical statistics."""
         import os
 
         # (a one-rank group skips it, except in the single-GPU rehearsal of the captured multi-GPU path, TSM_FORCE_DIST)
         if not self.global_adv_stats or (self.world == 1 and not os.environ.get("TSM_FORCE_DIST")):
             return stats
-        st = stats.reshape(-1, 2).to(torch.float64)
-        n = counts.reshape(-1).to(torch.float64)
-        mean, var = st[:, 0], st[:, 1] * st[:, 1]
-        pack = torch.stack([n, n * mean, (n - 1.0).clamp_min(0.0) * var + n * mean * mean], dim=1).contiguous()
+        pack_fn, unpack_fn = self._stat_codec or self._default_codec()
+        pack = pack_fn(stats, mb_start)
         self.dist.all_reduce(pack, op=self.dist.ReduceOp.SUM, group=self.group)
-        N, S1, S2 = pack[:, 0], pack[:, 1], pack[:, 2]
-        gmean = S1 / N
-        gvar = ((S2 - N * gmean * gmean) / (N - 1.0).clamp_min(1.0)).clamp_min(0.0)
-        stats.reshape(-1, 2).copy_(torch.stack([gmean, gvar.sqrt()], dim=1).to(stats.dtype))
+        unpack_fn(pack, stats)
         return stats
+
+    @staticmethod
+    def _default_codec():
+        from . import ops
+
+        return ops.ppo_adv_stats_pack, ops.ppo_adv_stats_unpack
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         self.dist.broadcast(t, src=src, group=self.group)
