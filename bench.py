@@ -68,7 +68,9 @@ def build_job(a, device, rank):
 
     env = DeviceSimpleSpreadVectorEnv(a.n_env, a.n_agent, max_cycles=a.horizon, device=device, seed=1626 + rank)
     net = DiscreteActorCritic(env.obs_dim, env.n_act, 64, device=device, init="orthogonal", seed=1626)
-    algo = PPO(net=net, lr=3e-4, dispatch=a.dispatch, shuffle="device", seed=1626 + rank, async_stats=True)
+    # (tools/soak_determinism.py --stable passes other PPO hyper-parameters; the bench itself keeps the reference defaults)
+    algo = PPO(net=net, lr=3e-4, dispatch=a.dispatch, shuffle="device", seed=1626 + rank, async_stats=True,
+               **getattr(a, "ppo_kwargs", {}))
     buf = DeviceVectorReplayBuffer(a.n_env * a.horizon, a.n_env, a.n_agent, env.obs_dim, device=device)
     col = Collector(algo, env, buf, async_stats=True)  # stats resolve lazily: no per-step host sync
     col.reset()

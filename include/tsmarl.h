@@ -99,6 +99,17 @@ int tsm_rms_update(const float *returns, const int64_t *ids, int64_t n, double *
 int tsm_mc_return_to_go_lanes(const float *rew, int64_t T, int64_t n_lane, double gamma,
                               float *out, void *stream);
 
+/* V(obs_next) (a2c.py:124) without a second critic pass over every row.  Rows written by a Collector are chained:
+ * obs_next of slot t is obs of slot t + 1 unless the episode ended at t (collector.py:1040-1069), so for T unrotated,
+ * equally filled slots of U units (lanes, or joint rows for a centralized critic)
+ *   v_next[t][u] = v_s[t + 1][u] (t < T - 1),  v_last[u] = V(obs_next of the last slot) (t = T - 1)
+ * provided no episode ended before the last slot: *flag == 0, flag = tsm_any_nonzero_u8(done[0 .. T-1)).  If one did,
+ * v_next = v_full, the complete pass (run it with tsm_mlp_forward_cond on the same flag).  Bit-identical to the full
+ * pass either way (the critic's rows are computed independently of each other). */
+int tsm_any_nonzero_u8(const uint8_t *x, int64_t n, int32_t *flag_out, void *stream);
+int tsm_value_next_select(const float *v_s, const float *v_last, const float *v_full, const int32_t *flag, int64_t T,
+                          int64_t U, float *v_next_out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * VectorReplayBuffer  [a8, a9]
  * Replaces  ReplayBufferManager.add / _update_state_pre_add / sample_indices(0) /
@@ -569,6 +580,10 @@ int64_t tsm_mlp_param_count(const tsm_mlp_desc *desc);
 int64_t tsm_mlp_act_elems(const tsm_mlp_desc *desc, int64_t B);
 int tsm_mlp_forward(const tsm_mlp_desc *desc, const float *params, const float *x, int64_t B, float *acts,
                     void *stream);
+/* tsm_mlp_forward whose launches are no-ops when *run_if_nonzero == 0 (device i32; read by every workgroup): lets a
+ * captured graph hold a pass that is only needed for some inputs (see tsm_value_next_select). */
+int tsm_mlp_forward_cond(const tsm_mlp_desc *desc, const float *params, const float *x, int64_t B, float *acts,
+                         const int32_t *run_if_nonzero, void *stream);
 int tsm_mlp_backward(const tsm_mlp_desc *desc, const float *params, const float *x, int64_t B, const float *acts,
                      const float *d_out, float *d_acts, int32_t n_split, float *slabs, int64_t slab_stride,
                      void *stream);

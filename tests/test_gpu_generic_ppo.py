@@ -371,3 +371,64 @@ def test_critic_rows_kernel_matches_float64_autograd(D, N, Mr, vclip):
     assert p[0] == 0 and p[2] == 0
     slabs2, _ = ops.ppo_critic_rows_update(f.flat.data, d(obs), d(ret), cfg, N, H, v_s_old=d(v_old) if vclip else None, rows=d(rows))
     assert torch.equal(slabs, slabs2)
+
+
+@pytest.mark.parametrize("glob,hidden,max_cycles,T,graph", [
+    (True, (128, 128), 10, 10, True),    # aligned: episodes end at the last slot only -> the full pass is skipped
+    (True, (128, 128), 7, 10, True),     # an episode ends mid-buffer -> device flag -> the full pass runs after all
+    (False, (64, 64), 10, 10, False), (False, (64, 64), 4, 10, True)])
+def test_next_values_from_the_next_slot_equal_the_full_critic_pass(glob, hidden, max_cycles, T, graph):
+    """Rows written by a Collector are chained (obs_next of slot t is obs of slot t + 1 unless the episode ended), so
+    GenericPPO takes V(obs_next) from V(obs) of the next slot + a pass over the last slot (ops.value_next_select) instead
+    of a second pass over every row (a2c.py:123-124).  The update must be bit-identical to the one that runs both passes,
+    over three collect + update rounds (graph replay included), aligned or not."""
+    n_env, N = 48, 3
+    finals = []
+    for shift in (True, False):
+        env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=max_cycles, device=DEV, seed=4)
+        D = env.obs_dim
+        net = MLPActorCritic(D, 5, hidden, critic_obs_dim=N * D if glob else None, device=DEV, seed=1)
+        algo = GenericPPO(net=net, critic_input="global" if glob else "local", n_agent=N, shuffle="device", seed=2,
+                          dispatch="pooled" if glob else "per_agent", graph=graph, shift_next_values=shift)
+        buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=DEV)
+        col = Collector(algo, env, buf)
+        col.reset()
+        outs = []
+        for _ in range(3):
+            with policy_within_training_step(algo):
+                col.collect(n_step=n_env * T)
+                assert buf.rows_chained is True
+                if shift:  # the two ways to V(obs_next) agree on this very batch
+                    pb = algo._preprocess_batch(buf, uniform_T=T)
+                    algo.shift_next_values = False
+                    ref = algo._preprocess_batch(buf, uniform_T=T)
+                    algo.shift_next_values = True
+                    assert torch.equal(pb["ret"], ref["ret"]) and torch.equal(pb["adv"], ref["adv"])
+                ts = algo.update(buf, batch_size=480, repeat=1)
+            col.reset_buffer(keep_statistics=True)
+            outs.append(ts.get_loss_stats_dict())
+        finals.append((net.flat.data.clone(), outs))
+    assert torch.equal(finals[0][0], finals[1][0])
+    assert finals[0][1] == finals[1][1]
+
+
+def test_rows_added_outside_a_collector_are_not_treated_as_chained():
+    n_env, N, T = 8, 3, 5
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=4)
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=DEV)
+    assert buf.rows_chained == "empty"
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=DEV)  # noqa: E731
+    buf.add_device(z(n_env, N, env.obs_dim), z(n_env, N, dt=torch.int32), z(n_env, N), z(n_env, N, dt=torch.uint8),
+                   z(n_env, N, dt=torch.uint8), z(n_env, N, env.obs_dim))
+    assert buf.rows_chained is False  # arbitrary rows: obs_next need not be the next slot's obs
+    buf.reset()
+    assert buf.rows_chained == "empty"
+    net = MLPActorCritic(env.obs_dim, 5, (64, 64), device=DEV, seed=1)
+    algo = GenericPPO(net=net, seed=2)
+    col = Collector(algo, env, buf)
+    col.reset()
+    col.collect(n_step=n_env * 2)
+    assert buf.rows_chained is True
+    col.reset_env()                  # the next rows do not continue the stored ones
+    col.collect(n_step=n_env * 2)
+    assert buf.rows_chained is False

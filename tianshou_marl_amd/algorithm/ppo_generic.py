@@ -34,7 +34,7 @@ class GenericPPO(PPO):
 
     def __init__(self, *, net: MLPActorCritic | None = None, critic_input: Literal["local", "global"] | None = None,
                  n_agent: int | None = None, graph: bool = True, fused_actor: bool = True,
-                 reuse_rollout_outputs: bool = True, **kwargs) -> None:
+                 reuse_rollout_outputs: bool = True, shift_next_values: bool = True, **kwargs) -> None:
         if net is None and kwargs.get("policy") is not None:  # reference-style construction (see PPO.__new__)
             from ..utils.net import net_from_reference_modules
 
@@ -66,7 +66,10 @@ class GenericPPO(PPO):
             net.critic_obs_dim, net.critic.dims[1:-1], self.n_agent if critic_input == "global" else 1, net.critic.act) \
             and net.critic.dims[-1] == 1
         self.reuse_rollout_outputs = bool(reuse_rollout_outputs)
-        self._ctor.update(fused_actor=fused_actor, reuse_rollout_outputs=reuse_rollout_outputs)
+        # V(obs_next) of chained rows from V(obs) of the next slot instead of a second full critic pass (_next_values_chained)
+        self.shift_next_values = bool(shift_next_values)
+        self._ctor.update(fused_actor=fused_actor, reuse_rollout_outputs=reuse_rollout_outputs,
+                          shift_next_values=shift_next_values)
 
     # ---- helpers --------------------------------------------------------------------------------------------------
     @property
@@ -77,12 +80,32 @@ class GenericPPO(PPO):
         per-lane form.  `batch_size` still counts samples (lanes) and must be a multiple of N."""
         return self.critic_input == "global" and self.dispatch == "pooled"
 
+    def _unit_values(self, obs_rows: torch.Tensor, joint: torch.Tensor | None) -> torch.Tensor:
+        """V per critic UNIT: a lane row (local critic) or a joint row of the env step (centralized critic)."""
+        return FlatMLP.forward(self.net.critic, obs_rows if self.critic_input == "local" else joint, save=False).reshape(-1)
+
+    def _lanes(self, v_units: torch.Tensor) -> torch.Tensor:
+        """Unit values -> one value per lane row (the joint row's value repeated for its agents)."""
+        if self.critic_input == "local":
+            return v_units.reshape(-1)
+        return v_units.reshape(-1, 1).expand(-1, self.n_agent).reshape(-1)
+
     def _values(self, obs_rows: torch.Tensor, joint: torch.Tensor | None) -> torch.Tensor:
         """V for every lane row.  local: critic(row).  global: critic(joint row of the env step), repeated per agent."""
-        if self.critic_input == "local":
-            return FlatMLP.forward(self.net.critic, obs_rows, save=False).reshape(-1)
-        v = FlatMLP.forward(self.net.critic, joint, save=False).reshape(-1, 1)
-        return v.expand(-1, self.n_agent).reshape(-1)
+        return self._lanes(self._unit_values(obs_rows, joint))
+
+    def _next_values_chained(self, vu_s: torch.Tensor, x_next: torch.Tensor, done: torch.Tensor, T: int) -> torch.Tensor:
+        """V(obs_next) per unit [T * U] for T unrotated slots of CHAINED rows (buffer.rows_chained): obs_next of slot t is
+        obs of slot t + 1 unless the episode ended at t, so the pass over obs_next (a2c.py:124) repeats the pass over obs
+        (a2c.py:123) except for the last slot -- its U rows get their own small pass -- and for rows that end an episode
+        early: then (device flag, no host round trip) the full pass runs after all.  Bit-identical to the full pass
+        either way; saves half of the preprocess' critic work in the aligned case (collect length == episode length)."""
+        U = vu_s.numel() // T
+        critic = self.net.critic
+        flag = ops.any_nonzero_u8(done[:T - 1].reshape(-1)) if T > 1 else torch.zeros(1, dtype=torch.int32, device=vu_s.device)
+        v_full, _ = ops.mlp_forward_cond(critic.desc, critic.flat.data, x_next, flag)
+        v_last = FlatMLP.forward(critic, x_next[(T - 1) * U:], save=False)
+        return ops.value_next_select(vu_s, v_last.reshape(-1), v_full.reshape(-1), flag, T, U).reshape(-1)
 
     # ---- rollout side -----------------------------------------------------------------------------------------------
     def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None,
@@ -124,15 +147,21 @@ class GenericPPO(PPO):
         reuse = allow_stored and self.reuse_rollout_outputs and rows is None and buffer.logp_store is not None
         # logp_old / v_s produced by the rollout with these very parameters (same kernels, row-wise arithmetic: the same bits
         # as recomputing them, a2c.py:121-127 / ppo.py:157-161) are taken from the buffer
+        vu_s = None
         if reuse and buffer.behaviour_outputs_version == self.param_version:
             v_s = buffer.vs_store[:T].reshape(T, L)
         else:
-            v_s = self._values(obs, joint).view(T, L)
+            vu_s = self._unit_values(obs, joint)
+            v_s = self._lanes(vu_s).view(T, L)
         if reuse and buffer.logp_outputs_version == self.param_version:
             logp_old = buffer.logp_store[:T].reshape(T * L)
         else:
             logp_old, _ = ops.categorical_logp_entropy(FlatMLP.forward(self.net.actor, obs, save=False), act)
-        v_next = self._values(obs_next, joint_next).view(T, L)
+        if vu_s is not None and rows is None and self.shift_next_values and buffer.rows_chained is True:
+            v_next = self._lanes(self._next_values_chained(vu_s, joint_next if glob else obs_next, buffer.done_store,
+                                                           T)).view(T, L)
+        else:
+            v_next = self._values(obs_next, joint_next).view(T, L)
         ret, adv = self._gae(v_s, v_next, buffer.rew_store[:T].reshape(T, L), buffer.term_store[:T].reshape(T, L),
                              buffer.trunc_store[:T].reshape(T, L), N, env_start=env_start, env_len=env_len, rows=rows)
         return dict(T=T, rows=rows, obs=obs, act=act, v_s=v_s.reshape(-1).contiguous(), ret=ret.reshape(-1),

@@ -40,6 +40,7 @@ struct GemmArgs {
     const float *X; int64_t ldx;   // dgrad: layer input (activation output of the previous layer)
     int act;                       // 0 none, 1 relu, 2 tanh (fwd: applied; dgrad: derivative w.r.t. X)
     int64_t slab_stride, w_off, b_off;  // wgrad
+    const int32_t *run_if;         // nullable device flag: the launch is a no-op when *run_if == 0 (tsm_mlp_forward_cond)
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
@@ -114,6 +115,7 @@ template <bool A_KMAJOR, bool B_KMAJOR, int EPI, int G>
 __global__ __launch_bounds__(NT * G) void gemm_kernel(GemmArgs g) {
     constexpr int kTile = (BM + BN) * LDT;  // one A tile + one B tile
     __shared__ __attribute__((aligned(16))) float lds_all[G][2 * kTile];
+    if (g.run_if && *g.run_if == 0) return;  // workgroup-uniform
     const int grp = threadIdx.x / NT;
     float *const lds_g = lds_all[grp];  // tile pair `buf` of this group: A at lds_g + buf * kTile, B behind it
     const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -264,12 +266,12 @@ TSM_EXPORT int64_t tsm_mlp_act_elems(const tsm_mlp_desc *d, int64_t B) {
     return n;
 }
 
-TSM_EXPORT int tsm_mlp_forward(const tsm_mlp_desc *d, const float *params, const float *x, int64_t B, float *acts,
-                               void *stream) {
-    if (int rc = check_desc(d, "tsm_mlp_forward")) return rc;
-    TSM_REQUIRE(B >= 0, "tsm_mlp_forward: negative batch");
+static int mlp_forward_impl(const tsm_mlp_desc *d, const float *params, const float *x, int64_t B, float *acts,
+                            const int32_t *run_if, void *stream, const char *who) {
+    if (int rc = check_desc(d, who)) return rc;
+    TSM_REQUIRE(B >= 0, "%s: negative batch", who);
     if (B == 0) return TSM_OK;
-    TSM_REQUIRE(params && x && acts, "tsm_mlp_forward: null pointer");
+    TSM_REQUIRE(params && x && acts, "%s: null pointer", who);
     const float *in = x;
     float *out = acts;
     const float *p = params;
@@ -278,9 +280,9 @@ TSM_EXPORT int tsm_mlp_forward(const tsm_mlp_desc *d, const float *params, const
         GemmArgs g{};
         g.A = in; g.lda = K; g.B = p; g.ldb = K; g.M = B; g.N = O; g.K = K; g.k_per_split = K;
         g.C = out; g.ldc = O; g.bias = p + O * K; g.act = l + 1 < d->n_layers ? d->act : 0;
+        g.run_if = run_if;
         dim3 grid((unsigned)ceil_div(O, BN), (unsigned)ceil_div(B, BM), 1);
-        TSM_REQUIRE(grid.y <= 65535, "tsm_mlp_forward: batch %lld too large for one launch (max %d rows)",
-                    (long long)B, 65535 * BM);
+        TSM_REQUIRE(grid.y <= 65535, "%s: batch %lld too large for one launch (max %d rows)", who, (long long)B, 65535 * BM);
         hipLaunchKernelGGL((gemm_kernel<false, false, EPI_FWD, 1>), grid, dim3(NT), 0, tsm_stream(stream), g);
         TSM_LAUNCH_CHECK();
         p += O * K + O;
@@ -288,6 +290,17 @@ TSM_EXPORT int tsm_mlp_forward(const tsm_mlp_desc *d, const float *params, const
         out += B * O;
     }
     return TSM_OK;
+}
+
+TSM_EXPORT int tsm_mlp_forward(const tsm_mlp_desc *d, const float *params, const float *x, int64_t B, float *acts,
+                               void *stream) {
+    return mlp_forward_impl(d, params, x, B, acts, nullptr, stream, "tsm_mlp_forward");
+}
+
+TSM_EXPORT int tsm_mlp_forward_cond(const tsm_mlp_desc *d, const float *params, const float *x, int64_t B, float *acts,
+                                    const int32_t *run_if_nonzero, void *stream) {
+    TSM_REQUIRE(run_if_nonzero, "tsm_mlp_forward_cond: null flag");
+    return mlp_forward_impl(d, params, x, B, acts, run_if_nonzero, stream, "tsm_mlp_forward_cond");
 }
 
 TSM_EXPORT int tsm_mlp_backward(const tsm_mlp_desc *d, const float *params, const float *x, int64_t B,

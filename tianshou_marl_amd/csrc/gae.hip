@@ -346,3 +346,56 @@ TSM_EXPORT int tsm_rms_update(const float *returns, const int64_t *ids, int64_t 
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }
+
+
+// ---- V(obs_next) from V(obs) of the next slot ------------------------------------------------------------------------
+// Rows written by a Collector are chained: obs_next of slot t IS obs of slot t + 1 unless the episode ended at t
+// (collector.py:1040-1069: the next observation becomes the current one; finished envs are reset).  For T unrotated,
+// equally filled slots the critic pass over obs_next (a2c.py:124) therefore repeats the pass over obs (a2c.py:123) row
+// for row, except for the last slot and for rows that end an episode.  tsm_any_nonzero_u8 tells whether any episode
+// ended before the last slot; tsm_value_next_select then takes V(obs_next) from the next slot's V(obs) and the last
+// slot's own critic pass -- or, if an episode did end early, from the full pass that tsm_mlp_forward_cond ran.
+namespace {
+
+__global__ __launch_bounds__(1024) void any_nonzero_u8_kernel(const uint8_t *__restrict__ x, int64_t n, int32_t *__restrict__ out) {
+    int any = 0;
+    const int64_t n16 = ((uintptr_t)x & 15) == 0 ? n / 16 : 0;
+    const uint4 *x16 = reinterpret_cast<const uint4 *>(x);
+    for (int64_t i = threadIdx.x; i < n16; i += 1024) {
+        const uint4 v = x16[i];
+        any |= (v.x | v.y | v.z | v.w) != 0u;
+    }
+    for (int64_t i = n16 * 16 + threadIdx.x; i < n; i += 1024) any |= x[i] != 0;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) *out = any ? 1 : 0;
+}
+
+__global__ void value_next_select_kernel(const float *__restrict__ v_s, const float *__restrict__ v_last,
+                                         const float *__restrict__ v_full, const int32_t *__restrict__ flag, int64_t T,
+                                         int64_t U, float *__restrict__ v_next) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * U) return;
+    if (*flag) { v_next[i] = v_full[i]; return; }
+    const int64_t t = i / U;
+    v_next[i] = t + 1 < T ? v_s[i + U] : v_last[i - t * U];
+}
+
+}  // namespace
+
+TSM_EXPORT int tsm_any_nonzero_u8(const uint8_t *x, int64_t n, int32_t *flag_out, void *stream) {
+    TSM_REQUIRE(n >= 0, "tsm_any_nonzero_u8: negative n");
+    TSM_REQUIRE(flag_out && (x || n == 0), "tsm_any_nonzero_u8: null pointer");
+    hipLaunchKernelGGL(any_nonzero_u8_kernel, dim3(1), dim3(1024), 0, tsm_stream(stream), x, n, flag_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+TSM_EXPORT int tsm_value_next_select(const float *v_s, const float *v_last, const float *v_full, const int32_t *flag,
+                                     int64_t T, int64_t U, float *v_next_out, void *stream) {
+    TSM_REQUIRE(T >= 1 && U >= 1, "tsm_value_next_select: T and U must be >= 1");
+    TSM_REQUIRE(v_s && v_last && v_full && flag && v_next_out, "tsm_value_next_select: null pointer");
+    hipLaunchKernelGGL(value_next_select_kernel, dim3((unsigned)ceil_div(T * U, 256)), dim3(256), 0, tsm_stream(stream),
+                       v_s, v_last, v_full, flag, T, U, v_next_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}

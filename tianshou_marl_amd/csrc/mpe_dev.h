@@ -69,34 +69,30 @@ __device__ __forceinline__ MpePos mpe_load_pos(const MpeCfg &c, const float *ap)
     return p;
 }
 
-// New position / velocity of agent i after one step (action force + soft contact forces, summed over the other
-// agents in increasing index; damping; optional speed clamp; explicit Euler).
-__device__ __forceinline__ void mpe_agent_move(const MpeCfg &c, const float *ap, const float *av, int i, int act,
-                                               float &npx, float &npy, float &nvx, float &nvy) {
-    const MpePos p = mpe_load_pos(c, ap);
-    const float px = ap[2 * i], py = ap[2 * i + 1];
-    const float vx = av[2 * i], vy = av[2 * i + 1];
-    float fx = (act == 1 ? -1.f : (act == 2 ? 1.f : 0.f)) * c.accel;
-    float fy = (act == 3 ? -1.f : (act == 4 ? 1.f : 0.f)) * c.accel;
+// Soft contact force agent i receives from agent j (j != i), signed as the serial pair loop adds it: seen from the lower
+// index (a, b) = (min, max): f_a += s*d, f_b -= s*d with d = p_a - p_b.  Returns false when the pair is far apart (the
+// common case): z < -104, so expf(z) == 0 exactly in f32 and the force is exactly 0 -- the sqrt / exp / log1p / divide
+// chain is skipped (the bound carries a margin of one contact_margin).
+__device__ __forceinline__ bool mpe_pair_force(const MpeCfg &c, float px, float py, float qx, float qy, int i, int j,
+                                               float &sx, float &sy) {
     const float k = c.contact_margin;
-    // far apart (the common case): z < -104, so expf(z) == 0 exactly in f32 and the contact force is exactly 0 --
-    // skip the sqrt / exp / log1p / divide chain.  The bound carries a margin of one contact_margin.
     const float far = 2.f * c.agent_size + 105.f * k;
-#pragma unroll
-    for (int j = 0; j < kMpeMaxN; ++j) {
-        if (j >= c.N) break;  // wave-uniform
-        // pair force seen from the lower index (a, b) = (min, max): f_a += s*d, f_b -= s*d with d = p_a - p_b
-        const float dx = i < j ? px - p.x[j] : p.x[j] - px, dy = i < j ? py - p.y[j] : p.y[j] - py;
-        const float d2 = dx * dx + dy * dy;
-        if (j != i && !(d2 > far * far)) {
-            const float dist = sqrtf(d2);
-            const float z = -(dist - 2.f * c.agent_size) / k;
-            const float pen = (z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z))) * k;  // logaddexp(0, z) * k
-            const float s = c.contact_force * pen / dist;
-            if (i < j) { fx += s * dx; fy += s * dy; }
-            else { fx -= s * dx; fy -= s * dy; }
-        }
-    }
+    const float dx = i < j ? px - qx : qx - px, dy = i < j ? py - qy : qy - py;
+    const float d2 = dx * dx + dy * dy;
+    if (d2 > far * far) return false;
+    const float dist = sqrtf(d2);
+    const float z = -(dist - 2.f * c.agent_size) / k;
+    const float pen = (z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z))) * k;  // logaddexp(0, z) * k
+    const float s = c.contact_force * pen / dist;
+    const float tx = s * dx, ty = s * dy;
+    sx = i < j ? tx : -tx;
+    sy = i < j ? ty : -ty;
+    return true;
+}
+
+// Damping, optional speed clamp and explicit Euler step of one agent under the total force (fx, fy).
+__device__ __forceinline__ void mpe_integrate(const MpeCfg &c, float px, float py, float vx, float vy, float fx, float fy,
+                                              float &npx, float &npy, float &nvx, float &nvy) {
     nvx = vx * (1.f - c.damping) + fx * c.dt;
     nvy = vy * (1.f - c.damping) + fy * c.dt;
     if (c.max_speed > 0.f) {
@@ -105,6 +101,29 @@ __device__ __forceinline__ void mpe_agent_move(const MpeCfg &c, const float *ap,
     }
     npx = px + nvx * c.dt;
     npy = py + nvy * c.dt;
+}
+
+__device__ __forceinline__ float mpe_action_force(const MpeCfg &c, int act, int axis) {
+    return axis == 0 ? (act == 1 ? -1.f : (act == 2 ? 1.f : 0.f)) * c.accel : (act == 3 ? -1.f : (act == 4 ? 1.f : 0.f)) * c.accel;
+}
+
+// New position / velocity of agent i after one step (action force + soft contact forces, summed over the other
+// agents in increasing index; damping; optional speed clamp; explicit Euler).  rollout_rows.hip evaluates the pair forces
+// on other lanes (mpe_pair_force) and folds them in the same order: the same bits.
+__device__ __forceinline__ void mpe_agent_move(const MpeCfg &c, const float *ap, const float *av, int i, int act,
+                                               float &npx, float &npy, float &nvx, float &nvy) {
+    const MpePos p = mpe_load_pos(c, ap);
+    const float px = ap[2 * i], py = ap[2 * i + 1];
+    const float vx = av[2 * i], vy = av[2 * i + 1];
+    float fx = mpe_action_force(c, act, 0);
+    float fy = mpe_action_force(c, act, 1);
+#pragma unroll
+    for (int j = 0; j < kMpeMaxN; ++j) {
+        if (j >= c.N) break;  // wave-uniform
+        float sx, sy;
+        if (j != i && mpe_pair_force(c, px, py, p.x[j], p.y[j], i, j, sx, sy)) { fx += sx; fy += sy; }
+    }
+    mpe_integrate(c, px, py, vx, vy, fx, fy, npx, npy, nvx, nvy);
 }
 
 // min over agents of the distance to landmark l (on the NEW positions).  Correctly rounded sqrt is monotone, so

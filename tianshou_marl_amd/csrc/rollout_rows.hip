@@ -21,12 +21,13 @@
 #include "vrb_dev.h"
 
 int tsm_mpe_check_cfg(const tsm_mpe_cfg *h, MpeCfg *c);  // mpe.hip
+extern long long *g_tsm_stamps;                               // abi.hip (diagnostics, tools/stamp_rollout_rows.py)
 
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int kH = 128, kTile = 32, kThreads = 512, kLdh = kH + 2, kLdo = 18, kRowsWg = 128;
+constexpr int kH = 128, kTile = 32, kThreads = 512, kLdh = kH + 2, kLdo = 8, kRowsWg = 128;  // kLdo: logits row (A <= 8)
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -45,7 +46,7 @@ struct RrLay {  // LDS layout in floats
         X = o; o += kTile * ld1;
         H1 = o; o += kTile * kLdh;
         H2 = o; o += kTile * kLdh;
-        LG = o; o += kTile * kLdo;
+        LG = o; o += kRowsWg * kLdo;  // logits of ALL rows of the step: the heads run once, after the last tile
         AP = o; o += kRowsWg * 2;
         AV = o; o += kRowsWg * 2;
         LP = o; o += kRowsWg * 2;
@@ -88,7 +89,12 @@ struct RrArgs {
     uint64_t offset_inc;
     uint64_t *offset_dev_rw;
     uint32_t *done_ctr;
+    long long *stamps;  // diagnostics only (tsm_debug_set_stamps): phase time stamps of workgroup 0, steps 0..3
 };
+
+// slot t * 32 + k of the stamp buffer: k = 0 step start, 1 index algebra, 2 obs(0), 3 + 3 i .. 5 + 3 i layers 1 / 2 / 3 of
+// tile i, 15 heads, 16 move, 17 publish, 18 reward terms + obs_next, 19 reward, 20 stores, 21 step end
+#define RSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && t < 4) a.stamps[t * 32 + (k)] = (long long)wall_clock64(); } while (0)
 
 template <int NJ>
 __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
@@ -156,11 +162,69 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
         s_lp[i] = a.lpos[(int64_t)e0 * st + i];
     }
     const uint64_t off0 = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
+
+    // ---- observation elements owned by this thread: element e = tid + 512 j of the workgroup's [rows][D] block ----
+    // mpe_obs_elem(row, k) is one LDS value or the difference of two (landmark / other agent minus own position); the two
+    // LDS offsets are worked out once here (a zero cell stands in for "no subtrahend": x - 0.f == x bit for bit), so that
+    // an element costs two LDS reads and a subtraction wherever it is needed -- the buffer's obs row and the layer-1
+    // tile at the start of a step, the obs_next row after the env step -- instead of the index arithmetic of
+    // mpe_obs_elem (measured: 1.7-2.4 us per 32-row tile, 3 times per step).
+    constexpr int kEl = 4 * NJ;
+    const int zoff = ly.B3 + 15;  // always 0.f (A <= 8 < 16)
+    uint32_t el_ab[kEl], el_rk[kEl];
+#pragma unroll
+    for (int q = 0; q < kEl; ++q) {
+        const int e_ = tid + kThreads * q;
+        int oa = zoff, ob = zoff;
+        uint32_t rk = 0xFFFFFFFFu;
+        if (e_ < rows_here * D) {
+            const int rr = e_ / D, k = e_ - rr * D, ee = rr / N, i_ = rr - ee * N, base = ee * st;
+            if (k < 2) oa = ly.AV + base + 2 * i_ + k;
+            else if (k < 4) oa = ly.AP + base + 2 * i_ + (k - 2);
+            else {
+                int kk = k - 4;
+                if (kk < 2 * N) { oa = ly.LP + base + kk; ob = ly.AP + base + 2 * i_ + (kk & 1); }
+                else {
+                    kk -= 2 * N;
+                    if (kk < 2 * (N - 1)) {
+                        int jj = kk >> 1;
+                        const int x = kk & 1;
+                        if (jj >= i_) ++jj;  // others in increasing index, skipping self
+                        oa = ly.AP + base + 2 * jj + x; ob = ly.AP + base + 2 * i_ + x;
+                    }
+                }
+            }
+            rk = ((uint32_t)ee << 24) | ((uint32_t)rr << 16) | ((uint32_t)i_ << 8) | (uint32_t)k;
+        }
+        el_ab[q] = ((uint32_t)oa << 16) | (uint32_t)ob;
+        el_rk[q] = rk;
+    }
+    auto obs_val = [&](int q) { return lds[el_ab[q] >> 16] - lds[el_ab[q] & 0xFFFFu]; };
+    // rows of tile `tile` into the layer-1 tile X (rows beyond rows_here keep stale values: their outputs are never read)
+    auto fill_x = [&](int tile) {
+#pragma unroll
+        for (int q = 0; q < kEl; ++q) {
+            const uint32_t rk = el_rk[q];
+            const int rr = (rk >> 16) & 0xFF;
+            if (rk != 0xFFFFFFFFu && (rr >> 5) == tile) lds[ly.X + (rr & 31) * ld1 + (int)(rk & 0xFF)] = obs_val(q);
+        }
+    };
+    // the pair (agent lane, other agent) tasks of the env step: task p = tid + 512 q -> agent lane p >> 3, other p & 7
+    int pair_ei[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rp = (tid + kThreads * q) >> 3, ep = rp / N;
+        pair_ei[q] = rp < rows_here ? (ep << 3) | (rp - ep * N) : -1;
+    }
+    float *s_cx = lds + ly.H1, *s_cy = s_cx + 8 * kRowsWg;           // [128][8] pair forces (H1 is idle during the env step)
+    int *s_cv = reinterpret_cast<int *>(s_cy + 8 * kRowsWg);         // [128][8] 1 = the pair is in contact range
+    const int ND = N * D;
     __syncthreads();
 
     for (int t = 0; t < a.n_steps; ++t) {
         // ---- A. buffer index algebra of this step on the env lanes (buffer_base.py:373-410 + manager.py:170-177; same
         //         arithmetic as vrb_add_row): the slot of the row is known before the payload exists ----
+        RSTAMP(0);
         bool tr = false, rec = false;
         int64_t o = 0;
         if (env_lane) {
@@ -185,21 +249,25 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
             s_done[bel] = tr ? 1 : 0;
         }
         __syncthreads();
-        // ---- B. per 32-row tile: observation rows from the LDS-resident state (also the buffer's obs rows), actor
-        //         forward, Categorical head ----
+        RSTAMP(1);
+        // ---- B. the buffer's obs rows from the LDS-resident state; per 32-row tile the actor forward; then the
+        //         Categorical heads of all rows.  The state does not change before the env step, so tile i + 1's rows go
+        //         into X as soon as layer 1 of tile i has read it, and the logits layer of tile i (waves 0-1) runs beside
+        //         layer 1 of tile i + 1: two barriers per tile.
+#pragma unroll
+        for (int q = 0; q < kEl; ++q) {
+            const uint32_t rk = el_rk[q];
+            if (rk != 0xFFFFFFFFu) {
+                const float v = obs_val(q);
+                a.obs_store[s_row[rk >> 24] * ND + (int)((rk >> 8) & 0xFF) * D + (int)(rk & 0xFF)] = v;
+                const int rr = (rk >> 16) & 0xFF;
+                if (rr < kTile) lds[ly.X + rr * ld1 + (int)(rk & 0xFF)] = v;
+            }
+        }
+        __syncthreads();
+        RSTAMP(2);
         for (int tile = 0; tile < n_tiles; ++tile) {
             const int r0 = tile * kTile;
-            for (int i = tid; i < kTile * D; i += kThreads) {
-                const int rr = i / D, k = i - rr * D, gr = r0 + rr;
-                float v = 0.f;
-                if (gr < rows_here) {
-                    const int ee = gr / N;
-                    v = mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, gr - ee * N, k);
-                    a.obs_store[(s_row[ee] * N + (gr - ee * N)) * D + k] = v;
-                }
-                lds[ly.X + rr * ld1 + k] = v;
-            }
-            __syncthreads();
             const int col = 16 * w + c16;
             {   // H1 = relu(X W1^T + b1)
                 f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
@@ -221,6 +289,8 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
                     }
             }
             __syncthreads();
+            RSTAMP(3 + 3 * tile);
+            if (tile + 1 < n_tiles) fill_x(tile + 1);
             {   // H2 = relu(H1 W2^T + b2)
                 f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
                 const float *pa = lds + ly.H1 + c16 * kLdh + kq;
@@ -241,6 +311,7 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
                     }
             }
             __syncthreads();
+            RSTAMP(4 + 3 * tile);
             if (w < 2) {  // logits (A padded to 16): waves 0 / 1 take the two row halves
                 f4 acc = f4{0.f, 0.f, 0.f, 0.f};
                 const float *pa = lds + ly.H2 + (16 * w + c16) * kLdh + kq;
@@ -248,44 +319,74 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
 #pragma unroll
                 for (int k0 = 0; k0 < kH; k0 += 4) acc = mfma4(pa[k0], pb[k0], acc);
                 const float bb = lds[ly.B3 + c16];
+                if (c16 < kLdo)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) lds[ly.LG + (16 * w + kq * 4 + q) * kLdo + c16] = acc[q] + bb;
+                    for (int q = 0; q < 4; ++q) lds[ly.LG + (r0 + 16 * w + kq * 4 + q) * kLdo + c16] = acc[q] + bb;
             }
-            __syncthreads();
-            if (tid < kTile && r0 + tid < rows_here) {  // head: one lane per row, the arithmetic of categorical.hip
-                const float *lg = lds + ly.LG + tid * kLdo;
-                float m = -INFINITY;
-                int arg = 0;
-                for (int j = 0; j < A; ++j) { const float v = lg[j]; if (v > m) { m = v; arg = j; } }
-                float s = 0.f;
-                for (int j = 0; j < A; ++j) s += expf(lg[j] - m);
-                const float lse = m + logf(s);
-                int act = arg;
-                if (a.mode == 1) {
-                    const uint64_t gi = (uint64_t)e0 * N + (uint64_t)(r0 + tid);  // global row env * N + agent
-                    const float u = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)t * B * N + gi) * s;
-                    float cs = 0.f;
-                    act = A - 1;
-                    for (int j = 0; j < A; ++j) {
-                        cs += expf(lg[j] - m);
-                        if (u < cs) { act = j; break; }
-                    }
-                }
-                s_act[r0 + tid] = act;
-                s_logp[r0 + tid] = lg[act] - lse;
-            }
-            // (the barrier after the next tile's observation build, or the one below, orders LG / X reuse)
-            __syncthreads();
+            // no barrier here: the next tile's layer 1 reads X (written before the last barrier) and writes H1 (its
+            // readers passed that barrier); its layer 2 overwrites H2 only behind the barrier that follows layer 1, which
+            // waves 0-1 reach after the logits above
+            RSTAMP(5 + 3 * tile);
         }
-        // ---- C. env step, one lane per agent (mpe_dev.h): move -> publish -> reward terms ----
-        float npx = 0.f, npy = 0.f, nvx = 0.f, nvy = 0.f;
-        if (lane_live) mpe_agent_move(c, s_ap + el * st, s_av + el * st, ai, s_act[r], npx, npy, nvx, nvy);
+        __syncthreads();  // LG complete
+        if (tid < rows_here) {  // heads: one lane per row, the arithmetic of categorical.hip
+            const float *lg = lds + ly.LG + tid * kLdo;
+            float m = -INFINITY;
+            int arg = 0;
+            for (int j = 0; j < A; ++j) { const float v = lg[j]; if (v > m) { m = v; arg = j; } }
+            float s = 0.f;
+            for (int j = 0; j < A; ++j) s += expf(lg[j] - m);
+            const float lse = m + logf(s);
+            int act = arg;
+            if (a.mode == 1) {
+                const uint64_t gi = (uint64_t)e0 * N + (uint64_t)tid;  // global row env * N + agent
+                const float u = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)t * B * N + gi) * s;
+                float cs = 0.f;
+                act = A - 1;
+                for (int j = 0; j < A; ++j) {
+                    cs += expf(lg[j] - m);
+                    if (u < cs) { act = j; break; }
+                }
+            }
+            s_act[tid] = act;
+            s_logp[tid] = lg[act] - lse;
+        }
+        // ---- C. env step (mpe_dev.h).  The soft contact forces -- sqrt / exp / log1p per pair in range, ~6 us when every
+        //         agent lane walks its N - 1 partners -- are evaluated as 128 x 8 pair tasks over all 512 threads and
+        //         folded by the agent lanes in partner order: the same additions in the same order as mpe_agent_move ----
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + kThreads * q, jp = p & 7;
+            float sx = 0.f, sy = 0.f;
+            int ok = 0;
+            if (pair_ei[q] >= 0 && jp < N) {
+                const int ip = pair_ei[q] & 7;
+                const float *ap = s_ap + (pair_ei[q] >> 3) * st;
+                if (jp != ip) ok = mpe_pair_force(c, ap[2 * ip], ap[2 * ip + 1], ap[2 * jp], ap[2 * jp + 1], ip, jp, sx, sy) ? 1 : 0;
+            }
+            s_cx[p] = sx; s_cy[p] = sy; s_cv[p] = ok;
+        }
         __syncthreads();
+        RSTAMP(15);
+        RSTAMP(16);
         if (lane_live) {
+            const float px = s_ap[el * st + 2 * ai], py = s_ap[el * st + 2 * ai + 1];
+            const float vx = s_av[el * st + 2 * ai], vy = s_av[el * st + 2 * ai + 1];
+            float fx = mpe_action_force(c, s_act[r], 0);
+            float fy = mpe_action_force(c, s_act[r], 1);
+#pragma unroll
+            for (int j = 0; j < kMpeMaxN; ++j) {
+                if (j >= N) break;
+                if (s_cv[8 * r + j]) { fx += s_cx[8 * r + j]; fy += s_cy[8 * r + j]; }
+            }
+            float npx, npy, nvx, nvy;
+            mpe_integrate(c, px, py, vx, vy, fx, fy, npx, npy, nvx, nvy);
+            // publish at once: the pair tasks (the only readers of other lanes' positions) are behind the barrier above
             s_ap[el * st + 2 * ai] = npx; s_ap[el * st + 2 * ai + 1] = npy;
             s_av[el * st + 2 * ai] = nvx; s_av[el * st + 2 * ai + 1] = nvy;
         }
         __syncthreads();
+        RSTAMP(17);
         float local = 0.f;
         if (lane_live) {
             const MpePos pos = mpe_load_pos(c, s_ap + el * st);
@@ -293,15 +394,19 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
             local = mpe_local_penalty(c, pos, s_ap + el * st, ai);
         }
         // obs_next rows (the terminal observation for finished episodes) straight into the buffer
-        if (a.obs_next_store)
-            for (int i = tid; i < rows_here * D; i += kThreads) {
-                const int rr = i / D, k = i - rr * D, ee = rr / N;
-                a.obs_next_store[(s_row[ee] * N + (rr - ee * N)) * D + k] =
-                    mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
+        if (a.obs_next_store) {
+#pragma unroll
+            for (int q = 0; q < kEl; ++q) {
+                const uint32_t rk = el_rk[q];
+                if (rk != 0xFFFFFFFFu)
+                    a.obs_next_store[s_row[rk >> 24] * ND + (int)((rk >> 8) & 0xFF) * D + (int)(rk & 0xFF)] = obs_val(q);
             }
+        }
         __syncthreads();
+        RSTAMP(18);
         if (lane_live) s_rew[r] = mpe_reward(c, s_m + el * N, local);
         __syncthreads();
+        RSTAMP(19);
         if (env_lane) {  // episode returns
             double *rec_rew = rec ? reinterpret_cast<double *>(a.ep_rec + B + (int64_t)B * a.max_ep) +
                                         ((int64_t)be * a.max_ep + n_fin) * N : nullptr;
@@ -324,7 +429,8 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
             a.trunc_store[dst] = (uint8_t)s_done[el];
             if (a.logp_store) a.logp_store[dst] = s_logp[r];
         }
-        // ---- D. finished episodes: re-initialise the env (the next step's observation build sees the new state) ----
+        RSTAMP(20);
+        // ---- D. finished episodes: re-initialise the env (the next step's observation rows see the new state) ----
         if (a.auto_reset) {
             if (env_lane && s_done[bel]) {
                 const uint64_t ep = a.episode_ctr[be];
@@ -337,14 +443,17 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
                 mpe_reset_agent(c, e, a.env_seed, s_ep[el], ai, s_ap + el * st, s_av + el * st, s_lp + el * st);
         }
         __syncthreads();
+        RSTAMP(21);
     }
     // the observation of the next collect() call, env state and sub-buffer bookkeeping back to HBM
-    if (a.obs_cur_out)
-        for (int i = tid; i < rows_here * D; i += kThreads) {
-            const int rr = i / D, k = i - rr * D, ee = rr / N;
-            a.obs_cur_out[((int64_t)e0 * N + rr) * D + k] =
-                mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
+    if (a.obs_cur_out) {
+#pragma unroll
+        for (int q = 0; q < kEl; ++q) {
+            const uint32_t rk = el_rk[q];
+            if (rk != 0xFFFFFFFFu)
+                a.obs_cur_out[((int64_t)e0 * N + (int)((rk >> 16) & 0xFF)) * D + (int)(rk & 0xFF)] = obs_val(q);
         }
+    }
     for (int i = tid; i < n_here * st; i += kThreads) {
         a.apos[(int64_t)e0 * st + i] = s_ap[i];
         a.avel[(int64_t)e0 * st + i] = s_av[i];
@@ -399,6 +508,7 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
     a.n_steps = h.n_steps; a.ep_rec = h.ep_rec; a.max_ep = h.max_ep;
     a.offset_inc = h.offset_inc; a.done_ctr = h.done_ctr;
     a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
+    a.stamps = g_tsm_stamps;
     const RrLay ly(h.obs_dim);
     const size_t shmem = (size_t)ly.total * sizeof(float);
     TSM_REQUIRE(shmem <= 160 * 1024, "tsm_rollout_spread_actor: LDS layout of %zu bytes does not fit", shmem);

@@ -55,6 +55,9 @@ class DeviceVectorReplayBuffer:
         # the same for logp / v_s alone (rows added by the unfused device collect path carry them but no V(obs_next))
         self.behaviour_outputs_version = "empty"
         self.logp_outputs_version = "empty"  # ... and for logp alone (the actor-only persistent rollout)
+        # "empty" | True | False: every row since the last reset came from collects that continue one another
+        # (mark_rows_chained); any add() from elsewhere clears it
+        self.rows_chained = "empty"
         self._host_rows: int | None = 0
         self._arange = torch.arange(self.maxsize, dtype=torch.int64, device=self.device)
 
@@ -82,6 +85,7 @@ class DeviceVectorReplayBuffer:
         self.policy_outputs_version = "empty"
         self.behaviour_outputs_version = "empty"
         self.logp_outputs_version = "empty"
+        self.rows_chained = "empty"
         self._host_rows = 0
 
     # host-side mirror of "every sub-buffer received the same number of rows since reset" (saves the update a
@@ -96,6 +100,14 @@ class DeviceVectorReplayBuffer:
         if h is None or (h > self.sub_size and h % self.sub_size != 0):
             return None
         return min(h, self.sub_size)
+
+    def mark_rows_chained(self, before, chained: bool) -> None:
+        """Called by a collect path after its adds.  `rows_chained` is True while EVERY row since the last reset came from
+        collects that continue one another: obs_next of slot t is obs of slot t + 1 of the same sub-buffer unless the
+        episode ended at t (collector.py:1040-1069) -- what lets the update take V(obs_next) from V(obs) of the next slot
+        (ops.value_next_select).  `before` = the marker's value when the collect began (direct add() calls in between
+        clear it)."""
+        self.rows_chained = bool(chained) and before in ("empty", True)
 
     def mark_behaviour_outputs(self, version) -> None:
         """Called by a collect path whose every added row carried logp / v_s of the acting policy at `version`
@@ -132,6 +144,7 @@ class DeviceVectorReplayBuffer:
         if v_s is not None and self.vs_store is not None:
             fields.append((v_s, self.vs_store))
         self.policy_outputs_version = None  # rows added without V(obs_next): the update recomputes critic passes
+        self.rows_chained = False  # (a Collector that knows its rows continue one another re-marks them afterwards)
         if logp is None or v_s is None or self.logp_store is None:
             self.behaviour_outputs_version = None
         if logp is None or self.logp_store is None:

@@ -654,6 +654,42 @@ def mlp_forward(desc, params, x, acts=None):
     return acts[n - B * O:].view(B, O), acts
 
 
+def mlp_forward_cond(desc, params, x, run_if, acts=None):
+    """`mlp_forward` whose launches are no-ops when the device flag `run_if` (i32[1]) is zero -- a pass a captured graph
+    holds but only some inputs need (value_next_select).  The returned tensors hold garbage when it did not run."""
+    x = _chk(x, torch.float32, "x")
+    B = x.shape[0]
+    if x.shape[1] != desc.dims[0]:
+        raise ValueError(f"mlp_forward_cond: input width {x.shape[1]} != dims[0] {desc.dims[0]}")
+    n = call("tsm_mlp_act_elems", C.byref(desc), B)
+    if acts is None:
+        acts = torch.empty(n, dtype=torch.float32, device=x.device)
+    call("tsm_mlp_forward_cond", C.byref(desc), ptr(_chk(params, torch.float32, "params")), ptr(x), B, ptr(acts),
+         ptr(_chk(run_if, torch.int32, "run_if")), stream_ptr())
+    O = desc.dims[desc.n_layers]
+    return acts[n - B * O:].view(B, O), acts
+
+
+def any_nonzero_u8(x, out=None):
+    """Device flag i32[1] = 1 if any byte of `x` (u8 / bool, contiguous) is non-zero."""
+    x = _chk(x, torch.uint8, "x")
+    flag = out if out is not None else torch.empty(1, dtype=torch.int32, device=x.device)
+    call("tsm_any_nonzero_u8", ptr(x), x.numel(), ptr(flag), stream_ptr())
+    return flag
+
+
+def value_next_select(v_s, v_last, v_full, flag, T: int, U: int, out=None):
+    """V(obs_next) [T, U] of chained rows: v_s shifted by one slot + the last slot's own values `v_last` [U], or the full
+    pass `v_full` [T, U] when `flag` says an episode ended before the last slot (include/tsmarl.h)."""
+    v_s, v_last, v_full = (_chk(t, torch.float32, n) for t, n in ((v_s, "v_s"), (v_last, "v_last"), (v_full, "v_full")))
+    if v_s.numel() != T * U or v_full.numel() != T * U or v_last.numel() != U:
+        raise ValueError("value_next_select: shapes do not match T x U")
+    res = out if out is not None else torch.empty(T, U, dtype=torch.float32, device=v_s.device)
+    call("tsm_value_next_select", ptr(v_s), ptr(v_last), ptr(v_full), ptr(_chk(flag, torch.int32, "flag")), T, U, ptr(res),
+         stream_ptr())
+    return res
+
+
 def mlp_n_split(B: int) -> int:
     """Default number of gradient slabs for a batch of B rows."""
     return max(1, min(64, -(-B // 256)))
