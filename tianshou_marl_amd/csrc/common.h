@@ -64,6 +64,39 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
+// Ordered folds over the 16 lanes of a row (lane j holds term j; A <= 16 terms, wave-uniform): the same additions in the
+// same order as a serial loop over j, so results are bit-identical to the one-lane form.
+//   row_prefix_sum: s += t[0] + t[1] + ... + t[A - 1]        row_prefix_sub: s = ((s - t[0]) - t[1]) - ...
+template <int J>
+__device__ __forceinline__ void row_prefix_sum(float t, int A, float &s) {
+    if constexpr (J < 16) {
+        if (J < A) {
+            s += row_dpp<0x150 + J>(t);
+            row_prefix_sum<J + 1>(t, A, s);
+        }
+    }
+}
+template <int J>
+__device__ __forceinline__ void row_prefix_sub(float t, int A, float &s) {
+    if constexpr (J < 16) {
+        if (J < A) {
+            s -= row_dpp<0x150 + J>(t);
+            row_prefix_sub<J + 1>(t, A, s);
+        }
+    }
+}
+// inverse-CDF pick: first j with u < t[0] + ... + t[j] (same running sum as row_prefix_sum)
+template <int J>
+__device__ __forceinline__ void row_cdf_pick(float t, int A, float u, float &cs, int &act, bool &found) {
+    if constexpr (J < 16) {
+        if (J < A) {
+            cs += row_dpp<0x150 + J>(t);
+            if (!found && u < cs) { act = J; found = true; }
+            row_cdf_pick<J + 1>(t, A, u, cs, act, found);
+        }
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -21,6 +21,8 @@
 // never touch HBM (the dense path writes and re-reads 4 x 512 B per sample).
 #include "common.h"
 
+extern long long *g_tsm_stamps;  // abi.hip (diagnostics, tools/stamp_actor_rows.py)
+
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -85,7 +87,10 @@ struct ActorArgs {
     int adv_norm, kind;
     float *slabs;            // [grid][P]
     double *partial;         // [grid][4] = {sum clip objective, 0, sum entropy, 0}
+    long long *stamps;       // diagnostics only (tsm_debug_set_stamps): phase time stamps of workgroup 0, its tiles 0..3
 };
+
+#define ASTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0 && it < 4) g.stamps[it * 16 + (k)] = (long long)wall_clock64(); } while (0)
 
 template <int NJ>
 __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
@@ -117,37 +122,63 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
     for (int i = 0; i < NJ; ++i) gW1[i] = f4{0.f, 0.f, 0.f, 0.f};
     gW3 = f4{0.f, 0.f, 0.f, 0.f};
     float gB = 0.f;               // threads 0..127: db1[tid]; 128..255: db2[tid - 128]; 256..271: db3[tid - 256]
-    double t_clip = 0.0, t_ent = 0.0;  // wave 0, lanes < 32
+    double t_clip = 0.0, t_ent = 0.0;  // sample leaders (lane 0 of every 16-lane group)
 
     // X tile of a tile: 32 samples x (4 nJ) float4 pieces; thread -> (sample, piece); prefetched one tile ahead
     const int n_piece = 4 * NJ;   // float4 pieces per padded row (16 nJ floats)
     const int xr = tid / n_piece, xp = tid - xr * n_piece;
     const bool x_thread = tid < kRows * n_piece;
     float xv[4] = {0.f, 0.f, 0.f, 0.f};
-    auto fetch_x = [&](int64_t tile) {
-        xv[0] = xv[1] = xv[2] = xv[3] = 0.f;
-        if (!x_thread) return;
-        const int64_t i = tile * kRows + xr;
-        if (i >= g.M) return;
-        const int64_t s = g.perm ? g.perm[i] : g.first_row + i;
-        const float *src = g.obs + s * D + 4 * xp;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (4 * xp + j < D) xv[j] = src[j];
+    // Sample ids go through the permutation: id -> row is two dependent global round trips.  The ids are therefore
+    // fetched TWO tiles ahead and the rows / loss-head inputs one tile ahead, so that neither round trip is ever waited
+    // for inside a tile (measured: the id wait in front of the row loads cost 1.0 us of a 14 us tile).
+    // x threads: (sample xr, 16-B piece xp) of the X tile; head lanes: sample tid >> 4 (its 16 lanes hold the 16 logits)
+    const int hs = tid >> 4, hj = tid & 15;
+    int64_t idx_x = -1, idx_h = -1;   // ids of the tile whose rows are fetched next
+    auto fetch_ids = [&](int64_t tile_) {
+        idx_x = -1; idx_h = -1;
+        if (tile_ >= n_tiles) return;
+        const int64_t ix = tile_ * kRows + xr, ih = tile_ * kRows + hs;
+        if (x_thread && ix < g.M) idx_x = g.perm ? g.perm[ix] : g.first_row + ix;
+        if (ih < g.M) idx_h = g.perm ? g.perm[ih] : g.first_row + ih;
     };
+    int h_act = 0, n_act = 0;         // loss-head inputs of the tile in progress / of the next tile (in flight)
+    float h_adv = 0.f, h_lpo = 0.f, n_adv = 0.f, n_lpo = 0.f;
+    auto fetch_rows = [&]() {          // rows of the ids in idx_x / idx_h
+        xv[0] = xv[1] = xv[2] = xv[3] = 0.f;
+        if (idx_x >= 0) {
+            const float *src = g.obs + idx_x * D + 4 * xp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * xp + j < D) xv[j] = src[j];
+        }
+        n_act = 0; n_adv = 0.f; n_lpo = 0.f;
+        if (idx_h >= 0) {
+            n_act = g.act[idx_h];
+            n_adv = g.adv[idx_h];
+            if (g.kind != 1) n_lpo = g.logp_old[idx_h];
+        }
+    };
+    const float adv_mean = g.adv_norm ? g.adv_stats[0] : 0.f, adv_std = g.adv_norm ? g.adv_stats[1] : 1.f;
     int64_t tile = blockIdx.x;
-    if (tile < n_tiles) fetch_x(tile);
+    fetch_ids(tile);
+    fetch_rows();
+    fetch_ids(tile + gridDim.x);
     __syncthreads();  // weights staged
 
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+        ASTAMP(0);
         // ---- P0: commit the prefetched X tile (the previous tile's readers are behind the loop-end barrier) ----
         if (x_thread) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) lds[ly.X + xr * ld1 + 4 * xp + j] = xv[j];
         }
+        h_act = n_act; h_adv = n_adv; h_lpo = n_lpo;
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) fetch_x(tile + gridDim.x);  // flies during the whole tile
+        fetch_rows();                              // next tile's rows (its ids arrived during the previous tile) ...
+        fetch_ids(tile + 2 * (int64_t)gridDim.x);  // ... and the ids of the tile after it: both fly during the whole tile
 
+        ASTAMP(1);
         const int col = 16 * w + c16;
         // ---- P1: H1 = relu(X W1^T + b1) ----
         {
@@ -167,6 +198,7 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
                 for (int r = 0; r < 4; ++r) lds[ly.H1 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
         }
         __syncthreads();
+        ASTAMP(2);
         // ---- P2: H2 = relu(H1 W2^T + b2) ----
         {
             f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
@@ -185,6 +217,7 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
                 for (int r = 0; r < 4; ++r) lds[ly.H2 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
         }
         __syncthreads();
+        ASTAMP(3);
         // ---- P3: logits = H2 W3^T + b3 (A padded to 16): waves 0 / 1 take the two row halves ----
         if (w < 2) {
             f4 acc = f4{0.f, 0.f, 0.f, 0.f};
@@ -197,33 +230,36 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
             for (int r = 0; r < 4; ++r) lds[ly.LG + (16 * w + kq * 4 + r) * kLdo + c16] = acc[r] + bb;
         }
         __syncthreads();
-        // ---- P4: loss head, one lane per sample (ppo.py:183-196, 210); logits -> d loss / d logits in place ----
-        if (w == 0 && lane < kRows) {
-            float *lg = lds + ly.LG + lane * kLdo;
-            const int64_t i = tile * kRows + lane;
-            if (i < g.M) {
-                const int64_t s = g.perm ? g.perm[i] : g.first_row + i;
+        ASTAMP(4);
+        // ---- P4: loss head (ppo.py:183-196, 210); logits -> d loss / d logits in place.  16 lanes per sample (lane j holds
+        //         action j) on all eight waves: the exponentials of a sample run side by side and are folded in action
+        //         order by DPP row operations -- the additions of the one-lane-per-sample loop, in its order ----
+        {
+            float *lg = lds + ly.LG + hs * kLdo;
+            const int64_t i = tile * kRows + hs;
+            float outv = 0.f;
+            if (i < g.M) {  // uniform over the sample's 16 lanes
+                const bool on = hj < A;
                 const float invM = 1.0f / (float)g.M;
-                float m = -INFINITY;
-                for (int j = 0; j < A; ++j) m = fmaxf(m, lg[j]);
+                const float x = on ? lg[hj] : -INFINITY;
+                const float m = row16_max(x);
+                const float ex = on ? expf(x - m) : 0.f;
                 float sum = 0.f;
-                for (int j = 0; j < A; ++j) sum += expf(lg[j] - m);
+                row_prefix_sum<0>(ex, A, sum);
                 const float lse = m + logf(sum);
-                const int a_idx = g.act[s];
-                float a = g.adv[s];
-                if (g.adv_norm) a = (a - g.adv_stats[0]) / (g.adv_stats[1] + 1e-8f);
-                float logp = 0.f, h = 0.f;
-                for (int j = 0; j < A; ++j) {
-                    const float l = lg[j] - lse;
-                    lg[j] = l;
-                    h -= expf(l) * l;
-                    if (j == a_idx) logp = l;
-                }
+                const float l = on ? x - lse : 0.f;
+                const float p = on ? expf(l) : 0.f;
+                float h = 0.f;
+                row_prefix_sub<0>(p * l, A, h);
+                const int a_idx = h_act;
+                float a = h_adv;
+                if (g.adv_norm) a = (a - adv_mean) / (adv_std + 1e-8f);
+                const float logp = __shfl(l, (lane & 48) + a_idx, 64);
                 float ratio, obj, g_ratio;
                 if (g.kind == 1) {
                     ratio = 1.f; obj = logp * a; g_ratio = a;
                 } else {
-                    ratio = expf(logp - g.logp_old[s]);
+                    ratio = expf(logp - h_lpo);
                     const float lo = 1.0f - g.eps_clip, hi = 1.0f + g.eps_clip;
                     const float rc = fminf(fmaxf(ratio, lo), hi);
                     const float s1 = ratio * a, s2 = rc * a;
@@ -239,18 +275,13 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
                 }
                 const float g_logp = -g_ratio * ratio * invM;
                 const float ec = g.ent_coef * invM;
-                for (int j = 0; j < A; ++j) {
-                    const float l = lg[j], p = expf(l);
-                    lg[j] = g_logp * ((j == a_idx ? 1.f : 0.f) - p) + ec * p * (l + h);
-                }
-                t_clip += obj;
-                t_ent += h;
-            } else {
-                for (int j = 0; j < A; ++j) lg[j] = 0.f;
+                if (on) outv = g_logp * ((hj == a_idx ? 1.f : 0.f) - p) + ec * p * (l + h);
+                if (hj == 0) { t_clip += obj; t_ent += h; }
             }
-            for (int j = A; j < 16; ++j) lg[j] = 0.f;
+            lg[hj] = outv;  // rows beyond M and actions beyond A: zero
         }
         __syncthreads();
+        ASTAMP(5);
         // ---- P5: dW3 += dLG^T H2 ; db3 ; dH2 = (dLG W3) * relu'(H2) ----
         {
             const float *a = lds + ly.LG + kq * kLdo + c16;            // A[i = a][k = row]
@@ -275,6 +306,7 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
             }
         }
         __syncthreads();  // every wave has read H2 for dW3
+        ASTAMP(6);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -283,6 +315,7 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
                 *p = *p > 0.f ? d2[mt][r] : 0.f;
             }
         __syncthreads();
+        ASTAMP(7);
         // ---- P6: dW2 += dH2^T H1 ; db2 ; dH1 = (dH2 W2) * relu'(H1) ----
         {
             const float *a = lds + ly.H2 + kq * kLdh + col;            // A[i = out o][k = row]
@@ -311,6 +344,7 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
             }
         }
         __syncthreads();  // every wave has read H1 for dW2
+        ASTAMP(8);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -319,6 +353,7 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
                 *p = *p > 0.f ? d1[mt][r] : 0.f;
             }
         __syncthreads();
+        ASTAMP(9);
         // ---- P7: dW1 += dH1^T X ; db1 ----
         {
             const float *a = lds + ly.H1 + kq * kLdh + col;            // A[i = out o][k = row]
@@ -336,6 +371,7 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
             gB += s;
         }
         __syncthreads();  // X / H1 / H2 / LG are free for the next tile
+        ASTAMP(10);
     }
 
     // ---- the workgroup's gradient slab: written once, streamed (consumed once, by the reduction kernel) ----
@@ -356,12 +392,17 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
     if (tid < 128) __builtin_nontemporal_store(gB, slab + oB1 + tid);
     else if (tid < 256) __builtin_nontemporal_store(gB, slab + oB2 + tid - 128);
     else if (tid < 256 + A) __builtin_nontemporal_store(gB, slab + oB3 + tid - 256);
-    if (w == 0) {
+    {   // loss statistics: the sample leaders (lane 0 of each 16-lane group) hold the terms; fixed order: wave sums, then waves
+        __shared__ double s_stat[2][kThreads / 64];
         const double c = wave_sum(t_clip), e = wave_sum(t_ent);
-        if (lane == 0) {
-            g.partial[4 * blockIdx.x + 0] = c;
+        if (lane == 0) { s_stat[0][w] = c; s_stat[1][w] = e; }
+        __syncthreads();
+        if (tid == 0) {
+            double cc = 0.0, ee = 0.0;
+            for (int k = 0; k < kThreads / 64; ++k) { cc += s_stat[0][k]; ee += s_stat[1][k]; }
+            g.partial[4 * blockIdx.x + 0] = cc;
             g.partial[4 * blockIdx.x + 1] = 0.0;
-            g.partial[4 * blockIdx.x + 2] = e;
+            g.partial[4 * blockIdx.x + 2] = ee;
             g.partial[4 * blockIdx.x + 3] = 0.0;
         }
     }
@@ -489,6 +530,18 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
             const int64_t i = blk * kRows + xr;
             x_row = (tid < 256 && i < g.Mr) ? (g.rows ? g.rows[i] : g.first_row + i) : -1;
         }
+        // value-loss inputs of (row tid / N, agent tid % N): row id -> returns / v_s_old are two dependent global round
+        // trips; issued here, they fly during the whole forward pass
+        float pf_ret = 0.f, pf_vs = 0.f;
+        if (tid < kRows * N) {
+            const int r_ = tid / N;
+            const int64_t i_ = blk * kRows + r_;
+            if (i_ < g.Mr) {
+                const int64_t sidx_ = (g.rows ? g.rows[i_] : g.first_row + i_) * N + (tid - r_ * N);
+                pf_ret = g.returns[sidx_];
+                if (g.value_clip) pf_vs = g.v_s_old[sidx_];
+            }
+        }
         // ---- L1: H1 = relu(X W1^T + b1), K-slices through the double buffer ----
         {
             f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
@@ -556,12 +609,10 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
             const int64_t i = blk * kRows + r;
             float dv = 0.f;
             if (i < g.Mr) {
-                const int64_t row = g.rows ? g.rows[i] : g.first_row + i;
-                const int64_t sidx = row * N + a;
-                const float v = lds[ly.V + r], ret = g.returns[sidx];
+                const float v = lds[ly.V + r], ret = pf_ret;
                 float vf, g_v;
                 if (g.value_clip) {
-                    const float vs = g.v_s_old[sidx];
+                    const float vs = pf_vs;
                     const float d = v - vs;
                     const float dc = fminf(fmaxf(d, -g.eps_clip), g.eps_clip);
                     const bool v_in = d >= -g.eps_clip && d <= g.eps_clip;
@@ -766,6 +817,7 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
     g.eps_clip = (float)cfg->eps_clip; g.dual_clip = (float)cfg->dual_clip; g.ent_coef = (float)cfg->ent_coef;
     g.adv_norm = cfg->adv_norm; g.kind = cfg->loss_kind;
     g.slabs = grad_slabs_out; g.partial = loss_partial_out;
+    g.stamps = g_tsm_stamps;
     const RowsLay ly(obs_dim);
     const size_t shmem = (size_t)ly.total * sizeof(float);
     TSM_REQUIRE(shmem <= 160 * 1024, "tsm_ppo_actor_rows_update: LDS layout of %zu bytes does not fit", shmem);
@@ -775,7 +827,7 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
     do {                                                                                                               \
         if (!attr_set[NJ - 1]) {                                                                                       \
             TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ppo_actor_rows_kernel<NJ>),                     \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                      \
             attr_set[NJ - 1] = true;                                                                                   \
         }                                                                                                              \
         hipLaunchKernelGGL((ppo_actor_rows_kernel<NJ>), dim3((unsigned)n_blocks), dim3(kThreads), shmem, st, g);       \

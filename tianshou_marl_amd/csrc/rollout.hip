@@ -63,27 +63,6 @@ struct RolloutArgs {
     long long *stamps;  // diagnostic build only (tsm_debug_set_stamps): phase time stamps of workgroup 0
 };
 
-// s += ex[0] + ex[1] + ... + ex[A - 1] in action order (ex[j] lives in lane j of the 16-lane row)
-template <int J>
-__device__ __forceinline__ void row_prefix_sum(float ex, int A, float &s) {
-    if constexpr (J < 16) {
-        if (J < A) {  // wave-uniform
-            s += row_dpp<0x150 + J>(ex);
-            row_prefix_sum<J + 1>(ex, A, s);
-        }
-    }
-}
-// inverse-CDF pick: first j with u < ex[0] + ... + ex[j] (same running sum as row_prefix_sum)
-template <int J>
-__device__ __forceinline__ void row_cdf_pick(float ex, int A, float u, float &cs, int &act, bool &found) {
-    if constexpr (J < 16) {
-        if (J < A) {
-            cs += row_dpp<0x150 + J>(ex);
-            if (!found && u < cs) { act = J; found = true; }
-            row_cdf_pick<J + 1>(ex, A, u, cs, act, found);
-        }
-    }
-}
 
 #define XSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[900 + t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 #define STAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[t * 8 + (k)] = (long long)wall_clock64(); } while (0)

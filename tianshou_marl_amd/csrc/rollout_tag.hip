@@ -62,27 +62,6 @@ struct TagRolloutArgs {
     uint32_t *done_ctr;
 };
 
-// s += ex[0] + ex[1] + ... + ex[A - 1] in action order (ex[j] lives in lane j of the 16-lane row)
-template <int J>
-__device__ __forceinline__ void row_prefix_sum(float ex, int A, float &s) {
-    if constexpr (J < 16) {
-        if (J < A) {  // wave-uniform
-            s += row_dpp<0x150 + J>(ex);
-            row_prefix_sum<J + 1>(ex, A, s);
-        }
-    }
-}
-// inverse-CDF pick: first j with u < ex[0] + ... + ex[j] (same running sum as row_prefix_sum)
-template <int J>
-__device__ __forceinline__ void row_cdf_pick(float ex, int A, float u, float &cs, int &act, bool &found) {
-    if constexpr (J < 16) {
-        if (J < A) {
-            cs += row_dpp<0x150 + J>(ex);
-            if (!found && u < cs) { act = J; found = true; }
-            row_cdf_pick<J + 1>(ex, A, u, cs, act, found);
-        }
-    }
-}
 
 constexpr int NT2 = 2 * NT;  // eight waves: actor chains on waves 0-3, critic chains on waves 4-7 (tile_forward_split)
 
