@@ -327,9 +327,10 @@ def c3_rooflines(device):
     rows, samples = n_env * T, n_env * T * N
     f_actor = 2 * (D * H + H * H + H * A)             # forward flops per sample
     f_critic = 2 * (N * D * H + H * H + H)            # forward flops per joint row
-    # executed: V(obs_next) for every row (logp_old / v_s come from the rollout) + forward and backward (2x) of every
-    # sample through the actor and of every joint row through the critic, once per epoch
-    flop = rows * f_critic + 3 * (samples * f_actor + rows * f_critic)
+    # executed: V(obs) for every joint row and V(obs_next) for the last slot's rows (the other slots take it from the next
+    # slot's V(obs): GenericPPO._next_values_chained; logp_old comes from the rollout) + forward and backward (2x) of
+    # every sample through the actor and of every joint row through the critic, once per epoch
+    flop = (rows + n_env) * f_critic + 3 * (samples * f_actor + rows * f_critic)
     steps = len(split_bounds(rows, mb // N, True))
     out = [{"kernel": "C3 whole GAE + PPO update (GenericPPO.update: V(obs_next), GAE, advantage statistics, %d gradient "
                       "steps of actor-rows kernel + critic-rows kernel + 2 Adam; one hipGraph replay)" % steps,

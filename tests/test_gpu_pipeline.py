@@ -301,12 +301,12 @@ def test_nan_in_buffer_raises_malformed_buffer_error():
 
 
 def test_update_grid_is_not_monotone_and_slabs_are_sized_for_the_largest_grid():
-    """tsm_ppo_update_grid gives a merged last minibatch (326 tiles, two per workgroup) FEWER workgroups than a regular
-    one (250 tiles, one per workgroup), so workspaces must be sized by the largest grid over the minibatches, not by the
-    grid of the largest minibatch.  9216 rows per agent with batch_size 4000 split into [4000, 5216] (Batch.split
+    """tsm_ppo_update_grid gives a merged last minibatch (320 tiles, two per workgroup) FEWER workgroups than a regular
+    one (256 tiles, one per workgroup), so workspaces must be sized by the largest grid over the minibatches, not by the
+    grid of the largest minibatch.  9216 rows per agent with batch_size 4096 split into [4096, 5120] (Batch.split
     merge_last): graph replay and eager launches must both run (ops.ppo_update_fused refuses a slab buffer that is too
     small) and agree bit for bit."""
-    assert ops.ppo_update_grid(5216) < ops.ppo_update_grid(4000)
+    assert ops.ppo_update_grid(5120) < ops.ppo_update_grid(4096)
     for M in (1, 15, 16, 17, 4096, 5120, 8192, 16384, 65536, 10**6):
         g = ops.ppo_update_grid(M)
         assert 1 <= g <= -(-M // 16)
@@ -325,11 +325,11 @@ def test_update_grid_is_not_monotone_and_slabs_are_sized_for_the_largest_grid():
         buf = DeviceVectorReplayBuffer(n_env * T, n_env, 3, 18, device=DEV)
         col = Collector(algo, env, buf)
         col.reset()
-        assert [e - s for s, e in split_bounds(n_env * T, 4000)] == [4000, 5216]
+        assert [e - s for s, e in split_bounds(n_env * T, 4096)] == [4096, 5120]
         for _ in range(3):
             with policy_within_training_step(algo):
                 col.collect(n_step=n_env * T)
-                st = algo.update(buf, 4000, 1)
+                st = algo.update(buf, 4096, 1)
             col.reset_buffer(keep_statistics=True)
         assert np.isfinite(st.get_loss_stats_dict()["agent_0/loss"])
         finals.append(net.flat.data.clone())

@@ -965,11 +965,13 @@ TSM_EXPORT int tsm_ppo_update_grid(int64_t M, int32_t max_blocks) {
     //   tiles  128: 14.8 @128 | 18.3 @64        256: 19.8 @256 | 19.2 @128 | 25.2 @86 | 27.0 @64 (tools/sweep_slab.py)
     //          320: 22.0 @160 | 22.2 @320 | 24.9 @107                       384: 22.4 @192 | 25.1 @384
     //          512: 24.8 @256 | 25.5 @384     1024: 34.3 @384 | 35.7 @256 | 44.7 @512     4096: 88 @384 | 103 @256 | 112 @512
-    // 256 tiles (the headline minibatch of 4096 rows) therefore run as 128 pairs of 2 tiles: the same time within noise
-    // and half the slab traffic (5.7 MB written + 5.7 MB read back per gradient step instead of 11.4 + 11.4).
+    // 256 tiles (the headline minibatch of 4096 rows): 128 pairs of 2 tiles halve the slab traffic (5.7 MB written + 5.7 MB
+    // read back per gradient step instead of 11.4 + 11.4) at the same isolated step time, but inside the update graph the
+    // job is not faster (0.419 vs 0.418 ms per update): the fused kernel gets 1.1 us longer, Adam 1.1 us shorter.  Kept at
+    // one tile per pair (profiles/r02_sweep_slab.txt).
     const int64_t n_tiles = ceil_div(M > 0 ? M : 1, R);
     int64_t g;
-    if (n_tiles < 256) g = n_tiles;
+    if (n_tiles <= 256) g = n_tiles;
     else if (n_tiles < 1024) g = (n_tiles + 1) / 2 < 256 ? (n_tiles + 1) / 2 : 256;
     else g = 384;
     if (max_blocks > 0 && g > max_blocks) g = max_blocks;
