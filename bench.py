@@ -501,7 +501,7 @@ def run_c3(a, device):
                      "hbm_GBps": (R * N * D * 4 + 2 * R * H * 4 * 2 + R * N * 4) / fwd_s / 1e9},
     }
     _ = ops
-    print(json.dumps(out))
+    _emit(json.dumps(out))
 
 
 def run_c3ppo(a, device):
@@ -551,7 +551,7 @@ def run_c3ppo(a, device):
     torch.cuda.synchronize()
     col.reset_buffer(keep_statistics=True)
     d = ts.get_loss_stats_dict()
-    print(json.dumps({
+    _emit(json.dumps({
         "metric": "env-steps/sec (n_env x n_agent) incl. PPO update, simple_spread N=8, centralized critic",
         "value": n_env * N * T / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, 2),
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -646,10 +646,34 @@ def run_tag(a, device, rank, world, dist):
                "losses": {k: float(v["loss"]) for k, v in losses.items()}}
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
-        print(json.dumps(out))
+        _emit(json.dumps(out))
+
+
+_OUT: list = []
+
+
+def _emit(line: str) -> None:
+    """The bench's JSON line: held back until fd 1 is the real stdout again (see main)."""
+    _OUT.append(line)
 
 
 def main():
+    # Libraries write to fd 1 behind Python's back (RCCL prints a version banner when a communicator comes up, gloo its
+    # connection notes): send fd 1 to stderr for the duration of the run so that stdout carries the ONE JSON line only.
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        _main()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    for line in _OUT:
+        print(line, flush=True)
+
+
+def _main():
     a = parse()
     if a.workload == "c3ppo":
         if not torch.cuda.is_available():
@@ -676,6 +700,17 @@ def main():
     #                               update falls back to eager launches on every rank alike
     if os.environ.get("TSM_SHARE_GPU") == "1":
         local = 0
+    # N > 1 over RCCL: ask a child process whether this box can capture collectives into a hipGraph BEFORE this process
+    # touches the GPU (a failed capture cannot be recovered from in-process); if any rank's probe fails, every rank runs
+    # eager collectives (slower, but a measured run instead of an aborted one)
+    capture_ok = None
+    if (world > 1 or os.environ.get("TSM_FORCE_DIST") == "1") and os.environ.get("TSM_DIST_BACKEND", "nccl") == "nccl" \
+            and "TSM_GRAPH_COLLECTIVES" not in os.environ:
+        from tianshou_marl_amd.parallel import probe_collective_capture
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        capture_ok = probe_collective_capture(rank, world, local)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
@@ -690,6 +725,14 @@ def main():
             dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if capture_ok is not None:  # every rank must take the same path
+            t = torch.tensor([1 if capture_ok else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            capture_ok = bool(t.item())
+            if not capture_ok:
+                os.environ["TSM_GRAPH_COLLECTIVES"] = "0"
+                if rank == 0:
+                    print("bench: the collective-capture probe failed on some rank: running eager collectives", file=sys.stderr)
     if a.workload == "tag":
         run_tag(a, device, rank, world, dist)
         if dist is not None:
@@ -740,7 +783,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "simple_spread_v3 N=%d shared PPO, num_envs=%d per GPU, obs %d, A=5, T=%d, MLP 64-64"
                        % (a.n_agent, a.n_env, 6 * a.n_agent, a.horizon),
-                       "minibatch": a.minibatch, "repeat": a.repeat, "dispatch": a.dispatch, "parallelism": "env-shard x%d" % world},
+                       "minibatch": a.minibatch, "repeat": a.repeat, "dispatch": a.dispatch, "parallelism": "env-shard x%d" % world,
+                       **({} if dist is None else {"collectives": "captured in the update hipGraph" if getattr(algo, "graph_collectives", False)
+                                                   else "eager launches"})},
             "collect_ms": t_col_ms, "ppo_update_ms": t_upd_ms,
             "collect_env_steps_per_s": a.n_env * a.n_agent * a.horizon / (t_col_ms * 1e-3),
             "gradient_steps_per_update": grad_steps,
@@ -753,7 +798,7 @@ def main():
             out["roofline_grid"] += c3_rooflines(device)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a)
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -175,3 +175,76 @@ def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) 
     if dist.get_backend(group) != "nccl" and os.environ.get("TSM_GRAPH_COLLECTIVES") != "force":
         algo.graph_collectives = False
     return sync
+
+
+# ---- can this box capture RCCL collectives into a hipGraph? -----------------------------------------------------------------
+def probe_collective_capture(rank: int, world: int, local_rank: int, timeout_s: float = 240.0) -> bool:
+    """Try, in a CHILD process, what the update graph does with more than one rank: create the RCCL communicator, capture
+    an all-reduce into a hipGraph on a side stream, replay it, check the sum.  A capture that fails leaves the stream --
+    and with it the process -- unusable (hipErrorStreamCaptureInvalidated on every later collective), so the question
+    cannot be asked in the process that goes on to do the work.  Call it on every rank BEFORE the caller touches the GPU
+    (the children rendezvous among themselves on MASTER_PORT + 1; at most `world` processes use the GPUs at any time).
+    False (child failed, crashed or timed out) -> run with TSM_GRAPH_COLLECTIVES=0 (eager collectives)."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29533")) + 1)
+    env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank))
+    try:
+        r = subprocess.run([sys.executable, "-m", "tianshou_marl_amd.parallel", "--probe-capture"], env=env,
+                           timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    except subprocess.TimeoutExpired:
+        return False
+    return r.returncode == 0
+
+
+def _probe_child() -> int:
+    import datetime
+    import os
+
+    import torch.distributed as dist
+
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        x = torch.ones(11142, device=dev)
+        dist.all_reduce(x)  # communicator up, outside any capture
+        torch.cuda.synchronize()
+        x.fill_(1.0)
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g.capture_begin(capture_error_mode="thread_local")
+            dist.all_reduce(x)
+            y = x * 0.5
+            g.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        ok = bool(torch.allclose(x, torch.full_like(x, float(world))) and torch.allclose(y, torch.full_like(y, world / 2.0)))
+        x.fill_(2.0)
+        g.replay()
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.allclose(x, torch.full_like(x, 2.0 * world)))
+        dist.barrier()
+        return 0 if ok else 1
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import sys
+
+    if "--probe-capture" in sys.argv:
+        try:
+            code = _probe_child()
+        except BaseException:  # noqa: BLE001  (any failure means "do not capture")
+            code = 1
+        sys.exit(code)
