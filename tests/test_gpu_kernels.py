@@ -53,6 +53,28 @@ def test_gae_matches_oracle(oracle, T, L):
     np.testing.assert_allclose(ret.cpu().numpy(), ret_o, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("T,L,per_env", [(12800, 1, False), (1024, 1, False), (1500, 3, True), (5000, 64, False),
+                                         (4097, 2, True), (20000, 5, False)])
+def test_gae_few_long_lanes_take_the_time_parallel_kernel(oracle, T, L, per_env):
+    """T >= 1024 with at most 64 lanes (the MARL trainers' per-agent batch is ONE lane of n_env * T rows): gae_long_kernel,
+    one workgroup per lane, chunks combined by a parallel suffix scan of their affine maps.  Same bar as the lane kernel
+    (1e-6 vs the f64 oracle); episode ends every ~25 steps, rare ones, and none at all (discount chains of 1000+ steps)."""
+    for p_end in (0.04, 0.001, 0.0):
+        rng = np.random.default_rng(T + L)
+        v_s, v_n, rew, term, trunc = _rand_gae_inputs(rng, T, L, p_end, p_end)
+        kw = {}
+        if per_env:  # one flag per env shared by its lanes (here: every lane its own env group of size L)
+            term, trunc = term[:, :1].copy(), trunc[:, :1].copy()
+            term_l, trunc_l = np.repeat(term, L, axis=1), np.repeat(trunc, L, axis=1)
+            kw = dict(lanes_per_env=L)
+        else:
+            term_l, trunc_l = term, trunc
+        ret_o, adv_o = oracle.gae_lanes(v_s, v_n, rew, term_l, trunc_l, 0.99, 0.95, v_scale=1.7)
+        ret, adv = ops.gae_lanes(t(v_s), t(v_n), t(rew), t(term), t(trunc), 0.99, 0.95, v_scale=1.7, **kw)
+        np.testing.assert_allclose(adv.cpu().numpy(), adv_o, rtol=1e-6, atol=2e-6)
+        np.testing.assert_allclose(ret.cpu().numpy(), ret_o, rtol=1e-6, atol=2e-6)
+
+
 def test_gae_env_level_flags_and_return_scaling(oracle):
     rng = np.random.default_rng(3)
     T, n_env, N = 25, 37, 3

@@ -634,7 +634,92 @@ class PPO(nn.Module):
     def learn(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
         """One PPO pass on an explicit agent batch holding obs, act, rew, obs_next, terminated[, truncated].
         Rows are one time-ordered lane (the reference's per-agent Batch); GAE treats the last row as end."""
+        if self.use_graph and self._grad_sync is None and not (self.recompute_adv and repeat > 1):
+            return self._learn_graph(batch, batch_size, repeat)
         return drive_steps(self.learn_steps(batch, batch_size, repeat, **kwargs), self._grad_sync)
+
+    def _learn_graph(self, batch: Batch, batch_size: int | None, repeat: int) -> dict[str, float]:
+        """`learn` as ONE hipGraph replay per call (the MARL trainers call it once per policy and step,
+        training_coordinator.py:118,154,336): the batch is copied into static HBM buffers, then the critic passes, GAE,
+        the permutations, advantage statistics and every gradient step replay as captured -- the same launches in the
+        same order as `learn_steps`, hence the same bits.  The optimizer step count and the permutation counter live in
+        HBM, so replays advance them; the learning rate is read from HBM."""
+        dev = self.device
+        n = len(batch.rew)
+        D, A, H = self.net.obs_dim, self.net.n_act, self.net.hidden
+        key = ("learn_graph", n, batch_size, repeat, "truncated" in batch, self.shuffle)
+        w = self._ws.get(key)
+        bounds = split_bounds(n, batch_size or -1, merge_last=True)
+        n_steps = repeat * len(bounds)
+        if w is None:
+            self._warm_kernels(None)
+            P = self.net.flat.data
+            z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
+            nb_max = max(ops.ppo_update_grid(e - s) for s, e in bounds)
+            w = dict(obs=z(n, D), obs_next=z(n, D), act=z(n, dt=torch.int32), rew=z(n, 1), term=z(n, 1, dt=torch.uint8),
+                     trunc=z(n, 1, dt=torch.uint8), scal=z(n_steps, 4), step_dev=z(1, dt=torch.int64),
+                     slabs=torch.empty(nb_max, P.numel(), dtype=torch.float32, device=dev),
+                     partial=torch.empty(nb_max * 4, dtype=torch.float64, device=dev),
+                     perm=z(repeat, n, dt=torch.int64),
+                     mb_start=torch.as_tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=dev))
+
+            def body():
+                # `flat` is the source of truth before the first Adam step of this call (the image may be stale)
+                cur = ops.policy_forward(P, w["obs"], A, H, image=None, mode="given", act=w["act"], want_logits=False)
+                nxt = ops.policy_forward(P, w["obs_next"], A, H, image=None, mode="none", want_logits=False)
+                ret, adv = ops.gae_lanes(cur["value"].view(n, 1), nxt["value"].view(n, 1), w["rew"], w["term"], w["trunc"],
+                                         self.gamma, self.gae_lambda)
+                ret, adv = ret.reshape(-1), adv.reshape(-1)
+                k = 0
+                for r in range(repeat):
+                    if self.shuffle != "numpy":
+                        ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, out=w["perm"][r:r + 1])
+                        ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
+                    perm = w["perm"][r]
+                    stats = (ops.ppo_adv_stats(adv, w["mb_start"], perm=perm, max_rows=max(e - s for s, e in bounds))
+                             if self.advantage_normalization else None)
+                    for j, (s_, e_) in enumerate(bounds):
+                        nb = ops.ppo_update_grid(e_ - s_)
+                        ops.ppo_update_fused(P, w["obs"], w["act"], cur["logp"], adv, ret, self._cfg, A, H,
+                                             adv_stats=None if stats is None else stats[j],
+                                             v_s_old=cur["value"] if self.value_clip else None, perm=perm[s_:e_],
+                                             image=self.net.image if k > 0 else None, M=e_ - s_, n_blocks=nb,
+                                             slabs=w["slabs"][:nb], partial=w["partial"], scalars=w["scal"][k],
+                                             opt_step_dev=w["step_dev"])
+                        ops.adam_step(P, w["slabs"][:nb], self.exp_avg, self.exp_avg_sq, 1, lr=self.lr, lr_dev=self._lr_dev,
+                                      betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
+                                      max_grad_norm=self.max_grad_norm, work=self._adam_work, step_dev=w["step_dev"],
+                                      image=self.net.image, image_map=self.net.image_map)
+                        k += 1
+
+            w["body"] = body
+            self._ws[key] = w
+        # the batch into the static buffers (copy_ converts int64 actions / bool flags; host arrays are uploaded)
+        t = lambda x: x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))  # noqa: E731
+        w["obs"].copy_(t(batch.obs).reshape(n, D), non_blocking=True)
+        w["obs_next"].copy_(t(batch.obs_next).reshape(n, D), non_blocking=True)
+        w["act"].copy_(t(batch.act).reshape(n), non_blocking=True)
+        w["rew"].copy_(t(batch.rew).reshape(n, 1), non_blocking=True)
+        w["term"].copy_(t(batch.terminated).reshape(n, 1), non_blocking=True)
+        if "truncated" in batch:
+            w["trunc"].copy_(t(batch.truncated).reshape(n, 1), non_blocking=True)
+        if self.shuffle == "numpy":  # Batch.split draws np.random.permutation per repeat (batch.py:1219)
+            for r in range(repeat):
+                w["perm"][r].copy_(torch.as_tensor(np.random.permutation(n)), non_blocking=True)
+        if w.get("step_host") != self.opt_step:  # the device-side step count is stale (eager updates, a loaded checkpoint)
+            w["step_dev"].fill_(self.opt_step)
+        if "graph" not in w:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                w["body"]()
+            w["graph"] = graph
+        w["graph"].replay()
+        self.opt_step += n_steps
+        w["step_host"] = self.opt_step
+        self.param_version += 1
+        s_h = w["scal"].cpu().numpy()  # the one host sync of the call
+        return {"loss": float(s_h[:, 0].mean()), "actor_loss": float(s_h[:, 1].mean()), "vf_loss": float(s_h[:, 2].mean()),
+                "ent_loss": float(s_h[:, 3].mean())}
 
     def __deepcopy__(self, memo):
         """Snapshot for opponent pools (training_coordinator.py:481-494): parameters, optimizer state and counters are

@@ -231,6 +231,92 @@ __global__ __launch_bounds__(64) void rms_merge_kernel(const double *__restrict_
     rms[2] = total;
 }
 
+// ---- few lanes, long series: TIME is the parallel axis ------------------------------------------------------------------
+// The MARL trainers hand PPO.learn ONE time-ordered lane of n_env * T rows (training_coordinator.py:118,154,336: a per-agent
+// Batch; episode ends are flags inside the lane).  gae_lanes_kernel walks such a lane in super-chunks of W * CH = 64 steps,
+// each behind its own round of loads: 200 dependent round trips for 12 800 rows (measured 682 us).  Here a workgroup owns
+// one lane and its 1024 threads each own CH consecutive steps of a super-chunk of 1024 * CH steps; the chunks' affine maps
+// (carry -> B + P * carry) are combined by a parallel suffix scan in LDS (10 doubling steps), every thread then replays its
+// chunk from its true carry-in.  Same f64 recurrence per step; the maps are composed in a different association order than
+// in gae_lanes_kernel (differences at the 1e-16 level, before the one rounding to f32).
+template <bool FLAGS_PER_LANE, int CH>
+__global__ __launch_bounds__(1024) void gae_long_kernel(
+    const float *__restrict__ v_s, const float *__restrict__ v_n, const float *__restrict__ rew,
+    const uint8_t *__restrict__ term, const uint8_t *__restrict__ trunc, int64_t T, int64_t L, int64_t lanes_per_env,
+    double gamma, double gl, double v_scale_arg, const double *__restrict__ rms, double rms_eps,
+    float *__restrict__ ret_out, float *__restrict__ adv_out) {
+    __shared__ double sP[2][1024], sB[2][1024];
+    const int t = threadIdx.x;
+    const int64_t lane = blockIdx.x;
+    const int64_t env = lane / lanes_per_env, n_env = L / lanes_per_env;
+    const double v_scale = rms ? sqrt(rms[1] + rms_eps) : v_scale_arg;
+    const double inv_scale = 1.0 / v_scale;
+    const int64_t SC = (int64_t)1024 * CH;
+    const int64_t n_sc = (T + SC - 1) / SC;
+    double carry_super = 0.0;
+    for (int64_t s = n_sc - 1; s >= 0; --s) {
+        const int64_t k0 = s * SC + (int64_t)t * CH;
+        double delta[CH], vs_[CH];
+        unsigned keep = 0, valid = 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int64_t kk = k0 + k;
+            delta[k] = 0.0; vs_[k] = 0.0;
+            if (kk < T) {
+                const int64_t i = kk * L + lane;
+                const uint8_t te = FLAGS_PER_LANE ? term[i] : term[kk * n_env + env];
+                const uint8_t tr = FLAGS_PER_LANE ? trunc[i] : trunc[kk * n_env + env];
+                const double vs = (double)v_s[i] * v_scale;
+                const double vn = te ? 0.0 : (double)v_n[i] * v_scale;
+                delta[k] = (double)rew[i] + vn * gamma - vs;
+                vs_[k] = vs;
+                const bool end = te | tr | (kk == T - 1);
+                keep |= (end ? 0u : 1u) << k;
+                valid |= 1u << k;
+            }
+        }
+        // own chunk with carry 0 -> affine map (masked step: identity)
+        double P = 1.0, B = 0.0;
+#pragma unroll
+        for (int k = CH - 1; k >= 0; --k) {
+            const double d = ((valid >> k) & 1u) ? (((keep >> k) & 1u) ? gl : 0.0) : 1.0;
+            B = delta[k] + d * B;
+            P *= d;
+        }
+        // inclusive suffix scan over the chunks: S[t] = map of chunks t .. 1023 (the later chunk is applied first)
+        int cur = 0;
+        sP[0][t] = P; sB[0][t] = B;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            double p = sP[cur][t], b = sB[cur][t];
+            if (t + off < 1024) {
+                const double p2 = sP[cur][t + off], b2 = sB[cur][t + off];
+                b = b + p * b2;
+                p = p * p2;
+            }
+            sP[cur ^ 1][t] = p; sB[cur ^ 1][t] = b;
+            cur ^= 1;
+            __syncthreads();
+        }
+        // carry-in of this chunk = the later chunks of the super-chunk applied to the carry of the later super-chunks
+        double g = carry_super;
+        if (t + 1 < 1024) g = sB[cur][t + 1] + sP[cur][t + 1] * carry_super;
+        const double next_super = sB[cur][0] + sP[cur][0] * carry_super;
+#pragma unroll
+        for (int k = CH - 1; k >= 0; --k) {
+            if ((valid >> k) & 1u) {
+                const double d = ((keep >> k) & 1u) ? gl : 0.0;
+                g = delta[k] + d * g;
+                const int64_t i = (k0 + k) * L + lane;
+                adv_out[i] = (float)g;
+                ret_out[i] = (float)((g + vs_[k]) * inv_scale);
+            }
+        }
+        carry_super = next_super;
+        __syncthreads();  // the LDS maps are rewritten by the next (earlier) super-chunk
+    }
+}
+
 int pick_waves(int64_t T, int64_t L, int vec, int ch) {
     // enough waves to fill 256 CUs x 8, but no more chunks than the series has
     int64_t blocks = ceil_div(L, 64 * vec);
@@ -278,6 +364,17 @@ static int gae_impl(const float *v_s, const float *v_s_next, const float *rew, c
     // Steps per thread: 4 (measured best on MI355X: 41.7 % of HBM peak at T=25 x 32768 lanes, 67 % at T=2048; 8 steps
     // per thread and the 8-/16-byte-per-lane variants VEC=2/4 lose to register pressure from the f64 scan state --
     // profiles/r01_gae_sweep.txt).  VEC stays a template parameter for that experiment; only VEC=1 is instantiated.
+    // few lanes and a long series (one lane per policy in the MARL trainers' learn(batch)): time-parallel kernel
+    if (!generic && n_lane <= 64 && T >= 1024 && !g_force_ch && !g_force_w) {
+        const dim3 grid((unsigned)n_lane), block(1024);
+#define LONG(F, C) hipLaunchKernelGGL((gae_long_kernel<F, C>), grid, block, 0, st, v_s, v_s_next, rew, terminated, truncated, T, \
+                                      n_lane, lanes_per_env, gamma, gl, v_scale, rms, rms_eps, returns_out, adv_out)
+        if (T > 4096) { if (flags_per_lane) LONG(true, 16); else LONG(false, 16); }
+        else { if (flags_per_lane) LONG(true, 4); else LONG(false, 4); }
+#undef LONG
+        TSM_LAUNCH_CHECK();
+        return TSM_OK;
+    }
     int ch = 4;
     if (g_force_ch) ch = g_force_ch;
     (void)g_force_vec;
