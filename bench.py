@@ -124,6 +124,15 @@ def phase_times(a, algo, buf, col, reps=5):
     return t_col / reps, t_upd / reps
 
 
+def loss_grid_threads(M: int) -> int:
+    """Grid of loss_kernel for M samples (csrc/ppo_loss.hip loss_blocks): 256-sample tiles, at most 2048 workgroups, every
+    workgroup the same number of tiles."""
+    n = -(-M // 256)
+    if n > 2048:
+        n = -(-n // -(-n // 2048))
+    return n * 256
+
+
 def pmc_traffic(kernel: str, grid_threads: int):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
     (profiles/*pmc_traffic.json, written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes with
@@ -233,7 +242,7 @@ def kernel_rooflines(a, algo, buf):
     grid.append({"kernel": "loss_kernel<5> (PPO clip loss fwd+bwd on given logits/value)", "rows": Mg, "bound": "hbm",
                  "bytes_per_launch": loss_bytes, "us_per_launch": s_l * 1e6, "achieved": loss_bytes / s_l / 1e9,
                  "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": loss_bytes / s_l / HBM_PEAK,
-                 "traffic": pmc_traffic("loss_kernel", 4096 * 256 if Mg > 4096 * 256 else -(-Mg // 256) * 256)})
+                 "traffic": pmc_traffic("loss_kernel", loss_grid_threads(Mg))})
     del lg_, vals, actg
     # (4) the fused gradient step when the workload hands it more than one 16-row tile per workgroup: pooled minibatch
     # of 65 536 rows (SURVEY 8d grid) out of 819 200 buffer rows of this job's observation width.  Opt-in

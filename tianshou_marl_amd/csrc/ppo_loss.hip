@@ -125,11 +125,13 @@ struct Cfg {
 
 constexpr int kLossThreads = 256;
 constexpr int kMaxA = 64;
-constexpr int64_t kMaxLossBlocks = 4096;  // 16 workgroups per CU: enough to saturate HBM, few enough to fold quickly
+constexpr int64_t kMaxLossBlocks = 2048;  // 8 workgroups per CU: all of them resident at once
 
+// Every workgroup walks the same number of 256-sample tiles (no tail round of a few workgroups on an otherwise idle chip).
 inline int64_t loss_blocks(int64_t M) {
     const int64_t n = ceil_div(M, kLossThreads);
-    return n < kMaxLossBlocks ? n : kMaxLossBlocks;
+    if (n <= kMaxLossBlocks) return n;
+    return ceil_div(n, ceil_div(n, kMaxLossBlocks));
 }
 
 template <int A_T>
@@ -186,11 +188,13 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
         float a = adv[row];
         if (cfg.adv_norm) a = (a - adv_stats[0]) / (adv_stats[1] + 1e-8f);
         float logp = 0.f, h = 0.f;
+        float pr[A_T > 0 ? A_T : kMaxA];  // p_j = exp(log-softmax_j): needed again for the gradient (one expf per action, not two)
 #pragma unroll
         for (int j = 0; j < A; ++j) {
             const float l = lg[j] - lse;
             lg[j] = l;
-            h -= expf(l) * l;
+            pr[j] = expf(l);
+            h -= pr[j] * l;
             if (j == a_idx) logp = l;
         }
         float ratio, obj, g_ratio;  // d obj / d logp = g_ratio * ratio
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_kernel(
         const float ec = cfg.ent_coef * invM;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
-            const float l = lg[j], p = expf(l);
+            const float l = lg[j], p = pr[j];
             const float dlogp = (j == a_idx ? 1.f : 0.f) - p;
             const float dent = -p * (l + h);
             dlogits[i * A + j] = g_logp * dlogp - ec * dent;
