@@ -596,7 +596,7 @@ def run_tag(a, device, rank, world, dist):
 
         attach_data_parallel(mgr, dist)
     buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=device)
-    col = Collector(mgr, env, buf)
+    col = Collector(mgr, env, buf, async_stats=True)  # statistics resolve lazily, as in the headline job
     col.reset()
     trainer = LeaguePlayTrainer(mgr, matchmaking="random")
     np.random.seed(1626)  # matchmaking draws must agree on every rank
@@ -613,6 +613,7 @@ def run_tag(a, device, rank, world, dist):
             batch["good"], batch["adversaries"] = batch["agent_0"], batch["adversary_0"]
             losses = trainer.train_step(batch)
             e[2].record()
+        _resolve(cs)  # read every step's collect statistics (see one_step); the losses are read one step late, below
         col.reset_buffer(keep_statistics=True)
         marks.append(e)
         return cs, losses
@@ -623,8 +624,13 @@ def run_tag(a, device, rank, world, dist):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    prev = None
     for _ in range(a.steps):
         cs, losses = step()
+        if prev is not None:  # every step's training statistics are read, one step late (as a logger would)
+            for v in prev.values():
+                float(v["loss"])
+        prev = losses
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -717,9 +717,24 @@ class PPO(nn.Module):
         self.opt_step += n_steps
         w["step_host"] = self.opt_step
         self.param_version += 1
-        s_h = w["scal"].cpu().numpy()  # the one host sync of the call
-        return {"loss": float(s_h[:, 0].mean()), "actor_loss": float(s_h[:, 1].mean()), "vf_loss": float(s_h[:, 2].mean()),
-                "ent_loss": float(s_h[:, 3].mean())}
+        # the statistics travel to a pinned host slot behind the replay; the returned mapping waits for them only when
+        # it is read (the reference's learn() returns floats: 4 .item() per minibatch) -- the host never blocks here,
+        # except to keep at most 4 calls in flight
+        ring = w.setdefault("ring", [])
+        if len(ring) < 4:
+            ring.append(dict(h=torch.empty(n_steps, 4, dtype=torch.float32, pin_memory=True), event=torch.cuda.Event(),
+                             pending=None))
+            slot = ring[-1]
+        else:
+            slot = ring[w.get("ring_pos", 0) % 4]
+            w["ring_pos"] = w.get("ring_pos", 0) + 1
+            if slot["pending"] is not None:
+                slot["pending"]._force()
+        slot["h"].copy_(w["scal"], non_blocking=True)
+        slot["event"].record()
+        out = LazyLosses(slot)
+        slot["pending"] = out
+        return out
 
     def __deepcopy__(self, memo):
         """Snapshot for opponent pools (training_coordinator.py:481-494): parameters, optimizer state and counters are
@@ -810,6 +825,78 @@ class PPO(nn.Module):
 
     def run_training(self, params):
         return self.create_trainer(params).run()
+
+
+class LazyLosses(dict):
+    """The dict `learn()` returns ({"loss", "actor_loss", "vf_loss", "ent_loss"}: means over the call's gradient steps),
+    filled in when it is first read: the statistics are on their way to pinned host memory behind the captured update."""
+
+    def __init__(self, slot: dict) -> None:
+        super().__init__()
+        self._slot = slot
+
+    def _force(self) -> None:
+        slot = self._slot
+        if slot is None:
+            return
+        self._slot = None
+        slot["event"].synchronize()
+        s_h = slot["h"].numpy()
+        dict.update(self, loss=float(s_h[:, 0].mean()), actor_loss=float(s_h[:, 1].mean()), vf_loss=float(s_h[:, 2].mean()),
+                    ent_loss=float(s_h[:, 3].mean()))
+        if slot.get("pending") is self:
+            slot["pending"] = None
+
+    def __getitem__(self, k):
+        self._force()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._force()
+        return dict.get(self, k, default)
+
+    def __contains__(self, k):
+        self._force()
+        return dict.__contains__(self, k)
+
+    def __iter__(self):
+        self._force()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._force()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._force()
+        return dict.keys(self)
+
+    def values(self):
+        self._force()
+        return dict.values(self)
+
+    def items(self):
+        self._force()
+        return dict.items(self)
+
+    def __eq__(self, other):
+        self._force()
+        if isinstance(other, LazyLosses):
+            other._force()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._force()
+        return dict.__repr__(self)
+
+    def copy(self):
+        self._force()
+        return dict(self)
 
 
 def drive_steps(gen, grad_sync):
