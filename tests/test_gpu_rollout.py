@@ -102,8 +102,10 @@ def _job128(n_env, N, T, fused, glob, seed=3, slots=None):
 
 # (600, 8): 38 workgroups of 16 envs; (50, 3): 42 envs per workgroup, 126 live rows (partial last tile); (4096, 8): the
 # BASELINE configs[2] size, one workgroup per CU
+# (40, 5) / (21, 7): observation widths 30 / 42 -- a thread's observation elements straddle the 32-row tiles
 @pytest.mark.parametrize("n_env,N,T,steps,glob", [(600, 8, 4, 6, True), (50, 3, 6, 15, False), (5, 1, 4, 9, False),
-                                                  (33, 8, 25, 25, True), (4096, 8, 25, 25, True)])
+                                                  (33, 8, 25, 25, True), (4096, 8, 25, 25, True), (40, 5, 5, 8, False),
+                                                  (21, 7, 4, 6, True)])
 def test_actor_rollout_is_bit_identical_to_unfused(n_env, N, T, steps, glob):
     slots = steps + 3 + 1
     outs = []

@@ -387,6 +387,7 @@ class DeviceAECReplayBuffer(DeviceVectorReplayBuffer):
         else:
             self._host_rows = None
         done = t(term_h | trunc_h, torch.uint8)
+        self.rows_chained = False  # agent turns: the next row of a sub-buffer belongs to another agent
         out = self.index.add(t(rew, torch.float32), done, ids, fields=fields)
         return tuple(x.cpu().numpy() for x in out)
 
