@@ -588,7 +588,8 @@ def run_tag(a, device, rank, world, dist):
     env = DeviceSimpleTagVectorEnv(n_env, device=device, seed=1626 + rank, max_cycles=T)
     N = env.n_agent
     mk = lambda s: PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=device, seed=s), seed=s + rank, lr=3e-4,  # noqa: E731
-                       shuffle="device")  # learn() replays one hipGraph per call on one GPU; lock-step eager launches under DP
+                       shuffle="device", async_stats=True)  # learn(): one hipGraph replay per call, statistics resolve when read
+    #                                                          (lock-step eager launches under data parallelism)
     teams = {"adversaries": mk(1626), "good": mk(1627)}
     mgr = FlexibleMultiAgentPolicyManager(teams, env, mode="grouped", agent_groups=env.agent_groups)
     if dist is not None:

@@ -717,9 +717,9 @@ class PPO(nn.Module):
         self.opt_step += n_steps
         w["step_host"] = self.opt_step
         self.param_version += 1
-        # the statistics travel to a pinned host slot behind the replay; the returned mapping waits for them only when
-        # it is read (the reference's learn() returns floats: 4 .item() per minibatch) -- the host never blocks here,
-        # except to keep at most 4 calls in flight
+        # the statistics travel to a pinned host slot behind the replay.  async_stats=True: the returned mapping waits for
+        # them only when it is read (the reference's learn() returns floats: 4 .item() per minibatch) -- the host never
+        # blocks here, except to keep at most 4 calls in flight
         ring = w.setdefault("ring", [])
         if len(ring) < 4:
             ring.append(dict(h=torch.empty(n_steps, 4, dtype=torch.float32, pin_memory=True), event=torch.cuda.Event(),
@@ -733,6 +733,8 @@ class PPO(nn.Module):
         slot["h"].copy_(w["scal"], non_blocking=True)
         slot["event"].record()
         out = LazyLosses(slot)
+        if not self.async_stats:  # plain floats at once, as the reference returns them
+            return dict(out)
         slot["pending"] = out
         return out
 
@@ -828,8 +830,10 @@ class PPO(nn.Module):
 
 
 class LazyLosses(dict):
-    """The dict `learn()` returns ({"loss", "actor_loss", "vf_loss", "ent_loss"}: means over the call's gradient steps),
-    filled in when it is first read: the statistics are on their way to pinned host memory behind the captured update."""
+    """What `learn()` returns with `async_stats=True` ({"loss", "actor_loss", "vf_loss", "ent_loss"}: means over the call's
+    gradient steps): a dict filled in when it is first read -- the statistics are on their way to pinned host memory behind
+    the captured update.  Every Python-level read resolves it; C code that walks the dict storage directly (json.dumps
+    without `indent`) does not, so pass `dict(x)` to such consumers."""
 
     def __init__(self, slot: dict) -> None:
         super().__init__()
