@@ -150,3 +150,46 @@ def test_update_after_actor_rollout_equals_update_after_unfused_collect():
         res.append((net.flat.data.clone(), st.get_loss_stats_dict()))
     assert torch.equal(res[0][0], res[1][0])
     assert res[0][1] == res[1][1]
+
+
+@pytest.mark.parametrize("kind", ["shared_ppo64", "ctde", "shared_ctde"])
+def test_wrapped_and_ctde_policies_take_the_persistent_rollouts(kind):
+    """A multi-agent wrapper in parameter-sharing mode forwards all rows to ONE policy (marl.py:137-190), and CTDEPolicy's
+    DecentralizedActor (ctde.py:346-396) is a 48-128-128-5 actor like GenericPPO's: both collect through the persistent
+    kernels, bit-identical to their unfused launch sequences (incl. a policy whose sampling counter was advanced by host
+    forward calls before)."""
+    from tianshou_marl_amd.algorithm.multiagent import CentralizedCritic, CTDEPolicy, DecentralizedActor, FlexibleMultiAgentPolicyManager
+
+    n_env, N, T, steps = 96, 8 if "ctde" in kind else 3, 5, 8
+    outs = []
+    for fused in (False, True):
+        env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=3)
+        D = env.obs_dim
+        if kind == "shared_ppo64":
+            base = PPO(net=DiscreteActorCritic(D, 5, 64, device=DEV, seed=3), seed=3)
+            base._sample_ctr = 1234  # as after host-side forward() calls
+            pol = FlexibleMultiAgentPolicyManager(base, env, mode="shared")
+        else:
+            base = CTDEPolicy(actor=DecentralizedActor(D, 5, 128, device=DEV, seed=1),
+                              critic=CentralizedCritic(N * D, N, 128, device=DEV, seed=2), seed=5)
+            pol = FlexibleMultiAgentPolicyManager(base, env, mode="shared") if kind == "shared_ctde" else base
+        buf = DeviceVectorReplayBuffer(n_env * (steps + 4), n_env, N, D, device=DEV)
+        col = Collector(pol, env, buf, fused_rollout=fused, use_graph=False)
+        col.reset()
+        assert col._can_fuse() == fused
+        with policy_within_training_step(pol):
+            st1 = col.collect(n_step=n_env * steps)
+            st2 = col.collect(n_step=n_env * 3)
+        outs.append(dict(obs=buf.obs_store.clone(), obs_next=buf.obs_next_store.clone(), act=buf.act_store.clone(),
+                         rew=buf.rew_store.clone(), trunc=buf.trunc_store.clone(), logp=buf.logp_store.clone(),
+                         done=buf.done_store.clone(), state=buf.index.state.clone(), apos=env.agent_pos.clone(),
+                         ep=env.episode_ctr.clone(), obs_cur=env.obs_cur.clone(), tick=env.rng_tick.clone(),
+                         ret1=st1.returns, ret2=st2.returns, n=st1.n_collected_episodes + st2.n_collected_episodes))
+    a, b = outs
+    for k in a:
+        if isinstance(a[k], torch.Tensor):
+            assert torch.equal(a[k], b[k]), k
+        elif isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
