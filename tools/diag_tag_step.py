@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Host-side wall-clock split of one step of the configs[4] shard (512 simple_tag worlds, grouped PPO, league trainer):
+collect / per-agent batch extraction / learn() of each team / the trainer's step.  Every phase is followed by a device
+synchronisation, so a phase's figure is its GPU time plus its host time (run it under rocprofv3 --kernel-trace --stats for
+the kernel split: that is how the 682 us single-lane GAE scan was found).
+
+    python tools/diag_tag_step.py
+"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

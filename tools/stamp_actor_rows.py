@@ -39,7 +39,7 @@ ops.ppo_actor_rows_update(net.actor.flat.data, obs, act, lp, adv, cfg, A, H, adv
 torch.cuda.synchronize()
 lib.tsm_debug_set_stamps(None)
 s = st.cpu().numpy()[:64].reshape(4, 16)
-names = ["P0 commit X", "P1 layer 1", "P2 layer 2", "P3 logits (2 waves)", "P4 loss head (32 lanes)", "P5 dW3 + dH2 mfma", "dH2 write",
+names = ["P0 commit X", "P1 layer 1", "P2 layer 2", "P3 logits (2 waves)", "P4 loss head (16 lanes per sample)", "P5 dW3 + dH2 mfma", "dH2 write",
          "P6 dW2 + dH1 mfma", "dH1 write", "P7 dW1"]
 for it in range(1, 4):
     d = [(s[it][k + 1] - s[it][k]) / 100.0 for k in range(10)]
