@@ -109,6 +109,10 @@ int tsm_mc_return_to_go_lanes(const float *rew, int64_t T, int64_t n_lane, doubl
 int tsm_any_nonzero_u8(const uint8_t *x, int64_t n, int32_t *flag_out, void *stream);
 int tsm_value_next_select(const float *v_s, const float *v_last, const float *v_full, const int32_t *flag, int64_t T,
                           int64_t U, float *v_next_out, void *stream);
+/* The same for ENV-major rows [E][T][U] (flat reference index order, sample_indices(0): what the MARL trainers' per-agent
+ * batches hold): v_next[e][t][u] = v_s[e][t + 1][u] (t < T - 1), v_last[e][u] (t = T - 1), or v_full when *flag != 0. */
+int tsm_value_next_select_env_major(const float *v_s, const float *v_last, const float *v_full, const int32_t *flag,
+                                    int64_t E, int64_t T, int64_t U, float *v_next_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * VectorReplayBuffer  [a8, a9]

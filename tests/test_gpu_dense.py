@@ -295,3 +295,45 @@ def test_c3_ctde_pipeline_full_size(n_env):
     out = SimultaneousTrainer(mgr).train_step(batch)
     assert set(out) == set(env.agents) and all(np.isfinite(list(v.values())).all() for v in out.values())
     assert not torch.equal(before[0], pol.actor.flat.data) and not torch.equal(before[1], pol.critic.flat.data)
+
+
+@pytest.mark.parametrize("max_cycles,T", [(6, 6), (4, 6)])
+def test_ctde_learn_takes_next_values_from_the_chained_forward(max_cycles, T):
+    """CTDEPolicy.learn evaluates the ONLINE critic on obs_next for its TD target (ctde.py:165-172); on per-agent batches of
+    chained rows (agent_batches_from_buffer after a Collector) those values are rows of its pass over obs, plus the last
+    step of every env block -- or the full pass when an episode ended early (device flag).  Losses, gradients' effect on
+    the weights and the optimizer state must equal the two-pass form bit for bit."""
+    from tianshou_marl_amd.algorithm.multiagent import (CentralizedCritic, CTDEPolicy, DecentralizedActor,
+                                                        FlexibleMultiAgentPolicyManager, SimultaneousTrainer,
+                                                        agent_batches_from_buffer)
+    from tianshou_marl_amd.algorithm.ppo import policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+
+    n_env, N = 40, 3
+    outs = []
+    for chained in (True, False):
+        env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=max_cycles, device=DEV, seed=9)
+        D = env.obs_dim
+        pol = CTDEPolicy(actor=DecentralizedActor(D, 5, 128, device=DEV, seed=1),
+                         critic=CentralizedCritic(N * D, N, 128, device=DEV, seed=2), seed=4)
+        mgr = FlexibleMultiAgentPolicyManager(pol, env, mode="shared")
+        buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=DEV)
+        col = Collector(mgr, env, buf)
+        col.reset()
+        trainer = SimultaneousTrainer(mgr)
+        losses = []
+        for _ in range(2):
+            with policy_within_training_step(mgr):
+                col.collect(n_step=n_env * T)
+                batch = agent_batches_from_buffer(buf, env.agents)
+                assert "chain_done" in batch and batch.chain_done.chain_T == T
+                if not chained:
+                    batch.pop("chain_done")
+                losses.append(trainer.train_step(batch))
+            col.reset_buffer(keep_statistics=True)
+        outs.append((pol.actor.flat.data.clone(), pol.critic.flat.data.clone(), pol.optim_critic.exp_avg_sq.clone(), losses))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3] == b[3]

@@ -142,8 +142,24 @@ class CTDEPolicy(nn.Module):
             critic_in, critic_in_next = self._t(batch.global_obs, torch.float32), self._t(batch.global_obs_next, torch.float32)
         else:
             critic_in, critic_in_next = obs, obs_next
-        q_next = self.critic(critic_in_next, save=False).reshape(B, -1)  # target side: no gradient (detach, :172)
         q = self.critic(critic_in, save=True).reshape(B, -1)
+        chain = batch.chain_done if "chain_done" in batch else None
+        T = getattr(chain, "chain_T", 0)
+        if isinstance(chain, torch.Tensor) and chain.is_cuda and T >= 1 and chain.numel() == B and B % T == 0:
+            # The TD target uses the ONLINE critic on obs_next (no target network in `learn`, ctde.py:165-172), and for
+            # chained rows obs_next of (env, t) is obs of (env, t + 1): its values are rows of `q`, except at the last
+            # step of each env's block -- a pass over those E rows -- and where an episode ended early: then (device flag)
+            # the full pass runs.  Bit-identical to evaluating the critic on obs_next; saves a third of the critic work.
+            E = B // T
+            n_out = q.shape[1]
+            flag = ops.any_nonzero_u8(chain.view(E, T)[:, :T - 1].contiguous().reshape(-1)) if T > 1 else \
+                torch.zeros(1, dtype=torch.int32, device=q.device)
+            q_full, _ = ops.mlp_forward_cond(self.critic.desc, self.critic.flat.data, critic_in_next, flag)
+            q_last = FlatMLP.forward(self.critic, critic_in_next.view(E, T, -1)[:, T - 1].contiguous(), save=False)
+            q_next = ops.value_next_select_env_major(q.contiguous(), q_last.reshape(E, n_out), q_full.reshape(B, n_out), flag,
+                                                     E, T, n_out)
+        else:
+            q_next = self.critic(critic_in_next, save=False).reshape(B, -1)  # target side: no gradient (detach, :172)
         logits = FlatMLP.forward(self.actor, obs, save=True)
         dq, dlogits, scalars = ops.ctde_td_head(q, q_next, rew, terminated, self.discount_factor, logits, act)
         self.optim_critic.zero_grad()

@@ -25,7 +25,7 @@ from ...data.batch import Batch
 
 
 def _attach_global(batch: Batch, agent_batch: Batch) -> Batch:
-    for k in ("global_obs", "global_obs_next"):
+    for k in ("global_obs", "global_obs_next", "chain_done"):
         if k in batch:
             agent_batch[k] = batch[k]
     return agent_batch
@@ -363,4 +363,12 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
     if global_state:
         out["global_obs"] = full(d["obs"])
         out["global_obs_next"] = full(d["obs_next"])
+        if T is not None and T > 0 and buffer.rows_chained is True:
+            # rows written by consecutive collects: obs_next of (env, t) is obs of (env, t + 1) unless the episode ended
+            # at t.  A learner whose target network IS its online network can then take the values of obs_next from its
+            # pass over obs (CTDEPolicy.learn) -- `chain_done` u8 [E * T] (env-major like every other leaf; its attribute
+            # `chain_T` = T) says where that does not hold.
+            cd = buffer.done_store[:T].transpose(0, 1).reshape(-1)
+            cd.chain_T = int(T)
+            out["chain_done"] = cd
     return out

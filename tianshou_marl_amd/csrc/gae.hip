@@ -477,7 +477,29 @@ __global__ void value_next_select_kernel(const float *__restrict__ v_s, const fl
     v_next[i] = t + 1 < T ? v_s[i + U] : v_last[i - t * U];
 }
 
+// the same selection for ENV-major rows [E][T][U] (the MARL trainers' per-agent batches, sample_indices(0) order)
+__global__ void value_next_select_em_kernel(const float *__restrict__ v_s, const float *__restrict__ v_last,
+                                            const float *__restrict__ v_full, const int32_t *__restrict__ flag, int64_t E,
+                                            int64_t T, int64_t U, float *__restrict__ v_next) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E * T * U) return;
+    if (*flag) { v_next[i] = v_full[i]; return; }
+    const int64_t u = i % U, r = i / U, t = r % T, e = r / T;
+    v_next[i] = t + 1 < T ? v_s[i + U] : v_last[e * U + u];
+}
+
 }  // namespace
+
+TSM_EXPORT int tsm_value_next_select_env_major(const float *v_s, const float *v_last, const float *v_full,
+                                               const int32_t *flag, int64_t E, int64_t T, int64_t U, float *v_next_out,
+                                               void *stream) {
+    TSM_REQUIRE(E >= 1 && T >= 1 && U >= 1, "tsm_value_next_select_env_major: E, T and U must be >= 1");
+    TSM_REQUIRE(v_s && v_last && v_full && flag && v_next_out, "tsm_value_next_select_env_major: null pointer");
+    hipLaunchKernelGGL(value_next_select_em_kernel, dim3((unsigned)ceil_div(E * T * U, 256)), dim3(256), 0, tsm_stream(stream),
+                       v_s, v_last, v_full, flag, E, T, U, v_next_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
 
 TSM_EXPORT int tsm_any_nonzero_u8(const uint8_t *x, int64_t n, int32_t *flag_out, void *stream) {
     TSM_REQUIRE(n >= 0, "tsm_any_nonzero_u8: negative n");

@@ -690,6 +690,17 @@ def value_next_select(v_s, v_last, v_full, flag, T: int, U: int, out=None):
     return res
 
 
+def value_next_select_env_major(v_s, v_last, v_full, flag, E: int, T: int, U: int, out=None):
+    """`value_next_select` for env-major rows [E, T, U] (the per-agent batches of the MARL trainers)."""
+    v_s, v_last, v_full = (_chk(t, torch.float32, n) for t, n in ((v_s, "v_s"), (v_last, "v_last"), (v_full, "v_full")))
+    if v_s.numel() != E * T * U or v_full.numel() != E * T * U or v_last.numel() != E * U:
+        raise ValueError("value_next_select_env_major: shapes do not match E x T x U")
+    res = out if out is not None else torch.empty(E * T, U, dtype=torch.float32, device=v_s.device)
+    call("tsm_value_next_select_env_major", ptr(v_s), ptr(v_last), ptr(v_full), ptr(_chk(flag, torch.int32, "flag")), E, T, U,
+         ptr(res), stream_ptr())
+    return res
+
+
 def mlp_n_split(B: int) -> int:
     """Default number of gradient slabs for a batch of B rows."""
     return max(1, min(64, -(-B // 256)))
