@@ -381,3 +381,40 @@ def test_learn_as_one_graph_replay_equals_eager_launches(shuffle, batch_size, re
     a, b = outs
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert a[3] == b[3] and a[4] == b[4] and a[5] == b[5]
+
+
+def test_self_play_checkpoint_restores_the_opponent_pool(tmp_path):
+    """SelfPlayTrainer.save_checkpoint / load_checkpoint (training_coordinator.py:225-263, 545-571) with the opponent pool
+    the reference leaves out: after a reload into fresh objects the pool holds the same frozen snapshots (parameters and
+    optimizer state), in order, with their win rates, and the learner continues bit-identically."""
+    from tianshou_marl_amd.algorithm.multiagent import SelfPlayTrainer
+
+    def build():
+        env = type("E", (), {"agents": ["a", "b"]})()
+        pols = {"a": PPO(net=DiscreteActorCritic(6, 5, 64, device=DEV, seed=1), seed=1, shuffle="device"),
+                "b": PPO(net=DiscreteActorCritic(6, 5, 64, device=DEV, seed=2), seed=2, shuffle="device")}
+        mgr = FlexibleMultiAgentPolicyManager(pols, env, mode="independent")
+        return mgr, SelfPlayTrainer(mgr, main_agent_id="a", snapshot_interval=1, opponent_pool_size=3)
+
+    g = torch.Generator().manual_seed(0)
+    mk = lambda n: Batch(obs=torch.randn(n, 6, generator=g).numpy(), act=torch.randint(0, 5, (n,), generator=g).numpy(),  # noqa: E731
+                         rew=torch.randn(n, generator=g).numpy(), obs_next=torch.randn(n, 6, generator=g).numpy(),
+                         terminated=np.zeros(n, bool))
+    batches = [Batch(a=mk(200), b=mk(200)) for _ in range(5)]
+    mgr, tr = build()
+    for b in batches[:4]:
+        tr.train_step(b)
+    assert len(tr.opponent_pool) == 3  # 4 snapshots taken, the oldest one dropped
+    tr.update_win_rate(id(tr.opponent_pool[1]), True)
+    path = str(tmp_path / "selfplay.pt")
+    tr.save_checkpoint(path)
+    mgr2, tr2 = build()
+    tr2.load_checkpoint(path)
+    assert tr2.step_count == tr.step_count and len(tr2.opponent_pool) == 3
+    for p, q in zip(tr.opponent_pool, tr2.opponent_pool):
+        assert torch.equal(p.net.flat.data, q.net.flat.data) and torch.equal(p.exp_avg_sq, q.exp_avg_sq) and not q.training
+    assert tr2.opponent_win_rates[id(tr2.opponent_pool[1])] == pytest.approx(0.55)
+    assert torch.equal(mgr.policies["a"].net.flat.data, mgr2.policies["a"].net.flat.data)
+    l1, l2 = tr.train_step(batches[4]), tr2.train_step(batches[4])
+    assert dict(l1["a"]) == dict(l2["a"])
+    assert torch.equal(mgr.policies["a"].net.flat.data, mgr2.policies["a"].net.flat.data)

@@ -200,7 +200,14 @@ def test_self_play_snapshots_sampling_and_state():
     assert st["opponent_pool_size"] == 2 and st["main_agent_id"] == "agent_0" and st["step_count"] == 6
     tr2 = SelfPlayTrainer(m, main_agent_id="x")
     tr2.load_state_dict(st)
-    assert tr2.main_agent_id == "agent_0" and tr2.step_count == 6 and tr2.opponent_win_rates == tr.opponent_win_rates
+    assert tr2.main_agent_id == "agent_0" and tr2.step_count == 6
+    # the opponent pool travels with the state (the reference leaves it out): same snapshots, in order, as frozen copies,
+    # with their win rates (the live dict is keyed by object identity: compared in pool order)
+    assert len(tr2.opponent_pool) == 2 and all(not p.training for p in tr2.opponent_pool)
+    for p, q in zip(tr.opponent_pool, tr2.opponent_pool):
+        assert q is not p and torch.equal(p.w, q.w)
+    rates = lambda t: [t.opponent_win_rates.get(id(p), 0.5) for p in t.opponent_pool]  # noqa: E731
+    assert rates(tr2) == pytest.approx(rates(tr)) and rates(tr)[0] == pytest.approx(0.495)
 
 
 def test_league_matchmaking_elo_and_promotion():

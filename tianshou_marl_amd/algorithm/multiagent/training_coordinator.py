@@ -253,15 +253,34 @@ class SelfPlayTrainer(MATrainer):
         self.opponent_win_rates[opponent_id] = alpha * (1.0 if won else 0.0) + (1 - alpha) * prev
 
     def state_dict(self) -> dict[str, Any]:
+        """The reference's keys (training_coordinator.py:545-571) plus the opponent pool itself, which the reference leaves
+        out (":571 pool persistence" in SURVEY 8f-3): every snapshot's own state_dict, oldest first, and the win rates in
+        pool order (the live dict is keyed by object identity, which does not survive a reload)."""
         state = super().state_dict()
         state.update(opponent_pool_size=len(self.opponent_pool), main_agent_id=self.main_agent_id,
-                     opponent_win_rates=self.opponent_win_rates)
+                     opponent_win_rates=self.opponent_win_rates,
+                     opponent_pool=[p.state_dict() for p in self.opponent_pool if hasattr(p, "state_dict")],
+                     opponent_win_rates_by_index=[self.opponent_win_rates.get(id(p), 0.5) for p in self.opponent_pool])
         return state
 
     def load_state_dict(self, state: dict[str, Any]) -> None:
         super().load_state_dict(state)
         self.main_agent_id = state.get("main_agent_id", self.main_agent_id)
         self.opponent_win_rates = state.get("opponent_win_rates", {})
+        saved = state.get("opponent_pool")
+        if saved and len(saved) == state.get("opponent_pool_size"):
+            # rebuild the snapshots as frozen copies of the learner, then load each one's state
+            learner = self.policy_manager.policies[self.main_agent_id]
+            self.opponent_pool, self.opponent_win_rates = [], {}
+            rates = state.get("opponent_win_rates_by_index", [])
+            for i, sd in enumerate(saved):
+                snap = copy.deepcopy(learner)
+                snap.load_state_dict(sd)
+                if hasattr(snap, "eval"):
+                    snap.eval()
+                self.opponent_pool.append(snap)
+                if i < len(rates):
+                    self.opponent_win_rates[id(snap)] = float(rates[i])
 
 
 class LeaguePlayTrainer(MATrainer):
