@@ -240,9 +240,12 @@ def _probe_child() -> int:
 
 
 if __name__ == "__main__":
+    import os
     import sys
 
     if "--probe-capture" in sys.argv:
+        if os.environ.get("TSM_PROBE_FAIL") == "1":  # rehearsal of the fall-back: pretend this box cannot capture
+            sys.exit(1)
         try:
             code = _probe_child()
         except BaseException:  # noqa: BLE001  (any failure means "do not capture")
