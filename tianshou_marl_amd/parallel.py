@@ -195,10 +195,15 @@ def probe_collective_capture(rank: int, world: int, local_rank: int, timeout_s: 
     env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank))
     try:
         r = subprocess.run([sys.executable, "-m", "tianshou_marl_amd.parallel", "--probe-capture"], env=env,
-                           timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     except subprocess.TimeoutExpired:
+        print(f"[rank {rank}] collective-capture probe timed out after {timeout_s:.0f} s", file=sys.stderr)
         return False
+    if r.returncode != 0:  # say why, for whoever reads the job's log
+        tail = (r.stderr or b"").decode(errors="replace").strip().splitlines()[-6:]
+        print(f"[rank {rank}] collective-capture probe failed (exit {r.returncode})" + ("".join("\n    " + t for t in tail)),
+              file=sys.stderr)
     return r.returncode == 0
 
 
@@ -248,6 +253,7 @@ if __name__ == "__main__":
             sys.exit(1)
         try:
             code = _probe_child()
-        except BaseException:  # noqa: BLE001  (any failure means "do not capture")
+        except BaseException as e:  # noqa: BLE001  (any failure means "do not capture")
+            print(f"probe: {type(e).__name__}: {e}", file=sys.stderr)
             code = 1
         sys.exit(code)
