@@ -801,7 +801,7 @@ def _main():
                        % (a.n_agent, a.n_env, 6 * a.n_agent, a.horizon),
                        "minibatch": a.minibatch, "repeat": a.repeat, "dispatch": a.dispatch, "parallelism": "env-shard x%d" % world,
                        **({} if dist is None else {"collectives": "captured in the update hipGraph" if getattr(algo, "graph_collectives", False)
-                                                   else "eager launches"})},
+                                                   else "eager, between segmented hipGraphs"})},
             "collect_ms": t_col_ms, "ppo_update_ms": t_upd_ms,
             "collect_env_steps_per_s": a.n_env * a.n_agent * a.horizon / (t_col_ms * 1e-3),
             "gradient_steps_per_update": grad_steps,

@@ -86,19 +86,32 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
             assert torch.equal(p_ref, net.flat.data)  # bit for bit: the single-GPU update on the union minibatch's statistics
             #                                           and the averaged gradient
         # ---- (2) PPO.update on two env shards: replicas stay bit-identical over synced updates ----
-        env = DeviceSimpleSpreadVectorEnv(32, 3, device=DEV, seed=50 + rank)  # this rank's shard
-        buf = DeviceVectorReplayBuffer(32 * 25, 32, 3, D, device=DEV)
-        algo2 = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=20 + rank), lr=1e-3, dispatch="per_agent",
-                    shuffle="device", seed=7 + rank)
-        attach_data_parallel(algo2, dist)
-        col = Collector(algo2, env, buf)
-        col.reset()
-        for _ in range(3):
-            with policy_within_training_step(algo2):
-                col.collect(n_step=32 * 25)
-                ts = algo2.update(buf, 256, 2)
-            col.reset_buffer(keep_statistics=True)
-        assert all(np.isfinite(v) for v in ts.get_loss_stats_dict().values())
+        # gloo collectives cannot be captured: the update runs as SEGMENTED hipGraphs (a graph per stretch between two
+        # collectives, the collectives eager in between) -- the same launches as the plain eager path, hence the same bits
+        def shard_job(segmented: bool):
+            os.environ["TSM_SEGMENTED"] = "1" if segmented else "0"
+            np.random.seed(11 + rank)  # shuffle="numpy": both forms replay the same np.random.permutation draws
+            env = DeviceSimpleSpreadVectorEnv(32, 3, device=DEV, seed=50 + rank)  # this rank's shard
+            buf = DeviceVectorReplayBuffer(32 * 25, 32, 3, D, device=DEV)
+            algo_ = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=20 + rank), lr=1e-3, dispatch="per_agent",
+                        shuffle="numpy", seed=7 + rank)
+            attach_data_parallel(algo_, dist)
+            col = Collector(algo_, env, buf)
+            col.reset()
+            for _ in range(3):
+                with policy_within_training_step(algo_):
+                    col.collect(n_step=32 * 25)
+                    ts_ = algo_.update(buf, 256, 2)
+                col.reset_buffer(keep_statistics=True)
+            assert all(np.isfinite(v) for v in ts_.get_loss_stats_dict().values())
+            return algo_, ts_.get_loss_stats_dict()
+
+        algo2, st_seg = shard_job(True)
+        assert any(k[0] == "graph" and "segments" in v for k, v in algo2._ws.items() if isinstance(k, tuple) and isinstance(v, dict))
+        algo2e, st_eager = shard_job(False)
+        assert torch.equal(algo2.net.flat.data, algo2e.net.flat.data) and torch.equal(algo2.exp_avg_sq, algo2e.exp_avg_sq)
+        assert st_seg == st_eager
+        os.environ.pop("TSM_SEGMENTED", None)
         # ---- (3) two policy groups trained in one step: their gradients travel in ONE packed all-reduce per step ----
         teams = {"adversaries": PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=30 + rank), use_graph=False, seed=1),
                  "good": PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=40 + rank), use_graph=False, seed=2)}

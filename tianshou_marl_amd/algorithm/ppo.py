@@ -271,6 +271,15 @@ class PPO(nn.Module):
             gs.merge_adv_stats_(stats.view(-1, 2), mb_start)
         return stats
 
+    def _global_adv_stats_steps(self, stats, mb_start):
+        """`_global_adv_stats` for the captured update: pack, YIELD the f64 pack (the caller sums it over the ranks), unpack."""
+        gs = self._grad_sync
+        if gs is not None and stats is not None and gs.wants_global_adv_stats():
+            pack_fn, unpack_fn = gs._stat_codec or gs._default_codec()
+            pack = pack_fn(stats, mb_start)
+            yield pack
+            unpack_fn(pack, stats)
+
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
                            buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:
         """ppo.py:164-224 for one sample set (all lanes, or one agent's lanes under per-agent dispatch)."""
@@ -378,7 +387,8 @@ class PPO(nn.Module):
         n_g = T * B if per_agent else T * L
         bounds = split_bounds(n_g, batch_size or -1, merge_last=True)
         stored = buffer.vnext_store is not None and buffer.policy_outputs_version == self.param_version
-        key = ("graph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored)
+        key = ("graph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored,
+               self._grad_sync is not None, self.graph_collectives)
         g = self._ws.get(key)
         P, A, H = self.net.flat.data, self.net.n_act, self.net.hidden
         if g is None:
@@ -436,6 +446,9 @@ class PPO(nn.Module):
                 self._gae(w["v_s"], w["v_next"], rew, term, trunc, N, out=(w["ret"], w["adv"]))
 
             def body():
+                # a generator: everything is launched in order; it yields the tensors that must be summed over the ranks at
+                # that point (data parallel only), so that one definition serves the single captured graph (collectives
+                # inside), and the segmented form (a graph per stretch between two collectives, collectives eager)
                 if self.shuffle == "device":
                     # every permutation of this update (one per agent group and repeat, batch.py:1219) in ONE launch;
                     # the draw counter is the device-resident optimizer step count (it advances by >= one per permutation
@@ -447,7 +460,7 @@ class PPO(nn.Module):
                 if "mb_start_all" in w:
                     ops.ppo_adv_stats(w["adv"], w["mb_start_all"], perm=w["perm"].view(-1), out=w["stats"].view(-1, 2),
                                       max_rows=max(e - s for s, e in bounds))
-                    self._global_adv_stats(w["stats"].view(-1, 2), w["mb_start_all"])
+                    yield from self._global_adv_stats_steps(w["stats"].view(-1, 2), w["mb_start_all"])
                 k = 0
                 for gi in range(len(groups)):
                     for r in range(repeat):
@@ -457,7 +470,7 @@ class PPO(nn.Module):
                         if self.advantage_normalization and "mb_start_all" not in w:
                             ops.ppo_adv_stats(w["adv"], w["mb_start"], perm=perm, out=w["stats"][gi, r],
                                               max_rows=max(e - s for s, e in bounds))
-                            self._global_adv_stats(w["stats"][gi, r], w["mb_start"])
+                            yield from self._global_adv_stats_steps(w["stats"][gi, r], w["mb_start"])
                         for j, (s, e) in enumerate(bounds):
                             nb = ops.ppo_update_grid(e - s)
                             ops.ppo_update_fused(P, obs, act, w["logp"], w["adv"].view(-1), w["ret"].view(-1), self._cfg,
@@ -469,7 +482,7 @@ class PPO(nn.Module):
                             grads = w["slabs"][:nb]
                             if self._grad_sync is not None:  # env-sharded replicas: one captured RCCL all-reduce
                                 ops.reduce_slabs(grads, out=w["flat_g"], scale=1.0 / self._grad_sync.world)
-                                self._grad_sync.all_reduce_sum_(w["flat_g"])
+                                yield w["flat_g"]  # summed over the ranks, in place
                                 grads = w["flat_g"].view(1, -1)
                             ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, 1, lr=self.lr, lr_dev=self._lr_dev,
                                           betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
@@ -479,21 +492,43 @@ class PPO(nn.Module):
                 # (the 4 loss statistics of every gradient step are folded from w["partial"] by ONE launch after the
                 # replay, straight into the pinned slot the host will read)
 
+            def run_inline():  # collectives inside the capture (RCCL) / no collectives at all
+                for t_ in body():
+                    self._grad_sync.all_reduce_sum_(t_)
+
             graph = torch.cuda.CUDAGraph()
-            if self._grad_sync is not None:
+            if self._grad_sync is not None and not self.graph_collectives:
+                # SEGMENTED form: the backend's collectives cannot be captured (gloo), or the capture probe failed.  Every
+                # stretch between two collectives is its own hipGraph (one shared memory pool, replayed in capture order);
+                # the collectives run eagerly in between: ~20 graph launches + ~19 collectives per update instead of ~80
+                # eager kernel launches (one rank over RCCL: 2.5 -> ~1 ms per step).
+                pool = torch.cuda.graph_pool_handle()
+                segs, gen, more = [], body(), True
+                while more:
+                    g_ = torch.cuda.CUDAGraph()
+                    t_ = None
+                    with torch.cuda.graph(g_, pool=pool):
+                        try:
+                            t_ = next(gen)
+                        except StopIteration:
+                            more = False
+                    segs.append((g_, t_))
+                w["segments"] = segs
+                graph = None
+            elif self._grad_sync is not None:
                 # Every rank captures the same collective sequence.  Whether a backend CAN be captured is decided before
-                # this point (parallel.attach_data_parallel: only RCCL; anything else runs the eager path from the
-                # start).  A capture that fails all the same is fatal: the process group's own stream has joined the
-                # capture, HIP leaves it invalidated, and every later collective on it dies
-                # (hipErrorStreamCaptureInvalidated) -- so there is no in-process fall-back; the job is re-started with
-                # eager collectives instead.  thread_local: the watchdog thread may touch the device meanwhile.
+                # this point (parallel.attach_data_parallel: only RCCL; bench.py probes it in a child process).  A capture
+                # that fails all the same is fatal: the process group's own stream has joined the capture, HIP leaves it
+                # invalidated, and every later collective on it dies (hipErrorStreamCaptureInvalidated) -- so there is no
+                # in-process fall-back; the job is re-started with TSM_GRAPH_COLLECTIVES=0 (segmented form) instead.
+                # thread_local: the watchdog thread may touch the device meanwhile.
                 err = None
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     graph.capture_begin(capture_error_mode="thread_local")
                     try:
-                        body()
+                        run_inline()
                     except Exception as e:  # noqa: BLE001
                         err = e
                     try:
@@ -506,12 +541,13 @@ class PPO(nn.Module):
                     raise RuntimeError(
                         "capturing the gradient all-reduce into the update hipGraph failed "
                         f"({type(err).__name__}: {err}).  Streams behind an invalidated capture are not usable, so this "
-                        "process cannot continue: start the job again with TSM_GRAPH_COLLECTIVES=0 (eager collectives)."
+                        "process cannot continue: start the job again with TSM_GRAPH_COLLECTIVES=0 (collectives outside "
+                        "the graphs)."
                     ) from err
                 torch.cuda.current_stream().wait_stream(side)
             else:
                 with torch.cuda.graph(graph):
-                    body()
+                    run_inline()
             w["graph"] = graph
             if self.shuffle == "numpy":
                 base = ref_order_rows(T, B, dev)
@@ -528,7 +564,13 @@ class PPO(nn.Module):
         # shuffle == "device": the permutations are drawn inside the graph (tsm_random_permutations)
         if g.get("step_host") != self.opt_step:  # the device-side step count is stale (eager updates, a loaded checkpoint)
             g["step_dev"].fill_(self.opt_step)
-        g["graph"].replay()
+        if g.get("segments") is not None:
+            for g_, t_ in g["segments"]:
+                g_.replay()
+                if t_ is not None:
+                    self._grad_sync.all_reduce_sum_(t_)
+        else:
+            g["graph"].replay()
         self.opt_step += g["n_steps"]
         g["step_host"] = self.opt_step
         self.param_version += 1
@@ -591,7 +633,8 @@ class PPO(nn.Module):
         # `flat` is the source of truth and may have been written from outside (load_state_dict, broadcast, tests); the
         # padded image is a cache that the Adam kernel refreshes.  The graph path reads `flat` itself until its first
         # Adam step has rewritten the image, so it needs no refresh launch; the eager path refreshes it here.
-        if self.use_graph and (self._grad_sync is None or self.graph_collectives):
+        # data parallel without capturable collectives: segmented graphs (TSM_SEGMENTED=0: plain eager launches)
+        if self.use_graph and (self._grad_sync is None or self.graph_collectives or os.environ.get("TSM_SEGMENTED", "1") != "0"):
             out = self._update_graph(buffer, batch_size, repeat)
             if out is not None:
                 return out

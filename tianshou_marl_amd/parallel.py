@@ -83,16 +83,19 @@ class GradSync:
         section 8e: "the advantage statistics make the sharded minibatch normalisation identical to a single global
         minibatch").  Three launches: pack to f64 (n, sum x, sum x^2) (`tsm_ppo_adv_stats_pack`), ONE all-reduce for every
         minibatch of the update, unpack; every rank ends with bit-identical statistics."""
-        import os
-
-        # (a one-rank group skips it, except in the single-GPU rehearsal of the captured multi-GPU path, TSM_FORCE_DIST)
-        if not self.global_adv_stats or (self.world == 1 and not os.environ.get("TSM_FORCE_DIST")):
+        if not self.wants_global_adv_stats():
             return stats
         pack_fn, unpack_fn = self._stat_codec or self._default_codec()
         pack = pack_fn(stats, mb_start)
         self.dist.all_reduce(pack, op=self.dist.ReduceOp.SUM, group=self.group)
         unpack_fn(pack, stats)
         return stats
+
+    def wants_global_adv_stats(self) -> bool:
+        """(a one-rank group skips the merge, except in the single-GPU rehearsal of the multi-GPU path, TSM_FORCE_DIST)"""
+        import os
+
+        return bool(self.global_adv_stats and (self.world > 1 or os.environ.get("TSM_FORCE_DIST")))
 
     @staticmethod
     def _default_codec():
