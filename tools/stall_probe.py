@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """One bounded look at the sporadic multi-ms stall of back-to-back 4096-env collects (DESIGN.md "open observation").
 
-    python tools/stall_probe.py [n_collects] [n_env]
+    python tools/stall_probe.py [n_collects] [n_env] [host|device]
+
+`device`: the episode record is written to HBM and copied to the pinned slot afterwards (Collector.stage_episode_record)
+instead of being written to mapped pinned host memory from inside the kernel.
 
 Every collect is bracketed by HIP events; the rollout kernel's per-workgroup start / end stamps (tsm_debug_set_stamps:
 slots 64 + 2b, 65 + 2b for workgroups b < 256, 100 MHz wall clock) are read after each one.  For the slowest launches the
@@ -34,6 +37,8 @@ def main():
     algo = PPO(net=net)
     buf = DeviceVectorReplayBuffer(E * 25, E, 3, 18, device=dev)
     col = Collector(algo, env, buf)
+    record = sys.argv[3] if len(sys.argv) > 3 else "host"
+    col.stage_episode_record = record == "device"
     col.reset()
     st = torch.zeros(1024, dtype=torch.int64, device=dev)
     lib = _abi.load()
@@ -60,7 +65,7 @@ def main():
             times.append(dt)
     lib.tsm_debug_set_stamps(None)
     t = np.array(times[5:])
-    print(json.dumps(dict(n=n, n_env=E, p50_us=round(float(np.median(t)), 1), p99_us=round(float(np.percentile(t, 99)), 1),
+    print(json.dumps(dict(n=n, n_env=E, record=record, p50_us=round(float(np.median(t)), 1), p99_us=round(float(np.percentile(t, 99)), 1),
                           max_us=round(float(t.max()), 1), n_over_2x_median=int((t > 2 * np.median(t)).sum()))))
     for r in sorted(rows[5:], key=lambda r: -r["event_us"])[:6]:
         print(json.dumps(r))
