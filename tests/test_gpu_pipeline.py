@@ -53,6 +53,37 @@ def test_mpe_step_matches_numpy_oracle(n_env, N):
         assert torch.equal(env.obs_cur, env.obs_next)
 
 
+@pytest.mark.parametrize("n_env,N", [(64, 3), (40, 8), (16, 1)])
+def test_mpe_single_steps_match_oracle_tightly(n_env, N):
+    """One step at a time from the SAME state (the oracle world is re-synchronised to the device state before every step, so
+    f32 rounding cannot accumulate through the contact dynamics): observations and rewards of the HIP kernel against the
+    numpy f64 restatement of the MPE spec at 2e-5 (f32 arithmetic on O(1) quantities) -- worlds squeezed so that contacts
+    happen in most steps."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import mpe_oracle
+
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=50, device=DEV, seed=5, auto_reset=False)
+    env.reset_device()
+    env.agent_pos.mul_(0.3)  # crowd the agents: soft contacts in most worlds
+    worlds = [mpe_oracle.SimpleSpreadWorld(N, 50, 0.5) for _ in range(n_env)]
+    rng = np.random.default_rng(1)
+    contacts = 0
+    for step in range(10):
+        apos, avel, lpos = (x.cpu().numpy().astype(np.float64) for x in (env.agent_pos, env.agent_vel, env.landmark_pos))
+        act = rng.integers(0, 5, (n_env, N)).astype(np.int32)
+        obs_next, rew, *_ = env.step_device(torch.from_numpy(act).to(DEV))
+        obs_next, rew = obs_next.cpu().numpy(), rew.cpu().numpy()
+        for e, w in enumerate(worlds):
+            w.set_state(apos[e], avel[e], lpos[e])
+            if N > 1:
+                d = np.linalg.norm(apos[e][:, None] - apos[e][None], axis=-1) + np.eye(N)
+                contacts += int((d < 0.3).any())
+            o, r, _, _ = w.step(act[e])
+            np.testing.assert_allclose(obs_next[e], o, rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(rew[e], r, rtol=2e-5, atol=2e-5)
+    assert N == 1 or contacts > n_env  # the contact force path was exercised
+
+
 def test_mpe_auto_reset_and_determinism():
     mk = lambda seed: DeviceSimpleSpreadVectorEnv(33, 3, max_cycles=4, device=DEV, seed=seed)  # noqa: E731
     a, b, c = mk(1), mk(1), mk(2)
