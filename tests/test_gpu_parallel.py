@@ -167,3 +167,76 @@ def test_two_rank_data_parallel_update_on_one_gpu(tmp_path):
         raise
     p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
     assert np.array_equal(p0, p1) and np.isfinite(p0).all()  # every replica of every policy: the same bits on both ranks
+
+
+def _rccl_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    """One rank over RCCL ("nccl"): the collectives of the data-parallel update are captured INTO the update hipGraph."""
+    import torch.distributed as dist
+
+    from tianshou_marl_amd.algorithm import GenericPPO
+    from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.parallel import attach_data_parallel
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic, MLPActorCritic
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSM_FORCE_DIST="1")  # (merge the statistics too)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=rank, world_size=world)
+    try:
+        finals = {}
+        for kind in ("ppo64", "generic128"):
+            for use_graph in (True, False):
+                np.random.seed(3)
+                n_env, N, T = 64, 8 if kind == "generic128" else 3, 5
+                env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=4)
+                Dd = env.obs_dim
+                if kind == "ppo64":
+                    algo = PPO(net=DiscreteActorCritic(Dd, 5, 64, device=DEV, seed=1), seed=2, shuffle="numpy", use_graph=use_graph)
+                else:
+                    algo = GenericPPO(net=MLPActorCritic(Dd, 5, (128, 128), critic_obs_dim=N * Dd, device=DEV, seed=1),
+                                      critic_input="global", n_agent=N, seed=2, shuffle="numpy", dispatch="pooled", graph=use_graph)
+                attach_data_parallel(algo, dist)
+                assert algo.graph_collectives is True
+                buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, Dd, device=DEV)
+                col = Collector(algo, env, buf)
+                col.reset()
+                for _ in range(4):
+                    with policy_within_training_step(algo):
+                        col.collect(n_step=n_env * T)
+                        algo.update(buf, 64 * N, 1)
+                    col.reset_buffer(keep_statistics=True)
+                captured = any(isinstance(k, tuple) and k[0] in ("graph", "ggraph") and isinstance(v, dict) and v.get("graph") is not None
+                               for k, v in algo._ws.items())
+                assert captured == use_graph, (kind, use_graph)
+                finals[(kind, use_graph)] = (algo.net.flat.data.clone(), algo.exp_avg_sq.clone())
+            a, b = finals[(kind, True)], finals[(kind, False)]
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), kind  # captured collectives == eager collectives
+        with open(os.path.join(out_dir, "ok"), "w") as f:
+            f.write("ok")
+    except BaseException:
+        import traceback
+
+        with open(os.path.join(out_dir, "err0.txt"), "w") as f:
+            traceback.print_exc(file=f)
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_collectives_are_captured_into_the_update_graphs(tmp_path):
+    """PPO (fused 64-wide) and GenericPPO (rows kernels, centralized critic) as data-parallel replicas over RCCL with ONE
+    rank: the gradient all-reduces and the advantage-statistics merge are part of the captured update, and the result
+    equals the eager launches with eager collectives bit for bit."""
+    import torch.multiprocessing as mp
+
+    try:
+        mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    except Exception:
+        f = tmp_path / "err0.txt"
+        if f.exists():
+            print(f.read_text())
+        raise
+    assert (tmp_path / "ok").exists()

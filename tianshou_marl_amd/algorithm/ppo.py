@@ -271,6 +271,43 @@ class PPO(nn.Module):
             gs.merge_adv_stats_(stats.view(-1, 2), mb_start)
         return stats
 
+    def _capture_graph(self, graph: "torch.cuda.CUDAGraph", fn) -> None:
+        """Capture `fn()` into `graph`.  With data-parallel collectives inside (RCCL): every rank captures the same
+        collective sequence, on a side stream in thread-local capture mode (the process group's watchdog thread may touch
+        the device meanwhile).  Whether a backend CAN be captured is decided before this point
+        (parallel.attach_data_parallel: only RCCL; bench.py probes it in a child process).  A capture that fails all the
+        same is fatal: the process group's own stream has joined the capture, HIP leaves it invalidated, and every later
+        collective on it dies (hipErrorStreamCaptureInvalidated) -- there is no in-process fall-back; the job is started
+        again with TSM_GRAPH_COLLECTIVES=0 (collectives outside the graphs)."""
+        if self._grad_sync is None:
+            with torch.cuda.graph(graph):
+                fn()
+            return
+        dev = self.device
+        err = None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph.capture_begin(capture_error_mode="thread_local")
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                err = e
+            try:
+                graph.capture_end()
+            except Exception as e:  # noqa: BLE001
+                err = err or e
+            if err is not None:
+                ops.call("tsm_stream_abort_capture", side.cuda_stream)
+        if err is not None:
+            raise RuntimeError(
+                "capturing the gradient all-reduce into the update hipGraph failed "
+                f"({type(err).__name__}: {err}).  Streams behind an invalidated capture are not usable, so this "
+                "process cannot continue: start the job again with TSM_GRAPH_COLLECTIVES=0 (collectives outside "
+                "the graphs)."
+            ) from err
+        torch.cuda.current_stream().wait_stream(side)
+
     def _global_adv_stats_steps(self, stats, mb_start):
         """`_global_adv_stats` for the captured update: pack, YIELD the f64 pack (the caller sums it over the ranks), unpack."""
         gs = self._grad_sync
@@ -515,39 +552,8 @@ class PPO(nn.Module):
                     segs.append((g_, t_))
                 w["segments"] = segs
                 graph = None
-            elif self._grad_sync is not None:
-                # Every rank captures the same collective sequence.  Whether a backend CAN be captured is decided before
-                # this point (parallel.attach_data_parallel: only RCCL; bench.py probes it in a child process).  A capture
-                # that fails all the same is fatal: the process group's own stream has joined the capture, HIP leaves it
-                # invalidated, and every later collective on it dies (hipErrorStreamCaptureInvalidated) -- so there is no
-                # in-process fall-back; the job is re-started with TSM_GRAPH_COLLECTIVES=0 (segmented form) instead.
-                # thread_local: the watchdog thread may touch the device meanwhile.
-                err = None
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    graph.capture_begin(capture_error_mode="thread_local")
-                    try:
-                        run_inline()
-                    except Exception as e:  # noqa: BLE001
-                        err = e
-                    try:
-                        graph.capture_end()
-                    except Exception as e:  # noqa: BLE001
-                        err = err or e
-                    if err is not None:
-                        ops.call("tsm_stream_abort_capture", side.cuda_stream)
-                if err is not None:
-                    raise RuntimeError(
-                        "capturing the gradient all-reduce into the update hipGraph failed "
-                        f"({type(err).__name__}: {err}).  Streams behind an invalidated capture are not usable, so this "
-                        "process cannot continue: start the job again with TSM_GRAPH_COLLECTIVES=0 (collectives outside "
-                        "the graphs)."
-                    ) from err
-                torch.cuda.current_stream().wait_stream(side)
             else:
-                with torch.cuda.graph(graph):
-                    run_inline()
+                self._capture_graph(graph, run_inline)
             w["graph"] = graph
             if self.shuffle == "numpy":
                 base = ref_order_rows(T, B, dev)

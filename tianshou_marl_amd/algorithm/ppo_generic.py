@@ -305,7 +305,8 @@ class GenericPPO(PPO):
         row_mode = unit > 1
         stored = (self.reuse_rollout_outputs, buffer.behaviour_outputs_version == self.param_version,
                   buffer.logp_outputs_version == self.param_version)
-        key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored)
+        key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored,
+               self._grad_sync is not None)
         w = self._ws.get(key)
         if w is None:  # first update of this shape runs eagerly (one-time kernel attributes, allocator warm-up)
             self._ws[key] = {}
@@ -347,8 +348,7 @@ class GenericPPO(PPO):
                             k += 1
 
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                body()
+            self._capture_graph(graph, body)  # (data parallel over RCCL: the all-reduces of every step are captured too)
             w["graph"] = graph
             if self.shuffle == "numpy":
                 base = ref_order_rows(T, B, dev)
@@ -376,7 +376,8 @@ class GenericPPO(PPO):
         return mk(s_h)
 
     def _update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int, t0: float):
-        if self.graph and self._grad_sync is None and not self.recompute_adv:
+        # (data parallel: only with capturable collectives -- RCCL; otherwise eager launches with inline collectives)
+        if self.graph and (self._grad_sync is None or self.graph_collectives) and not self.recompute_adv:
             out = self._update_graph_generic(buffer, batch_size, repeat)
             if out is not None:
                 return out
