@@ -450,7 +450,10 @@ struct CriticArgs {
     int value_clip;
     float *slabs;            // [grid][P]
     double *partial;         // [grid][4] = {0, sum vf, 0, 0}
+    long long *stamps;       // diagnostics only (tsm_debug_set_stamps): phase time stamps of workgroup 0
 };
+
+#define CSTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[200 + (k)] = (long long)wall_clock64(); } while (0)
 
 template <int NS>
 __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g) {
@@ -463,6 +466,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
     stage_w2(lds + ly.W2, g.P + oW2, (oW2 & 3) == 0);
     if (tid < kH) { lds[ly.W3 + tid] = g.P[oW3 + tid]; lds[ly.B1 + tid] = g.P[oB1 + tid]; lds[ly.B2 + tid] = g.P[oB2 + tid]; }
     const float b3 = g.P[oB3];
+    CSTAMP(0);
 
     // dW2 lives in registers for the whole launch; dW1 (2 NS tiles per wave: 96 registers at K1 = 384) only during a
     // block's layer-1 weight-gradient phase -- it is folded into the workgroup's slab (plain store for the first block,
@@ -542,6 +546,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
                 if (g.value_clip) pf_vs = g.v_s_old[sidx_];
             }
         }
+        CSTAMP(1);
         // ---- L1: H1 = relu(X W1^T + b1), K-slices through the double buffer ----
         {
             f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
@@ -574,6 +579,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
                 }
         }
         __syncthreads();
+        CSTAMP(2);
         // ---- L2 ----
         {
             f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
@@ -595,6 +601,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
                 }
         }
         __syncthreads();
+        CSTAMP(3);
         // ---- L3: value of every row (one lane per row, k-ordered fma chain) ----
         if (tid < kRows) {
             const float *h = lds + ly.H2 + tid * kLdh;
@@ -603,6 +610,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
             lds[ly.V + tid] = sacc + b3;
         }
         __syncthreads();
+        CSTAMP(4);
         // ---- value term for the N agents of every row (ppo.py:198-208) ----
         if (tid < kRows * N) {
             const int r = tid / N, a = tid - r * N;
@@ -638,6 +646,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
             lds[ly.V + tid] = sacc;
         }
         __syncthreads();
+        CSTAMP(5);
         // ---- backward: dW3, db3 (VALU), dH2 = dv (x) w3 * relu'(H2) in place ----
         if (tid >= 256 && tid < 256 + kH) {
             const int j = tid - 256;
@@ -656,6 +665,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
             *p = *p > 0.f ? lds[ly.V + r] * lds[ly.W3 + j] : 0.f;
         }
         __syncthreads();
+        CSTAMP(6);
         // ---- dW2 += dH2^T H1 ; db2 ; dH1 = (dH2 W2) * relu'(H1) ----
         {
             const float *pa = lds + ly.H2 + kq * kLdh + col;
@@ -697,6 +707,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
             for (int r = 0; r < kRows; ++r) sacc += lds[ly.H1 + r * kLdh + tid];
             gB += sacc;
         }
+        CSTAMP(7);
         // ---- dW1[:, slice s] += dH1^T X[:, slice s]: the observation slices once more (L2-hot) ----
         // slices in groups of GS: a group's 2 GS accumulator tiles live in registers, then go to the slab
         constexpr int GS = NS > 4 ? 4 : NS;
@@ -743,6 +754,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
         }
     }
 
+    CSTAMP(8);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 16 * w + kq * 4 + r;
@@ -755,6 +767,7 @@ __global__ __launch_bounds__(kThreads) void ppo_critic_rows_kernel(CriticArgs g)
     else if (tid == 384) __builtin_nontemporal_store(gB, slab + oB3);
     __shared__ double sm[kThreads / 64];
     const double tot = block_sum<double, kThreads>(t_vf, sm);
+    CSTAMP(9);
     if (tid == 0) {
         g.partial[4 * blockIdx.x + 0] = 0.0;
         g.partial[4 * blockIdx.x + 1] = tot;
@@ -880,6 +893,7 @@ TSM_EXPORT int tsm_ppo_critic_rows_update(const float *critic_params, int32_t in
     g.first_row = first_row; g.Mr = Mr; g.K1 = in_dim; g.N = n_agent;
     g.eps_clip = (float)cfg->eps_clip; g.vf_coef = (float)cfg->vf_coef; g.value_clip = cfg->value_clip;
     g.slabs = grad_slabs_out; g.partial = loss_partial_out;
+    g.stamps = g_tsm_stamps;
     const CritLay ly;
     const size_t shmem = (size_t)ly.total * sizeof(float);
     const int ns = (in_dim + kKs - 1) / kKs;
