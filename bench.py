@@ -572,7 +572,7 @@ def run_c3ppo(a, device):
         "loss": d.get("agent_0/loss", d.get("loss"))}))
 
 
-def run_tag(a, device, rank, world, dist):
+def run_tag(a, device, rank, world, dist, census=None):
     """`--workload tag` (BASELINE configs[4]): simple_tag (3 adversaries v 1 prey, 2 obstacles), grouped policies (one PPO
     per team), league trainer -- per GPU `--tag-envs` worlds (512: 4096 over 8 GPUs), T = 25.  A step = collect + one
     `LeaguePlayTrainer.train_step` in which both teams learn; with N > 1 the two teams' gradients travel in ONE packed
@@ -651,7 +651,8 @@ def run_tag(a, device, rank, world, dist):
         replicas_identical = bool(diff.item() == 0.0)
     if rank == 0:
         out = {"metric": "env-steps/sec (n_env x n_agent) incl. league PPO update, simple_tag 3v1",
-               "value": n_env * N * T * world / (dt / a.steps), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
+               "value": n_env * N * T * world / (dt / a.steps), "unit": "env-steps/s", "n_gpus": world, **(census or {}),
+               "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "simple_tag_v3 3 adversaries + 1 prey, 2 obstacles, grouped PPO (one policy per team), "
@@ -689,8 +690,69 @@ def main():
         print(line, flush=True)
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start N fresh interpreters, one rank per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what `torch.distributed.run` would export), relay rank 0's ONE JSON line
+    and fail if any rank fails.  This process never touches the GPU (no HIP call happens before this point), and no
+    process that has touched one is ever replaced or restarted."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port (the capture probe uses port + 1)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), stderr=None))
+    out0, failed = b"", None
+    alive = set(range(n))
+    while alive and failed is None:
+        for r in sorted(alive):
+            try:
+                if r == 0:
+                    out0 += procs[0].communicate(timeout=0.5)[0] or b""
+                else:
+                    procs[r].wait(timeout=0.05)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.discard(r)
+            if procs[r].returncode != 0:
+                failed = r
+                break
+    if failed is not None:  # stop exactly the ranks this process started
+        for r in alive:
+            procs[r].terminate()
+        for r in alive:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        print("bench: rank %d exited with code %s; stopped the other ranks" % (failed, procs[failed].returncode), file=sys.stderr)
+        return int(procs[failed].returncode or 1)
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if not lines:
+        print("bench: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    _emit(lines[-1])
+    return 0
+
+
 def _main():
     a = parse()
+    # ---- who runs: nothing below this block may run before it, and nothing in it calls into HIP -----------------------
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        if a.workload in ("c3", "c3ppo"):
+            raise SystemExit("bench.py --workload %s is a single-GPU job (BASELINE configs[2]): use --gpus 1" % a.workload)
+        code = launch_ranks(a.gpus)
+        if code:
+            raise SystemExit(code)
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        raise SystemExit("bench.py --gpus %d, but the launcher started WORLD_SIZE=%d ranks: pass --gpus %d" % (a.gpus, world, world))
     if a.workload == "c3ppo":
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
@@ -703,10 +765,9 @@ def _main():
         torch.cuda.set_device(0)
         run_c3(a, torch.device("cuda", 0))
         return
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if torch.cuda.device_count() == 0:  # (counting devices does not initialise the GPU)
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # Rehearsal switches for a single-GPU box (never used by the real multi-GPU run):
     #   TSM_FORCE_DIST=1            process group + replica broadcast + captured all-reduce with a world of ONE rank (RCCL)
@@ -727,9 +788,12 @@ def _main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         capture_ok = probe_collective_capture(rank, world, local)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
+    ranks_seen, backend = 1, None
     force_dist = os.environ.get("TSM_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         import torch.distributed as dist
@@ -741,6 +805,12 @@ def _main():
             dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # who showed up: a sum of ones over the process group -- `n_gpus` of the JSON line is THIS number, not an env var
+        ones = torch.ones(1, device=device, dtype=torch.int32)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if ranks_seen != world:
+            raise SystemExit("bench.py: the %s process group counts %d ranks, WORLD_SIZE says %d" % (backend, ranks_seen, world))
         if capture_ok is not None:  # every rank must take the same path
             t = torch.tensor([1 if capture_ok else 0], device=device, dtype=torch.int32)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -749,8 +819,12 @@ def _main():
                 os.environ["TSM_GRAPH_COLLECTIVES"] = "0"
                 if rank == 0:
                     print("bench: the collective-capture probe failed on some rank: running eager collectives", file=sys.stderr)
+    # `n_gpus` = the ranks the process group itself counted; `ranks_backend` says who counted (nccl == RCCL)
+    census = {} if dist is None else {"rccl_ranks" if backend == "nccl" else "group_ranks": ranks_seen, "ranks_backend": backend}
+    if dist is not None and os.environ.get("TSM_SHARE_GPU") == "1":
+        census["rehearsal"] = "%d ranks share cuda:0 (TSM_SHARE_GPU=1): multi-process logic only, not a scaling figure" % ranks_seen
     if a.workload == "tag":
-        run_tag(a, device, rank, world, dist)
+        run_tag(a, device, rank, ranks_seen, dist, census)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -777,7 +851,7 @@ def _main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / a.steps * 1e3
-    agent_steps = a.n_env * a.n_agent * a.horizon * world
+    agent_steps = a.n_env * a.n_agent * a.horizon * ranks_seen
     value = agent_steps / (dt / a.steps)
     grad_steps = getattr(ts, "gradient_steps", None) or sum(
         s.gradient_steps for s in getattr(ts, "_agent_id_to_stats", {}).values())
@@ -794,7 +868,7 @@ def _main():
     if rank == 0:
         out = {
             "metric": "env-steps/sec (n_env x n_agent) incl. PPO update, simple_spread N=%d" % a.n_agent,
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": "env-steps/s", "n_gpus": ranks_seen, **census, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "simple_spread_v3 N=%d shared PPO, num_envs=%d per GPU, obs %d, A=5, T=%d, MLP 64-64"

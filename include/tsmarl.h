@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TSM_ABI_VERSION 1
+#define TSM_ABI_VERSION 2  /* 2: tsm_adam_step(lr_dev), tsm_ppo_cfg.value_group, tsm_ppo_actor_rows_update(opt_step_dev), *_segs */
 
 enum {
     TSM_OK = 0,
@@ -278,6 +278,23 @@ int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t
                   float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, const double *lr_dev,
                   double beta1, double beta2, double eps, double weight_decay, double max_grad_norm, float *work,
                   float *param_image, const int32_t *image_map, void *stream);
+/* Segmented forms: the flat vector is covered, in order, by up to TSM_MAX_SLAB_SEGS segments whose gradients come from
+ * different kernels (tsm_ppo_actor_rows_update / tsm_ppo_critic_rows_update write separate slab arrays): the gradient of
+ * parameter offset + i, i < n, in slab s is slabs[s * stride + i].  One launch for the whole vector; with
+ * max_grad_norm > 0 one reduction launch in front and ONE norm over all segments (clip_grad_norm_ over
+ * ActorCritic.parameters(), algorithm_base.py:485-498). */
+#define TSM_MAX_SLAB_SEGS 4
+typedef struct tsm_slab_seg {
+    const float *slabs;
+    int64_t offset, n, stride;
+    int32_t n_slab, _pad;
+} tsm_slab_seg;
+int tsm_reduce_slabs_segs(const tsm_slab_seg *segs_host, int32_t n_seg, int64_t n, double scale, float *out,
+                          void *stream);
+int tsm_adam_step_segs(float *param, const tsm_slab_seg *segs_host, int32_t n_seg, int64_t n, float *exp_avg,
+                       float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, const double *lr_dev,
+                       double beta1, double beta2, double eps, double weight_decay, double max_grad_norm, float *work,
+                       void *stream);
 /* param_image[image_map[i]] = param[i]  (initial fill of the padded image; pads must already be zero) */
 int tsm_scatter_image(const float *param, int64_t n, const int32_t *image_map, float *param_image,
                       void *stream);
@@ -501,6 +518,7 @@ int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stream);
  * n_blocks = tsm_ppo_actor_rows_grid(M) persistent workgroups, each writes ONE gradient slab:
  * grad_slabs_out [n_blocks][tsm_ppo_actor_rows_param_count]; loss_partial_out f64 [n_blocks][4] =
  * {sum clip objective, 0, sum entropy, 0} (the layout tsm_ppo_finalize_many folds).
+ * opt_step_dev (nullable, device i64[1]): advanced by one per call, as tsm_ppo_update_fused does.
  * ------------------------------------------------------------------------------------------- */
 int tsm_ppo_actor_rows_supported(int32_t obs_dim, int32_t hidden, int32_t n_act);
 int64_t tsm_ppo_actor_rows_param_count(int32_t obs_dim, int32_t hidden, int32_t n_act);
@@ -509,7 +527,7 @@ int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_dim, int32_
                               const float *obs, const int32_t *act, const float *logp_old, const float *adv,
                               const int64_t *perm, int64_t first_row, int64_t M, const float *adv_stats,
                               const tsm_ppo_cfg *cfg, int32_t n_blocks, float *grad_slabs_out,
-                              double *loss_partial_out, void *stream);
+                              double *loss_partial_out, int64_t *opt_step_dev, void *stream);
 
 /* The critic of the same configuration in one launch: value = MLP(row) with in_dim = n_agent * obs_dim inputs (centralized
  * critic over the joint row, ctde.py:291-294 "concatenate"; n_agent = 1: a local critic on the sample's own observation),

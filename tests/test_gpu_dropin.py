@@ -78,6 +78,15 @@ def test_reference_shaped_script_trains_through_run_training():
 def test_wider_reference_nets_select_the_general_kernels():
     algorithm, actor, critic = _reference_shaped_algorithm(48, [128, 128], lr=3e-4)
     assert isinstance(algorithm, GenericPPO) and algorithm.net.actor.dims == [48, 128, 128, 5]
+    # what the reference objects say carries over as for the 64-wide class: the policy's greedy evaluation and an update
+    # on the whole batch handed over (ppo.py:55-133)
+    assert algorithm.deterministic_eval is True and algorithm.dispatch == "pooled"
+    obs = torch.randn(64, 48, device=DEV)
+    out = algorithm.act_device(obs)  # outside a training step: the arg-max action (reinforce.py:185-189)
+    assert torch.equal(out["act"].long(), out["logits"].argmax(-1))
+    with policy_within_training_step(algorithm):
+        sampled = algorithm.act_device(obs)["act"]
+    assert not torch.equal(sampled.long(), out["logits"].argmax(-1))
     keys = [k for k in algorithm.state_dict() if k != "_optimizers"]
     ref = ["policy.actor." + k for k in actor.state_dict()] + ["critic." + k for k in critic.state_dict()]
     assert keys == ref

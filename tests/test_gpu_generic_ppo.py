@@ -432,3 +432,38 @@ def test_rows_added_outside_a_collector_are_not_treated_as_chained():
     col.reset_env()                  # the next rows do not continue the stored ones
     col.collect(n_step=n_env * 2)
     assert buf.rows_chained is False
+
+
+def test_graph_captured_over_chained_rows_is_not_replayed_on_unchained_rows():
+    """The update graph bakes in, at capture time, whether V(obs_next) comes from the next slot's V(obs)
+    (`buffer.rows_chained`).  Two half-collects with `reset_env()` between them fill the same buffer shape with rows that do
+    NOT continue one another: the chained graph must not be replayed on them (its key carries the marker).  The update
+    has to equal the one of an algorithm that always runs both critic passes (shift_next_values=False)."""
+    n_env, N, T = 48, 3, 10
+    finals = []
+    for shift in (True, False):
+        env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=25, device=DEV, seed=4)
+        D = env.obs_dim
+        net = MLPActorCritic(D, 5, (128, 128), critic_obs_dim=N * D, device=DEV, seed=1)
+        algo = GenericPPO(net=net, critic_input="global", n_agent=N, shuffle="device", seed=2, dispatch="pooled", graph=True,
+                          shift_next_values=shift)
+        buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=DEV)
+        col = Collector(algo, env, buf)
+        col.reset()
+        outs = []
+        for it in range(5):
+            with policy_within_training_step(algo):
+                if it < 3:  # eager, capture, replay: on chained rows
+                    col.collect(n_step=n_env * T)
+                    assert buf.rows_chained is True
+                else:       # the same shape, but slot T/2 does not continue slot T/2 - 1
+                    col.collect(n_step=n_env * (T // 2))
+                    col.reset_env()
+                    col.collect(n_step=n_env * (T - T // 2))
+                    assert buf.rows_chained is False
+                ts = algo.update(buf, batch_size=480, repeat=1)
+            col.reset_buffer(keep_statistics=True)
+            outs.append(ts.get_loss_stats_dict())
+        finals.append((net.flat.data.clone(), outs))
+    assert torch.equal(finals[0][0], finals[1][0])
+    assert finals[0][1] == finals[1][1]

@@ -449,6 +449,44 @@ def test_adam_step_matches_torch(max_norm, n_slab):
         np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-7)
 
 
+@pytest.mark.parametrize("max_norm", [None, 0.5])
+def test_adam_step_over_slab_segments(max_norm):
+    """`tsm_adam_step_segs`: actor and critic gradients arrive in slab arrays of their own (csrc/ppo_rows.hip), with
+    different slab counts and pitches; one launch must equal what the unsegmented entry points do -- without clipping, two
+    `adam_step` calls on the halves (bit for bit: the same slab order per parameter); with clipping, ONE norm over the whole
+    vector as `clip_grad_norm_` over ActorCritic.parameters() computes it (vs torch)."""
+    torch.manual_seed(1)
+    n_a, n_c = 23429, 65921  # not multiples of the 64-parameter blocks
+    n = n_a + n_c
+    sl_a = (torch.randn(37, n_a) * 0.1).to(DEV)
+    wide = (torch.randn(5, n_c + 77) * 0.1).to(DEV)   # a view into wider slabs: pitch > parameter count
+    sl_c = wide[:, :n_c]
+    p0 = torch.randn(n)
+    segs = [(sl_a, 0, n_a), (wide, n_a, n_c)]
+    g = ops.reduce_slabs_segs(segs, n, scale=0.5)
+    assert torch.equal(g[:n_a], ops.reduce_slabs(sl_a, scale=0.5))
+    assert torch.equal(g[n_a:], ops.reduce_slabs(sl_c.contiguous(), scale=0.5))
+    p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step_dev = torch.tensor([0], dtype=torch.int64, device=DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=3e-4)
+    q, qm, qv = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(3):
+        step_dev += 1
+        ops.adam_step_segs(p, segs, m, v, 1, lr=3e-4, max_grad_norm=max_norm, step_dev=step_dev)
+        ref.grad = torch.cat([sl_a.sum(0), sl_c.sum(0)]).cpu()
+        if max_norm:
+            torch.nn.utils.clip_grad_norm_([ref], max_norm)
+        opt.step()
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-7)
+        if not max_norm:
+            ops.adam_step(q[:n_a], sl_a, qm[:n_a], qv[:n_a], step + 1, lr=3e-4)
+            ops.adam_step(q[n_a:], sl_c.contiguous(), qm[n_a:], qv[n_a:], step + 1, lr=3e-4)
+            assert torch.equal(p, q) and torch.equal(m, qm) and torch.equal(v, qv)
+    with pytest.raises(ValueError):  # a gap between the segments
+        ops.adam_step_segs(p, [(sl_a, 0, n_a), (wide, n_a + 1, n_c - 1)], m, v, 1)
+
+
 # ------------------------------------------------------------------------------------------------
 # CTDE global state
 # ------------------------------------------------------------------------------------------------

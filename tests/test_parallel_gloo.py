@@ -104,13 +104,17 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         for k, g in enumerate(got_b):
             assert torch.allclose(g, torch.full((7,), (10.0 + k) * mean_rank))
         # every rank must take the same number of gradient steps per update (unequal env shards can split into a
-        # different number of minibatches -> a different number of all-reduces -> deadlock): agreed values pass (and are
-        # checked once), a disagreement raises on EVERY rank instead of hanging
+        # different number of minibatches -> a different number of all-reduces -> deadlock): agreed values pass, a
+        # disagreement raises on EVERY rank instead of hanging
         sync.require_equal(18, "the number of gradient steps per update")
         sync.require_equal(18, "the number of gradient steps per update")
-        assert ("the number of gradient steps per update", 18) in sync._checked
         with pytest.raises(ValueError, match="disagree"):
             sync.require_equal(30 + rank, "the number of gradient steps per update")
+        # ... also when ONE rank comes back with a count all ranks have agreed on before (n_episode collection: the
+        # number of valid rows varies per rank and per update): the check is a collective on every call, never skipped
+        # because of what this rank has seen
+        with pytest.raises(ValueError, match="disagree"):
+            sync.require_equal(18 if rank == 0 else 12, "the number of gradient steps per update")
         # advantage statistics of the GLOBAL minibatch: every rank holds (mean, unbiased std) of its own
         # part of each minibatch; pack -> ONE all-reduce -> unpack turns them into the statistics of the union, identical
         # on every rank.  The pack / unpack arithmetic is a pair of HIP kernels in the product (checked bit for bit in

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtsmarl_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tsmarl.h")
 
+ABI_VERSION = 2  # include/tsmarl.h TSM_ABI_VERSION: bumped whenever a signature or a struct layout changes
 TSM_OK, TSM_ERR_INVALID, TSM_ERR_HIP, TSM_ERR_MALFORMED_BUFFER, TSM_ERR_UNSUPPORTED = range(5)
 
 
@@ -30,6 +31,11 @@ class tsm_ppo_cfg(C.Structure):
     _fields_ = [("eps_clip", C.c_double), ("dual_clip", C.c_double), ("vf_coef", C.c_double),
                 ("ent_coef", C.c_double), ("value_clip", C.c_int32), ("adv_norm", C.c_int32),
                 ("loss_kind", C.c_int32), ("value_group", C.c_int32)]
+
+
+class tsm_slab_seg(C.Structure):
+    _fields_ = [("slabs", C.c_void_p), ("offset", C.c_int64), ("n", C.c_int64), ("stride", C.c_int64),
+                ("n_slab", C.c_int32), ("_pad", C.c_int32)]
 
 
 class tsm_mpe_cfg(C.Structure):
@@ -166,7 +172,9 @@ SIGNATURES = {
     "tsm_ppo_actor_rows_param_count": (_i64, [_i32, _i32, _i32]),
     "tsm_ppo_actor_rows_grid": (_int, [_i64]),
     "tsm_ppo_actor_rows_update": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _i64, _p, C.POINTER(tsm_ppo_cfg),
-                                         _i32, _p, _p, _p]),
+                                         _i32, _p, _p, _p, _p]),
+    "tsm_reduce_slabs_segs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
+    "tsm_adam_step_segs": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _p, _f64, _p, _f64, _f64, _f64, _f64, _f64, _p, _p]),
     "tsm_ppo_update_grid": (_int, [_i64, _i32]),
     "tsm_ppo_finalize_many": (_int, [_p, _i64, _p, _p, _i32, C.POINTER(tsm_ppo_cfg), _p, _p]),
     "tsm_ppo_update_fused": (_int, [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p,
@@ -203,7 +211,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.tsm_abi_version() != 1:
+    if lib.tsm_abi_version() != ABI_VERSION:
         raise ImportError(f"ABI version mismatch: library reports {lib.tsm_abi_version()}")
     _lib = lib
     return lib

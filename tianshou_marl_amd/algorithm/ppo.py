@@ -407,6 +407,10 @@ class PPO(nn.Module):
 
     def _update_graph(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int):
         T = buffer.host_uniform_len()  # host mirror of the fill level (no device round trip)
+        if T is None and self._grad_sync is not None:
+            # data parallel: graph or eager must not depend on what the episodes happened to do on THIS rank (the two
+            # paths issue different collective sequences) -- only host-known uniform fills (n_step collection) replay
+            return None
         if T is None:
             lens_h = buffer.index.lengths.cpu().numpy()
             ins_h = buffer.index.insertion_idx.cpu().numpy()

@@ -9,7 +9,9 @@ those this class composes the general kernels instead:
     PPO loss forward + backward         csrc/ppo_loss.hip   (on given logits / value -> dlogits, dvalue)
     clip_grad_norm_ + Adam              csrc/adam.hip       (ONE optimizer over actor + critic, as ActorCritic does)
 Interface, hyper-parameters, per-agent dispatch, statistics and the reference call sites are those of `PPO`
-(ppo.py:17-224, a2c.py:113-151, marl.py:208-268).  Launches are eager (no hipGraph capture yet).
+(ppo.py:17-224, a2c.py:113-151, marl.py:208-268).  With `graph=True` (the default) the second update of a shape captures
+the whole sequence -- permutations, critic passes, GAE, every gradient step -- into ONE hipGraph that later updates replay;
+128-wide nets take the one-launch row kernels of csrc/ppo_rows.hip (`fused_actor` / `fused_critic`).
 `critic_input="global"`: the critic sees the env's joint observation `[N * obs_dim]` (GlobalStateConstructor
 "concatenate", ctde.py:291-294) and its single value is shared by the env's agents (centralized-critic PPO).
 """
@@ -39,6 +41,12 @@ class GenericPPO(PPO):
             from ..utils.net import net_from_reference_modules
 
             net = net_from_reference_modules(kwargs["policy"], kwargs.get("critic"), kwargs.get("device", "cuda"))
+            # what PPO.__init__ takes from the reference objects when it builds the net itself (ppo.py:55-133): greedy
+            # evaluation as the policy says, and an update on the whole batch handed over (MARLDispatcher's per-agent
+            # sequence is `dispatch="per_agent"`)
+            kwargs["deterministic_eval"] = bool(getattr(kwargs["policy"], "deterministic_eval",
+                                                        kwargs.get("deterministic_eval", False)))
+            kwargs["dispatch"] = kwargs.get("dispatch") or "pooled"
         if not isinstance(net, MLPActorCritic):
             raise TypeError("GenericPPO needs an MLPActorCritic (use PPO for DiscreteActorCritic)")
         if critic_input is None:  # a critic that is wider than the actor's observation sees the env's joint observation
@@ -168,14 +176,15 @@ class GenericPPO(PPO):
                     adv=adv.reshape(-1), logp_old=logp_old, n_env=B, n_agent=N, joint=joint)
 
     def _grad_step(self, pb: dict, idx: torch.Tensor, adv_stats, step_dev: torch.Tensor | None = None,
-                   rows: torch.Tensor | None = None) -> torch.Tensor:
+                   rows: torch.Tensor | None = None, partial_out: torch.Tensor | None = None) -> torch.Tensor | None:
         """One minibatch: forward both nets, loss, backward into joint slabs, clip + Adam.  Returns the 4 scalars.
         idx: lane (sample) ids of the minibatch; rows: its joint-row ids when the minibatch is made of whole rows
         (`row_minibatches`: idx == rows * N + agent, row-major).  step_dev: device-resident optimizer step count (graph
-        capture); None = the host counter."""
+        capture); None = the host counter.  partial_out (f64, row-kernel path only): the step's loss partials are left
+        there for ONE `ppo_finalize_many` over all steps of the update and None is returned."""
         net = self.net
         if self.fused_actor:
-            return self._grad_step_fused_actor(pb, idx, adv_stats, step_dev, rows)
+            return self._grad_step_fused_actor(pb, idx, adv_stats, step_dev, rows, partial_out)
         if rows is not None:
             N = pb["n_agent"]
             cx = ops.gather_rows(pb["joint"], rows)                    # [Mr, N * D]: read once ...
@@ -214,18 +223,25 @@ class GenericPPO(PPO):
                       work=self._adam_work, step_dev=step_dev)
         return scalars
 
-    def _grad_step_fused_actor(self, pb: dict, idx: torch.Tensor, adv_stats, step_dev, rows) -> torch.Tensor:
+    def _rows_grids(self, M: int, Mr: int, crit_rows: bool) -> tuple[int, int]:
+        """(actor workgroups, loss-partial groups of the value term) of a row-kernel gradient step of M samples / Mr units."""
+        return ops.ppo_actor_rows_grid(M), (ops.ppo_critic_rows_grid(Mr) if crit_rows else ops.ppo_loss_partial_elems(M) // 4)
+
+    def _grad_step_fused_actor(self, pb: dict, idx: torch.Tensor, adv_stats, step_dev, rows,
+                               partial_out: torch.Tensor | None = None) -> torch.Tensor | None:
         """The same gradient step with the 128-wide actor in ONE launch (forward, policy loss, backward:
-        csrc/ppo_rows.hip) and the critic beside it on the dense GEMMs with the value term alone; the two gradient halves
-        are folded into one flat gradient for the (jointly clipped) Adam step.  Loss statistics: one finalize launch over
-        the actor's and the value kernel's partial sums."""
+        csrc/ppo_rows.hip) and the critic beside it -- in one launch of its own when the minibatch is made of whole joint
+        rows or the critic is local, else on the dense GEMMs with the value term alone.  The two halves keep their own
+        slab arrays and meet in ONE segmented Adam launch (`tsm_adam_step_segs`: slab sums, the joint gradient norm when
+        clipping, Adam); data parallel: one segmented reduction -> all-reduce -> Adam.  Three launches per gradient step
+        in the captured update: the optimizer step count is advanced by the actor kernel and the loss statistics of all
+        steps are folded by one launch at the end (`partial_out`)."""
         net, dev = self.net, self.device
         M, P_a, P_c = idx.numel(), net.n_actor, net.n_critic
         # the critic in one launch too when the minibatch is made of whole joint rows (or the critic is local)
         crit_rows = self.fused_critic and (rows is not None or pb["joint"] is None)
         Mr = rows.numel() if rows is not None else M
-        na = ops.ppo_actor_rows_grid(M)
-        nv = ops.ppo_critic_rows_grid(Mr) if crit_rows else ops.ppo_loss_partial_elems(M) // 4
+        na, nv = self._rows_grids(M, Mr, crit_rows)
         n_split = nv if crit_rows else ops.mlp_n_split(Mr)
         w = self._ws.get(("rows", M, n_split, crit_rows))
         if w is None:
@@ -235,14 +251,17 @@ class GenericPPO(PPO):
                 partial=torch.zeros((na + nv) * 4, dtype=torch.float64, device=dev),
                 nb=torch.tensor([na + nv], dtype=torch.int32, device=dev), M=torch.tensor([M], dtype=torch.int64, device=dev),
                 flat_g=torch.empty(P_a + P_c, dtype=torch.float32, device=dev))
+        partial = w["partial"] if partial_out is None else partial_out
+        if partial.numel() < (na + nv) * 4:
+            raise ValueError(f"loss partials: {partial.numel()} values, this step needs {(na + nv) * 4}")
         ops.ppo_actor_rows_update(net.actor.flat.data, pb["obs"], pb["act"], pb["logp_old"], pb["adv"], self._cfg, net.n_act,
                                   net.actor.dims[1], adv_stats=adv_stats, perm=idx, M=M, n_blocks=na, slabs=w["slabs_a"],
-                                  partial=w["partial"][:na * 4])
+                                  partial=partial[:na * 4], opt_step_dev=step_dev)
         if crit_rows:
             src, N_c = (pb["joint"], pb["n_agent"]) if rows is not None else (pb["obs"], 1)
             ops.ppo_critic_rows_update(net.critic.flat.data, src, pb["ret"], self._cfg, N_c, net.critic.dims[1],
                                        v_s_old=pb["v_s"] if self.value_clip else None, rows=rows if rows is not None else idx,
-                                       Mr=Mr, n_blocks=nv, slabs=w["slabs_c"], partial=w["partial"][na * 4:])
+                                       Mr=Mr, n_blocks=nv, slabs=w["slabs_c"], partial=partial[na * 4:(na + nv) * 4])
         else:
             if rows is not None:
                 cx, vg = ops.gather_rows(pb["joint"], rows), pb["n_agent"]
@@ -252,28 +271,23 @@ class GenericPPO(PPO):
                 cx, vg = ops.gather_rows(pb["obs"], idx), 1
             value = FlatMLP.forward(net.critic, cx, save=True).reshape(-1)
             dvalue, _ = ops.ppo_value_loss(value, pb["ret"], self._cfg_value[vg], M, v_s_old=pb["v_s"] if self.value_clip else None,
-                                           perm=idx, partial=w["partial"][na * 4:])
+                                           perm=idx, partial=partial[na * 4:(na + nv) * 4])
             net.critic.backward(dvalue.view(-1, 1), n_split, slabs=w["slabs_c"], slab_stride=P_c)
         if step_dev is None:
             self.opt_step += 1
+        segs = [(w["slabs_a"][:na], 0, P_a), (w["slabs_c"][:n_split], P_a, P_c)]
+        hyper = dict(lr=self.lr, lr_dev=self._lr_dev, betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
+                     step_dev=step_dev)
+        if self._grad_sync is None:
+            ops.adam_step_segs(net.flat.data, segs, self.exp_avg, self.exp_avg_sq, self.opt_step,
+                               max_grad_norm=self.max_grad_norm, work=self._adam_work, **hyper)
         else:
-            ops.call("tsm_u64_add", ops.ptr(step_dev), 1, ops.stream_ptr())
-        adam = lambda p, g, m, v, **kw: ops.adam_step(  # noqa: E731
-            p, g, m, v, self.opt_step, lr=self.lr, lr_dev=self._lr_dev, betas=self.betas, eps=self.adam_eps,
-            weight_decay=self.weight_decay, step_dev=step_dev, **kw)
-        if self._grad_sync is None and not self.max_grad_norm:
-            # no joint norm and nothing to exchange: each half's slabs go straight into its own Adam launch (the slab sum
-            # is part of tsm_adam_step), two launches instead of two reductions + one Adam
-            adam(net.flat.data[:P_a], w["slabs_a"], self.exp_avg[:P_a], self.exp_avg_sq[:P_a])
-            adam(net.flat.data[P_a:], w["slabs_c"][:n_split], self.exp_avg[P_a:], self.exp_avg_sq[P_a:])
-        else:
-            scale = 1.0 / self._grad_sync.world if self._grad_sync is not None else 1.0
-            ops.reduce_slabs(w["slabs_a"], out=w["flat_g"][:P_a], scale=scale)
-            ops.reduce_slabs(w["slabs_c"], out=w["flat_g"][P_a:], scale=scale)
-            if self._grad_sync is not None:
-                self._grad_sync.all_reduce_sum_(w["flat_g"])
-            adam(net.flat.data, w["flat_g"].view(1, -1), self.exp_avg, self.exp_avg_sq, max_grad_norm=self.max_grad_norm,
-                 work=self._adam_work)
+            ops.reduce_slabs_segs(segs, P_a + P_c, out=w["flat_g"], scale=1.0 / self._grad_sync.world)
+            self._grad_sync.all_reduce_sum_(w["flat_g"])
+            ops.adam_step(net.flat.data, w["flat_g"].view(1, -1), self.exp_avg, self.exp_avg_sq, self.opt_step,
+                          max_grad_norm=self.max_grad_norm, work=self._adam_work, **hyper)
+        if partial_out is not None:
+            return None
         scal = torch.empty(1, 4, dtype=torch.float32, device=dev)
         ops.ppo_finalize_many(w["partial"], (na + nv) * 4, w["nb"], w["M"], self._cfg, scal)
         return scal[0]
@@ -305,8 +319,11 @@ class GenericPPO(PPO):
         row_mode = unit > 1
         stored = (self.reuse_rollout_outputs, buffer.behaviour_outputs_version == self.param_version,
                   buffer.logp_outputs_version == self.param_version)
-        key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored,
-               self._grad_sync is not None)
+        # every property of the buffer that `_preprocess_batch` branches on at CAPTURE time belongs to the key: a graph
+        # captured over chained rows (V(obs_next) from the next slot's V(obs)) must never replay on rows that are not
+        chained = buffer.rows_chained is True and self.shift_next_values
+        key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored, chained,
+               self._grad_sync is not None, self.graph_collectives)
         w = self._ws.get(key)
         if w is None:  # first update of this shape runs eagerly (one-time kernel attributes, allocator warm-up)
             self._ws[key] = {}
@@ -314,6 +331,8 @@ class GenericPPO(PPO):
         dev = self.device
         n_steps = len(groups) * repeat * len(bounds)
         if "graph" not in w:
+            if self._grad_sync is not None:
+                self._grad_sync.require_equal(n_steps, "the number of gradient steps per update")
             w.update(perm=torch.zeros(len(groups), repeat, n_g, dtype=torch.int64, device=dev),
                      step_dev=torch.zeros(1, dtype=torch.int64, device=dev),
                      scal=torch.zeros(n_steps, 4, dtype=torch.float32, device=dev),
@@ -323,6 +342,19 @@ class GenericPPO(PPO):
             w["mb_all"] = mb_all = torch.cat([(seg + w["mb_start"][:-1].view(1, -1)).reshape(-1),
                                               torch.tensor([len(groups) * repeat * n_g * unit], dtype=torch.int64, device=dev)])
             w["lane_of_row"] = torch.arange(N, dtype=torch.int64, device=dev).view(1, 1, 1, N)
+            # row-kernel steps leave their loss partials behind; ONE launch folds them all at the end of the update
+            defer = self.fused_actor
+            if defer:
+                glob_rows = self.critic_input == "global"
+                grids = []
+                for s_, e_ in bounds:
+                    M_, Mr_ = (e_ - s_) * unit, e_ - s_
+                    crit = self.fused_critic and (row_mode or not glob_rows)
+                    grids.append(sum(self._rows_grids(M_, Mr_ if row_mode else M_, crit)))
+                reps = len(groups) * repeat
+                w["partial"] = torch.zeros(n_steps, max(grids) * 4, dtype=torch.float64, device=dev)
+                w["nb_dev"] = torch.as_tensor(grids * reps, dtype=torch.int32, device=dev)
+                w["M_dev"] = torch.as_tensor([(e_ - s_) * unit for s_, e_ in bounds] * reps, dtype=torch.int64, device=dev)
 
             def body():
                 if self.shuffle == "device":
@@ -343,9 +375,13 @@ class GenericPPO(PPO):
                     for r in range(repeat):
                         for j, (s, e) in enumerate(bounds):
                             sc = self._grad_step(pb, lanes[gi, r, s * unit:e * unit], None if stats is None else stats[gi, r, j],
-                                                 step_dev=w["step_dev"], rows=w["perm"][gi, r, s:e] if row_mode else None)
-                            w["scal"][k].copy_(sc)
+                                                 step_dev=w["step_dev"], rows=w["perm"][gi, r, s:e] if row_mode else None,
+                                                 partial_out=w["partial"][k] if defer else None)
+                            if not defer:
+                                w["scal"][k].copy_(sc)
                             k += 1
+                if defer:  # the loss statistics of every gradient step: one launch
+                    ops.ppo_finalize_many(w["partial"], w["partial"].shape[1], w["nb_dev"], w["M_dev"], self._cfg, w["scal"])
 
             graph = torch.cuda.CUDAGraph()
             self._capture_graph(graph, body)  # (data parallel over RCCL: the all-reduces of every step are captured too)
@@ -405,6 +441,8 @@ class GenericPPO(PPO):
             unit, size = 1, batch_size or -1
         n = ids.numel()
         bounds = split_bounds(n, size, merge_last=True)
+        if self._grad_sync is not None:  # (a collective on every eager update: parallel.GradSync.require_equal)
+            self._grad_sync.require_equal(repeat * len(bounds), "the number of gradient steps per update")
         mb_start = torch.as_tensor([b[0] * unit for b in bounds] + [n * unit], dtype=torch.int64, device=dev)
         lane_of_row = torch.arange(N, dtype=torch.int64, device=dev).view(1, N)
         scal = []

@@ -30,8 +30,9 @@ __device__ __forceinline__ double ipow(double b, int64_t e) {
     return r;
 }
 
+// `n` = parameters covered (bounds), `stride` = floats between two consecutive slabs
 __device__ __forceinline__ float slab_sum_block(const float *__restrict__ slabs, int32_t n_slab, int64_t n,
-                                                int64_t i, float *sm /* [4][64] */) {
+                                                int64_t i, float *sm /* [4][64] */, int64_t stride) {
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     float acc = 0.f;
     if (i < n) {
@@ -40,18 +41,18 @@ __device__ __forceinline__ float slab_sum_block(const float *__restrict__ slabs,
         for (; s + 60 < n_slab; s += 64) {  // 16 independent loads in flight per lane (32 measured no faster)
             float t[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * n + i];
+            for (int u = 0; u < 16; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc += t[u];
         }
         for (; s + 28 < n_slab; s += 32) {
             float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * n + i];
+            for (int u = 0; u < 8; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += t[u];
         }
-        for (; s < n_slab; s += 4) acc += slabs[(int64_t)s * n + i];
+        for (; s < n_slab; s += 4) acc += slabs[(int64_t)s * stride + i];
     }
     sm[sl * 64 + lane] = acc;
     __syncthreads();
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void reduce_norm_kernel(const float *__restric
     __shared__ float sm[256];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * kCols + lane;
-    const float g = slab_sum_block(slabs, n_slab, n, i, sm);
+    const float g = slab_sum_block(slabs, n_slab, n, i, sm, n);
     if (sl == 0) {
         if (i < n) work[i] = g;
         float q = i < n ? g * g : 0.f;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         __syncthreads();
         g = i < n ? work[i] * s_coef : 0.f;
     } else {
-        g = slab_sum_block(slabs, n_slab, n, i, sm);
+        g = slab_sum_block(slabs, n_slab, n, i, sm, n);
     }
     if (sl != 0 || i >= n) return;
     // bias corrections from the (host or device-resident) step count, in f64 like torch's python scalars
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restri
     __shared__ float sm[256];
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * kCols + lane;
-    const float g = slab_sum_block(slabs, n_slab, n, i, sm);
+    const float g = slab_sum_block(slabs, n_slab, n, i, sm, n);
     if (sl == 0 && i < n) out[i] = g * scale;
 }
 
@@ -137,6 +138,106 @@ __global__ void scatter_image_kernel(const float *__restrict__ p, int64_t n, con
                                      float *__restrict__ img) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) img[map[i]] = p[i];
+}
+
+
+// ---- segmented forms: the flat vector is covered by up to TSM_MAX_SLAB_SEGS segments, each with its own slab array
+// (actor slabs from one kernel, critic slabs from another: csrc/ppo_rows.hip) -- one launch for the whole vector ----
+struct SegArgs {
+    tsm_slab_seg seg[TSM_MAX_SLAB_SEGS];
+    int32_t first_blk[TSM_MAX_SLAB_SEGS + 1];  // block range of every segment
+    int32_t n_seg;
+};
+
+__device__ __forceinline__ int seg_of_block(const SegArgs &a, int blk) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < TSM_MAX_SLAB_SEGS; ++j)
+        if (j < a.n_seg && blk >= a.first_blk[j]) k = j;
+    return k;
+}
+
+// g[offset + i] = scale * sum of the segment's slabs; with `norm_work` also the per-block sum of squares (clip path)
+__global__ __launch_bounds__(256) void reduce_segs_kernel(SegArgs a, int64_t n_total, float scale, float *__restrict__ out,
+                                                          float *__restrict__ blk_sq) {
+    __shared__ float sm[256];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int k = seg_of_block(a, blockIdx.x);
+    const tsm_slab_seg sg = a.seg[k];
+    const int64_t i = (int64_t)(blockIdx.x - a.first_blk[k]) * kCols + lane;
+    const float g = slab_sum_block(sg.slabs, sg.n_slab, sg.n, i, sm, sg.stride) * scale;
+    if (sl == 0) {
+        if (i < sg.n) out[sg.offset + i] = g;
+        if (blk_sq) {
+            float q = i < sg.n ? g * g : 0.f;
+            q = wave_sum(q);
+            if (lane == 0) blk_sq[blockIdx.x] = q;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_segs_kernel(float *__restrict__ p, SegArgs a, int64_t n_total, float *__restrict__ m,
+                                                        float *__restrict__ v, double lr_host,
+                                                        const double *__restrict__ lr_dev, double beta1d, double beta2d,
+                                                        int64_t step_host, const int64_t *__restrict__ step_dev,
+                                                        float eps, float weight_decay, float max_norm,
+                                                        const float *__restrict__ work) {
+    __shared__ float sm[256];
+    __shared__ float s_coef;
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int k = seg_of_block(a, blockIdx.x);
+    const tsm_slab_seg sg = a.seg[k];
+    const int64_t il = (int64_t)(blockIdx.x - a.first_blk[k]) * kCols + lane;
+    const int64_t i = sg.offset + il;
+    float g;
+    if (max_norm > 0.f) {  // clipping path: reduce_segs_kernel left the summed gradient in work[0..n) and the blocks' squares behind it
+        const int nblk = a.first_blk[a.n_seg];
+        float q = 0.f;
+        for (int b = threadIdx.x; b < nblk; b += 256) q += work[n_total + b];
+        q = wave_sum(q);
+        if (lane == 0) sm[sl] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float tot = sm[0] + sm[1] + sm[2] + sm[3];
+            const float c = max_norm / (sqrtf(tot) + 1e-6f);
+            s_coef = c < 1.f ? c : 1.f;
+        }
+        __syncthreads();
+        g = il < sg.n ? work[i] * s_coef : 0.f;
+    } else {
+        g = slab_sum_block(sg.slabs, sg.n_slab, sg.n, il, sm, sg.stride);
+    }
+    if (sl != 0 || il >= sg.n) return;
+    const int64_t step = step_dev ? *step_dev : step_host;
+    const double lr = lr_dev ? *lr_dev : lr_host;
+    const float step_size = (float)(lr / (1.0 - ipow(beta1d, step)));
+    const float bc2_sqrt = (float)sqrt(1.0 - ipow(beta2d, step));
+    const float beta1 = (float)beta1d, beta2 = (float)beta2d;
+    const float pi = p[i];
+    if (weight_decay != 0.f) g += weight_decay * pi;
+    const float mi = beta1 * m[i] + (1.f - beta1) * g;
+    const float vi = beta2 * v[i] + (1.f - beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+}
+
+int fill_segs(SegArgs &a, const tsm_slab_seg *segs, int32_t n_seg, int64_t n_total) {
+    if (!segs || n_seg < 1 || n_seg > TSM_MAX_SLAB_SEGS) return -1;
+    a.n_seg = n_seg;
+    int64_t covered = 0, blk = 0;
+    for (int k = 0; k < n_seg; ++k) {
+        const tsm_slab_seg &s = segs[k];
+        // segments tile [0, n_total) in order: every parameter gets exactly one gradient
+        if (!s.slabs || s.n < 1 || s.n_slab < 1 || s.stride < s.n || s.offset != covered) return -1;
+        a.seg[k] = s;
+        a.first_blk[k] = (int32_t)blk;
+        blk += ceil_div(s.n, kCols);
+        covered += s.n;
+    }
+    for (int k = n_seg; k <= TSM_MAX_SLAB_SEGS; ++k) a.first_blk[k] = (int32_t)blk;
+    return covered == n_total ? (int)blk : -1;
 }
 
 }  // namespace
@@ -154,7 +255,47 @@ TSM_EXPORT int tsm_reduce_slabs(const float *grad_slabs, int32_t n_slab, int64_t
     return TSM_OK;
 }
 
-TSM_EXPORT int64_t tsm_adam_work_elems(int64_t n) { return n < 0 ? -1 : n + ceil_div(n > 0 ? n : 1, kCols); }
+// The same for a flat vector whose parts were differentiated by different kernels: segment k covers parameters
+// [offset, offset + n) and owns n_slab slabs, `stride` floats apart.  One launch.
+TSM_EXPORT int tsm_reduce_slabs_segs(const tsm_slab_seg *segs, int32_t n_seg, int64_t n, double scale, float *out,
+                                     void *stream) {
+    SegArgs a{};
+    const int blocks = fill_segs(a, segs, n_seg, n);
+    TSM_REQUIRE(blocks > 0 && out, "tsm_reduce_slabs_segs: the segments must tile [0, n) in order (1..%d of them), non-null",
+                TSM_MAX_SLAB_SEGS);
+    hipLaunchKernelGGL(reduce_segs_kernel, dim3((unsigned)blocks), dim3(256), 0, tsm_stream(stream), a, n, (float)scale,
+                       out, (float *)nullptr);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+// tsm_adam_step over segmented slabs (one launch for actor + critic; with max_grad_norm > 0 one reduction launch in
+// front of it and ONE norm over the whole vector, as clip_grad_norm_ over ActorCritic.parameters() has it).
+// work: tsm_adam_work_elems(n) floats when clipping.
+TSM_EXPORT int tsm_adam_step_segs(float *param, const tsm_slab_seg *segs, int32_t n_seg, int64_t n, float *exp_avg,
+                                  float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, const double *lr_dev,
+                                  double beta1, double beta2, double eps, double weight_decay, double max_grad_norm,
+                                  float *work, void *stream) {
+    SegArgs a{};
+    const int blocks = fill_segs(a, segs, n_seg, n);
+    TSM_REQUIRE(blocks > 0, "tsm_adam_step_segs: the segments must tile [0, n) in order (1..%d of them), non-null",
+                TSM_MAX_SLAB_SEGS);
+    TSM_REQUIRE(step >= 1 || step_dev, "tsm_adam_step_segs: step = %lld", (long long)step);
+    TSM_REQUIRE(param && exp_avg && exp_avg_sq, "tsm_adam_step_segs: null pointer");
+    TSM_REQUIRE(max_grad_norm <= 0.0 || work, "tsm_adam_step_segs: clipping needs work[tsm_adam_work_elems(n)]");
+    hipStream_t st = tsm_stream(stream);
+    if (max_grad_norm > 0.0) {
+        hipLaunchKernelGGL(reduce_segs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, n, 1.0f, work, work + n);
+        TSM_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(adam_segs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, a, n, exp_avg, exp_avg_sq, lr,
+                       lr_dev, beta1, beta2, step, step_dev, (float)eps, (float)weight_decay, (float)max_grad_norm, work);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+// (room for the per-block squares of the segmented form too: every segment rounds its block count up)
+TSM_EXPORT int64_t tsm_adam_work_elems(int64_t n) { return n < 0 ? -1 : n + ceil_div(n > 0 ? n : 1, kCols) + TSM_MAX_SLAB_SEGS; }
 
 TSM_EXPORT int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
                              float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, const double *lr_dev,

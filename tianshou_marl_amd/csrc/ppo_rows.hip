@@ -88,6 +88,7 @@ struct ActorArgs {
     float *slabs;            // [grid][P]
     double *partial;         // [grid][4] = {sum clip objective, 0, sum entropy, 0}
     long long *stamps;       // diagnostics only (tsm_debug_set_stamps): phase time stamps of workgroup 0, its tiles 0..3
+    int64_t *opt_step_dev;   // nullable: the device-resident optimizer step count, advanced by one per launch
 };
 
 #define ASTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0 && it < 4) g.stamps[it * 16 + (k)] = (long long)wall_clock64(); } while (0)
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
     const int D = g.D, A = g.A, ld1 = ly.ld1;
     const int64_t n_tiles = (g.M + kRows - 1) / kRows;
+    // the gradient step this launch opens: the Adam launch behind it reads the advanced count (tsm_adam_step(step_dev))
+    if (g.opt_step_dev && blockIdx.x == 0 && tid == 0) *g.opt_step_dev += 1;
 
     // ---- stage the weights once (zero pads: W1 columns >= D, W3 rows >= A) ----
     const int oW1 = 0, oB1 = kH * D, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + A * kH;
@@ -812,7 +815,7 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
                                          const float *obs, const int32_t *act, const float *logp_old, const float *adv,
                                          const int64_t *perm, int64_t first_row, int64_t M, const float *adv_stats,
                                          const tsm_ppo_cfg *cfg, int32_t n_blocks, float *grad_slabs_out,
-                                         double *loss_partial_out, void *stream) {
+                                         double *loss_partial_out, int64_t *opt_step_dev, void *stream) {
     TSM_REQUIRE(rows_supported(obs_dim, hidden, n_act),
                 "tsm_ppo_actor_rows_update supports hidden == 128, obs_dim <= 64, n_act <= 16 (got %d / %d / %d)", hidden,
                 obs_dim, n_act);
@@ -831,6 +834,7 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
     g.adv_norm = cfg->adv_norm; g.kind = cfg->loss_kind;
     g.slabs = grad_slabs_out; g.partial = loss_partial_out;
     g.stamps = g_tsm_stamps;
+    g.opt_step_dev = opt_step_dev;
     const RowsLay ly(obs_dim);
     const size_t shmem = (size_t)ly.total * sizeof(float);
     TSM_REQUIRE(shmem <= 160 * 1024, "tsm_ppo_actor_rows_update: LDS layout of %zu bytes does not fit", shmem);

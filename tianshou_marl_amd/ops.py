@@ -344,6 +344,41 @@ def adam_step(param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9,
     return param
 
 
+def _slab_segs(segs, n: int):
+    """[(slabs [n_slab, stride >= n_k] or [n_slab * stride], offset, n_k), ...] -> ctypes array of tsm_slab_seg.
+    A segment's slabs tensor may be wider than its parameter count (a view into joint slabs): stride = its row pitch."""
+    arr = (_abi.tsm_slab_seg * len(segs))()
+    for k, (sl, off, nk) in enumerate(segs):
+        sl = _chk(sl, torch.float32, "slabs")
+        if sl.dim() != 2 or sl.shape[1] < nk:
+            raise ValueError("slab segment: expected slabs [n_slab, >= n] for n = %d, got %s" % (nk, tuple(sl.shape)))
+        arr[k] = _abi.tsm_slab_seg(ptr(sl), int(off), int(nk), int(sl.shape[1]), int(sl.shape[0]), 0)
+    return arr
+
+
+def adam_step_segs(param, segs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                   max_grad_norm=None, work=None, step_dev=None, lr_dev=None):
+    """`adam_step` for a flat vector whose parts have their own slab arrays: segs = [(slabs, offset, n), ...] tiling
+    [0, param.numel()) in order.  One launch (+ one reduction launch when clipping; ONE norm over all segments)."""
+    n = param.numel()
+    if max_grad_norm and work is None:
+        work = torch.empty(call("tsm_adam_work_elems", n), dtype=torch.float32, device=param.device)
+    arr = _slab_segs(segs, n)
+    call("tsm_adam_step_segs", ptr(param), arr, len(segs), n, ptr(exp_avg), ptr(exp_avg_sq), int(step), ptr(step_dev),
+         float(lr), ptr(lr_dev), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+         float(max_grad_norm or 0.0), ptr(work), stream_ptr())
+    return param
+
+
+def reduce_slabs_segs(segs, n: int, out=None, scale: float = 1.0):
+    """Flat gradient [n] = scale * per-segment slab sums (see adam_step_segs); one launch."""
+    dev = segs[0][0].device
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+    call("tsm_reduce_slabs_segs", _slab_segs(segs, n), len(segs), n, float(scale), ptr(out), stream_ptr())
+    return out
+
+
 def reduce_slabs(grad_slabs, out=None, scale: float = 1.0):
     """Flat gradient = scale * sum of per-workgroup slabs [n_slab, n] (deterministic slab order)."""
     grad_slabs = _chk(grad_slabs, torch.float32, "grad_slabs")
@@ -473,9 +508,10 @@ def ppo_actor_rows_grid(M: int) -> int:
 
 
 def ppo_actor_rows_update(actor_params, obs, act, logp_old, adv, cfg: tsm_ppo_cfg, n_act: int, hidden: int = 128,
-                          adv_stats=None, perm=None, first_row=0, M=None, n_blocks=None, slabs=None, partial=None):
+                          adv_stats=None, perm=None, first_row=0, M=None, n_blocks=None, slabs=None, partial=None,
+                          opt_step_dev=None):
     """Actor half of one PPO gradient step in one launch -> (grad_slabs [n_blocks, P_actor], loss partials f64
-    [n_blocks, 4] = {sum clip objective, 0, sum entropy, 0})."""
+    [n_blocks, 4] = {sum clip objective, 0, sum entropy, 0}).  opt_step_dev (device i64[1]): advanced by one."""
     obs = _chk(obs, torch.float32, "obs")
     D = obs.shape[-1]
     if M is None:
@@ -499,7 +535,7 @@ def ppo_actor_rows_update(actor_params, obs, act, logp_old, adv, cfg: tsm_ppo_cf
     call("tsm_ppo_actor_rows_update", ptr(_chk(actor_params, torch.float32, "actor_params")), D, hidden, n_act, ptr(obs),
          ptr(_chk(act, torch.int32, "act")), ptr(_chk(logp_old, torch.float32, "logp_old")),
          ptr(_chk(adv, torch.float32, "adv")), ptr(perm), first_row, M, ptr(adv_stats), C.byref(cfg), n_blocks, ptr(slabs),
-         ptr(partial), stream_ptr())
+         ptr(partial), ptr(opt_step_dev), stream_ptr())
     return slabs, partial
 
 

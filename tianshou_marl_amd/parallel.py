@@ -31,7 +31,6 @@ class GradSync:
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self._checked: set = set()
         self.global_adv_stats = True  # minibatch advantage statistics over all ranks (merge_adv_stats_)
         self._stat_codec = None       # (pack, unpack) callables; None = the HIP kernels (ops.ppo_adv_stats_pack / _unpack)
         self._probe_device = torch.device("cpu")  # attach_data_parallel points it at the replica's device for RCCL
@@ -49,11 +48,12 @@ class GradSync:
 
     def require_equal(self, value: int, what: str) -> None:
         """Every rank must issue the same number of gradient all-reduces per update, or the job deadlocks: env shards of
-        different sizes can split into a different number of minibatches (Batch.split merge-last rule).  Checked once per
-        distinct value (one tiny all-reduce), before any capture."""
-        key = (what, int(value))
-        if key in self._checked:
-            return
+        different sizes can split into a different number of minibatches (Batch.split merge-last rule), and with
+        `n_episode` collection the number of valid rows differs per rank and per update.  One tiny all-reduce, EVERY call
+        (never cached: a rank that skipped this collective because of rank-local state while another rank issued it would
+        pair it with the other's gradient all-reduce).  Eager updates call it once per update; the captured update calls
+        it at capture time -- its step count is a function of the graph key, and the graph path is only taken for
+        host-known uniform fills (`n_step` collection), a choice every rank makes alike."""
         t = torch.tensor([int(value), -int(value)], dtype=torch.int64, device=self._probe_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         hi, lo = int(t[0].item()), -int(t[1].item())
@@ -62,7 +62,6 @@ class GradSync:
                 f"data-parallel ranks disagree on {what}: between {lo} and {hi} (this rank: {value}).  Give every rank the "
                 "same number of environments (and the same batch_size / repeat) so that all replicas take the same "
                 "number of gradient steps.")
-        self._checked.add(key)
 
     def check_same(self, names: list, what: str) -> None:
         """Every rank must train the same policy groups in a step (random matchmaking has to be seeded identically on
