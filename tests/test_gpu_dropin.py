@@ -179,21 +179,25 @@ def test_checkpoint_interchange_with_the_reference(golden_dir):
     np.testing.assert_array_equal(fresh.net.flat.data.cpu().numpy(), _flat(g, "mb64_", "after_"))
     assert fresh.opt_step == 6 and fresh.lr == pytest.approx(3e-4)
     np.testing.assert_allclose(fresh.exp_avg.cpu().numpy(), algo.exp_avg.cpu().numpy(), rtol=2e-4, atol=1e-7)
-    # own round trip restores everything needed to continue bit-identically (counters, statistics, moments)
-    # (eager launches on both sides: the captured update draws its device permutations from the optimizer step count,
-    # the eager one from the permutation counter)
-    clone = PPO(net=DiscreteActorCritic(18, 5, 64, device=DEV, seed=5), shuffle="device", dispatch="pooled", use_graph=False)
-    algo2, _, buf2 = _job(g, "mb64", use_graph=False)
-    algo2.shuffle = clone.shuffle
-    with policy_within_training_step(algo2):
-        algo2.update(buf2, 64, 1)
-    clone.load_state_dict(algo2.state_dict())
-    assert torch.equal(clone.net.flat.data, algo2.net.flat.data) and torch.equal(clone.exp_avg_sq, algo2.exp_avg_sq)
-    assert clone.opt_step == algo2.opt_step and int(clone._perm_ctr.item()) == int(algo2._perm_ctr.item()) > 0
-    for a in (algo2, clone):
-        with policy_within_training_step(a):
-            a.update(buf2, 64, 1)
-    assert torch.equal(clone.net.flat.data, algo2.net.flat.data)
+    # own round trip restores everything needed to continue bit-identically (counters, statistics, moments) -- in either
+    # launch mode: eager and captured updates number their device-side permutations alike (from the optimizer step count
+    # at the start of the update, PPO._device_perm), so a checkpoint of an eager run continues in a captured one and back
+    for mode_src, mode_dst in ((False, False), (False, True), (True, True), (True, False)):
+        src, _, buf2 = _job(g, "mb64", use_graph=mode_src)
+        src.shuffle = "device"
+        for _ in range(3 if mode_src else 1):  # (graph mode: eager warm-up, capture, replay)
+            with policy_within_training_step(src):
+                src.update(buf2, 64, 1)
+        clone = PPO(net=DiscreteActorCritic(18, 5, 64, device=DEV, seed=5), shuffle="device", dispatch="pooled",
+                    use_graph=mode_dst)
+        clone.load_state_dict(src.state_dict())
+        assert torch.equal(clone.net.flat.data, src.net.flat.data) and torch.equal(clone.exp_avg_sq, src.exp_avg_sq)
+        assert clone.opt_step == src.opt_step > 0
+        for _ in range(2):
+            for a in (src, clone):
+                with policy_within_training_step(a):
+                    a.update(buf2, 64, 1)
+            assert torch.equal(clone.net.flat.data, src.net.flat.data), (mode_src, mode_dst)
 
 
 def test_ctde_policy_state_dict_has_the_reference_keys(golden_dir):

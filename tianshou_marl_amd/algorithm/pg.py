@@ -108,8 +108,8 @@ class Reinforce(PPO):
         return dict(T=T, rows=rows, obs=buffer.obs_store[:T].reshape(T * L, D), act=buffer.act_store[:T].reshape(T * L),
                     v_s=zeros, ret=flat, adv=flat, logp_old=zeros, n_env=B, n_agent=N)
 
-    def _update_with_batch(self, pb, batch_size, repeat, agent=None, buffer=None):
-        st = super()._update_with_batch(pb, batch_size, repeat, agent=agent, buffer=buffer)
+    def _update_with_batch(self, pb, batch_size, repeat, agent=None, buffer=None, perm_base=None):
+        st = super()._update_with_batch(pb, batch_size, repeat, agent=agent, buffer=buffer, perm_base=perm_base)
         return LossSequenceTrainingStats(loss=st.loss, gradient_steps=st.gradient_steps)
 
     def learn(self, batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:

@@ -318,12 +318,26 @@ class PPO(nn.Module):
             unpack_fn(pack, stats)
 
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
-                           buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:
+                           buffer: DeviceVectorReplayBuffer | None = None, perm_base: int | None = None) -> A2CTrainingStats:
         """ppo.py:164-224 for one sample set (all lanes, or one agent's lanes under per-agent dispatch)."""
-        return drive_steps(self._update_steps(pb, batch_size, repeat, agent=agent, buffer=buffer), self._grad_sync)
+        return drive_steps(self._update_steps(pb, batch_size, repeat, agent=agent, buffer=buffer, perm_base=perm_base),
+                           self._grad_sync)
+
+    def _device_perm(self, n: int, perm_base: int | None, agent: int | None, repeat: int, step: int) -> torch.Tensor:
+        """The device-side permutation (shuffle="device") of repeat `step` for `agent`'s sample set.  Inside `update()`
+        (`perm_base` = the optimizer step count when the update began) it is draw number perm_base + agent * repeat + step
+        of the keyed generator -- exactly the draws the captured update makes in one launch (`_update_graph`), so eager and
+        captured updates shuffle alike and a checkpoint continues bit-identically in either mode.  `learn()` calls
+        (perm_base None) count their draws in `_perm_ctr`."""
+        if perm_base is not None:
+            return ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter=perm_base + (agent or 0) * repeat + step,
+                                           device=self.device)[0]
+        perm = ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, device=self.device)[0]
+        ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
+        return perm
 
     def _update_steps(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
-                      buffer: DeviceVectorReplayBuffer | None = None):
+                      buffer: DeviceVectorReplayBuffer | None = None, perm_base: int | None = None):
         """The minibatch loop as a generator: with data-parallel replicas it YIELDS the flat gradient of each gradient
         step (already scaled by 1 / world) at the point where it has to be summed over the ranks, and continues with the
         Adam step once the caller has reduced it in place.  `drive_steps` does that with one all-reduce per step;
@@ -353,8 +367,7 @@ class PPO(nn.Module):
             if self.shuffle == "numpy":  # Batch.split draws np.random.permutation (batch.py:1219)
                 perm_local = torch.as_tensor(np.random.permutation(n)).to(dev)
             else:
-                perm_local = ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, device=dev)[0]
-                ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
+                perm_local = self._device_perm(n, perm_base, agent, repeat, step)
             perm = perm_local if ids is None else ids[perm_local]
             stats = (ops.ppo_adv_stats(pb["adv"], mb_start, perm=perm, max_rows=max(e - s for s, e in bounds))
                      if self.advantage_normalization else None)
@@ -650,16 +663,19 @@ class PPO(nn.Module):
                 return out
         self.net.sync_image()
         pb = self._preprocess_batch(buffer)
+        # device-side shuffling: the draws are numbered from the optimizer step count at the start of the update, as in
+        # the captured update (`_device_perm`); ragged buffers list their rows explicitly and keep the same numbering
+        perm_base = self.opt_step
         if self.dispatch == "per_agent":
             # MARLDispatcher.dispatch_update_with_batch: the (shared) algorithm is updated once per agent id,
             # each time on that agent's rows only (marl.py:251-268); stats keyed "{agent}/..." (marl.py:51-59)
             per_agent = {}
             for a in range(buffer.n_agent):
-                st = self._update_with_batch(pb, batch_size, repeat, agent=a, buffer=buffer)
+                st = self._update_with_batch(pb, batch_size, repeat, agent=a, buffer=buffer, perm_base=perm_base)
                 st.train_time = time.time() - t0
                 per_agent[f"agent_{a}"] = st
             return MapTrainingStats(per_agent)
-        return self._update_with_batch(pb, batch_size, repeat, agent=None, buffer=buffer)
+        return self._update_with_batch(pb, batch_size, repeat, agent=None, buffer=buffer, perm_base=perm_base)
 
     # ---- `.learn(batch)` for the MARL trainers (training_coordinator.py:336) ----------------------
     def learn_steps(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs):

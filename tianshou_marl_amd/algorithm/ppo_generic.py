@@ -420,7 +420,7 @@ class GenericPPO(PPO):
         return super()._update(buffer, batch_size, repeat, t0)
 
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
-                           buffer: DeviceVectorReplayBuffer | None = None) -> A2CTrainingStats:
+                           buffer: DeviceVectorReplayBuffer | None = None, perm_base: int | None = None) -> A2CTrainingStats:
         dev = self.device
         N = pb["n_agent"]
         row_mode = agent is None and self.row_minibatches and pb.get("joint") is not None and N > 1
@@ -452,8 +452,7 @@ class GenericPPO(PPO):
             if self.shuffle == "numpy":
                 perm_local = torch.as_tensor(np.random.permutation(n)).to(dev)
             else:
-                perm_local = ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, device=dev)[0]
-                ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
+                perm_local = self._device_perm(n, perm_base, agent, repeat, step)
             perm = ids[perm_local]
             lanes = (perm.view(-1, 1) * N + lane_of_row).reshape(-1) if row_mode else perm
             stats = (ops.ppo_adv_stats(pb["adv"], mb_start, perm=lanes, max_rows=max(e - s for s, e in bounds) * unit)
