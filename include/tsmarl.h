@@ -544,6 +544,20 @@ int tsm_ppo_critic_rows_update(const float *critic_params, int32_t in_dim, int32
                                int64_t first_row, int64_t Mr, const tsm_ppo_cfg *cfg, int32_t n_blocks,
                                float *grad_slabs_out, double *loss_partial_out, void *stream);
 
+/* V(row) of the same critic for MANY rows in one launch, activations never leaving the CU  [a7, a11]
+ * Replaces  the critic passes of the on-policy preprocessing, `critic(batch.obs)` / `critic(batch.obs_next)`
+ *           (tianshou/algorithm/modelfree/a2c.py:121-127, chunked by max_batchsize there), three GEMM launches here before.
+ * critic_params as for tsm_ppo_critic_rows_update (H == 128, in_dim <= 384); row i is rows[i] (NULL: first_row + i) of
+ * obs_rows [n][in_dim]; values_out [Mr].  run_if (nullable, device i32[1]): the launch is a no-op when it holds 0 (a pass a
+ * captured graph carries for the rows that need it, tsm_value_next_select).  The first layer sums k in a fixed permuted
+ * order (csrc/critic_rows.hip): values agree with tsm_mlp_forward to f32 rounding, not bit for bit.
+ * tsm_critic_rows_init: one-time function attributes of the instantiation serving in_dim -- call outside stream capture. */
+int tsm_critic_rows_forward_supported(int32_t in_dim, int32_t hidden);
+int tsm_critic_rows_init(int32_t in_dim, int32_t hidden);
+int tsm_critic_rows_forward(const float *critic_params, int32_t in_dim, int32_t hidden, const float *obs_rows,
+                            const int64_t *rows, int64_t first_row, int64_t Mr, const int32_t *run_if,
+                            float *values_out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * CTDE global state  [a16]
  * Replaces  GlobalStateConstructor.build("concatenate" | "mean")

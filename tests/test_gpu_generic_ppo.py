@@ -467,3 +467,52 @@ def test_graph_captured_over_chained_rows_is_not_replayed_on_unchained_rows():
         finals.append((net.flat.data.clone(), outs))
     assert torch.equal(finals[0][0], finals[1][0])
     assert finals[0][1] == finals[1][1]
+
+
+@pytest.mark.parametrize("K1,Mr,perm", [(384, 4099, False), (384, 70000, True), (48, 1000, True), (18, 300, False), (20, 31, True),
+                                        (6, 1, False), (200, 257, True)])
+def test_critic_rows_forward_matches_float64(K1, Mr, perm):
+    """csrc/critic_rows.hip: V(row) of an in-128-128-1 critic for many rows in one launch (layer-1 weights in registers,
+    observation tile swizzled in LDS, layer 3 folded into layer 2's epilogue) vs the same MLP in float64 (a2c.py:121-127),
+    1e-5 of the value scale; the dense GEMM chain it replaces agrees to f32 rounding; `run_if` = 0 leaves the output alone;
+    misaligned parameter storage (the critic half of a joint flat vector starts at an odd offset) gives the same bits."""
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.utils.net import FlatMLP
+
+    rng = np.random.default_rng(K1 + Mr)
+    f = FlatMLP([K1, 128, 128, 1], device=DEV, seed=4)
+    with torch.no_grad():
+        for i in range(3):
+            f.bias(i).copy_(torch.randn(f.bias(i).shape) * 0.1)
+    n_rows = Mr + 5
+    obs = torch.from_numpy(rng.standard_normal((n_rows, K1)).astype(np.float32)).to(DEV)
+    rows = torch.from_numpy(rng.permutation(n_rows)[:Mr]).to(DEV) if perm else None
+    v = ops.critic_rows_forward(f.flat.data, obs, 128, rows=rows, first_row=0 if perm else 3, Mr=Mr)
+    x = (obs[rows] if perm else obs[3:3 + Mr]).double().cpu()
+    W = [f.weight(i).double().cpu() for i in range(3)]
+    b = [f.bias(i).double().cpu() for i in range(3)]
+    ref = (torch.relu(torch.relu(x @ W[0].T + b[0]) @ W[1].T + b[1]) @ W[2].T + b[2]).reshape(-1)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(v.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * scale)
+    dense = FlatMLP.forward(f, obs[rows] if perm else obs[3:3 + Mr].contiguous(), save=False).reshape(-1)
+    np.testing.assert_allclose(v.cpu().numpy(), dense.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
+    # deterministic, and independent of how the rows fall into tiles / workgroups
+    assert torch.equal(v, ops.critic_rows_forward(f.flat.data, obs, 128, rows=rows, first_row=0 if perm else 3, Mr=Mr))
+    if Mr > 40:
+        part = ops.critic_rows_forward(f.flat.data, obs, 128, rows=None if rows is None else rows[7:].contiguous(),
+                                       first_row=0 if perm else 10, Mr=Mr - 7)
+        assert torch.equal(part, v[7:])
+    # a pass a captured graph carries for the rows that need it: flag 0 = no-op
+    out = torch.full((Mr,), -7.0, device=DEV)
+    ops.critic_rows_forward(f.flat.data, obs, 128, rows=rows, first_row=0 if perm else 3, Mr=Mr,
+                            run_if=torch.zeros(1, dtype=torch.int32, device=DEV), out=out)
+    assert bool((out == -7.0).all())
+    ops.critic_rows_forward(f.flat.data, obs, 128, rows=rows, first_row=0 if perm else 3, Mr=Mr,
+                            run_if=torch.ones(1, dtype=torch.int32, device=DEV), out=out)
+    assert torch.equal(out, v)
+    # parameters at a 4-byte (not 16-byte) aligned address
+    pad = torch.zeros(f.flat.numel() + 1, device=DEV)
+    pad[1:].copy_(f.flat.data)
+    assert torch.equal(ops.critic_rows_forward(pad[1:], obs, 128, rows=rows, first_row=0 if perm else 3, Mr=Mr), v)
+    with pytest.raises(ValueError):
+        ops.critic_rows_forward(f.flat.data[:-1], obs, 128)

@@ -73,6 +73,12 @@ class GenericPPO(PPO):
         self.fused_critic = self.fused_actor and ops.ppo_critic_rows_supported(
             net.critic_obs_dim, net.critic.dims[1:-1], self.n_agent if critic_input == "global" else 1, net.critic.act) \
             and net.critic.dims[-1] == 1
+        # ... and V(row) of such a critic for all rows of a pass in one launch (csrc/critic_rows.hip) instead of three GEMMs
+        self.fused_values = bool(fused_actor) and ops.critic_rows_forward_supported(
+            net.critic_obs_dim, net.critic.dims[1:-1], net.critic.dims[-1], net.critic.act)
+        if self.fused_values:
+            ops.call("tsm_critic_rows_init", net.critic_obs_dim, net.critic.dims[1])  # (function attributes: before any capture)
+            ops._critic_rows_ready.add((net.critic_obs_dim, net.critic.dims[1]))
         self.reuse_rollout_outputs = bool(reuse_rollout_outputs)
         # V(obs_next) of chained rows from V(obs) of the next slot instead of a second full critic pass (_next_values_chained)
         self.shift_next_values = bool(shift_next_values)
@@ -88,9 +94,20 @@ class GenericPPO(PPO):
         per-lane form.  `batch_size` still counts samples (lanes) and must be a multiple of N."""
         return self.critic_input == "global" and self.dispatch == "pooled"
 
+    def _critic_values(self, x: torch.Tensor, run_if: torch.Tensor | None = None) -> torch.Tensor:
+        """critic(x) for rows x [n, critic_obs_dim] -> [n].  One launch with activations on-chip for 128-wide critics
+        (`fused_values`), else the dense GEMM chain.  run_if (device flag): the pass runs only if it is non-zero (the result
+        is garbage otherwise).  Every value this class compares with another one comes from this one function."""
+        critic = self.net.critic
+        if self.fused_values:
+            return ops.critic_rows_forward(critic.flat.data, x, critic.dims[1], run_if=run_if)
+        if run_if is not None:
+            return ops.mlp_forward_cond(critic.desc, critic.flat.data, x, run_if)[0].reshape(-1)
+        return FlatMLP.forward(critic, x, save=False).reshape(-1)
+
     def _unit_values(self, obs_rows: torch.Tensor, joint: torch.Tensor | None) -> torch.Tensor:
         """V per critic UNIT: a lane row (local critic) or a joint row of the env step (centralized critic)."""
-        return FlatMLP.forward(self.net.critic, obs_rows if self.critic_input == "local" else joint, save=False).reshape(-1)
+        return self._critic_values(obs_rows if self.critic_input == "local" else joint)
 
     def _lanes(self, v_units: torch.Tensor) -> torch.Tensor:
         """Unit values -> one value per lane row (the joint row's value repeated for its agents)."""
@@ -109,11 +126,10 @@ class GenericPPO(PPO):
         early: then (device flag, no host round trip) the full pass runs after all.  Bit-identical to the full pass
         either way; saves half of the preprocess' critic work in the aligned case (collect length == episode length)."""
         U = vu_s.numel() // T
-        critic = self.net.critic
         flag = ops.any_nonzero_u8(done[:T - 1].reshape(-1)) if T > 1 else torch.zeros(1, dtype=torch.int32, device=vu_s.device)
-        v_full, _ = ops.mlp_forward_cond(critic.desc, critic.flat.data, x_next, flag)
-        v_last = FlatMLP.forward(critic, x_next[(T - 1) * U:], save=False)
-        return ops.value_next_select(vu_s, v_last.reshape(-1), v_full.reshape(-1), flag, T, U).reshape(-1)
+        v_full = self._critic_values(x_next, run_if=flag)
+        v_last = self._critic_values(x_next[(T - 1) * U:])
+        return ops.value_next_select(vu_s, v_last, v_full, flag, T, U).reshape(-1)
 
     # ---- rollout side -----------------------------------------------------------------------------------------------
     def act_device(self, obs: torch.Tensor, out: dict | None = None, offset_dev: torch.Tensor | None = None,
@@ -480,12 +496,10 @@ class GenericPPO(PPO):
             if "global_obs" not in batch:
                 raise ValueError("GenericPPO(critic_input='global').learn needs batch.global_obs / global_obs_next")
             joint, joint_next = t(batch.global_obs, torch.float32), t(batch.global_obs_next, torch.float32)
-            v_s = FlatMLP.forward(self.net.critic, joint, save=False).reshape(n)
-            v_next = FlatMLP.forward(self.net.critic, joint_next, save=False).reshape(n)
+            v_s, v_next = self._critic_values(joint), self._critic_values(joint_next)
         else:
             joint = None
-            v_s = FlatMLP.forward(self.net.critic, obs, save=False).reshape(n)
-            v_next = FlatMLP.forward(self.net.critic, obs_next, save=False).reshape(n)
+            v_s, v_next = self._critic_values(obs), self._critic_values(obs_next)
         logp_old, _ = ops.categorical_logp_entropy(FlatMLP.forward(self.net.actor, obs, save=False), act)
         term = t(batch.terminated, torch.uint8).reshape(n, 1)
         trunc = t(batch.truncated, torch.uint8).reshape(n, 1) if "truncated" in batch else torch.zeros_like(term)

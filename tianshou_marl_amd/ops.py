@@ -581,6 +581,45 @@ def ppo_critic_rows_update(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n
     return slabs, partial
 
 
+def critic_rows_forward_supported(in_dim: int, hidden_sizes, n_out: int = 1, act: str = "relu") -> bool:
+    """Does the one-launch critic forward (csrc/critic_rows.hip) cover this critic?  in -> 128 -> 128 -> 1, ReLU."""
+    hs = list(hidden_sizes)
+    return (act == "relu" and n_out == 1 and len(hs) == 2 and hs[0] == hs[1]
+            and bool(call("tsm_critic_rows_forward_supported", in_dim, hs[0])))
+
+
+_critic_rows_ready: set = set()
+
+
+def critic_rows_forward(critic_params, obs_rows, hidden: int = 128, rows=None, first_row: int = 0, Mr=None, run_if=None,
+                        out=None):
+    """V(row) for Mr rows of obs_rows [n, in_dim] (row ids `rows`, or first_row + i) in ONE launch -> values [Mr].
+    run_if (device i32[1]): the launch is a no-op (and `out` is left as it is) when it holds 0."""
+    obs_rows = _chk(obs_rows, torch.float32, "obs_rows")
+    K1 = obs_rows.shape[-1]
+    if Mr is None:
+        Mr = rows.numel() if rows is not None else obs_rows.shape[0] - first_row
+    if rows is not None and rows.numel() < Mr:
+        raise ValueError(f"critic_rows_forward: rows holds {rows.numel()} ids, Mr = {Mr}")
+    if rows is None and first_row + Mr > obs_rows.shape[0]:
+        raise ValueError(f"critic_rows_forward: rows [{first_row}, {first_row + Mr}) exceed the {obs_rows.shape[0]} given")
+    if critic_params.numel() != call("tsm_ppo_critic_rows_param_count", K1, hidden):
+        raise ValueError(f"critic_rows_forward: {critic_params.numel()} parameters do not match {K1} -> {hidden} -> {hidden} -> 1")
+    if (K1, hidden) not in _critic_rows_ready:  # one-time function attributes, outside any capture
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("critic_rows_forward: first use inside a stream capture; call it (or ops.call('tsm_critic_rows_init')) once before")
+        call("tsm_critic_rows_init", K1, hidden)
+        _critic_rows_ready.add((K1, hidden))
+    if out is None:
+        out = torch.empty(Mr, dtype=torch.float32, device=obs_rows.device)
+    elif out.numel() < Mr:
+        raise ValueError("critic_rows_forward: out is too small")
+    call("tsm_critic_rows_forward", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, ptr(obs_rows),
+         ptr(None if rows is None else _chk(rows, torch.int64, "rows")), first_row, Mr,
+         ptr(None if run_if is None else _chk(run_if, torch.int32, "run_if")), ptr(out), stream_ptr())
+    return out
+
+
 def ppo_value_loss(value, returns, cfg: tsm_ppo_cfg, M: int, v_s_old=None, perm=None, first_row=0, partial=None):
     """Value term of the PPO loss alone (loss_kind = 2) for M samples whose values are `value` (one per sample, or one
     per joint row with cfg.value_group = N) -> (dvalue [len(value)], loss partials f64 [blocks, 4] = {0, sum vf, 0, 0})."""
