@@ -15,6 +15,7 @@ Each fixture holds inputs + the reference's outputs for one hot-path function
                    weights, last gradients)                             [(f)4]
   ppo_update.npz   PPO._preprocess_batch + PPO._update_with_batch (loss scalars, gradients,
                    Adam-updated weights, minibatch permutation)         [a7, a11, a13, a14, a15]
+  ppo_update_wide.npz  the same for Net(hidden_sizes=[128, 128]) on 48-wide observations  [a7, a14 at configs[2]'s widths]
   marl_dispatch.npz MultiAgentPolicy.forward scatter + MARLDispatcher per-agent GAE (incl. quirk Q1),
                    FlexibleMultiAgentPolicyManager shared forward       [a5, a6, a10]
   ctde.npz         GlobalStateConstructor.build + CTDEPolicy.learn      [a16]
@@ -211,21 +212,13 @@ def net_grads(actor, critic):
     return d
 
 
-def make_ppo_update() -> None:
+def _ppo_update_variants(variants, n_env, T, obs_dim, n_act, hidden) -> dict:
+    """Run the reference's `_preprocess_batch` + `_update_with_batch` for every variant; inputs and outputs by key."""
     out = {}
-    variants = [
-        dict(name="default", ppo={}, batch_size=None, repeat=1),
-        dict(name="mb64", ppo={}, batch_size=64, repeat=2),
-        dict(name="dualclip_vclip", ppo=dict(dual_clip=2.0, value_clip=True, max_grad_norm=0.5),
-             batch_size=100, repeat=1),
-        dict(name="noadvnorm_retscale", ppo=dict(advantage_normalization=False, return_scaling=True),
-             batch_size=None, repeat=1),
-    ]
-    n_env, T, obs_dim, n_act = 8, 25, 18, 5
     for v in variants:
         rng = np.random.default_rng(7)
         p = v["name"] + "_"
-        algo, actor, critic = build_ppo(obs_dim, n_act, [64, 64], seed=3, **v["ppo"])
+        algo, actor, critic = build_ppo(obs_dim, n_act, hidden, seed=3, **v["ppo"])
         buf = fill_vector_buffer(rng, n_env, T, obs_dim, p_term=0.03, trunc_at=25, n_act=n_act)
         batch, indices = buf.sample(0)
         out.update({p + k: val for k, val in net_params(actor, critic).items()})
@@ -271,7 +264,32 @@ def make_ppo_update() -> None:
                                        float(algo.advantage_normalization), algo.vf_coef, algo.ent_coef,
                                        algo.gamma, algo.gae_lambda,
                                        v["ppo"].get("max_grad_norm") or 0.0, 3e-4], np.float64)
+    return out
+
+
+def make_ppo_update() -> None:
+    variants = [
+        dict(name="default", ppo={}, batch_size=None, repeat=1),
+        dict(name="mb64", ppo={}, batch_size=64, repeat=2),
+        dict(name="dualclip_vclip", ppo=dict(dual_clip=2.0, value_clip=True, max_grad_norm=0.5),
+             batch_size=100, repeat=1),
+        dict(name="noadvnorm_retscale", ppo=dict(advantage_normalization=False, return_scaling=True),
+             batch_size=None, repeat=1),
+    ]
+    out = _ppo_update_variants(variants, n_env=8, T=25, obs_dim=18, n_act=5, hidden=[64, 64])
     save("ppo_update.npz", variants=np.array([v["name"] for v in variants]), **out)
+
+
+def make_ppo_update_wide() -> None:
+    """The same runs for `Net(hidden_sizes=[128, 128])` on 48-wide observations (the actor / local-critic shape of BASELINE
+    configs[2]): pins the 128-wide kernels (csrc/ppo_rows.hip, csrc/critic_rows.hip) to the reference's own tensors."""
+    variants = [
+        dict(name="w128_mb64", ppo={}, batch_size=64, repeat=2),
+        dict(name="w128_vclip_gn", ppo=dict(value_clip=True, max_grad_norm=0.5), batch_size=64, repeat=2),
+        dict(name="w128_dualclip_full", ppo=dict(dual_clip=2.0, value_clip=True), batch_size=None, repeat=1),
+    ]
+    out = _ppo_update_variants(variants, n_env=8, T=25, obs_dim=48, n_act=5, hidden=[128, 128])
+    save("ppo_update_wide.npz", variants=np.array([v["name"] for v in variants]), **out)
 
 
 def make_pg_update() -> None:
@@ -518,6 +536,6 @@ def make_misc() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "pg_update", "marl_dispatch", "ctde", "misc"]
+    which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "ppo_update_wide", "pg_update", "marl_dispatch", "ctde", "misc"]
     for w in which:
         globals()["make_" + w]()
