@@ -547,16 +547,36 @@ int tsm_ppo_critic_rows_update(const float *critic_params, int32_t in_dim, int32
 /* V(row) of the same critic for MANY rows in one launch, activations never leaving the CU  [a7, a11]
  * Replaces  the critic passes of the on-policy preprocessing, `critic(batch.obs)` / `critic(batch.obs_next)`
  *           (tianshou/algorithm/modelfree/a2c.py:121-127, chunked by max_batchsize there), three GEMM launches here before.
- * critic_params as for tsm_ppo_critic_rows_update (H == 128, in_dim <= 384); row i is rows[i] (NULL: first_row + i) of
- * obs_rows [n][in_dim]; values_out [Mr].  run_if (nullable, device i32[1]): the launch is a no-op when it holds 0 (a pass a
+ * critic_params: w0[H][in_dim] b0[H] w1[H][H] b1[H] w2[n_out][H] b2[n_out] (H == 128, in_dim <= 384, n_out <= 16); the value
+ * of a row is the MEAN of its n_out outputs (CentralizedCritic: one output per agent, averaged by CTDEPolicy.learn,
+ * ctde.py:154-157; n_out = 1: the PPO critic).  Row i is rows[i] (NULL: first_row + i) of obs_rows [n][in_dim]; values_out [Mr].  run_if (nullable, device i32[1]): the launch is a no-op when it holds 0 (a pass a
  * captured graph carries for the rows that need it, tsm_value_next_select).  The first layer sums k in a fixed permuted
  * order (csrc/critic_rows.hip): values agree with tsm_mlp_forward to f32 rounding, not bit for bit.
  * tsm_critic_rows_init: one-time function attributes of the instantiation serving in_dim -- call outside stream capture. */
 int tsm_critic_rows_forward_supported(int32_t in_dim, int32_t hidden);
 int tsm_critic_rows_init(int32_t in_dim, int32_t hidden);
-int tsm_critic_rows_forward(const float *critic_params, int32_t in_dim, int32_t hidden, const float *obs_rows,
-                            const int64_t *rows, int64_t first_row, int64_t Mr, const int32_t *run_if,
-                            float *values_out, void *stream);
+int tsm_critic_rows_forward(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_out,
+                            const float *obs_rows, const int64_t *rows, int64_t first_row, int64_t Mr,
+                            const int32_t *run_if, float *values_out, void *stream);
+
+/* CTDEPolicy.learn, the critic half in one launch  [a16 at BASELINE configs[2]]
+ * Replaces  values = critic(global_obs).mean(1); values_next = critic(global_obs_next).mean(1);
+ *           td_target = rew + discount_factor * values_next * (~terminated); critic_loss = mse_loss(values, td_target);
+ *           critic_loss.backward()                       (tianshou/algorithm/multiagent/ctde.py:149-172, 188-190)
+ * for rows that are CHAINED: the batch is the env-major view [E][T] of a time-major store joint_rows [T][E][in_dim]
+ * (store row t * E + e), and obs_next of (e, t) is obs of (e, t + 1) for t < T - 1 -- its value is the next row's, out of
+ * the same forward pass (a tile owns 31 rows and computes the 32nd as a halo).  v_last [E] = values of obs_next of the last
+ * slot (tsm_critic_rows_forward on those E rows).  rew / terminated of store row r: rew[r * scalar_stride + scalar_offset]
+ * (one agent's column of [T][E][N] arrays).  critic_params: w0[H][in_dim] b0 w1[H][H] b1 w2[n_out][H] b2[n_out], H == 128.
+ * grad_slabs_out [n_blocks][param_count] (d critic_loss / d params, summed over slabs); loss_partial_out f64 [n_blocks][4] =
+ * {sum (td_target - values), sum (values - td_target)^2, 0, 0}: mean advantage and critic_loss after division by T * E. */
+int64_t tsm_ctde_critic_rows_param_count(int32_t in_dim, int32_t hidden, int32_t n_out);
+int tsm_ctde_critic_rows_grid(int64_t B);
+int tsm_ctde_critic_rows_update(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_out,
+                                const float *joint_rows, int64_t T, int64_t E, const float *rew,
+                                const uint8_t *terminated, int64_t scalar_stride, int64_t scalar_offset,
+                                const float *v_last, double gamma, int32_t n_blocks, float *grad_slabs_out,
+                                double *loss_partial_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CTDE global state  [a16]

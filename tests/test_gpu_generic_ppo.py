@@ -516,3 +516,51 @@ def test_critic_rows_forward_matches_float64(K1, Mr, perm):
     assert torch.equal(ops.critic_rows_forward(pad[1:], obs, 128, rows=rows, first_row=0 if perm else 3, Mr=Mr), v)
     with pytest.raises(ValueError):
         ops.critic_rows_forward(f.flat.data[:-1], obs, 128)
+
+
+@pytest.mark.parametrize("K1,n_out,T,E,N", [(384, 8, 25, 40, 8), (48, 3, 7, 9, 3), (18, 1, 5, 13, 1), (384, 8, 1, 70, 8), (20, 2, 33, 3, 2)])
+def test_ctde_critic_rows_kernel_matches_float64_autograd(K1, n_out, T, E, N):
+    """csrc/critic_train.hip, LOSS 1: the critic half of CTDEPolicy.learn (ctde.py:149-172) on chained rows in one launch --
+    values = critic(global_obs).mean(1), the TD target from the NEXT row's value (same forward pass, halo row per tile;
+    v_last for the last slot), MSE, backward -- vs float64 autograd of the same arithmetic."""
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.utils.net import FlatMLP
+
+    rng = np.random.default_rng(K1 + T + E)
+    f = FlatMLP([K1, 128, 128, n_out], device=DEV, seed=4)
+    with torch.no_grad():
+        for i in range(3):
+            f.bias(i).copy_(torch.randn(f.bias(i).shape) * 0.1)
+    joint = rng.standard_normal((T, E, K1)).astype(np.float32)
+    rew = rng.standard_normal((T, E, N)).astype(np.float32)
+    term = (rng.random((T, E, N)) < 0.1)
+    v_last = rng.standard_normal(E).astype(np.float32)
+    a, gamma = N - 1, 0.97
+    d = lambda x, dt=None: torch.from_numpy(np.ascontiguousarray(x)).to(DEV, dt)  # noqa: E731
+    slabs, partial = ops.ctde_critic_rows_update(f.flat.data, d(joint), T, E, d(rew), d(term.astype(np.uint8)), a, N, d(v_last),
+                                                 gamma, n_out)
+    lins = []
+    for i in range(3):
+        lin = torch.nn.Linear(f.dims[i], f.dims[i + 1]).double()
+        with torch.no_grad():
+            lin.weight.copy_(f.weight(i).cpu().double())
+            lin.bias.copy_(f.bias(i).cpu().double())
+        lins.append(lin)
+    x = torch.as_tensor(joint).double().transpose(0, 1).reshape(E * T, K1)       # env-major rows (e, t)
+    v = lins[2](torch.relu(lins[1](torch.relu(lins[0](x))))).mean(1).view(E, T)
+    vn = torch.cat([v[:, 1:], torch.as_tensor(v_last).double().view(E, 1)], dim=1).detach()
+    r_t = torch.as_tensor(rew[:, :, a]).double().t()
+    nt = 1.0 - torch.as_tensor(term[:, :, a].astype(np.float64)).t()
+    td = r_t + gamma * vn * nt
+    loss = ((v - td) ** 2).mean()
+    loss.backward()
+    g_ref = torch.cat([t.grad.flatten() for lin in lins for t in (lin.weight, lin.bias)]).numpy()
+    g = slabs.double().sum(0).cpu().numpy()
+    assert np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref) < 2e-5
+    np.testing.assert_allclose(g, g_ref, rtol=1e-3, atol=2e-4 * np.abs(g_ref).max())
+    p = partial.view(-1, 4).sum(0).cpu().numpy()
+    np.testing.assert_allclose(p[0], float((td - v).sum()), rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(p[1], float(((v - td) ** 2).sum()), rtol=2e-5)
+    slabs2, _ = ops.ctde_critic_rows_update(f.flat.data, d(joint), T, E, d(rew), d(term.astype(np.uint8)), a, N, d(v_last),
+                                            gamma, n_out)
+    assert torch.equal(slabs, slabs2)

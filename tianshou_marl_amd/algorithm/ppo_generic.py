@@ -74,8 +74,8 @@ class GenericPPO(PPO):
             net.critic_obs_dim, net.critic.dims[1:-1], self.n_agent if critic_input == "global" else 1, net.critic.act) \
             and net.critic.dims[-1] == 1
         # ... and V(row) of such a critic for all rows of a pass in one launch (csrc/critic_rows.hip) instead of three GEMMs
-        self.fused_values = bool(fused_actor) and ops.critic_rows_forward_supported(
-            net.critic_obs_dim, net.critic.dims[1:-1], net.critic.dims[-1], net.critic.act)
+        self.fused_values = bool(fused_actor) and net.critic.dims[-1] == 1 and ops.critic_rows_forward_supported(
+            net.critic_obs_dim, net.critic.dims[1:-1], 1, net.critic.act)
         if self.fused_values:
             ops.call("tsm_critic_rows_init", net.critic_obs_dim, net.critic.dims[1])  # (function attributes: before any capture)
             ops._critic_rows_ready.add((net.critic_obs_dim, net.critic.dims[1]))

@@ -23,18 +23,9 @@
 //     lane multiplies its relu(h2) by w3[col], 16-lane DPP row sums, then the 8 waves' partial sums in wave order.
 //     Two barriers per tile.
 // Algorithmic HBM traffic: 4 K1 B read + 4 B written per row.
-#include "common.h"
+#include "critic_rows_dev.h"
 
 namespace {
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-constexpr int kH = 128;        // hidden width
-constexpr int kRows = 32;      // rows per tile (two 16-row MFMA tiles)
-constexpr int kThreads = 512;  // 8 waves
-constexpr int kLdh = kH + 2;   // 130 = 2 x odd: conflict-free [lane & 15][lane >> 4] operand reads
-
-__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 struct FwdLay {  // LDS layout in floats
     int ldx, W2, X, H1, B1, B2, W3, RED, RID, total;
@@ -51,10 +42,15 @@ struct FwdLay {  // LDS layout in floats
         RID = o; o += 2 * kRows;  // row ids of the tile being fetched (int64)
         total = o;
     }
+    __device__ void launder() {   // (critic_rows_dev.h: opaque_s)
+        W2 = opaque_s(W2); X = opaque_s(X); H1 = opaque_s(H1); B1 = opaque_s(B1); B2 = opaque_s(B2); W3 = opaque_s(W3);
+        RED = opaque_s(RED); RID = opaque_s(RID);
+    }
 };
 
 struct FwdArgs {
-    const float *P;        // critic parameters: w0[H][K1] b0[H] w1[H][H] b1[H] w2[1][H] b2[1]
+    const float *P;        // critic parameters: w0[H][K1] b0[H] w1[H][H] b1[H] w2[n_out][H] b2[n_out]
+    int n_out;             // outputs; the value of a row is their mean (CTDEPolicy.learn, ctde.py:154-157), n_out = 1: itself
     const float *obs;      // rows [n][K1]
     const int64_t *rows;   // row ids (nullable: first_row + i)
     int64_t first_row, Mr;
@@ -63,64 +59,40 @@ struct FwdArgs {
     const int32_t *run_if; // nullable device flag: 0 -> the launch is a no-op
 };
 
-// swizzled position (in floats) of 16-B chunk c of tile row r
-__device__ __forceinline__ int xs_off(int r, int c, int ldx) { return r * ldx + (((c & ~15) | ((c & 15) ^ (r & 15))) << 2); }
-
 // VEC: K1 % 4 == 0 (rows and W1 rows are whole 16-B chunks).  All loads go to clamped, always-valid addresses and
 // are zeroed by a select afterwards: no divergent branches, every load of a batch in flight at once.
 template <int KJ, bool VEC>
 __global__ __launch_bounds__(kThreads) void critic_rows_forward_kernel(FwdArgs g) {
     if (g.run_if && *g.run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const FwdLay ly(KJ);
+    FwdLay ly(KJ);
+    constexpr int ldx = ((16 * KJ + 63) / 64) * 64;
+    ly.launder();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
-    const int K1 = g.K1, ldx = ly.ldx;
+    const int K1 = g.K1;
     const int64_t n_tiles = (g.Mr + kRows - 1) / kRows;
-    const int oB1 = kH * K1, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + kH;
+    const int oB1 = kH * K1, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + g.n_out * kH;
     const int col = 16 * w + c16;
 
     // ---- this wave's fragment of W1, once, into registers ----
     f4 w1f[KJ];
-    {
-        const float *src = g.P + (size_t)col * K1;
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {
-            const int k = 16 * j + 4 * kq;
-            if constexpr (VEC) {
-                const int kc = k < K1 ? k : K1 - 4;
-                const float4 q = *reinterpret_cast<const float4 *>(src + kc);
-                w1f[j] = k < K1 ? f4{q.x, q.y, q.z, q.w} : f4{0.f, 0.f, 0.f, 0.f};
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = src[k + i < K1 ? k + i : K1 - 1];
-                    w1f[j][i] = k + i < K1 ? v : 0.f;
-                }
-            }
-        }
-    }
+    for (int j = 0; j < KJ; ++j) w1f[j] = load_w1_frag<VEC>(g.P + (size_t)col * K1, 16 * j + 4 * kq, K1);
     // ---- W2, biases, w3 into LDS; X pads zeroed (staging only ever rewrites the real chunks) ----
-    {   // W2 [128][128] -> rows of kLdh floats: 8 16-B loads per thread, all in flight (global memory takes them at any
-        // 4-B alignment), 8-B LDS stores (kLdh is even)
-        float4 q[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) q[u] = reinterpret_cast<const float4 *>(g.P + oW2)[tid + u * kThreads];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e4 = tid + u * kThreads, r = e4 >> 5, c = (e4 & 31) * 4;
-            float *p = lds + ly.W2 + r * kLdh + c;
-            *reinterpret_cast<float2 *>(p) = make_float2(q[u].x, q[u].y);
-            *reinterpret_cast<float2 *>(p + 2) = make_float2(q[u].z, q[u].w);
-        }
-    }
-    for (int e = tid; e < kH * 2; e += kThreads) lds[ly.W2 + (e >> 1) * kLdh + kH + (e & 1)] = 0.f;
+    stage_w2_rows(lds + ly.W2, g.P + oW2);
+    // the mean over the outputs of a linear layer is a linear layer with the mean weights: w3[col] = mean_j W3[j][col]
+    const int n_out = g.n_out;
     if (tid < kH) {
         lds[ly.B1 + tid] = g.P[oB1 + tid];
         lds[ly.B2 + tid] = g.P[oB2 + tid];
-        lds[ly.W3 + tid] = g.P[oW3 + tid];
+        float s3 = 0.f;
+        for (int j = 0; j < n_out; ++j) s3 += g.P[oW3 + j * kH + tid];
+        lds[ly.W3 + tid] = n_out == 1 ? s3 : s3 / (float)n_out;
     }
     for (int e = tid; e < kRows * ldx; e += kThreads) lds[ly.X + e] = 0.f;
-    const float b3 = g.P[oB3];
+    float b3 = 0.f;
+    for (int j = 0; j < n_out; ++j) b3 += g.P[oB3 + j];
+    if (n_out > 1) b3 /= (float)n_out;
 
     // ---- staging of a tile: thread -> chunks q = tid + 512 u of the 32 x (4 KJ) chunk grid ----
     constexpr int CPR = 4 * KJ;                                       // chunks per (padded) row
@@ -183,12 +155,12 @@ __global__ __launch_bounds__(kThreads) void critic_rows_forward_kernel(FwdArgs g
         // ---- L1: H1 = relu(X W1^T + b1); W1 from registers, X by ds_read_b128 ----
         {
             f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-            const float *xa = lds + ly.X;
+            const float *xa[4] = {lds + ly.X + xa_base(c16, kq, ldx, 0), lds + ly.X + xa_base(c16, kq, ldx, 1),
+                                  lds + ly.X + xa_base(c16, kq, ldx, 2), lds + ly.X + xa_base(c16, kq, ldx, 3)};
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
-                const int c = 4 * j + kq;
-                const f4 a0 = *reinterpret_cast<const f4 *>(xa + xs_off(c16, c, ldx));
-                const f4 a1 = *reinterpret_cast<const f4 *>(xa + xs_off(16 + c16, c, ldx));
+                const f4 a0 = *reinterpret_cast<const f4 *>(xa[j & 3] + 64 * (j >> 2));
+                const f4 a1 = *reinterpret_cast<const f4 *>(xa[j & 3] + 64 * (j >> 2) + 16 * ldx);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     acc[0] = mfma4(a0[i], w1f[j][i], acc[0]);
@@ -235,19 +207,6 @@ __global__ __launch_bounds__(kThreads) void critic_rows_forward_kernel(FwdArgs g
     }
 }
 
-int n_cu_dev() {
-    static int cached = 0;
-    if (!cached) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cached = p.multiProcessorCount;
-        if (cached <= 0) cached = 256;
-    }
-    return cached;
-}
-
-constexpr size_t kMaxLds = 160 * 1024;
-
 template <int KJ, bool VEC>
 int launch_forward_v(const FwdArgs &g, int grid, hipStream_t st) {
     const FwdLay ly(KJ);
@@ -276,14 +235,6 @@ int launch_forward(const FwdArgs &g, int grid, hipStream_t st) {
     return (g.K1 & 3) == 0 ? launch_forward_v<KJ, true>(g, grid, st) : launch_forward_v<KJ, false>(g, grid, st);
 }
 
-// smallest instantiated KJ (k-groups of 16) covering in_dim; 0 = unsupported
-int pick_kj(int in_dim) {
-    static const int inst[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
-    for (int kj : inst)
-        if (16 * kj >= in_dim) return kj;
-    return 0;
-}
-
 int dispatch_forward(int kj, const FwdArgs &g, int grid, hipStream_t st) {
     switch (kj) {
         case 1: return launch_forward<1>(g, grid, st);
@@ -309,23 +260,26 @@ TSM_EXPORT int tsm_critic_rows_forward_supported(int32_t in_dim, int32_t hidden)
 
 // One-time function attributes (dynamic LDS size) for the instantiation that serves `in_dim`: call it outside any
 // stream capture (the first launch would otherwise set them inside one).
+int tsm_critic_train_init(int32_t in_dim);  // critic_train.hip
+
 TSM_EXPORT int tsm_critic_rows_init(int32_t in_dim, int32_t hidden) {
     TSM_REQUIRE(tsm_critic_rows_forward_supported(in_dim, hidden), "tsm_critic_rows_init: unsupported critic %d -> %d", in_dim, hidden);
     FwdArgs g{};
-    return dispatch_forward(pick_kj(in_dim), g, 0, nullptr);
+    const int rc = dispatch_forward(pick_kj(in_dim), g, 0, nullptr);
+    return rc != TSM_OK ? rc : tsm_critic_train_init(in_dim);
 }
 
-TSM_EXPORT int tsm_critic_rows_forward(const float *critic_params, int32_t in_dim, int32_t hidden, const float *obs_rows,
-                                       const int64_t *rows, int64_t first_row, int64_t Mr, const int32_t *run_if,
-                                       float *values_out, void *stream) {
+TSM_EXPORT int tsm_critic_rows_forward(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_out,
+                                       const float *obs_rows, const int64_t *rows, int64_t first_row, int64_t Mr,
+                                       const int32_t *run_if, float *values_out, void *stream) {
     TSM_REQUIRE(tsm_critic_rows_forward_supported(in_dim, hidden),
                 "tsm_critic_rows_forward supports hidden == 128, in_dim <= 384 (got %d / %d)", hidden, in_dim);
-    TSM_REQUIRE(Mr >= 0, "tsm_critic_rows_forward: negative row count");
+    TSM_REQUIRE(Mr >= 0 && n_out >= 1 && n_out <= 16, "tsm_critic_rows_forward: bad sizes (Mr %lld, n_out %d)", (long long)Mr, n_out);
     if (Mr == 0) return TSM_OK;
     TSM_REQUIRE(critic_params && obs_rows && values_out, "tsm_critic_rows_forward: null pointer");
     FwdArgs g{};
     g.P = critic_params; g.obs = obs_rows; g.rows = rows; g.first_row = first_row; g.Mr = Mr; g.K1 = in_dim;
-    g.out = values_out; g.run_if = run_if;
+    g.out = values_out; g.run_if = run_if; g.n_out = n_out;
     const int64_t tiles = ceil_div(Mr, kRows);
     const int cu = n_cu_dev();
     return dispatch_forward(pick_kj(in_dim), g, (int)(tiles < cu ? tiles : cu), tsm_stream(stream));

@@ -575,6 +575,7 @@ def ppo_critic_rows_update(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n
         raise ValueError("ppo_critic_rows_update: partial is too small")
     if rows is not None and rows.numel() < Mr:
         raise ValueError("ppo_critic_rows_update: rows holds fewer ids than Mr")
+    _critic_rows_init(K1, hidden)
     call("tsm_ppo_critic_rows_update", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_agent,
          ptr(obs_rows), ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old), ptr(rows), first_row, Mr, C.byref(cfg),
          n_blocks, ptr(slabs), ptr(partial), stream_ptr())
@@ -582,19 +583,33 @@ def ppo_critic_rows_update(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n
 
 
 def critic_rows_forward_supported(in_dim: int, hidden_sizes, n_out: int = 1, act: str = "relu") -> bool:
-    """Does the one-launch critic forward (csrc/critic_rows.hip) cover this critic?  in -> 128 -> 128 -> 1, ReLU."""
+    """Does the one-launch critic forward (csrc/critic_rows.hip) cover this critic?  in -> 128 -> 128 -> n_out <= 16, ReLU
+    (n_out > 1: the value is the mean of the outputs)."""
     hs = list(hidden_sizes)
-    return (act == "relu" and n_out == 1 and len(hs) == 2 and hs[0] == hs[1]
+    return (act == "relu" and 1 <= n_out <= 16 and len(hs) == 2 and hs[0] == hs[1]
             and bool(call("tsm_critic_rows_forward_supported", in_dim, hs[0])))
 
 
 _critic_rows_ready: set = set()
 
 
+def _critic_rows_init(K1: int, hidden: int) -> None:
+    """One-time function attributes (dynamic LDS size) of the one-launch critic kernels serving this input width; must
+    happen outside any stream capture."""
+    if (K1, hidden) in _critic_rows_ready:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("one-launch critic kernels: first use inside a stream capture; run them (or "
+                           "ops.call('tsm_critic_rows_init', in_dim, hidden)) once before capturing")
+    call("tsm_critic_rows_init", K1, hidden)
+    _critic_rows_ready.add((K1, hidden))
+
+
 def critic_rows_forward(critic_params, obs_rows, hidden: int = 128, rows=None, first_row: int = 0, Mr=None, run_if=None,
-                        out=None):
-    """V(row) for Mr rows of obs_rows [n, in_dim] (row ids `rows`, or first_row + i) in ONE launch -> values [Mr].
-    run_if (device i32[1]): the launch is a no-op (and `out` is left as it is) when it holds 0."""
+                        out=None, n_out: int = 1):
+    """V(row) for Mr rows of obs_rows [n, in_dim] (row ids `rows`, or first_row + i) in ONE launch -> values [Mr]
+    (n_out > 1: the mean of the critic's outputs).  run_if (device i32[1]): the launch is a no-op (and `out` is left
+    as it is) when it holds 0."""
     obs_rows = _chk(obs_rows, torch.float32, "obs_rows")
     K1 = obs_rows.shape[-1]
     if Mr is None:
@@ -603,21 +618,53 @@ def critic_rows_forward(critic_params, obs_rows, hidden: int = 128, rows=None, f
         raise ValueError(f"critic_rows_forward: rows holds {rows.numel()} ids, Mr = {Mr}")
     if rows is None and first_row + Mr > obs_rows.shape[0]:
         raise ValueError(f"critic_rows_forward: rows [{first_row}, {first_row + Mr}) exceed the {obs_rows.shape[0]} given")
-    if critic_params.numel() != call("tsm_ppo_critic_rows_param_count", K1, hidden):
-        raise ValueError(f"critic_rows_forward: {critic_params.numel()} parameters do not match {K1} -> {hidden} -> {hidden} -> 1")
-    if (K1, hidden) not in _critic_rows_ready:  # one-time function attributes, outside any capture
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("critic_rows_forward: first use inside a stream capture; call it (or ops.call('tsm_critic_rows_init')) once before")
-        call("tsm_critic_rows_init", K1, hidden)
-        _critic_rows_ready.add((K1, hidden))
+    if critic_params.numel() != hidden * K1 + hidden + hidden * hidden + hidden + n_out * hidden + n_out:
+        raise ValueError(f"critic_rows_forward: {critic_params.numel()} parameters do not match {K1} -> {hidden} -> {hidden} -> {n_out}")
+    _critic_rows_init(K1, hidden)
     if out is None:
         out = torch.empty(Mr, dtype=torch.float32, device=obs_rows.device)
     elif out.numel() < Mr:
         raise ValueError("critic_rows_forward: out is too small")
-    call("tsm_critic_rows_forward", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, ptr(obs_rows),
+    call("tsm_critic_rows_forward", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_out, ptr(obs_rows),
          ptr(None if rows is None else _chk(rows, torch.int64, "rows")), first_row, Mr,
          ptr(None if run_if is None else _chk(run_if, torch.int32, "run_if")), ptr(out), stream_ptr())
     return out
+
+
+def ctde_critic_rows_grid(B: int) -> int:
+    return call("tsm_ctde_critic_rows_grid", B)
+
+
+def ctde_critic_rows_update(critic_params, joint_store, T: int, E: int, rew, terminated, agent: int, n_agent: int, v_last,
+                            gamma: float, n_out: int, hidden: int = 128, n_blocks=None, slabs=None, partial=None):
+    """The critic half of CTDEPolicy.learn (ctde.py:149-172, 188-190) in one launch on CHAINED rows.
+    joint_store f32 [T, E, in_dim] (time-major joint rows), rew f32 / terminated u8 [T, E, n_agent] (agent column `agent`),
+    v_last f32 [E].  -> (grad_slabs [n_blocks, P], partial f64 [n_blocks, 4] = {sum adv, sum sq, 0, 0})."""
+    joint_store = _chk(joint_store, torch.float32, "joint_store")
+    K1 = joint_store.shape[-1]
+    B = T * E
+    if joint_store.numel() < B * K1 or rew.numel() < B * n_agent or terminated.numel() < B * n_agent or v_last.numel() < E:
+        raise ValueError("ctde_critic_rows_update: store tensors are smaller than T x E")
+    P = call("tsm_ctde_critic_rows_param_count", K1, hidden, n_out)
+    if critic_params.numel() != P:
+        raise ValueError(f"ctde_critic_rows_update: {critic_params.numel()} parameters do not match {K1} -> {hidden} -> {hidden} -> {n_out}")
+    _critic_rows_init(K1, hidden)
+    if n_blocks is None:
+        n_blocks = ctde_critic_rows_grid(B)
+    dev = joint_store.device
+    if slabs is None:
+        slabs = torch.empty(n_blocks, P, dtype=torch.float32, device=dev)
+    elif slabs.numel() < n_blocks * P:
+        raise ValueError("ctde_critic_rows_update: slabs is too small")
+    if partial is None:
+        partial = torch.empty(n_blocks * 4, dtype=torch.float64, device=dev)
+    elif partial.numel() < n_blocks * 4:
+        raise ValueError("ctde_critic_rows_update: partial is too small")
+    term = terminated.view(torch.uint8) if terminated.dtype == torch.bool else _chk(terminated, torch.uint8, "terminated")
+    call("tsm_ctde_critic_rows_update", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_out,
+         ptr(joint_store), T, E, ptr(_chk(rew, torch.float32, "rew")), ptr(term), n_agent, agent,
+         ptr(_chk(v_last, torch.float32, "v_last")), float(gamma), n_blocks, ptr(slabs), ptr(partial), stream_ptr())
+    return slabs, partial
 
 
 def ppo_value_loss(value, returns, cfg: tsm_ppo_cfg, M: int, v_s_old=None, perm=None, first_row=0, partial=None):
