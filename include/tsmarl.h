@@ -559,24 +559,41 @@ int tsm_critic_rows_forward(const float *critic_params, int32_t in_dim, int32_t 
                             const float *obs_rows, const int64_t *rows, int64_t first_row, int64_t Mr,
                             const int32_t *run_if, float *values_out, void *stream);
 
-/* CTDEPolicy.learn, the critic half in one launch  [a16 at BASELINE configs[2]]
- * Replaces  values = critic(global_obs).mean(1); values_next = critic(global_obs_next).mean(1);
+/* One gradient step of the same critic in two launches (second generation of tsm_ppo_critic_rows_update)  [a7, a14, a16]
+ * (A) tsm_critic_rows_grad_ppo / _td: forward, loss and backward down to dH1 = d loss / d (layer-1 pre-activation), with
+ *     the layer-1 weights resident in registers and the observation tile in LDS (csrc/critic_train.hip).
+ *       dh1_out [Mr][128] (minibatch row order); rest_slabs_out [n_blocks][P - 128 in_dim]: the gradients of
+ *       b1 | W2 | b2 | W3 | b3 (parameter order), one slab per workgroup; n_blocks = tsm_critic_rows_grad_grid(Mr, td).
+ *     _ppo  Replaces  the value term of PPO._update_with_batch (ppo.py:198-212) on joint rows, as tsm_ppo_critic_rows_update:
+ *           loss_partial_out f64 [n_blocks][4] = {0, sum of the value-loss terms, 0, 0}.
+ *     _td   Replaces  values = critic(global_obs).mean(1); values_next = critic(global_obs_next).mean(1);
  *           td_target = rew + discount_factor * values_next * (~terminated); critic_loss = mse_loss(values, td_target);
- *           critic_loss.backward()                       (tianshou/algorithm/multiagent/ctde.py:149-172, 188-190)
- * for rows that are CHAINED: the batch is the env-major view [E][T] of a time-major store joint_rows [T][E][in_dim]
- * (store row t * E + e), and obs_next of (e, t) is obs of (e, t + 1) for t < T - 1 -- its value is the next row's, out of
- * the same forward pass (a tile owns 31 rows and computes the 32nd as a halo).  v_last [E] = values of obs_next of the last
- * slot (tsm_critic_rows_forward on those E rows).  rew / terminated of store row r: rew[r * scalar_stride + scalar_offset]
- * (one agent's column of [T][E][N] arrays).  critic_params: w0[H][in_dim] b0 w1[H][H] b1 w2[n_out][H] b2[n_out], H == 128.
- * grad_slabs_out [n_blocks][param_count] (d critic_loss / d params, summed over slabs); loss_partial_out f64 [n_blocks][4] =
- * {sum (td_target - values), sum (values - td_target)^2, 0, 0}: mean advantage and critic_loss after division by T * E. */
-int64_t tsm_ctde_critic_rows_param_count(int32_t in_dim, int32_t hidden, int32_t n_out);
-int tsm_ctde_critic_rows_grid(int64_t B);
-int tsm_ctde_critic_rows_update(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_out,
-                                const float *joint_rows, int64_t T, int64_t E, const float *rew,
-                                const uint8_t *terminated, int64_t scalar_stride, int64_t scalar_offset,
-                                const float *v_last, double gamma, int32_t n_blocks, float *grad_slabs_out,
-                                double *loss_partial_out, void *stream);
+ *           critic_loss.backward()                   (tianshou/algorithm/multiagent/ctde.py:149-172, 188-190)
+ *           for CHAINED rows: the batch is the env-major view [E][T] of a time-major store joint_rows [T][E][in_dim] (store
+ *           row t * E + e) and obs_next of (e, t) is obs of (e, t + 1) for t < T - 1 -- its value is the next row's, out of
+ *           the same forward pass (a tile owns 31 rows and computes the 32nd as a halo); v_last [E] = values of obs_next of
+ *           the last slot (tsm_critic_rows_forward on those E rows).  rew / terminated of store row r:
+ *           x[r * scalar_stride + scalar_offset] (one agent's column of [T][E][N] arrays).  loss_partial_out =
+ *           {sum (td_target - values), sum (values - td_target)^2, 0, 0}: mean advantage / critic_loss after division by T E.
+ * (B) tsm_critic_rows_dw1: dW1 = dH1^T X over the same rows as a split-K pass (csrc/critic_dw1.hip):
+ *       w1_slabs_out [n_chunks][128 in_dim], n_chunks = tsm_critic_rows_dw1_chunks(Mr, in_dim) partial sums over row chunks.
+ *     Row i of the minibatch is rows[i], else (tm_T > 0) store row (i % tm_T) * tm_E + i / tm_T, else first_row + i.
+ * The optimizer takes both slab arrays as segments (tsm_adam_step_segs: W1 at offset 0, the rest at offset 128 in_dim).
+ * critic_params: w0[H][in_dim] b0 w1[H][H] b1 w2[n_out][H] b2[n_out], H == 128, in_dim <= 384 (a multiple of 4 above 64). */
+int64_t tsm_critic_rows_param_count(int32_t in_dim, int32_t hidden, int32_t n_out);
+int tsm_critic_rows_grad_grid(int64_t Mr, int32_t td);
+int tsm_critic_rows_grad_ppo(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_agent,
+                             const float *obs_rows, const float *returns, const float *v_s_old, const int64_t *rows,
+                             int64_t first_row, int64_t Mr, const tsm_ppo_cfg *cfg, int32_t n_blocks, float *dh1_out,
+                             float *rest_slabs_out, double *loss_partial_out, void *stream);
+int tsm_critic_rows_grad_td(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_out,
+                            const float *joint_rows, int64_t T, int64_t E, const float *rew, const uint8_t *terminated,
+                            int64_t scalar_stride, int64_t scalar_offset, const float *v_last, double gamma,
+                            int32_t n_blocks, float *dh1_out, float *rest_slabs_out, double *loss_partial_out,
+                            void *stream);
+int tsm_critic_rows_dw1_chunks(int64_t Mr, int32_t in_dim);
+int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim, const int64_t *rows, int64_t first_row,
+                        int64_t tm_T, int64_t tm_E, int64_t Mr, int32_t n_chunks, float *w1_slabs_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CTDE global state  [a16]

@@ -176,9 +176,12 @@ SIGNATURES = {
     "tsm_critic_rows_forward_supported": (_int, [_i32, _i32]),
     "tsm_critic_rows_init": (_int, [_i32, _i32]),
     "tsm_critic_rows_forward": (_int, [_p, _i32, _i32, _i32, _p, _p, _i64, _i64, _p, _p, _p]),
-    "tsm_ctde_critic_rows_param_count": (_i64, [_i32, _i32, _i32]),
-    "tsm_ctde_critic_rows_grid": (_int, [_i64]),
-    "tsm_ctde_critic_rows_update": (_int, [_p, _i32, _i32, _i32, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _f64, _i32, _p, _p, _p]),
+    "tsm_critic_rows_param_count": (_i64, [_i32, _i32, _i32]),
+    "tsm_critic_rows_grad_grid": (_int, [_i64, _i32]),
+    "tsm_critic_rows_grad_ppo": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i64, C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p]),
+    "tsm_critic_rows_grad_td": (_int, [_p, _i32, _i32, _i32, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _f64, _i32, _p, _p, _p, _p]),
+    "tsm_critic_rows_dw1_chunks": (_int, [_i64, _i32]),
+    "tsm_critic_rows_dw1": (_int, [_p, _p, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p]),
     "tsm_reduce_slabs_segs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
     "tsm_adam_step_segs": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _p, _f64, _p, _f64, _f64, _f64, _f64, _f64, _p, _p]),
     "tsm_ppo_update_grid": (_int, [_i64, _i32]),
@@ -187,7 +190,7 @@ SIGNATURES = {
                                     C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p, _p]),
 }
 
-_NO_STATUS = {"tsm_critic_rows_forward_supported", "tsm_ctde_critic_rows_param_count", "tsm_ctde_critic_rows_grid", "tsm_ppo_critic_rows_supported", "tsm_ppo_critic_rows_param_count", "tsm_ppo_critic_rows_grid",
+_NO_STATUS = {"tsm_critic_rows_forward_supported", "tsm_critic_rows_param_count", "tsm_critic_rows_grad_grid", "tsm_critic_rows_dw1_chunks", "tsm_ppo_critic_rows_supported", "tsm_ppo_critic_rows_param_count", "tsm_ppo_critic_rows_grid",
               "tsm_ppo_actor_rows_supported", "tsm_ppo_actor_rows_param_count", "tsm_ppo_actor_rows_grid",
               "tsm_rms_update_work_elems", "tsm_ppo_adv_stats_work_elems", "tsm_abi_version", "tsm_last_error", "tsm_stream_abort_capture", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
               "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems",

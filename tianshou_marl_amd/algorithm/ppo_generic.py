@@ -18,6 +18,7 @@ the whole sequence -- permutations, critic passes, GAE, every gradient step -- i
 from __future__ import annotations
 
 import copy
+import os
 from typing import Literal
 
 import numpy as np
@@ -73,6 +74,9 @@ class GenericPPO(PPO):
         self.fused_critic = self.fused_actor and ops.ppo_critic_rows_supported(
             net.critic_obs_dim, net.critic.dims[1:-1], self.n_agent if critic_input == "global" else 1, net.critic.act) \
             and net.critic.dims[-1] == 1
+        # second generation of the critic step (csrc/critic_train.hip + critic_dw1.hip: two launches, dW1 as a split-K pass)
+        self.critic_gen2 = self.fused_critic and os.environ.get("TSM_CRITIC_GEN", "2") != "1" and \
+            ops.critic_rows_grad_supported(net.critic_obs_dim, net.critic.dims[1:-1], 1, net.critic.act)
         # ... and V(row) of such a critic for all rows of a pass in one launch (csrc/critic_rows.hip) instead of three GEMMs
         self.fused_values = bool(fused_actor) and net.critic.dims[-1] == 1 and ops.critic_rows_forward_supported(
             net.critic_obs_dim, net.critic.dims[1:-1], 1, net.critic.act)
@@ -263,7 +267,7 @@ class GenericPPO(PPO):
         if w is None:
             w = self._ws[("rows", M, n_split, crit_rows)] = dict(
                 slabs_a=torch.empty(na, P_a, dtype=torch.float32, device=dev),
-                slabs_c=torch.empty(n_split, P_c, dtype=torch.float32, device=dev),
+                slabs_c=None if (crit_rows and self.critic_gen2) else torch.empty(n_split, P_c, dtype=torch.float32, device=dev),
                 partial=torch.zeros((na + nv) * 4, dtype=torch.float64, device=dev),
                 nb=torch.tensor([na + nv], dtype=torch.int32, device=dev), M=torch.tensor([M], dtype=torch.int64, device=dev),
                 flat_g=torch.empty(P_a + P_c, dtype=torch.float32, device=dev))
@@ -273,7 +277,16 @@ class GenericPPO(PPO):
         ops.ppo_actor_rows_update(net.actor.flat.data, pb["obs"], pb["act"], pb["logp_old"], pb["adv"], self._cfg, net.n_act,
                                   net.actor.dims[1], adv_stats=adv_stats, perm=idx, M=M, n_blocks=na, slabs=w["slabs_a"],
                                   partial=partial[:na * 4], opt_step_dev=step_dev)
-        if crit_rows:
+        segs_c = None
+        if crit_rows and self.critic_gen2:
+            src, N_c = (pb["joint"], pb["n_agent"]) if rows is not None else (pb["obs"], 1)
+            nW1 = net.critic.dims[1] * net.critic_obs_dim
+            w1s, rest, _ = ops.critic_rows_grad_ppo(net.critic.flat.data, src, pb["ret"], self._cfg, N_c, net.critic.dims[1],
+                                                    v_s_old=pb["v_s"] if self.value_clip else None,
+                                                    rows=rows if rows is not None else idx, Mr=Mr,
+                                                    partial=partial[na * 4:(na + nv) * 4], ws=self._ws)
+            segs_c = [(w1s, P_a, nW1), (rest, P_a + nW1, P_c - nW1)]
+        elif crit_rows:
             src, N_c = (pb["joint"], pb["n_agent"]) if rows is not None else (pb["obs"], 1)
             ops.ppo_critic_rows_update(net.critic.flat.data, src, pb["ret"], self._cfg, N_c, net.critic.dims[1],
                                        v_s_old=pb["v_s"] if self.value_clip else None, rows=rows if rows is not None else idx,
@@ -291,7 +304,7 @@ class GenericPPO(PPO):
             net.critic.backward(dvalue.view(-1, 1), n_split, slabs=w["slabs_c"], slab_stride=P_c)
         if step_dev is None:
             self.opt_step += 1
-        segs = [(w["slabs_a"][:na], 0, P_a), (w["slabs_c"][:n_split], P_a, P_c)]
+        segs = [(w["slabs_a"][:na], 0, P_a)] + (segs_c or [(w["slabs_c"][:n_split], P_a, P_c)])
         hyper = dict(lr=self.lr, lr_dev=self._lr_dev, betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
                      step_dev=step_dev)
         if self._grad_sync is None:

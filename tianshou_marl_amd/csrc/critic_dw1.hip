@@ -1,0 +1,198 @@
+// critic_dw1.hip -- the first layer's weight gradient of the one-launch critic step as a split-K pass:
+//     dW1[o][k] = sum_i dH1[i][o] * X[row(i)][k]          (o < 128, k < K1, i over the minibatch rows)
+// i.e. `w0.grad` of `loss.backward()` for the critic of PPO / CTDEPolicy.learn (modelfree/ppo.py:209-212,
+// multiagent/ctde.py:188-190), given dH1 = d loss / d (layer-1 pre-activation) published by csrc/critic_train.hip.
+//
+// Why a pass of its own: accumulated inside the per-tile kernel, every workgroup wrote a full 128 x K1 slab for a rank-32
+// update (196 KB x 256 workgroups = 50 MB per step at K1 = 384, read back by the optimizer).  Here workgroup (cb, rc) owns
+// the 128 x 96 block of columns [96 cb, 96 cb + 96) and sums over the row chunk rc in registers (6 accumulator tiles per wave:
+// wave w owns outputs [16 w, 16 w + 16)), so the reduction over ROWS happens on chip and only n_chunk partial slabs (64 at
+// 8192 rows) go to memory.  Sub-chunks of 64 rows are staged through LDS (dH1 [64][128], X [64][96]; row pitches = 16 mod 32
+// floats: the [k = row][lane = column] operand reads are bank-conflict free), the next sub-chunk's rows are in flight in
+// registers meanwhile, their ids one sub-chunk further ahead.
+#include "critic_rows_dev.h"
+
+namespace {
+
+constexpr int kSub = 64;       // rows per sub-chunk
+constexpr int kCB = 96;        // columns per workgroup (6 MFMA tiles)
+constexpr int kLdA = 144;      // dH1 rows in LDS (128 + 16): pitch = 16 mod 32
+constexpr int kLdB = 112;      // X rows in LDS (96 + 16)
+
+struct Dw1Args {
+    const float *dh1;        // [Mr][128]
+    const float *obs;        // rows [n][K1]
+    const int64_t *rows;     // nullable
+    int64_t first_row, Mr, tm_T, tm_E;   // row addressing as in critic_train.hip
+    int K1;
+    int64_t RC;              // rows per chunk (a multiple of 64)
+    float *slabs;            // [n_chunk][128 K1]
+};
+
+__device__ __forceinline__ int64_t dw1_row_of(const Dw1Args &g, int64_t i) {
+    const int64_t ic = i < g.Mr ? i : g.Mr - 1;
+    return g.rows ? g.rows[ic] : (g.tm_T > 0 ? (ic % g.tm_T) * g.tm_E + ic / g.tm_T : g.first_row + ic);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *sA = lds, *sB = lds + kSub * kLdA;
+    int64_t *rid = reinterpret_cast<int64_t *>(lds + kSub * (kLdA + kLdB));
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+    const int K1 = g.K1, c0 = kCB * blockIdx.x;
+    const int64_t i_lo = (int64_t)blockIdx.y * g.RC, i_hi = i_lo + g.RC < g.Mr ? i_lo + g.RC : g.Mr;
+    const int n_sub = (int)((i_hi - i_lo + kSub - 1) / kSub);
+
+    f4 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: dH1 sub-chunk = 64 rows x 32 chunks of 16 B (4 per thread), X block = 64 rows x 24 chunks (3 per thread)
+    f4 ra[4], rb[3];
+    auto fetch = [&](int s) {
+        const int64_t i0 = i_lo + (int64_t)s * kSub;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + kThreads * u, r = q >> 5, c = q & 31;
+            const int64_t i = i0 + r;
+            const int64_t ic = i < i_hi ? i : i_hi - 1;
+            const float4 v = *reinterpret_cast<const float4 *>(g.dh1 + ic * kH + 4 * c);
+            ra[u] = i < i_hi ? f4{v.x, v.y, v.z, v.w} : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = tid + kThreads * u, r = q / 24, c = q - r * 24;
+            const int64_t i = i0 + r;
+            const int k = c0 + 4 * c;
+            const bool ok = i < i_hi && k < K1;
+            const int64_t row = rid[r];
+            if constexpr (VEC) {
+                const int kc = k < K1 ? k : K1 - 4;
+                const float4 v = *reinterpret_cast<const float4 *>(g.obs + row * K1 + kc);
+                rb[u] = ok ? f4{v.x, v.y, v.z, v.w} : f4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = g.obs[row * K1 + (k + e < K1 ? k + e : K1 - 1)];
+                    rb[u][e] = (ok && k + e < K1) ? v : 0.f;
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + kThreads * u, r = q >> 5, c = q & 31;
+            *reinterpret_cast<f4 *>(sA + r * kLdA + 4 * c) = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = tid + kThreads * u, r = q / 24, c = q - r * 24;
+            *reinterpret_cast<f4 *>(sB + r * kLdB + 4 * c) = rb[u];
+        }
+    };
+
+    int64_t my_id = 0;
+    if (tid < kSub) rid[tid] = dw1_row_of(g, i_lo + tid < i_hi ? i_lo + tid : i_hi - 1);
+    __syncthreads();
+    fetch(0);
+    if (tid < kSub) {
+        const int64_t i = i_lo + kSub + tid;
+        my_id = dw1_row_of(g, i < i_hi ? i : i_hi - 1);
+    }
+    for (int s = 0; s < n_sub; ++s) {
+        commit();             // sub-chunk s: registers -> LDS (the previous one's readers are behind the loop-end barrier)
+        __syncthreads();      // ... and every thread has read RID for it
+        if (tid < kSub) {
+            rid[tid] = my_id;  // ids of sub-chunk s + 1; those of s + 2 fly during this one
+            const int64_t i = i_lo + (int64_t)(s + 2) * kSub + tid;
+            my_id = dw1_row_of(g, i < i_hi ? i : i_hi - 1);
+        }
+        __syncthreads();
+        if (s + 1 < n_sub) fetch(s + 1);
+        const float *pa = sA + kq * kLdA + 16 * w + c16;   // A[i = o][k = row]
+        const float *pb = sB + kq * kLdB + c16;            // B[k = row][j = column]
+#pragma unroll 4
+        for (int r0 = 0; r0 < kSub; r0 += 4) {
+            const float av = pa[r0 * kLdA];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc[t] = mfma4(av, pb[r0 * kLdB + 16 * t], acc[t]);
+        }
+        __syncthreads();
+    }
+    float *slab = g.slabs + (size_t)blockIdx.y * (size_t)kH * K1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 16 * w + kq * 4 + r;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int k = c0 + 16 * t + c16;
+            if (k < K1) __builtin_nontemporal_store(acc[t][r], slab + (size_t)o * K1 + k);
+        }
+    }
+}
+
+}  // namespace
+
+constexpr size_t kDw1Lds = (size_t)kSub * (kLdA + kLdB) * sizeof(float) + kSub * sizeof(int64_t);  // 66 048 B
+
+// one-time function attributes (dynamic LDS above 64 KB): outside any stream capture (tsm_critic_rows_init)
+int tsm_critic_dw1_init() {
+    static bool done = false;
+    if (!done) {
+        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_dw1_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDw1Lds));
+        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_dw1_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDw1Lds));
+        done = true;
+    }
+    return TSM_OK;
+}
+
+// rows per chunk / number of chunks (= partial slabs of dW1) for Mr rows: a full chip of workgroups, chunks of whole
+// 64-row sub-chunks
+static void dw1_plan(int64_t Mr, int32_t in_dim, int64_t *RC, int *n_chunk) {
+    const int ncb = (int)ceil_div(in_dim, kCB);
+    int64_t want = n_cu_dev() / ncb;
+    if (want < 1) want = 1;
+    const int64_t subs = ceil_div(Mr, kSub);
+    if (want > subs) want = subs;
+    *RC = ceil_div(subs, want) * kSub;
+    *n_chunk = (int)ceil_div(Mr, *RC);
+}
+
+TSM_EXPORT int tsm_critic_rows_dw1_chunks(int64_t Mr, int32_t in_dim) {
+    if (Mr <= 0 || in_dim < 1) return 0;
+    int64_t RC;
+    int n;
+    dw1_plan(Mr, in_dim, &RC, &n);
+    return n;
+}
+
+TSM_EXPORT int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim, const int64_t *rows,
+                                   int64_t first_row, int64_t tm_T, int64_t tm_E, int64_t Mr, int32_t n_chunks,
+                                   float *w1_slabs_out, void *stream) {
+    TSM_REQUIRE(in_dim >= 1 && in_dim <= 384 && ((in_dim & 3) == 0 || in_dim <= 64) && Mr >= 1,
+                "tsm_critic_rows_dw1: in_dim = %d (<= 384, a multiple of 4 above 64), Mr = %lld", in_dim, (long long)Mr);
+    TSM_REQUIRE(dh1 && obs_rows && w1_slabs_out, "tsm_critic_rows_dw1: null pointer");
+    TSM_REQUIRE(tm_T == 0 || (tm_T > 0 && tm_E > 0 && tm_T * tm_E == Mr), "tsm_critic_rows_dw1: T x E must equal Mr");
+    {
+        const int rc_ = tsm_critic_dw1_init();
+        if (rc_ != TSM_OK) return rc_;
+    }
+    int64_t RC;
+    int n;
+    dw1_plan(Mr, in_dim, &RC, &n);
+    TSM_REQUIRE(n_chunks == n, "tsm_critic_rows_dw1: n_chunks = %d, tsm_critic_rows_dw1_chunks says %d", n_chunks, n);
+    Dw1Args g{};
+    g.dh1 = dh1; g.obs = obs_rows; g.rows = rows; g.first_row = first_row; g.Mr = Mr; g.tm_T = tm_T; g.tm_E = tm_E;
+    g.K1 = in_dim; g.RC = RC; g.slabs = w1_slabs_out;
+    const dim3 grid((unsigned)ceil_div(in_dim, kCB), (unsigned)n);
+    if ((in_dim & 3) == 0)
+        hipLaunchKernelGGL(critic_dw1_kernel<true>, grid, dim3(kThreads), kDw1Lds, tsm_stream(stream), g);
+    else
+        hipLaunchKernelGGL(critic_dw1_kernel<false>, grid, dim3(kThreads), kDw1Lds, tsm_stream(stream), g);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}

@@ -20,7 +20,6 @@
 // Algorithmic HBM traffic per sample and step: obs 4 D + act 4 + logp_old 4 + adv 4 + id 8; activations
 // never touch HBM (the dense path writes and re-reads 4 x 512 B per sample).
 #include "common.h"
-#include <stdlib.h>
 
 extern long long *g_tsm_stamps;  // abi.hip (diagnostics, tools/stamp_actor_rows.py)
 
@@ -862,12 +861,6 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
 }
 
 // ---- critic ----
-// second-generation kernel (csrc/critic_train.hip): layer-1 weights from registers, observation tile resident in LDS
-int tsm_critic_train_ppo(const float *critic_params, int32_t in_dim, int32_t n_agent, const float *obs_rows,
-                         const float *returns, const float *v_s_old, const int64_t *rows, int64_t first_row, int64_t Mr,
-                         const tsm_ppo_cfg *cfg, int32_t n_blocks, float *grad_slabs_out, double *loss_partial_out,
-                         void *stream);
-
 TSM_EXPORT int tsm_ppo_critic_rows_supported(int32_t in_dim, int32_t hidden, int32_t n_agent) {
     return hidden == kH && in_dim >= 1 && in_dim <= 12 * kKs && n_agent >= 1 && n_agent <= 16;
 }
@@ -899,12 +892,6 @@ TSM_EXPORT int tsm_ppo_critic_rows_update(const float *critic_params, int32_t in
                 "tsm_ppo_critic_rows_update: null pointer");
     TSM_REQUIRE(!cfg->value_clip || v_s_old, "tsm_ppo_critic_rows_update: value_clip needs v_s_old");
     TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(Mr, kRows), "tsm_ppo_critic_rows_update: n_blocks = %d out of range", n_blocks);
-    {   // TSM_CRITIC_V1=1 keeps the first-generation kernel below (A/B measurements, tools/bench_rows_kernels.py)
-        static const bool v1 = [] { const char *e = getenv("TSM_CRITIC_V1"); return e && e[0] == '1'; }();
-        if (!v1 && ((in_dim & 3) == 0 || in_dim <= 64))
-            return tsm_critic_train_ppo(critic_params, in_dim, n_agent, obs_rows, returns, v_s_old, rows, first_row, Mr, cfg,
-                                        n_blocks, grad_slabs_out, loss_partial_out, stream);
-    }
     CriticArgs g{};
     g.P = critic_params; g.obs = obs_rows; g.returns = returns; g.v_s_old = v_s_old; g.rows = rows;
     g.first_row = first_row; g.Mr = Mr; g.K1 = in_dim; g.N = n_agent;

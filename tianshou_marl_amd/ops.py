@@ -631,40 +631,77 @@ def critic_rows_forward(critic_params, obs_rows, hidden: int = 128, rows=None, f
     return out
 
 
-def ctde_critic_rows_grid(B: int) -> int:
-    return call("tsm_ctde_critic_rows_grid", B)
+def critic_rows_grad_supported(in_dim: int, hidden_sizes, n_out: int = 1, act: str = "relu") -> bool:
+    """Does the two-launch critic gradient step (csrc/critic_train.hip + critic_dw1.hip) cover this critic?"""
+    return critic_rows_forward_supported(in_dim, hidden_sizes, n_out, act) and (in_dim % 4 == 0 or in_dim <= 64)
 
 
-def ctde_critic_rows_update(critic_params, joint_store, T: int, E: int, rew, terminated, agent: int, n_agent: int, v_last,
-                            gamma: float, n_out: int, hidden: int = 128, n_blocks=None, slabs=None, partial=None):
-    """The critic half of CTDEPolicy.learn (ctde.py:149-172, 188-190) in one launch on CHAINED rows.
+def _critic_grad_ws(K1: int, hidden: int, n_out: int, Mr: int, td: bool, dev, ws: dict | None):
+    """(n_blocks, n_chunks, dh1, rest slabs, w1 slabs, partial) for a gradient step of Mr rows; cached in `ws` (the
+    buffers are what captured graphs hold on to)."""
+    nb = call("tsm_critic_rows_grad_grid", Mr, int(td))
+    nc = call("tsm_critic_rows_dw1_chunks", Mr, K1)
+    key = ("critic_grad", K1, hidden, n_out, Mr, td)
+    w = None if ws is None else ws.get(key)
+    if w is None:
+        n_rest = hidden + hidden * hidden + hidden + n_out * hidden + n_out
+        w = dict(nb=nb, nc=nc, dh1=torch.empty(Mr, hidden, dtype=torch.float32, device=dev),
+                 rest=torch.empty(nb, n_rest, dtype=torch.float32, device=dev),
+                 w1=torch.empty(nc, hidden * K1, dtype=torch.float32, device=dev),
+                 partial=torch.zeros(nb * 4, dtype=torch.float64, device=dev))
+        if ws is not None:
+            ws[key] = w
+    return w
+
+
+def critic_rows_grad_ppo(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n_agent: int, hidden: int = 128, v_s_old=None,
+                         rows=None, first_row=0, Mr=None, partial=None, ws: dict | None = None):
+    """Critic half of one PPO gradient step on joint rows in two launches -> (w1_slabs [n_chunks, H * in_dim],
+    rest_slabs [n_blocks, P - H * in_dim], partial f64 [n_blocks * 4] = {0, sum vf, 0, 0} per workgroup): feed the two slab
+    arrays to `adam_step_segs` as segments (W1 first).  `partial`: where to leave the loss partials (>= n_blocks * 4)."""
+    obs_rows = _chk(obs_rows, torch.float32, "obs_rows")
+    K1 = obs_rows.shape[-1]
+    if Mr is None:
+        Mr = rows.numel() if rows is not None else obs_rows.shape[0] - first_row
+    if critic_params.numel() != call("tsm_critic_rows_param_count", K1, hidden, 1):
+        raise ValueError(f"critic_rows_grad_ppo: {critic_params.numel()} parameters do not match {K1} -> {hidden} -> {hidden} -> 1")
+    if rows is not None and rows.numel() < Mr:
+        raise ValueError("critic_rows_grad_ppo: rows holds fewer ids than Mr")
+    _critic_rows_init(K1, hidden)
+    w = _critic_grad_ws(K1, hidden, 1, Mr, False, obs_rows.device, ws)
+    part = w["partial"] if partial is None else partial
+    if part.numel() < w["nb"] * 4:
+        raise ValueError("critic_rows_grad_ppo: partial is too small")
+    call("tsm_critic_rows_grad_ppo", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_agent,
+         ptr(obs_rows), ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old), ptr(rows), first_row, Mr, C.byref(cfg),
+         w["nb"], ptr(w["dh1"]), ptr(w["rest"]), ptr(part), stream_ptr())
+    call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(obs_rows), K1, ptr(rows), first_row, 0, 0, Mr, w["nc"], ptr(w["w1"]),
+         stream_ptr())
+    return w["w1"], w["rest"], part
+
+
+def critic_rows_grad_td(critic_params, joint_store, T: int, E: int, rew, terminated, agent: int, n_agent: int, v_last,
+                        gamma: float, n_out: int, hidden: int = 128, partial=None, ws: dict | None = None):
+    """The critic half of CTDEPolicy.learn (ctde.py:149-172, 188-190) on CHAINED rows in two launches.
     joint_store f32 [T, E, in_dim] (time-major joint rows), rew f32 / terminated u8 [T, E, n_agent] (agent column `agent`),
-    v_last f32 [E].  -> (grad_slabs [n_blocks, P], partial f64 [n_blocks, 4] = {sum adv, sum sq, 0, 0})."""
+    v_last f32 [E].  -> (w1_slabs, rest_slabs, partial f64 = {sum adv, sum sq, 0, 0} per workgroup)."""
     joint_store = _chk(joint_store, torch.float32, "joint_store")
     K1 = joint_store.shape[-1]
     B = T * E
     if joint_store.numel() < B * K1 or rew.numel() < B * n_agent or terminated.numel() < B * n_agent or v_last.numel() < E:
-        raise ValueError("ctde_critic_rows_update: store tensors are smaller than T x E")
-    P = call("tsm_ctde_critic_rows_param_count", K1, hidden, n_out)
-    if critic_params.numel() != P:
-        raise ValueError(f"ctde_critic_rows_update: {critic_params.numel()} parameters do not match {K1} -> {hidden} -> {hidden} -> {n_out}")
+        raise ValueError("critic_rows_grad_td: store tensors are smaller than T x E")
+    if critic_params.numel() != call("tsm_critic_rows_param_count", K1, hidden, n_out):
+        raise ValueError(f"critic_rows_grad_td: {critic_params.numel()} parameters do not match {K1} -> {hidden} -> {hidden} -> {n_out}")
     _critic_rows_init(K1, hidden)
-    if n_blocks is None:
-        n_blocks = ctde_critic_rows_grid(B)
-    dev = joint_store.device
-    if slabs is None:
-        slabs = torch.empty(n_blocks, P, dtype=torch.float32, device=dev)
-    elif slabs.numel() < n_blocks * P:
-        raise ValueError("ctde_critic_rows_update: slabs is too small")
-    if partial is None:
-        partial = torch.empty(n_blocks * 4, dtype=torch.float64, device=dev)
-    elif partial.numel() < n_blocks * 4:
-        raise ValueError("ctde_critic_rows_update: partial is too small")
+    w = _critic_grad_ws(K1, hidden, n_out, B, True, joint_store.device, ws)
+    part = w["partial"] if partial is None else partial
     term = terminated.view(torch.uint8) if terminated.dtype == torch.bool else _chk(terminated, torch.uint8, "terminated")
-    call("tsm_ctde_critic_rows_update", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_out,
+    call("tsm_critic_rows_grad_td", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_out,
          ptr(joint_store), T, E, ptr(_chk(rew, torch.float32, "rew")), ptr(term), n_agent, agent,
-         ptr(_chk(v_last, torch.float32, "v_last")), float(gamma), n_blocks, ptr(slabs), ptr(partial), stream_ptr())
-    return slabs, partial
+         ptr(_chk(v_last, torch.float32, "v_last")), float(gamma), w["nb"], ptr(w["dh1"]), ptr(w["rest"]), ptr(part),
+         stream_ptr())
+    call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(joint_store), K1, None, 0, T, E, B, w["nc"], ptr(w["w1"]), stream_ptr())
+    return w["w1"], w["rest"], part
 
 
 def ppo_value_loss(value, returns, cfg: tsm_ppo_cfg, M: int, v_s_old=None, perm=None, first_row=0, partial=None):
