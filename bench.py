@@ -448,8 +448,9 @@ def run_c3(a, device):
     n_env, N, T, H = 4096, 8, 25, 128
     env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=device, seed=1626)
     D = env.obs_dim
+    # (async_stats: the losses of a learn() are read when the caller looks at them, one step late below)
     pol = CTDEPolicy(actor=DecentralizedActor(D, 5, H, device=device, seed=1),
-                     critic=CentralizedCritic(N * D, N, H, device=device, seed=2), seed=1626)
+                     critic=CentralizedCritic(N * D, N, H, device=device, seed=2), seed=1626, async_stats=True)
     mgr = FlexibleMultiAgentPolicyManager(pol, env, mode="shared")
     buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=device)
     col = Collector(mgr, env, buf, async_stats=True)
@@ -459,17 +460,23 @@ def run_c3(a, device):
     def step():
         with policy_within_training_step(mgr):
             cs = col.collect(n_step=n_env * T)
-            losses = trainer.train_step(agent_batches_from_buffer(buf, env.agents))
+            # copies=False: the learners read the time-major stores in place (no env-major copies of the 157 MB joint rows)
+            losses = trainer.train_step(agent_batches_from_buffer(buf, env.agents, copies=False))
         _resolve(cs)  # read every step's statistics (see one_step)
         col.reset_buffer(keep_statistics=True)
         return losses
 
+    prev = None
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = step()
+        if prev is not None:  # every learner's losses are read, one step late (as a logger would)
+            for v in prev.values():
+                float(v["critic_loss"])
+        prev = losses
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
@@ -478,7 +485,7 @@ def run_c3(a, device):
         e0.record()
         col.collect(n_step=n_env * T)
         e1.record()
-        trainer.train_step(agent_batches_from_buffer(buf, env.agents))
+        trainer.train_step(agent_batches_from_buffer(buf, env.agents, copies=False))
         e2.record()
     torch.cuda.synchronize()
     col.reset_buffer(keep_statistics=True)
@@ -501,7 +508,8 @@ def run_c3(a, device):
         "unit": "env-steps/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "simple_spread_v3 N=8 CTDEPolicy (shared actor 48-128-128-5, centralized critic 384-128-128-8), "
-                               "num_envs=4096, T=25", "learn_calls_per_step": N, "rows_per_learn": R},
+                               "num_envs=4096, T=25", "learn_calls_per_step": N, "rows_per_learn": R,
+                               "learn": "fused: rows read in place, critic forward / TD step / dW1 / actor step / two Adam steps"},
         "collect_ms": e0.elapsed_time(e1), "ctde_update_ms": e1.elapsed_time(e2),
         "losses_agent_0": {k: float(v) for k, v in losses["agent_0"].items()},
         "roofline": {"bound": "mfma", "kernel": "gemm_kernel<fwd> x3 (centralized critic forward, 384-128-128-8)",

@@ -288,6 +288,8 @@ typedef struct tsm_slab_seg {
     const float *slabs;
     int64_t offset, n, stride;
     int32_t n_slab, _pad;
+    const float *scale_dev; /* nullable device f32[1]: the segment's summed gradient is multiplied by it (a loss whose
+                               gradient is a device-side scalar times a sum, e.g. CTDEPolicy's actor loss, ctde.py:185) */
 } tsm_slab_seg;
 int tsm_reduce_slabs_segs(const tsm_slab_seg *segs_host, int32_t n_seg, int64_t n, double scale, float *out,
                           void *stream);
@@ -519,6 +521,9 @@ int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stream);
  * grad_slabs_out [n_blocks][tsm_ppo_actor_rows_param_count]; loss_partial_out f64 [n_blocks][4] =
  * {sum clip objective, 0, sum entropy, 0} (the layout tsm_ppo_finalize_many folds).
  * opt_step_dev (nullable, device i64[1]): advanced by one per call, as tsm_ppo_update_fused does.
+ * cfg->loss_kind == 1 (policy gradient, obj = logp * adv): logp_old may be NULL, and adv NULL means adv = 1 for every
+ * sample -- the launch then yields d(-mean logp)/d params and sum logp (CTDEPolicy.learn's actor term up to the scalar
+ * mean(advantage), quirk Q7).
  * ------------------------------------------------------------------------------------------- */
 int tsm_ppo_actor_rows_supported(int32_t obs_dim, int32_t hidden, int32_t n_act);
 int64_t tsm_ppo_actor_rows_param_count(int32_t obs_dim, int32_t hidden, int32_t n_act);
@@ -591,6 +596,13 @@ int tsm_critic_rows_grad_td(const float *critic_params, int32_t in_dim, int32_t 
                             int64_t scalar_stride, int64_t scalar_offset, const float *v_last, double gamma,
                             int32_t n_blocks, float *dh1_out, float *rest_slabs_out, double *loss_partial_out,
                             void *stream);
+/* The two scalars of CTDEPolicy.learn and the actor gradient's scale from the kernels' partial sums (ctde.py:181-199):
+ * critic_partial [nb_c][4] = {sum (td - v), sum (v - td)^2, ..} (tsm_critic_rows_grad_td), actor_partial [nb_a][4] =
+ * {sum log_probs, ..} (tsm_ppo_actor_rows_update, loss_kind 1, adv NULL) -> scalars_out[2] = {actor_loss =
+ * -mean(log_probs) * mean(advantage), critic_loss}, mean_adv_out[1] = mean(advantage) (the scale_dev of the actor's slab
+ * segment).  One workgroup; fixed summation order.  scalars_out may be pinned host memory. */
+int tsm_ctde_finalize(const double *critic_partial, int32_t nb_c, const double *actor_partial, int32_t nb_a, int64_t B,
+                      float *scalars_out, float *mean_adv_out, void *stream);
 int tsm_critic_rows_dw1_chunks(int64_t Mr, int32_t in_dim);
 int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim, const int64_t *rows, int64_t first_row,
                         int64_t tm_T, int64_t tm_E, int64_t Mr, int32_t n_chunks, float *w1_slabs_out, void *stream);

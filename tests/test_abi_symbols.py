@@ -33,7 +33,7 @@ def test_abi_version_and_sizes(lib):
     # ctypes mirrors of the header's structs keep their layout
     import ctypes
 
-    assert ctypes.sizeof(_abi.tsm_slab_seg) == 40 and ctypes.sizeof(_abi.tsm_ppo_cfg) == 48
+    assert ctypes.sizeof(_abi.tsm_slab_seg) == 48 and ctypes.sizeof(_abi.tsm_ppo_cfg) == 48
     assert lib.tsm_vrb_state_bytes(4, 1) == (6 * 4 + 4 + 1) * 8
     assert lib.tsm_vrb_state_bytes(8, 3) == (6 * 8 + 24 + 1) * 8
     assert lib.tsm_ppo_loss_partial_elems(0) == 0

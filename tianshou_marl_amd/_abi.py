@@ -35,7 +35,7 @@ class tsm_ppo_cfg(C.Structure):
 
 class tsm_slab_seg(C.Structure):
     _fields_ = [("slabs", C.c_void_p), ("offset", C.c_int64), ("n", C.c_int64), ("stride", C.c_int64),
-                ("n_slab", C.c_int32), ("_pad", C.c_int32)]
+                ("n_slab", C.c_int32), ("_pad", C.c_int32), ("scale_dev", C.c_void_p)]
 
 
 class tsm_mpe_cfg(C.Structure):
@@ -181,6 +181,7 @@ SIGNATURES = {
     "tsm_critic_rows_grad_ppo": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i64, C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p]),
     "tsm_critic_rows_grad_td": (_int, [_p, _i32, _i32, _i32, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _f64, _i32, _p, _p, _p, _p]),
     "tsm_critic_rows_dw1_chunks": (_int, [_i64, _i32]),
+    "tsm_ctde_finalize": (_int, [_p, _i32, _p, _i32, _i64, _p, _p, _p]),
     "tsm_critic_rows_dw1": (_int, [_p, _p, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p]),
     "tsm_reduce_slabs_segs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
     "tsm_adam_step_segs": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _p, _f64, _p, _f64, _f64, _f64, _f64, _f64, _p, _p]),

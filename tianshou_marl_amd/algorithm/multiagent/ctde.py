@@ -76,6 +76,62 @@ class GlobalStateConstructor(nn.Module):
         return ops.global_state([obs[:, a].contiguous() for a in range(obs.shape[1])], "mean")
 
 
+class LazyScalars(dict):
+    """Named f32 scalars a kernel is writing into pinned host memory: a dict filled in when first read (the reference
+    returns `.item()` floats, ctde.py:196-199; here the host need not wait for them to queue the next learner)."""
+
+    def __init__(self, slot: dict, names: tuple) -> None:
+        super().__init__()
+        self._slot, self._names = slot, names
+
+    def _force(self) -> None:
+        slot = self._slot
+        if slot is None:
+            return
+        self._slot = None
+        slot["event"].synchronize()
+        vals = slot["h"].numpy()
+        dict.update(self, {k: float(vals[i]) for i, k in enumerate(self._names)})
+        if slot.get("pending") is self:
+            slot["pending"] = None
+
+    def __getitem__(self, k):
+        self._force()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._force()
+        return dict.get(self, k, default)
+
+    def __contains__(self, k):
+        self._force()
+        return dict.__contains__(self, k)
+
+    def __iter__(self):
+        self._force()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._force()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._force()
+        return dict.keys(self)
+
+    def values(self):
+        self._force()
+        return dict.values(self)
+
+    def items(self):
+        self._force()
+        return dict.items(self)
+
+    def __repr__(self):
+        self._force()
+        return dict.__repr__(self)
+
+
 class CTDEPolicy(nn.Module):
     def __init__(self, actor: FlatMLP, critic: FlatMLP, optim_actor: FlatAdam | None = None,
                  optim_critic: FlatAdam | None = None, observation_space: Any = None, action_space: Any = None,
@@ -95,6 +151,12 @@ class CTDEPolicy(nn.Module):
         self.deterministic_eval = bool(kwargs.pop("deterministic_eval", False))
         self.seed = int(kwargs.pop("seed", 0))
         self._sample_ctr = 0
+        # fused=True: learn() on rows readable in place runs on the one-launch kernels (_learn_store); async_stats=True:
+        # its losses come back as a mapping that waits for the device only when it is read
+        self.fused = bool(kwargs.pop("fused", True))
+        self.async_stats = bool(kwargs.pop("async_stats", False))
+        self._ws: dict = {}
+        self._cfg_pg = ops.make_ppo_cfg(adv_norm=False, ent_coef=0.0, vf_coef=0.0, loss_kind=1)
 
     @property
     def device(self) -> torch.device:
@@ -130,8 +192,73 @@ class CTDEPolicy(nn.Module):
             return out
         return dict(act=act, logp=logp, value=torch.zeros_like(logp), logits=logits)
 
+    # ---- fused learn: the stores read in place, 8 launches, no activation ever in HBM ------------------------------
+    def _store_path(self, batch: Batch):
+        """(store, agent) when this call can take the one-launch kernels: rows of a device buffer readable in place
+        (`batch.chain_done.store`, training_coordinator.agent_batches_from_buffer), a centralized critic in-128-128-n_out on
+        the concatenated joint row and a 128-wide actor."""
+        if not self.fused or not self.enable_global_info or "chain_done" not in batch or "agent_index" not in batch:
+            return None
+        store = getattr(batch.chain_done, "store", None)
+        if store is None:
+            return None
+        a, c = self.actor, self.critic
+        ok = (c.dims[0] == store.N * store.D and a.dims[0] == store.D and len(a.dims) == 4 and len(c.dims) == 4
+              and ops.critic_rows_grad_supported(c.dims[0], c.dims[1:-1], c.dims[-1], c.act)
+              and ops.ppo_actor_rows_supported(a.dims[0], a.dims[1:-1], a.dims[-1], a.act)
+              and not self.optim_actor.max_grad_norm and not self.optim_critic.max_grad_norm)
+        return (store, int(batch.agent_index)) if ok else None
+
+    def _learn_store(self, store, agent: int):
+        """ctde.py:121-199 on the rows of `store` for agent column `agent`:
+            v_last      critic on obs_next of the last slot                        tsm_critic_rows_forward
+            critic      forward + TD loss + backward (values_next = the next row)  tsm_critic_rows_grad_td, tsm_critic_rows_dw1
+            actor       forward + d(-mean log_probs) + backward                    tsm_ppo_actor_rows_update (loss_kind 1, adv = 1)
+            scalars     actor_loss, critic_loss, mean(advantage)                   tsm_ctde_finalize
+            two Adam steps (the actor's gradient scaled by mean(advantage) on the device: quirk Q7)   tsm_adam_step_segs
+        The statistics land in pinned host memory behind the launches and are read when the returned mapping is."""
+        T, E, N, D = store.T, store.E, store.N, store.D
+        B, dev = T * E, self.device
+        actor, critic = self.actor, self.critic
+        H, n_out, A = critic.dims[1], critic.dims[-1], actor.dims[-1]
+        K1 = N * D
+        w = self._ws.get((store.key, T, agent))
+        if w is None:
+            na = ops.ppo_actor_rows_grid(B)
+            w = self._ws[(store.key, T, agent)] = dict(
+                ids=(torch.arange(B, dtype=torch.int64, device=dev) * N + agent).contiguous(), na=na,
+                slabs_a=torch.empty(na, actor.flat.numel(), dtype=torch.float32, device=dev),
+                part_a=torch.zeros(na * 4, dtype=torch.float64, device=dev),
+                v_last=torch.empty(E, dtype=torch.float32, device=dev),
+                mean_adv=torch.zeros(1, dtype=torch.float32, device=dev), ring=[], pos=0)
+        ops.critic_rows_forward(critic.flat.data, store.obs_next[T - 1].reshape(E, K1), H, n_out=n_out, out=w["v_last"])
+        w1s, rest, part_c = ops.critic_rows_grad_td(critic.flat.data, store.obs[:T].reshape(T, E, K1), T, E, store.rew[:T],
+                                                    store.term[:T], agent, N, w["v_last"], self.discount_factor, n_out, H,
+                                                    ws=self._ws)
+        ops.ppo_actor_rows_update(actor.flat.data, store.obs[:T].reshape(B * N, D), store.act[:T].reshape(-1), None, None,
+                                  self._cfg_pg, A, actor.dims[1], perm=w["ids"], M=B, n_blocks=w["na"], slabs=w["slabs_a"],
+                                  partial=w["part_a"])
+        if len(w["ring"]) < 4:  # pinned slots the finalize kernel writes straight into (no copy on the stream)
+            w["ring"].append(dict(h=torch.zeros(2, dtype=torch.float32).pin_memory(), event=torch.cuda.Event(), pending=None))
+        slot = w["ring"][w["pos"] % len(w["ring"])] if len(w["ring"]) == 4 else w["ring"][-1]
+        w["pos"] += 1
+        if slot["pending"] is not None:
+            slot["pending"]._force()
+        ops.ctde_finalize(part_c, part_c.numel() // 4, w["part_a"], w["na"], B, slot["h"], w["mean_adv"])
+        slot["event"].record()
+        nW1 = H * K1
+        self.optim_critic.step_segs([(w1s, 0, nW1), (rest, nW1, critic.flat.numel() - nW1)])
+        self.optim_actor.step_segs([(w["slabs_a"], 0, actor.flat.numel(), w["mean_adv"])])
+        out = LazyScalars(slot, ("actor_loss", "critic_loss"))
+        slot["pending"] = out
+        return out
+
     def learn(self, batch: Batch, **kwargs: Any) -> dict[str, float]:
         """One centralized-critic TD step + one policy-gradient step (ctde.py:121-199)."""
+        fast = self._store_path(batch)
+        if fast is not None:
+            out = self._learn_store(*fast)
+            return out if self.async_stats else dict(out)
         obs = self._t(batch.obs, torch.float32)
         act = self._t(batch.act, torch.int64).reshape(-1)
         rew = self._t(batch.rew, torch.float32).reshape(-1)

@@ -343,7 +343,21 @@ class LeaguePlayTrainer(MATrainer):
         self.elo_ratings[loser] = rl + k * (0 - (1 - expected_w))
 
 
-def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, only: list | None = None) -> Batch:
+class DeviceStoreRows:
+    """Handle on the rows of a device buffer that `collect(n_step)` left behind (T unrotated, equally filled slots, rows
+    chained, no episode end before the last slot): the time-major stores themselves, no copies.  Learners that can read
+    the stores in place (CTDEPolicy.learn: csrc/critic_train.hip walks the env-major view of the time-major store) take it
+    from `batch.chain_done.store` instead of the env-major copies."""
+
+    def __init__(self, buffer, T: int) -> None:
+        self.T, self.E, self.N, self.D = int(T), buffer.buffer_num, buffer.n_agent, buffer.obs_dim
+        self.obs, self.obs_next, self.act = buffer.obs_store, buffer.obs_next_store, buffer.act_store
+        self.rew, self.term = buffer.rew_store, buffer.term_store
+        self.key = buffer.storage_key()
+
+
+def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, only: list | None = None,
+                              copies: bool = True) -> Batch:
     """The trainers' batch format straight from the device buffer (no host copy).
 
     Returns Batch({agent: Batch(obs, act, rew, obs_next, terminated, truncated)}, global_obs, global_obs_next) whose
@@ -352,7 +366,10 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
     is that row's `[N*D]` view (GlobalStateConstructor.build, ctde.py:291-294).  `only`: build the batches of these
     agents alone (a league / self-play step trains one agent per team).
     Equally filled sub-buffers that start at slot 0 (what `collect(n_step)` leaves behind a `reset_buffer`) are read as
-    strided views of the time-major store -- one copy per field and agent, no index kernel and no host round trip."""
+    strided views of the time-major store -- one copy per field and agent, no index kernel and no host round trip.
+    copies=False (chained rows whose episodes end at the last slot only): no env-major copies at all -- every agent's
+    batch is `Batch(agent_index=a)` and the stores travel as `batch.chain_done.store` (`DeviceStoreRows`); for learners that
+    read the stores in place (CTDEPolicy).  Falls back to the copies when the rows do not qualify."""
     T = buffer.host_uniform_len()
     if T is not None:
         E = buffer.buffer_num
@@ -373,12 +390,31 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
         col = lambda x, a: x[:, a].contiguous()  # noqa: E731
         full = lambda x: x.reshape(x.shape[0], -1)  # noqa: E731
     out = Batch()
+    store = None
+    if global_state and T is not None and T > 0 and buffer.rows_chained is True and buffer.obs_next_store is not None:
+        # episodes that end before the last slot break the chain (obs_next of that row is not the next slot's obs): one
+        # small device reduction + one flag read per call (not per agent) decides whether learners may read in place
+        from ... import ops
+
+        early = bool(ops.any_nonzero_u8(buffer.done_store[:T - 1].reshape(-1)).item()) if T > 1 else False
+        if not early:
+            store = DeviceStoreRows(buffer, T)
+    if store is not None and not copies:
+        for a, name in enumerate(agents):
+            if only is None or name in only:
+                out[name] = Batch(agent_index=np.int64(a))
+        cd = buffer.done_store[:T].transpose(0, 1).reshape(-1)
+        cd.chain_T, cd.store = int(T), store
+        out["chain_done"] = cd
+        return out
     for a, name in enumerate(agents):
         if only is not None and name not in only:
             continue
         out[name] = Batch(obs=col(d["obs"], a), act=col(d["act"], a).to(torch.int64),
                           rew=col(d["rew"], a), obs_next=col(d["obs_next"], a),
                           terminated=col(d["terminated"], a).bool(), truncated=col(d["truncated"], a).bool())
+        if store is not None:
+            out[name]["agent_index"] = np.int64(a)
     if global_state:
         out["global_obs"] = full(d["obs"])
         out["global_obs_next"] = full(d["obs_next"])
@@ -389,5 +425,7 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
             # `chain_T` = T) says where that does not hold.
             cd = buffer.done_store[:T].transpose(0, 1).reshape(-1)
             cd.chain_T = int(T)
+            if store is not None:
+                cd.store = store
             out["chain_done"] = cd
     return out

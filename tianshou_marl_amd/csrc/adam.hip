@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void reduce_segs_kernel(SegArgs a, int64_t n_t
     const int k = seg_of_block(a, blockIdx.x);
     const tsm_slab_seg sg = a.seg[k];
     const int64_t i = (int64_t)(blockIdx.x - a.first_blk[k]) * kCols + lane;
-    const float g = slab_sum_block(sg.slabs, sg.n_slab, sg.n, i, sm, sg.stride) * scale;
+    const float g = slab_sum_block(sg.slabs, sg.n_slab, sg.n, i, sm, sg.stride) * scale * (sg.scale_dev ? *sg.scale_dev : 1.f);
     if (sl == 0) {
         if (i < sg.n) out[sg.offset + i] = g;
         if (blk_sq) {
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void adam_segs_kernel(float *__restrict__ p, S
         g = il < sg.n ? work[i] * s_coef : 0.f;
     } else {
         g = slab_sum_block(sg.slabs, sg.n_slab, sg.n, il, sm, sg.stride);
+        if (sg.scale_dev) g *= *sg.scale_dev;
     }
     if (sl != 0 || il >= sg.n) return;
     const int64_t step = step_dev ? *step_dev : step_host;

@@ -157,3 +157,35 @@ TSM_EXPORT int tsm_ctde_td_head(const float *q, const float *q_next, int32_t n_o
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }
+
+
+// ---- the two scalars of CTDEPolicy.learn + mean(advantage) from the one-launch kernels' partial sums -----------------
+namespace {
+__global__ __launch_bounds__(64) void ctde_finalize_kernel(const double *__restrict__ pc, int32_t nb_c,
+                                                           const double *__restrict__ pa, int32_t nb_a, int64_t B,
+                                                           float *__restrict__ scalars, float *__restrict__ mean_adv) {
+    // one wave: lane l takes entries l, l + 64, ... (all loads of a lane in flight), then the xor butterfly -- a fixed order
+    const int lane = threadIdx.x;
+    double s_adv = 0.0, s_sq = 0.0, s_logp = 0.0;
+    for (int i = lane; i < nb_c; i += 64) { s_adv += pc[4 * i]; s_sq += pc[4 * i + 1]; }
+    for (int i = lane; i < nb_a; i += 64) s_logp += pa[4 * i];
+    s_adv = wave_sum(s_adv);
+    s_sq = wave_sum(s_sq);
+    s_logp = wave_sum(s_logp);
+    if (lane != 0) return;
+    const double m_adv = s_adv / (double)B, m_logp = s_logp / (double)B;
+    scalars[0] = (float)(-m_logp * m_adv);
+    scalars[1] = (float)(s_sq / (double)B);
+    *mean_adv = (float)m_adv;
+}
+}  // namespace
+
+TSM_EXPORT int tsm_ctde_finalize(const double *critic_partial, int32_t nb_c, const double *actor_partial, int32_t nb_a,
+                                 int64_t B, float *scalars_out, float *mean_adv_out, void *stream) {
+    TSM_REQUIRE(nb_c >= 1 && nb_a >= 1 && B >= 1, "tsm_ctde_finalize: bad sizes");
+    TSM_REQUIRE(critic_partial && actor_partial && scalars_out && mean_adv_out, "tsm_ctde_finalize: null pointer");
+    hipLaunchKernelGGL(ctde_finalize_kernel, dim3(1), dim3(64), 0, tsm_stream(stream), critic_partial, nb_c, actor_partial,
+                       nb_a, B, scalars_out, mean_adv_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}

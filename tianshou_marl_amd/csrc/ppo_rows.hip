@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
         n_act = 0; n_adv = 0.f; n_lpo = 0.f;
         if (idx_h >= 0) {
             n_act = g.act[idx_h];
-            n_adv = g.adv[idx_h];
+            n_adv = g.adv ? g.adv[idx_h] : 1.f;
             if (g.kind != 1) n_lpo = g.logp_old[idx_h];
         }
     };
@@ -820,8 +820,9 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
                 "tsm_ppo_actor_rows_update supports hidden == 128, obs_dim <= 64, n_act <= 16 (got %d / %d / %d)", hidden,
                 obs_dim, n_act);
     TSM_REQUIRE(M >= 1 && cfg, "tsm_ppo_actor_rows_update: empty minibatch or null cfg");
-    TSM_REQUIRE(actor_params && obs && act && logp_old && adv && grad_slabs_out && loss_partial_out,
-                "tsm_ppo_actor_rows_update: null pointer");
+    TSM_REQUIRE(actor_params && obs && act && grad_slabs_out && loss_partial_out, "tsm_ppo_actor_rows_update: null pointer");
+    TSM_REQUIRE(cfg->loss_kind == 1 || (logp_old && adv), "tsm_ppo_actor_rows_update: the clip objective needs logp_old and adv");
+    TSM_REQUIRE(adv || !cfg->adv_norm, "tsm_ppo_actor_rows_update: adv_norm without adv");
     TSM_REQUIRE(!cfg->adv_norm || adv_stats, "tsm_ppo_actor_rows_update: adv_norm needs adv_stats");
     TSM_REQUIRE(cfg->loss_kind == 0 || cfg->loss_kind == 1, "tsm_ppo_actor_rows_update: loss_kind must be 0 or 1");
     TSM_REQUIRE(cfg->dual_clip <= 0.0 || cfg->dual_clip > 1.0,

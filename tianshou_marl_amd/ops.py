@@ -345,14 +345,18 @@ def adam_step(param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9,
 
 
 def _slab_segs(segs, n: int):
-    """[(slabs [n_slab, stride >= n_k] or [n_slab * stride], offset, n_k), ...] -> ctypes array of tsm_slab_seg.
-    A segment's slabs tensor may be wider than its parameter count (a view into joint slabs): stride = its row pitch."""
+    """[(slabs [n_slab, stride >= n_k], offset, n_k[, scale_dev]), ...] -> ctypes array of tsm_slab_seg.
+    A segment's slabs tensor may be wider than its parameter count (a view into joint slabs): stride = its row pitch.
+    scale_dev (optional device f32[1]): the segment's summed gradient is multiplied by it."""
     arr = (_abi.tsm_slab_seg * len(segs))()
-    for k, (sl, off, nk) in enumerate(segs):
+    for k, seg in enumerate(segs):
+        sl, off, nk = seg[:3]
+        sc = seg[3] if len(seg) > 3 else None
         sl = _chk(sl, torch.float32, "slabs")
         if sl.dim() != 2 or sl.shape[1] < nk:
             raise ValueError("slab segment: expected slabs [n_slab, >= n] for n = %d, got %s" % (nk, tuple(sl.shape)))
-        arr[k] = _abi.tsm_slab_seg(ptr(sl), int(off), int(nk), int(sl.shape[1]), int(sl.shape[0]), 0)
+        arr[k] = _abi.tsm_slab_seg(ptr(sl), int(off), int(nk), int(sl.shape[1]), int(sl.shape[0]), 0,
+                                   ptr(None if sc is None else _chk(sc, torch.float32, "scale_dev")))
     return arr
 
 
@@ -533,9 +537,9 @@ def ppo_actor_rows_update(actor_params, obs, act, logp_old, adv, cfg: tsm_ppo_cf
     if perm is not None and perm.numel() < M:
         raise ValueError(f"ppo_actor_rows_update: perm holds {perm.numel()} sample ids, M = {M}")
     call("tsm_ppo_actor_rows_update", ptr(_chk(actor_params, torch.float32, "actor_params")), D, hidden, n_act, ptr(obs),
-         ptr(_chk(act, torch.int32, "act")), ptr(_chk(logp_old, torch.float32, "logp_old")),
-         ptr(_chk(adv, torch.float32, "adv")), ptr(perm), first_row, M, ptr(adv_stats), C.byref(cfg), n_blocks, ptr(slabs),
-         ptr(partial), ptr(opt_step_dev), stream_ptr())
+         ptr(_chk(act, torch.int32, "act")), ptr(None if logp_old is None else _chk(logp_old, torch.float32, "logp_old")),
+         ptr(None if adv is None else _chk(adv, torch.float32, "adv")), ptr(perm), first_row, M, ptr(adv_stats), C.byref(cfg),
+         n_blocks, ptr(slabs), ptr(partial), ptr(opt_step_dev), stream_ptr())
     return slabs, partial
 
 
@@ -702,6 +706,21 @@ def critic_rows_grad_td(critic_params, joint_store, T: int, E: int, rew, termina
          stream_ptr())
     call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(joint_store), K1, None, 0, T, E, B, w["nc"], ptr(w["w1"]), stream_ptr())
     return w["w1"], w["rest"], part
+
+
+def ctde_finalize(critic_partial, nb_c: int, actor_partial, nb_a: int, B: int, scalars_out, mean_adv_out):
+    """{actor_loss, critic_loss} and mean(advantage) of CTDEPolicy.learn from the kernels' partial sums (one launch).
+    scalars_out: device f32[2] or pinned host f32[2]; mean_adv_out: device f32[1]."""
+    if scalars_out.is_cuda:
+        out_p = ptr(scalars_out)
+    elif scalars_out.is_pinned() and scalars_out.is_contiguous() and scalars_out.dtype == torch.float32:
+        out_p = scalars_out.data_ptr()
+    else:
+        raise RuntimeError("ctde_finalize: scalars_out must be a device tensor or pinned host memory (f32)")
+    call("tsm_ctde_finalize", ptr(_chk(critic_partial, torch.float64, "critic_partial")), nb_c,
+         ptr(_chk(actor_partial, torch.float64, "actor_partial")), nb_a, B, out_p,
+         ptr(_chk(mean_adv_out, torch.float32, "mean_adv_out")), stream_ptr())
+    return scalars_out
 
 
 def ppo_value_loss(value, returns, cfg: tsm_ppo_cfg, M: int, v_s_old=None, perm=None, first_row=0, partial=None):

@@ -309,6 +309,15 @@ class FlatAdam:
                       betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, max_grad_norm=self.max_grad_norm,
                       work=self._work)
 
+    def step_segs(self, segs: list, step_dev: torch.Tensor | None = None) -> None:
+        """`step` for gradients that arrive as several slab arrays (ops.adam_step_segs: segments tiling the vector, each
+        optionally scaled by a device scalar).  step_dev: device-resident step count (captured graphs)."""
+        if step_dev is None:
+            self.step_count += 1
+        ops.adam_step_segs(self.param, segs, self.exp_avg, self.exp_avg_sq, self.step_count if step_dev is None else 1,
+                           lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay,
+                           max_grad_norm=self.max_grad_norm, work=self._work, step_dev=step_dev)
+
     def _shapes(self) -> list[tuple[int, ...]]:
         m = self._module
         if isinstance(m, FlatMLP):
