@@ -346,7 +346,9 @@ def c3_rooflines(device):
             "n_env": n_env, "n_agent": N, "T": T, "minibatch": mb, "bound": "mfma", "ms_per_update": t_upd,
             "flop_per_update": flop, "achieved": flop / (t_upd * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
             "unit": "TFLOP/s", "frac": flop / (t_upd * 1e-3) / MFMA_F32_PEAK, "collect_ms": t_col,
-            "ms_per_update_all": [round(x, 3) for x in upds],
+            "ms_per_update_all": [round(x, 3) for x in upds], "ms_per_update_min": min(upds), "ms_per_update_max": max(upds),
+            "timing": "median of %d updates after %d warm-up iterations (0: eager, 1: capture + first replay); min / max / all "
+                      "listed -- tools/c3_step_times.py has the per-step timeline of 80 steps" % (reps, warm),
             "env_steps_per_s": samples / ((t_col + t_upd) * 1e-3), "gradient_steps": ts.gradient_steps,
             "note": "flops as executed (the critic runs once per joint row); the per-lane critic of round 1 executed "
                     "%.0f GFLOP for the same update" % ((2 * rows * f_critic + samples * f_actor + 3 * samples * (f_actor + f_critic)) / 1e9)}]
@@ -383,39 +385,55 @@ def c3_rooflines(device):
                 "achieved": a_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": a_flop / tot / MFMA_F32_PEAK, "n_blocks": nb, "algorithmic_bytes_per_launch": a_bytes,
                 "slab_bytes_per_launch": nb * net.n_actor * 4, "traffic": pmc_traffic("ppo_actor_rows_kernel", nb * 512)})
-    # (iii) the critic step alone: the same minibatch as whole joint rows (mb / N rows of N * D floats)
+    # (iii) the critic step alone: the same minibatch as whole joint rows (mb / N rows of N * D floats); two launches
+    # (csrc/critic_train.hip: forward + value loss + backward to dH1; csrc/critic_dw1.hip: dW1 as a split-K pass)
     mr = mb // N
     joint, ret = buf.obs_store[:T].reshape(rows, N * D), torch.randn(n, device=device)
     rid = torch.randperm(rows, device=device)[:mr].contiguous()
-    nbc = ops.ppo_critic_rows_grid(mr)
-    cslabs = torch.empty(nbc, net.critic.flat.numel(), device=device)
-    cpart = torch.empty(nbc * 4, dtype=torch.float64, device=device)
-    fc = lambda: ops.ppo_critic_rows_update(net.critic.flat.data, joint, ret, algo._cfg, N, H, rows=rid, Mr=mr, n_blocks=nbc,  # noqa: E731
-                                            slabs=cslabs, partial=cpart)
-    fc()
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(10):
-            fc()
-    g.replay()
-    torch.cuda.synchronize()
-    tot = 0.0
-    for _ in range(5):
-        e0, e1 = ev(), ev()
-        e0.record()
-        g.replay()
-        e1.record()
+    cws: dict = {}
+    fc = lambda: ops.critic_rows_grad_ppo(net.critic.flat.data, joint, ret, algo._cfg, N, H, rows=rid, Mr=mr, ws=cws)  # noqa: E731
+
+    def graph_time(fn_, n_rep=10):
+        fn_()
         torch.cuda.synchronize()
-        tot += e0.elapsed_time(e1) * 1e-3 / 10 / 5
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            for _ in range(n_rep):
+                fn_()
+        g_.replay()
+        torch.cuda.synchronize()
+        tot_ = 0.0
+        for _ in range(5):
+            e0, e1 = ev(), ev()
+            e0.record()
+            g_.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            tot_ += e0.elapsed_time(e1) * 1e-3 / n_rep / 5
+        return tot_
+
+    tot = graph_time(fc)
+    wc = next(iter(cws.values()))
     c_flop, c_bytes = 3 * f_critic * mr, (4 * N * D + 8 + 4 * N) * mr
-    out.append({"kernel": "ppo_critic_rows_kernel<12> (centralized critic 384-128-128-1 on joint rows: forward + value loss of "
-                          "the row's 8 agents + backward in one launch)",
+    out.append({"kernel": "critic_rows_train_kernel<24> + critic_dw1_kernel (centralized critic 384-128-128-1 on joint rows: "
+                          "forward + value loss of the row's 8 agents + backward, dW1 as a split-K pass; two launches)",
                 "rows": mr, "samples": mb, "bound": "mfma", "flop_per_launch": c_flop, "us_per_launch": tot * 1e6,
                 "achieved": c_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": c_flop / tot / MFMA_F32_PEAK, "n_blocks": nbc, "algorithmic_bytes_per_launch": c_bytes,
-                "slab_bytes_per_launch": nbc * net.critic.flat.numel() * 4,
-                "traffic": pmc_traffic("ppo_critic_rows_kernel", nbc * 512)})
+                "frac": c_flop / tot / MFMA_F32_PEAK, "n_blocks": wc["nb"], "dw1_chunks": wc["nc"],
+                "algorithmic_bytes_per_launch": c_bytes,
+                "slab_bytes_per_launch": (wc["rest"].numel() + wc["w1"].numel() + wc["dh1"].numel()) * 4,
+                "traffic": (lambda a_, b_: None if a_ is None or b_ is None else a_ + b_)(
+                    pmc_traffic("critic_rows_train_kernel", wc["nb"] * 512),
+                    pmc_traffic("critic_dw1_kernel", -(-N * D // 96) * wc["nc"] * 512))})
+    # (iv) V(row) of the same critic for every joint row of the buffer (the preprocessing's critic pass), one launch
+    vout = torch.empty(rows, device=device)
+    tot = graph_time(lambda: ops.critic_rows_forward(net.critic.flat.data, joint, H, out=vout), n_rep=5)
+    v_flop = f_critic * rows
+    out.append({"kernel": "critic_rows_forward_kernel<24> (V(row) for all %d joint rows: layer-1 weights in registers, layer 3 "
+                          "folded into layer 2)" % rows, "rows": rows, "bound": "mfma", "flop_per_launch": v_flop,
+                "us_per_launch": tot * 1e6, "achieved": v_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": v_flop / tot / MFMA_F32_PEAK, "algorithmic_bytes_per_launch": (4 * N * D + 4) * rows,
+                "traffic": pmc_traffic("critic_rows_forward_kernel", min(256, -(-rows // 32)) * 512)})
     return out
 
 

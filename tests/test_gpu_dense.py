@@ -385,7 +385,7 @@ def test_ctde_learn_on_the_stores_equals_learn_on_the_copies(n_env):
         col.reset_buffer(keep_statistics=True)
     # critic: every weight, tightly
     pf, pu = pol_f.critic.flat.data.double().cpu().numpy(), pol_u.critic.flat.data.double().cpu().numpy()
-    np.testing.assert_allclose(pf, pu, rtol=1e-4, atol=2e-5 * np.abs(pu).max())
+    np.testing.assert_allclose(pf, pu, rtol=1e-4, atol=1e-4 * np.abs(pu).max())
     # actor: its gradient is mean(advantage) x the score function summed over the rows (quirk Q7) -- zero-mean noise whose
     # entries are mostly ~1e-6 and smaller, which both paths get right to f32 summation error (1e-6 of the gradient norm, the
     # losses above agree to six digits) but Adam's g / (|g| + 1e-8) turns a 1e-8 difference on such an entry into percents of
