@@ -577,7 +577,9 @@ int tsm_critic_rows_forward(const float *critic_params, int32_t in_dim, int32_t 
  *           for CHAINED rows: the batch is the env-major view [E][T] of a time-major store joint_rows [T][E][in_dim] (store
  *           row t * E + e) and obs_next of (e, t) is obs of (e, t + 1) for t < T - 1 -- its value is the next row's, out of
  *           the same forward pass (a tile owns 31 rows and computes the 32nd as a halo); v_last [E] = values of obs_next of
- *           the last slot (tsm_critic_rows_forward on those E rows).  rew / terminated of store row r:
+ *           the last slot (tsm_critic_rows_forward on those E rows).  use_full (nullable device i32[1]) != 0: an episode
+ *           ended before the last slot, so rows are not chained there -- every target then takes v_next_full[i] (env-major
+ *           [T E]: V(obs_next) of every row, a pass the caller launches under the same flag).  rew / terminated of store row r:
  *           x[r * scalar_stride + scalar_offset] (one agent's column of [T][E][N] arrays).  loss_partial_out =
  *           {sum (td_target - values), sum (values - td_target)^2, 0, 0}: mean advantage / critic_loss after division by T E.
  * (B) tsm_critic_rows_dw1: dW1 = dH1^T X over the same rows as a split-K pass (csrc/critic_dw1.hip):
@@ -593,9 +595,9 @@ int tsm_critic_rows_grad_ppo(const float *critic_params, int32_t in_dim, int32_t
                              float *rest_slabs_out, double *loss_partial_out, void *stream);
 int tsm_critic_rows_grad_td(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_out,
                             const float *joint_rows, int64_t T, int64_t E, const float *rew, const uint8_t *terminated,
-                            int64_t scalar_stride, int64_t scalar_offset, const float *v_last, double gamma,
-                            int32_t n_blocks, float *dh1_out, float *rest_slabs_out, double *loss_partial_out,
-                            void *stream);
+                            int64_t scalar_stride, int64_t scalar_offset, const float *v_last, const float *v_next_full,
+                            const int32_t *use_full, double gamma, int32_t n_blocks, float *dh1_out,
+                            float *rest_slabs_out, double *loss_partial_out, void *stream);
 /* The two scalars of CTDEPolicy.learn and the actor gradient's scale from the kernels' partial sums (ctde.py:181-199):
  * critic_partial [nb_c][4] = {sum (td - v), sum (v - td)^2, ..} (tsm_critic_rows_grad_td), actor_partial [nb_a][4] =
  * {sum log_probs, ..} (tsm_ppo_actor_rows_update, loss_kind 1, adv NULL) -> scalars_out[2] = {actor_loss =

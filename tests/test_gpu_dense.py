@@ -340,37 +340,41 @@ def test_ctde_learn_takes_next_values_from_the_chained_forward(max_cycles, T):
     assert a[3] == b[3]
 
 
-@pytest.mark.parametrize("n_env", [40, 600])
-def test_ctde_learn_on_the_stores_equals_learn_on_the_copies(n_env):
+@pytest.mark.parametrize("n_env,max_cycles,rounds,graph", [(40, 25, 4, True), (600, 25, 2, True), (40, 7, 4, True), (40, 25, 2, False)])
+def test_ctde_learn_on_the_stores_equals_learn_on_the_copies(n_env, max_cycles, rounds, graph):
     """CTDEPolicy.learn (ctde.py:121-199) two ways on the SAME collected rows of BASELINE configs[2]'s shape: the
     unfused path on env-major copies (dense GEMMs + tsm_ctde_td_head, pinned to the reference by ctde.npz) and the fused
     path that reads the time-major stores in place (csrc/critic_rows.hip, critic_train.hip, critic_dw1.hip, ppo_rows.hip,
     tsm_ctde_finalize, tsm_adam_step_segs).  Losses and both networks' post-update weights agree over two rounds of all
     eight agents' updates (the summation orders differ: 2e-5 of the weight scale for all but a few ill-conditioned
-    Adam quotients)."""
+    Adam quotients).  max_cycles 7: episodes end in the middle of the 25 collected slots, where obs_next of a row is not
+    the next slot's obs -- a device flag switches the targets to a full V(obs_next) pass, no host round trip.  graph: the
+    fused learn replays as ONE hipGraph per call from its second call on (two graphs per agent take turns: four rounds
+    replay both)."""
     from tianshou_marl_amd.algorithm.ppo import policy_within_training_step
     from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
     from tianshou_marl_amd.data.collector import Collector
     from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
 
     N, T = 8, 25
-    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=4)
+    env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=max_cycles, device=DEV, seed=4)
     D = env.obs_dim
     mk = lambda fused: CTDEPolicy(actor=DecentralizedActor(D, 5, 128, device=DEV, seed=1),  # noqa: E731
-                                  critic=CentralizedCritic(N * D, N, 128, device=DEV, seed=2), seed=9, fused=fused)
+                                  critic=CentralizedCritic(N * D, N, 128, device=DEV, seed=2), seed=9, fused=fused, graph=graph)
     pol_f, pol_u = mk(True), mk(False)
     actor0 = pol_f.actor.flat.data.double().cpu().numpy()
     mgr = FlexibleMultiAgentPolicyManager(pol_f, env, mode="shared")
     buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=DEV)
     col = Collector(mgr, env, buf)
     col.reset()
-    for rnd in range(2):
+    for rnd in range(rounds):
         with policy_within_training_step(mgr):
             col.collect(n_step=n_env * T)
         lazy = agent_batches_from_buffer(buf, env.agents, copies=False)
         full = agent_batches_from_buffer(buf, env.agents)
         assert "obs" not in lazy.agent_0 and getattr(lazy.chain_done, "store", None) is not None
         assert int(full.agent_5.agent_index) == 5 and full.chain_done.store.T == T
+        assert int(lazy.chain_done.store.early_done.item()) == int(max_cycles < T)
         for a in env.agents:
             from tianshou_marl_amd.algorithm.multiagent.training_coordinator import _attach_global
 
@@ -389,10 +393,12 @@ def test_ctde_learn_on_the_stores_equals_learn_on_the_copies(n_env):
     # actor: its gradient is mean(advantage) x the score function summed over the rows (quirk Q7) -- zero-mean noise whose
     # entries are mostly ~1e-6 and smaller, which both paths get right to f32 summation error (1e-6 of the gradient norm, the
     # losses above agree to six digits) but Adam's g / (|g| + 1e-8) turns a 1e-8 difference on such an entry into percents of
-    # a step.  So: tight after the first two updates (checked above through the snapshot), and the 16-update movement of the
+    # a step.  So: tight after the first two updates (checked above through the snapshot), and the whole movement of the
     # two paths points the same way
     af, au = pol_f.actor.flat.data.double().cpu().numpy(), pol_u.actor.flat.data.double().cpu().numpy()
     mf, mu = af - actor0, au - actor0
     assert float(mf @ mu / (np.linalg.norm(mf) * np.linalg.norm(mu))) > 0.999
-    assert np.abs(af - au).max() <= 2 * 16 * pol_u.optim_actor.lr
-    assert pol_f.optim_actor.step_count == pol_u.optim_actor.step_count == 16
+    assert np.abs(af - au).max() <= 2 * 8 * rounds * pol_u.optim_actor.lr
+    if graph:
+        assert sum(len(w["graphs"]) for w in pol_f._ws.values() if isinstance(w, dict) and "graphs" in w) == 8 * min(2, rounds - 1)
+    assert pol_f.optim_actor.step_count == pol_u.optim_actor.step_count == pol_f.optim_critic.step_count == 8 * rounds

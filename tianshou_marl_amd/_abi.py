@@ -179,7 +179,8 @@ SIGNATURES = {
     "tsm_critic_rows_param_count": (_i64, [_i32, _i32, _i32]),
     "tsm_critic_rows_grad_grid": (_int, [_i64, _i32]),
     "tsm_critic_rows_grad_ppo": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i64, C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p]),
-    "tsm_critic_rows_grad_td": (_int, [_p, _i32, _i32, _i32, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _f64, _i32, _p, _p, _p, _p]),
+    "tsm_critic_rows_grad_td": (_int, [_p, _i32, _i32, _i32, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _p, _f64, _i32, _p, _p,
+                                       _p, _p]),
     "tsm_critic_rows_dw1_chunks": (_int, [_i64, _i32]),
     "tsm_ctde_finalize": (_int, [_p, _i32, _p, _i32, _i64, _p, _p, _p]),
     "tsm_critic_rows_dw1": (_int, [_p, _p, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p]),

@@ -155,6 +155,7 @@ class CTDEPolicy(nn.Module):
         # its losses come back as a mapping that waits for the device only when it is read
         self.fused = bool(kwargs.pop("fused", True))
         self.async_stats = bool(kwargs.pop("async_stats", False))
+        self.graph = bool(kwargs.pop("graph", True))  # the fused learn as one hipGraph replay per call
         self._ws: dict = {}
         self._cfg_pg = ops.make_ppo_cfg(adv_norm=False, ent_coef=0.0, vf_coef=0.0, loss_kind=1)
 
@@ -230,25 +231,64 @@ class CTDEPolicy(nn.Module):
                 slabs_a=torch.empty(na, actor.flat.numel(), dtype=torch.float32, device=dev),
                 part_a=torch.zeros(na * 4, dtype=torch.float64, device=dev),
                 v_last=torch.empty(E, dtype=torch.float32, device=dev),
-                mean_adv=torch.zeros(1, dtype=torch.float32, device=dev), ring=[], pos=0)
-        ops.critic_rows_forward(critic.flat.data, store.obs_next[T - 1].reshape(E, K1), H, n_out=n_out, out=w["v_last"])
-        w1s, rest, part_c = ops.critic_rows_grad_td(critic.flat.data, store.obs[:T].reshape(T, E, K1), T, E, store.rew[:T],
-                                                    store.term[:T], agent, N, w["v_last"], self.discount_factor, n_out, H,
-                                                    ws=self._ws)
-        ops.ppo_actor_rows_update(actor.flat.data, store.obs[:T].reshape(B * N, D), store.act[:T].reshape(-1), None, None,
-                                  self._cfg_pg, A, actor.dims[1], perm=w["ids"], M=B, n_blocks=w["na"], slabs=w["slabs_a"],
-                                  partial=w["part_a"])
-        if len(w["ring"]) < 4:  # pinned slots the finalize kernel writes straight into (no copy on the stream)
-            w["ring"].append(dict(h=torch.zeros(2, dtype=torch.float32).pin_memory(), event=torch.cuda.Event(), pending=None))
-        slot = w["ring"][w["pos"] % len(w["ring"])] if len(w["ring"]) == 4 else w["ring"][-1]
-        w["pos"] += 1
-        if slot["pending"] is not None:
-            slot["pending"]._force()
-        ops.ctde_finalize(part_c, part_c.numel() // 4, w["part_a"], w["na"], B, slot["h"], w["mean_adv"])
-        slot["event"].record()
+                # V(obs_next) of every row, env-major; filled only when an episode ended before the last slot (device flag)
+                v_full=torch.empty(B, dtype=torch.float32, device=dev),
+                em_rows=(torch.arange(B, dtype=torch.int64, device=dev) % T * E
+                         + torch.div(torch.arange(B, dtype=torch.int64, device=dev), T, rounding_mode="floor")).contiguous(),
+                mean_adv=torch.zeros(1, dtype=torch.float32, device=dev), ring=[], pos=0, calls=0, graphs={}, gslots={},
+                step_dev=torch.zeros(1, dtype=torch.int64, device=dev))
         nW1 = H * K1
-        self.optim_critic.step_segs([(w1s, 0, nW1), (rest, nW1, critic.flat.numel() - nW1)])
-        self.optim_actor.step_segs([(w["slabs_a"], 0, actor.flat.numel(), w["mean_adv"])])
+
+        def body(slot, step_dev):
+            ops.critic_rows_forward(critic.flat.data, store.obs_next[T - 1].reshape(E, K1), H, n_out=n_out, out=w["v_last"])
+            ops.critic_rows_forward(critic.flat.data, store.obs_next[:T].reshape(B, K1), H, n_out=n_out, rows=w["em_rows"],
+                                    Mr=B, run_if=store.early_done, out=w["v_full"])  # (a no-op launch for aligned collects)
+            w1s, rest, part_c = ops.critic_rows_grad_td(
+                critic.flat.data, store.obs[:T].reshape(T, E, K1), T, E, store.rew[:T], store.term[:T], agent, N, w["v_last"],
+                self.discount_factor, n_out, H, ws=self._ws, v_next_full=w["v_full"], use_full=store.early_done)
+            ops.ppo_actor_rows_update(actor.flat.data, store.obs[:T].reshape(B * N, D), store.act[:T].reshape(-1), None, None,
+                                      self._cfg_pg, A, actor.dims[1], perm=w["ids"], M=B, n_blocks=w["na"],
+                                      slabs=w["slabs_a"], partial=w["part_a"], opt_step_dev=step_dev)
+            ops.ctde_finalize(part_c, part_c.numel() // 4, w["part_a"], w["na"], B, slot["h"], w["mean_adv"])
+            self.optim_critic.step_segs([(w1s, 0, nW1), (rest, nW1, critic.flat.numel() - nW1)], step_dev=step_dev)
+            self.optim_actor.step_segs([(w["slabs_a"], 0, actor.flat.numel(), w["mean_adv"])], step_dev=step_dev)
+
+        mk_slot = lambda: dict(h=torch.zeros(2, dtype=torch.float32).pin_memory(), event=torch.cuda.Event(), pending=None)  # noqa: E731
+        w["calls"] += 1
+        same_steps = self.optim_actor.step_count == self.optim_critic.step_count
+        hyper = tuple((o.lr, tuple(o.betas), o.eps, o.weight_decay) for o in (self.optim_actor, self.optim_critic)) + \
+            (self.discount_factor,)
+        if w.get("hyper") != hyper:  # captured launches hold these as kernel arguments
+            w["graphs"].clear()
+            w["hyper"] = hyper
+        if self.graph and w["calls"] >= 2 and same_steps:
+            # ONE hipGraph replay per call (the first call of a shape runs eagerly: one-time kernel attributes).  Two graphs
+            # per agent take turns, each with a pinned slot of its own for the statistics, so that a replay never overwrites
+            # numbers the caller has not read yet; the optimizer step count lives in HBM (advanced by the actor kernel)
+            k = w["calls"] & 1
+            slot = w["gslots"].setdefault(k, mk_slot())
+            if slot["pending"] is not None:
+                slot["pending"]._force()
+            if w.get("step_host") != self.optim_actor.step_count:
+                w["step_dev"].fill_(self.optim_actor.step_count)
+            if k not in w["graphs"]:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body(slot, w["step_dev"])
+                w["graphs"][k] = g
+            w["graphs"][k].replay()
+            self.optim_actor.step_count += 1
+            self.optim_critic.step_count += 1
+            w["step_host"] = self.optim_actor.step_count
+        else:
+            if len(w["ring"]) < 4:  # pinned slots the finalize kernel writes straight into (no copy on the stream)
+                w["ring"].append(mk_slot())
+            slot = w["ring"][w["pos"] % len(w["ring"])] if len(w["ring"]) == 4 else w["ring"][-1]
+            w["pos"] += 1
+            if slot["pending"] is not None:
+                slot["pending"]._force()
+            body(slot, None)
+        slot["event"].record()
         out = LazyScalars(slot, ("actor_loss", "critic_loss"))
         slot["pending"] = out
         return out

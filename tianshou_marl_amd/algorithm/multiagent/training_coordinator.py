@@ -345,11 +345,13 @@ class LeaguePlayTrainer(MATrainer):
 
 class DeviceStoreRows:
     """Handle on the rows of a device buffer that `collect(n_step)` left behind (T unrotated, equally filled slots, rows
-    chained, no episode end before the last slot): the time-major stores themselves, no copies.  Learners that can read
-    the stores in place (CTDEPolicy.learn: csrc/critic_train.hip walks the env-major view of the time-major store) take it
-    from `batch.chain_done.store` instead of the env-major copies."""
+    chained): the time-major stores themselves, no copies.  Learners that can read the stores in place (CTDEPolicy.learn:
+    csrc/critic_train.hip walks the env-major view of the time-major store) take it from `batch.chain_done.store` instead
+    of the env-major copies.  `early_done` (device i32[1]) != 0: an episode ended before the last slot, i.e. obs_next of
+    that row is not the next slot's obs -- decided on the device, no host round trip."""
 
-    def __init__(self, buffer, T: int) -> None:
+    def __init__(self, buffer, T: int, early_done) -> None:
+        self.early_done = early_done
         self.T, self.E, self.N, self.D = int(T), buffer.buffer_num, buffer.n_agent, buffer.obs_dim
         self.obs, self.obs_next, self.act = buffer.obs_store, buffer.obs_next_store, buffer.act_store
         self.rew, self.term = buffer.rew_store, buffer.term_store
@@ -393,12 +395,17 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
     store = None
     if global_state and T is not None and T > 0 and buffer.rows_chained is True and buffer.obs_next_store is not None:
         # episodes that end before the last slot break the chain (obs_next of that row is not the next slot's obs): one
-        # small device reduction + one flag read per call (not per agent) decides whether learners may read in place
+        # small device reduction per call (not per agent); the flag stays on the device and the kernels branch on it
         from ... import ops
 
-        early = bool(ops.any_nonzero_u8(buffer.done_store[:T - 1].reshape(-1)).item()) if T > 1 else False
-        if not early:
-            store = DeviceStoreRows(buffer, T)
+        early = getattr(buffer, "_early_done_flag", None)  # one allocation per buffer: captured graphs hold its address
+        if early is None:
+            early = buffer._early_done_flag = torch.zeros(1, dtype=torch.int32, device=buffer.device)
+        if T > 1:
+            ops.any_nonzero_u8(buffer.done_store[:T - 1].reshape(-1), out=early)
+        else:
+            early.zero_()
+        store = DeviceStoreRows(buffer, T, early)
     if store is not None and not copies:
         for a, name in enumerate(agents):
             if only is None or name in only:

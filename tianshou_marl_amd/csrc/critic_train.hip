@@ -77,6 +77,8 @@ struct TrainArgs {
     const uint8_t *term;
     int64_t sc_stride, sc_off;
     const float *v_last;     // [Mr / tm_T]: V(obs_next) of the last row of every env block
+    const float *v_full;     // nullable [Mr]: V(obs_next) of every row (env-major), used INSTEAD of the next row's value when
+    const int32_t *use_full; //   *use_full != 0 (an episode ended before the last slot: rows there are not chained)
     float gamma;
     float *dh1;              // [Mr][128]: d loss / d (layer-1 pre-activation) of minibatch row i (kernel B's A operand)
     float *slabs;            // [grid][P - 128 K1]: b1 | W2 | b2 | W3 | b3 gradients of the workgroup
@@ -314,7 +316,8 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
                 if (tid < OWN && i < g.Mr) {
                     const float v = lds[ly.V + tid];
                     const bool last = (i + 1) % g.tm_T == 0;   // last row of its env's block
-                    const float vn = last ? g.v_last[i / g.tm_T] : lds[ly.V + tid + 1];
+                    const float vn = (g.use_full && *g.use_full) ? g.v_full[i]
+                                     : (last ? g.v_last[i / g.tm_T] : lds[ly.V + tid + 1]);
                     const float td = pf_a + g.gamma * vn * pf_b;
                     const float diff = v - td;
                     dq = 2.f * diff / ((float)g.Mr * (float)n_out);
@@ -540,8 +543,9 @@ TSM_EXPORT int tsm_critic_rows_grad_ppo(const float *critic_params, int32_t in_d
 TSM_EXPORT int tsm_critic_rows_grad_td(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_out,
                                        const float *joint_rows, int64_t T, int64_t E, const float *rew,
                                        const uint8_t *terminated, int64_t scalar_stride, int64_t scalar_offset,
-                                       const float *v_last, double gamma, int32_t n_blocks, float *dh1_out,
-                                       float *rest_slabs_out, double *loss_partial_out, void *stream) {
+                                       const float *v_last, const float *v_next_full, const int32_t *use_full,
+                                       double gamma, int32_t n_blocks, float *dh1_out, float *rest_slabs_out,
+                                       double *loss_partial_out, void *stream) {
     TSM_REQUIRE(hidden == kH && pick_kj(in_dim) != 0 && ((in_dim & 3) == 0 || in_dim <= 64) && n_out >= 1 && n_out <= 16,
                 "tsm_critic_rows_grad_td supports hidden == 128, in_dim <= 384 (a multiple of 4 above 64), n_out <= 16 "
                 "(got %d / %d / %d)", hidden, in_dim, n_out);
@@ -549,12 +553,14 @@ TSM_EXPORT int tsm_critic_rows_grad_td(const float *critic_params, int32_t in_di
                 "tsm_critic_rows_grad_td: bad sizes (T %lld, E %lld)", (long long)T, (long long)E);
     TSM_REQUIRE(critic_params && joint_rows && rew && terminated && v_last && dh1_out && rest_slabs_out && loss_partial_out,
                 "tsm_critic_rows_grad_td: null pointer");
+    TSM_REQUIRE(!use_full || v_next_full, "tsm_critic_rows_grad_td: use_full needs v_next_full");
     const int64_t B = T * E;
     TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(B, kRows - 1), "tsm_critic_rows_grad_td: n_blocks = %d out of range", n_blocks);
     TrainArgs g{};
     g.P = critic_params; g.obs = joint_rows; g.rows = nullptr; g.first_row = 0; g.Mr = B; g.tm_T = T; g.tm_E = E;
     g.K1 = in_dim; g.n_out = n_out; g.N = 1;
     g.rew = rew; g.term = terminated; g.sc_stride = scalar_stride; g.sc_off = scalar_offset; g.v_last = v_last;
+    g.v_full = v_next_full; g.use_full = use_full;
     g.gamma = (float)gamma;
     g.dh1 = dh1_out; g.slabs = rest_slabs_out; g.partial = loss_partial_out; g.stamps = g_tsm_stamps;
     return dispatch_train(pick_kj(in_dim), g, 1, n_blocks, tsm_stream(stream));

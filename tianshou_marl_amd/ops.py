@@ -685,10 +685,12 @@ def critic_rows_grad_ppo(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n_a
 
 
 def critic_rows_grad_td(critic_params, joint_store, T: int, E: int, rew, terminated, agent: int, n_agent: int, v_last,
-                        gamma: float, n_out: int, hidden: int = 128, partial=None, ws: dict | None = None):
+                        gamma: float, n_out: int, hidden: int = 128, partial=None, ws: dict | None = None, v_next_full=None,
+                        use_full=None):
     """The critic half of CTDEPolicy.learn (ctde.py:149-172, 188-190) on CHAINED rows in two launches.
     joint_store f32 [T, E, in_dim] (time-major joint rows), rew f32 / terminated u8 [T, E, n_agent] (agent column `agent`),
-    v_last f32 [E].  -> (w1_slabs, rest_slabs, partial f64 = {sum adv, sum sq, 0, 0} per workgroup)."""
+    v_last f32 [E].  use_full (device i32[1]) != 0: targets take v_next_full [T * E] (env-major V(obs_next)) instead of the
+    next row's value.  -> (w1_slabs, rest_slabs, partial f64 = {sum adv, sum sq, 0, 0} per workgroup)."""
     joint_store = _chk(joint_store, torch.float32, "joint_store")
     K1 = joint_store.shape[-1]
     B = T * E
@@ -702,8 +704,9 @@ def critic_rows_grad_td(critic_params, joint_store, T: int, E: int, rew, termina
     term = terminated.view(torch.uint8) if terminated.dtype == torch.bool else _chk(terminated, torch.uint8, "terminated")
     call("tsm_critic_rows_grad_td", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_out,
          ptr(joint_store), T, E, ptr(_chk(rew, torch.float32, "rew")), ptr(term), n_agent, agent,
-         ptr(_chk(v_last, torch.float32, "v_last")), float(gamma), w["nb"], ptr(w["dh1"]), ptr(w["rest"]), ptr(part),
-         stream_ptr())
+         ptr(_chk(v_last, torch.float32, "v_last")), ptr(None if v_next_full is None else _chk(v_next_full, torch.float32, "v_next_full")),
+         ptr(None if use_full is None else _chk(use_full, torch.int32, "use_full")), float(gamma), w["nb"], ptr(w["dh1"]),
+         ptr(w["rest"]), ptr(part), stream_ptr())
     call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(joint_store), K1, None, 0, T, E, B, w["nc"], ptr(w["w1"]), stream_ptr())
     return w["w1"], w["rest"], part
 
