@@ -107,9 +107,10 @@ __global__ __launch_bounds__(kThreads) void critic_rows_forward_kernel(FwdArgs g
         return g.rows ? g.rows[ic] : g.first_row + ic;
     };
     auto fetch_tile = [&](int64_t tile_) {           // data of tile_ whose row ids are in RID
+        const int tq = opaque_v(tid);                // (chunk coordinates recomputed per call, not kept across the tile)
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
-            const int q = tid + kThreads * u, r = (q / CPR) & (kRows - 1), c = q % CPR;
+            const int q = tq + kThreads * u, r = (q / CPR) & (kRows - 1), c = q % CPR;
             const int64_t i = tile_ * kRows + r;
             const bool ok = q < kRows * CPR && i < g.Mr && 4 * c < K1;
             const int64_t row = rid[r];
@@ -128,9 +129,10 @@ __global__ __launch_bounds__(kThreads) void critic_rows_forward_kernel(FwdArgs g
         }
     };
     auto commit_tile = [&]() {
+        const int tq = opaque_v(tid);
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
-            const int q = tid + kThreads * u, r = q / CPR, c = q - r * CPR;
+            const int q = tq + kThreads * u, r = q / CPR, c = q - r * CPR;
             if (q < kRows * CPR) *reinterpret_cast<f4 *>(lds + ly.X + xs_off(r, c, ldx)) = xr[u];
         }
     };

@@ -22,6 +22,13 @@ __device__ __forceinline__ int opaque_s(int x) {
     return x;
 }
 
+// The same for a per-lane value: what is computed from the result is recomputed where it is used instead of being hoisted
+// out of the tile loop and kept (or spilled) across every phase -- registers are the scarce resource of these kernels.
+__device__ __forceinline__ int opaque_v(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // swizzled position (in floats) of 16-B chunk c of tile row r
 __device__ __forceinline__ int xs_off(int r, int c, int ldx) { return r * ldx + (((c & ~15) | ((c & 15) ^ (r & 15))) << 2); }
 
@@ -56,11 +63,13 @@ __device__ __forceinline__ f4 load_w1_frag(const float *__restrict__ src, int k,
 }
 
 // W2 [128][128] -> LDS rows of kLdh floats: 8 16-B loads per thread, all in flight (global memory takes them at any
-// 4-B alignment), 8-B LDS stores (kLdh is even); pad columns zeroed
-__device__ __forceinline__ void stage_w2_rows(float *dst, const float *__restrict__ src) {
-    float4 q[8];
+// 4-B alignment), 8-B LDS stores (kLdh is even); pad columns zeroed.  Two halves, so that a caller can put other loads
+// between the request and the use.
+__device__ __forceinline__ void w2_load(float4 (&q)[8], const float *__restrict__ src) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) q[u] = reinterpret_cast<const float4 *>(src)[threadIdx.x + u * kThreads];
+}
+__device__ __forceinline__ void w2_store(float *dst, const float4 (&q)[8]) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int e4 = threadIdx.x + u * kThreads, r = e4 >> 5, c = (e4 & 31) * 4;
@@ -69,6 +78,11 @@ __device__ __forceinline__ void stage_w2_rows(float *dst, const float *__restric
         *reinterpret_cast<float2 *>(p + 2) = make_float2(q[u].z, q[u].w);
     }
     for (int e = threadIdx.x; e < kH * 2; e += kThreads) dst[(e >> 1) * kLdh + kH + (e & 1)] = 0.f;
+}
+__device__ __forceinline__ void stage_w2_rows(float *dst, const float *__restrict__ src) {
+    float4 q[8];
+    w2_load(q, src);
+    w2_store(dst, q);
 }
 
 int n_cu_dev() {

@@ -47,7 +47,7 @@ struct TrainLay {  // LDS layout in floats
         Q = o; o += kRows * kLdo;       // layer-3 outputs, then d loss / d outputs in place
         V = o; o += kRows;              // row values (LOSS 1)
         DV = o; o += kRows * 16;        // LOSS 0: d loss / d value of a row's agents (N <= 16); final reduction scratch
-        RID = o; o += 2 * kRows;        // row ids of the tile being FETCHED (int64)
+        RID = o; o += 4 * kRows;        // row ids of the tile being FETCHED (int64), two buffers by tile parity
         RIDC = o; o += 2 * kRows;       // row ids of the tile being COMPUTED (int64)
         RED = DV;
         total = o;
@@ -86,11 +86,23 @@ struct TrainArgs {
     long long *stamps;
 };
 
-#define TSTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0 && it == 0) g.stamps[300 + (k)] = (long long)wall_clock64(); } while (0)
+#define TSTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0 && it < 3) g.stamps[300 + 16 * it + (k)] = (long long)wall_clock64(); } while (0)
 
+// Store row of minibatch row i (clamped to a valid row; masked by the caller).  LOSS 1 walks the env-major view of a
+// time-major store: computed, no load (32-bit arithmetic: Mr < 2^31).  LOSS 0: an id list or a contiguous range -- written
+// as a uniform BRANCH, not a select, so that the loaded id is not consumed (and waited for) where it is requested.
+template <int LOSS>
 __device__ __forceinline__ int64_t row_of(const TrainArgs &g, int64_t i) {
-    const int64_t ic = i < g.Mr ? i : g.Mr - 1;  // (Mr >= 1): clamped to a valid row, masked by the caller
-    return g.rows ? g.rows[ic] : (g.tm_T > 0 ? (ic % g.tm_T) * g.tm_E + ic / g.tm_T : g.first_row + ic);
+    const int64_t ic = i < g.Mr ? i : g.Mr - 1;  // (Mr >= 1)
+    if constexpr (LOSS == 1) {
+        const int t_ = (int)g.tm_T, ii = (int)ic;
+        return (int64_t)(ii % t_) * g.tm_E + ii / t_;
+    } else {
+        int64_t r;
+        if (g.rows) r = g.rows[ic];
+        else r = g.first_row + ic;
+        return r;
+    }
 }
 
 template <int KJ, bool VEC, int LOSS>
@@ -105,32 +117,41 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     const int64_t n_tiles = (g.Mr + OWN - 1) / OWN;
     const int oB1 = kH * K1, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + n_out * kH;
     const int col = 16 * w + c16;
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[298] = (long long)wall_clock64();
 
+    // row-id pipeline of threads < 32: ids of row tid of the tiles t (being computed) .. t + 3.  Requested FIRST: id -> row is
+    // a dependent round trip, and the weight loads below cover it
+    const int64_t gs = gridDim.x;
+    int64_t tile = blockIdx.x;
+    int64_t id0 = 0, id1 = 0, id2 = 0, id3 = 0;   // (LOSS 0 only: LOSS 1 computes its row ids where it needs them)
+    if (tid < kRows) {
+        id0 = row_of<LOSS>(g, tile * OWN + tid);
+        id1 = row_of<LOSS>(g, (tile + gs) * OWN + tid);
+        if constexpr (LOSS == 0) {
+            id2 = row_of<LOSS>(g, (tile + 2 * gs) * OWN + tid);
+            id3 = row_of<LOSS>(g, (tile + 3 * gs) * OWN + tid);
+        }
+    }
     // ---- this wave's fragment of W1, once, into registers ----
     f4 w1f[KJ];
 #pragma unroll
     for (int j = 0; j < KJ; ++j) w1f[j] = load_w1_frag<VEC>(g.P + (size_t)col * K1, 16 * j + 4 * kq, K1);
-    // ---- resident weights: W2, W3 (rows >= n_out zero), biases ----
-    stage_w2_rows(lds + ly.W2, g.P + oW2);
-    for (int e = tid; e < 16 * kLdh; e += kThreads) {
-        const int r = e / kLdh, c = e - r * kLdh;
-        lds[ly.W3 + e] = (r < n_out && c < kH) ? g.P[oW3 + r * kH + c] : 0.f;
-    }
-    if (tid < kH) { lds[ly.B1 + tid] = g.P[oB1 + tid]; lds[ly.B2 + tid] = g.P[oB2 + tid]; }
-    if (tid < 16) lds[ly.B3 + tid] = tid < n_out ? g.P[oB3 + tid] : 0.f;
+    float4 w2q[8];            // W2 requested here, stored to LDS after the first tile's rows have been requested too
+    w2_load(w2q, g.P + oW2);
 
     // ---- staging of a tile (as csrc/critic_rows.hip): thread -> chunks q = tid + 512 u of the 32 x (4 KJ) chunk grid ----
     constexpr int CPR = 4 * KJ;
     constexpr int NX = (kRows * CPR + kThreads - 1) / kThreads;
     f4 xr[NX];
     int64_t *rid = reinterpret_cast<int64_t *>(lds + ly.RID), *ridc = reinterpret_cast<int64_t *>(lds + ly.RIDC);
-    auto fetch_tile = [&](int64_t tile_) {           // data of tile_ whose row ids are in RID
+    auto fetch_tile = [&](int64_t tile_, int par) {  // data of tile_ whose row ids are in RID buffer `par`
+        const int tq = opaque_v(tid);                // (chunk coordinates recomputed per call, not kept across the tile)
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
-            const int q = tid + kThreads * u, r = (q / CPR) & (kRows - 1), c = q % CPR;
+            const int q = tq + kThreads * u, r = (q / CPR) & (kRows - 1), c = q % CPR;
             const int64_t i = tile_ * OWN + r;
             const bool ok = q < kRows * CPR && i < g.Mr && 4 * c < K1;
-            const int64_t row = rid[r];
+            const int64_t row = rid[par * kRows + r];
             if constexpr (VEC) {
                 const int cc = 4 * c < K1 ? 4 * c : K1 - 4;
                 const float4 v = *reinterpret_cast<const float4 *>(g.obs + row * K1 + cc);
@@ -146,9 +167,10 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         }
     };
     auto commit_tile = [&]() {
+        const int tq = opaque_v(tid);
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
-            const int q = tid + kThreads * u, r = (q / CPR) & (kRows - 1), c = q % CPR;
+            const int q = tq + kThreads * u, r = (q / CPR) & (kRows - 1), c = q % CPR;
             if (q < kRows * CPR) *reinterpret_cast<f4 *>(lds + ly.X + xs_off(r, c, ldx)) = xr[u];
         }
     };
@@ -162,34 +184,36 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     float gB1 = 0.f;           // db1[col], this lane's rows (folded over kq at the end)
     double t_a = 0.0, t_b = 0.0;  // loss statistics (LOSS 0: t_b = sum vf; LOSS 1: t_a = sum adv, t_b = sum sq)
 
-    // row-id pipeline of threads < 32: ids of row tid of the tiles t (being computed) .. t + 3
-    const int64_t gs = gridDim.x;
-    int64_t tile = blockIdx.x;
-    int64_t id0 = 0, id1 = 0, id2 = 0, id3 = 0;
-    if (tid < kRows) {
-        id0 = row_of(g, tile * OWN + tid);
-        id1 = row_of(g, (tile + gs) * OWN + tid);
-        id2 = row_of(g, (tile + 2 * gs) * OWN + tid);
-        id3 = row_of(g, (tile + 3 * gs) * OWN + tid);
-        rid[tid] = id0;
-    }
+    if (tid < kRows) rid[tid] = id0;
     __syncthreads();
-    fetch_tile(tile);
+    fetch_tile(tile, 0);      // the first tile's rows are in flight behind the weights ...
+    // ---- resident weights: W2, W3 (rows >= n_out zero), biases ----
+    w2_store(lds + ly.W2, w2q);
+    for (int e = tid; e < 16 * kLdh; e += kThreads) {
+        const int r = e / kLdh, c = e - r * kLdh;
+        lds[ly.W3 + e] = (r < n_out && c < kH) ? g.P[oW3 + r * kH + c] : 0.f;
+    }
+    if (tid < kH) { lds[ly.B1 + tid] = g.P[oB1 + tid]; lds[ly.B2 + tid] = g.P[oB2 + tid]; }
+    if (tid < 16) lds[ly.B3 + tid] = tid < n_out ? g.P[oB3 + tid] : 0.f;
     commit_tile();
     __syncthreads();          // every thread has read RID
     if (tid < kRows) rid[tid] = id1;
     __syncthreads();
-    fetch_tile(tile + gs);
-    __syncthreads();          // (RID is rewritten at the top of the loop)
+    fetch_tile(tile + gs, 0);
+    __syncthreads();          // (RID buffer 0 is rewritten at the top of the loop)
 
     int it = 0;
     for (; tile < n_tiles; tile += gs, ++it) {
         TSTAMP(0);
         if (tid < kRows) {    // published by barrier (A)
-            ridc[tid] = id0;
-            rid[tid] = id2;
-            id0 = id1; id1 = id2; id2 = id3;
-            id3 = row_of(g, (tile + 4 * gs) * OWN + tid);
+            if constexpr (LOSS == 0) {
+                ridc[tid] = id0;
+                rid[(it & 1) * kRows + tid] = id2;
+                id0 = id1; id1 = id2; id2 = id3;
+            } else {
+                ridc[tid] = row_of<LOSS>(g, tile * OWN + tid);
+                rid[(it & 1) * kRows + tid] = row_of<LOSS>(g, (tile + 2 * gs) * OWN + tid);
+            }
         }
         // ---- P1: H1 = relu(X W1^T + b1); W1 from registers, X by ds_read_b128 ----
         {
@@ -214,8 +238,10 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         }
         __syncthreads();  // (A) H1 complete; every wave is done with X; RID / RIDC published
         TSTAMP(1);
-        commit_tile();                // the next tile's rows (in registers since the previous tile) ...
-        fetch_tile(tile + 2 * gs);    // ... and the loads of the one after it fly during the rest of this tile
+        commit_tile();                // the next tile's rows: requested at the end of the previous tile, they flew during L1
+        if constexpr (LOSS == 0) {
+            if (tid < kRows) id3 = row_of<LOSS>(g, (tile + 4 * gs) * OWN + tid);  // (three tiles ahead)
+        }
         // loss inputs of this tile: row id -> scalars are dependent global loads; they fly during layers 2 and 3
         float pf_a = 0.f, pf_b = 0.f;
         if constexpr (LOSS == 0) {
@@ -404,6 +430,11 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
                 }
         }
         __syncthreads();  // H1 / H2 / Q are free for the next tile
+        // the rows of the tile after the next: in flight during the next tile's layer 1, committed behind its barrier (A)
+        // (requested HERE and not a phase earlier: 24 registers less across the backward phases)
+        // (RID buffer it & 1: written at the top of this iteration, published by its barrier (A); the next iteration writes
+        // the other buffer, so these reads need no barrier behind them)
+        fetch_tile(tile + 2 * gs, it & 1);
         TSTAMP(6);
     }
 
@@ -437,6 +468,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
             g.partial[4 * blockIdx.x + 1] = bb;
             g.partial[4 * blockIdx.x + 2] = 0.0;
             g.partial[4 * blockIdx.x + 3] = 0.0;
+            if (g.stamps && blockIdx.x == 0) g.stamps[299] = (long long)wall_clock64();
         }
     }
 }
