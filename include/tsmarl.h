@@ -113,6 +113,12 @@ int tsm_value_next_select(const float *v_s, const float *v_last, const float *v_
  * batches hold): v_next[e][t][u] = v_s[e][t + 1][u] (t < T - 1), v_last[e][u] (t = T - 1), or v_full when *flag != 0. */
 int tsm_value_next_select_env_major(const float *v_s, const float *v_last, const float *v_full, const int32_t *flag,
                                     int64_t E, int64_t T, int64_t U, float *v_next_out, void *stream);
+/* V(obs_next) for a buffer that does not store obs_next (ReplayBuffer(ignore_obs_next=True), buffer_base.py:612-616: obs_next
+ * is read as obs[next(index)], and next(index) is the row itself at an episode end and at the newest row): for T unrotated,
+ * equally filled slots v_next[t][u] = (t == T - 1 || done[t][u / lanes_per_env]) ? v_s[t][u] : v_s[t + 1][u].
+ * v_s, v_next_out f32 [T][U]; done u8 [T][U / lanes_per_env]. */
+int tsm_value_next_index(const float *v_s, const uint8_t *done, int64_t T, int64_t U, int64_t lanes_per_env,
+                         float *v_next_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * VectorReplayBuffer  [a8, a9]

@@ -193,3 +193,59 @@ def test_wrapped_and_ctde_policies_take_the_persistent_rollouts(kind):
             assert np.array_equal(a[k], b[k]), k
         else:
             assert a[k] == b[k], k
+
+
+@pytest.mark.parametrize("kind", ["ppo64", "generic128", "generic128_global"])
+def test_ignore_obs_next_buffer_collects_and_updates_with_the_reference_semantics(kind):
+    """`VectorReplayBuffer(..., ignore_obs_next=True)` (buffer_base.py:612-616): no obs_next store; a row's obs_next is READ as
+    obs[next(index)], next(index) being the row itself at an episode end and at the newest row.  The persistent rollouts
+    skip the obs_next rows (half of their HBM writes) and leave every other store bit-identical; the update takes
+    V(obs_next) from V(obs) at next(index) (tsm_value_next_index) -- bit-identical to an update on a full buffer whose
+    obs_next rows hold exactly those observations.  Episodes end in the middle of the collected slots (max_cycles 10, 25
+    slots)."""
+    from tianshou_marl_amd.algorithm import GenericPPO
+    from tianshou_marl_amd.utils.net import MLPActorCritic
+
+    n_env, N, T, cyc = 48, 3, 25, 10
+    finals = []
+    for ign in (True, False):
+        env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=cyc, device=DEV, seed=5)
+        D = env.obs_dim
+        if kind == "ppo64":
+            net = DiscreteActorCritic(D, 5, 64, device=DEV, seed=2)
+            algo = PPO(net=net, seed=7, shuffle="device", dispatch="per_agent")
+        else:
+            glob = kind.endswith("global")
+            net = MLPActorCritic(D, 5, (128, 128), critic_obs_dim=N * D if glob else None, device=DEV, seed=2)
+            algo = GenericPPO(net=net, critic_input="global" if glob else "local", n_agent=N, seed=7, shuffle="device",
+                              dispatch="pooled" if glob else "per_agent")
+        buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=DEV, ignore_obs_next=ign)
+        col = Collector(algo, env, buf)
+        col.reset()
+        assert col._can_fuse()
+        stores = []
+        for _ in range(3):  # eager update, captured update, replay
+            with policy_within_training_step(algo):
+                col.collect(n_step=n_env * T)
+                assert (buf.obs_next_store is None) == ign
+                if not ign:  # what an ignore_obs_next buffer hands out as obs_next, written into the full buffer
+                    done = buf.done_store[:T].bool()
+                    self_next = done.clone()
+                    self_next[T - 1] = True
+                    nxt = torch.where(self_next, torch.arange(T, device=DEV).view(T, 1), torch.arange(T, device=DEV).view(T, 1) + 1)
+                    buf.obs_next_store[:T] = buf.obs_store[:T][nxt.clamp(max=T - 1), torch.arange(n_env, device=DEV).view(1, -1)]
+                    buf.policy_outputs_version = None   # (the rollout's V(obs_next) belongs to the true next observation)
+                    buf.behaviour_outputs_version = None
+                    buf.rows_chained = False
+                else:
+                    idx = np.arange(n_env * T)  # the reference layout on read: obs_next = obs[next(index)]
+                    got = buf[idx]
+                    assert np.array_equal(got.obs_next, got.obs[buf.index.next(torch.as_tensor(idx, device=DEV)).cpu().numpy()])
+                stores.append([x[:T].clone() for x in (buf.obs_store, buf.act_store, buf.rew_store, buf.term_store,
+                                                       buf.trunc_store, buf.logp_store, buf.done_store)])
+                algo.update(buf, 480, 1)
+            col.reset_buffer(keep_statistics=True)
+        finals.append((net.flat.data.clone(), stores))
+    assert torch.equal(finals[0][0], finals[1][0])
+    for a, b in zip(finals[0][1], finals[1][1]):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))

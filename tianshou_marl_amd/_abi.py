@@ -149,6 +149,7 @@ SIGNATURES = {
     "tsm_mlp_forward_cond": (_int, [C.POINTER(tsm_mlp_desc), _p, _p, _i64, _p, _p, _p]),
     "tsm_any_nonzero_u8": (_int, [_p, _i64, _p, _p]),
     "tsm_value_next_select": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _p]),
+    "tsm_value_next_index": (_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "tsm_value_next_select_env_major": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "tsm_mlp_backward": (_int, [C.POINTER(tsm_mlp_desc), _p, _p, _i64, _p, _p, _p, _i32, _p, _i64, _p]),
     "tsm_policy_param_count": (_i64, [_i32, _i32, _i32]),

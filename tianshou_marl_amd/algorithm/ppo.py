@@ -204,17 +204,31 @@ class PPO(nn.Module):
         P = self.net.flat.data
         obs = buffer.obs_store[:T].reshape(T * L, D)
         act = buffer.act_store[:T].reshape(T * L)
-        if buffer.obs_next_store is None:
-            raise ValueError("PPO.update needs a buffer that stores obs_next (ignore_obs_next=False)")
         # critic(obs), critic(obs_next), logp_old: two fused passes (no max_batchsize chunking needed in HBM)
         cur = ops.policy_forward(P, obs, self.net.n_act, self.net.hidden, image=self.net.image, mode="given", act=act, want_logits=False)
-        nxt = ops.policy_forward(P, buffer.obs_next_store[:T].reshape(T * L, D), self.net.n_act, self.net.hidden,
-                                 mode="none", want_logits=False)
-        v_s, v_next, logp_old = cur["value"].view(T, L), nxt["value"].view(T, L), cur["logp"]
+        v_s, logp_old = cur["value"].view(T, L), cur["logp"]
+        if buffer.obs_next_store is None:  # ignore_obs_next: obs_next is obs[next(index)] (buffer_base.py:612-616)
+            v_next = self._next_values_by_index(buffer, v_s, T, rows)
+        else:
+            v_next = ops.policy_forward(P, buffer.obs_next_store[:T].reshape(T * L, D), self.net.n_act, self.net.hidden,
+                                        mode="none", want_logits=False)["value"].view(T, L)
         ret, adv = self._gae(v_s, v_next, buffer.rew_store[:T].reshape(T, L), buffer.term_store[:T].reshape(T, L),
                              buffer.trunc_store[:T].reshape(T, L), N, env_start=env_start, env_len=env_len, rows=rows)
         return dict(T=T, rows=rows, obs=obs, act=act, v_s=v_s.reshape(-1), ret=ret.reshape(-1), adv=adv.reshape(-1),
                     logp_old=logp_old, n_env=B, n_agent=N)
+
+    def _next_values_by_index(self, buffer: DeviceVectorReplayBuffer, v_s: torch.Tensor, T: int, rows, out=None) -> torch.Tensor:
+        """V(obs_next) [T, L] for a buffer WITHOUT an obs_next store (`ignore_obs_next=True`): the reference then reads
+        obs_next as obs[next(index)] (buffer_base.py:612-616), next(index) being the row itself at an episode end and at the
+        newest row -- so the critic pass over obs_next is a re-indexing of the pass over obs.  Uniform, unrotated slots:
+        one launch (tsm_value_next_index); ragged / rotated sub-buffers: the buffer's own `next` on the flat indices."""
+        B, N = buffer.buffer_num, buffer.n_agent
+        if rows is None:
+            return ops.value_next_index(v_s, buffer.done_store[:T], T, B * N, N, out=out)
+        S, dev = buffer.sub_size, self.device
+        flat = (torch.arange(B, device=dev).view(1, B) * S + torch.arange(S, device=dev).view(S, 1)).reshape(-1)
+        nxt = buffer.index.next(flat)
+        return v_s.view(S, B, N)[nxt % S, torch.div(nxt, S, rounding_mode="floor")].reshape(S, B * N)
 
     def _gae(self, v_s, v_next, rew, term, trunc, N: int, env_start=None, env_len=None, rows=None, out=None):
         """compute_episodic_return on [T, L] lanes, with the return_scaling arithmetic of a2c.py:132-146 when enabled:
@@ -432,15 +446,15 @@ class PPO(nn.Module):
                 return None  # ragged / rotated sub-buffers: eager path with explicit index lists
         if T == 0:
             return None
-        if buffer.obs_next_store is None:
-            raise ValueError("PPO.update needs a buffer that stores obs_next (ignore_obs_next=False)")
+        no_next = buffer.obs_next_store is None  # ignore_obs_next: V(obs_next) = V(obs) at next(index), see _next_values_by_index
         B, N, D = buffer.buffer_num, buffer.n_agent, buffer.obs_dim
         L, dev = B * N, self.device
         per_agent = self.dispatch == "per_agent"
         groups = list(range(N)) if per_agent else [None]
         n_g = T * B if per_agent else T * L
         bounds = split_bounds(n_g, batch_size or -1, merge_last=True)
-        stored = buffer.vnext_store is not None and buffer.policy_outputs_version == self.param_version
+        # (the rollout's stored V(obs_next) is that of the TRUE next observation: not what an ignore_obs_next buffer hands out)
+        stored = buffer.vnext_store is not None and buffer.policy_outputs_version == self.param_version and not no_next
         key = ("graph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored,
                self._grad_sync is not None, self.graph_collectives)
         g = self._ws.get(key)
@@ -465,7 +479,7 @@ class PPO(nn.Module):
                      step_dev=torch.zeros(1, dtype=torch.int64, device=dev), v_s=f(T, L), v_next=f(T, L),
                      logp=f(T * L), ret=f(T, L), adv=f(T, L), n_steps=n_steps, flat_g=f(P.numel()))
             obs = buffer.obs_store[:T].reshape(T * L, D)
-            obs_next = buffer.obs_next_store[:T].reshape(T * L, D)
+            obs_next = None if no_next else buffer.obs_next_store[:T].reshape(T * L, D)
             act = buffer.act_store[:T].reshape(T * L)
             rew, term, trunc = (x[:T].reshape(T, L) for x in (buffer.rew_store, buffer.term_store, buffer.trunc_store))
 
@@ -495,8 +509,11 @@ class PPO(nn.Module):
                                        image=img,
                                        out=dict(value=w["v_s"].view(-1), logp=None if recompute else w["logp"],
                                                 logits=None))
-                    ops.policy_forward(P, obs_next, A, H, mode="none", image=img,
-                                       out=dict(value=w["v_next"].view(-1), logits=None))
+                    if no_next:
+                        self._next_values_by_index(buffer, w["v_s"], T, None, out=w["v_next"])
+                    else:
+                        ops.policy_forward(P, obs_next, A, H, mode="none", image=img,
+                                           out=dict(value=w["v_next"].view(-1), logits=None))
                 self._gae(w["v_s"], w["v_next"], rew, term, trunc, N, out=(w["ret"], w["adv"]))
 
             def body():

@@ -164,19 +164,18 @@ class GenericPPO(PPO):
         if self.critic_input == "global" and N != self.n_agent:
             raise ValueError(f"buffer holds {N} agents, the centralized critic was built for {self.n_agent}")
         L = B * N
-        if buffer.obs_next_store is None:
-            raise ValueError("PPO.update needs a buffer that stores obs_next (ignore_obs_next=False)")
+        no_next = buffer.obs_next_store is None  # ignore_obs_next (PPO._next_values_by_index)
         obs = buffer.obs_store[:T].reshape(T * L, D)
-        obs_next = buffer.obs_next_store[:T].reshape(T * L, D)
+        obs_next = None if no_next else buffer.obs_next_store[:T].reshape(T * L, D)
         act = buffer.act_store[:T].reshape(T * L)
         glob = self.critic_input == "global"
         joint = buffer.obs_store[:T].reshape(T * B, N * D) if glob else None
-        joint_next = buffer.obs_next_store[:T].reshape(T * B, N * D) if glob else None
+        joint_next = buffer.obs_next_store[:T].reshape(T * B, N * D) if glob and not no_next else None
         reuse = allow_stored and self.reuse_rollout_outputs and rows is None and buffer.logp_store is not None
         # logp_old / v_s produced by the rollout with these very parameters (same kernels, row-wise arithmetic: the same bits
         # as recomputing them, a2c.py:121-127 / ppo.py:157-161) are taken from the buffer
         vu_s = None
-        if reuse and buffer.behaviour_outputs_version == self.param_version:
+        if reuse and buffer.behaviour_outputs_version == self.param_version and not no_next:
             v_s = buffer.vs_store[:T].reshape(T, L)
         else:
             vu_s = self._unit_values(obs, joint)
@@ -185,7 +184,9 @@ class GenericPPO(PPO):
             logp_old = buffer.logp_store[:T].reshape(T * L)
         else:
             logp_old, _ = ops.categorical_logp_entropy(FlatMLP.forward(self.net.actor, obs, save=False), act)
-        if vu_s is not None and rows is None and self.shift_next_values and buffer.rows_chained is True:
+        if no_next:
+            v_next = self._next_values_by_index(buffer, v_s.contiguous(), T, rows)
+        elif vu_s is not None and rows is None and self.shift_next_values and buffer.rows_chained is True:
             v_next = self._lanes(self._next_values_chained(vu_s, joint_next if glob else obs_next, buffer.done_store,
                                                            T)).view(T, L)
         else:
@@ -340,7 +341,7 @@ class GenericPPO(PPO):
         from ..data.stats import MapTrainingStats
 
         T = buffer.host_uniform_len()
-        if not T or buffer.obs_next_store is None:
+        if not T:
             return None
         B, N = buffer.buffer_num, buffer.n_agent
         per_agent = self.dispatch == "per_agent"
@@ -350,7 +351,7 @@ class GenericPPO(PPO):
                   buffer.logp_outputs_version == self.param_version)
         # every property of the buffer that `_preprocess_batch` branches on at CAPTURE time belongs to the key: a graph
         # captured over chained rows (V(obs_next) from the next slot's V(obs)) must never replay on rows that are not
-        chained = buffer.rows_chained is True and self.shift_next_values
+        chained = buffer.rows_chained is True and self.shift_next_values and buffer.obs_next_store is not None
         key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored, chained,
                self._grad_sync is not None, self.graph_collectives)
         w = self._ws.get(key)

@@ -488,7 +488,30 @@ __global__ void value_next_select_em_kernel(const float *__restrict__ v_s, const
     v_next[i] = t + 1 < T ? v_s[i + U] : v_last[e * U + u];
 }
 
+// ignore_obs_next buffers (buffer_base.py:612-616): obs_next of a row is READ as obs[next(index)], and next(index) is the
+// row itself at an episode end and at the newest row, else the following slot.  For T unrotated, equally filled slots:
+//   V(obs_next)[t][u] = (t == T - 1 || done[t][u / lanes_per_env]) ? V(obs)[t][u] : V(obs)[t + 1][u]
+__global__ void value_next_index_kernel(const float *__restrict__ v_s, const uint8_t *__restrict__ done, int64_t T,
+                                        int64_t U, int64_t lanes_per_env, float *__restrict__ v_next) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * U) return;
+    const int64_t t = i / U, u = i - t * U;
+    const bool self = t + 1 >= T || done[t * (U / lanes_per_env) + u / lanes_per_env] != 0;
+    v_next[i] = self ? v_s[i] : v_s[i + U];
+}
+
 }  // namespace
+
+TSM_EXPORT int tsm_value_next_index(const float *v_s, const uint8_t *done, int64_t T, int64_t U, int64_t lanes_per_env,
+                                    float *v_next_out, void *stream) {
+    TSM_REQUIRE(T >= 1 && U >= 1 && lanes_per_env >= 1 && U % lanes_per_env == 0,
+                "tsm_value_next_index: T, U >= 1 and U a multiple of lanes_per_env");
+    TSM_REQUIRE(v_s && done && v_next_out, "tsm_value_next_index: null pointer");
+    hipLaunchKernelGGL(value_next_index_kernel, dim3((unsigned)ceil_div(T * U, 256)), dim3(256), 0, tsm_stream(stream), v_s,
+                       done, T, U, lanes_per_env, v_next_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
 
 TSM_EXPORT int tsm_value_next_select_env_major(const float *v_s, const float *v_last, const float *v_full,
                                                const int32_t *flag, int64_t E, int64_t T, int64_t U, float *v_next_out,

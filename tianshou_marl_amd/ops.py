@@ -871,6 +871,18 @@ def value_next_select(v_s, v_last, v_full, flag, T: int, U: int, out=None):
     return res
 
 
+def value_next_index(v_s, done, T: int, U: int, lanes_per_env: int = 1, out=None):
+    """V(obs_next) [T, U] of a buffer without an obs_next store (ignore_obs_next, buffer_base.py:612-616): the next slot's
+    V(obs), or the row's own at an episode end (`done` u8 [T, U / lanes_per_env]) and in the newest slot."""
+    v_s = _chk(v_s, torch.float32, "v_s")
+    done = done.contiguous().view(torch.uint8) if done.dtype == torch.bool else _chk(done, torch.uint8, "done")
+    if v_s.numel() != T * U or done.numel() * lanes_per_env != T * U:
+        raise ValueError("value_next_index: shapes do not match T x U")
+    res = out if out is not None else torch.empty(T, U, dtype=torch.float32, device=v_s.device)
+    call("tsm_value_next_index", ptr(v_s), ptr(done), T, U, lanes_per_env, ptr(res), stream_ptr())
+    return res
+
+
 def value_next_select_env_major(v_s, v_last, v_full, flag, E: int, T: int, U: int, out=None):
     """`value_next_select` for env-major rows [E, T, U] (the per-agent batches of the MARL trainers)."""
     v_s, v_last, v_full = (_chk(t, torch.float32, n) for t, n in ((v_s, "v_s"), (v_last, "v_last"), (v_full, "v_full")))
