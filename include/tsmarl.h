@@ -616,6 +616,24 @@ int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim,
                         int64_t tm_T, int64_t tm_E, int64_t Mr, int32_t n_chunks, float *w1_slabs_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Latency-grade all-reduce of a small vector over peer-mapped memory  [SURVEY 8e: the 45 KB shared-policy gradient]
+ * Replaces  torch.distributed.all_reduce(flat_grad) in front of Optimizer.step (algorithm_base.py:485-498) for env-sharded
+ *           replicas on one node (the reference itself has no distributed path: utils/net/common.py:477-519).
+ * One-shot write-to-peers over IPC-mapped fine-grained memory, one launch per call, rank-ordered sum (bit-identical on
+ * every rank); csrc/p2p.hip has the protocol.  Setup: every rank tsm_p2p_create -> tsm_p2p_export -> the ranks exchange
+ * the tsm_p2p_ipc_handle_bytes()-byte handles by any channel (the host binding uses the process group) -> tsm_p2p_import of
+ * every peer.  tsm_p2p_failed: 1 after a peer failed to answer within the bounded spin (no hang).  Opt-in
+ * (TSM_P2P_ALLREDUCE=1 in the host binding); RCCL stays the default.
+ * ------------------------------------------------------------------------------------------- */
+int64_t tsm_p2p_ipc_handle_bytes(void);
+int tsm_p2p_create(int32_t rank, int32_t world, int64_t max_floats, void **handle_out);
+int tsm_p2p_export(void *handle, void *ipc_handle_out);
+int tsm_p2p_import(void *handle, int32_t peer, const void *ipc_handle);
+int tsm_p2p_all_reduce(void *handle, float *data, int64_t n, void *stream);
+int tsm_p2p_failed(void *handle);
+int tsm_p2p_destroy(void *handle);
+
+/* ---------------------------------------------------------------------------------------------
  * CTDE global state  [a16]
  * Replaces  GlobalStateConstructor.build("concatenate" | "mean")
  *           (tianshou/algorithm/multiagent/ctde.py:291-300) for per-agent arrays [B][D] given in

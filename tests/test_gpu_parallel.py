@@ -240,3 +240,108 @@ def test_rccl_collectives_are_captured_into_the_update_graphs(tmp_path):
             print(f.read_text())
         raise
     assert (tmp_path / "ok").exists()
+
+
+def _p2p_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    """Two processes on cuda:0, handles exchanged over gloo: the one-shot peer-memory all-reduce (csrc/p2p.hip)."""
+    import torch.distributed as dist
+
+    from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.parallel import P2PAllReduce, attach_data_parallel
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 11142
+        p2p = P2PAllReduce(dist, None, torch.device("cuda", 0), n)
+        gen = [torch.Generator(device=DEV).manual_seed(100 + r) for r in range(world)]
+        # (a) 300 back-to-back calls, no host synchronisation in between: both inbox halves are reused many times
+        xs = [[torch.randn(n, device=DEV, generator=gen[r]) for _ in range(300)] for r in range(world)]
+        mine = [x.clone() for x in xs[rank]]
+        for x in mine:
+            p2p.all_reduce_sum_(x)
+        torch.cuda.synchronize()
+        p2p.check()
+        for k in range(300):
+            assert torch.equal(mine[k], xs[0][k] + xs[1][k]), k  # the rank-ordered sum, bit for bit
+        # shorter vectors and odd lengths use the same inbox
+        for m in (1, 31, 257, 11141):
+            y = torch.full((m,), float(rank + 1), device=DEV)
+            p2p.all_reduce_sum_(y)
+            assert torch.equal(y, torch.full((m,), 3.0, device=DEV))
+        # (b) captured into a hipGraph and replayed: the call's stamp lives in device memory
+        buf = torch.zeros(n, device=DEV)
+        src = torch.zeros(n, device=DEV)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            buf.copy_(src)
+            p2p.all_reduce_sum_(buf)
+            p2p.all_reduce_sum_(buf)   # two calls per replay: sum of sums
+        for k in range(40):
+            src.fill_(float(k + rank))
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(buf, torch.full((n,), 2.0 * (2 * k + 1), device=DEV)), k
+        p2p.check()
+        with pytest.raises(ValueError):
+            p2p.all_reduce_sum_(torch.zeros(n + 1, device=DEV))
+        p2p.close()
+        # (c) the product path: PPO.update on two env shards with the gradient on the peer-memory path equals the same update
+        # with the gradient on the process group's all-reduce (two ranks: x0 + x1 either way), bit for bit
+        finals = {}
+        for mode in ("p2p", "gloo"):
+            os.environ["TSM_P2P_ALLREDUCE"] = "1" if mode == "p2p" else "0"
+            np.random.seed(11 + rank)
+            env = DeviceSimpleSpreadVectorEnv(32, 3, device=DEV, seed=50 + rank)
+            bufr = DeviceVectorReplayBuffer(32 * 25, 32, 3, D, device=DEV)
+            algo = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=20 + rank), lr=1e-3, dispatch="per_agent", shuffle="numpy",
+                       seed=7 + rank)
+            sync = attach_data_parallel(algo, dist)
+            assert (sync.p2p is not None) == (mode == "p2p")
+            col = Collector(algo, env, bufr)
+            col.reset()
+            for _ in range(3):
+                with policy_within_training_step(algo):
+                    col.collect(n_step=32 * 25)
+                    algo.update(bufr, 256, 2)
+                col.reset_buffer(keep_statistics=True)
+            if sync.p2p is not None:
+                sync.p2p.check()
+            finals[mode] = (algo.net.flat.data.clone(), algo.exp_avg_sq.clone())
+        os.environ.pop("TSM_P2P_ALLREDUCE", None)
+        assert torch.equal(finals["p2p"][0], finals["gloo"][0]) and torch.equal(finals["p2p"][1], finals["gloo"][1])
+        np.save(os.path.join(out_dir, f"p{rank}.npy"), finals["p2p"][0].cpu().numpy())
+    except BaseException:
+        import traceback
+
+        with open(os.path.join(out_dir, f"err{rank}.txt"), "w") as f:
+            traceback.print_exc(file=f)
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_peer_memory_all_reduce_with_two_processes_on_one_gpu(tmp_path):
+    """SURVEY.md section 8e, csrc/p2p.hip: one-shot write-to-peers all-reduce over IPC-mapped fine-grained memory -- rank-
+    ordered sums bit for bit, inbox halves reused without host synchronisation, replay from a hipGraph, and the product's
+    update with the gradient on this path equal to the process group's all-reduce."""
+    import torch.multiprocessing as mp
+
+    try:
+        mp.spawn(_p2p_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    except Exception:
+        for r in range(2):
+            f = tmp_path / f"err{r}.txt"
+            if f.exists():
+                print(f"---- rank {r} ----\n{f.read_text()}")
+        raise
+    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
+    assert np.array_equal(p0, p1) and np.isfinite(p0).all()

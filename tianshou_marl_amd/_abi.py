@@ -185,6 +185,13 @@ SIGNATURES = {
     "tsm_critic_rows_dw1_chunks": (_int, [_i64, _i32]),
     "tsm_ctde_finalize": (_int, [_p, _i32, _p, _i32, _i64, _p, _p, _p]),
     "tsm_critic_rows_dw1": (_int, [_p, _p, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p]),
+    "tsm_p2p_ipc_handle_bytes": (_i64, []),
+    "tsm_p2p_create": (_int, [_i32, _i32, _i64, C.POINTER(_p)]),
+    "tsm_p2p_export": (_int, [_p, _p]),
+    "tsm_p2p_import": (_int, [_p, _i32, _p]),
+    "tsm_p2p_all_reduce": (_int, [_p, _p, _i64, _p]),
+    "tsm_p2p_failed": (_int, [_p]),
+    "tsm_p2p_destroy": (_int, [_p]),
     "tsm_reduce_slabs_segs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
     "tsm_adam_step_segs": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _p, _f64, _p, _f64, _f64, _f64, _f64, _f64, _p, _p]),
     "tsm_ppo_update_grid": (_int, [_i64, _i32]),
@@ -193,7 +200,7 @@ SIGNATURES = {
                                     C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p, _p]),
 }
 
-_NO_STATUS = {"tsm_critic_rows_forward_supported", "tsm_critic_rows_param_count", "tsm_critic_rows_grad_grid", "tsm_critic_rows_dw1_chunks", "tsm_ppo_critic_rows_supported", "tsm_ppo_critic_rows_param_count", "tsm_ppo_critic_rows_grid",
+_NO_STATUS = {"tsm_p2p_ipc_handle_bytes", "tsm_p2p_failed", "tsm_critic_rows_forward_supported", "tsm_critic_rows_param_count", "tsm_critic_rows_grad_grid", "tsm_critic_rows_dw1_chunks", "tsm_ppo_critic_rows_supported", "tsm_ppo_critic_rows_param_count", "tsm_ppo_critic_rows_grid",
               "tsm_ppo_actor_rows_supported", "tsm_ppo_actor_rows_param_count", "tsm_ppo_actor_rows_grid",
               "tsm_rms_update_work_elems", "tsm_ppo_adv_stats_work_elems", "tsm_abi_version", "tsm_last_error", "tsm_stream_abort_capture", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
               "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems",

@@ -24,6 +24,69 @@ def shard_range(n_total: int, world_size: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class P2PAllReduce:
+    """One-shot all-reduce of a small f32 vector over peer-mapped memory (csrc/p2p.hip): every rank stores its vector into
+    every peer's IPC-mapped inbox, stamps a flag, and sums the senders in rank order -- ONE launch per call, no ring, the
+    same bits on every rank.  Setup exchanges the IPC handles through the process group (any backend); any failure raises
+    (a data-parallel job must not limp on with one rank on another path).  Opt-in: TSM_P2P_ALLREDUCE=1."""
+
+    def __init__(self, dist, group, device: torch.device, max_floats: int) -> None:
+        import ctypes as C
+
+        from . import _abi
+
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.max_floats = int(max_floats)
+        self.device = device
+        torch.cuda.set_device(device)
+        h = C.c_void_p()
+        _abi.call("tsm_p2p_create", self.rank, self.world, self.max_floats, C.byref(h))
+        self._h = h
+        nb = int(_abi.call("tsm_p2p_ipc_handle_bytes"))
+        mine = (C.c_ubyte * nb)()
+        _abi.call("tsm_p2p_export", self._h, mine)
+        on_dev = dist.get_backend(group) == "nccl"
+        t = torch.frombuffer(bytearray(mine), dtype=torch.uint8).clone()
+        t = t.to(device) if on_dev else t
+        gathered = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(gathered, t, group=group)
+        for r, g in enumerate(gathered):
+            if r == self.rank:
+                continue
+            raw = bytes(g.cpu().numpy().tobytes())
+            _abi.call("tsm_p2p_import", self._h, r, (C.c_ubyte * nb).from_buffer_copy(raw))
+        dist.barrier(group=group)  # every rank has mapped every inbox before the first store
+
+    def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
+        from . import _abi
+
+        if flat.dtype != torch.float32 or not flat.is_cuda or not flat.is_contiguous() or flat.numel() > self.max_floats:
+            raise ValueError(f"P2PAllReduce: needs a contiguous f32 device tensor of at most {self.max_floats} elements")
+        _abi.call("tsm_p2p_all_reduce", self._h, flat.data_ptr(), flat.numel(), _abi.stream_ptr())
+        return flat
+
+    def check(self) -> None:
+        """Raise if a peer failed to answer inside the kernels' bounded spin (synchronises the device)."""
+        from . import _abi
+
+        if self._h is not None and _abi.call("tsm_p2p_failed", self._h):
+            raise RuntimeError("P2P all-reduce: a peer did not answer within the time limit (a rank died or fell out of step)")
+
+    def close(self) -> None:
+        from . import _abi
+
+        if getattr(self, "_h", None) is not None:
+            _abi.call("tsm_p2p_destroy", self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 class GradSync:
     """Sums a flat gradient across ranks and divides by world size (mean of per-shard mean losses)."""
 
@@ -34,6 +97,7 @@ class GradSync:
         self.global_adv_stats = True  # minibatch advantage statistics over all ranks (merge_adv_stats_)
         self._stat_codec = None       # (pack, unpack) callables; None = the HIP kernels (ops.ppo_adv_stats_pack / _unpack)
         self._probe_device = torch.device("cpu")  # attach_data_parallel points it at the replica's device for RCCL
+        self.p2p: P2PAllReduce | None = None      # TSM_P2P_ALLREDUCE=1: the gradient takes the one-shot peer-memory path
 
     def all_reduce_mean_(self, flat: torch.Tensor) -> torch.Tensor:
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -43,8 +107,14 @@ class GradSync:
     def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
         """Plain sum (the caller pre-scales its contribution by 1/world inside the slab reduction kernel, which saves
         an elementwise launch per gradient step)."""
+        if self.p2p is not None and flat.dtype == torch.float32 and flat.numel() <= self.p2p.max_floats:
+            return self.p2p.all_reduce_sum_(flat)
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
         return flat
+
+    def enable_p2p(self, device: torch.device, max_floats: int) -> None:
+        """Route f32 gradient sums of up to `max_floats` elements through `P2PAllReduce` (setup failures raise)."""
+        self.p2p = P2PAllReduce(self.dist, self.group, device, max_floats)
 
     def require_equal(self, value: int, what: str) -> None:
         """Every rank must issue the same number of gradient all-reduces per update, or the job deadlocks: env shards of
@@ -138,6 +208,12 @@ def learn_lockstep(jobs, sync: "GradSync") -> list:
     return results
 
 
+def _want_p2p() -> bool:
+    import os
+
+    return os.environ.get("TSM_P2P_ALLREDUCE", "0") == "1"
+
+
 def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) -> GradSync:
     """Make `algo` a data-parallel replica: parameters and optimizer state are broadcast from rank 0, and every gradient
     step all-reduces the flat gradient.  `algo` is a PPO-family algorithm, or a policy manager
@@ -160,6 +236,8 @@ def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) 
             pol.graph_collectives = False  # the packed reduction is driven from the host: eager launches
         if dist.get_backend(group) == "nccl" and seen:
             sync._probe_device = seen[0].net.flat.device
+        if _want_p2p() and seen:  # the packed gradient of every group that can train in one step
+            sync.enable_p2p(seen[0].net.flat.device, sum(p.net.flat.numel() for p in seen))
         algo._grad_sync = sync
         return sync
     sync.broadcast_(algo.net.flat.data)
@@ -168,6 +246,8 @@ def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) 
     if hasattr(algo.net, "sync_image"):
         algo.net.sync_image()  # the padded LDS image is a cache of `flat`: refresh it behind the broadcast
     algo._grad_sync = sync
+    if _want_p2p():
+        sync.enable_p2p(algo.net.flat.device, algo.net.flat.numel())
     if dist.get_backend(group) == "nccl":
         sync._probe_device = algo.net.flat.device
     # only RCCL ("nccl") collectives can be captured into a hipGraph; with any other backend the update stays on eager

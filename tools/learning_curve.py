@@ -155,6 +155,7 @@ def replica_curve(n_updates: int, every: int, return_scaling=False, max_grad_nor
         if i % every == 0 or i == n_updates - 1:
             r = torch.cat(finished).mean().item() if finished else float("nan")
             out.append((i, r, vf_last, ent_last))
+            print(f"replica update {i}: return {r:.2f} vf_loss {vf_last:.4g} entropy {ent_last:.3f}", file=sys.stderr, flush=True)
     return out
 
 
