@@ -683,7 +683,9 @@ def run_tag(a, device, rank, world, dist, census=None):
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "simple_tag_v3 3 adversaries + 1 prey, 2 obstacles, grouped PPO (one policy per team), "
                                       "LeaguePlayTrainer, num_envs=%d per GPU, T=%d" % (n_env, T),
-                          "parallelism": "env-shard x%d, one packed gradient all-reduce per step for both teams" % world},
+                          "parallelism": "env-shard x%d, one packed gradient all-reduce per step for both teams" % world,
+                          **({"gradient_all_reduce": "peer memory (one-shot)"} if getattr(getattr(mgr, "_grad_sync", None), "p2p", None)
+                             is not None else {})},
                "collect_ms": float(np.median([e[0].elapsed_time(e[1]) for e in marks[-a.steps:]])),
                "league_train_step_ms": float(np.median([e[1].elapsed_time(e[2]) for e in marks[-a.steps:]])),
                "losses": {k: float(v["loss"]) for k, v in losses.items()}}
@@ -901,7 +903,9 @@ def _main():
                        % (a.n_agent, a.n_env, 6 * a.n_agent, a.horizon),
                        "minibatch": a.minibatch, "repeat": a.repeat, "dispatch": a.dispatch, "parallelism": "env-shard x%d" % world,
                        **({} if dist is None else {"collectives": "captured in the update hipGraph" if getattr(algo, "graph_collectives", False)
-                                                   else "eager, between segmented hipGraphs"})},
+                                                   else "eager, between segmented hipGraphs"}),
+                       **({"gradient_all_reduce": "peer memory (one-shot)"} if getattr(getattr(algo, "_grad_sync", None), "p2p", None)
+                          is not None else {})},
             "collect_ms": t_col_ms, "ppo_update_ms": t_upd_ms,
             "collect_env_steps_per_s": a.n_env * a.n_agent * a.horizon / (t_col_ms * 1e-3),
             "gradient_steps_per_update": grad_steps,

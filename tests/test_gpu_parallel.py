@@ -136,7 +136,24 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         assert set(out) == {"adversaries", "good"} and all(np.isfinite(v["loss"]) for v in out.values())
         P = teams["good"].net.flat.numel()
         assert calls == [2 * P], calls  # one gradient step per group (full batch), ONE packed reduce for both
-        flats = torch.cat([net.flat.data, algo2.net.flat.data, teams["adversaries"].net.flat.data, teams["good"].net.flat.data])
+        # ---- (3b) the same lock step for WIDE nets: GenericPPO.learn_steps (128-wide row kernels) under grouped policies ----
+        from tianshou_marl_amd.algorithm import GenericPPO
+        from tianshou_marl_amd.utils.net import MLPActorCritic
+
+        wide = {"adversaries": GenericPPO(net=MLPActorCritic(D, A, (128, 128), device=DEV, seed=70 + rank), graph=False, seed=1),
+                "good": GenericPPO(net=MLPActorCritic(D, A, (128, 128), device=DEV, seed=80 + rank), graph=False, seed=2)}
+        mgr_w = FlexibleMultiAgentPolicyManager(wide, _Env(), mode="grouped",
+                                                agent_groups={"adversaries": _Env.agents[:2], "good": _Env.agents[2:]})
+        sync_w = attach_data_parallel(mgr_w, dist)
+        calls_w = []
+        orig_w = sync_w.all_reduce_sum_
+        sync_w.all_reduce_sum_ = lambda t: (calls_w.append(t.numel()), orig_w(t))[1]
+        np.random.seed(9)
+        out_w = LeaguePlayTrainer(mgr_w, matchmaking="random").train_step(Batch(adversaries=mk(300), good=mk(300)))
+        assert set(out_w) == {"adversaries", "good"} and all(np.isfinite(v["loss"]) for v in out_w.values())
+        assert calls_w == [2 * wide["good"].net.flat.numel()], calls_w  # ONE packed reduce for both wide groups
+        flats = torch.cat([net.flat.data, algo2.net.flat.data, teams["adversaries"].net.flat.data, teams["good"].net.flat.data,
+                           wide["adversaries"].net.flat.data, wide["good"].net.flat.data])
         np.save(os.path.join(out_dir, f"p{rank}.npy"), flats.cpu().numpy())
         # ---- (4) unequal shards are refused instead of deadlocking ----
         algo3 = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=1), dispatch="pooled", shuffle="numpy", use_graph=False)

@@ -29,11 +29,10 @@ from ..data.batch import Batch, split_bounds
 from ..data.buffer import DeviceVectorReplayBuffer
 from ..data.stats import A2CTrainingStats, SequenceSummaryStats
 from ..utils.net import FlatMLP, MLPActorCritic
-from .ppo import PPO, ref_order_rows
+from .ppo import PPO, drive_steps, ref_order_rows
 
 
 class GenericPPO(PPO):
-    learn_steps = None  # (its gradient steps reduce inside `_grad_step`; no lock-step generator form)
 
     def __init__(self, *, net: MLPActorCritic | None = None, critic_input: Literal["local", "global"] | None = None,
                  n_agent: int | None = None, graph: bool = True, fused_actor: bool = True,
@@ -198,14 +197,22 @@ class GenericPPO(PPO):
 
     def _grad_step(self, pb: dict, idx: torch.Tensor, adv_stats, step_dev: torch.Tensor | None = None,
                    rows: torch.Tensor | None = None, partial_out: torch.Tensor | None = None) -> torch.Tensor | None:
-        """One minibatch: forward both nets, loss, backward into joint slabs, clip + Adam.  Returns the 4 scalars.
+        """`_grad_step_steps` run to its end, the gradient summed over the data-parallel ranks where it falls due."""
+        return drive_steps(self._grad_step_steps(pb, idx, adv_stats, step_dev, rows, partial_out), self._grad_sync)
+
+    def _grad_step_steps(self, pb: dict, idx: torch.Tensor, adv_stats, step_dev: torch.Tensor | None = None,
+                         rows: torch.Tensor | None = None, partial_out: torch.Tensor | None = None):
+        """One minibatch: forward both nets, loss, backward into joint slabs, clip + Adam.  A generator: with data-parallel
+        replicas it YIELDS the flat gradient (scaled by 1 / world) where it has to be summed over the ranks and continues
+        with Adam once the caller has reduced it in place (`drive_steps`: one all-reduce; `parallel.learn_lockstep`:
+        several policy groups packed into one).  Returns (StopIteration.value) the 4 scalars.
         idx: lane (sample) ids of the minibatch; rows: its joint-row ids when the minibatch is made of whole rows
         (`row_minibatches`: idx == rows * N + agent, row-major).  step_dev: device-resident optimizer step count (graph
         capture); None = the host counter.  partial_out (f64, row-kernel path only): the step's loss partials are left
         there for ONE `ppo_finalize_many` over all steps of the update and None is returned."""
         net = self.net
         if self.fused_actor:
-            return self._grad_step_fused_actor(pb, idx, adv_stats, step_dev, rows, partial_out)
+            return (yield from self._grad_step_fused_actor(pb, idx, adv_stats, step_dev, rows, partial_out))
         if rows is not None:
             N = pb["n_agent"]
             cx = ops.gather_rows(pb["joint"], rows)                    # [Mr, N * D]: read once ...
@@ -236,7 +243,7 @@ class GenericPPO(PPO):
         if self._grad_sync is not None:
             flat_g = self._ws.setdefault("flat_grad", torch.empty_like(net.flat.data))
             ops.reduce_slabs(grads, out=flat_g, scale=1.0 / self._grad_sync.world)
-            self._grad_sync.all_reduce_sum_(flat_g)
+            yield flat_g  # summed over the ranks by the driver, in place
             grads = flat_g.view(1, -1)
         ops.adam_step(net.flat.data, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr, lr_dev=self._lr_dev,
                       betas=self.betas,
@@ -313,7 +320,7 @@ class GenericPPO(PPO):
                                max_grad_norm=self.max_grad_norm, work=self._adam_work, **hyper)
         else:
             ops.reduce_slabs_segs(segs, P_a + P_c, out=w["flat_g"], scale=1.0 / self._grad_sync.world)
-            self._grad_sync.all_reduce_sum_(w["flat_g"])
+            yield w["flat_g"]  # summed over the ranks by the driver, in place
             ops.adam_step(net.flat.data, w["flat_g"].view(1, -1), self.exp_avg, self.exp_avg_sq, self.opt_step,
                           max_grad_norm=self.max_grad_norm, work=self._adam_work, **hyper)
         if partial_out is not None:
@@ -451,6 +458,12 @@ class GenericPPO(PPO):
 
     def _update_with_batch(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
                            buffer: DeviceVectorReplayBuffer | None = None, perm_base: int | None = None) -> A2CTrainingStats:
+        return drive_steps(self._update_steps(pb, batch_size, repeat, agent=agent, buffer=buffer, perm_base=perm_base),
+                           self._grad_sync)
+
+    def _update_steps(self, pb: dict, batch_size: int | None, repeat: int, agent: int | None = None,
+                      buffer: DeviceVectorReplayBuffer | None = None, perm_base: int | None = None):
+        """The minibatch loop as a generator of gradient synchronisation points (see PPO._update_steps)."""
         dev = self.device
         N = pb["n_agent"]
         row_mode = agent is None and self.row_minibatches and pb.get("joint") is not None and N > 1
@@ -489,8 +502,10 @@ class GenericPPO(PPO):
                      if self.advantage_normalization else None)
             self._global_adv_stats(stats, mb_start)
             for j, (s, e) in enumerate(bounds):
-                scal.append(self._grad_step(pb, lanes[s * unit:e * unit].contiguous(), None if stats is None else stats[j],
-                                            rows=perm[s:e].contiguous() if row_mode else None))
+                sc = yield from self._grad_step_steps(pb, lanes[s * unit:e * unit].contiguous(),
+                                                      None if stats is None else stats[j],
+                                                      rows=perm[s:e].contiguous() if row_mode else None)
+                scal.append(sc)
         self.param_version += 1
         s_h = torch.stack(scal).cpu().numpy()
         return A2CTrainingStats(
@@ -501,6 +516,11 @@ class GenericPPO(PPO):
     def learn(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
         """One PPO pass on an explicit agent batch (training_coordinator.py:336); a centralized critic takes
         `batch.global_obs` / `batch.global_obs_next`."""
+        return drive_steps(self.learn_steps(batch, batch_size, repeat, **kwargs), self._grad_sync)
+
+    def learn_steps(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs):
+        """`learn` as a generator of gradient synchronisation points: wide nets take part in the lock-step of grouped /
+        league policies under data parallelism (`parallel.learn_lockstep`)."""
         dev = self.device
         t = lambda x, dt: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))).to(dev, dt).contiguous()  # noqa: E731
         obs, obs_next = t(batch.obs, torch.float32), t(batch.obs_next, torch.float32)
@@ -521,7 +541,7 @@ class GenericPPO(PPO):
                                  self.gamma, self.gae_lambda)
         pb = dict(T=n, rows=None, obs=obs, act=act, v_s=v_s.contiguous(), ret=ret.reshape(-1), adv=adv.reshape(-1),
                   logp_old=logp_old, n_env=1, n_agent=1, joint=joint)
-        st = self._update_with_batch(pb, batch_size, repeat)
+        st = yield from self._update_steps(pb, batch_size, repeat)
         return {"loss": st.loss.mean, "actor_loss": st.actor_loss.mean, "vf_loss": st.vf_loss.mean,
                 "ent_loss": st.ent_loss.mean}
 
