@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--c3-dispatch", default="pooled", choices=["per_agent", "pooled"],
                     help="c3ppo: pooled = minibatches of joint rows (critic once per row); per_agent = MARLDispatcher order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ignore-obs-next", action="store_true",
+                    help="c3ppo: a buffer without an obs_next store (VectorReplayBuffer(ignore_obs_next=True), buffer_base.py:612-616): "
+                         "the rollout writes half the observation rows, V(obs_next) comes from V(obs) at next(index)")
     ap.add_argument("--no-c3-grid", action="store_true", help="skip the roofline_grid entries of the 4096 x 8 configuration")
     ap.add_argument("--pooled-grid", action="store_true",
                     help="extended roofline_grid: the fused gradient step at a pooled 65 536-row minibatch and GAE at the "
@@ -555,7 +558,7 @@ def run_c3ppo(a, device):
     D = env.obs_dim
     net = MLPActorCritic(D, 5, (128, 128), critic_obs_dim=N * D, device=device, seed=1626)
     algo = GenericPPO(net=net, critic_input="global", n_agent=N, lr=3e-4, shuffle="device", seed=1626, dispatch=a.c3_dispatch)
-    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=device)
+    buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=device, ignore_obs_next=a.ignore_obs_next)
     col = Collector(algo, env, buf, async_stats=True)
     col.reset()
 
@@ -592,7 +595,8 @@ def run_c3ppo(a, device):
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "simple_spread_v3 N=8 PPO, shared actor 48-128-128-5 + centralized critic 384-128-128-1, "
-                               "num_envs=4096, T=25", "minibatch": mb, "repeat": 1, "dispatch": a.c3_dispatch},
+                               "num_envs=4096, T=25", "minibatch": mb, "repeat": 1, "dispatch": a.c3_dispatch,
+                   **({"buffer": "ignore_obs_next=True"} if a.ignore_obs_next else {})},
         "collect_ms": e0.elapsed_time(e1), "gae_ppo_update_ms": e1.elapsed_time(e2),
         "gradient_steps_per_update": sum(int(v) for k, v in d.items() if k.endswith("gradient_steps")),
         "loss": d.get("agent_0/loss", d.get("loss"))}))
