@@ -782,6 +782,9 @@ def _main():
         if code:
             raise SystemExit(code)
         return
+    from tianshou_marl_amd.utils.host import limit_host_threads
+
+    limit_host_threads()  # torch's pool sized for the machine, not for the CPU quota, gets the launch thread frozen (utils/host.py)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
         raise SystemExit("bench.py --gpus %d, but the launcher started WORLD_SIZE=%d ranks: pass --gpus %d" % (a.gpus, world, world))

@@ -16,6 +16,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    from tianshou_marl_amd.utils.host import limit_host_threads
+
+    limit_host_threads()  # torch's 128-thread default against a 16-CPU quota freezes the process for tens of ms (utils/host.py)
 
 
 @pytest.fixture(scope="session")

@@ -26,6 +26,7 @@ struct Dw1Args {
     int64_t first_row, Mr, tm_T, tm_E;   // row addressing as in critic_train.hip
     int K1;
     int64_t RC;              // rows per chunk (a multiple of 64)
+    int ncb, n_chunk;        // column blocks, row chunks
     float *slabs;            // [n_chunk][128 K1]
 };
 
@@ -40,8 +41,14 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
     float *sA = lds, *sB = lds + kSub * kLdA;
     int64_t *rid = reinterpret_cast<int64_t *>(lds + kSub * (kLdA + kLdB));
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
-    const int K1 = g.K1, c0 = kCB * blockIdx.x;
-    const int64_t i_lo = (int64_t)blockIdx.y * g.RC, i_hi = i_lo + g.RC < g.Mr ? i_lo + g.RC : g.Mr;
+    // XCD-aware block -> (column block, row chunk) map: workgroups are dealt round-robin over the 8 XCDs (each with an L2 of its
+    // own), and the ncb workgroups of one row chunk read the SAME dH1 rows -- give them ids that differ by multiples of 8, so
+    // that they share an L2 and the chunk leaves memory once instead of ncb times (speed / traffic only: any placement is correct)
+    const int ncb = g.ncb, bid = blockIdx.x;
+    const int rc_lo = bid & 7, t_ = bid >> 3, cb = t_ % ncb, rc = (t_ / ncb) * 8 + rc_lo;
+    if (rc >= g.n_chunk) return;   // (the grid is padded to whole groups of 8 chunks)
+    const int K1 = g.K1, c0 = kCB * cb;
+    const int64_t i_lo = (int64_t)rc * g.RC, i_hi = i_lo + g.RC < g.Mr ? i_lo + g.RC : g.Mr;
     const int n_sub = (int)((i_hi - i_lo + kSub - 1) / kSub);
 
     f4 acc[6];
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
         }
         __syncthreads();
     }
-    float *slab = g.slabs + (size_t)blockIdx.y * (size_t)kH * K1;
+    float *slab = g.slabs + (size_t)rc * (size_t)kH * K1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 16 * w + kq * 4 + r;
@@ -188,7 +195,8 @@ TSM_EXPORT int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int3
     Dw1Args g{};
     g.dh1 = dh1; g.obs = obs_rows; g.rows = rows; g.first_row = first_row; g.Mr = Mr; g.tm_T = tm_T; g.tm_E = tm_E;
     g.K1 = in_dim; g.RC = RC; g.slabs = w1_slabs_out;
-    const dim3 grid((unsigned)ceil_div(in_dim, kCB), (unsigned)n);
+    g.ncb = (int)ceil_div(in_dim, kCB); g.n_chunk = n;
+    const dim3 grid((unsigned)(g.ncb * ceil_div(n, 8) * 8));
     if ((in_dim & 3) == 0)
         hipLaunchKernelGGL(critic_dw1_kernel<true>, grid, dim3(kThreads), kDw1Lds, tsm_stream(stream), g);
     else

@@ -3,7 +3,9 @@
 host wall time and, from HIP events on the launch stream, the device time of collect and of update -- which steps are
 slow, and whether the time is on the device (inside the bracket) or on the host (outside it).
 
-    python tools/c3_step_times.py [n_steps]
+    python tools/c3_step_times.py [n_steps] [nosync] [nolimit]
+
+`nosync`: no per-step synchronisation (the bench's own loop); the events are read after the last step.
 
 Runs once; prints one line per step that is slower than 1.3x the median, and the labels of the first steps (eager update,
 capture, first replay)."""
@@ -24,6 +26,11 @@ from tianshou_marl_amd.utils.net import MLPActorCritic  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    nosync = "nosync" in sys.argv[2:]
+    if "nolimit" not in sys.argv[2:]:  # `nolimit`: torch's default pool (128 threads on these hosts) -- reproduces the stall
+        from tianshou_marl_amd.utils.host import cpu_budget, limit_host_threads
+
+        print("host threads: torch pool %d of a CPU budget of %d" % (limit_host_threads(), cpu_budget()))
     dev = torch.device("cuda", 0)
     n_env, N, T, mb = 4096, 8, 25, 65536
     env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=dev, seed=1626)
@@ -35,6 +42,36 @@ def main():
     col.reset()
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
     rec = []
+    import gc
+
+    gc_log, gc_t = [], [0.0]
+
+    def on_gc(phase, info):  # how long the interpreter's cyclic collector holds the loop, and in which step
+        if phase == "start":
+            gc_t[0] = time.perf_counter()
+        else:
+            gc_log.append((len(rec), info["generation"], (time.perf_counter() - gc_t[0]) * 1e3, info["collected"]))
+
+    gc.callbacks.append(on_gc)
+    # time every hipGraph launch on the host: wall, and the calling thread's CPU time (wall >> cpu: the thread slept or was
+    # descheduled inside hipGraphLaunch; wall == cpu: it was working or spinning)
+    replays = []
+    _replay = torch.cuda.CUDAGraph.replay
+
+    def timed_replay(self):
+        w0, c0 = time.perf_counter(), time.thread_time()
+        _replay(self)
+        replays.append((len(rec), (time.perf_counter() - w0) * 1e3, (time.thread_time() - c0) * 1e3))
+
+    torch.cuda.CUDAGraph.replay = timed_replay
+
+    def cpu_stat():
+        try:
+            return {k: int(v) for k, v in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))}
+        except OSError:
+            return {}
+
+    cs0 = cpu_stat()
     for i in range(n):
         e = [ev() for _ in range(3)]
         t0 = time.perf_counter()
@@ -52,8 +89,14 @@ def main():
         t3 = time.perf_counter()
         col.reset_buffer(keep_statistics=True)
         t4 = time.perf_counter()
+        if nosync:
+            rec.append([t4 - t0, t1 - t0, t2 - t1, t3 - t2, t4 - t3, e])
+            continue
         torch.cuda.synchronize()
         rec.append((t4 - t0, t1 - t0, t2 - t1, t3 - t2, t4 - t3, e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])))
+    if nosync:  # the events are read once, after the loop
+        torch.cuda.synchronize()
+        rec = [(*r[:5], r[5][0].elapsed_time(r[5][1]), r[5][1].elapsed_time(r[5][2])) for r in rec]
     a = np.array(rec) * np.array([1e3, 1e3, 1e3, 1e3, 1e3, 1, 1])
     med = np.median(a[5:], axis=0)
     names = "wall host_collect host_update host_resolve host_reset dev_collect dev_update".split()
@@ -62,6 +105,14 @@ def main():
     for i, row in enumerate(a):
         if i < 6 or row[0] > 1.3 * med[0]:
             print(f"step {i:3d} " + "  ".join(f"{k} {v:.3f}" for k, v in zip(names, row)) + ("   <- " + label[i] if i in label else ""))
+    cs1 = cpu_stat()
+    print("cgroup cpu.stat over the loop: " + ", ".join(f"{k} +{cs1[k] - cs0[k]}" for k in cs1 if k in cs0 and ("throttled" in k or k == "nr_periods")))
+    for st, wall, cpu in replays:
+        if wall > 1.0:
+            print(f"hipGraphLaunch in step {st}: {wall:.2f} ms on the host, {cpu:.2f} ms of them on the CPU")
+    for st, gen, ms, coll in gc_log:
+        if ms > 1.0:
+            print(f"python gc: generation {gen} collection during step {st}: {ms:.1f} ms ({coll} objects freed)")
     print("steps over 1.3x the median wall: %d of %d" % (int((a[:, 0] > 1.3 * med[0]).sum()), n))
 
 
