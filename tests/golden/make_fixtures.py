@@ -19,6 +19,8 @@ Each fixture holds inputs + the reference's outputs for one hot-path function
   marl_dispatch.npz MultiAgentPolicy.forward scatter + MARLDispatcher per-agent GAE (incl. quirk Q1),
                    FlexibleMultiAgentPolicyManager shared forward       [a5, a6, a10]
   ctde.npz         GlobalStateConstructor.build + CTDEPolicy.learn      [a16]
+  ctde_wide.npz    CTDEPolicy.learn at configs[2]'s widths (128-wide actor and centralized critic) on rows laid out as a
+                   time-major store: every agent's learn() in turn, with and without episodes ending mid-store   [a16, a17]
   misc.npz         Batch.split bounds, RunningMeanStd, episode_mc_return_to_go   [a11, a14]
 """
 from __future__ import annotations
@@ -506,6 +508,92 @@ def make_ctde() -> None:
     save("ctde.npz", **out)
 
 
+def make_ctde_wide() -> None:
+    """CTDEPolicy.learn (ctde.py:121-199) at the widths the one-launch kernels serve (hidden 128, critic on the N*D joint
+    row), called the way the MARL trainers call it (training_coordinator.py:118: one learn() per agent, in env.agents order, on
+    that agent's column of the same joint rows).  The rows are generated as a time-major store [T, E, N, ...] whose obs_next
+    is the next slot's obs unless the episode ended (what a Collector leaves behind, collector.py:1040-1069); the reference
+    gets the env-major flattening.  Variant `chain`: episodes end at the last slot only; `early`: some end mid-store."""
+    N, D, A, H, E, T = 4, 24, 5, 128, 6, 11
+    out = dict(dims=np.array([N, D, A, H, E, T]), gamma=np.float64(0.99), lr=np.float64(1e-3))
+
+    def run(variant, seed):
+        res = {}
+        rng = np.random.default_rng(seed)
+        torch.manual_seed(seed)
+        obs = rng.standard_normal((T, E, N, D)).astype(np.float32)
+        act = rng.integers(0, A, (T, E, N))
+        rew = rng.standard_normal((T, E, N)).astype(np.float32)
+        done = np.zeros((T, E), bool)
+        done[T - 1] = rng.random(E) < 0.6
+        if variant == "early":
+            done[3, 1] = done[6, 4] = done[7, 1] = done[0, 5] = True
+        is_term = rng.random((T, E)) < 0.5  # an ended episode is terminated for every agent or truncated for every agent
+        term = np.repeat((done & is_term)[:, :, None], N, axis=2)
+        trunc = np.repeat((done & ~is_term)[:, :, None], N, axis=2)
+        obs_next = np.empty_like(obs)
+        obs_next[:-1] = obs[1:]
+        fresh = rng.standard_normal((T, E, N, D)).astype(np.float32)  # the final observation of an episode / of the store
+        obs_next[T - 1] = fresh[T - 1]
+        obs_next[done] = fresh[done]
+        actor = DecentralizedActor(D, A, hidden_dim=H)
+        critic = CentralizedCritic(N * D, N, hidden_dim=H)
+        pol = CTDEPolicy(actor=actor, critic=critic,
+                         optim_actor=torch.optim.Adam(actor.parameters(), lr=1e-3),
+                         optim_critic=torch.optim.Adam(critic.parameters(), lr=1e-3),
+                         observation_space=gym.spaces.Box(-np.inf, np.inf, (D,)),
+                         action_space=gym.spaces.Discrete(A), discount_factor=0.99)
+
+        def snap(tag):
+            for name, mod in (("actor", actor), ("critic", critic)):
+                for i, l in enumerate([mod.fc1, mod.fc2, mod.fc3]):
+                    res[f"{variant}_{tag}_{name}_w{i}"] = l.weight.detach().numpy().copy()
+                    res[f"{variant}_{tag}_{name}_b{i}"] = l.bias.detach().numpy().copy()
+
+        def min_preact(mod, x):  # how close any hidden unit of the reference's own run comes to the ReLU kink
+            with torch.no_grad():
+                z1 = mod.fc1(torch.as_tensor(x))
+                z2 = mod.fc2(torch.relu(z1))
+            return min(float(z1.abs().min()), float(z2.abs().min()))
+
+        snap("init")
+        em = lambda x: np.ascontiguousarray(np.swapaxes(x, 0, 1))  # noqa: E731  [E, T, ...]: env-major rows
+        losses, minz = [], np.inf
+        for a in range(N):
+            batch = Batch(obs=em(obs)[:, :, a].reshape(E * T, D), act=em(act)[:, :, a].reshape(E * T),
+                          rew=em(rew)[:, :, a].reshape(E * T), obs_next=em(obs_next)[:, :, a].reshape(E * T, D),
+                          terminated=em(term)[:, :, a].reshape(E * T),
+                          global_obs=em(obs).reshape(E * T, N * D), global_obs_next=em(obs_next).reshape(E * T, N * D))
+            minz = min(minz, min_preact(actor, batch.obs), min_preact(critic, batch.global_obs), min_preact(critic, batch.global_obs_next))
+            r = pol.learn(batch)
+            losses.append([r["actor_loss"], r["critic_loss"]])
+            if a == 0:
+                snap("after1")
+                for name, mod in (("actor", actor), ("critic", critic)):
+                    for i, l in enumerate([mod.fc1, mod.fc2, mod.fc3]):
+                        res[f"{variant}_grad1_{name}_w{i}"] = l.weight.grad.detach().numpy().copy()
+                        res[f"{variant}_grad1_{name}_b{i}"] = l.bias.grad.detach().numpy().copy()
+        snap("afterN")
+        res.update({f"{variant}_obs": obs, f"{variant}_act": act, f"{variant}_rew": rew, f"{variant}_term": term,
+                    f"{variant}_trunc": trunc, f"{variant}_obs_next": obs_next, f"{variant}_losses": np.array(losses),
+                    f"{variant}_seed": np.int64(seed), f"{variant}_min_abs_preact": np.float64(minz)})
+        return res, minz
+
+    # A hidden unit whose pre-activation is ~1e-7 on some row takes either side of the ReLU depending on the summation order of
+    # a 96-term f32 dot product; Adam then turns that one row's gradient into full +-lr steps on the unit's whole weight row
+    # (seed 21 of `chain` has |z| = 1.06e-7 in the fourth call: f64 and the reference's f32 land on one side, a k-ordered f32 FMA
+    # chain on the other).  The fixture is for arithmetic parity, not for tie-breaking at a kink: take the first seed whose
+    # every pre-activation (reference's own f32 run, all four calls, both nets) stays 2e-6 away from it; the margin is recorded.
+    for variant in ("chain", "early"):
+        for seed in range(21, 200):
+            res, minz = run(variant, seed)
+            if minz >= 2e-6:
+                break
+        print(f"ctde_wide {variant}: seed {seed}, min |pre-activation| {minz:.2e}")
+        out.update(res)
+    save("ctde_wide.npz", **out)
+
+
 # ------------------------------------------------------------------------------------------------
 def make_misc() -> None:
     out = {}
@@ -536,6 +624,6 @@ def make_misc() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "ppo_update_wide", "pg_update", "marl_dispatch", "ctde", "misc"]
+    which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "ppo_update_wide", "pg_update", "marl_dispatch", "ctde", "ctde_wide", "misc"]
     for w in which:
         globals()["make_" + w]()

@@ -402,3 +402,66 @@ def test_ctde_learn_on_the_stores_equals_learn_on_the_copies(n_env, max_cycles, 
     if graph:
         assert sum(len(w["graphs"]) for w in pol_f._ws.values() if isinstance(w, dict) and "graphs" in w) == 8 * min(2, rounds - 1)
     assert pol_f.optim_actor.step_count == pol_u.optim_actor.step_count == pol_f.optim_critic.step_count == 8 * rounds
+
+
+def _wide_flat(g, prefix, name):
+    """Layer tensors of the fixture in FlatMLP's flat order (per layer: weight, bias)."""
+    return np.concatenate([np.concatenate([g[f"{prefix}_{name}_w{i}"].reshape(-1), g[f"{prefix}_{name}_b{i}"].reshape(-1)])
+                           for i in range(3)]).astype(np.float64)
+
+
+@pytest.mark.parametrize("path", ["store", "store_eager", "copies"])
+@pytest.mark.parametrize("variant", ["chain", "early"])
+def test_ctde_learn_wide_matches_reference_fixture(variant, path):
+    """CTDEPolicy.learn against the REFERENCE's own run at configs[2]'s widths (tests/golden/ctde_wide.npz: 128-wide actor,
+    centralized critic on the N*D joint row, four agents' learn() calls in turn on the same rows, as the MARL trainers issue
+    them).  `store`: the one-launch kernels reading the time-major stores in place (critic_rows / critic_train / critic_dw1 /
+    ppo_rows / ctde_finalize / adam_step_segs; the 2nd call of an agent would replay a hipGraph -- here every agent is called
+    once, so `store` and `store_eager` differ in nothing but the flag and both must hold); `copies`: dense GEMMs on env-major
+    copies.  `early`: episodes end mid-store, obs_next of those rows is not the next slot's obs.
+    Bars: both losses of every call 1e-5; weights after the first call rtol 1e-5 + atol 5e-6 plus what ONE Adam step from zero
+    moments does to a gradient known to 1e-5 of its scale (u = lr g / (|g| + eps): du = lr eps dg / (|g| + eps)^2, at most a
+    step of lr where |g| < dg); after all four calls every weight of both nets rtol 1e-5 + atol 5e-6.  (The generator picks
+    data whose every ReLU pre-activation in the reference's run stays 2e-6 off the kink -- `*_min_abs_preact` in the fixture:
+    a unit at |z| ~ 1e-7 takes either side depending on the f32 summation order and Adam turns that into +-lr steps.)"""
+    from tianshou_marl_amd.algorithm.multiagent.training_coordinator import _attach_global
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+
+    g = np.load(os.path.join(GOLD, "ctde_wide.npz"))
+    N, D, A, H, E, T = (int(x) for x in g["dims"])
+    lr, eps = float(g["lr"]), 1e-8
+    actor = DecentralizedActor(D, A, hidden_dim=H, device=DEV)
+    critic = CentralizedCritic(N * D, N, hidden_dim=H, device=DEV)
+    actor.load_layers([(g[f"{variant}_init_actor_w{i}"], g[f"{variant}_init_actor_b{i}"]) for i in range(3)])
+    critic.load_layers([(g[f"{variant}_init_critic_w{i}"], g[f"{variant}_init_critic_b{i}"]) for i in range(3)])
+    pol = CTDEPolicy(actor=actor, critic=critic, optim_actor=FlatAdam(actor, lr=lr), optim_critic=FlatAdam(critic, lr=lr),
+                     discount_factor=float(g["gamma"]), fused=path != "copies", graph=path == "store")
+    buf = DeviceVectorReplayBuffer(E * T, E, N, D, device=DEV)
+    f = lambda k, t: g[f"{variant}_{k}"][t]  # noqa: E731
+    for t in range(T):
+        buf.add(Batch(obs=f("obs", t), act=f("act", t), rew=f("rew", t), terminated=f("term", t), truncated=f("trunc", t),
+                      obs_next=f("obs_next", t)))
+    buf.mark_rows_chained("empty", True)  # the fixture's rows continue one another by construction (what a Collector marks)
+    agents = [f"agent_{i}" for i in range(N)]
+    batches = agent_batches_from_buffer(buf, agents, copies=path == "copies")
+    for a, name in enumerate(agents):
+        b = _attach_global(batches, batches[name])
+        assert (pol._store_path(b) is not None) == (path != "copies")
+        out = pol.learn(b)
+        ref_al, ref_cl = (float(x) for x in g[f"{variant}_losses"][a])
+        assert out["critic_loss"] == pytest.approx(ref_cl, rel=1e-5), (a, "critic")
+        assert out["actor_loss"] == pytest.approx(ref_al, rel=1e-5, abs=1e-7), (a, "actor")
+        if a == 0:
+            for nm, net in (("actor", actor), ("critic", critic)):
+                ref, gr = _wide_flat(g, f"{variant}_after1", nm), _wide_flat(g, f"{variant}_grad1", nm)
+                dg = 1e-5 * np.abs(gr).max()
+                tol = 5e-6 + 1e-5 * np.abs(ref) + np.minimum(lr * eps * dg / (np.abs(gr) + eps) ** 2, 2 * lr)
+                got = net.flat.data.double().cpu().numpy()
+                bad = np.abs(got - ref) > tol
+                assert not bad.any(), (nm, int(bad.sum()), float(np.abs(got - ref)[bad].max()))
+                # and most of the weights are nowhere near those ill-conditioned entries: plain tolerance for 95 % of them
+                assert (np.abs(got - ref) <= 5e-6 + 1e-5 * np.abs(ref)).mean() > 0.95, nm
+    for nm, net in (("actor", actor), ("critic", critic)):  # four Adam steps in: every weight of both nets
+        ref = _wide_flat(g, f"{variant}_afterN", nm)
+        np.testing.assert_allclose(net.flat.data.double().cpu().numpy(), ref, rtol=1e-5, atol=5e-6, err_msg=nm)
+    assert pol.optim_actor.step_count == pol.optim_critic.step_count == N
