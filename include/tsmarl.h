@@ -532,6 +532,9 @@ int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stream);
  * mean(advantage), quirk Q7).
  * ------------------------------------------------------------------------------------------- */
 int tsm_ppo_actor_rows_supported(int32_t obs_dim, int32_t hidden, int32_t n_act);
+/* Raises the dynamic-LDS limit of every instantiation of the actor / critic rows kernels (idempotent, no stream work).  The
+ * launch entry points call it themselves; a host that CAPTURES them into a hipGraph calls it once before its first capture. */
+int tsm_ppo_rows_init(void);
 int64_t tsm_ppo_actor_rows_param_count(int32_t obs_dim, int32_t hidden, int32_t n_act);
 int tsm_ppo_actor_rows_grid(int64_t M);
 int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_dim, int32_t hidden, int32_t n_act,

@@ -170,6 +170,7 @@ SIGNATURES = {
     "tsm_ppo_critic_rows_grid": (_int, [_i64]),
     "tsm_ppo_critic_rows_update": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i64, C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p]),
     "tsm_ppo_actor_rows_supported": (_int, [_i32, _i32, _i32]),
+    "tsm_ppo_rows_init": (_int, []),
     "tsm_ppo_actor_rows_param_count": (_i64, [_i32, _i32, _i32]),
     "tsm_ppo_actor_rows_grid": (_int, [_i64]),
     "tsm_ppo_actor_rows_update": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _i64, _p, C.POINTER(tsm_ppo_cfg),

@@ -43,6 +43,21 @@ static inline hipStream_t tsm_stream(void *s) { return reinterpret_cast<hipStrea
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Dynamic LDS of a workgroup on gfx950: 160 KB.  ONE constant for the host-side layout checks and for the value handed to
+// hipFuncAttributeMaxDynamicSharedMemorySize (a layout that passes the check can always be launched).
+constexpr size_t kTsmMaxLds = 160 * 1024;
+
+// Raise a kernel's dynamic-LDS limit to all the LDS a workgroup can have beside the kernel's own static __shared__
+// variables (the runtime refuses static + dynamic > 160 KB with "invalid argument").  A layout above that room still fails
+// loudly: the launch returns an error that TSM_LAUNCH_CHECK reports.
+static inline hipError_t tsm_allow_max_lds(const void *kernel) {
+    hipFuncAttributes a{};
+    hipError_t e = hipFuncGetAttributes(&a, kernel);
+    if (e != hipSuccess) return e;
+    const size_t room = a.sharedSizeBytes < kTsmMaxLds ? kTsmMaxLds - a.sharedSizeBytes : 0;
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)room);
+}
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- wave / block reductions (64-wide) ----

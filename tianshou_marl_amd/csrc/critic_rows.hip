@@ -216,8 +216,7 @@ int launch_forward_v(const FwdArgs &g, int grid, hipStream_t st) {
     TSM_REQUIRE(shmem <= kMaxLds, "tsm_critic_rows_forward: LDS layout of %zu bytes does not fit", shmem);
     static bool attr_set = false;  // (set before any capture: tsm_critic_rows_init)
     if (!attr_set) {
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_rows_forward_kernel<KJ, VEC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(critic_rows_forward_kernel<KJ, VEC>)));
         attr_set = true;
     }
     if (grid > 0) {

@@ -96,7 +96,7 @@ int n_cu_dev() {
     return cached;
 }
 
-constexpr size_t kMaxLds = 160 * 1024;
+constexpr size_t kMaxLds = kTsmMaxLds;
 
 // smallest instantiated KJ (k-groups of 16) covering in_dim; 0 = unsupported
 int pick_kj(int in_dim) {

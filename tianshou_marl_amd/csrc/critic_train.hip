@@ -480,8 +480,7 @@ int launch_train_v(const TrainArgs &g, int grid, hipStream_t st) {
     TSM_REQUIRE(shmem <= kMaxLds, "critic gradient step: LDS layout of %zu bytes does not fit", shmem);
     static bool attr_set = false;  // (set before any capture: tsm_critic_rows_init)
     if (!attr_set) {
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_rows_train_kernel<KJ, VEC, LOSS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(critic_rows_train_kernel<KJ, VEC, LOSS>)));
         attr_set = true;
     }
     if (grid > 0) {

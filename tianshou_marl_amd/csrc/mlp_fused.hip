@@ -941,8 +941,7 @@ TSM_EXPORT int tsm_policy_forward(const float *params, const float *param_image,
     const unsigned grid = (unsigned)(n_tiles < 1024 ? n_tiles : 1024);
     static bool attr_set = false;
     if (!attr_set) {
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(policy_forward_kernel<64>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(policy_forward_kernel<64>)));
         attr_set = true;
     }
     hipLaunchKernelGGL((policy_forward_kernel<64>), dim3(grid), dim3(NT), shmem, tsm_stream(stream), params,
@@ -1011,8 +1010,7 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
     static bool attr_set = false;
     if (!attr_set) {
         // the kernel also has a few hundred bytes of static LDS: leave headroom below the 160 KiB of a CU
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ppo_update_kernel<64>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(ppo_update_kernel<64>)));
         attr_set = true;
     }
     hipStream_t st = tsm_stream(stream);

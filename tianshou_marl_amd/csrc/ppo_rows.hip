@@ -811,6 +811,21 @@ TSM_EXPORT int tsm_ppo_actor_rows_grid(int64_t M) {
     return (int)(tiles < cu ? tiles : cu);
 }
 
+// Raise the dynamic-LDS limit of EVERY instantiation of the two kernels (once per process: one process drives one GPU).  Hosts
+// that capture the launches into a hipGraph call this first, outside the capture (GenericPPO does when it picks these
+// kernels); the launch entry points call it too, so a plain caller needs nothing.
+TSM_EXPORT int tsm_ppo_rows_init(void) {
+    static bool done = false;
+    if (done) return TSM_OK;
+#define ALLOW(k) TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(k)))
+    ALLOW(ppo_actor_rows_kernel<1>); ALLOW(ppo_actor_rows_kernel<2>); ALLOW(ppo_actor_rows_kernel<3>); ALLOW(ppo_actor_rows_kernel<4>);
+    ALLOW(ppo_critic_rows_kernel<1>); ALLOW(ppo_critic_rows_kernel<2>); ALLOW(ppo_critic_rows_kernel<3>); ALLOW(ppo_critic_rows_kernel<4>);
+    ALLOW(ppo_critic_rows_kernel<6>); ALLOW(ppo_critic_rows_kernel<8>); ALLOW(ppo_critic_rows_kernel<12>);
+#undef ALLOW
+    done = true;
+    return TSM_OK;
+}
+
 TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_dim, int32_t hidden, int32_t n_act,
                                          const float *obs, const int32_t *act, const float *logp_old, const float *adv,
                                          const int64_t *perm, int64_t first_row, int64_t M, const float *adv_stats,
@@ -838,16 +853,11 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
     g.opt_step_dev = opt_step_dev;
     const RowsLay ly(obs_dim);
     const size_t shmem = (size_t)ly.total * sizeof(float);
-    TSM_REQUIRE(shmem <= 160 * 1024, "tsm_ppo_actor_rows_update: LDS layout of %zu bytes does not fit", shmem);
-    static bool attr_set[4] = {false, false, false, false};
+    TSM_REQUIRE(shmem <= kTsmMaxLds, "tsm_ppo_actor_rows_update: LDS layout of %zu bytes does not fit", shmem);
+    if (const int rc = tsm_ppo_rows_init(); rc != TSM_OK) return rc;
     hipStream_t st = tsm_stream(stream);
 #define LAUNCH(NJ)                                                                                                     \
     do {                                                                                                               \
-        if (!attr_set[NJ - 1]) {                                                                                       \
-            TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ppo_actor_rows_kernel<NJ>),                     \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                      \
-            attr_set[NJ - 1] = true;                                                                                   \
-        }                                                                                                              \
         hipLaunchKernelGGL((ppo_actor_rows_kernel<NJ>), dim3((unsigned)n_blocks), dim3(kThreads), shmem, st, g);       \
     } while (0)
     switch (ly.nJ) {
@@ -902,15 +912,10 @@ TSM_EXPORT int tsm_ppo_critic_rows_update(const float *critic_params, int32_t in
     const CritLay ly;
     const size_t shmem = (size_t)ly.total * sizeof(float);
     const int ns = (in_dim + kKs - 1) / kKs;
-    static bool attr_set[13] = {false};
+    if (const int rc = tsm_ppo_rows_init(); rc != TSM_OK) return rc;
     hipStream_t st = tsm_stream(stream);
 #define LAUNCHC(NS)                                                                                                    \
     case NS:                                                                                                           \
-        if (!attr_set[NS]) {                                                                                           \
-            TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ppo_critic_rows_kernel<NS>),                    \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                      \
-            attr_set[NS] = true;                                                                                       \
-        }                                                                                                              \
         hipLaunchKernelGGL((ppo_critic_rows_kernel<NS>), dim3((unsigned)n_blocks), dim3(kThreads), shmem, st, g);      \
         break;
     switch (ns) {

@@ -413,10 +413,8 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     const size_t shmem = ((size_t)ly.total + extra) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_kernel<64, NT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_kernel<64, 2 * NT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_kernel<64, NT>)));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_kernel<64, 2 * NT>)));
         attr_set = true;
     }
     const int EPB = R / a.c.N;

@@ -511,7 +511,7 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
     a.stamps = g_tsm_stamps;
     const RrLay ly(h.obs_dim);
     const size_t shmem = (size_t)ly.total * sizeof(float);
-    TSM_REQUIRE(shmem <= 160 * 1024, "tsm_rollout_spread_actor: LDS layout of %zu bytes does not fit", shmem);
+    TSM_REQUIRE(shmem <= kTsmMaxLds, "tsm_rollout_spread_actor: LDS layout of %zu bytes does not fit", shmem);
     const int EPB = kRowsWg / a.c.N;
     const unsigned n_wg = (unsigned)ceil_div(a.c.n_env, EPB);
     static bool attr_set[4] = {false, false, false, false};
@@ -519,8 +519,7 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
 #define LAUNCH(NJ)                                                                                                     \
     do {                                                                                                               \
         if (!attr_set[NJ - 1]) {                                                                                       \
-            TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_rows_kernel<NJ>),                       \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
+            TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_rows_kernel<NJ>)));                      \
             attr_set[NJ - 1] = true;                                                                                   \
         }                                                                                                              \
         hipLaunchKernelGGL((rollout_rows_kernel<NJ>), dim3(n_wg), dim3(kThreads), shmem, st, a);                       \

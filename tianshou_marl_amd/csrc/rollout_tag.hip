@@ -366,11 +366,10 @@ TSM_EXPORT int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stre
     a.offset_inc = h.offset_inc; a.done_ctr = h.done_ctr;
     a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
     const size_t shmem = tag_rollout_lds_floats(a.d) * sizeof(float);
-    TSM_REQUIRE(shmem <= 156 * 1024, "tsm_rollout_tag: %zu bytes of LDS needed", shmem);
+    TSM_REQUIRE(shmem <= kTsmMaxLds, "tsm_rollout_tag: %zu bytes of LDS needed", shmem);
     static bool attr_set = false;
     if (!attr_set) {
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rollout_tag_kernel<64>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_tag_kernel<64>)));
         attr_set = true;
     }
     const int EPB = R / NA;

@@ -504,7 +504,22 @@ def ppo_update_fused(params, obs, act, logp_old, adv, returns, cfg: tsm_ppo_cfg,
 def ppo_actor_rows_supported(obs_dim: int, hidden_sizes, n_act: int, act: str = "relu") -> bool:
     """Does the one-launch actor step (csrc/ppo_rows.hip) cover this actor?  obs -> 128 -> 128 -> n_act, ReLU."""
     hs = list(hidden_sizes)
-    return act == "relu" and len(hs) == 2 and hs[0] == hs[1] and bool(call("tsm_ppo_actor_rows_supported", obs_dim, hs[0], n_act))
+    ok = act == "relu" and len(hs) == 2 and hs[0] == hs[1] and bool(call("tsm_ppo_actor_rows_supported", obs_dim, hs[0], n_act))
+    if ok:
+        _ppo_rows_init()
+    return ok
+
+
+_ppo_rows_ready = False
+
+
+def _ppo_rows_init() -> None:
+    """The rows kernels' LDS attributes, set when a host first asks whether they serve its nets -- at construction time,
+    outside any stream capture (tsm_ppo_rows_init)."""
+    global _ppo_rows_ready
+    if not _ppo_rows_ready and torch.cuda.is_available():
+        call("tsm_ppo_rows_init")
+        _ppo_rows_ready = True
 
 
 def ppo_actor_rows_grid(M: int) -> int:
@@ -547,8 +562,11 @@ def ppo_critic_rows_supported(in_dim: int, hidden_sizes, n_agent: int, act: str 
     """Does the one-launch critic step (csrc/ppo_rows.hip) cover this critic?  in_dim -> 128 -> 128 -> 1, ReLU."""
     hs = list(hidden_sizes)
     n_slice = -(-in_dim // 32)
-    return (act == "relu" and len(hs) == 2 and hs[0] == hs[1] and n_slice in (1, 2, 3, 4, 6, 8, 12)
-            and bool(call("tsm_ppo_critic_rows_supported", in_dim, hs[0], n_agent)))
+    ok = (act == "relu" and len(hs) == 2 and hs[0] == hs[1] and n_slice in (1, 2, 3, 4, 6, 8, 12)
+          and bool(call("tsm_ppo_critic_rows_supported", in_dim, hs[0], n_agent)))
+    if ok:
+        _ppo_rows_init()
+    return ok
 
 
 def ppo_critic_rows_grid(Mr: int) -> int:
