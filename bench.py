@@ -619,7 +619,8 @@ def run_tag(a, device, rank, world, dist, census=None):
     N = env.n_agent
     mk = lambda s: PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=device, seed=s), seed=s + rank, lr=3e-4,  # noqa: E731
                        shuffle="device", async_stats=True)  # learn(): one hipGraph replay per call, statistics resolve when read
-    #                                                          (lock-step eager launches under data parallelism)
+    #                                                          (data parallel: the groups' lock-step replays from captured graphs,
+    #                                                          parallel.learn_lockstep_graph)
     teams = {"adversaries": mk(1626), "good": mk(1627)}
     mgr = FlexibleMultiAgentPolicyManager(teams, env, mode="grouped", agent_groups=env.agent_groups)
     if dist is not None:

@@ -152,8 +152,56 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         out_w = LeaguePlayTrainer(mgr_w, matchmaking="random").train_step(Batch(adversaries=mk(300), good=mk(300)))
         assert set(out_w) == {"adversaries", "good"} and all(np.isfinite(v["loss"]) for v in out_w.values())
         assert calls_w == [2 * wide["good"].net.flat.numel()], calls_w  # ONE packed reduce for both wide groups
+        # ---- (3c) the league step from CAPTURED graphs: both groups' launch sequences interleaved, the packed reductions eager
+        # in between (gloo cannot be captured: segmented graphs) == the eager lock-step, bit for bit, over three steps ----
+        def league(captured: bool):
+            os.environ["TSM_LOCKSTEP_GRAPH"] = "1" if captured else "0"
+            tms = {"adversaries": PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=30), seed=1),
+                   "good": PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=40), seed=2)}
+            mgr_ = FlexibleMultiAgentPolicyManager(tms, _Env(), mode="grouped",
+                                                   agent_groups={"adversaries": _Env.agents[:2], "good": _Env.agents[2:]})
+            sync_ = attach_data_parallel(mgr_, dist)
+            calls_ = []
+            orig_ = sync_.all_reduce_sum_
+            sync_.all_reduce_sum_ = lambda t: (calls_.append((t.numel(), t.dtype)), orig_(t))[1]
+            g_ = torch.Generator().manual_seed(90 + rank)  # this rank's rows, the same in both modes
+            mk_ = lambda n: Batch(obs=torch.randn(n, D, generator=g_).numpy(), act=torch.randint(0, A, (n,), generator=g_).numpy(),  # noqa: E731
+                                  rew=torch.randn(n, generator=g_).numpy(), obs_next=torch.randn(n, D, generator=g_).numpy(),
+                                  terminated=np.zeros(n, bool))
+            tr = LeaguePlayTrainer(mgr_, matchmaking="random")
+            np.random.seed(9)
+            outs = [tr.train_step(Batch(adversaries=mk_(300), good=mk_(300))) for _ in range(3)]
+            outs = [{k: dict(v) for k, v in o.items()} for o in outs]
+            return tms, outs, calls_, sync_
+
+        tg, og, cg, sg = league(True)
+        te, oe, ce, _ = league(False)
+        os.environ.pop("TSM_LOCKSTEP_GRAPH", None)
+        for k in tg:
+            assert torch.equal(tg[k].net.flat.data, te[k].net.flat.data) and torch.equal(tg[k].exp_avg_sq, te[k].exp_avg_sq), k
+            assert tg[k].opt_step == te[k].opt_step == 3
+        assert og == oe
+        cache = sg._lockstep_graphs
+        assert len(cache) == 1 and "segments" in next(iter(cache.values()))  # captured once, replayed three times
+        Pq = tg["good"].net.flat.numel()
+        assert [c for c in cg if c[1] == torch.float32] == [(2 * Pq, torch.float32)] * 3  # ONE packed gradient reduce per step
+        assert len(cg) == 6 and all(c[1] == torch.float64 for c in cg[0::2])  # + the groups' statistics packs, packed too
+        # a single policy's learn() as a replica takes the same machinery (one job)
+        solo = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=31), seed=3)
+        solo_e = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=31), seed=3, use_graph=False)
+        attach_data_parallel(solo, dist)
+        attach_data_parallel(solo_e, dist)
+        for it in range(2):
+            bb = mk(200)
+            np.random.seed(100 + it)  # (shuffle="numpy": both must see the same np.random.permutation draws)
+            ls = solo.learn(bb, 64, 2)
+            np.random.seed(100 + it)
+            le = solo_e.learn(bb, 64, 2)
+            assert dict(ls) == dict(le)
+        assert torch.equal(solo.net.flat.data, solo_e.net.flat.data) and solo.opt_step == solo_e.opt_step == 2 * 2 * 3
         flats = torch.cat([net.flat.data, algo2.net.flat.data, teams["adversaries"].net.flat.data, teams["good"].net.flat.data,
-                           wide["adversaries"].net.flat.data, wide["good"].net.flat.data])
+                           wide["adversaries"].net.flat.data, wide["good"].net.flat.data, tg["adversaries"].net.flat.data,
+                           tg["good"].net.flat.data, solo.net.flat.data])
         np.save(os.path.join(out_dir, f"p{rank}.npy"), flats.cpu().numpy())
         # ---- (4) unequal shards are refused instead of deadlocking ----
         algo3 = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=1), dispatch="pooled", shuffle="numpy", use_graph=False)
@@ -230,6 +278,38 @@ def _rccl_worker(rank: int, world: int, port: int, out_dir: str) -> None:
                 finals[(kind, use_graph)] = (algo.net.flat.data.clone(), algo.exp_avg_sq.clone())
             a, b = finals[(kind, True)], finals[(kind, False)]
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), kind  # captured collectives == eager collectives
+        # the league step of two policy groups: launch sequences + packed reductions captured into ONE hipGraph
+        from tianshou_marl_amd.algorithm.multiagent import FlexibleMultiAgentPolicyManager, LeaguePlayTrainer
+        from tianshou_marl_amd.data import Batch
+
+        class _Env:
+            agents = ["adversary_0", "adversary_1", "agent_0"]
+
+        def league(captured: bool):
+            os.environ["TSM_LOCKSTEP_GRAPH"] = "1" if captured else "0"
+            tms = {"adversaries": PPO(net=DiscreteActorCritic(18, 5, 64, device=DEV, seed=30), seed=1),
+                   "good": PPO(net=DiscreteActorCritic(18, 5, 64, device=DEV, seed=40), seed=2)}
+            mgr_ = FlexibleMultiAgentPolicyManager(tms, _Env(), mode="grouped",
+                                                   agent_groups={"adversaries": _Env.agents[:2], "good": _Env.agents[2:]})
+            sync_ = attach_data_parallel(mgr_, dist)
+            assert all(p.graph_collectives for p in tms.values())
+            g_ = torch.Generator().manual_seed(90)
+            mk_ = lambda n: Batch(obs=torch.randn(n, 18, generator=g_).numpy(), act=torch.randint(0, 5, (n,), generator=g_).numpy(),  # noqa: E731
+                                  rew=torch.randn(n, generator=g_).numpy(), obs_next=torch.randn(n, 18, generator=g_).numpy(),
+                                  terminated=np.zeros(n, bool))
+            tr = LeaguePlayTrainer(mgr_, matchmaking="random")
+            np.random.seed(9)
+            outs = [{k: dict(v) for k, v in tr.train_step(Batch(adversaries=mk_(300), good=mk_(300))).items()} for _ in range(3)]
+            return tms, outs, sync_
+
+        tg, og, sg = league(True)
+        te, oe, _ = league(False)
+        os.environ.pop("TSM_LOCKSTEP_GRAPH", None)
+        assert og == oe
+        for k in tg:
+            assert torch.equal(tg[k].net.flat.data, te[k].net.flat.data) and torch.equal(tg[k].exp_avg_sq, te[k].exp_avg_sq), k
+        cache = sg._lockstep_graphs
+        assert len(cache) == 1 and next(iter(cache.values())).get("graph") is not None  # ONE graph, collectives inside
         with open(os.path.join(out_dir, "ok"), "w") as f:
             f.write("ok")
     except BaseException:

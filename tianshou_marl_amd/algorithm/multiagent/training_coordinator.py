@@ -79,11 +79,16 @@ class MATrainer:
         distinct = len({id(p) for _, p, _ in pairs}) == len(pairs)
         if sync is not None and len(pairs) > 1 and distinct and all(
                 getattr(p, "_grad_sync", None) is sync and callable(getattr(p, "learn_steps", None)) for _, p, _ in pairs):
-            from ...parallel import learn_lockstep
+            from ...parallel import learn_lockstep, learn_lockstep_graph, lockstep_graphs_enabled
 
             pairs.sort(key=lambda t: str(t[0]))  # the packing order must not depend on a rank's matchmaking draw
-            sync.check_same([a for a, _, _ in pairs], "the policy groups that train in this step")
-            out = learn_lockstep([p.learn_steps(b) for _, p, b in pairs], sync)
+            if lockstep_graphs_enabled() and all(hasattr(p, "_learn_static") and p.learn_graph_ok() for _, p, _ in pairs):
+                # the groups' launch sequences and their packed reductions replay from captured graphs (the agreement
+                # check on groups AND row counts is the function's own)
+                out = learn_lockstep_graph([(p, b, None, 1) for _, p, b in pairs], sync, names=[a for a, _, _ in pairs])
+            else:
+                sync.check_same([a for a, _, _ in pairs], "the policy groups that train in this step")
+                out = learn_lockstep([p.learn_steps(b) for _, p, b in pairs], sync)
             return {a: r for (a, _, _), r in zip(pairs, out)}
         return {a: p.learn(b) for a, p, b in pairs}
 

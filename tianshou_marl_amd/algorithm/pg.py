@@ -112,6 +112,13 @@ class Reinforce(PPO):
         st = super()._update_with_batch(pb, batch_size, repeat, agent=agent, buffer=buffer, perm_base=perm_base)
         return LossSequenceTrainingStats(loss=st.loss, gradient_steps=st.gradient_steps)
 
+    # `learn` below has its own preprocessing (no critic, Monte-Carlo returns): PPO's static-buffer / generator forms of
+    # learn() do not describe it, so Reinforce policies of a data-parallel manager learn one after the other
+    learn_steps = None
+
+    def learn_graph_ok(self, repeat: int = 1) -> bool:
+        return False
+
     def learn(self, batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
         """One Reinforce pass on an explicit agent batch (one time-ordered lane; the last row ends the lane)."""
         dev = self.device

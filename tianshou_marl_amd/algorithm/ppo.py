@@ -719,68 +719,97 @@ class PPO(nn.Module):
 
     def learn(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
         """One PPO pass on an explicit agent batch holding obs, act, rew, obs_next, terminated[, truncated].
-        Rows are one time-ordered lane (the reference's per-agent Batch); GAE treats the last row as end."""
-        if self.use_graph and self._grad_sync is None and not (self.recompute_adv and repeat > 1):
-            return self._learn_graph(batch, batch_size, repeat)
+        Rows are one time-ordered lane (the reference's per-agent Batch); GAE treats the last row as end.
+        Single GPU: ONE hipGraph replay per call.  Data-parallel replicas: the same static-buffer body with its collectives
+        captured (RCCL) or between segmented graphs (`parallel.learn_lockstep_graph` with this one policy)."""
+        if self.learn_graph_ok(repeat):
+            if self._grad_sync is None:
+                return self._learn_graph(batch, batch_size, repeat)
+            from ..parallel import learn_lockstep_graph, lockstep_graphs_enabled
+
+            if lockstep_graphs_enabled():
+                return learn_lockstep_graph([(self, batch, batch_size, repeat)], self._grad_sync)[0]
         return drive_steps(self.learn_steps(batch, batch_size, repeat, **kwargs), self._grad_sync)
 
-    def _learn_graph(self, batch: Batch, batch_size: int | None, repeat: int) -> dict[str, float]:
-        """`learn` as ONE hipGraph replay per call (the MARL trainers call it once per policy and step,
-        training_coordinator.py:118,154,336): the batch is copied into static HBM buffers, then the critic passes, GAE,
-        the permutations, advantage statistics and every gradient step replay as captured -- the same launches in the
-        same order as `learn_steps`, hence the same bits.  The optimizer step count and the permutation counter live in
-        HBM, so replays advance them; the learning rate is read from HBM."""
+    def learn_graph_ok(self, repeat: int = 1) -> bool:
+        """Can `learn` run from static buffers inside captured graphs?  (recompute_advantage re-runs the critic between
+        repeats from the host.)"""
+        return bool(self.use_graph and not (self.recompute_adv and repeat > 1))
+
+    def _learn_static(self, n: int, batch_size: int | None, repeat: int, has_trunc: bool) -> dict:
+        """Static HBM buffers + the launch sequence of one `learn` call on n rows (cached per shape): `w["body"]()` is a
+        generator that issues the critic passes, GAE, the permutations, advantage statistics and every gradient step on
+        the static buffers -- the same launches in the same order as `learn_steps`, hence the same bits -- and, for a
+        data-parallel replica, YIELDS every tensor that has to be summed over the ranks (the advantage-statistics pack,
+        the flat gradient of each step) exactly where `learn_steps` does.  The optimizer step count and the permutation
+        counter live in HBM, so replays advance them; the learning rate is read from HBM."""
         dev = self.device
-        n = len(batch.rew)
         D, A, H = self.net.obs_dim, self.net.n_act, self.net.hidden
-        key = ("learn_graph", n, batch_size, repeat, "truncated" in batch, self.shuffle)
+        dp = self._grad_sync is not None
+        key = ("learn_graph", n, batch_size, repeat, has_trunc, self.shuffle, dp)
         w = self._ws.get(key)
+        if w is not None:
+            return w
         bounds = split_bounds(n, batch_size or -1, merge_last=True)
         n_steps = repeat * len(bounds)
-        if w is None:
-            self._warm_kernels(None)
-            P = self.net.flat.data
-            z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
-            nb_max = max(ops.ppo_update_grid(e - s) for s, e in bounds)
-            w = dict(obs=z(n, D), obs_next=z(n, D), act=z(n, dt=torch.int32), rew=z(n, 1), term=z(n, 1, dt=torch.uint8),
-                     trunc=z(n, 1, dt=torch.uint8), scal=z(n_steps, 4), step_dev=z(1, dt=torch.int64),
-                     slabs=torch.empty(nb_max, P.numel(), dtype=torch.float32, device=dev),
-                     partial=torch.empty(nb_max * 4, dtype=torch.float64, device=dev),
-                     perm=z(repeat, n, dt=torch.int64),
-                     mb_start=torch.as_tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=dev))
+        self._warm_kernels(None)
+        P = self.net.flat.data
+        z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
+        nb_max = max(ops.ppo_update_grid(e - s) for s, e in bounds)
+        w = dict(n=n, n_steps=n_steps, repeat=repeat, has_trunc=has_trunc,
+                 obs=z(n, D), obs_next=z(n, D), act=z(n, dt=torch.int32), rew=z(n, 1), term=z(n, 1, dt=torch.uint8),
+                 trunc=z(n, 1, dt=torch.uint8), scal=z(n_steps, 4), step_dev=z(1, dt=torch.int64),
+                 slabs=torch.empty(nb_max, P.numel(), dtype=torch.float32, device=dev),
+                 partial=torch.empty(nb_max * 4, dtype=torch.float64, device=dev),
+                 perm=z(repeat, n, dt=torch.int64),
+                 mb_start=torch.as_tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=dev))
+        if dp:
+            w["flat_g"] = z(P.numel())
 
-            def body():
-                # `flat` is the source of truth before the first Adam step of this call (the image may be stale)
-                cur = ops.policy_forward(P, w["obs"], A, H, image=None, mode="given", act=w["act"], want_logits=False)
-                nxt = ops.policy_forward(P, w["obs_next"], A, H, image=None, mode="none", want_logits=False)
-                ret, adv = ops.gae_lanes(cur["value"].view(n, 1), nxt["value"].view(n, 1), w["rew"], w["term"], w["trunc"],
-                                         self.gamma, self.gae_lambda)
-                ret, adv = ret.reshape(-1), adv.reshape(-1)
-                k = 0
-                for r in range(repeat):
-                    if self.shuffle != "numpy":
-                        ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, out=w["perm"][r:r + 1])
-                        ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
-                    perm = w["perm"][r]
-                    stats = (ops.ppo_adv_stats(adv, w["mb_start"], perm=perm, max_rows=max(e - s for s, e in bounds))
-                             if self.advantage_normalization else None)
-                    for j, (s_, e_) in enumerate(bounds):
-                        nb = ops.ppo_update_grid(e_ - s_)
-                        ops.ppo_update_fused(P, w["obs"], w["act"], cur["logp"], adv, ret, self._cfg, A, H,
-                                             adv_stats=None if stats is None else stats[j],
-                                             v_s_old=cur["value"] if self.value_clip else None, perm=perm[s_:e_],
-                                             image=self.net.image if k > 0 else None, M=e_ - s_, n_blocks=nb,
-                                             slabs=w["slabs"][:nb], partial=w["partial"], scalars=w["scal"][k],
-                                             opt_step_dev=w["step_dev"])
-                        ops.adam_step(P, w["slabs"][:nb], self.exp_avg, self.exp_avg_sq, 1, lr=self.lr, lr_dev=self._lr_dev,
-                                      betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
-                                      max_grad_norm=self.max_grad_norm, work=self._adam_work, step_dev=w["step_dev"],
-                                      image=self.net.image, image_map=self.net.image_map)
-                        k += 1
+        def body():
+            # `flat` is the source of truth before the first Adam step of this call (the image may be stale)
+            cur = ops.policy_forward(P, w["obs"], A, H, image=None, mode="given", act=w["act"], want_logits=False)
+            nxt = ops.policy_forward(P, w["obs_next"], A, H, image=None, mode="none", want_logits=False)
+            ret, adv = ops.gae_lanes(cur["value"].view(n, 1), nxt["value"].view(n, 1), w["rew"], w["term"], w["trunc"],
+                                     self.gamma, self.gae_lambda)
+            ret, adv = ret.reshape(-1), adv.reshape(-1)
+            k = 0
+            for r in range(repeat):
+                if self.shuffle != "numpy":
+                    ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, out=w["perm"][r:r + 1])
+                    ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
+                perm = w["perm"][r]
+                stats = (ops.ppo_adv_stats(adv, w["mb_start"], perm=perm, max_rows=max(e - s for s, e in bounds))
+                         if self.advantage_normalization else None)
+                if dp:  # the union minibatch's statistics: ONE f64 pack summed over the ranks (SURVEY.md section 8e)
+                    yield from self._global_adv_stats_steps(stats, w["mb_start"])
+                for j, (s_, e_) in enumerate(bounds):
+                    nb = ops.ppo_update_grid(e_ - s_)
+                    ops.ppo_update_fused(P, w["obs"], w["act"], cur["logp"], adv, ret, self._cfg, A, H,
+                                         adv_stats=None if stats is None else stats[j],
+                                         v_s_old=cur["value"] if self.value_clip else None, perm=perm[s_:e_],
+                                         image=self.net.image if k > 0 else None, M=e_ - s_, n_blocks=nb,
+                                         slabs=w["slabs"][:nb], partial=w["partial"], scalars=w["scal"][k],
+                                         opt_step_dev=w["step_dev"])
+                    grads = w["slabs"][:nb]
+                    if dp:
+                        ops.reduce_slabs(grads, out=w["flat_g"], scale=1.0 / self._grad_sync.world)
+                        yield w["flat_g"]  # summed over the ranks, in place
+                        grads = w["flat_g"].view(1, -1)
+                    ops.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, 1, lr=self.lr, lr_dev=self._lr_dev,
+                                  betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
+                                  max_grad_norm=self.max_grad_norm, work=self._adam_work, step_dev=w["step_dev"],
+                                  image=self.net.image, image_map=self.net.image_map)
+                    k += 1
 
-            w["body"] = body
-            self._ws[key] = w
-        # the batch into the static buffers (copy_ converts int64 actions / bool flags; host arrays are uploaded)
+        w["body"] = body
+        self._ws[key] = w
+        return w
+
+    def _learn_load(self, w: dict, batch: Batch) -> None:
+        """The batch into the static buffers (copy_ converts int64 actions / bool flags; host arrays are uploaded), this
+        call's host-drawn permutations, and the device-side step count if it went stale."""
+        n, D, repeat = w["n"], self.net.obs_dim, w["repeat"]
         t = lambda x: x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))  # noqa: E731
         w["obs"].copy_(t(batch.obs).reshape(n, D), non_blocking=True)
         w["obs_next"].copy_(t(batch.obs_next).reshape(n, D), non_blocking=True)
@@ -794,18 +823,15 @@ class PPO(nn.Module):
                 w["perm"][r].copy_(torch.as_tensor(np.random.permutation(n)), non_blocking=True)
         if w.get("step_host") != self.opt_step:  # the device-side step count is stale (eager updates, a loaded checkpoint)
             w["step_dev"].fill_(self.opt_step)
-        if "graph" not in w:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                w["body"]()
-            w["graph"] = graph
-        w["graph"].replay()
+
+    def _learn_finish(self, w: dict):
+        """Behind the replay: host-side counters, and the statistics on their way to a pinned host slot.
+        async_stats=True: the returned mapping waits for them only when it is read (the reference's learn() returns floats:
+        4 .item() per minibatch) -- the host never blocks here, except to keep at most 4 calls in flight."""
+        n_steps = w["n_steps"]
         self.opt_step += n_steps
         w["step_host"] = self.opt_step
         self.param_version += 1
-        # the statistics travel to a pinned host slot behind the replay.  async_stats=True: the returned mapping waits for
-        # them only when it is read (the reference's learn() returns floats: 4 .item() per minibatch) -- the host never
-        # blocks here, except to keep at most 4 calls in flight
         ring = w.setdefault("ring", [])
         if len(ring) < 4:
             ring.append(dict(h=torch.empty(n_steps, 4, dtype=torch.float32, pin_memory=True), event=torch.cuda.Event(),
@@ -823,6 +849,21 @@ class PPO(nn.Module):
             return dict(out)
         slot["pending"] = out
         return out
+
+    def _learn_graph(self, batch: Batch, batch_size: int | None, repeat: int) -> dict[str, float]:
+        """`learn` as ONE hipGraph replay per call (the MARL trainers call it once per policy and step,
+        training_coordinator.py:118,154,336): the batch is copied into static HBM buffers, then `_learn_static`'s body
+        replays as captured."""
+        w = self._learn_static(len(batch.rew), batch_size, repeat, "truncated" in batch)
+        self._learn_load(w, batch)
+        if "graph" not in w:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in w["body"]():  # (no replica: nothing is yielded)
+                    raise RuntimeError("a single-GPU learn() has no collectives")
+            w["graph"] = graph
+        w["graph"].replay()
+        return self._learn_finish(w)
 
     def __deepcopy__(self, memo):
         """Snapshot for opponent pools (training_coordinator.py:481-494): parameters, optimizer state and counters are

@@ -14,6 +14,8 @@ union minibatch; `global_adv_stats=False` keeps the rank-local statistics and sa
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 
@@ -177,13 +179,12 @@ class GradSync:
         return t
 
 
-def learn_lockstep(jobs, sync: "GradSync") -> list:
-    """Advance several policies' updates (generators from `PPO.learn_steps` / `_update_steps`) gradient step by gradient
-    step.  The flat gradients that fall due at the same step -- one per policy GROUP that trains this step -- are packed
-    into ONE buffer and summed over the ranks with ONE all-reduce (SURVEY.md section 8e: "one reduce per policy group
-    that trained this step, packed in one buffer"), then handed back so that each group applies its own Adam step.
-    Every rank must submit the same groups in the same order.  Returns the generators' results in job order."""
-    results = [None] * len(jobs)
+def lockstep_steps(jobs, results: list, packed_buf: torch.Tensor | None = None):
+    """The lock-step of `learn_lockstep` as a generator of ITS collectives: advances every live generator to its next
+    synchronisation point, packs what fell due into one buffer, yields it (the driver sums it over the ranks in place),
+    hands the sums back.  `results[i]` receives generator i's return value.  `packed_buf`: a preallocated buffer to pack
+    into (captured graphs want fixed addresses); tensors of one step share a dtype by construction (every group yields its
+    statistics pack, then its gradients), a mixed step is packed in the widest."""
     alive = dict(enumerate(jobs))
     while alive:
         due = {}
@@ -197,15 +198,106 @@ def learn_lockstep(jobs, sync: "GradSync") -> list:
             continue
         flats = list(due.values())
         if len(flats) == 1:
-            sync.all_reduce_sum_(flats[0])
+            yield flats[0]
             continue
-        packed = torch.cat([f.reshape(-1) for f in flats])
-        sync.all_reduce_sum_(packed)
+        total = sum(f.numel() for f in flats)
+        dt = flats[0].dtype
+        if packed_buf is not None and all(f.dtype == packed_buf.dtype for f in flats) and total <= packed_buf.numel():
+            packed = packed_buf[:total]
+            o = 0
+            for f in flats:
+                packed[o:o + f.numel()].copy_(f.reshape(-1))
+                o += f.numel()
+        else:
+            for f in flats:
+                dt = torch.promote_types(dt, f.dtype)
+            packed = torch.cat([f.reshape(-1).to(dt) for f in flats])
+        yield packed
         o = 0
         for f in flats:
             f.copy_(packed[o:o + f.numel()].view_as(f))
             o += f.numel()
+
+
+def learn_lockstep(jobs, sync: "GradSync") -> list:
+    """Advance several policies' updates (generators from `PPO.learn_steps` / `_update_steps`) gradient step by gradient
+    step.  The flat gradients that fall due at the same step -- one per policy GROUP that trains this step -- are packed
+    into ONE buffer and summed over the ranks with ONE all-reduce (SURVEY.md section 8e: "one reduce per policy group
+    that trained this step, packed in one buffer"), then handed back so that each group applies its own Adam step.
+    Every rank must submit the same groups in the same order.  Returns the generators' results in job order."""
+    results = [None] * len(jobs)
+    for t in lockstep_steps(jobs, results):
+        sync.all_reduce_sum_(t)
     return results
+
+
+def lockstep_graphs_enabled() -> bool:
+    """TSM_LOCKSTEP_GRAPH=0: `learn()` of data-parallel replicas stays on eager lock-step launches."""
+    import os
+
+    return os.environ.get("TSM_LOCKSTEP_GRAPH", "1") != "0"
+
+
+def learn_lockstep_graph(jobs, sync: "GradSync", names: list | None = None) -> list:
+    """`learn_lockstep` from captured graphs.  jobs = [(policy, batch, batch_size, repeat)], every policy a replica on `sync`
+    that offers `_learn_static / _learn_load / _learn_finish` (PPO).  Each policy's batch goes into ITS static buffers;
+    the lock-step of their launch sequences (`_learn_static(...)["body"]`) -- kernels of all groups interleaved, one packed
+    reduction per gradient step -- is captured once per (policies, shapes):
+      * collectives capturable (RCCL, probe passed: `policy.graph_collectives`): ONE hipGraph with the all-reduces inside;
+      * otherwise (gloo, failed probe, TSM_GRAPH_COLLECTIVES=0): every stretch between two collectives is its own hipGraph
+        on one shared pool and the collectives run eagerly in between -- as `PPO.update` does.
+    The same launches in the same order as the eager lock-step, hence the same bits.  Every call first makes sure that all
+    ranks submit the same groups (`names`) with the same row counts, minibatch sizes and repeats -- they select the graph,
+    and ranks replaying different graphs would pair different collectives (one tiny all-reduce, never cached)."""
+    sync.check_same([f"{nm}:{len(b.rew)}:{bs}:{rep}:{int('truncated' in b)}"
+                     for nm, (_, b, bs, rep) in zip(names or range(len(jobs)), jobs)],
+                    "the policy groups that train in this step (and their row counts)")
+    ws = [p._learn_static(len(b.rew), bs, rep, "truncated" in b) for p, b, bs, rep in jobs]
+    for (p, b, _, _), w in zip(jobs, ws):
+        p._learn_load(w, b)
+    inline = all(getattr(p, "graph_collectives", False) for p, _, _, _ in jobs)
+    key = (tuple((id(p), id(w)) for (p, _, _, _), w in zip(jobs, ws)), inline)
+    cache = sync.__dict__.setdefault("_lockstep_graphs", {})
+    g = cache.get(key)
+    if g is None:
+        total = sum(p.net.flat.numel() for p, _, _, _ in jobs)
+        g = dict(packed=torch.empty(total, dtype=torch.float32, device=ws[0]["obs"].device) if len(jobs) > 1 else None,
+                 results=[None] * len(jobs))
+
+        def steps():
+            return lockstep_steps([w["body"]() for w in ws], g["results"], g["packed"])
+
+        if inline:
+            graph = torch.cuda.CUDAGraph()
+
+            def run():
+                for t in steps():
+                    sync.all_reduce_sum_(t)
+
+            jobs[0][0]._capture_graph(graph, run)  # side stream, thread-local capture mode; a failure is fatal (see there)
+            g["graph"] = graph
+        else:
+            pool = torch.cuda.graph_pool_handle()
+            segs, gen, more = [], steps(), True
+            while more:
+                g_ = torch.cuda.CUDAGraph()
+                t_ = None
+                with torch.cuda.graph(g_, pool=pool):
+                    try:
+                        t_ = next(gen)
+                    except StopIteration:
+                        more = False
+                segs.append((g_, t_))
+            g["segments"] = segs
+        cache[key] = g
+    if "graph" in g:
+        g["graph"].replay()
+    else:
+        for g_, t_ in g["segments"]:
+            g_.replay()
+            if t_ is not None:
+                sync.all_reduce_sum_(t_)
+    return [p._learn_finish(w) for (p, _, _, _), w in zip(jobs, ws)]
 
 
 def _want_p2p() -> bool:
@@ -233,7 +325,10 @@ def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) 
             pol._grad_sync = sync
             if hasattr(pol.net, "sync_image"):
                 pol.net.sync_image()
-            pol.graph_collectives = False  # the packed reduction is driven from the host: eager launches
+            # the packed reduction of the groups that train in a step is captured with their launches when the backend's
+            # collectives can be (RCCL), and runs between segmented graphs otherwise (learn_lockstep_graph)
+            if dist.get_backend(group) != "nccl" and os.environ.get("TSM_GRAPH_COLLECTIVES") != "force":
+                pol.graph_collectives = False
         if dist.get_backend(group) == "nccl" and seen:
             sync._probe_device = seen[0].net.flat.device
         if _want_p2p() and seen:  # the packed gradient of every group that can train in one step
@@ -252,8 +347,6 @@ def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) 
         sync._probe_device = algo.net.flat.device
     # only RCCL ("nccl") collectives can be captured into a hipGraph; with any other backend the update stays on eager
     # launches (TSM_GRAPH_COLLECTIVES=force overrides: used to rehearse the failed-capture fallback)
-    import os
-
     if dist.get_backend(group) != "nccl" and os.environ.get("TSM_GRAPH_COLLECTIVES") != "force":
         algo.graph_collectives = False
     return sync
