@@ -286,7 +286,8 @@ def test_actor_rows_kernel_matches_float64_autograd(D, A, M, variant):
     stats = ops.ppo_adv_stats(adv_d, d(np.array([0, M], np.int64)), perm=perm_d, max_rows=M) if kw.get("adv_norm", True) else None
     slabs, partial = ops.ppo_actor_rows_update(f.flat.data, d(obs), d(act, torch.int32), d(logp_old), adv_d, cfg, A, H,
                                                adv_stats=None if stats is None else stats[0], perm=perm_d)
-    assert slabs.shape[0] == min(-(-M // 32), ops.device_info()["n_cu"])
+    n_cu = ops.device_info()["n_cu"]
+    assert slabs.shape[0] == ops.ppo_actor_rows_grid(M) and slabs.shape[0] in (min(-(-M // 32), n_cu), min(-(-M // 64), n_cu))
     # float64 replica
     lins = []
     for i in range(3):

@@ -19,7 +19,8 @@
 // assigned statically, slabs are summed in order by tsm_reduce_slabs / tsm_adam_step).
 // Algorithmic HBM traffic per sample and step: obs 4 D + act 4 + logp_old 4 + adv 4 + id 8; activations
 // never touch HBM (the dense path writes and re-reads 4 x 512 B per sample).
-#include "common.h"
+#include "actor_rows_dev.h"
+#include <stdlib.h>
 
 extern long long *g_tsm_stamps;  // abi.hip (diagnostics, tools/stamp_actor_rows.py)
 
@@ -74,22 +75,7 @@ struct RowsLay {  // LDS layout in floats
     }
 };
 
-struct ActorArgs {
-    const float *P;          // actor parameters: w0[H][D] b0[H] w1[H][H] b1[H] w2[A][H] b2[A]
-    const float *obs;        // [n][D]
-    const int32_t *act;
-    const float *logp_old, *adv;
-    const int64_t *perm;     // sample ids of the minibatch (nullable: first_row + i)
-    int64_t first_row, M;
-    const float *adv_stats;  // {mean, std} of the minibatch (adv_norm)
-    int D, A;
-    float eps_clip, dual_clip, ent_coef;
-    int adv_norm, kind;
-    float *slabs;            // [grid][P]
-    double *partial;         // [grid][4] = {sum clip objective, 0, sum entropy, 0}
-    long long *stamps;       // diagnostics only (tsm_debug_set_stamps): phase time stamps of workgroup 0, its tiles 0..3
-    int64_t *opt_step_dev;   // nullable: the device-resident optimizer step count, advanced by one per launch
-};
+using ActorArgs = TsmActorArgs;  // actor_rows_dev.h
 
 #define ASTAMP(k) do { if (g.stamps && blockIdx.x == 0 && tid == 0 && it < 4) g.stamps[it * 16 + (k)] = (long long)wall_clock64(); } while (0)
 
@@ -242,44 +228,9 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
             const int64_t i = tile * kRows + hs;
             float outv = 0.f;
             if (i < g.M) {  // uniform over the sample's 16 lanes
-                const bool on = hj < A;
-                const float invM = 1.0f / (float)g.M;
-                const float x = on ? lg[hj] : -INFINITY;
-                const float m = row16_max(x);
-                const float ex = on ? expf(x - m) : 0.f;
-                float sum = 0.f;
-                row_prefix_sum<0>(ex, A, sum);
-                const float lse = m + logf(sum);
-                const float l = on ? x - lse : 0.f;
-                const float p = on ? expf(l) : 0.f;
-                float h = 0.f;
-                row_prefix_sub<0>(p * l, A, h);
-                const int a_idx = h_act;
-                float a = h_adv;
-                if (g.adv_norm) a = (a - adv_mean) / (adv_std + 1e-8f);
-                const float logp = __shfl(l, (lane & 48) + a_idx, 64);
-                float ratio, obj, g_ratio;
-                if (g.kind == 1) {
-                    ratio = 1.f; obj = logp * a; g_ratio = a;
-                } else {
-                    ratio = expf(logp - h_lpo);
-                    const float lo = 1.0f - g.eps_clip, hi = 1.0f + g.eps_clip;
-                    const float rc = fminf(fmaxf(ratio, lo), hi);
-                    const float s1 = ratio * a, s2 = rc * a;
-                    const bool in_range = ratio >= lo && ratio <= hi;
-                    if (s1 < s2) { obj = s1; g_ratio = a; }
-                    else if (s1 > s2) { obj = s2; g_ratio = in_range ? a : 0.f; }
-                    else { obj = s1; g_ratio = 0.5f * a + (in_range ? 0.5f * a : 0.f); }
-                    if (g.dual_clip > 0.f && a < 0.f) {
-                        const float c = g.dual_clip * a;
-                        if (c > obj) { obj = c; g_ratio = 0.f; }
-                        else if (c == obj) g_ratio *= 0.5f;
-                    }
-                }
-                const float g_logp = -g_ratio * ratio * invM;
-                const float ec = g.ent_coef * invM;
-                if (on) outv = g_logp * ((hj == a_idx ? 1.f : 0.f) - p) + ec * p * (l + h);
-                if (hj == 0) { t_clip += obj; t_ent += h; }
+                float obj, ent;
+                outv = tsm_actor_head(g, lg[hj], hj, lane, h_act, h_adv, h_lpo, adv_mean, adv_std, obj, ent);
+                if (hj == 0) { t_clip += obj; t_ent += ent; }
             }
             lg[hj] = outv;  // rows beyond M and actions beyond A: zero
         }
@@ -803,10 +754,23 @@ TSM_EXPORT int64_t tsm_ppo_actor_rows_param_count(int32_t obs_dim, int32_t hidde
     return (int64_t)hidden * obs_dim + hidden + (int64_t)hidden * hidden + hidden + (int64_t)n_act * hidden + n_act;
 }
 
+// Which actor kernel serves a minibatch of M samples: 64-sample tiles with W2 in registers (csrc/actor_rows64.hip) once
+// every CU gets at least one of them, the 32-sample tiles of this file below that (twice the tiles to spread over the CUs).
+// TSM_ACTOR_TILE = 32 | 64 forces one (tests, A/B timing); read once per process.
+static bool actor_tile64(int64_t M) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("TSM_ACTOR_TILE");
+        forced = !e ? 0 : (atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : 0));
+    }
+    if (forced) return forced == 64;
+    return ceil_div(M, 64) >= n_cu();
+}
+
 // workgroups (= gradient slabs) for a minibatch of M samples: one per CU, never more than there are tiles
 TSM_EXPORT int tsm_ppo_actor_rows_grid(int64_t M) {
     if (M <= 0) return 0;
-    const int64_t tiles = ceil_div(M, kRows);
+    const int64_t tiles = ceil_div(M, actor_tile64(M) ? 64 : kRows);
     const int cu = n_cu();
     return (int)(tiles < cu ? tiles : cu);
 }
@@ -822,6 +786,7 @@ TSM_EXPORT int tsm_ppo_rows_init(void) {
     ALLOW(ppo_critic_rows_kernel<1>); ALLOW(ppo_critic_rows_kernel<2>); ALLOW(ppo_critic_rows_kernel<3>); ALLOW(ppo_critic_rows_kernel<4>);
     ALLOW(ppo_critic_rows_kernel<6>); ALLOW(ppo_critic_rows_kernel<8>); ALLOW(ppo_critic_rows_kernel<12>);
 #undef ALLOW
+    if (const int rc = tsm_actor_rows64_init(); rc != TSM_OK) return rc;
     done = true;
     return TSM_OK;
 }
@@ -842,7 +807,9 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
     TSM_REQUIRE(cfg->loss_kind == 0 || cfg->loss_kind == 1, "tsm_ppo_actor_rows_update: loss_kind must be 0 or 1");
     TSM_REQUIRE(cfg->dual_clip <= 0.0 || cfg->dual_clip > 1.0,
                 "Dual-clip PPO parameter should greater than 1.0 but got %g", cfg->dual_clip);
-    TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(M, kRows), "tsm_ppo_actor_rows_update: n_blocks = %d out of range", n_blocks);
+    const bool t64 = actor_tile64(M);
+    TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(M, t64 ? 64 : kRows), "tsm_ppo_actor_rows_update: n_blocks = %d out of range",
+                n_blocks);
     ActorArgs g{};
     g.P = actor_params; g.obs = obs; g.act = act; g.logp_old = logp_old; g.adv = adv; g.perm = perm;
     g.first_row = first_row; g.M = M; g.adv_stats = adv_stats; g.D = obs_dim; g.A = n_act;
@@ -851,6 +818,7 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
     g.slabs = grad_slabs_out; g.partial = loss_partial_out;
     g.stamps = g_tsm_stamps;
     g.opt_step_dev = opt_step_dev;
+    if (t64) return tsm_actor_rows64_launch(g, n_blocks, tsm_stream(stream));
     const RowsLay ly(obs_dim);
     const size_t shmem = (size_t)ly.total * sizeof(float);
     TSM_REQUIRE(shmem <= kTsmMaxLds, "tsm_ppo_actor_rows_update: LDS layout of %zu bytes does not fit", shmem);

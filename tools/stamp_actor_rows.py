@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Phase time stamps of the one-launch actor step (csrc/ppo_rows.hip, ppo_actor_rows_kernel) at BASELINE configs[2]:
-65 536 samples of 48 -> 128 -> 128 -> 5, workgroup 0, its tiles 1-3 (100 MHz wall clock).
+"""Phase time stamps of the one-launch actor step at BASELINE configs[2]: 65 536 samples of 48 -> 128 -> 128 -> 5, workgroup 0,
+its tiles 1-3 (100 MHz wall clock).  The minibatch size picks the kernel (csrc/actor_rows64.hip: 64-sample tiles, W2 in
+registers; csrc/ppo_rows.hip: 32-sample tiles); TSM_ACTOR_TILE=32 | 64 forces one.
 
     python tools/stamp_actor_rows.py
 """
@@ -39,9 +40,12 @@ ops.ppo_actor_rows_update(net.actor.flat.data, obs, act, lp, adv, cfg, A, H, adv
 torch.cuda.synchronize()
 lib.tsm_debug_set_stamps(None)
 s = st.cpu().numpy()[:64].reshape(4, 16)
-names = ["P0 commit X", "P1 layer 1", "P2 layer 2", "P3 logits (2 waves)", "P4 loss head (16 lanes per sample)", "P5 dW3 + dH2 mfma", "dH2 write",
+names = ["P0 commit X", "P1 layer 1", "P2 layer 2", "P3 logits", "P4 loss head (16 lanes per sample)", "P5 dW3 + dH2 mfma", "dH2 write",
          "P6 dW2 + dH1 mfma", "dH1 write", "P7 dW1"]
 for it in range(1, 4):
     d = [(s[it][k + 1] - s[it][k]) / 100.0 for k in range(10)]
     print(f"tile {it}: total {(s[it][10] - s[it][0]) / 100.0:.2f} us   " + ", ".join(f"{n_} {x:.2f}" for n_, x in zip(names, d)))
-print(f"n_blocks {nb}, tiles per workgroup {M // 32 // nb}")
+rows = 64 if -(-M // 64) >= ops.device_info()["n_cu"] else 32  # (the rule of tsm_ppo_actor_rows_grid)
+if os.environ.get("TSM_ACTOR_TILE") in ("32", "64"):
+    rows = int(os.environ["TSM_ACTOR_TILE"])
+print(f"n_blocks {nb}, {rows}-sample tiles, {M // rows // nb} tiles per workgroup (P3: logits on {'all eight waves, two k halves' if rows == 64 else 'two waves'})")
