@@ -557,16 +557,22 @@ def run_c3ppo(a, device):
     env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=device, seed=1626)
     D = env.obs_dim
     net = MLPActorCritic(D, 5, (128, 128), critic_obs_dim=N * D, device=device, seed=1626)
-    algo = GenericPPO(net=net, critic_input="global", n_agent=N, lr=3e-4, shuffle="device", seed=1626, dispatch=a.c3_dispatch)
+    algo = GenericPPO(net=net, critic_input="global", n_agent=N, lr=3e-4, shuffle="device", seed=1626, dispatch=a.c3_dispatch,
+                      async_stats=True)
     buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, D, device=device, ignore_obs_next=a.ignore_obs_next)
     col = Collector(algo, env, buf, async_stats=True)
     col.reset()
+    prev = [None]
 
     def step():
         with policy_within_training_step(algo):
             cs = col.collect(n_step=n_env * T)
             ts = algo.update(buf, mb, 1)
-        _resolve(cs)  # read every step's statistics (see one_step)
+        # every step's statistics are read, as in one_step: the collect statistics while the update runs on the device (the
+        # wait is for the rollout only), the training statistics one step late -- the device never idles behind the host
+        _resolve(cs)
+        _resolve(prev[0])
+        prev[0] = ts
         col.reset_buffer(keep_statistics=True)
         return ts
 

@@ -173,6 +173,51 @@ def test_generic_ppo_graph_replay_equals_eager_launches():
     assert l_e == l_g
 
 
+def test_generic_ppo_async_statistics_equal_the_synchronous_ones():
+    """GenericPPO(async_stats=True): update() returns before the device has finished and the training statistics are read one
+    step late from a ring of pinned slots (what bench.py --workload c3ppo does) -- the same numbers and the same weights as
+    the synchronous read, over more updates than the ring has slots; statistics left unread for four updates expire."""
+    def run(async_stats):
+        env = DeviceSimpleSpreadVectorEnv(16, 3, max_cycles=25, device=DEV, seed=6)
+        net = MLPActorCritic(env.obs_dim, 5, (128, 128), critic_obs_dim=3 * env.obs_dim, device=DEV, seed=6)
+        algo = GenericPPO(net=net, critic_input="global", n_agent=3, shuffle="device", seed=6, dispatch="pooled", async_stats=async_stats)
+        buf = DeviceVectorReplayBuffer(16 * 25, 16, 3, env.obs_dim, device=DEV)
+        col = Collector(algo, env, buf)
+        col.reset()
+        losses, prev = [], None
+        for _ in range(7):
+            with policy_within_training_step(algo):
+                col.collect(n_step=16 * 25)
+                ts = algo.update(buf, 96 * 3, 1)
+            if prev is not None:
+                losses.append(prev.get_loss_stats_dict())  # one step late
+            prev = ts
+            col.reset_buffer(keep_statistics=True)
+        losses.append(prev.get_loss_stats_dict())
+        return net.flat.data.cpu().numpy(), losses, algo
+
+    p_s, l_s, _ = run(False)
+    p_a, l_a, algo = run(True)
+    assert np.array_equal(p_s, p_a) and l_s == l_a and len(l_a) == 7
+    # unread statistics are dropped after four further updates, loudly
+    env = DeviceSimpleSpreadVectorEnv(16, 3, max_cycles=25, device=DEV, seed=6)
+    buf = DeviceVectorReplayBuffer(16 * 25, 16, 3, env.obs_dim, device=DEV)
+    col = Collector(algo, env, buf)
+    col.reset()
+    held = []
+    for _ in range(6):
+        with policy_within_training_step(algo):
+            col.collect(n_step=16 * 25)
+            held.append(algo.update(buf, 96 * 3, 1))
+        col.reset_buffer(keep_statistics=True)
+    # (this buffer's first update runs eagerly and returns finished statistics; the replays behind it use the ring: the slot of
+    # update 1 is taken again by update 5)
+    assert np.isfinite(list(held[0].get_loss_stats_dict().values())).all()
+    with pytest.raises(RuntimeError, match="not read within 4"):
+        held[1].get_loss_stats_dict()
+    assert np.isfinite(list(held[-1].get_loss_stats_dict().values())).all()
+
+
 @pytest.mark.parametrize("N,graph,H", [(3, False, 32), (8, True, 32), (4, False, 32), (8, True, 128), (3, False, 128)])
 def test_row_minibatches_with_centralized_critic_match_float64_autograd(oracle, N, graph, H):
     """Pooled dispatch + centralized critic: a minibatch is a set of joint rows; the critic runs once per row on the

@@ -438,15 +438,46 @@ class GenericPPO(PPO):
         self.opt_step += n_steps
         w["step_host"] = self.opt_step
         self.param_version += 1
-        s_h = w["scal"].cpu().numpy()
         mk = lambda x: A2CTrainingStats(  # noqa: E731
             loss=SequenceSummaryStats.from_sequence(x[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(x[:, 1]),
             vf_loss=SequenceSummaryStats.from_sequence(x[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(x[:, 3]),
             gradient_steps=len(x))
-        if per_agent:
-            per = len(s_h) // N
-            return MapTrainingStats({f"agent_{a}": mk(s_h[a * per:(a + 1) * per]) for a in range(N)})
-        return mk(s_h)
+
+        def finish(s_h):
+            if per_agent:
+                per = len(s_h) // N
+                return MapTrainingStats({f"agent_{a}": mk(s_h[a * per:(a + 1) * per]) for a in range(N)})
+            return mk(s_h)
+
+        if not self.async_stats:
+            return finish(w["scal"].cpu().numpy())
+        # async_stats=True (as PPO.update): the statistics travel to a pinned host slot behind the replay and are parsed when
+        # the returned object is first read -- the host goes on to queue the next collect while the update runs; a ring of
+        # four slots bounds the run-ahead
+        ring = w.setdefault("ring", [])
+        if len(ring) < 4:
+            ring.append(dict(h=torch.empty(w["scal"].shape, dtype=torch.float32, pin_memory=True), event=torch.cuda.Event(),
+                             pending=None))
+            slot = ring[-1]
+        else:
+            slot = ring[w.get("ring_pos", 0) % 4]
+            w["ring_pos"] = w.get("ring_pos", 0) + 1
+            if slot["pending"] is not None:
+                slot["pending"].expire("training stats were not read within 4 update() calls (async_stats=True)")
+            slot["event"].synchronize()
+        slot["h"].copy_(w["scal"], non_blocking=True)
+        slot["event"].record()
+
+        def build():
+            slot["event"].synchronize()
+            slot["pending"] = None
+            return finish(slot["h"].numpy().copy())
+
+        from ..data.stats import LazyStats
+
+        out = LazyStats(build)
+        slot["pending"] = out
+        return out
 
     def _update(self, buffer: DeviceVectorReplayBuffer, batch_size: int | None, repeat: int, t0: float):
         # (data parallel: only with capturable collectives -- RCCL; otherwise eager launches with inline collectives)

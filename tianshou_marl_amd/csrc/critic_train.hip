@@ -180,7 +180,10 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
 #pragma unroll
     for (int i = 0; i < 8; ++i) gW2[i] = f4{0.f, 0.f, 0.f, 0.f};
     gW3 = f4{0.f, 0.f, 0.f, 0.f};
-    float gB = 0.f;            // threads 128..255: db2[tid - 128]; 256..271: db3[tid - 256]
+    // db2 / db3 = column sums of dH2 / dQ over the tile's rows as per-thread PARTIAL sums, folded after the last tile (a serial
+    // loop of two waves / 16 threads over the 32 rows held the other waves at the next barrier): thread (c = tid & 127,
+    // q = tid >> 7) sums rows [8 q, 8 q + 8) of dH2 column c; thread (c = tid & 15, q = tid >> 4 < 16) rows 2 q, 2 q + 1 of dQ column c
+    float gB2 = 0.f, gB3 = 0.f;
     float gB1 = 0.f;           // db1[col], this lane's rows (folded over kq at the end)
     double t_a = 0.0, t_b = 0.0;  // loss statistics (LOSS 0: t_b = sum vf; LOSS 1: t_a = sum adv, t_b = sum sq)
 
@@ -362,11 +365,9 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
 #pragma unroll
             for (int r0 = 0; r0 < kRows; r0 += 4) gW3 = mfma4(a[r0 * kLdo], b[r0 * kLdh], gW3);
         }
-        if (tid >= 256 && tid < 272) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < kRows; ++r) s += lds[ly.Q + r * kLdo + (tid - 256)];
-            gB += s;
+        if (tid < 256) {
+            const float *q = lds + ly.Q + 2 * (tid >> 4) * kLdo + (tid & 15);
+            gB3 += q[0] + q[kLdo];
         }
         f4 d2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
         {
@@ -400,11 +401,9 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
                 for (int ti = 0; ti < 8; ++ti) gW2[ti] = mfma4(av, b[r0 * kLdh + 16 * ti], gW2[ti]);
             }
         }
-        if (tid >= 128 && tid < 256) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < kRows; ++r) s += lds[ly.H2 + r * kLdh + (tid - 128)];
-            gB += s;
+        {
+            const float *q = lds + ly.H2 + 8 * (tid >> 7) * kLdh + (tid & 127);
+            gB2 += ((q[0] + q[kLdh]) + (q[2 * kLdh] + q[3 * kLdh])) + ((q[4 * kLdh] + q[5 * kLdh]) + (q[6 * kLdh] + q[7 * kLdh]));
         }
         {
             f4 d1[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
@@ -453,8 +452,18 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         const int a = kq * 4 + r;
         if (a < n_out) __builtin_nontemporal_store(gW3[r], slab + sW3 + a * kH + 16 * w + c16);
     }
-    if (tid >= 128 && tid < 256) __builtin_nontemporal_store(gB, slab + sB2 + tid - 128);
-    else if (tid >= 256 && tid < 256 + n_out) __builtin_nontemporal_store(gB, slab + sB3 + tid - 256);
+    {   // fold the bias partials (fixed order) through the idle H1 region
+        float *sc = lds + ly.H1;   // [4][128] db2 | [16][16] db3
+        sc[tid] = gB2;
+        if (tid < 256) sc[512 + tid] = gB3;
+        __syncthreads();
+        if (tid < 128) __builtin_nontemporal_store((sc[tid] + sc[128 + tid]) + (sc[256 + tid] + sc[384 + tid]), slab + sB2 + tid);
+        else if (tid >= 256 && tid < 256 + n_out) {
+            float t = 0.f;
+            for (int k = 0; k < 16; ++k) t += sc[512 + 16 * k + (tid - 256)];
+            __builtin_nontemporal_store(t, slab + sB3 + tid - 256);
+        }
+    }
     {   // loss statistics: wave sums, then the waves in order
         double *red = reinterpret_cast<double *>(lds + ly.RED);
         const double a = wave_sum(t_a), b = wave_sum(t_b);
