@@ -383,11 +383,14 @@ def c3_rooflines(device):
         torch.cuda.synchronize()
         tot += e0.elapsed_time(e1) * 1e-3 / 10 / 5
     a_flop, a_bytes = 3 * f_actor * mb, (4 * D + 4 + 4 + 4 + 8) * mb
-    out.append({"kernel": "ppo_actor_rows_kernel<3> (actor 48-128-128-5: forward + policy loss + backward in one launch)",
+    t64 = -(-mb // 64) >= ops.device_info()["n_cu"]  # (tsm_ppo_actor_rows_grid's rule: 64-sample tiles once every CU gets one)
+    a_kernel = "actor_rows64_kernel" if t64 else "ppo_actor_rows_kernel"
+    out.append({"kernel": a_kernel + "<3> (actor 48-128-128-5: forward + policy loss + backward in one launch; "
+                          + ("64-sample tiles, layer-2 weights in registers)" if t64 else "32-sample tiles)"),
                 "rows": mb, "bound": "mfma", "flop_per_launch": a_flop, "us_per_launch": tot * 1e6,
                 "achieved": a_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": a_flop / tot / MFMA_F32_PEAK, "n_blocks": nb, "algorithmic_bytes_per_launch": a_bytes,
-                "slab_bytes_per_launch": nb * net.n_actor * 4, "traffic": pmc_traffic("ppo_actor_rows_kernel", nb * 512)})
+                "slab_bytes_per_launch": nb * net.n_actor * 4, "traffic": pmc_traffic(a_kernel, nb * 512)})
     # (iii) the critic step alone: the same minibatch as whole joint rows (mb / N rows of N * D floats); two launches
     # (csrc/critic_train.hip: forward + value loss + backward to dH1; csrc/critic_dw1.hip: dW1 as a split-K pass)
     mr = mb // N

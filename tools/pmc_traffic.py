@@ -40,7 +40,7 @@ def main(d_fetch: str, d_write: str, out: str) -> None:
     rows = []
     for key in sorted(set(fetch) | set(write)):
         if not any(t in key[0] for t in ("gae_lanes", "loss_kernel", "ppo_update", "rollout", "adam", "policy_forward",
-                                        "adv_stats", "finalize", "ppo_actor_rows", "ppo_critic_rows", "reduce_slabs",
+                                        "adv_stats", "finalize", "ppo_actor_rows", "actor_rows64", "ppo_critic_rows", "reduce_slabs",
                                         "critic_rows", "critic_dw1")):
             continue
         f = fetch.get(key, [])
