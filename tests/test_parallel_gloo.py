@@ -103,6 +103,33 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
             assert torch.allclose(g, torch.full((5,), (1.0 + k) * mean_rank))
         for k, g in enumerate(got_b):
             assert torch.allclose(g, torch.full((7,), (10.0 + k) * mean_rank))
+        # the same lock-step as a generator of its collectives with a PREALLOCATED packing buffer (what the captured form,
+        # parallel.learn_lockstep_graph, replays: fixed addresses) -- f32 gradients go through the buffer, a step whose
+        # tensors are f64 statistics packs (or mixed) is packed in the widest type; results as above
+        from tianshou_marl_amd.parallel import lockstep_steps
+
+        def group2(n_param, base):
+            pack = torch.full((3,), base * (rank + 1) / world, dtype=torch.float64)  # the advantage-statistics pack comes first
+            yield pack
+            g = torch.full((n_param,), (base + 1) * (rank + 1) / world)
+            yield g
+            return pack.clone(), g.clone()
+
+        buf = torch.empty(12)
+        res = [None, None]
+        seen_t = []
+        for t in lockstep_steps([group2(5, 1.0), group2(7, 10.0)], res, buf):
+            seen_t.append((t.dtype, t.numel(), t.data_ptr() == buf.data_ptr()))
+            sync.all_reduce_sum_(t)
+        assert seen_t == [(torch.float64, 6, False), (torch.float32, 12, True)]
+        for (pack, g), base in zip(res, (1.0, 10.0)):
+            assert torch.allclose(pack, torch.full((3,), base * mean_rank, dtype=torch.float64))
+            assert torch.allclose(g, torch.full((g.numel(),), (base + 1) * mean_rank))
+        # the captured lock-step selects its graph by (groups, row counts): ranks that disagree on them are stopped by the same
+        # every-call agreement check before any graph is replayed
+        sync.check_same(["adversaries:300:None:1:0", "good:300:None:1:0"], "the policy groups that train in this step (and their row counts)")
+        with pytest.raises(ValueError, match="disagree"):
+            sync.check_same([f"adversaries:{300 + rank}:None:1:0"], "the policy groups that train in this step (and their row counts)")
         # every rank must take the same number of gradient steps per update (unequal env shards can split into a
         # different number of minibatches -> a different number of all-reduces -> deadlock): agreed values pass, a
         # disagreement raises on EVERY rank instead of hanging
