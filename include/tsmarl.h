@@ -523,6 +523,9 @@ int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stream);
  * tsm_ppo_loss_fwd_bwd(loss_kind = 2) -> tsm_mlp_backward, and the gradient halves meet in tsm_adam_step.
  * actor_params: w0[H][D] b0[H] w1[H][H] b1[H] w2[A][H] b2[A] (torch parameters() order), H == 128, D <= 64, A <= 16.
  * Sample i of the minibatch is row perm[i] (NULL: first_row + i) of obs [n][D], act, logp_old, adv.
+ * Two kernels behind one entry point, picked by M alone (tsm_ppo_actor_rows_grid follows the same rule): 64-sample tiles with the
+ * layer-2 weights in registers (csrc/actor_rows64.hip) once every CU gets at least one such tile, 32-sample tiles with all
+ * weights in LDS (csrc/ppo_rows.hip) below that; environment variable TSM_ACTOR_TILE = 32 | 64 forces one (read once).
  * n_blocks = tsm_ppo_actor_rows_grid(M) persistent workgroups, each writes ONE gradient slab:
  * grad_slabs_out [n_blocks][tsm_ppo_actor_rows_param_count]; loss_partial_out f64 [n_blocks][4] =
  * {sum clip objective, 0, sum entropy, 0} (the layout tsm_ppo_finalize_many folds).
