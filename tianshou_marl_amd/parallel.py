@@ -262,7 +262,9 @@ def learn_lockstep_graph(jobs, sync: "GradSync", names: list | None = None) -> l
     if g is None:
         total = sum(p.net.flat.numel() for p, _, _, _ in jobs)
         g = dict(packed=torch.empty(total, dtype=torch.float32, device=ws[0]["obs"].device) if len(jobs) > 1 else None,
-                 results=[None] * len(jobs))
+                 results=[None] * len(jobs),
+                 # the key is made of object ids: keep the objects alive as long as the graphs that replay into their buffers
+                 keep=([p for p, _, _, _ in jobs], ws))
 
         def steps():
             return lockstep_steps([w["body"]() for w in ws], g["results"], g["packed"])
