@@ -513,20 +513,14 @@ def run_c3(a, device):
         e2.record()
     torch.cuda.synchronize()
     col.reset_buffer(keep_statistics=True)
-    # dominant kernel: the 384-wide critic GEMMs (forward on global_obs and global_obs_next, dgrad, wgrad) -- time the
-    # critic forward over one agent batch and price it against the f32-MFMA peak
+    # roofline of one learn() call AS EXECUTED (one hipGraph replay: V(last slot), TD step of the critic with its split-K dW1
+    # pass, actor step, finalize, two Adam launches), priced against the f32-MFMA peak: flops per row of the agent batch =
+    # critic forward + backward down to dH1 (2 (K1 H + H H + H n) + 4 H H + 4 n H) + dW1 (2 K1 H) + actor 3 x forward
     R = n_env * T
-    g = torch.randn(R, N * D, device=device)
-    pol.critic(g, save=False)
-    torch.cuda.synchronize()
-    f0, f1 = ev(), ev()
-    f0.record()
-    for _ in range(10):
-        pol.critic(g, save=False)
-    f1.record()
-    torch.cuda.synchronize()
-    fwd_s = f0.elapsed_time(f1) * 1e-3 / 10
-    fwd_flop = 2 * R * (N * D * H + H * H + H * N)
+    K1, A_ = N * D, 5
+    flop_row = (2 * (K1 * H + H * H + H * N) + 4 * H * H + 4 * N * H) + 2 * K1 * H + 6 * (D * H + H * H + H * A_)
+    learn_flop = R * flop_row + n_env * 2 * (K1 * H + H * H + H * N)
+    learn_s = e1.elapsed_time(e2) * 1e-3 / N
     out = {
         "metric": "env-steps/sec (n_env x n_agent) incl. CTDE update, simple_spread N=8", "value": n_env * N * T / dt,
         "unit": "env-steps/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3,
@@ -536,10 +530,11 @@ def run_c3(a, device):
                                "learn": "fused: rows read in place, critic forward / TD step / dW1 / actor step / two Adam steps"},
         "collect_ms": e0.elapsed_time(e1), "ctde_update_ms": e1.elapsed_time(e2),
         "losses_agent_0": {k: float(v) for k, v in losses["agent_0"].items()},
-        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<fwd> x3 (centralized critic forward, 384-128-128-8)",
-                     "achieved": fwd_flop / fwd_s / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": fwd_flop / fwd_s / MFMA_F32_PEAK, "traffic": None, "us_per_forward": fwd_s * 1e6,
-                     "hbm_GBps": (R * N * D * 4 + 2 * R * H * 4 * 2 + R * N * 4) / fwd_s / 1e9},
+        "roofline": {"bound": "mfma", "kernel": "CTDEPolicy.learn as executed (critic_rows_forward + critic_rows_train_kernel<24, true, 1> + "
+                               "critic_dw1_kernel + actor_rows64_kernel<3> + ctde_finalize + 2 x adam_segs; one hipGraph replay)",
+                     "achieved": learn_flop / learn_s / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": learn_flop / learn_s / MFMA_F32_PEAK, "traffic": None, "us_per_learn": learn_s * 1e6,
+                     "flop_per_learn": learn_flop, "rows_per_learn": R},
     }
     _ = ops
     _emit(json.dumps(out))
@@ -607,6 +602,15 @@ def run_c3ppo(a, device):
                                "num_envs=4096, T=25", "minibatch": mb, "repeat": 1, "dispatch": a.c3_dispatch,
                    **({"buffer": "ignore_obs_next=True"} if a.ignore_obs_next else {})},
         "collect_ms": e0.elapsed_time(e1), "gae_ppo_update_ms": e1.elapsed_time(e2),
+        # the whole GAE + PPO update as executed (one hipGraph replay), priced against the f32-MFMA peak: V(obs) of every joint
+        # row + V(obs_next) of the last slot, then forward + backward (2x) of every sample through the actor and of every joint
+        # row through the critic (the default bench line's roofline_grid[2] has the same count, medians and the kernels' own entries)
+        "roofline": (lambda fl, s_: {"bound": "mfma", "kernel": "C3 whole GAE + PPO update (GenericPPO.update, one hipGraph replay)",
+                                     "achieved": fl / s_ / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                                     "frac": fl / s_ / MFMA_F32_PEAK, "traffic": None, "flop_per_update": fl})(
+            (n_env * T + n_env) * 2 * (N * D * 128 + 128 * 128 + 128)
+            + 3 * (n_env * T * N * 2 * (D * 128 + 128 * 128 + 128 * 5) + n_env * T * 2 * (N * D * 128 + 128 * 128 + 128)),
+            e1.elapsed_time(e2) * 1e-3),
         "gradient_steps_per_update": sum(int(v) for k, v in d.items() if k.endswith("gradient_steps")),
         "loss": d.get("agent_0/loss", d.get("loss"))}))
 
