@@ -292,9 +292,16 @@ def test_c3_ctde_pipeline_full_size(n_env):
     _close(dq, (2 * (v - td) / (R * N)).unsqueeze(1).expand(R, N))
     # one learn() step per agent batch on the shared policy moves both networks and returns finite losses
     before = (pol.actor.flat.data.clone(), pol.critic.flat.data.clone())
+    from tianshou_marl_amd.algorithm.multiagent.training_coordinator import _attach_global
+
+    assert pol._store_path(_attach_global(batch, batch.agent_0)) is not None  # the one-launch kernels on the stores serve this shape
     out = SimultaneousTrainer(mgr).train_step(batch)
     assert set(out) == set(env.agents) and all(np.isfinite(list(v.values())).all() for v in out.values())
     assert not torch.equal(before[0], pol.actor.flat.data) and not torch.equal(before[1], pol.critic.flat.data)
+    # the first learner (agent_0) saw the initial weights: its losses, from the fused kernels reading the stores in place at
+    # FULL size, equal the float64 restatement above (and the dense head's `s`)
+    assert float(out["agent_0"]["critic_loss"]) == pytest.approx(float(((v - td) ** 2).mean()), rel=2e-5)
+    assert float(out["agent_0"]["actor_loss"]) == pytest.approx(float(-lp.mean() * (td - v).mean()), rel=1e-4, abs=1e-6)
 
 
 @pytest.mark.parametrize("max_cycles,T", [(6, 6), (4, 6)])
