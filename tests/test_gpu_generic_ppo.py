@@ -173,6 +173,35 @@ def test_generic_ppo_graph_replay_equals_eager_launches():
     assert l_e == l_g
 
 
+def test_c3_update_at_full_size_graph_equals_eager():
+    """BASELINE configs[2] at its full size (4096 envs x 8 agents x T = 25, minibatch 65 536 as whole joint rows): three
+    updates through the captured graph and through eager launches end with the same bits (64-sample actor kernel, two-launch
+    critic step, segmented Adam, one-launch V(obs), chained next values, the rollout's log-probabilities reused as logp_old):
+    a size-independent property checked at the size the bench runs."""
+    def run(graph):
+        n_env, N, T = 4096, 8, 25
+        env = DeviceSimpleSpreadVectorEnv(n_env, N, max_cycles=T, device=DEV, seed=11)
+        net = MLPActorCritic(env.obs_dim, 5, (128, 128), critic_obs_dim=N * env.obs_dim, device=DEV, seed=11)
+        algo = GenericPPO(net=net, critic_input="global", n_agent=N, shuffle="device", seed=11, dispatch="pooled", graph=graph)
+        buf = DeviceVectorReplayBuffer(n_env * T, n_env, N, env.obs_dim, device=DEV)
+        col = Collector(algo, env, buf)
+        col.reset()
+        losses = []
+        for _ in range(3):
+            with policy_within_training_step(algo):
+                col.collect(n_step=n_env * T)
+                ts = algo.update(buf, 65536, 1)
+            col.reset_buffer(keep_statistics=True)
+            losses.append(ts.get_loss_stats_dict())
+        return net.flat.data.clone(), algo.exp_avg_sq.clone(), losses, algo.opt_step
+
+    p_g, v_g, l_g, s_g = run(True)
+    p_e, v_e, l_e, s_e = run(False)
+    assert s_g == s_e == 3 * 12  # 102 400 joint rows / 8 192 -> 12 minibatches + merge-last
+    assert torch.equal(p_g, p_e) and torch.equal(v_g, v_e) and l_g == l_e
+    assert all(np.isfinite(list(d.values())).all() for d in l_g)
+
+
 def test_generic_ppo_async_statistics_equal_the_synchronous_ones():
     """GenericPPO(async_stats=True): update() returns before the device has finished and the training statistics are read one
     step late from a ring of pinned slots (what bench.py --workload c3ppo does) -- the same numbers and the same weights as
