@@ -115,6 +115,17 @@ class OnPolicyTrainer:
         self._best_epoch = 0
         self._stop_fn_flag = False
         self._start_time = time.time()
+        # A training loop is where a frozen launch thread costs device time: cap torch's intra-op pool to the CPU quota of the
+        # process (utils/host.py has the measurement; TSM_LIMIT_HOST_THREADS=0 leaves the pool alone)
+        import os
+
+        if os.environ.get("TSM_LIMIT_HOST_THREADS", "1") != "0":
+            from .utils.host import cpu_budget, limit_host_threads
+
+            import torch
+
+            if torch.get_num_threads() > cpu_budget():
+                limit_host_threads()
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _log(self, method: str, *args) -> None:
