@@ -24,6 +24,7 @@
 //     Two barriers per tile.
 // Algorithmic HBM traffic: 4 K1 B read + 4 B written per row.
 #include "critic_rows_dev.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -236,6 +237,252 @@ int launch_forward(const FwdArgs &g, int grid, hipStream_t st) {
     return (g.K1 & 3) == 0 ? launch_forward_v<KJ, true>(g, grid, st) : launch_forward_v<KJ, false>(g, grid, st);
 }
 
+// ================================================================================================================
+// EXPERIMENTAL, opt-in (TSM_SPLIT_BF16=1; never the default path): layer 1 of the same forward on the bf16 matrix pipe with
+// f32-level accuracy.  gfx950 issues v_mfma_f32_16x16x32_bf16 (16 384 flop) every 16 cycles per SIMD, v_mfma_f32_16x16x4_f32
+// (2 048 flop) every 32: 16x the rate.  An f32 value is the sum of three bf16 values, x = x0 + x1 + x2 (x0 = bf16(x),
+// x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 24 mantissa bits), so a product is the sum of nine bf16 x bf16 products, each
+// EXACT in the f32 accumulator; the six largest (x0 w0, x0 w1, x1 w0, x1 w1, x0 w2, x2 w0) leave a relative error of
+// ~2^-22 per product, the size of f32 rounding itself.  Six 16-cycle MFMAs per 32 k instead of eight 32-cycle ones: 2.67x.
+// The observation tile sits in LDS as three bf16 planes (same XOR swizzle, a plane row = 16 KJ2 dwords), split once when the
+// tile is committed; W1's fragments are split once per launch into registers (3 x 4 VGPRs per 32 k).  Layers 2 / 3 as above.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+struct FwdLayB {  // LDS layout in floats (a bf16 plane row: 16 KJ2 floats = 32 KJ2 bf16)
+    int ldx, W2, X, H1, B1, B2, W3, RED, RID, total;
+    __host__ __device__ explicit FwdLayB(int KJ2) {
+        ldx = ((16 * KJ2 + 63) / 64) * 64;
+        int o = 0;
+        W2 = o; o += kH * kLdh;
+        X = o; o += 3 * kRows * ldx;      // planes x0 | x1 | x2
+        H1 = o; o += kRows * kLdh;
+        B1 = o; o += kH;
+        B2 = o; o += kH;
+        W3 = o; o += kH;
+        RED = o; o += 8 * kRows;
+        RID = o; o += 2 * kRows;
+        total = o;
+    }
+    __device__ void launder() {
+        W2 = opaque_s(W2); X = opaque_s(X); H1 = opaque_s(H1); B1 = opaque_s(B1); B2 = opaque_s(B2); W3 = opaque_s(W3);
+        RED = opaque_s(RED); RID = opaque_s(RID);
+    }
+};
+
+template <int KJ2>   // K1 <= 32 KJ2, K1 % 4 == 0
+__global__ __launch_bounds__(kThreads) void critic_rows_forward_bf16x6_kernel(FwdArgs g) {
+    if (g.run_if && *g.run_if == 0) return;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    FwdLayB ly(KJ2);
+    constexpr int ldx = ((16 * KJ2 + 63) / 64) * 64;
+    constexpr int plane = kRows * ldx;
+    ly.launder();
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+    const int K1 = g.K1;
+    const int64_t n_tiles = (g.Mr + kRows - 1) / kRows;
+    const int oB1 = kH * K1, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + g.n_out * kH;
+    const int col = 16 * w + c16;
+
+    // ---- this wave's fragment of W1: lane (c16, kq) keeps W1[col][32 J + 8 kq + i], i < 8, as three bf16 x 8 ----
+    bf8 w0[KJ2], w1[KJ2], w2[KJ2];
+#pragma unroll
+    for (int J = 0; J < KJ2; ++J) {
+        const f4 lo4 = load_w1_frag<true>(g.P + (size_t)col * K1, 32 * J + 8 * kq, K1);
+        const f4 hi4 = load_w1_frag<true>(g.P + (size_t)col * K1, 32 * J + 8 * kq + 4, K1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __bf16 h, m, l;
+            split3(lo4[i], h, m, l); w0[J][i] = h; w1[J][i] = m; w2[J][i] = l;
+            split3(hi4[i], h, m, l); w0[J][4 + i] = h; w1[J][4 + i] = m; w2[J][4 + i] = l;
+        }
+    }
+    stage_w2_rows(lds + ly.W2, g.P + oW2);
+    const int n_out = g.n_out;
+    if (tid < kH) {
+        lds[ly.B1 + tid] = g.P[oB1 + tid];
+        lds[ly.B2 + tid] = g.P[oB2 + tid];
+        float s3 = 0.f;
+        for (int j = 0; j < n_out; ++j) s3 += g.P[oW3 + j * kH + tid];
+        lds[ly.W3 + tid] = n_out == 1 ? s3 : s3 / (float)n_out;
+    }
+    for (int e = tid; e < 3 * plane; e += kThreads) lds[ly.X + e] = 0.f;
+    float b3 = 0.f;
+    for (int j = 0; j < n_out; ++j) b3 += g.P[oB3 + j];
+    if (n_out > 1) b3 /= (float)n_out;
+
+    // ---- staging: thread -> f32 chunks (4 floats) q = tid + 512 u of the 32 x (8 KJ2) chunk grid ----
+    constexpr int CPR = 8 * KJ2;
+    constexpr int NX = (kRows * CPR + kThreads - 1) / kThreads;
+    f4 xr[NX];
+    int64_t *rid = reinterpret_cast<int64_t *>(lds + ly.RID);
+    auto load_id = [&](int64_t tile_) -> int64_t {
+        const int64_t i = tile_ * kRows + (tid & (kRows - 1));
+        const int64_t ic = i < g.Mr ? i : g.Mr - 1;
+        return g.rows ? g.rows[ic] : g.first_row + ic;
+    };
+    auto fetch_tile = [&](int64_t tile_) {
+        const int tq = opaque_v(tid);
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int q = tq + kThreads * u, r = (q / CPR) & (kRows - 1), c = q % CPR;
+            const int64_t i = tile_ * kRows + r;
+            const bool ok = q < kRows * CPR && i < g.Mr && 4 * c < K1;
+            const int64_t row = rid[r];
+            const int cc = 4 * c < K1 ? 4 * c : K1 - 4;
+            const float4 v = *reinterpret_cast<const float4 *>(g.obs + row * K1 + cc);
+            xr[u] = ok ? f4{v.x, v.y, v.z, v.w} : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit_tile = [&]() {   // split into the three planes: f32 chunk c -> half (c & 1) of bf16 chunk c >> 1
+        const int tq = opaque_v(tid);
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int q = tq + kThreads * u, r = q / CPR, c = q - r * CPR;
+            if (q < kRows * CPR) {
+                bf2 p[3][2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 h, m, l;
+                    split3(xr[u][e], h, m, l);
+                    p[0][e >> 1][e & 1] = h; p[1][e >> 1][e & 1] = m; p[2][e >> 1][e & 1] = l;
+                }
+                float *dst = lds + ly.X + xs_off(r, c >> 1, ldx) + 2 * (c & 1);
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    *reinterpret_cast<bf2 *>(dst + s_ * plane) = p[s_][0];
+                    *reinterpret_cast<bf2 *>(dst + s_ * plane + 1) = p[s_][1];
+                }
+            }
+        }
+    };
+
+    int64_t tile = blockIdx.x;
+    const int64_t gs = gridDim.x;
+    int64_t my_id = 0;
+    if (tid < kRows) rid[tid] = load_id(tile);
+    __syncthreads();
+    fetch_tile(tile);
+    if (tid < kRows) my_id = load_id(tile + gs);
+    commit_tile();
+    __syncthreads();
+    if (tid < kRows) { rid[tid] = my_id; my_id = load_id(tile + 2 * gs); }
+    __syncthreads();
+    fetch_tile(tile + gs);
+    __syncthreads();
+
+    for (; tile < n_tiles; tile += gs) {
+        if (tid < kRows) { rid[tid] = my_id; my_id = load_id(tile + 3 * gs); }
+        // ---- L1 on the bf16 pipe: six products per 32 k and row half, smallest terms first ----
+        {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            const float *xa[4] = {lds + ly.X + xa_base(c16, kq, ldx, 0), lds + ly.X + xa_base(c16, kq, ldx, 1),
+                                  lds + ly.X + xa_base(c16, kq, ldx, 2), lds + ly.X + xa_base(c16, kq, ldx, 3)};
+#pragma unroll
+            for (int J = 0; J < KJ2; ++J) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float *pa = xa[J & 3] + 64 * (J >> 2) + 16 * h * ldx;
+                    const bf8 a0 = *reinterpret_cast<const bf8 *>(pa);
+                    const bf8 a1 = *reinterpret_cast<const bf8 *>(pa + plane);
+                    const bf8 a2 = *reinterpret_cast<const bf8 *>(pa + 2 * plane);
+                    f4 c = acc[h];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, w0[J], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w2[J], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w1[J], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w0[J], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w1[J], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w0[J], c, 0, 0, 0);
+                    acc[h] = c;
+                }
+            }
+            const float bb = lds[ly.B1 + col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[ly.H1 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
+        }
+        __syncthreads();
+        commit_tile();
+        fetch_tile(tile + 2 * gs);
+        // ---- L2 + L3 (f32 matrix pipe, as in critic_rows_forward_kernel) ----
+        {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            const float *pa = lds + ly.H1 + c16 * kLdh + kq;
+            const float *pb = lds + ly.W2 + col * kLdh + kq;
+#pragma unroll
+            for (int k0 = 0; k0 < kH; k0 += 4) {
+                const float bv = pb[k0];
+                acc[0] = mfma4(pa[k0], bv, acc[0]);
+                acc[1] = mfma4(pa[16 * kLdh + k0], bv, acc[1]);
+            }
+            const float bb = lds[ly.B2 + col], w3c = lds[ly.W3 + col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = row16_sum(fmaxf(acc[mt][r] + bb, 0.f) * w3c);
+                    if (c16 == 0) lds[ly.RED + w * kRows + mt * 16 + kq * 4 + r] = s;
+                }
+        }
+        __syncthreads();
+        if (tid < kRows) {
+            float v = lds[ly.RED + tid];
+#pragma unroll
+            for (int ww = 1; ww < 8; ++ww) v += lds[ly.RED + ww * kRows + tid];
+            const int64_t i = tile * kRows + tid;
+            if (i < g.Mr) g.out[i] = v + b3;
+        }
+    }
+}
+
+template <int KJ2>
+int launch_forward_bf16(const FwdArgs &g, int grid, hipStream_t st) {
+    const FwdLayB ly(KJ2);
+    const size_t shmem = (size_t)ly.total * sizeof(float);
+    TSM_REQUIRE(shmem <= kMaxLds, "tsm_critic_rows_forward (bf16 x 6): LDS layout of %zu bytes does not fit", shmem);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(critic_rows_forward_bf16x6_kernel<KJ2>)));
+        attr_set = true;
+    }
+    if (grid > 0) {
+        hipLaunchKernelGGL((critic_rows_forward_bf16x6_kernel<KJ2>), dim3((unsigned)grid), dim3(kThreads), shmem, st, g);
+        TSM_LAUNCH_CHECK();
+    }
+    return TSM_OK;
+}
+
+// experimental path on?  (read once; only widths with an instantiation: K1 % 4 == 0, K1 <= 384)
+int split_bf16_kj2(int K1) {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("TSM_SPLIT_BF16");
+        on = e && atoi(e) == 1;
+    }
+    if (!on || (K1 & 3)) return 0;
+    static const int inst[] = {2, 3, 6, 12};
+    for (int k : inst)
+        if (32 * k >= K1) return k;
+    return 0;
+}
+
+int dispatch_forward_bf16(int kj2, const FwdArgs &g, int grid, hipStream_t st) {
+    switch (kj2) {
+        case 2: return launch_forward_bf16<2>(g, grid, st);
+        case 3: return launch_forward_bf16<3>(g, grid, st);
+        case 6: return launch_forward_bf16<6>(g, grid, st);
+        default: return launch_forward_bf16<12>(g, grid, st);
+    }
+}
+
 int dispatch_forward(int kj, const FwdArgs &g, int grid, hipStream_t st) {
     switch (kj) {
         case 1: return launch_forward<1>(g, grid, st);
@@ -266,7 +513,8 @@ int tsm_critic_train_init(int32_t in_dim);  // critic_train.hip
 TSM_EXPORT int tsm_critic_rows_init(int32_t in_dim, int32_t hidden) {
     TSM_REQUIRE(tsm_critic_rows_forward_supported(in_dim, hidden), "tsm_critic_rows_init: unsupported critic %d -> %d", in_dim, hidden);
     FwdArgs g{};
-    const int rc = dispatch_forward(pick_kj(in_dim), g, 0, nullptr);
+    int rc = dispatch_forward(pick_kj(in_dim), g, 0, nullptr);
+    if (rc == TSM_OK && split_bf16_kj2(in_dim)) rc = dispatch_forward_bf16(split_bf16_kj2(in_dim), g, 0, nullptr);
     return rc != TSM_OK ? rc : tsm_critic_train_init(in_dim);
 }
 
@@ -283,5 +531,7 @@ TSM_EXPORT int tsm_critic_rows_forward(const float *critic_params, int32_t in_di
     g.out = values_out; g.run_if = run_if; g.n_out = n_out;
     const int64_t tiles = ceil_div(Mr, kRows);
     const int cu = n_cu_dev();
+    if (const int kj2 = split_bf16_kj2(in_dim))   // experimental, opt-in (TSM_SPLIT_BF16=1)
+        return dispatch_forward_bf16(kj2, g, (int)(tiles < cu ? tiles : cu), tsm_stream(stream));
     return dispatch_forward(pick_kj(in_dim), g, (int)(tiles < cu ? tiles : cu), tsm_stream(stream));
 }
