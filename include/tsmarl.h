@@ -636,6 +636,13 @@ int tsm_p2p_create(int32_t rank, int32_t world, int64_t max_floats, void **handl
 int tsm_p2p_export(void *handle, void *ipc_handle_out);
 int tsm_p2p_import(void *handle, int32_t peer, const void *ipc_handle);
 int tsm_p2p_all_reduce(void *handle, float *data, int64_t n, void *stream);
+/* tsm_reduce_slabs (scale 1 / world) + tsm_p2p_all_reduce + tsm_adam_step (without a gradient-norm clip) in ONE launch: every
+ * workgroup sums the slabs of its own slice of the parameter vector, runs the one-shot protocol on that slice and applies Adam to
+ * it (the three steps have no grid-wide dependency), so the replicas' gradient step is one launch like the single-GPU step.
+ * Bit-identical to the three-launch form.  Arguments as tsm_adam_step; n <= the handle's max_floats. */
+int tsm_p2p_adam_step(void *handle, float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
+                      float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, const double *lr_dev, double beta1,
+                      double beta2, double eps, double weight_decay, float *param_image, const int32_t *image_map, void *stream);
 int tsm_p2p_failed(void *handle);
 int tsm_p2p_destroy(void *handle);
 

@@ -392,16 +392,44 @@ def _p2p_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         p2p.close()
         # (c) the product path: PPO.update on two env shards with the gradient on the peer-memory path equals the same update
         # with the gradient on the process group's all-reduce (two ranks: x0 + x1 either way), bit for bit
+        # (b2) the one-launch gradient step (slab sum x 1 / world + all-reduce + Adam, each workgroup on its own slice) against
+        # the three launches it replaces, on random slabs: parameters, both moments and the padded image, bit for bit, over
+        # several steps with a device-resident step count
+        from tianshou_marl_amd import ops
+
+        p2q = P2PAllReduce(dist, None, torch.device("cuda", 0), n)
+        gs = torch.Generator(device=DEV).manual_seed(7)          # the same parameters on both ranks ...
+        gr = torch.Generator(device=DEV).manual_seed(70 + rank)  # ... different gradients
+        P1 = torch.randn(n, device=DEV, generator=gs)
+        P2, m1, v1, m2, v2 = P1.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        imap = torch.randperm(n + 64, device=DEV, generator=gs)[:n].to(torch.int32).contiguous()
+        img1, img2 = torch.zeros(n + 64, device=DEV), torch.zeros(n + 64, device=DEV)
+        sd1, sd2 = torch.ones(1, dtype=torch.int64, device=DEV), torch.ones(1, dtype=torch.int64, device=DEV)
+        flat = torch.empty(n, device=DEV)
+        for it in range(5):
+            slabs = torch.randn(37 + it, n, device=DEV, generator=gr) * 1e-2
+            ops.reduce_slabs(slabs, out=flat, scale=1.0 / world)
+            p2q.all_reduce_sum_(flat)
+            ops.adam_step(P1, flat.view(1, -1), m1, v1, 1, lr=3e-4, weight_decay=1e-3 * (it % 2), step_dev=sd1, image=img1, image_map=imap)
+            p2q.adam_step(P2, slabs, m2, v2, 1, lr=3e-4, weight_decay=1e-3 * (it % 2), step_dev=sd2, image=img2, image_map=imap)
+            sd1 += 1
+            sd2 += 1
+        torch.cuda.synchronize()
+        p2q.check()
+        assert torch.equal(P1, P2) and torch.equal(m1, m2) and torch.equal(v1, v2) and torch.equal(img1, img2)
+        p2q.close()
         finals = {}
-        for mode in ("p2p", "gloo"):
-            os.environ["TSM_P2P_ALLREDUCE"] = "1" if mode == "p2p" else "0"
+        for mode in ("p2p", "p2p_three_launches", "gloo"):
+            os.environ["TSM_P2P_ALLREDUCE"] = "0" if mode == "gloo" else "1"
+            os.environ["TSM_P2P_FUSED_ADAM"] = "0" if mode == "p2p_three_launches" else "1"
             np.random.seed(11 + rank)
             env = DeviceSimpleSpreadVectorEnv(32, 3, device=DEV, seed=50 + rank)
             bufr = DeviceVectorReplayBuffer(32 * 25, 32, 3, D, device=DEV)
             algo = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=20 + rank), lr=1e-3, dispatch="per_agent", shuffle="numpy",
                        seed=7 + rank)
             sync = attach_data_parallel(algo, dist)
-            assert (sync.p2p is not None) == (mode == "p2p")
+            assert (sync.p2p is not None) == (mode != "gloo")
+            assert sync.fused_step_ok(None, algo.net.flat.numel()) == (mode == "p2p")
             col = Collector(algo, env, bufr)
             col.reset()
             for _ in range(3):
@@ -413,7 +441,9 @@ def _p2p_worker(rank: int, world: int, port: int, out_dir: str) -> None:
                 sync.p2p.check()
             finals[mode] = (algo.net.flat.data.clone(), algo.exp_avg_sq.clone())
         os.environ.pop("TSM_P2P_ALLREDUCE", None)
-        assert torch.equal(finals["p2p"][0], finals["gloo"][0]) and torch.equal(finals["p2p"][1], finals["gloo"][1])
+        os.environ.pop("TSM_P2P_FUSED_ADAM", None)
+        for other in ("p2p_three_launches", "gloo"):
+            assert torch.equal(finals["p2p"][0], finals[other][0]) and torch.equal(finals["p2p"][1], finals[other][1]), other
         np.save(os.path.join(out_dir, f"p{rank}.npy"), finals["p2p"][0].cpu().numpy())
     except BaseException:
         import traceback

@@ -395,6 +395,13 @@ class PPO(nn.Module):
                                      n_blocks=nb, slabs=slabs[:nb], partial=partial, scalars=scal[k])
                 self.opt_step += 1
                 grads = slabs[:nb]
+                if self._grad_sync is not None and self._grad_sync.fused_step_ok(self.max_grad_norm, P.numel()):
+                    # peer-memory path: slab sum, sum over the replicas and Adam in ONE launch (csrc/p2p.hip)
+                    self._grad_sync.p2p.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, self.opt_step, lr=self.lr,
+                                                  lr_dev=self._lr_dev, betas=self.betas, eps=self.adam_eps,
+                                                  weight_decay=self.weight_decay, image=self.net.image, image_map=self.net.image_map)
+                    k += 1
+                    continue
                 if self._grad_sync is not None:  # env-sharded data parallel: ONE flat all-reduce (parallel.py)
                     flat_g = self._ws.setdefault("flat_grad", torch.empty_like(P))
                     ops.reduce_slabs(grads, out=flat_g, scale=1.0 / self._grad_sync.world)  # mean = sum of g_i / world
@@ -551,6 +558,14 @@ class PPO(nn.Module):
                                                  M=e - s, n_blocks=nb, slabs=w["slabs"][:nb], partial=w["partial"][k],
                                                  want_scalars=False, opt_step_dev=w["step_dev"])
                             grads = w["slabs"][:nb]
+                            if self._grad_sync is not None and self._grad_sync.fused_step_ok(self.max_grad_norm, P.numel()):
+                                # peer-memory path: slab sum + sum over the replicas + Adam, ONE launch per gradient step
+                                self._grad_sync.p2p.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, 1, lr=self.lr,
+                                                              lr_dev=self._lr_dev, betas=self.betas, eps=self.adam_eps,
+                                                              weight_decay=self.weight_decay, step_dev=w["step_dev"],
+                                                              image=self.net.image, image_map=self.net.image_map)
+                                k += 1
+                                continue
                             if self._grad_sync is not None:  # env-sharded replicas: one captured RCCL all-reduce
                                 ops.reduce_slabs(grads, out=w["flat_g"], scale=1.0 / self._grad_sync.world)
                                 yield w["flat_g"]  # summed over the ranks, in place
@@ -792,6 +807,12 @@ class PPO(nn.Module):
                                          slabs=w["slabs"][:nb], partial=w["partial"], scalars=w["scal"][k],
                                          opt_step_dev=w["step_dev"])
                     grads = w["slabs"][:nb]
+                    if dp and self._grad_sync.fused_step_ok(self.max_grad_norm, P.numel()):
+                        self._grad_sync.p2p.adam_step(P, grads, self.exp_avg, self.exp_avg_sq, 1, lr=self.lr, lr_dev=self._lr_dev,
+                                                      betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
+                                                      step_dev=w["step_dev"], image=self.net.image, image_map=self.net.image_map)
+                        k += 1
+                        continue
                     if dp:
                         ops.reduce_slabs(grads, out=w["flat_g"], scale=1.0 / self._grad_sync.world)
                         yield w["flat_g"]  # summed over the ranks, in place

@@ -14,50 +14,9 @@
 // the 4 waves walk disjoint slab subsets with 8 loads in flight each; partial sums meet in LDS.
 // Optionally the kernel also refreshes a padded "LDS image" copy of the parameters (img[map[i]] = p[i]) that
 // the fused MLP kernels stage with straight 16-B copies (csrc/mlp_fused.hip).
-#include "common.h"
+#include "adam_dev.h"
 
 namespace {
-
-constexpr int kCols = 64;  // parameters per workgroup
-
-__device__ __forceinline__ double ipow(double b, int64_t e) {
-    double r = 1.0;
-    while (e > 0) {
-        if (e & 1) r *= b;
-        b *= b;
-        e >>= 1;
-    }
-    return r;
-}
-
-// `n` = parameters covered (bounds), `stride` = floats between two consecutive slabs
-__device__ __forceinline__ float slab_sum_block(const float *__restrict__ slabs, int32_t n_slab, int64_t n,
-                                                int64_t i, float *sm /* [4][64] */, int64_t stride) {
-    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    float acc = 0.f;
-    if (i < n) {
-        int s = sl;
-#pragma unroll 1
-        for (; s + 60 < n_slab; s += 64) {  // 16 independent loads in flight per lane (32 measured no faster)
-            float t[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc += t[u];
-        }
-        for (; s + 28 < n_slab; s += 32) {
-            float t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += t[u];
-        }
-        for (; s < n_slab; s += 4) acc += slabs[(int64_t)s * stride + i];
-    }
-    sm[sl * 64 + lane] = acc;
-    __syncthreads();
-    return sm[lane] + sm[64 + lane] + sm[128 + lane] + sm[192 + lane];
-}
 
 // pass 1 of the clipping path: g = sum of slabs -> work[0..n), per-block sum of squares -> work[n + blk]
 __global__ __launch_bounds__(256) void reduce_norm_kernel(const float *__restrict__ slabs, int32_t n_slab, int64_t n,
@@ -105,23 +64,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         g = slab_sum_block(slabs, n_slab, n, i, sm, n);
     }
     if (sl != 0 || i >= n) return;
-    // bias corrections from the (host or device-resident) step count, in f64 like torch's python scalars
-    // beta^step by repeated squaring in f64 (step is an integer; ~20 multiplies instead of the pow() routine)
-    const int64_t step = step_dev ? *step_dev : step_host;
-    // the learning rate may live in HBM (LR schedulers, algorithm_base.py:626-627): a captured graph then follows it
-    const double lr = lr_dev ? *lr_dev : lr_host;
-    const float step_size = (float)(lr / (1.0 - ipow(beta1d, step)));
-    const float bc2_sqrt = (float)sqrt(1.0 - ipow(beta2d, step));
-    const float beta1 = (float)beta1d, beta2 = (float)beta2d;
-    const float pi = p[i];
-    if (weight_decay != 0.f) g += weight_decay * pi;
-    const float mi = beta1 * m[i] + (1.f - beta1) * g;
-    const float vi = beta2 * v[i] + (1.f - beta2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    const float pn = pi - step_size * (mi / denom);
-    p[i] = pn;
+    const float pn = adam_apply(p, m, v, i, g, lr_host, lr_dev, beta1d, beta2d, step_host, step_dev, eps, weight_decay);
     if (img) img[img_map[i]] = pn;
 }
 
@@ -209,19 +152,7 @@ __global__ __launch_bounds__(256) void adam_segs_kernel(float *__restrict__ p, S
         if (sg.scale_dev) g *= *sg.scale_dev;
     }
     if (sl != 0 || il >= sg.n) return;
-    const int64_t step = step_dev ? *step_dev : step_host;
-    const double lr = lr_dev ? *lr_dev : lr_host;
-    const float step_size = (float)(lr / (1.0 - ipow(beta1d, step)));
-    const float bc2_sqrt = (float)sqrt(1.0 - ipow(beta2d, step));
-    const float beta1 = (float)beta1d, beta2 = (float)beta2d;
-    const float pi = p[i];
-    if (weight_decay != 0.f) g += weight_decay * pi;
-    const float mi = beta1 * m[i] + (1.f - beta1) * g;
-    const float vi = beta2 * v[i] + (1.f - beta2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - step_size * (mi / denom);
+    adam_apply(p, m, v, i, g, lr_host, lr_dev, beta1d, beta2d, step_host, step_dev, eps, weight_decay);
 }
 
 int fill_segs(SegArgs &a, const tsm_slab_seg *segs, int32_t n_seg, int64_t n_total) {

@@ -21,13 +21,14 @@
 //     inbox halves suffice; stamps are 64-bit and never reset.
 // Failure behaviour: a peer that never stamps (crashed rank) ends the spin after ~2 s with the handle's error word set;
 // the host reads it at its next synchronisation point and raises -- no hang.
-#include "common.h"
+#include "adam_dev.h"
 #include <string.h>
 
 namespace {
 
 constexpr int kP2PMaxWorld = 16;
 constexpr int kP2PSlices = 32;        // workgroups per all-reduce (= slices of the vector)
+constexpr int kP2PMaxSlices = 256;    // flag slots per (parity, sender): the fused step below slices finer (one per 64+ parameters)
 constexpr int kP2PThreads = 256;
 constexpr uint64_t kSpinLimit = 40000000ull;   // polls (~50 ns each): a couple of seconds
 
@@ -76,12 +77,12 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PArgs a) 
     __syncthreads();
     // (3) stamp: flags[par][rank][s] on every rank
     if (tid < a.world) {
-        uint64_t *fl = reinterpret_cast<uint64_t *>(a.peer[tid] + flag_off) + ((size_t)par * a.world + a.rank) * kP2PSlices + s;
+        uint64_t *fl = reinterpret_cast<uint64_t *>(a.peer[tid] + flag_off) + ((size_t)par * a.world + a.rank) * kP2PMaxSlices + s;
         __hip_atomic_store(fl, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // (4) wait for every sender's stamp of this slice (my own flags, written by the peers)
     if (tid < a.world) {
-        const uint64_t *fl = reinterpret_cast<const uint64_t *>(a.peer[a.rank] + flag_off) + ((size_t)par * a.world + tid) * kP2PSlices + s;
+        const uint64_t *fl = reinterpret_cast<const uint64_t *>(a.peer[a.rank] + flag_off) + ((size_t)par * a.world + tid) * kP2PMaxSlices + s;
         uint64_t spins = 0;
         while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(2);
@@ -111,6 +112,85 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PArgs a) 
     }
 }
 
+// ---- slab reduction + all-reduce + Adam in ONE launch ----------------------------------------------------------------------
+// The data-parallel gradient step was three launches (tsm_reduce_slabs -> all-reduce -> tsm_adam_step).  None of the three needs
+// more than its own SLICE of the parameter vector, so one kernel can do all of it per parameter -- if the exchange itself has no
+// workgroup-wide step.  The flag protocol above has two system-scope fences per workgroup (an L2 write-back + invalidate each):
+// with one workgroup per 64 parameters they serialise per XCD, and a first fused version built on it took ~30 us per call.  This
+// kernel therefore exchanges LL-style ("low latency", as RCCL's LL protocol): every element travels as ONE naturally aligned
+// 8-byte store {float bits, 32-bit stamp of the call} into a second inbox region [parity][sender][max_floats] of 8-byte words;
+// the receiving lane polls ITS OWN elements until the stamp matches.  An 8-byte store is a single transaction, so data and stamp
+// arrive together: no fence, no flag array, no barrier -- the thread that summed parameter i's slabs sends it, waits for the
+// peers' element i, sums in rank order and applies Adam to i.  Same instructions as the three-launch form (adam_dev.h):
+// bit-identical.  (No gradient-norm clip: the global norm is a grid-wide dependency; such steps keep the three launches.)
+struct P2PAdamArgs {
+    P2PArgs c;                    // data unused
+    float *p, *m, *v;
+    const float *slabs;
+    int32_t n_slab;
+    double lr_host, beta1, beta2;
+    const double *lr_dev;
+    int64_t step_host;
+    const int64_t *step_dev;
+    float eps, weight_decay, scale;
+    float *img;
+    const int32_t *img_map;
+    size_t ll_off;                // byte offset of the LL region inside an inbox allocation
+};
+
+__global__ __launch_bounds__(256) void p2p_adam_kernel(P2PAdamArgs g) {
+    __shared__ float sm[256];
+    const P2PArgs &a = g.c;
+    const int tid = threadIdx.x, lane = tid & 63, sl = tid >> 6;
+    const uint64_t seq = __hip_atomic_load(a.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int par = (int)(seq & 1);
+    const uint64_t tag = (seq & 0xFFFFFFFFull) << 32;
+    const int64_t i = (int64_t)blockIdx.x * kCols + lane;
+    const float gsum = slab_sum_block(g.slabs, g.n_slab, a.n, i, sm, a.n);
+    if (sl == 0 && i < a.n) {
+        const float val = gsum * g.scale;
+        const uint64_t word = tag | (uint64_t)__float_as_uint(val);
+        for (int r = 0; r < a.world; ++r)
+            if (r != a.rank) {
+                uint64_t *dst = reinterpret_cast<uint64_t *>(a.peer[r] + g.ll_off) + ((size_t)par * a.world + a.rank) * a.max_floats + i;
+                __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        const uint64_t *in = reinterpret_cast<const uint64_t *>(a.peer[a.rank] + g.ll_off) + (size_t)par * a.world * a.max_floats + i;
+        float acc = 0.f;
+        for (int r = 0; r < a.world; ++r) {
+            float vr = val;
+            if (r != a.rank) {
+                uint64_t wv, spins = 0;
+                while (((wv = __hip_atomic_load(in + (size_t)r * a.max_floats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) &
+                        0xFFFFFFFF00000000ull) != tag) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kSpinLimit) {  // a peer is gone: flag the error, go on with what there is
+                        atomicExch(a.err, 1);
+                        break;
+                    }
+                }
+                vr = __uint_as_float((uint32_t)wv);
+            }
+            acc = r == 0 ? vr : acc + vr;
+        }
+        const float pn = adam_apply(g.p, g.m, g.v, i, acc, g.lr_host, g.lr_dev, g.beta1, g.beta2, g.step_host, g.step_dev, g.eps,
+                                    g.weight_decay);
+        if (g.img) g.img[g.img_map[i]] = pn;
+    }
+    __syncthreads();
+    if (tid == 0) {   // the last workgroup to get here advances the stamp for the next call (every workgroup read it at its start)
+        const uint64_t done = __hip_atomic_fetch_add(a.seq_dev + 1, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (uint64_t)gridDim.x - 1) {
+            __hip_atomic_store(a.seq_dev + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.seq_dev, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__host__ __device__ inline size_t p2p_ll_offset_bytes(int world, int64_t max_floats) {
+    return (p2p_flag_offset_bytes(world, max_floats) + (size_t)2 * world * kP2PMaxSlices * sizeof(uint64_t) + 255) / 256 * 256;
+}
+
 }  // namespace
 
 TSM_EXPORT int64_t tsm_p2p_ipc_handle_bytes(void) { return (int64_t)sizeof(hipIpcMemHandle_t); }
@@ -121,7 +201,7 @@ TSM_EXPORT int tsm_p2p_create(int32_t rank, int32_t world, int64_t max_floats, v
                 "tsm_p2p_create: rank %d / world %d (<= %d), max_floats %lld", rank, world, kP2PMaxWorld, (long long)max_floats);
     P2PHandle *h = new P2PHandle();
     h->rank = rank; h->world = world; h->max_floats = max_floats;
-    h->bytes = p2p_flag_offset_bytes(world, max_floats) + (size_t)2 * world * kP2PSlices * sizeof(uint64_t);
+    h->bytes = p2p_ll_offset_bytes(world, max_floats) + (size_t)2 * world * max_floats * sizeof(uint64_t);   // + the LL region
     for (int i = 0; i < kP2PMaxWorld; ++i) { h->peer[i] = nullptr; h->opened[i] = false; }
     hipError_t e = hipExtMallocWithFlags(&h->local, h->bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) {
@@ -173,6 +253,33 @@ TSM_EXPORT int tsm_p2p_all_reduce(void *handle, float *data, int64_t n, void *st
     for (int r = 0; r < h->world; ++r) a.peer[r] = static_cast<char *>(h->peer[r]);
     a.err = h->err_dev;
     hipLaunchKernelGGL(p2p_all_reduce_kernel, dim3(kP2PSlices), dim3(kP2PThreads), 0, tsm_stream(stream), a);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+// tsm_reduce_slabs (x 1 / world) + all-reduce + tsm_adam_step (no gradient-norm clip) in ONE launch: every lane does all three
+// for its own parameter (p2p_adam_kernel, LL exchange).  Arguments as tsm_adam_step; n <= max_floats.
+TSM_EXPORT int tsm_p2p_adam_step(void *handle, float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
+                                 float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, const double *lr_dev,
+                                 double beta1, double beta2, double eps, double weight_decay, float *param_image,
+                                 const int32_t *image_map, void *stream) {
+    TSM_REQUIRE(handle && param && grad_slabs && exp_avg && exp_avg_sq, "tsm_p2p_adam_step: null pointer");
+    P2PHandle *h = static_cast<P2PHandle *>(handle);
+    TSM_REQUIRE(n >= 1 && n <= h->max_floats && n_slab >= 1 && (step >= 1 || step_dev),
+                "tsm_p2p_adam_step: bad sizes n=%lld (inbox %lld floats) n_slab=%d step=%lld", (long long)n, (long long)h->max_floats,
+                n_slab, (long long)step);
+    TSM_REQUIRE(!param_image || image_map, "tsm_p2p_adam_step: param_image needs image_map");
+    for (int r = 0; r < h->world; ++r) TSM_REQUIRE(h->peer[r], "tsm_p2p_adam_step: peer %d was never imported", r);
+    P2PAdamArgs g{};
+    g.c.data = nullptr; g.c.n = n; g.c.rank = h->rank; g.c.world = h->world; g.c.max_floats = h->max_floats; g.c.seq_dev = h->seq_dev;
+    for (int r = 0; r < h->world; ++r) g.c.peer[r] = static_cast<char *>(h->peer[r]);
+    g.c.err = h->err_dev;
+    g.p = param; g.m = exp_avg; g.v = exp_avg_sq; g.slabs = grad_slabs; g.n_slab = n_slab;
+    g.lr_host = lr; g.lr_dev = lr_dev; g.beta1 = beta1; g.beta2 = beta2; g.step_host = step; g.step_dev = step_dev;
+    g.eps = (float)eps; g.weight_decay = (float)weight_decay; g.scale = 1.0f / (float)h->world;
+    g.img = param_image; g.img_map = image_map;
+    g.ll_off = p2p_ll_offset_bytes(h->world, h->max_floats);
+    hipLaunchKernelGGL(p2p_adam_kernel, dim3((unsigned)ceil_div(n, kCols)), dim3(256), 0, tsm_stream(stream), g);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

@@ -68,6 +68,23 @@ class P2PAllReduce:
         _abi.call("tsm_p2p_all_reduce", self._h, flat.data_ptr(), flat.numel(), _abi.stream_ptr())
         return flat
 
+    def adam_step(self, param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                  step_dev=None, lr_dev=None, image=None, image_map=None):
+        """The replicas' whole gradient step in ONE launch (csrc/p2p.hip, p2p_adam_kernel): slab sum x 1 / world, one-shot
+        all-reduce and Adam, each workgroup on its own slice of the vector.  Bit-identical to ops.reduce_slabs ->
+        all_reduce_sum_ -> ops.adam_step (without a gradient-norm clip)."""
+        from . import _abi
+        from ._abi import ptr
+
+        n = param.numel()
+        if n > self.max_floats or param.dtype != torch.float32:
+            raise ValueError(f"P2PAllReduce.adam_step: needs an f32 vector of at most {self.max_floats} elements")
+        grad_slabs = grad_slabs.reshape(-1, n)
+        _abi.call("tsm_p2p_adam_step", self._h, ptr(param), ptr(grad_slabs), grad_slabs.shape[0], n, ptr(exp_avg), ptr(exp_avg_sq),
+                  int(step), ptr(step_dev), float(lr), ptr(lr_dev), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                  ptr(image), ptr(image_map), _abi.stream_ptr())
+        return param
+
     def check(self) -> None:
         """Raise if a peer failed to answer inside the kernels' bounded spin (synchronises the device)."""
         from . import _abi
@@ -113,6 +130,12 @@ class GradSync:
             return self.p2p.all_reduce_sum_(flat)
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
         return flat
+
+    def fused_step_ok(self, max_grad_norm, n: int) -> bool:
+        """Can a gradient step of n parameters take the one-launch form (P2PAllReduce.adam_step)?  Needs the peer-memory path,
+        no gradient-norm clip (the global norm is a grid-wide dependency), and TSM_P2P_FUSED_ADAM != 0."""
+        return (self.p2p is not None and not max_grad_norm and n <= self.p2p.max_floats
+                and os.environ.get("TSM_P2P_FUSED_ADAM", "1") != "0")
 
     def enable_p2p(self, device: torch.device, max_floats: int) -> None:
         """Route f32 gradient sums of up to `max_floats` elements through `P2PAllReduce` (setup failures raise)."""
