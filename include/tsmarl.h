@@ -625,8 +625,8 @@ int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim,
  * Latency-grade all-reduce of a small vector over peer-mapped memory  [SURVEY 8e: the 45 KB shared-policy gradient]
  * Replaces  torch.distributed.all_reduce(flat_grad) in front of Optimizer.step (algorithm_base.py:485-498) for env-sharded
  *           replicas on one node (the reference itself has no distributed path: utils/net/common.py:477-519).
- * One-shot write-to-peers over IPC-mapped fine-grained memory, one launch per call, rank-ordered sum (bit-identical on
- * every rank); csrc/p2p.hip has the protocol.  Setup: every rank tsm_p2p_create -> tsm_p2p_export -> the ranks exchange
+ * One-shot write-to-peers over IPC-mapped fine-grained memory (every element one 8-byte store {value, call stamp}: no fences),
+ * one launch per call, rank-ordered sum (bit-identical on every rank); csrc/p2p.hip has the protocol.  Setup: every rank tsm_p2p_create -> tsm_p2p_export -> the ranks exchange
  * the tsm_p2p_ipc_handle_bytes()-byte handles by any channel (the host binding uses the process group) -> tsm_p2p_import of
  * every peer.  tsm_p2p_failed: 1 after a peer failed to answer within the bounded spin (no hang).  Opt-in
  * (TSM_P2P_ALLREDUCE=1 in the host binding); RCCL stays the default.

@@ -6,20 +6,24 @@
 // /root/reference/tianshou/utils/net/common.py:477-519); this replaces the one collective the env-sharded update has:
 // `torch.distributed.all_reduce(flat_grad)` in front of Optimizer.step (algorithm_base.py:485-498) for replicas.
 //
-// One-shot, write-to-peers:
+// One-shot, write-to-peers, LL-style ("low latency", as RCCL's LL protocol):
 //   * every rank owns an INBOX in fine-grained device memory, exported with hipIpcGetMemHandle and mapped by every peer
-//     (on a node all 8 GPUs are one xGMI hop apart): inbox[parity][sender][max_floats] + flags[parity][sender][slice].
-//   * one launch per all-reduce, S workgroups.  Workgroup s of rank r (1) stores slice s of its vector into
-//     inbox[p][r][slice s] of EVERY rank (its own included), (2) drains its stores and release-fences at system scope,
-//     (3) stamps flags[p][r][s] = sequence number on every rank, (4) polls its OWN flags[p][*][s] until every sender's stamp
-//     has arrived (bounded spin), (5) sums slice s over the senders in RANK ORDER out of its own inbox and writes the result
-//     back into the vector.  No grid-wide barrier: a slice only ever waits for the same slice of the other ranks.
+//     (on a node all 8 GPUs are one xGMI hop apart): inbox[parity][sender][max_floats] of 8-BYTE words.
+//   * every element travels as ONE naturally aligned 8-byte store {float bits, low 32 bits of the call's sequence number}: a
+//     single transaction, so data and stamp arrive together -- no fence, no flag array, no barrier.  One launch per all-reduce;
+//     the lane that owns element i stores it into every peer's inbox, polls ITS OWN inbox for the peers' element i until the
+//     stamp matches (bounded spin), sums the senders in RANK ORDER and writes the result back.
 //   * every rank adds the same numbers in the same order: the result is bit-identical on all ranks (replicas stay
 //     bit-identical), and equal to (((x_0 + x_1) + x_2) + ...).
-//   * parity = call count & 1.  A sender can be at most one call ahead of a receiver that it has not heard from (its call
-//     k + 1 needs the receiver's stamps of call k + 1, which the receiver issues only after it finished call k), so two
-//     inbox halves suffice; stamps are 64-bit and never reset.
-// Failure behaviour: a peer that never stamps (crashed rank) ends the spin after ~2 s with the handle's error word set;
+//   * parity = call count & 1.  A rank starts call k + 1 only after its call k has finished, i.e. after it received every
+//     peer's call-k elements -- which the peers sent after finishing THEIR call k - 1: when call k + 1 overwrites the inbox half
+//     of call k - 1, every receiver is done with it.  Two halves suffice; a stale word carries an older stamp and never matches.
+//   * the sequence number lives in device memory (read by every workgroup at its start, advanced by the last one to finish), so
+//     launch arguments are constant and a captured launch replays inside a hipGraph.
+// An earlier version signalled per 1/32 slice with flags behind system-scope fences (an L2 write-back + invalidate each): ~10 us
+// per call with nobody to wait for, and ~30 us once a fused step used one workgroup per 64 parameters (the fences serialise per
+// XCD).  The LL form has neither.
+// Failure behaviour: a peer that never sends (crashed rank) ends the spin after ~2 s with the handle's error word set;
 // the host reads it at its next synchronisation point and raises -- no hang.
 #include "adam_dev.h"
 #include <string.h>
@@ -27,8 +31,6 @@
 namespace {
 
 constexpr int kP2PMaxWorld = 16;
-constexpr int kP2PSlices = 32;        // workgroups per all-reduce (= slices of the vector)
-constexpr int kP2PMaxSlices = 256;    // flag slots per (parity, sender): the fused step below slices finer (one per 64+ parameters)
 constexpr int kP2PThreads = 256;
 constexpr uint64_t kSpinLimit = 40000000ull;   // polls (~50 ns each): a couple of seconds
 
@@ -43,11 +45,6 @@ struct P2PHandle {
     int *err_dev;                      // device int: set by a timed-out spin
 };
 
-__host__ __device__ inline size_t p2p_data_floats(int world, int64_t max_floats) { return (size_t)2 * world * max_floats; }
-__host__ __device__ inline size_t p2p_flag_offset_bytes(int world, int64_t max_floats) {
-    return (p2p_data_floats(world, max_floats) * sizeof(float) + 255) / 256 * 256;
-}
-
 struct P2PArgs {
     float *data;
     int64_t n;
@@ -60,50 +57,40 @@ struct P2PArgs {
     int *err;
 };
 
-__global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PArgs a) {
-    const int s = blockIdx.x, tid = threadIdx.x;
-    const uint64_t seq = __hip_atomic_load(a.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int par = (int)(seq & 1);
-    const int64_t per = (a.n + kP2PSlices - 1) / kP2PSlices;
-    const int64_t lo = (int64_t)s * per, hi = lo + per < a.n ? lo + per : a.n;
-    const size_t flag_off = p2p_flag_offset_bytes(a.world, a.max_floats);
-    // (1) my slice into everybody's inbox
+// element i of sender `from`, call parity `par`, inside an inbox
+__device__ __forceinline__ uint64_t *ll_slot(char *inbox, int par, int world, int from, int64_t max_floats, int64_t i) {
+    return reinterpret_cast<uint64_t *>(inbox) + ((size_t)par * world + from) * max_floats + i;
+}
+
+// send `val` as element i of this call to every peer, receive the peers' element i, return the rank-ordered sum
+__device__ __forceinline__ float ll_exchange(const P2PArgs &a, int par, uint64_t tag, int64_t i, float val) {
+    const uint64_t word = tag | (uint64_t)__float_as_uint(val);
+    for (int r = 0; r < a.world; ++r)
+        if (r != a.rank) __hip_atomic_store(ll_slot(a.peer[r], par, a.world, a.rank, a.max_floats, i), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    float acc = 0.f;
     for (int r = 0; r < a.world; ++r) {
-        float *dst = reinterpret_cast<float *>(a.peer[r]) + ((size_t)par * a.world + a.rank) * a.max_floats;
-        for (int64_t i = lo + tid; i < hi; i += kP2PThreads) dst[i] = a.data[i];
-    }
-    // (2) all stores of this workgroup are out and visible system-wide before the stamps
-    __threadfence_system();
-    __syncthreads();
-    // (3) stamp: flags[par][rank][s] on every rank
-    if (tid < a.world) {
-        uint64_t *fl = reinterpret_cast<uint64_t *>(a.peer[tid] + flag_off) + ((size_t)par * a.world + a.rank) * kP2PMaxSlices + s;
-        __hip_atomic_store(fl, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // (4) wait for every sender's stamp of this slice (my own flags, written by the peers)
-    if (tid < a.world) {
-        const uint64_t *fl = reinterpret_cast<const uint64_t *>(a.peer[a.rank] + flag_off) + ((size_t)par * a.world + tid) * kP2PMaxSlices + s;
-        uint64_t spins = 0;
-        while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > kSpinLimit) {  // a peer is gone: flag the error, leave (the host raises at its next sync)
-                atomicExch(a.err, 1);
-                break;
+        float vr = val;
+        if (r != a.rank) {
+            const uint64_t *src = ll_slot(a.peer[a.rank], par, a.world, r, a.max_floats, i);
+            uint64_t wv, spins = 0;
+            while (((wv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) & 0xFFFFFFFF00000000ull) != tag) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) {  // a peer is gone: flag the error, go on with what there is (the host raises at its next sync)
+                    atomicExch(a.err, 1);
+                    break;
+                }
             }
+            vr = __uint_as_float((uint32_t)wv);
         }
+        acc = r == 0 ? vr : acc + vr;
     }
+    return acc;
+}
+
+// the last workgroup to get here advances the stamp for the next call (every workgroup read it at its start)
+__device__ __forceinline__ void ll_finish(const P2PArgs &a, uint64_t seq) {
     __syncthreads();
-    __threadfence_system();
-    // (5) sum over the senders in rank order
-    const float *in = reinterpret_cast<const float *>(a.peer[a.rank]) + (size_t)par * a.world * a.max_floats;
-    for (int64_t i = lo + tid; i < hi; i += kP2PThreads) {
-        float acc = in[i];
-        for (int r = 1; r < a.world; ++r) acc += in[(size_t)r * a.max_floats + i];
-        a.data[i] = acc;
-    }
-    // the last workgroup to get here advances the stamp for the next call (every workgroup read it at its start)
-    __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         const uint64_t done = __hip_atomic_fetch_add(a.seq_dev + 1, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (uint64_t)gridDim.x - 1) {
             __hip_atomic_store(a.seq_dev + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -112,17 +99,21 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PArgs a) 
     }
 }
 
+__global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PArgs a) {
+    const uint64_t seq = __hip_atomic_load(a.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int par = (int)(seq & 1);
+    const uint64_t tag = (seq & 0xFFFFFFFFull) << 32;
+    const int64_t i = (int64_t)blockIdx.x * kP2PThreads + threadIdx.x;
+    if (i < a.n) a.data[i] = ll_exchange(a, par, tag, i, a.data[i]);
+    ll_finish(a, seq);
+}
+
 // ---- slab reduction + all-reduce + Adam in ONE launch ----------------------------------------------------------------------
 // The data-parallel gradient step was three launches (tsm_reduce_slabs -> all-reduce -> tsm_adam_step).  None of the three needs
-// more than its own SLICE of the parameter vector, so one kernel can do all of it per parameter -- if the exchange itself has no
-// workgroup-wide step.  The flag protocol above has two system-scope fences per workgroup (an L2 write-back + invalidate each):
-// with one workgroup per 64 parameters they serialise per XCD, and a first fused version built on it took ~30 us per call.  This
-// kernel therefore exchanges LL-style ("low latency", as RCCL's LL protocol): every element travels as ONE naturally aligned
-// 8-byte store {float bits, 32-bit stamp of the call} into a second inbox region [parity][sender][max_floats] of 8-byte words;
-// the receiving lane polls ITS OWN elements until the stamp matches.  An 8-byte store is a single transaction, so data and stamp
-// arrive together: no fence, no flag array, no barrier -- the thread that summed parameter i's slabs sends it, waits for the
-// peers' element i, sums in rank order and applies Adam to i.  Same instructions as the three-launch form (adam_dev.h):
-// bit-identical.  (No gradient-norm clip: the global norm is a grid-wide dependency; such steps keep the three launches.)
+// more than its own element of the parameter vector, and the LL exchange has no workgroup-wide step: the lane that summed
+// parameter i's slabs (x 1 / world) sends it, waits for the peers' element i, sums in rank order and applies Adam to i.  Same
+// instructions as the three-launch form (adam_dev.h): bit-identical.  (No gradient-norm clip: the global norm is a grid-wide
+// dependency; such steps keep the three launches.)
 struct P2PAdamArgs {
     P2PArgs c;                    // data unused
     float *p, *m, *v;
@@ -135,60 +126,24 @@ struct P2PAdamArgs {
     float eps, weight_decay, scale;
     float *img;
     const int32_t *img_map;
-    size_t ll_off;                // byte offset of the LL region inside an inbox allocation
 };
 
 __global__ __launch_bounds__(256) void p2p_adam_kernel(P2PAdamArgs g) {
     __shared__ float sm[256];
     const P2PArgs &a = g.c;
-    const int tid = threadIdx.x, lane = tid & 63, sl = tid >> 6;
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const uint64_t seq = __hip_atomic_load(a.seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int par = (int)(seq & 1);
     const uint64_t tag = (seq & 0xFFFFFFFFull) << 32;
     const int64_t i = (int64_t)blockIdx.x * kCols + lane;
     const float gsum = slab_sum_block(g.slabs, g.n_slab, a.n, i, sm, a.n);
     if (sl == 0 && i < a.n) {
-        const float val = gsum * g.scale;
-        const uint64_t word = tag | (uint64_t)__float_as_uint(val);
-        for (int r = 0; r < a.world; ++r)
-            if (r != a.rank) {
-                uint64_t *dst = reinterpret_cast<uint64_t *>(a.peer[r] + g.ll_off) + ((size_t)par * a.world + a.rank) * a.max_floats + i;
-                __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        const uint64_t *in = reinterpret_cast<const uint64_t *>(a.peer[a.rank] + g.ll_off) + (size_t)par * a.world * a.max_floats + i;
-        float acc = 0.f;
-        for (int r = 0; r < a.world; ++r) {
-            float vr = val;
-            if (r != a.rank) {
-                uint64_t wv, spins = 0;
-                while (((wv = __hip_atomic_load(in + (size_t)r * a.max_floats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) &
-                        0xFFFFFFFF00000000ull) != tag) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > kSpinLimit) {  // a peer is gone: flag the error, go on with what there is
-                        atomicExch(a.err, 1);
-                        break;
-                    }
-                }
-                vr = __uint_as_float((uint32_t)wv);
-            }
-            acc = r == 0 ? vr : acc + vr;
-        }
+        const float acc = ll_exchange(a, par, tag, i, gsum * g.scale);
         const float pn = adam_apply(g.p, g.m, g.v, i, acc, g.lr_host, g.lr_dev, g.beta1, g.beta2, g.step_host, g.step_dev, g.eps,
                                     g.weight_decay);
         if (g.img) g.img[g.img_map[i]] = pn;
     }
-    __syncthreads();
-    if (tid == 0) {   // the last workgroup to get here advances the stamp for the next call (every workgroup read it at its start)
-        const uint64_t done = __hip_atomic_fetch_add(a.seq_dev + 1, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == (uint64_t)gridDim.x - 1) {
-            __hip_atomic_store(a.seq_dev + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.seq_dev, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-__host__ __device__ inline size_t p2p_ll_offset_bytes(int world, int64_t max_floats) {
-    return (p2p_flag_offset_bytes(world, max_floats) + (size_t)2 * world * kP2PMaxSlices * sizeof(uint64_t) + 255) / 256 * 256;
+    ll_finish(a, seq);
 }
 
 }  // namespace
@@ -201,7 +156,7 @@ TSM_EXPORT int tsm_p2p_create(int32_t rank, int32_t world, int64_t max_floats, v
                 "tsm_p2p_create: rank %d / world %d (<= %d), max_floats %lld", rank, world, kP2PMaxWorld, (long long)max_floats);
     P2PHandle *h = new P2PHandle();
     h->rank = rank; h->world = world; h->max_floats = max_floats;
-    h->bytes = p2p_ll_offset_bytes(world, max_floats) + (size_t)2 * world * max_floats * sizeof(uint64_t);   // + the LL region
+    h->bytes = (size_t)2 * world * max_floats * sizeof(uint64_t);   // inbox[parity][sender][max_floats] of 8-byte words
     for (int i = 0; i < kP2PMaxWorld; ++i) { h->peer[i] = nullptr; h->opened[i] = false; }
     hipError_t e = hipExtMallocWithFlags(&h->local, h->bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) {
@@ -252,7 +207,7 @@ TSM_EXPORT int tsm_p2p_all_reduce(void *handle, float *data, int64_t n, void *st
     a.data = data; a.n = n; a.rank = h->rank; a.world = h->world; a.max_floats = h->max_floats; a.seq_dev = h->seq_dev;
     for (int r = 0; r < h->world; ++r) a.peer[r] = static_cast<char *>(h->peer[r]);
     a.err = h->err_dev;
-    hipLaunchKernelGGL(p2p_all_reduce_kernel, dim3(kP2PSlices), dim3(kP2PThreads), 0, tsm_stream(stream), a);
+    hipLaunchKernelGGL(p2p_all_reduce_kernel, dim3((unsigned)ceil_div(n, kP2PThreads)), dim3(kP2PThreads), 0, tsm_stream(stream), a);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }
@@ -278,7 +233,6 @@ TSM_EXPORT int tsm_p2p_adam_step(void *handle, float *param, const float *grad_s
     g.lr_host = lr; g.lr_dev = lr_dev; g.beta1 = beta1; g.beta2 = beta2; g.step_host = step; g.step_dev = step_dev;
     g.eps = (float)eps; g.weight_decay = (float)weight_decay; g.scale = 1.0f / (float)h->world;
     g.img = param_image; g.img_map = image_map;
-    g.ll_off = p2p_ll_offset_bytes(h->world, h->max_floats);
     hipLaunchKernelGGL(p2p_adam_kernel, dim3((unsigned)ceil_div(n, kCols)), dim3(256), 0, tsm_stream(stream), g);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
