@@ -27,10 +27,12 @@ def shard_range(n_total: int, world_size: int, rank: int) -> tuple[int, int]:
 
 
 class P2PAllReduce:
-    """One-shot all-reduce of a small f32 vector over peer-mapped memory (csrc/p2p.hip): every rank stores its vector into
-    every peer's IPC-mapped inbox, stamps a flag, and sums the senders in rank order -- ONE launch per call, no ring, the
-    same bits on every rank.  Setup exchanges the IPC handles through the process group (any backend); any failure raises
-    (a data-parallel job must not limp on with one rank on another path).  Opt-in: TSM_P2P_ALLREDUCE=1."""
+    """One-shot all-reduce of a small f32 vector over peer-mapped memory (csrc/p2p.hip): every rank stores each element into
+    every peer's IPC-mapped inbox as ONE 8-byte word {value, stamp of the call} (no fences, flags or barriers), polls its own
+    inbox for the peers' elements and sums the senders in rank order -- ONE launch per call, no ring, the same bits on every
+    rank; `adam_step` is the replica's whole gradient step (slab sum, exchange, Adam) in one launch.  Setup exchanges the IPC
+    handles through the process group (any backend); any failure raises (a data-parallel job must not limp on with one rank
+    on another path).  Opt-in: TSM_P2P_ALLREDUCE=1."""
 
     def __init__(self, dist, group, device: torch.device, max_floats: int) -> None:
         import ctypes as C
