@@ -32,6 +32,35 @@ HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 MFMA_F32_PEAK = 157.3e12  # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix) 157.3 TFLOPS" (f32-input MFMA)
 
 
+def mlp_flops(dims) -> tuple[int, int]:
+    """USEFUL flops per input row of an MLP `dims[0] -> ... -> dims[-1]` (multiply-add = 2; biases, activations, padding of
+    narrow layers to MFMA tiles not counted): (forward, backward).  Backward = weight gradient of every layer + input
+    gradient of every layer but the first (nothing consumes dX of layer 1, and no kernel here forms it):
+    forward 2 sum(a b); backward 4 sum over layers >= 2 of (a b) + 2 dims[0] dims[1]."""
+    pairs = list(zip(dims[:-1], dims[1:]))
+    return 2 * sum(a * b for a, b in pairs), 4 * sum(a * b for a, b in pairs[1:]) + 2 * pairs[0][0] * pairs[0][1]
+
+
+def in_situ_us(kernel: str, workload: str = "bench", grid: int | None = None, near_us: float | None = None):
+    """Average duration (us) of `kernel` INSIDE the job's own launch sequence, from the committed rocprofv3 --kernel-trace
+    --stats summary of that job (profiles/*_{workload}_kernel_stats.json, tools/summarize_profile.py); None if absent.
+    grid (threads) / near_us pick the row where the summary lists the kernel at several grids or problem sizes."""
+    import glob
+    import math
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_kernel_stats.json" % workload)))
+    if not files:
+        return None
+    rows = [r for r in json.load(open(files[-1])).get("by_grid", []) if kernel in r["kernel"] and (grid is None or r["grid"] == grid)]
+    if not rows:
+        return None
+    if near_us is not None:
+        rows.sort(key=lambda r: abs(math.log(r["avg_us"] / near_us)))
+    else:
+        rows.sort(key=lambda r: -r["total_ms"])
+    return round(rows[0]["avg_us"], 3)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,19 +165,24 @@ def loss_grid_threads(M: int) -> int:
     return n * 256
 
 
-def pmc_traffic(kernel: str, grid_threads: int):
+def pmc_traffic(kernel: str, grid_threads: int, expect: float | None = None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
     (profiles/*pmc_traffic.json, written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes with
-    the guide's gfx950 correction); None when no profile covers that kernel and grid."""
+    the guide's gfx950 correction); None when no profile covers that kernel and grid.  Where the summary lists one (kernel,
+    grid) at several problem sizes, `expect` (algorithmic bytes) picks the nearest."""
     import glob
+    import math
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
         return None
-    for r in json.load(open(files[-1]))["kernels"]:
-        if kernel in r["kernel"] and r["grid"] == grid_threads and r.get("fetch_KiB") is not None:
-            return r["traffic_B"]
-    return None
+    hits = [r["traffic_B"] for r in json.load(open(files[-1]))["kernels"]
+            if kernel in r["kernel"] and r["grid"] == grid_threads and r.get("fetch_KiB") is not None]
+    if not hits:
+        return None
+    if expect is None or len(hits) == 1:
+        return hits[0]
+    return min(hits, key=lambda t: abs(math.log(max(t, 1.0) / expect)))
 
 
 def gae_grid_threads(T: int, L: int, ch: int = 4) -> int:
@@ -218,21 +252,43 @@ def kernel_rooflines(a, algo, buf):
     fl, fl2 = (torch.zeros(T, L, dtype=torch.uint8, device=dev) for _ in range(2))
     out = (torch.empty_like(v), torch.empty_like(v))
     gae_s = per_launch(lambda: ops.gae_lanes(v, v2, v3, fl, fl2, out=out))
-    # (3) the HBM-bound kernels at the north star's roofline size (n_env=4096, n_agent=8, T=25: 819 200 samples)
+    # (3) the HBM-bound kernels at the north star's roofline size (n_env=4096, n_agent=8: 32 768 lanes)
     grid = []
     Lg = 4096 * 8
-    # SURVEY 8d roofline grid: the env's own T = 25; the synthetic horizons 2048 and 256 only with --pooled-grid (their
-    # launches have the same kernel name and grid as the T = 25 one and would blur the committed per-kernel summaries)
-    for Tg in ((2048, 256, 25) if getattr(a, "pooled_grid", False) else (25,)):
-        vg, vg2, vg3 = (torch.randn(Tg, Lg, device=dev) for _ in range(3))
-        flg, flg2 = (torch.zeros(Tg, Lg, dtype=torch.uint8, device=dev) for _ in range(2))
-        outg = (torch.empty_like(vg), torch.empty_like(vg))
-        s_g = per_launch(lambda: ops.gae_lanes(vg, vg2, vg3, flg, flg2, out=outg), n=20 if Tg <= 256 else 4, reps=3)
-        grid.append({"kernel": "gae_lanes_kernel", "n_env": 4096, "n_agent": 8, "T": Tg, "bound": "hbm",
-                     "bytes_per_launch": 22 * Tg * Lg, "us_per_launch": s_g * 1e6, "achieved": 22 * Tg * Lg / s_g / 1e9,
-                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 22 * Tg * Lg / s_g / HBM_PEAK,
-                     "traffic": pmc_traffic("gae_lanes_kernel", gae_grid_threads(Tg, Lg))})
-        del vg, vg2, vg3, flg, flg2, outg
+
+    def gae_entry(Tg, n_sets, label, n, reps):
+        """`n` launches per graph over `n_sets` distinct operand sets in rotation: with n_sets x 22 B x Tg x Lg above the
+        256 MB Infinity Cache (+ 32 MB of L2) every launch finds its operands in HBM."""
+        sets = []
+        for _ in range(n_sets):
+            sets.append(([torch.randn(Tg, Lg, device=dev) for _ in range(3)],
+                         [torch.zeros(Tg, Lg, dtype=torch.uint8, device=dev) for _ in range(2)],
+                         (torch.empty(Tg, Lg, device=dev), torch.empty(Tg, Lg, device=dev))))
+        k = [0]
+
+        def launch():
+            (v_, vn_, r_), (f1, f2), o_ = sets[k[0] % n_sets]
+            k[0] += 1
+            ops.gae_lanes(v_, vn_, r_, f1, f2, out=o_)
+
+        s_g = per_launch(launch, n=n, reps=reps)
+        b = 22 * Tg * Lg
+        grid.append({"kernel": "gae_lanes_kernel", "n_env": 4096, "n_agent": 8, "T": Tg, "bound": "hbm", "operands": label,
+                     "timing": "back_to_back (graph of %d launches, HIP events)" % n,
+                     "in_situ_us_rocprof": in_situ_us("gae_lanes_kernel", "c3ppo", gae_grid_threads(Tg, Lg)) if Tg == 25 else None,
+                     "bytes_per_launch": b, "us_per_launch": s_g * 1e6, "achieved": b / s_g / 1e9,
+                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": b / s_g / HBM_PEAK,
+                     "traffic": pmc_traffic("gae_lanes_kernel", gae_grid_threads(Tg, Lg), expect=b)})
+        del sets
+
+    # SURVEY 8d roofline grid.  T = 25 (the env's own horizon, 18 MB): once on ONE operand set replayed back to back -- a
+    # cache-resident figure, labelled so -- and once cold, rotating 16 sets (288 MB).  T = 2048 (1.48 GB per launch): HBM-bound
+    # by size, the figure the 40 % target of the north star is about.  (T = 256 only with --pooled-grid.)
+    gae_entry(25, 1, "cache-resident: one 18 MB operand set, back-to-back launches (L2 32 MB / Infinity Cache 256 MB)", 20, 5)
+    gae_entry(25, 16, "cold: 16 operand sets in rotation (288 MB > Infinity Cache)", 32, 5)
+    gae_entry(2048, 1, "HBM-resident by size: 1.48 GB per launch", 4, 3)
+    if getattr(a, "pooled_grid", False):
+        gae_entry(256, 2, "2 operand sets of 185 MB in rotation", 8, 3)
     Tg = 25
     Mg, A = Tg * Lg, net.n_act
     lg_ = torch.randn(Mg, A, device=dev)
@@ -243,6 +299,7 @@ def kernel_rooflines(a, algo, buf):
                                                   adv_stats=stg[0], finalize=False))
     loss_bytes = (8 * A + 24) * Mg  # logits + dlogits, value/act/logp_old/adv/ret read, dvalue written (64 B at A=5)
     grid.append({"kernel": "loss_kernel<5> (PPO clip loss fwd+bwd on given logits/value)", "rows": Mg, "bound": "hbm",
+                 "timing": "back_to_back (graph of 20 launches on one 52 MB operand set, HIP events)",
                  "bytes_per_launch": loss_bytes, "us_per_launch": s_l * 1e6, "achieved": loss_bytes / s_l / 1e9,
                  "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": loss_bytes / s_l / HBM_PEAK,
                  "traffic": pmc_traffic("loss_kernel", loss_grid_threads(Mg))})
@@ -253,7 +310,8 @@ def kernel_rooflines(a, algo, buf):
     # which has to agree with the live figure of the headline launch.
     if getattr(a, "pooled_grid", False):
         Hn = net.hidden
-        fwd_flop_row = 2 * (2 * D * Hn + 2 * Hn * Hn + Hn * net.n_act + Hn)
+        (fa_, ba_), (fc_, bc_) = mlp_flops((D, Hn, Hn, net.n_act)), mlp_flops((D, Hn, Hn, 1))
+        step_flop_row = fa_ + ba_ + fc_ + bc_  # useful flops of one sample's gradient step, actor + critic
         nG, MG = Tg * Lg, 65536
         obsG = torch.randn(nG, D, device=dev)
         actG = torch.randint(0, net.n_act, (nG,), dtype=torch.int32, device=dev)
@@ -267,13 +325,14 @@ def kernel_rooflines(a, algo, buf):
                                                       adv_stats=stG[0], perm=permG, M=MG, n_blocks=nbG, slabs=slabsG,
                                                       partial=partG, want_scalars=False, image=img_), n=10)
         grid.append({"kernel": "ppo_update_split_kernel<64> (fused fwd+loss+bwd) at a pooled minibatch", "rows": MG, "bound": "mfma",
-                     "flop_per_launch": 3 * fwd_flop_row * MG, "us_per_launch": s_u * 1e6,
-                     "achieved": 3 * fwd_flop_row * MG / s_u / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": 3 * fwd_flop_row * MG / s_u / MFMA_F32_PEAK, "n_blocks": nbG, "traffic": None})
+                     "timing": "back_to_back (graph of 10 launches, HIP events)",
+                     "flop_per_launch": step_flop_row * MG, "us_per_launch": s_u * 1e6,
+                     "achieved": step_flop_row * MG / s_u / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": step_flop_row * MG / s_u / MFMA_F32_PEAK, "n_blocks": nbG, "traffic": None})
         del obsG, actG, lpG, advG, retG, permG, slabsG
     H = net.hidden
-    fwd_flop = 2 * (2 * D * H + 2 * H * H + H * net.n_act + H)          # actor + critic forward per sample
-    upd_flop = 3 * fwd_flop * M                                          # forward + 2x backward (~65 kFLOP)
+    (fa, ba), (fc, bc) = mlp_flops((D, H, H, net.n_act)), mlp_flops((D, H, H, 1))
+    upd_flop = (fa + ba + fc + bc) * M        # useful flops: forward + backward without layer-1 dX (60 672 per sample at D = 18)
     upd_bytes = (4 * D + 16 + 8) * M                                     # obs + act/logp/adv/ret + perm (88 B)
     gae_bytes = 22 * T * L                                               # 22 B / sample
     return {
@@ -284,15 +343,22 @@ def kernel_rooflines(a, algo, buf):
                      "traffic": pmc_traffic("ppo_update_split_kernel", nb * 2 * 256),
                      "traffic_note": "HBM bytes per launch (PMC): dominated by the per-workgroup gradient slabs "
                                      "(n_blocks x n_param x 4 B written, read back by adam_kernel)",
-                     "flop_per_launch": upd_flop,
+                     "flop_per_launch": upd_flop, "flop_per_sample": fa + ba + fc + bc,
+                     "flop_note": "useful flops (forward + weight gradients + input gradients of layers 2, 3; no layer-1 dX, "
+                                  "no padding of the 5 / 1-wide heads to MFMA tiles)",
                      "algorithmic_bytes_per_launch": upd_bytes, "hbm_GBps": upd_bytes / upd_s / 1e9,
+                     "hbm_frac": upd_bytes / upd_s / HBM_PEAK,
                      "us_per_launch": upd_s * 1e6, "rows_per_launch": M,
+                     "timing": "back_to_back: gap-inclusive (graph of 20 x (update, adam) minus 20 x adam, HIP events)",
+                     "in_situ_us_rocprof": in_situ_us("ppo_update_split_kernel"),
                      "how": "graph of 20 x (ppo_update_kernel, adam_kernel) timed with HIP events, minus the same graph "
                             "of adam_kernel alone", "grad_step_us": step_s * 1e6, "adam_us": adam_s * 1e6},
         "roofline_gae": {"bound": "hbm", "kernel": "gae_lanes_kernel", "achieved": gae_bytes / gae_s / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": gae_bytes / gae_s / HBM_PEAK,
-                         "traffic": pmc_traffic("gae_lanes_kernel", gae_grid_threads(T, L)),
-                         "bytes_per_launch": gae_bytes, "us_per_launch": gae_s * 1e6},
+                         "traffic": pmc_traffic("gae_lanes_kernel", gae_grid_threads(T, L), expect=gae_bytes),
+                         "bytes_per_launch": gae_bytes, "us_per_launch": gae_s * 1e6,
+                         "timing": "back_to_back (graph of 20 launches on one operand set: launch latency at this size)",
+                         "in_situ_us_rocprof": in_situ_us("gae_lanes_kernel", "bench", gae_grid_threads(T, L))},
         "roofline_grid": grid,
     }
 
@@ -337,24 +403,31 @@ def c3_rooflines(device):
             upds.append(e1.elapsed_time(e2))
     t_col, t_upd = sorted(cols)[reps // 2], sorted(upds)[reps // 2]
     rows, samples = n_env * T, n_env * T * N
-    f_actor = 2 * (D * H + H * H + H * A)             # forward flops per sample
-    f_critic = 2 * (N * D * H + H * H + H)            # forward flops per joint row
-    # executed: V(obs) for every joint row and V(obs_next) for the last slot's rows (the other slots take it from the next
-    # slot's V(obs): GenericPPO._next_values_chained; logp_old comes from the rollout) + forward and backward (2x) of
-    # every sample through the actor and of every joint row through the critic, once per epoch
-    flop = (rows + n_env) * f_critic + 3 * (samples * f_actor + rows * f_critic)
+    (f_actor, b_actor), (f_critic, b_critic) = mlp_flops((D, H, H, A)), mlp_flops((N * D, H, H, 1))
+    # USEFUL flops as executed: V(obs) for every joint row and V(obs_next) for the last slot's rows (the other slots take it
+    # from the next slot's V(obs): GenericPPO._next_values_chained; logp_old comes from the rollout) + one gradient step of
+    # every sample through the actor and of every joint row through the critic (forward + weight gradients + input gradients
+    # of layers 2 and 3 -- no kernel forms dX of layer 1; actor 126 720 per sample, critic 295 680 per joint row)
+    flop = (rows + n_env) * f_critic + samples * (f_actor + b_actor) + rows * (f_critic + b_critic)
+    # issued on the matrix pipe beyond that: the A = 5 logits / their two backward products run as 16-wide MFMA tiles
+    issued_extra = samples * 6 * H * (16 - A)
     steps = len(split_bounds(rows, mb // N, True))
     out = [{"kernel": "C3 whole GAE + PPO update (GenericPPO.update: V(obs_next), GAE, advantage statistics, %d gradient "
                       "steps of actor-rows kernel + critic-rows kernel + 2 Adam; one hipGraph replay)" % steps,
             "n_env": n_env, "n_agent": N, "T": T, "minibatch": mb, "bound": "mfma", "ms_per_update": t_upd,
-            "flop_per_update": flop, "achieved": flop / (t_upd * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
-            "unit": "TFLOP/s", "frac": flop / (t_upd * 1e-3) / MFMA_F32_PEAK, "collect_ms": t_col,
+            "flop_per_update": flop, "issued_mfma_flop": flop + issued_extra,
+            "flop_note": "useful flops (mlp_flops: forward + backward without layer-1 dX, no padding); issued_mfma_flop adds "
+                         "the actor head's 5 -> 16 padding",
+            "achieved": flop / (t_upd * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+            "unit": "TFLOP/s", "frac": flop / (t_upd * 1e-3) / MFMA_F32_PEAK,
+            "hbm_frac": (22 + 4 * D + 24) * samples / (t_upd * 1e-3) / HBM_PEAK, "collect_ms": t_col,
             "ms_per_update_all": [round(x, 3) for x in upds], "ms_per_update_min": min(upds), "ms_per_update_max": max(upds),
             "timing": "median of %d updates after %d warm-up iterations (0: eager, 1: capture + first replay); min / max / all "
                       "listed -- tools/c3_step_times.py has the per-step timeline of 80 steps" % (reps, warm),
             "env_steps_per_s": samples / ((t_col + t_upd) * 1e-3), "gradient_steps": ts.gradient_steps,
-            "note": "flops as executed (the critic runs once per joint row); the per-lane critic of round 1 executed "
-                    "%.0f GFLOP for the same update" % ((2 * rows * f_critic + samples * f_actor + 3 * samples * (f_actor + f_critic)) / 1e9)}]
+            "note": "the critic runs once per joint row (the reference evaluates it once per sample: 8x the flops on identical "
+                    "inputs); hbm_frac: SURVEY 8d's algorithmic bytes (GAE 22 B + fused step 4 D + 24 B per sample) against the "
+                    "HBM peak -- the update is compute-bound, the MFMA roof is the one that binds"}]
     # (ii) the actor step alone, graph-batched launches on the job's own rows
     n = samples
     obs, act = buf.obs_store[:T].reshape(n, D), buf.act_store[:T].reshape(n)
@@ -382,12 +455,14 @@ def c3_rooflines(device):
         e1.record()
         torch.cuda.synchronize()
         tot += e0.elapsed_time(e1) * 1e-3 / 10 / 5
-    a_flop, a_bytes = 3 * f_actor * mb, (4 * D + 4 + 4 + 4 + 8) * mb
+    a_flop, a_bytes = (f_actor + b_actor) * mb, (4 * D + 4 + 4 + 4 + 8) * mb
     t64 = -(-mb // 64) >= ops.device_info()["n_cu"]  # (tsm_ppo_actor_rows_grid's rule: 64-sample tiles once every CU gets one)
     a_kernel = "actor_rows64_kernel" if t64 else "ppo_actor_rows_kernel"
     out.append({"kernel": a_kernel + "<3> (actor 48-128-128-5: forward + policy loss + backward in one launch; "
                           + ("64-sample tiles, layer-2 weights in registers)" if t64 else "32-sample tiles)"),
-                "rows": mb, "bound": "mfma", "flop_per_launch": a_flop, "us_per_launch": tot * 1e6,
+                "rows": mb, "bound": "mfma", "flop_per_launch": a_flop, "issued_mfma_flop": a_flop + 6 * H * (16 - A) * mb,
+                "timing": "back_to_back (graph of 10 launches, HIP events)",
+                "in_situ_us_rocprof": in_situ_us(a_kernel, "c3ppo"), "us_per_launch": tot * 1e6,
                 "achieved": a_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": a_flop / tot / MFMA_F32_PEAK, "n_blocks": nb, "algorithmic_bytes_per_launch": a_bytes,
                 "slab_bytes_per_launch": nb * net.n_actor * 4, "traffic": pmc_traffic(a_kernel, nb * 512)})
@@ -420,10 +495,14 @@ def c3_rooflines(device):
 
     tot = graph_time(fc)
     wc = next(iter(cws.values()))
-    c_flop, c_bytes = 3 * f_critic * mr, (4 * N * D + 8 + 4 * N) * mr
+    c_flop, c_bytes = (f_critic + b_critic) * mr, (4 * N * D + 8 + 4 * N) * mr
     out.append({"kernel": "critic_rows_train_kernel<24> + critic_dw1_kernel (centralized critic 384-128-128-1 on joint rows: "
                           "forward + value loss of the row's 8 agents + backward, dW1 as a split-K pass; two launches)",
-                "rows": mr, "samples": mb, "bound": "mfma", "flop_per_launch": c_flop, "us_per_launch": tot * 1e6,
+                "rows": mr, "samples": mb, "bound": "mfma", "flop_per_launch": c_flop,
+                "timing": "back_to_back (graph of 10 launch pairs, HIP events)",
+                "in_situ_us_rocprof": (lambda a_, b_: None if a_ is None or b_ is None else round(a_ + b_, 3))(
+                    in_situ_us("critic_rows_train_kernel", "c3ppo"), in_situ_us("critic_dw1_kernel", "c3ppo")),
+                "us_per_launch": tot * 1e6,
                 "achieved": c_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": c_flop / tot / MFMA_F32_PEAK, "n_blocks": wc["nb"], "dw1_chunks": wc["nc"],
                 "algorithmic_bytes_per_launch": c_bytes,
@@ -437,6 +516,8 @@ def c3_rooflines(device):
     v_flop = f_critic * rows
     out.append({"kernel": "critic_rows_forward_kernel<24> (V(row) for all %d joint rows: layer-1 weights in registers, layer 3 "
                           "folded into layer 2)" % rows, "rows": rows, "bound": "mfma", "flop_per_launch": v_flop,
+                "timing": "back_to_back (graph of 5 launches, HIP events)",
+                "in_situ_us_rocprof": in_situ_us("critic_rows_forward_kernel", "c3ppo", near_us=tot * 1e6),
                 "us_per_launch": tot * 1e6, "achieved": v_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": v_flop / tot / MFMA_F32_PEAK, "algorithmic_bytes_per_launch": (4 * N * D + 4) * rows,
                 "traffic": pmc_traffic("critic_rows_forward_kernel", min(256, -(-rows // 32)) * 512)})
@@ -515,10 +596,11 @@ def run_c3(a, device):
     col.reset_buffer(keep_statistics=True)
     # roofline of one learn() call AS EXECUTED (one hipGraph replay: V(last slot), TD step of the critic with its split-K dW1
     # pass, actor step, finalize, two Adam launches), priced against the f32-MFMA peak: flops per row of the agent batch =
-    # critic forward + backward down to dH1 (2 (K1 H + H H + H n) + 4 H H + 4 n H) + dW1 (2 K1 H) + actor 3 x forward
+    # critic forward + backward down to dH1 (2 (K1 H + H H + H n) + 4 H H + 4 n H) + dW1 (2 K1 H) + the actor's gradient step
+    # (useful flops, mlp_flops: no layer-1 dX)
     R = n_env * T
     K1, A_ = N * D, 5
-    flop_row = (2 * (K1 * H + H * H + H * N) + 4 * H * H + 4 * N * H) + 2 * K1 * H + 6 * (D * H + H * H + H * A_)
+    flop_row = sum(mlp_flops((K1, H, H, N))) + sum(mlp_flops((D, H, H, A_)))
     learn_flop = R * flop_row + n_env * 2 * (K1 * H + H * H + H * N)
     learn_s = e1.elapsed_time(e2) * 1e-3 / N
     out = {
@@ -603,13 +685,14 @@ def run_c3ppo(a, device):
                    **({"buffer": "ignore_obs_next=True"} if a.ignore_obs_next else {})},
         "collect_ms": e0.elapsed_time(e1), "gae_ppo_update_ms": e1.elapsed_time(e2),
         # the whole GAE + PPO update as executed (one hipGraph replay), priced against the f32-MFMA peak: V(obs) of every joint
-        # row + V(obs_next) of the last slot, then forward + backward (2x) of every sample through the actor and of every joint
-        # row through the critic (the default bench line's roofline_grid[2] has the same count, medians and the kernels' own entries)
+        # row + V(obs_next) of the last slot, then one gradient step (useful flops: mlp_flops) of every sample through the actor
+        # and of every joint row through the critic (the default bench line's roofline_grid has the same count, medians and
+        # the kernels' own entries)
         "roofline": (lambda fl, s_: {"bound": "mfma", "kernel": "C3 whole GAE + PPO update (GenericPPO.update, one hipGraph replay)",
                                      "achieved": fl / s_ / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                                      "frac": fl / s_ / MFMA_F32_PEAK, "traffic": None, "flop_per_update": fl})(
-            (n_env * T + n_env) * 2 * (N * D * 128 + 128 * 128 + 128)
-            + 3 * (n_env * T * N * 2 * (D * 128 + 128 * 128 + 128 * 5) + n_env * T * 2 * (N * D * 128 + 128 * 128 + 128)),
+            (n_env * T + n_env) * mlp_flops((N * D, 128, 128, 1))[0]
+            + n_env * T * N * sum(mlp_flops((D, 128, 128, 5))) + n_env * T * sum(mlp_flops((N * D, 128, 128, 1))),
             e1.elapsed_time(e2) * 1e-3),
         "gradient_steps_per_update": sum(int(v) for k, v in d.items() if k.endswith("gradient_steps")),
         "loss": d.get("agent_0/loss", d.get("loss"))}))

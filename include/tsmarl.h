@@ -49,6 +49,15 @@ const char *tsm_last_error(void);
 /* name_out: >= 64 bytes.  Fails with TSM_ERR_HIP when no gfx950 device is visible. */
 int tsm_device_info(int *n_cu, int *wave_size, int64_t *hbm_bytes, char *name_out);
 
+/* Kernel selection options.  Where one entry point has two kernels behind it the choice is a rule over the problem size; an
+ * option overrides the rule for this process.  Default: the environment variable (read at first use); tsm_kernel_option_set
+ * replaces it at any time (hosts that cache launches -- hipGraphs -- key them by the option values).  No reference counterpart.
+ *   "actor_tile"   0 = by minibatch size | 32 | 64 (tsm_ppo_actor_rows_update / _grid)            TSM_ACTOR_TILE
+ *   "split_bf16"   0 | 1 = layer 1 of tsm_critic_rows_forward on the bf16 matrix pipe, three-way split operands, f32
+ *                  accumulation (experimental, never the default)                                   TSM_SPLIT_BF16 */
+int tsm_kernel_option_get(const char *name, int32_t *value_out);
+int tsm_kernel_option_set(const char *name, int32_t value);
+
 /* memory / stream helpers for hosts that do not bring their own allocator (PyTorch does) */
 int tsm_mem_alloc(void **dptr, int64_t bytes);
 int tsm_mem_free(void *dptr);
@@ -525,7 +534,7 @@ int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stream);
  * Sample i of the minibatch is row perm[i] (NULL: first_row + i) of obs [n][D], act, logp_old, adv.
  * Two kernels behind one entry point, picked by M alone (tsm_ppo_actor_rows_grid follows the same rule): 64-sample tiles with the
  * layer-2 weights in registers (csrc/actor_rows64.hip) once every CU gets at least one such tile, 32-sample tiles with all
- * weights in LDS (csrc/ppo_rows.hip) below that; environment variable TSM_ACTOR_TILE = 32 | 64 forces one (read once).
+ * weights in LDS (csrc/ppo_rows.hip) below that; option "actor_tile" = 32 | 64 forces one (tsm_kernel_option_set).
  * n_blocks = tsm_ppo_actor_rows_grid(M) persistent workgroups, each writes ONE gradient slab:
  * grad_slabs_out [n_blocks][tsm_ppo_actor_rows_param_count]; loss_partial_out f64 [n_blocks][4] =
  * {sum clip objective, 0, sum entropy, 0} (the layout tsm_ppo_finalize_many folds).

@@ -19,8 +19,10 @@ Each fixture holds inputs + the reference's outputs for one hot-path function
   marl_dispatch.npz MultiAgentPolicy.forward scatter + MARLDispatcher per-agent GAE (incl. quirk Q1),
                    FlexibleMultiAgentPolicyManager shared forward       [a5, a6, a10]
   ctde.npz         GlobalStateConstructor.build + CTDEPolicy.learn      [a16]
-  ctde_wide.npz    CTDEPolicy.learn at configs[2]'s widths (128-wide actor and centralized critic) on rows laid out as a
-                   time-major store: every agent's learn() in turn, with and without episodes ending mid-store   [a16, a17]
+  ctde_wide.npz    CTDEPolicy.learn with a 128-wide actor and centralized critic at N = 4, D = 24 (critic input 96) on rows
+                   laid out as a time-major store: every agent's learn() in turn, with and without episodes ending mid-store
+                   [a16, a17]
+  ctde_c3.npz      the same at configs[2]'s own widths: N = 8, D = 48 (critic input 384, 8 outputs)   [a16, a17]
   misc.npz         Batch.split bounds, RunningMeanStd, episode_mc_return_to_go   [a11, a14]
 """
 from __future__ import annotations
@@ -253,8 +255,11 @@ def _ppo_update_variants(variants, n_env, T, obs_dim, n_act, hidden) -> dict:
             with torch.enable_grad():
                 algo.train()
                 stats = algo._update_with_batch(pb, v["batch_size"], v["repeat"])
+        if v["ppo"].get("return_scaling"):  # (recompute_advantage updates the statistics again before every later repeat)
+            out[p + "rms_final"] = np.array([algo.ret_rms.mean, algo.ret_rms.var, algo.ret_rms.count], np.float64)
         out[p + "batch_size"] = -1 if v["batch_size"] is None else v["batch_size"]
         out[p + "repeat"] = v["repeat"]
+        out[p + "recompute_advantage"] = int(bool(v["ppo"].get("recompute_advantage")))
         out[p + "gradient_steps"] = stats.gradient_steps
         # per-gradient-step loss values are summarised by SequenceSummaryStats; keep mean/std/min/max
         for k in ("loss", "actor_loss", "vf_loss", "ent_loss"):
@@ -277,6 +282,11 @@ def make_ppo_update() -> None:
              batch_size=100, repeat=1),
         dict(name="noadvnorm_retscale", ppo=dict(advantage_normalization=False, return_scaling=True),
              batch_size=None, repeat=1),
+        # ppo.py:174-178: returns / advantages recomputed with the current critic before every repeat after the first
+        # (logp_old stays); with return_scaling the running statistics are updated again by every recomputation (a2c.py:132-146)
+        dict(name="recompute", ppo=dict(recompute_advantage=True), batch_size=64, repeat=2),
+        dict(name="recompute_retscale_vclip", ppo=dict(recompute_advantage=True, return_scaling=True, value_clip=True),
+             batch_size=100, repeat=3),
     ]
     out = _ppo_update_variants(variants, n_env=8, T=25, obs_dim=18, n_act=5, hidden=[64, 64])
     save("ppo_update.npz", variants=np.array([v["name"] for v in variants]), **out)
@@ -289,6 +299,7 @@ def make_ppo_update_wide() -> None:
         dict(name="w128_mb64", ppo={}, batch_size=64, repeat=2),
         dict(name="w128_vclip_gn", ppo=dict(value_clip=True, max_grad_norm=0.5), batch_size=64, repeat=2),
         dict(name="w128_dualclip_full", ppo=dict(dual_clip=2.0, value_clip=True), batch_size=None, repeat=1),
+        dict(name="w128_recompute", ppo=dict(recompute_advantage=True), batch_size=64, repeat=2),
     ]
     out = _ppo_update_variants(variants, n_env=8, T=25, obs_dim=48, n_act=5, hidden=[128, 128])
     save("ppo_update_wide.npz", variants=np.array([v["name"] for v in variants]), **out)
@@ -508,13 +519,12 @@ def make_ctde() -> None:
     save("ctde.npz", **out)
 
 
-def make_ctde_wide() -> None:
-    """CTDEPolicy.learn (ctde.py:121-199) at the widths the one-launch kernels serve (hidden 128, critic on the N*D joint
-    row), called the way the MARL trainers call it (training_coordinator.py:118: one learn() per agent, in env.agents order, on
-    that agent's column of the same joint rows).  The rows are generated as a time-major store [T, E, N, ...] whose obs_next
-    is the next slot's obs unless the episode ended (what a Collector leaves behind, collector.py:1040-1069); the reference
-    gets the env-major flattening.  Variant `chain`: episodes end at the last slot only; `early`: some end mid-store."""
-    N, D, A, H, E, T = 4, 24, 5, 128, 6, 11
+def _make_ctde_rows(fname: str, N: int, D: int, A: int, H: int, E: int, T: int, first_seed: int) -> None:
+    """CTDEPolicy.learn (ctde.py:121-199) with 128-wide nets and the critic on the N*D joint row, called the way the MARL
+    trainers call it (training_coordinator.py:118: one learn() per agent, in env.agents order, on that agent's column of the
+    same joint rows).  The rows are generated as a time-major store [T, E, N, ...] whose obs_next is the next slot's obs unless
+    the episode ended (what a Collector leaves behind, collector.py:1040-1069); the reference gets the env-major flattening.
+    Variant `chain`: episodes end at the last slot only; `early`: some end mid-store."""
     out = dict(dims=np.array([N, D, A, H, E, T]), gamma=np.float64(0.99), lr=np.float64(1e-3))
 
     def run(variant, seed):
@@ -567,6 +577,17 @@ def make_ctde_wide() -> None:
             minz = min(minz, min_preact(actor, batch.obs), min_preact(critic, batch.global_obs), min_preact(critic, batch.global_obs_next))
             r = pol.learn(batch)
             losses.append([r["actor_loss"], r["critic_loss"]])
+            # How far one Adam step moves a parameter per unit of gradient error, summed over the calls, from the reference's
+            # own optimizer state: u_k = lr m^_k / (sqrt(v^_k) + eps), |du_k / dg| <= lr / (sqrt(v^_k) + eps).  A parameter
+            # whose gradients all but cancel (|g| ~ eps) takes a sign-like step of up to lr whatever the summation order says;
+            # the replay tests allow `adamcond` x (their gradient bar) on top of the plain weight tolerance.
+            for name, mod, opt in (("actor", actor, pol.optim_actor), ("critic", critic, pol.optim_critic)):
+                for i, l in enumerate([mod.fc1, mod.fc2, mod.fc3]):
+                    for kind, prm in (("w", l.weight), ("b", l.bias)):
+                        st = opt.state[prm]
+                        v_hat = st["exp_avg_sq"].detach().double().numpy() / (1.0 - 0.999 ** float(st["step"]))
+                        key = f"{variant}_adamcond_{name}_{kind}{i}"
+                        res[key] = res.get(key, 0.0) + 1e-3 / (np.sqrt(v_hat) + 1e-8)
             if a == 0:
                 snap("after1")
                 for name, mod in (("actor", actor), ("critic", critic)):
@@ -574,24 +595,40 @@ def make_ctde_wide() -> None:
                         res[f"{variant}_grad1_{name}_w{i}"] = l.weight.grad.detach().numpy().copy()
                         res[f"{variant}_grad1_{name}_b{i}"] = l.bias.grad.detach().numpy().copy()
         snap("afterN")
+        for k in [k for k in res if "_adamcond_" in k]:
+            res[k] = res[k].astype(np.float32)
         res.update({f"{variant}_obs": obs, f"{variant}_act": act, f"{variant}_rew": rew, f"{variant}_term": term,
                     f"{variant}_trunc": trunc, f"{variant}_obs_next": obs_next, f"{variant}_losses": np.array(losses),
                     f"{variant}_seed": np.int64(seed), f"{variant}_min_abs_preact": np.float64(minz)})
         return res, minz
 
     # A hidden unit whose pre-activation is ~1e-7 on some row takes either side of the ReLU depending on the summation order of
-    # a 96-term f32 dot product; Adam then turns that one row's gradient into full +-lr steps on the unit's whole weight row
+    # a K1-term f32 dot product; Adam then turns that one row's gradient into full +-lr steps on the unit's whole weight row
     # (seed 21 of `chain` has |z| = 1.06e-7 in the fourth call: f64 and the reference's f32 land on one side, a k-ordered f32 FMA
     # chain on the other).  The fixture is for arithmetic parity, not for tie-breaking at a kink: take the first seed whose
-    # every pre-activation (reference's own f32 run, all four calls, both nets) stays 2e-6 away from it; the margin is recorded.
+    # every pre-activation (reference's own f32 run, all N calls, both nets) stays 2e-6 away from it; the margin is recorded.
+    # (The criterion is computed from the reference's run alone; the fixture is therefore silent about tie-breaking at a kink.)
     for variant in ("chain", "early"):
-        for seed in range(21, 200):
+        for seed in range(first_seed, first_seed + 400):
             res, minz = run(variant, seed)
             if minz >= 2e-6:
                 break
-        print(f"ctde_wide {variant}: seed {seed}, min |pre-activation| {minz:.2e}")
+        else:
+            raise RuntimeError(f"{fname} {variant}: no seed keeps every pre-activation 2e-6 off the kink")
+        print(f"{fname} {variant}: seed {seed}, min |pre-activation| {minz:.2e}")
         out.update(res)
-    save("ctde_wide.npz", **out)
+    save(fname, **out)
+
+
+def make_ctde_wide() -> None:
+    """128-wide nets at N = 4, D = 24: critic input K1 = 96 (the <6> instantiations of the critic kernels), n_out = 4."""
+    _make_ctde_rows("ctde_wide.npz", N=4, D=24, A=5, H=128, E=6, T=11, first_seed=21)
+
+
+def make_ctde_c3() -> None:
+    """BASELINE configs[2]'s own widths: N = 8 agents, obs 48 -> critic input K1 = 384, n_out = 8 (ctde.py:346-414) -- the
+    <24> instantiations of critic_rows_train_kernel / critic_dw1_kernel / critic_rows_forward_kernel, the ones the bench runs."""
+    _make_ctde_rows("ctde_c3.npz", N=8, D=48, A=5, H=128, E=6, T=11, first_seed=21)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -624,6 +661,7 @@ def make_misc() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "ppo_update_wide", "pg_update", "marl_dispatch", "ctde", "ctde_wide", "misc"]
+    which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "ppo_update_wide", "pg_update", "marl_dispatch", "ctde", "ctde_wide",
+                             "ctde_c3", "misc"]
     for w in which:
         globals()["make_" + w]()

@@ -417,26 +417,43 @@ def _wide_flat(g, prefix, name):
                            for i in range(3)]).astype(np.float64)
 
 
+@pytest.mark.parametrize("tile", [32, 64], ids=["tile32", "tile64"])
 @pytest.mark.parametrize("path", ["store", "store_eager", "copies"])
 @pytest.mark.parametrize("variant", ["chain", "early"])
-def test_ctde_learn_wide_matches_reference_fixture(variant, path):
-    """CTDEPolicy.learn against the REFERENCE's own run at configs[2]'s widths (tests/golden/ctde_wide.npz: 128-wide actor,
-    centralized critic on the N*D joint row, four agents' learn() calls in turn on the same rows, as the MARL trainers issue
-    them).  `store`: the one-launch kernels reading the time-major stores in place (critic_rows / critic_train / critic_dw1 /
+@pytest.mark.parametrize("fixture", ["ctde_wide.npz", "ctde_c3.npz"])
+def test_ctde_learn_wide_matches_reference_fixture(fixture, variant, path, tile):
+    """CTDEPolicy.learn against the REFERENCE's own run with 128-wide nets (128-wide actor, centralized critic on the N*D joint
+    row, every agent's learn() call in turn on the same rows, as the MARL trainers issue them).  `ctde_wide.npz`: N = 4,
+    D = 24 -- critic input K1 = 96, the <6> instantiations of the critic kernels; `ctde_c3.npz`: BASELINE configs[2]'s own
+    widths, N = 8, D = 48 -- K1 = 384, 8 outputs: the <24> instantiations of critic_rows_train_kernel / critic_dw1_kernel /
+    critic_rows_forward_kernel that the bench runs.  `tile`: the actor gradient step on the 32-sample kernel (csrc/ppo_rows.hip)
+    and on the 64-sample kernel (csrc/actor_rows64.hip), forced through the `actor_tile` kernel option.  `store`: the one-launch kernels reading the time-major stores in place (critic_rows / critic_train / critic_dw1 /
     ppo_rows / ctde_finalize / adam_step_segs; the 2nd call of an agent would replay a hipGraph -- here every agent is called
     once, so `store` and `store_eager` differ in nothing but the flag and both must hold); `copies`: dense GEMMs on env-major
     copies.  `early`: episodes end mid-store, obs_next of those rows is not the next slot's obs.
     Bars: both losses of every call 1e-5; weights after the first call rtol 1e-5 + atol 5e-6 plus what ONE Adam step from zero
     moments does to a gradient known to 1e-5 of its scale (u = lr g / (|g| + eps): du = lr eps dg / (|g| + eps)^2, at most a
-    step of lr where |g| < dg); after all four calls every weight of both nets rtol 1e-5 + atol 5e-6.  (The generator picks
+    step of lr where |g| < dg); after all N calls every weight of both nets rtol 1e-5 + atol 5e-6 plus the same allowance
+    summed over the calls from the reference's own Adam state (`*_adamcond_*`), and 99.9 % of them without it.  (The generator picks
     data whose every ReLU pre-activation in the reference's run stays 2e-6 off the kink -- `*_min_abs_preact` in the fixture:
     a unit at |z| ~ 1e-7 takes either side depending on the f32 summation order and Adam turns that into +-lr steps.)"""
     from tianshou_marl_amd.algorithm.multiagent.training_coordinator import _attach_global
     from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
 
-    g = np.load(os.path.join(GOLD, "ctde_wide.npz"))
+    if path == "copies" and tile == 64:
+        pytest.skip("the dense path on copies has no actor tile")
+    g = np.load(os.path.join(GOLD, fixture))
     N, D, A, H, E, T = (int(x) for x in g["dims"])
     lr, eps = float(g["lr"]), 1e-8
+    with ops.kernel_override(actor_tile=tile):
+        _ctde_wide_replay(g, variant, path, N, D, A, H, E, T, lr, eps)
+    assert ops.kernel_option("actor_tile") == 0
+
+
+def _ctde_wide_replay(g, variant, path, N, D, A, H, E, T, lr, eps):
+    from tianshou_marl_amd.algorithm.multiagent.training_coordinator import _attach_global
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+
     actor = DecentralizedActor(D, A, hidden_dim=H, device=DEV)
     critic = CentralizedCritic(N * D, N, hidden_dim=H, device=DEV)
     actor.load_layers([(g[f"{variant}_init_actor_w{i}"], g[f"{variant}_init_actor_b{i}"]) for i in range(3)])
@@ -468,7 +485,14 @@ def test_ctde_learn_wide_matches_reference_fixture(variant, path):
                 assert not bad.any(), (nm, int(bad.sum()), float(np.abs(got - ref)[bad].max()))
                 # and most of the weights are nowhere near those ill-conditioned entries: plain tolerance for 95 % of them
                 assert (np.abs(got - ref) <= 5e-6 + 1e-5 * np.abs(ref)).mean() > 0.95, nm
-    for nm, net in (("actor", actor), ("critic", critic)):  # four Adam steps in: every weight of both nets
-        ref = _wide_flat(g, f"{variant}_afterN", nm)
-        np.testing.assert_allclose(net.flat.data.double().cpu().numpy(), ref, rtol=1e-5, atol=5e-6, err_msg=nm)
+    for nm, net in (("actor", actor), ("critic", critic)):  # N Adam steps in: every weight of both nets
+        ref, got = _wide_flat(g, f"{variant}_afterN", nm), net.flat.data.double().cpu().numpy()
+        # plain tolerance + what N Adam steps do to a gradient known to 1e-5 of its scale: `adamcond` is the reference's own
+        # sum over the calls of lr / (sqrt(v^_k) + eps) per parameter (make_fixtures.py), a handful of parameters whose
+        # gradient all but cancelled in the first call (|g| ~ 1e-9: a sign-like step of up to lr) carry it to the end
+        dg = 1e-5 * np.abs(_wide_flat(g, f"{variant}_grad1", nm)).max()
+        tol = 5e-6 + 1e-5 * np.abs(ref) + np.minimum(_wide_flat(g, f"{variant}_adamcond", nm) * dg, 2 * lr * N)
+        bad = np.abs(got - ref) > tol
+        assert not bad.any(), (nm, int(bad.sum()), float(np.abs(got - ref)[bad].max()))
+        assert (np.abs(got - ref) <= 5e-6 + 1e-5 * np.abs(ref)).mean() > 0.999, nm  # ... and all but a handful: plain tolerance
     assert pol.optim_actor.step_count == pol.optim_critic.step_count == N

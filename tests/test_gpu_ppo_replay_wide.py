@@ -7,8 +7,13 @@ utils/net/common.py:246-369 -- run in the build container) holds the buffer rows
     w128_mb64            batch 64, repeat 2 (200 rows -> 64, 64, 72)
     w128_vclip_gn        value clipping + max_grad_norm 0.5, batch 64, repeat 2
     w128_dualclip_full   dual clip 2.0 + value clipping, the whole batch in one step
-They are replayed through `GenericPPO` with the one-launch actor / critic steps (csrc/ppo_rows.hip), the one-launch critic
-forward (csrc/critic_rows.hip) and the segmented Adam, captured (hipGraph) and eager: loss statistics 2e-5, weights 1e-5."""
+    w128_recompute       recompute_advantage (ppo.py:174-178), batch 64, repeat 2
+They are replayed through `GenericPPO` with the one-launch actor / critic steps, the one-launch critic forward
+(csrc/critic_rows.hip) and the segmented Adam, captured (hipGraph) and eager: loss statistics 2e-5, weights 1e-5.
+Every replay runs once per ACTOR KERNEL behind `tsm_ppo_actor_rows_update`: the 32-sample tiles of csrc/ppo_rows.hip (what the
+size rule picks for these 64..200-sample minibatches) and the 64-sample tiles of csrc/actor_rows64.hip (what it picks at the
+bench's 65 536-sample minibatches), forced through the `actor_tile` kernel option -- so the kernel behind the roofline figure
+meets the reference's tensors, partial tiles included (64 -> one full tile, 72 -> 64 + 8, 200 -> 3 x 64 + 8)."""
 import os
 
 import numpy as np
@@ -18,6 +23,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
+    from tianshou_marl_amd import ops
     from tianshou_marl_amd.algorithm import GenericPPO, policy_within_training_step
     from tianshou_marl_amd.data.batch import Batch
     from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
@@ -25,7 +31,8 @@ if torch.cuda.is_available():
 
 DEV = "cuda"
 N_ENV, T, D, H, A = 8, 25, 48, 128, 5
-VARIANTS = ["w128_mb64", "w128_vclip_gn", "w128_dualclip_full"]
+VARIANTS = ["w128_mb64", "w128_vclip_gn", "w128_dualclip_full", "w128_recompute"]
+TILES = [32, 64]
 
 
 def _layers(g, p, kind, net):
@@ -62,7 +69,7 @@ def _job(g, name, graph, **kw):
     algo = GenericPPO(net=net, lr=float(lr), eps_clip=float(eps_clip), dual_clip=float(dual_clip) or None,
                       value_clip=bool(value_clip), advantage_normalization=bool(adv_norm), vf_coef=float(vf_coef),
                       ent_coef=float(ent_coef), gamma=float(gamma), gae_lambda=float(lam), max_grad_norm=float(max_gn) or None,
-                      dispatch="pooled", shuffle="numpy", graph=graph, **kw)
+                      recompute_advantage=bool(g[p + "recompute_advantage"]), dispatch="pooled", shuffle="numpy", graph=graph, **kw)
     assert np.array_equal(g[p + "indices"], np.arange(N_ENV * T))  # env-major, time-ordered rows (sample(0))
     buf = DeviceVectorReplayBuffer(N_ENV * T, N_ENV, 1, D, device=DEV)
     rows = lambda k, t: g[p + k].reshape(N_ENV, T, *g[p + k].shape[1:])[:, t]  # noqa: E731
@@ -87,31 +94,40 @@ def test_preprocess_batch_of_the_wide_nets_matches_reference(golden_dir, name):
     np.testing.assert_allclose(em(pb["adv"]), g[p + "adv"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("tile", TILES, ids=["tile32", "tile64"])
 @pytest.mark.parametrize("graph", [True, False], ids=["graph", "eager"])
 @pytest.mark.parametrize("name", VARIANTS)
-def test_update_of_the_wide_nets_replays_reference_minibatch_loop(golden_dir, name, graph):
+def test_update_of_the_wide_nets_replays_reference_minibatch_loop(golden_dir, name, graph, tile):
     """ppo.py:164-224 with the reference's permutations on the row kernels: loss statistics of every gradient step and
     the weights after the last Adam step.  The captured form needs a warm-up update of the same shape (the first one of a
     shape runs eagerly, the second captures): it runs on a twin and the measured object replays a graph of its own."""
     g = np.load(os.path.join(golden_dir, "ppo_update_wide.npz"), allow_pickle=True)
     p = name + "_"
-    algo, net, buf = _job(g, name, graph)
-    bs, rep = int(g[p + "batch_size"]), int(g[p + "repeat"])
-    bs = None if bs == -1 else bs
-    if graph:  # eager update, then the capturing one, on throw-away parameters; then restore and replay
-        p0 = net.flat.data.clone()
-        for _ in range(2):
-            with policy_within_training_step(algo):
-                algo.update(buf, bs, rep)
-        assert any(isinstance(k, tuple) and k and k[0] == "ggraph" and "graph" in v for k, v in algo._ws.items())
-        net.flat.data.copy_(p0)
-        algo.exp_avg.zero_()
-        algo.exp_avg_sq.zero_()
-        algo.opt_step = 0
-        algo.param_version += 1
-    np.random.seed(11)  # the state make_ppo_update_wide drew `perms` from
-    with policy_within_training_step(algo):
-        stats = algo.update(buf, bs, rep)
+    with ops.kernel_override(actor_tile=tile):
+        # the slab count says which kernel serves a minibatch: one slab per tile of the forced size
+        assert ops.ppo_actor_rows_grid(72) == -(-72 // tile) and ops.ppo_actor_rows_grid(200) == -(-200 // tile)
+        algo, net, buf = _job(g, name, graph)
+        bs, rep = int(g[p + "batch_size"]), int(g[p + "repeat"])
+        bs = None if bs == -1 else bs
+        captured = lambda: any(isinstance(k, tuple) and k and k[0] == "ggraph" and "graph" in v  # noqa: E731
+                               for k, v in algo._ws.items())
+        if graph:  # eager update, then the capturing one, on throw-away parameters; then restore and replay
+            p0 = net.flat.data.clone()
+            for _ in range(2):
+                with policy_within_training_step(algo):
+                    algo.update(buf, bs, rep)
+            # recompute_advantage re-runs the critic passes between repeats from the host: the update stays on eager
+            # launches by design (GenericPPO._update), whatever `graph` says
+            assert captured() == (not algo.recompute_adv)
+            net.flat.data.copy_(p0)
+            algo.exp_avg.zero_()
+            algo.exp_avg_sq.zero_()
+            algo.opt_step = 0
+            algo.param_version += 1
+        np.random.seed(11)  # the state make_ppo_update_wide drew `perms` from
+        with policy_within_training_step(algo):
+            stats = algo.update(buf, bs, rep)
+    assert ops.kernel_option("actor_tile") == 0
     assert stats.gradient_steps == int(g[p + "gradient_steps"])
     for k in ("loss", "actor_loss", "vf_loss", "ent_loss"):
         s = getattr(stats, k)

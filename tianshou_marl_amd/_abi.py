@@ -96,6 +96,8 @@ SIGNATURES = {
     "tsm_abi_version": (_int, []),
     "tsm_last_error": (C.c_char_p, []),
     "tsm_device_info": (_int, [C.POINTER(_int), C.POINTER(_int), C.POINTER(_i64), C.c_char_p]),
+    "tsm_kernel_option_get": (_int, [C.c_char_p, C.POINTER(_i32)]),
+    "tsm_kernel_option_set": (_int, [C.c_char_p, _i32]),
     "tsm_mem_alloc": (_int, [C.POINTER(_p), _i64]),
     "tsm_mem_free": (_int, [_p]),
     "tsm_mem_h2d": (_int, [_p, _p, _i64, _p]),

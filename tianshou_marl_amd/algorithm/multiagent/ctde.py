@@ -223,10 +223,11 @@ class CTDEPolicy(nn.Module):
         actor, critic = self.actor, self.critic
         H, n_out, A = critic.dims[1], critic.dims[-1], actor.dims[-1]
         K1 = N * D
-        w = self._ws.get((store.key, T, agent))
+        wkey = (store.key, T, agent, ops.kernel_options())  # (the options pick kernels and slab counts: captured per value)
+        w = self._ws.get(wkey)
         if w is None:
             na = ops.ppo_actor_rows_grid(B)
-            w = self._ws[(store.key, T, agent)] = dict(
+            w = self._ws[wkey] = dict(
                 ids=(torch.arange(B, dtype=torch.int64, device=dev) * N + agent).contiguous(), na=na,
                 slabs_a=torch.empty(na, actor.flat.numel(), dtype=torch.float32, device=dev),
                 part_a=torch.zeros(na * 4, dtype=torch.float64, device=dev),

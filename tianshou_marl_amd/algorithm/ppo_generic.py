@@ -271,9 +271,9 @@ class GenericPPO(PPO):
         Mr = rows.numel() if rows is not None else M
         na, nv = self._rows_grids(M, Mr, crit_rows)
         n_split = nv if crit_rows else ops.mlp_n_split(Mr)
-        w = self._ws.get(("rows", M, n_split, crit_rows))
+        w = self._ws.get(("rows", M, na, n_split, crit_rows))
         if w is None:
-            w = self._ws[("rows", M, n_split, crit_rows)] = dict(
+            w = self._ws[("rows", M, na, n_split, crit_rows)] = dict(
                 slabs_a=torch.empty(na, P_a, dtype=torch.float32, device=dev),
                 slabs_c=None if (crit_rows and self.critic_gen2) else torch.empty(n_split, P_c, dtype=torch.float32, device=dev),
                 partial=torch.zeros((na + nv) * 4, dtype=torch.float64, device=dev),
@@ -360,7 +360,7 @@ class GenericPPO(PPO):
         # captured over chained rows (V(obs_next) from the next slot's V(obs)) must never replay on rows that are not
         chained = buffer.rows_chained is True and self.shift_next_values and buffer.obs_next_store is not None
         key = ("ggraph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored, chained,
-               self._grad_sync is not None, self.graph_collectives)
+               self._grad_sync is not None, self.graph_collectives, ops.kernel_options())
         w = self._ws.get(key)
         if w is None:  # first update of this shape runs eagerly (one-time kernel attributes, allocator warm-up)
             self._ws[key] = {}

@@ -2,6 +2,7 @@
 // include/tsmarl.h.  No reference counterpart (the reference is pure Python; these exist so that a
 // non-PyTorch host can drive the C-ABI).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -72,6 +73,52 @@ TSM_EXPORT int tsm_stream_abort_capture(void *stream) {
     (void)hipGetLastError();
     if (g) (void)hipGraphDestroy(g);
     return 1;
+}
+
+// ---- kernel selection options ----------------------------------------------------------------------------------------
+// Where one entry point has two kernels behind it, the choice is a rule over the problem size.  An option overrides the rule
+// for this process: its default comes from the environment (read once, at first use), tsm_kernel_option_set() replaces it at
+// any time -- so one test process can run the same reference fixture through every kernel of an entry point.
+//   "actor_tile"  0: by minibatch size (tsm_ppo_actor_rows_grid) | 32 | 64      env TSM_ACTOR_TILE
+//   "split_bf16"  0: f32 matrix pipe | 1: layer 1 of the critic forward on the bf16 pipe with three-way split operands
+//                 (experimental, never the default)                              env TSM_SPLIT_BF16
+namespace {
+struct KernelOption { const char *name, *env; int value; bool resolved; };
+KernelOption g_opts[TSM_OPT_COUNT] = {{"actor_tile", "TSM_ACTOR_TILE", 0, false}, {"split_bf16", "TSM_SPLIT_BF16", 0, false}};
+bool opt_valid(int id, int v) { return id == TSM_OPT_ACTOR_TILE ? (v == 0 || v == 32 || v == 64) : (v == 0 || v == 1); }
+}  // namespace
+
+int tsm_opt(int id) {
+    KernelOption &o = g_opts[id];
+    if (!o.resolved) {
+        const char *e = getenv(o.env);
+        const int v = e ? atoi(e) : 0;
+        o.value = opt_valid(id, v) ? v : 0;
+        o.resolved = true;
+    }
+    return o.value;
+}
+
+static int opt_id(const char *name) {
+    for (int i = 0; name && i < TSM_OPT_COUNT; ++i)
+        if (!strcmp(name, g_opts[i].name)) return i;
+    return -1;
+}
+
+TSM_EXPORT int tsm_kernel_option_get(const char *name, int32_t *value_out) {
+    const int id = opt_id(name);
+    TSM_REQUIRE(id >= 0 && value_out, "tsm_kernel_option_get: unknown option '%s'", name ? name : "(null)");
+    *value_out = tsm_opt(id);
+    return TSM_OK;
+}
+
+TSM_EXPORT int tsm_kernel_option_set(const char *name, int32_t value) {
+    const int id = opt_id(name);
+    TSM_REQUIRE(id >= 0, "tsm_kernel_option_set: unknown option '%s'", name ? name : "(null)");
+    TSM_REQUIRE(opt_valid(id, value), "tsm_kernel_option_set: %d is not a value of '%s'", value, name);
+    g_opts[id].value = value;
+    g_opts[id].resolved = true;
+    return TSM_OK;
 }
 
 // diagnostic hook (not part of the public ABI header): device buffer of i64 phase time stamps written by

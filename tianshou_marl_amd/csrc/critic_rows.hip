@@ -460,14 +460,10 @@ int launch_forward_bf16(const FwdArgs &g, int grid, hipStream_t st) {
     return TSM_OK;
 }
 
-// experimental path on?  (read once; only widths with an instantiation: K1 % 4 == 0, K1 <= 384)
+// experimental path on?  (option "split_bf16": tsm_kernel_option_set, default from TSM_SPLIT_BF16; only widths with an
+// instantiation: K1 % 4 == 0, K1 <= 384)
 int split_bf16_kj2(int K1) {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("TSM_SPLIT_BF16");
-        on = e && atoi(e) == 1;
-    }
-    if (!on || (K1 & 3)) return 0;
+    if (!tsm_opt(TSM_OPT_SPLIT_BF16) || (K1 & 3)) return 0;
     static const int inst[] = {2, 3, 6, 12};
     for (int k : inst)
         if (32 * k >= K1) return k;

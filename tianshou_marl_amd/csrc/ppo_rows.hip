@@ -756,14 +756,10 @@ TSM_EXPORT int64_t tsm_ppo_actor_rows_param_count(int32_t obs_dim, int32_t hidde
 
 // Which actor kernel serves a minibatch of M samples: 64-sample tiles with W2 in registers (csrc/actor_rows64.hip) once
 // every CU gets at least one of them, the 32-sample tiles of this file below that (twice the tiles to spread over the CUs).
-// TSM_ACTOR_TILE = 32 | 64 forces one (tests, A/B timing); read once per process.
+// Option "actor_tile" = 32 | 64 forces one (tsm_kernel_option_set; default from TSM_ACTOR_TILE): tests run the reference
+// fixtures through both, tools time them A/B.
 static bool actor_tile64(int64_t M) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("TSM_ACTOR_TILE");
-        forced = !e ? 0 : (atoi(e) == 64 ? 64 : (atoi(e) == 32 ? 32 : 0));
-    }
-    if (forced) return forced == 64;
+    if (const int forced = tsm_opt(TSM_OPT_ACTOR_TILE)) return forced == 64;
     return ceil_div(M, 64) >= n_cu();
 }
 

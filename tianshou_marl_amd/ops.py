@@ -940,5 +940,44 @@ def device_info() -> dict:
     return dict(n_cu=n_cu.value, wave_size=wave.value, hbm_bytes=hbm.value, arch=name.value.decode())
 
 
+KERNEL_OPTIONS = ("actor_tile", "split_bf16")
+
+
+def kernel_option(name: str) -> int:
+    """Value of a kernel selection option (include/tsmarl.h: tsm_kernel_option_get)."""
+    v = C.c_int32()
+    call("tsm_kernel_option_get", name.encode(), C.byref(v))
+    return v.value
+
+
+def set_kernel_option(name: str, value: int) -> int:
+    """Override a kernel selection rule for this process; returns the previous value."""
+    old = kernel_option(name)
+    call("tsm_kernel_option_set", name.encode(), int(value))
+    return old
+
+
+def kernel_options() -> tuple:
+    """All option values in KERNEL_OPTIONS order: part of every launch-cache (hipGraph) key."""
+    return tuple(kernel_option(n) for n in KERNEL_OPTIONS)
+
+
+class kernel_override:
+    """`with ops.kernel_override(actor_tile=64): ...` -- options set inside, restored on exit."""
+
+    def __init__(self, **opts: int):
+        self._opts, self._old = opts, {}
+
+    def __enter__(self):
+        for k, v in self._opts.items():
+            self._old[k] = set_kernel_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._old.items():
+            set_kernel_option(k, v)
+        return False
+
+
 __all__ = [n for n in dir() if not n.startswith("_")]
 _ = _abi

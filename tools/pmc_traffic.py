@@ -26,6 +26,20 @@ def short(name: str) -> str:
     return m.group(1) if m else name[:60]
 
 
+def clusters(vals: list, ratio: float = 3.0) -> list:
+    """Sorted values split wherever the next one exceeds `ratio` x the previous one: launches of one (kernel, grid) at very
+    different problem sizes (gae_lanes_kernel at T = 25 and T = 2048 share name and grid) are reported apart."""
+    out, cur = [], []
+    for v in sorted(vals):
+        if cur and v > ratio * max(cur[-1], 1.0):
+            out.append(cur)
+            cur = []
+        cur.append(v)
+    if cur:
+        out.append(cur)
+    return out
+
+
 def load(d: str, counter: str):
     f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
     per = defaultdict(list)  # (kernel, grid) -> [KiB]
@@ -35,8 +49,25 @@ def load(d: str, counter: str):
     return per
 
 
+def split_sizes(fetch: dict, write: dict):
+    """(kernel, grid) -> (kernel, grid, cluster): only where BOTH passes show the same number (> 1) of value clusters (the two
+    passes are separate runs of one command, so the k-th smallest problem size of one is the k-th smallest of the other)."""
+    f2, w2 = {}, {}
+    for key in set(fetch) | set(write):
+        cf, cw = clusters(fetch.get(key, [])), clusters(write.get(key, []))
+        if len(cf) == len(cw) and len(cf) > 1:
+            for i, (a, b) in enumerate(zip(cf, cw)):
+                f2[key + (i,)], w2[key + (i,)] = a, b
+        else:
+            if key in fetch:
+                f2[key + (0,)] = fetch[key]
+            if key in write:
+                w2[key + (0,)] = write[key]
+    return f2, w2
+
+
 def main(d_fetch: str, d_write: str, out: str) -> None:
-    fetch, write = load(d_fetch, "FETCH_SIZE"), load(d_write, "WRITE_SIZE")
+    fetch, write = split_sizes(load(d_fetch, "FETCH_SIZE"), load(d_write, "WRITE_SIZE"))
     rows = []
     for key in sorted(set(fetch) | set(write)):
         if not any(t in key[0] for t in ("gae_lanes", "loss_kernel", "ppo_update", "rollout", "adam", "policy_forward",
@@ -45,7 +76,7 @@ def main(d_fetch: str, d_write: str, out: str) -> None:
             continue
         f = fetch.get(key, [])
         w = write.get(key, [])
-        rows.append(dict(kernel=key[0], grid=key[1], launches=max(len(f), len(w)),
+        rows.append(dict(kernel=key[0], grid=key[1], size_cluster=key[2], launches=max(len(f), len(w)),
                          fetch_KiB=sum(f) / len(f) if f else None, write_KiB=sum(w) / len(w) if w else None))
     # calibration of the read factor on known streaming byte counts (4 B per lane loads)
     known = {  # (kernel substring, grid threads) -> (read bytes, write bytes)
@@ -55,7 +86,7 @@ def main(d_fetch: str, d_write: str, out: str) -> None:
     calib = []
     for r in rows:
         for (name, grid), (rd, wr) in known.items():
-            if name in r["kernel"] and r["grid"] == grid and r["fetch_KiB"]:
+            if name in r["kernel"] and r["grid"] == grid and r["fetch_KiB"] and 0.25 < rd / (r["fetch_KiB"] * 1024) < 8:
                 calib.append(dict(kernel=r["kernel"], grid=grid, algorithmic_read_B=rd, fetch_reported_B=r["fetch_KiB"] * 1024,
                                   read_factor=rd / (r["fetch_KiB"] * 1024), algorithmic_write_B=wr,
                                   write_reported_B=(r["write_KiB"] or 0) * 1024))
