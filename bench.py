@@ -493,11 +493,16 @@ def c3_rooflines(device):
             tot_ += e0.elapsed_time(e1) * 1e-3 / n_rep / 5
         return tot_
 
-    tot = graph_time(fc)
+    tot_gather = graph_time(fc)  # (first step of an update: W1 gathered from the flat vector)
     wc = next(iter(cws.values()))
     c_flop, c_bytes = (f_critic + b_critic) * mr, (4 * N * D + 8 + 4 * N) * mr
+    # (as GenericPPO runs every step but the first of an update: first-layer weights from the fragment image the optimizer keeps)
+    w1_img = ops.critic_w1_image(net.critic.flat.data, N * D)
+    tot = graph_time(lambda: ops.critic_rows_grad_ppo(net.critic.flat.data, joint, ret, algo._cfg, N, H, rows=rid, Mr=mr, ws=cws,
+                                                     w1_image=w1_img))
     out.append({"kernel": "critic_rows_train_kernel<24> + critic_dw1_kernel (centralized critic 384-128-128-1 on joint rows: "
                           "forward + value loss of the row's 8 agents + backward, dW1 as a split-K pass; two launches)",
+                "us_per_launch_w1_gathered": tot_gather * 1e6,
                 "rows": mr, "samples": mb, "bound": "mfma", "flop_per_launch": c_flop,
                 "timing": "back_to_back (graph of 10 launch pairs, HIP events)",
                 "in_situ_us_rocprof": (lambda a_, b_: None if a_ is None or b_ is None else round(a_ + b_, 3))(
@@ -509,7 +514,7 @@ def c3_rooflines(device):
                 "slab_bytes_per_launch": (wc["rest"].numel() + wc["w1"].numel() + wc["dh1"].numel()) * 4,
                 "traffic": (lambda a_, b_: None if a_ is None or b_ is None else a_ + b_)(
                     pmc_traffic("critic_rows_train_kernel", wc["nb"] * 512),
-                    pmc_traffic("critic_dw1_kernel", -(-N * D // 96) * wc["nc"] * 512))})
+                    pmc_traffic("critic_dw1_kernel", -(-N * D // 48) * (-(-wc["nc"] // 8) * 8) * 512))})
     # (iv) V(row) of the same critic for every joint row of the buffer (the preprocessing's critic pass), one launch
     vout = torch.empty(rows, device=device)
     tot = graph_time(lambda: ops.critic_rows_forward(net.critic.flat.data, joint, H, out=vout), n_rep=5)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TSM_ABI_VERSION 2  /* 2: tsm_adam_step(lr_dev), tsm_ppo_cfg.value_group, tsm_ppo_actor_rows_update(opt_step_dev), *_segs */
+#define TSM_ABI_VERSION 3  /* 3: tsm_slab_seg.frag_image, tsm_critic_rows_grad_*(w1_image), tsm_kernel_option_* */
 
 enum {
     TSM_OK = 0,
@@ -302,9 +302,14 @@ int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t
 typedef struct tsm_slab_seg {
     const float *slabs;
     int64_t offset, n, stride;
-    int32_t n_slab, _pad;
+    int32_t n_slab;
+    int32_t frag_k1;        /* with frag_image: the segment is a row-major [128][frag_k1] first-layer weight matrix */
     const float *scale_dev; /* nullable device f32[1]: the segment's summed gradient is multiplied by it (a loss whose
                                gradient is a device-side scalar times a sum, e.g. CTDEPolicy's actor loss, ctde.py:185) */
+    float *frag_image;      /* nullable: the updated parameters are ALSO stored in the fragment order the one-launch critic
+                               kernels load with coalesced 16-B loads (tsm_critic_rows_w1_image: same layout), so the
+                               next gradient step need not gather W1 through 64-B pieces of 1.5 KB rows */
+    int32_t frag_kj, _pad;  /* k-groups of 16 per image row: tsm_critic_rows_w1_image_kj(frag_k1) */
 } tsm_slab_seg;
 int tsm_reduce_slabs_segs(const tsm_slab_seg *segs_host, int32_t n_seg, int64_t n, double scale, float *out,
                           void *stream);
@@ -607,14 +612,22 @@ int tsm_critic_rows_forward(const float *critic_params, int32_t in_dim, int32_t 
  *       w1_slabs_out [n_chunks][128 in_dim], n_chunks = tsm_critic_rows_dw1_chunks(Mr, in_dim) partial sums over row chunks.
  *     Row i of the minibatch is rows[i], else (tm_T > 0) store row (i % tm_T) * tm_E + i / tm_T, else first_row + i.
  * The optimizer takes both slab arrays as segments (tsm_adam_step_segs: W1 at offset 0, the rest at offset 128 in_dim).
- * critic_params: w0[H][in_dim] b0 w1[H][H] b1 w2[n_out][H] b2[n_out], H == 128, in_dim <= 384 (a multiple of 4 above 64). */
+ * critic_params: w0[H][in_dim] b0 w1[H][H] b1 w2[n_out][H] b2[n_out], H == 128, in_dim <= 384 (a multiple of 4 above 64).
+ * w1_image (nullable): w0 in the kernels' FRAGMENT ORDER, [8 waves][kj][64 lanes][4] floats with element (w, j, lane, i) =
+ * w0[16 w + lane % 16][16 j + 4 (lane / 16) + i] (zero where the column is >= in_dim), kj = tsm_critic_rows_w1_image_kj(in_dim):
+ * every wave then loads its share with 1 KB-coalesced instructions instead of gathering 64-B pieces of sixteen 1.5 KB rows
+ * (3.8 us of a 10 us prologue at in_dim = 384).  tsm_critic_rows_w1_image builds it from w0; tsm_adam_step_segs keeps it in
+ * step with the parameters (tsm_slab_seg.frag_image).  It must hold the SAME values as critic_params' w0; NULL = gather. */
 int64_t tsm_critic_rows_param_count(int32_t in_dim, int32_t hidden, int32_t n_out);
+int tsm_critic_rows_w1_image_kj(int32_t in_dim);
+int64_t tsm_critic_rows_w1_image_elems(int32_t in_dim);
+int tsm_critic_rows_w1_image(const float *w0, int32_t in_dim, float *image_out, void *stream);
 int tsm_critic_rows_grad_grid(int64_t Mr, int32_t td);
-int tsm_critic_rows_grad_ppo(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_agent,
+int tsm_critic_rows_grad_ppo(const float *critic_params, const float *w1_image, int32_t in_dim, int32_t hidden, int32_t n_agent,
                              const float *obs_rows, const float *returns, const float *v_s_old, const int64_t *rows,
                              int64_t first_row, int64_t Mr, const tsm_ppo_cfg *cfg, int32_t n_blocks, float *dh1_out,
                              float *rest_slabs_out, double *loss_partial_out, void *stream);
-int tsm_critic_rows_grad_td(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_out,
+int tsm_critic_rows_grad_td(const float *critic_params, const float *w1_image, int32_t in_dim, int32_t hidden, int32_t n_out,
                             const float *joint_rows, int64_t T, int64_t E, const float *rew, const uint8_t *terminated,
                             int64_t scalar_stride, int64_t scalar_offset, const float *v_last, const float *v_next_full,
                             const int32_t *use_full, double gamma, int32_t n_blocks, float *dh1_out,

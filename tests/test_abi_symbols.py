@@ -29,11 +29,11 @@ def test_abi_version_and_sizes(lib):
     import re
 
     hdr = int(re.search(r"#define\s+TSM_ABI_VERSION\s+(\d+)", open(_abi.HEADER_PATH).read()).group(1))
-    assert lib.tsm_abi_version() == hdr == _abi.ABI_VERSION == 2
+    assert lib.tsm_abi_version() == hdr == _abi.ABI_VERSION == 3
     # ctypes mirrors of the header's structs keep their layout
     import ctypes
 
-    assert ctypes.sizeof(_abi.tsm_slab_seg) == 48 and ctypes.sizeof(_abi.tsm_ppo_cfg) == 48
+    assert ctypes.sizeof(_abi.tsm_slab_seg) == 64 and ctypes.sizeof(_abi.tsm_ppo_cfg) == 48
     assert lib.tsm_vrb_state_bytes(4, 1) == (6 * 4 + 4 + 1) * 8
     assert lib.tsm_vrb_state_bytes(8, 3) == (6 * 8 + 24 + 1) * 8
     assert lib.tsm_ppo_loss_partial_elems(0) == 0

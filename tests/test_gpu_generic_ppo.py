@@ -459,6 +459,49 @@ def test_critic_rows_kernel_matches_float64_autograd(D, N, Mr, vclip, gen):
     assert torch.equal(slabs, run()[2])  # deterministic
 
 
+@pytest.mark.parametrize("K1,Mr", [(384, 8192), (384, 77), (96, 1000), (72, 300), (48, 64), (18, 50)])
+def test_critic_step_from_the_fragment_image_is_bit_identical_and_adam_keeps_the_image(K1, Mr):
+    """The critic gradient step may take its first-layer weights from a FRAGMENT-ORDER copy (`ops.critic_w1_image`: coalesced
+    16-B loads instead of a gather through sixteen 1.5 KB rows per 16-lane group; include/tsmarl.h).  Same values, same
+    arithmetic: every output of the step is bit-identical to the gather's; and the segmented Adam launch that consumes the
+    step's slabs leaves the image equal to one rebuilt from the updated flat vector (with and without a gradient-norm clip),
+    three steps in a row, for widths with and without zero-padded k-groups."""
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.utils.net import FlatMLP
+
+    H, N = 128, 1
+    rng = np.random.default_rng(K1 + Mr)
+    f = FlatMLP([K1, H, H, 1], device=DEV, seed=5)
+    d = lambda x, dt=None: torch.from_numpy(np.ascontiguousarray(x)).to(DEV, dt)  # noqa: E731
+    obs, ret = d(rng.standard_normal((Mr + 9, K1)).astype(np.float32)), d(rng.standard_normal(Mr + 9).astype(np.float32))
+    rows = d(rng.permutation(Mr + 9)[:Mr])
+    cfg = ops.make_ppo_cfg()
+    img = ops.critic_w1_image(f.flat.data, K1)
+    kj = ops.call("tsm_critic_rows_w1_image_kj", K1)
+    assert img.numel() == H * 16 * kj
+    # the layout the header documents: element (w, j, lane, i) = w0[16 w + lane % 16][16 j + 4 (lane / 16) + i], zero pads
+    w0 = f.flat.data[:H * K1].view(H, K1).cpu().numpy()
+    pad = np.zeros((H, 16 * kj), np.float32)
+    pad[:, :K1] = w0
+    want = pad.reshape(8, 16, kj, 4, 4).transpose(0, 2, 3, 1, 4)  # [w][o16][j][kq][i] -> [w][j][kq][o16][i]
+    assert np.array_equal(img.cpu().numpy().reshape(8, kj, 4, 16, 4), want)
+    nW1 = H * K1
+    for clip in (None, 0.5):
+        p = f.flat.data.clone()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        im = ops.critic_w1_image(p, K1)
+        for step in range(3):
+            a = [t.clone() for t in ops.critic_rows_grad_ppo(p, obs, ret, cfg, N, H, rows=rows)]
+            ws: dict = {}
+            b = ops.critic_rows_grad_ppo(p, obs, ret, cfg, N, H, rows=rows, ws=ws, w1_image=im)
+            wsb = next(iter(ws.values()))
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+            ops.adam_step_segs(p, [(b[0], 0, nW1, None, im), (b[1], nW1, p.numel() - nW1)], m, v, step + 1, lr=1e-2,
+                               max_grad_norm=clip)
+            assert torch.equal(im, ops.critic_w1_image(p, K1)), (clip, step)
+            assert wsb["dh1"].shape == (Mr, H)
+
+
 @pytest.mark.parametrize("glob,hidden,max_cycles,T,graph", [
     (True, (128, 128), 10, 10, True),    # aligned: episodes end at the last slot only -> the full pass is skipped
     (True, (128, 128), 7, 10, True),     # an episode ends mid-buffer -> device flag -> the full pass runs after all

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtsmarl_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tsmarl.h")
 
-ABI_VERSION = 2  # include/tsmarl.h TSM_ABI_VERSION: bumped whenever a signature or a struct layout changes
+ABI_VERSION = 3  # include/tsmarl.h TSM_ABI_VERSION: bumped whenever a signature or a struct layout changes
 TSM_OK, TSM_ERR_INVALID, TSM_ERR_HIP, TSM_ERR_MALFORMED_BUFFER, TSM_ERR_UNSUPPORTED = range(5)
 
 
@@ -35,7 +35,8 @@ class tsm_ppo_cfg(C.Structure):
 
 class tsm_slab_seg(C.Structure):
     _fields_ = [("slabs", C.c_void_p), ("offset", C.c_int64), ("n", C.c_int64), ("stride", C.c_int64),
-                ("n_slab", C.c_int32), ("_pad", C.c_int32), ("scale_dev", C.c_void_p)]
+                ("n_slab", C.c_int32), ("frag_k1", C.c_int32), ("scale_dev", C.c_void_p), ("frag_image", C.c_void_p),
+                ("frag_kj", C.c_int32), ("_pad", C.c_int32)]
 
 
 class tsm_mpe_cfg(C.Structure):
@@ -182,8 +183,11 @@ SIGNATURES = {
     "tsm_critic_rows_forward": (_int, [_p, _i32, _i32, _i32, _p, _p, _i64, _i64, _p, _p, _p]),
     "tsm_critic_rows_param_count": (_i64, [_i32, _i32, _i32]),
     "tsm_critic_rows_grad_grid": (_int, [_i64, _i32]),
-    "tsm_critic_rows_grad_ppo": (_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i64, C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p]),
-    "tsm_critic_rows_grad_td": (_int, [_p, _i32, _i32, _i32, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _p, _f64, _i32, _p, _p,
+    "tsm_critic_rows_w1_image_kj": (_int, [_i32]),
+    "tsm_critic_rows_w1_image_elems": (_i64, [_i32]),
+    "tsm_critic_rows_w1_image": (_int, [_p, _i32, _p, _p]),
+    "tsm_critic_rows_grad_ppo": (_int, [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i64, C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p]),
+    "tsm_critic_rows_grad_td": (_int, [_p, _p, _i32, _i32, _i32, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _p, _f64, _i32, _p, _p,
                                        _p, _p]),
     "tsm_critic_rows_dw1_chunks": (_int, [_i64, _i32]),
     "tsm_ctde_finalize": (_int, [_p, _i32, _p, _i32, _i64, _p, _p, _p]),
@@ -204,7 +208,7 @@ SIGNATURES = {
                                     C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p, _p]),
 }
 
-_NO_STATUS = {"tsm_p2p_ipc_handle_bytes", "tsm_p2p_failed", "tsm_critic_rows_forward_supported", "tsm_critic_rows_param_count", "tsm_critic_rows_grad_grid", "tsm_critic_rows_dw1_chunks", "tsm_ppo_critic_rows_supported", "tsm_ppo_critic_rows_param_count", "tsm_ppo_critic_rows_grid",
+_NO_STATUS = {"tsm_critic_rows_w1_image_kj", "tsm_critic_rows_w1_image_elems", "tsm_p2p_ipc_handle_bytes", "tsm_p2p_failed", "tsm_critic_rows_forward_supported", "tsm_critic_rows_param_count", "tsm_critic_rows_grad_grid", "tsm_critic_rows_dw1_chunks", "tsm_ppo_critic_rows_supported", "tsm_ppo_critic_rows_param_count", "tsm_ppo_critic_rows_grid",
               "tsm_ppo_actor_rows_supported", "tsm_ppo_actor_rows_param_count", "tsm_ppo_actor_rows_grid",
               "tsm_rms_update_work_elems", "tsm_ppo_adv_stats_work_elems", "tsm_abi_version", "tsm_last_error", "tsm_stream_abort_capture", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
               "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems",

@@ -82,6 +82,11 @@ class GenericPPO(PPO):
         if self.fused_values:
             ops.call("tsm_critic_rows_init", net.critic_obs_dim, net.critic.dims[1])  # (function attributes: before any capture)
             ops._critic_rows_ready.add((net.critic_obs_dim, net.critic.dims[1]))
+        # the critic's first-layer weights in the gradient kernel's fragment order (csrc/critic_train.hip): written by the
+        # segmented Adam launch of every step, read by the NEXT step of the same update (`_w1_img_ok`: cleared when an update
+        # begins -- its first step gathers from the flat vector, which is the source of truth)
+        self._w1_img = ops.critic_w1_image(net.critic.flat.data, net.critic_obs_dim) if self.critic_gen2 else None
+        self._w1_img_ok = False
         self.reuse_rollout_outputs = bool(reuse_rollout_outputs)
         # V(obs_next) of chained rows from V(obs) of the next slot instead of a second full critic pass (_next_values_chained)
         self.shift_next_values = bool(shift_next_values)
@@ -289,11 +294,13 @@ class GenericPPO(PPO):
         if crit_rows and self.critic_gen2:
             src, N_c = (pb["joint"], pb["n_agent"]) if rows is not None else (pb["obs"], 1)
             nW1 = net.critic.dims[1] * net.critic_obs_dim
+            img = self._w1_img if self._grad_sync is None else None  # (kept in step by the segmented Adam launch only)
             w1s, rest, _ = ops.critic_rows_grad_ppo(net.critic.flat.data, src, pb["ret"], self._cfg, N_c, net.critic.dims[1],
                                                     v_s_old=pb["v_s"] if self.value_clip else None,
                                                     rows=rows if rows is not None else idx, Mr=Mr,
-                                                    partial=partial[na * 4:(na + nv) * 4], ws=self._ws)
-            segs_c = [(w1s, P_a, nW1), (rest, P_a + nW1, P_c - nW1)]
+                                                    partial=partial[na * 4:(na + nv) * 4], ws=self._ws,
+                                                    w1_image=img if self._w1_img_ok else None)
+            segs_c = [(w1s, P_a, nW1, None, img), (rest, P_a + nW1, P_c - nW1)]
         elif crit_rows:
             src, N_c = (pb["joint"], pb["n_agent"]) if rows is not None else (pb["obs"], 1)
             ops.ppo_critic_rows_update(net.critic.flat.data, src, pb["ret"], self._cfg, N_c, net.critic.dims[1],
@@ -318,6 +325,7 @@ class GenericPPO(PPO):
         if self._grad_sync is None:
             ops.adam_step_segs(net.flat.data, segs, self.exp_avg, self.exp_avg_sq, self.opt_step,
                                max_grad_norm=self.max_grad_norm, work=self._adam_work, **hyper)
+            self._w1_img_ok = segs_c is not None and self._w1_img is not None
         else:
             ops.reduce_slabs_segs(segs, P_a + P_c, out=w["flat_g"], scale=1.0 / self._grad_sync.world)
             yield w["flat_g"]  # summed over the ranks by the driver, in place
@@ -394,6 +402,7 @@ class GenericPPO(PPO):
                 w["M_dev"] = torch.as_tensor([(e_ - s_) * unit for s_, e_ in bounds] * reps, dtype=torch.int64, device=dev)
 
             def body():
+                self._w1_img_ok = False  # (the parameters may have changed since the last step this object took)
                 if self.shuffle == "device":
                     ops.random_permutations(n_g, len(groups) * repeat, self.seed ^ 0x5DEECE66D, counter_dev=w["step_dev"],
                                             scale=N if per_agent else 1, group_size=repeat,
@@ -520,6 +529,7 @@ class GenericPPO(PPO):
         mb_start = torch.as_tensor([b[0] * unit for b in bounds] + [n * unit], dtype=torch.int64, device=dev)
         lane_of_row = torch.arange(N, dtype=torch.int64, device=dev).view(1, N)
         scal = []
+        self._w1_img_ok = False  # (the parameters may have changed since the last step this object took)
         for step in range(repeat):
             if self.recompute_adv and step > 0:
                 pb = dict(self._preprocess_batch(buffer, allow_stored=False), logp_old=pb["logp_old"])

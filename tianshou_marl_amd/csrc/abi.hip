@@ -84,8 +84,12 @@ TSM_EXPORT int tsm_stream_abort_capture(void *stream) {
 //                 (experimental, never the default)                              env TSM_SPLIT_BF16
 namespace {
 struct KernelOption { const char *name, *env; int value; bool resolved; };
-KernelOption g_opts[TSM_OPT_COUNT] = {{"actor_tile", "TSM_ACTOR_TILE", 0, false}, {"split_bf16", "TSM_SPLIT_BF16", 0, false}};
-bool opt_valid(int id, int v) { return id == TSM_OPT_ACTOR_TILE ? (v == 0 || v == 32 || v == 64) : (v == 0 || v == 1); }
+KernelOption g_opts[TSM_OPT_COUNT] = {{"actor_tile", "TSM_ACTOR_TILE", 0, false}, {"split_bf16", "TSM_SPLIT_BF16", 0, false},
+                                      {"dbg", "TSM_DBG", 0, false}};
+bool opt_valid(int id, int v) {
+    if (id == TSM_OPT_DBG) return v >= 0;   // diagnostics bit mask (tools/ only; kernels compute garbage under it)
+    return id == TSM_OPT_ACTOR_TILE ? (v == 0 || v == 32 || v == 64) : (v == 0 || v == 1);
+}
 }  // namespace
 
 int tsm_opt(int id) {

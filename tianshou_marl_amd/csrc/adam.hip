@@ -9,6 +9,11 @@
 //   m   = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2
 //   p  -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
 //
+// (Round 4, measured: 16-B slab loads -- four consecutive parameters per lane -- were built and dropped.  Slab rows start at
+// odd float offsets (23 429 / 17 025 parameters per slab), and a dwordx4 load that is not 16-B aligned runs at a quarter of
+// the rate: 26.1 us against 14.1 us for the C3 step's 54 MB of slabs; with strides padded to multiples of four it was
+// 12.6 against 13.6 us -- the launch moves 4.3 TB/s either way, so what shortens it is fewer slab bytes, not wider loads.)
+//
 // gfx950 mapping: the slab reduction is latency-bound (n ~ 11 k parameters, up to 256 slabs), so a
 // workgroup owns 64 parameters x 4 slab lanes: every wave reads 256-B coalesced rows of 64 parameters and
 // the 4 waves walk disjoint slab subsets with 8 loads in flight each; partial sums meet in LDS.
@@ -92,6 +97,14 @@ struct SegArgs {
     int32_t n_seg;
 };
 
+// Position of W1[o][k] (row-major [128][K1] segment, element il = o K1 + k) in the FRAGMENT IMAGE the one-launch critic
+// kernels stage with coalesced 16-B loads (csrc/critic_train.hip): [wave = o / 16][k-group j = k / 16][lane = 16 (k / 4 % 4)
+// + o % 16][k % 4] -- wave w's j-th load instruction reads 1 KB of consecutive bytes.
+__device__ __forceinline__ int64_t frag_image_index(int64_t il, int K1, int KJ) {
+    const int o = (int)(il / K1), k = (int)(il - (int64_t)o * K1);
+    return ((((int64_t)(o >> 4) * KJ + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (o & 15)) << 2) + (k & 3);
+}
+
 __device__ __forceinline__ int seg_of_block(const SegArgs &a, int blk) {
     int k = 0;
 #pragma unroll
@@ -152,7 +165,8 @@ __global__ __launch_bounds__(256) void adam_segs_kernel(float *__restrict__ p, S
         if (sg.scale_dev) g *= *sg.scale_dev;
     }
     if (sl != 0 || il >= sg.n) return;
-    adam_apply(p, m, v, i, g, lr_host, lr_dev, beta1d, beta2d, step_host, step_dev, eps, weight_decay);
+    const float pn = adam_apply(p, m, v, i, g, lr_host, lr_dev, beta1d, beta2d, step_host, step_dev, eps, weight_decay);
+    if (sg.frag_image) sg.frag_image[frag_image_index(il, sg.frag_k1, sg.frag_kj)] = pn;
 }
 
 int fill_segs(SegArgs &a, const tsm_slab_seg *segs, int32_t n_seg, int64_t n_total) {
@@ -163,6 +177,8 @@ int fill_segs(SegArgs &a, const tsm_slab_seg *segs, int32_t n_seg, int64_t n_tot
         const tsm_slab_seg &s = segs[k];
         // segments tile [0, n_total) in order: every parameter gets exactly one gradient
         if (!s.slabs || s.n < 1 || s.n_slab < 1 || s.stride < s.n || s.offset != covered) return -1;
+        // a fragment image is that of a [128][frag_k1] row-major weight matrix in k-groups of 16
+        if (s.frag_image && (s.frag_k1 < 1 || s.n != (int64_t)128 * s.frag_k1 || 16 * s.frag_kj < s.frag_k1)) return -1;
         a.seg[k] = s;
         a.first_blk[k] = (int32_t)blk;
         blk += ceil_div(s.n, kCols);

@@ -5,19 +5,22 @@
 //
 // Why a pass of its own: accumulated inside the per-tile kernel, every workgroup wrote a full 128 x K1 slab for a rank-32
 // update (196 KB x 256 workgroups = 50 MB per step at K1 = 384, read back by the optimizer).  Here workgroup (cb, rc) owns
-// the 128 x 96 block of columns [96 cb, 96 cb + 96) and sums over the row chunk rc in registers (6 accumulator tiles per wave:
-// wave w owns outputs [16 w, 16 w + 16)), so the reduction over ROWS happens on chip and only n_chunk partial slabs (64 at
-// 8192 rows) go to memory.  Sub-chunks of 64 rows are staged through LDS (dH1 [64][128], X [64][96]; row pitches = 16 mod 32
-// floats: the [k = row][lane = column] operand reads are bank-conflict free), the next sub-chunk's rows are in flight in
-// registers meanwhile, their ids one sub-chunk further ahead.
+// the 128 x 48 block of columns [48 cb, 48 cb + 48) and sums over the row chunk rc in registers (3 accumulator tiles per wave:
+// wave w owns outputs [16 w, 16 w + 16)), so the reduction over ROWS happens on chip and only n_chunk partial slabs (32 at
+// 8192 rows, K1 = 384) go to memory.  Sub-chunks of 64 rows are staged through LDS (dH1 [64][128], X [64][48]; row pitches =
+// 16 mod 32 floats: the [k = row][lane = column] operand reads are bank-conflict free), the next sub-chunk's rows are in
+// flight in registers meanwhile, their ids one sub-chunk further ahead.
+// Round 4 (tools/dbg/pair_time.py, 8192 rows of 384, launch alone back to back): 4 x 96 columns x 64 chunks 13.4 us; 8 x 48
+// columns x 32 chunks 13.6 us; the same x 64 chunks (two workgroups per CU) 12.9 us; 4 x 96 x 128 chunks 13.5 us -- the launch
+// is a latency chain (ids -> rows -> LDS -> 5.6 us of MFMA -> slab) that no split shortens, so the form with the FEWEST slab
+// bytes is the one kept: half the writes here and half the optimizer's reads of them (12.6 -> 6.3 MB each).
 #include "critic_rows_dev.h"
 
 namespace {
 
 constexpr int kSub = 64;       // rows per sub-chunk
-constexpr int kCB = 96;        // columns per workgroup (6 MFMA tiles)
 constexpr int kLdA = 144;      // dH1 rows in LDS (128 + 16): pitch = 16 mod 32
-constexpr int kLdB = 112;      // X rows in LDS (96 + 16)
+// NT = MFMA column tiles per workgroup: 6 (96 columns) or 3 (48 columns); X rows in LDS: 112 / 80 floats (pitch = 16 mod 32)
 
 struct Dw1Args {
     const float *dh1;        // [Mr][128]
@@ -35,11 +38,13 @@ __device__ __forceinline__ int64_t dw1_row_of(const Dw1Args &g, int64_t i) {
     return g.rows ? g.rows[ic] : (g.tm_T > 0 ? (ic % g.tm_T) * g.tm_E + ic / g.tm_T : g.first_row + ic);
 }
 
-template <bool VEC>
+template <bool VEC, int NT>
 __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
+    constexpr int kCB = 16 * NT, kLdB = NT == 6 ? 112 : 80, CPRB = 4 * NT;   // CPRB: 16-B chunks per X row of the block
+    constexpr int NB = (kSub * CPRB + kThreads - 1) / kThreads;     // X chunks per thread (3 at NT = 6, 2 at NT = 3)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *sA = lds, *sB = lds + kSub * kLdA;
-    int64_t *rid = reinterpret_cast<int64_t *>(lds + kSub * (kLdA + kLdB));
+    int64_t *rid = reinterpret_cast<int64_t *>(lds + kSub * (kLdA + 112));   // (one LDS size for both forms: 112 = the wider X pitch)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
     // XCD-aware block -> (column block, row chunk) map: workgroups are dealt round-robin over the 8 XCDs (each with an L2 of its
     // own), and the ncb workgroups of one row chunk read the SAME dH1 rows -- give them ids that differ by multiples of 8, so
@@ -51,12 +56,12 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
     const int64_t i_lo = (int64_t)rc * g.RC, i_hi = i_lo + g.RC < g.Mr ? i_lo + g.RC : g.Mr;
     const int n_sub = (int)((i_hi - i_lo + kSub - 1) / kSub);
 
-    f4 acc[6];
+    f4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 6; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
 
-    // staging: dH1 sub-chunk = 64 rows x 32 chunks of 16 B (4 per thread), X block = 64 rows x 24 chunks (3 per thread)
-    f4 ra[4], rb[3];
+    // staging: dH1 sub-chunk = 64 rows x 32 chunks of 16 B (4 per thread), X block = 64 rows x 4 NT chunks (NB per thread)
+    f4 ra[4], rb[NB];
     auto fetch = [&](int s) {
         const int64_t i0 = i_lo + (int64_t)s * kSub;
 #pragma unroll
@@ -68,11 +73,11 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
             ra[u] = i < i_hi ? f4{v.x, v.y, v.z, v.w} : f4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int q = tid + kThreads * u, r = q / 24, c = q - r * 24;
+        for (int u = 0; u < NB; ++u) {
+            const int q = tid + kThreads * u, r = (q / CPRB) & (kSub - 1), c = q % CPRB;
             const int64_t i = i0 + r;
             const int k = c0 + 4 * c;
-            const bool ok = i < i_hi && k < K1;
+            const bool ok = q < kSub * CPRB && i < i_hi && k < K1;
             const int64_t row = rid[r];
             if constexpr (VEC) {
                 const int kc = k < K1 ? k : K1 - 4;
@@ -94,9 +99,9 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
             *reinterpret_cast<f4 *>(sA + r * kLdA + 4 * c) = ra[u];
         }
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int q = tid + kThreads * u, r = q / 24, c = q - r * 24;
-            *reinterpret_cast<f4 *>(sB + r * kLdB + 4 * c) = rb[u];
+        for (int u = 0; u < NB; ++u) {
+            const int q = tid + kThreads * u, r = q / CPRB, c = q - r * CPRB;
+            if (q < kSub * CPRB) *reinterpret_cast<f4 *>(sB + r * kLdB + 4 * c) = rb[u];
         }
     };
 
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
         for (int r0 = 0; r0 < kSub; r0 += 4) {
             const float av = pa[r0 * kLdA];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) acc[t] = mfma4(av, pb[r0 * kLdB + 16 * t], acc[t]);
+            for (int t = 0; t < NT; ++t) acc[t] = mfma4(av, pb[r0 * kLdB + 16 * t], acc[t]);
         }
         __syncthreads();
     }
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
     for (int r = 0; r < 4; ++r) {
         const int o = 16 * w + kq * 4 + r;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
+        for (int t = 0; t < NT; ++t) {
             const int k = c0 + 16 * t + c16;
             if (k < K1) __builtin_nontemporal_store(acc[t][r], slab + (size_t)o * K1 + k);
         }
@@ -142,16 +147,17 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
 
 }  // namespace
 
-constexpr size_t kDw1Lds = (size_t)kSub * (kLdA + kLdB) * sizeof(float) + kSub * sizeof(int64_t);  // 66 048 B
+constexpr int kDw1Nt = 3;  // column tiles per workgroup (48 columns)
+constexpr size_t kDw1Lds = (size_t)kSub * (kLdA + 112) * sizeof(float) + kSub * sizeof(int64_t);  // 66 048 B
 
 // one-time function attributes (dynamic LDS above 64 KB): outside any stream capture (tsm_critic_rows_init)
 int tsm_critic_dw1_init() {
     static bool done = false;
     if (!done) {
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_dw1_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDw1Lds));
-        TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_dw1_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDw1Lds));
+#define DW1_ATTR(V, T) TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_dw1_kernel<V, T>), \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDw1Lds))
+        DW1_ATTR(true, kDw1Nt); DW1_ATTR(false, kDw1Nt);
+#undef DW1_ATTR
         done = true;
     }
     return TSM_OK;
@@ -159,9 +165,12 @@ int tsm_critic_dw1_init() {
 
 // rows per chunk / number of chunks (= partial slabs of dW1) for Mr rows: a full chip of workgroups, chunks of whole
 // 64-row sub-chunks
+static int dw1_nt() { return kDw1Nt; }
+static int dw1_per_cu() { return 1; }
+
 static void dw1_plan(int64_t Mr, int32_t in_dim, int64_t *RC, int *n_chunk) {
-    const int ncb = (int)ceil_div(in_dim, kCB);
-    int64_t want = n_cu_dev() / ncb;
+    const int ncb = (int)ceil_div(in_dim, 16 * dw1_nt());
+    int64_t want = (int64_t)n_cu_dev() * dw1_per_cu() / ncb;
     if (want < 1) want = 1;
     const int64_t subs = ceil_div(Mr, kSub);
     if (want > subs) want = subs;
@@ -195,12 +204,13 @@ TSM_EXPORT int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int3
     Dw1Args g{};
     g.dh1 = dh1; g.obs = obs_rows; g.rows = rows; g.first_row = first_row; g.Mr = Mr; g.tm_T = tm_T; g.tm_E = tm_E;
     g.K1 = in_dim; g.RC = RC; g.slabs = w1_slabs_out;
-    g.ncb = (int)ceil_div(in_dim, kCB); g.n_chunk = n;
+    const int nt = dw1_nt();
+    g.ncb = (int)ceil_div(in_dim, 16 * nt); g.n_chunk = n;
     const dim3 grid((unsigned)(g.ncb * ceil_div(n, 8) * 8));
-    if ((in_dim & 3) == 0)
-        hipLaunchKernelGGL(critic_dw1_kernel<true>, grid, dim3(kThreads), kDw1Lds, tsm_stream(stream), g);
-    else
-        hipLaunchKernelGGL(critic_dw1_kernel<false>, grid, dim3(kThreads), kDw1Lds, tsm_stream(stream), g);
+    const bool vec = (in_dim & 3) == 0;
+#define DW1_LAUNCH(V, T) hipLaunchKernelGGL((critic_dw1_kernel<V, T>), grid, dim3(kThreads), kDw1Lds, tsm_stream(stream), g)
+    if (vec) DW1_LAUNCH(true, kDw1Nt); else DW1_LAUNCH(false, kDw1Nt);
+#undef DW1_LAUNCH
     TSM_LAUNCH_CHECK();
     return TSM_OK;
 }

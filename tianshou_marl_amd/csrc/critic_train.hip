@@ -32,7 +32,7 @@ namespace {
 constexpr int kLdo = 18;
 
 struct TrainLay {  // LDS layout in floats
-    int ldx, W2, W3, X, H1, H2, B1, B2, B3, Q, V, DV, RID, RIDC, RED, total;
+    int ldx, W2, W3, X, H1, H2, B1, B2, B3, Q, V, DV, RID, RIDC, RED, PV, total;
     __host__ __device__ explicit TrainLay(int KJ) {
         ldx = ((16 * KJ + 63) / 64) * 64;
         int o = 0;
@@ -49,18 +49,21 @@ struct TrainLay {  // LDS layout in floats
         DV = o; o += kRows * 16;        // LOSS 0: d loss / d value of a row's agents (N <= 16); final reduction scratch
         RID = o; o += 4 * kRows;        // row ids of the tile being FETCHED (int64), two buffers by tile parity
         RIDC = o; o += 2 * kRows;       // row ids of the tile being COMPUTED (int64)
+        PV = Q;                         // LOSS 0: the eight waves' partial sums of V(row) [8][32] (layer 3 folded into layer 2);
+                                        // read by the loss head BEFORE the barrier behind which it writes d loss / d value to Q
         RED = DV;
         total = o;
     }
     __device__ void launder() {         // (critic_rows_dev.h: opaque_s)
         W2 = opaque_s(W2); W3 = opaque_s(W3); X = opaque_s(X); H1 = opaque_s(H1); H2 = opaque_s(H2); B1 = opaque_s(B1);
         B2 = opaque_s(B2); B3 = opaque_s(B3); Q = opaque_s(Q); V = opaque_s(V); DV = opaque_s(DV); RID = opaque_s(RID);
-        RIDC = opaque_s(RIDC); RED = DV;
+        RIDC = opaque_s(RIDC); PV = Q; RED = DV;
     }
 };
 
 struct TrainArgs {
     const float *P;          // critic parameters: w0[H][K1] b0[H] w1[H][H] b1[H] w2[n_out][H] b2[n_out]
+    const float *w1_img;     // nullable: w0 in fragment order [8 waves][KJ][64 lanes][4] (tsm_critic_rows_w1_image)
     const float *obs;        // rows [n][K1]
     const int64_t *rows;     // row ids of the minibatch (nullable)
     int64_t first_row, Mr;   // Mr: rows in the minibatch
@@ -132,12 +135,22 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
             id3 = row_of<LOSS>(g, (tile + 3 * gs) * OWN + tid);
         }
     }
-    // ---- this wave's fragment of W1, once, into registers ----
+    // ---- this wave's fragment of W1, once, into registers: from the fragment image when there is one (1 KB of consecutive
+    // bytes per wave instruction; the gather from the row-major matrix touches sixteen 1.5 KB rows per 16-lane group and
+    // costs 3.8 us more at K1 = 384: tools/dbg/critic_prologue.py) ----
     f4 w1f[KJ];
+    if (g.w1_img) {
 #pragma unroll
-    for (int j = 0; j < KJ; ++j) w1f[j] = load_w1_frag<VEC>(g.P + (size_t)col * K1, 16 * j + 4 * kq, K1);
-    float4 w2q[8];            // W2 requested here, stored to LDS after the first tile's rows have been requested too
-    w2_load(w2q, g.P + oW2);
+        for (int j = 0; j < KJ; ++j) {
+            const float4 q = reinterpret_cast<const float4 *>(g.w1_img)[(size_t)(w * KJ + j) * 64 + lane];
+            w1f[j] = f4{q.x, q.y, q.z, q.w};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) w1f[j] = load_w1_frag<VEC>(g.P + (size_t)col * K1, 16 * j + 4 * kq, K1);
+    }
+    float4 w2q[8];            // W2 requested here, stored to LDS after the first tile's rows have been requested too (requesting
+    w2_load(w2q, g.P + oW2);  // it BEHIND the rows was measured 1 us slower: the LDS stores then wait for the rows as well)
 
     // ---- staging of a tile (as csrc/critic_rows.hip): thread -> chunks q = tid + 512 u of the 32 x (4 KJ) chunk grid ----
     constexpr int CPR = 4 * KJ;
@@ -180,6 +193,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
 #pragma unroll
     for (int i = 0; i < 8; ++i) gW2[i] = f4{0.f, 0.f, 0.f, 0.f};
     gW3 = f4{0.f, 0.f, 0.f, 0.f};
+    float gW3s = 0.f;          // LOSS 0 (one output): dW3[col] over this lane's rows (folded over kq at the end)
     // db2 / db3 = column sums of dH2 / dQ over the tile's rows as per-thread PARTIAL sums, folded after the last tile (a serial
     // loop of two waves / 16 threads over the 32 rows held the other waves at the next barrier): thread (c = tid & 127,
     // q = tid >> 7) sums rows [8 q, 8 q + 8) of dH2 column c; thread (c = tid & 15, q = tid >> 4 < 16) rows 2 q, 2 q + 1 of dQ column c
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     __syncthreads();          // every thread has read RID
     if (tid < kRows) rid[tid] = id1;
     __syncthreads();
-    fetch_tile(tile + gs, 0);
+    if (tile + gs < n_tiles) fetch_tile(tile + gs, 0);   // (uniform: a workgroup with one tile -- the PPO minibatch -- skips it)
     __syncthreads();          // (RID buffer 0 is rewritten at the top of the loop)
 
     int it = 0;
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         }
         __syncthreads();  // (A) H1 complete; every wave is done with X; RID / RIDC published
         TSTAMP(1);
-        commit_tile();                // the next tile's rows: requested at the end of the previous tile, they flew during L1
+        if (tile + gs < n_tiles) commit_tile();   // the next tile's rows: requested at the end of the previous tile, they flew during L1
         if constexpr (LOSS == 0) {
             if (tid < kRows) id3 = row_of<LOSS>(g, (tile + 4 * gs) * OWN + tid);  // (three tiles ahead)
         }
@@ -264,6 +278,10 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
             }
         }
         // ---- P2: H2 = relu(H1 W2^T + b2) ----
+        // LOSS 0 (n_out == 1): layer 3 is a 128-long dot product per row -- folded into this epilogue exactly as
+        // csrc/critic_rows.hip does it (the same additions in the same order: V here is bit-identical to tsm_critic_rows_forward's),
+        // H2 stays in REGISTERS across the loss head and only dH2 goes to LDS: no layer-3 MFMA phases, three barriers less
+        float h2r[2][4];
         {
             f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
             const float *pa = lds + ly.H1 + c16 * kLdh + kq;
@@ -275,25 +293,39 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
                 acc[1] = mfma4(pa[16 * kLdh + k0], bv, acc[1]);
             }
             const float bb = lds[ly.B2 + col];
+            if constexpr (LOSS == 0) {
+                const float w3c = lds[ly.W3 + col];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lds[ly.H2 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
+                    for (int r = 0; r < 4; ++r) {
+                        h2r[mt][r] = fmaxf(acc[mt][r] + bb, 0.f);
+                        const float sv = row16_sum(h2r[mt][r] * w3c);  // over this wave's 16 columns
+                        if (c16 == 0) lds[ly.PV + w * kRows + mt * 16 + kq * 4 + r] = sv;
+                    }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lds[ly.H2 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
+            }
         }
         __syncthreads();
         TSTAMP(2);
-        // ---- P3: Q = H2 W3^T + b3 (n_out padded to 16): waves 0 / 1 take the two row halves ----
-        if (w < 2) {
-            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-            const float *a = lds + ly.H2 + (16 * w + c16) * kLdh + kq;
-            const float *b = lds + ly.W3 + c16 * kLdh + kq;
+        // ---- P3 (LOSS 1): Q = H2 W3^T + b3 (n_out padded to 16): waves 0 / 1 take the two row halves ----
+        if constexpr (LOSS != 0) {
+            if (w < 2) {
+                f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+                const float *a = lds + ly.H2 + (16 * w + c16) * kLdh + kq;
+                const float *b = lds + ly.W3 + c16 * kLdh + kq;
 #pragma unroll 8
-            for (int k0 = 0; k0 < kH; k0 += 4) acc = mfma4(a[k0], b[k0], acc);
-            const float bb = lds[ly.B3 + c16];
+                for (int k0 = 0; k0 < kH; k0 += 4) acc = mfma4(a[k0], b[k0], acc);
+                const float bb = lds[ly.B3 + c16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds[ly.Q + (16 * w + kq * 4 + r) * kLdo + c16] = acc[r] + bb;
+                for (int r = 0; r < 4; ++r) lds[ly.Q + (16 * w + kq * 4 + r) * kLdo + c16] = acc[r] + bb;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         TSTAMP(3);
         // ---- P4: loss head: Q -> d loss / d Q in place ----
         if constexpr (LOSS == 0) {
@@ -303,7 +335,11 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
                 const int64_t i = tile * OWN + r;
                 float dv = 0.f;
                 if (i < g.Mr) {
-                    const float v = lds[ly.Q + r * kLdo], ret = pf_a;
+                    float v = lds[ly.PV + r];
+#pragma unroll
+                    for (int ww = 1; ww < 8; ++ww) v += lds[ly.PV + ww * kRows + r];
+                    v += lds[ly.B3];
+                    const float ret = pf_a;
                     float vf, g_v;
                     if (g.value_clip) {
                         const float vs = pf_b;
@@ -329,7 +365,8 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
             if (tid < kRows) {  // d loss / d value of the row = sum over its agents, in agent order
                 float sacc = 0.f;
                 for (int a = 0; a < N; ++a) sacc += lds[ly.DV + tid * 16 + a];
-                lds[ly.Q + tid * kLdo] = sacc;   // (columns 1..15 hold exact zeros: W3 / b3 pads)
+                lds[ly.Q + tid * kLdo] = sacc;
+                gB3 += sacc;                     // db3 = sum of the rows' d loss / d value (folded over the 32 threads at the end)
             }
         } else {
             // values = Q.mean(1) (ctde.py:154-157: sequential f32 sum / n); td target from the NEXT row's value
@@ -359,35 +396,50 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         __syncthreads();
         TSTAMP(4);
         // ---- P5: dW3 += dQ^T H2 ; db3 ; dH2 = (dQ W3) * relu'(H2) ----
-        {
-            const float *a = lds + ly.Q + kq * kLdo + c16;             // A[i = out][k = row]
-            const float *b = lds + ly.H2 + kq * kLdh + col;            // B[k = row][j = hidden col]
+        if constexpr (LOSS == 0) {
+            // one output: dH2[row][col] = dq[row] w3[col] where H2 > 0 and dW3[col] += dq[row] H2[row][col], from the
+            // registers that still hold this lane's eight H2 values
+            const float w3c = lds[ly.W3 + col];
 #pragma unroll
-            for (int r0 = 0; r0 < kRows; r0 += 4) gW3 = mfma4(a[r0 * kLdo], b[r0 * kLdh], gW3);
-        }
-        if (tid < 256) {
-            const float *q = lds + ly.Q + 2 * (tid >> 4) * kLdo + (tid & 15);
-            gB3 += q[0] + q[kLdo];
-        }
-        f4 d2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        {
-            const float *a = lds + ly.Q + c16 * kLdo + kq;             // A[i = row][k = out]
-            const float *b = lds + ly.W3 + kq * kLdh + col;            // B[k = out][j = hidden col]
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int k0 = 0; k0 < 16; k0 += 4) {
-                const float bv = b[k0 * kLdh];
-                d2[0] = mfma4(a[k0], bv, d2[0]);
-                d2[1] = mfma4(a[16 * kLdo + k0], bv, d2[1]);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mt * 16 + kq * 4 + r;
+                    const float dq = lds[ly.Q + row * kLdo];
+                    gW3s += dq * h2r[mt][r];
+                    lds[ly.H2 + row * kLdh + col] = h2r[mt][r] > 0.f ? dq * w3c : 0.f;
+                }
+        } else {
+            {
+                const float *a = lds + ly.Q + kq * kLdo + c16;             // A[i = out][k = row]
+                const float *b = lds + ly.H2 + kq * kLdh + col;            // B[k = row][j = hidden col]
+#pragma unroll
+                for (int r0 = 0; r0 < kRows; r0 += 4) gW3 = mfma4(a[r0 * kLdo], b[r0 * kLdh], gW3);
             }
-        }
-        __syncthreads();  // every wave has read H2 for dW3
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float *p = lds + ly.H2 + (mt * 16 + kq * 4 + r) * kLdh + col;
-                *p = *p > 0.f ? d2[mt][r] : 0.f;
+            if (tid < 256) {
+                const float *q = lds + ly.Q + 2 * (tid >> 4) * kLdo + (tid & 15);
+                gB3 += q[0] + q[kLdo];
             }
+            f4 d2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            {
+                const float *a = lds + ly.Q + c16 * kLdo + kq;             // A[i = row][k = out]
+                const float *b = lds + ly.W3 + kq * kLdh + col;            // B[k = out][j = hidden col]
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += 4) {
+                    const float bv = b[k0 * kLdh];
+                    d2[0] = mfma4(a[k0], bv, d2[0]);
+                    d2[1] = mfma4(a[16 * kLdo + k0], bv, d2[1]);
+                }
+            }
+            __syncthreads();  // every wave has read H2 for dW3
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float *p = lds + ly.H2 + (mt * 16 + kq * 4 + r) * kLdh + col;
+                    *p = *p > 0.f ? d2[mt][r] : 0.f;
+                }
+        }
         __syncthreads();
         TSTAMP(5);
         // ---- P6: dW2 += dH2^T H1 ; db2 ; dH1 = (dH2 W2) * relu'(H1) -> global (kernel B), db1 ----
@@ -433,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         // (requested HERE and not a phase earlier: 24 registers less across the backward phases)
         // (RID buffer it & 1: written at the top of this iteration, published by its barrier (A); the next iteration writes
         // the other buffer, so these reads need no barrier behind them)
-        fetch_tile(tile + 2 * gs, it & 1);
+        if (tile + 2 * gs < n_tiles) fetch_tile(tile + 2 * gs, it & 1);
         TSTAMP(6);
     }
 
@@ -449,8 +501,15 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         const int o = 16 * w + kq * 4 + r;
 #pragma unroll
         for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + sW2 + o * kH + 16 * ti + c16);
-        const int a = kq * 4 + r;
-        if (a < n_out) __builtin_nontemporal_store(gW3[r], slab + sW3 + a * kH + 16 * w + c16);
+        if constexpr (LOSS != 0) {
+            const int a = kq * 4 + r;
+            if (a < n_out) __builtin_nontemporal_store(gW3[r], slab + sW3 + a * kH + 16 * w + c16);
+        }
+    }
+    if constexpr (LOSS == 0) {
+        gW3s += __shfl_xor(gW3s, 16, 64);   // fold the four row groups (kq) of a column, as db1
+        gW3s += __shfl_xor(gW3s, 32, 64);
+        if (kq == 0) __builtin_nontemporal_store(gW3s, slab + sW3 + col);
     }
     {   // fold the bias partials (fixed order) through the idle H1 region
         float *sc = lds + ly.H1;   // [4][128] db2 | [16][16] db3
@@ -460,7 +519,11 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         if (tid < 128) __builtin_nontemporal_store((sc[tid] + sc[128 + tid]) + (sc[256 + tid] + sc[384 + tid]), slab + sB2 + tid);
         else if (tid >= 256 && tid < 256 + n_out) {
             float t = 0.f;
-            for (int k = 0; k < 16; ++k) t += sc[512 + 16 * k + (tid - 256)];
+            if constexpr (LOSS == 0) {   // (one output: threads 0..31 hold the rows' partial sums)
+                for (int k = 0; k < kRows; ++k) t += sc[512 + k];
+            } else {
+                for (int k = 0; k < 16; ++k) t += sc[512 + 16 * k + (tid - 256)];
+            }
             __builtin_nontemporal_store(t, slab + sB3 + tid - 256);
         }
     }
@@ -559,7 +622,34 @@ TSM_EXPORT int tsm_critic_rows_grad_grid(int64_t Mr, int32_t td) {
     return (int)(tiles < cu ? tiles : cu);
 }
 
-TSM_EXPORT int tsm_critic_rows_grad_ppo(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_agent,
+// ---- W1 in fragment order (see TrainArgs::w1_img) ----
+namespace {
+__global__ void w1_image_kernel(const float *__restrict__ w1, int K1, int KJ, float *__restrict__ img) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // image element [w][j][lane][i]
+    if (e >= (int64_t)8 * KJ * 64 * 4) return;
+    const int i = (int)(e & 3), lane = (int)((e >> 2) & 63), wj = (int)(e >> 8), j = wj % KJ, w = wj / KJ;
+    const int o = 16 * w + (lane & 15), k = 16 * j + 4 * (lane >> 4) + i;
+    img[e] = k < K1 ? w1[(size_t)o * K1 + k] : 0.f;
+}
+}  // namespace
+
+TSM_EXPORT int tsm_critic_rows_w1_image_kj(int32_t in_dim) { return pick_kj(in_dim); }
+
+TSM_EXPORT int64_t tsm_critic_rows_w1_image_elems(int32_t in_dim) {
+    const int kj = pick_kj(in_dim);
+    return kj ? (int64_t)kH * 16 * kj : -1;
+}
+
+TSM_EXPORT int tsm_critic_rows_w1_image(const float *w1, int32_t in_dim, float *image_out, void *stream) {
+    const int kj = pick_kj(in_dim);
+    TSM_REQUIRE(kj != 0 && w1 && image_out, "tsm_critic_rows_w1_image: in_dim = %d unsupported or null pointer", in_dim);
+    const int64_t n = (int64_t)kH * 16 * kj;
+    hipLaunchKernelGGL(w1_image_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, tsm_stream(stream), w1, in_dim, kj, image_out);
+    TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+TSM_EXPORT int tsm_critic_rows_grad_ppo(const float *critic_params, const float *w1_image, int32_t in_dim, int32_t hidden, int32_t n_agent,
                                         const float *obs_rows, const float *returns, const float *v_s_old,
                                         const int64_t *rows, int64_t first_row, int64_t Mr, const tsm_ppo_cfg *cfg,
                                         int32_t n_blocks, float *dh1_out, float *rest_slabs_out, double *loss_partial_out,
@@ -573,14 +663,14 @@ TSM_EXPORT int tsm_critic_rows_grad_ppo(const float *critic_params, int32_t in_d
     TSM_REQUIRE(!cfg->value_clip || v_s_old, "tsm_critic_rows_grad_ppo: value_clip needs v_s_old");
     TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(Mr, kRows), "tsm_critic_rows_grad_ppo: n_blocks = %d out of range", n_blocks);
     TrainArgs g{};
-    g.P = critic_params; g.obs = obs_rows; g.rows = rows; g.first_row = first_row; g.Mr = Mr; g.K1 = in_dim; g.n_out = 1;
+    g.P = critic_params; g.w1_img = w1_image; g.obs = obs_rows; g.rows = rows; g.first_row = first_row; g.Mr = Mr; g.K1 = in_dim; g.n_out = 1;
     g.returns = returns; g.v_s_old = v_s_old; g.N = n_agent;
     g.eps_clip = (float)cfg->eps_clip; g.vf_coef = (float)cfg->vf_coef; g.value_clip = cfg->value_clip;
     g.dh1 = dh1_out; g.slabs = rest_slabs_out; g.partial = loss_partial_out; g.stamps = g_tsm_stamps;
     return dispatch_train(pick_kj(in_dim), g, 0, n_blocks, tsm_stream(stream));
 }
 
-TSM_EXPORT int tsm_critic_rows_grad_td(const float *critic_params, int32_t in_dim, int32_t hidden, int32_t n_out,
+TSM_EXPORT int tsm_critic_rows_grad_td(const float *critic_params, const float *w1_image, int32_t in_dim, int32_t hidden, int32_t n_out,
                                        const float *joint_rows, int64_t T, int64_t E, const float *rew,
                                        const uint8_t *terminated, int64_t scalar_stride, int64_t scalar_offset,
                                        const float *v_last, const float *v_next_full, const int32_t *use_full,
@@ -597,7 +687,7 @@ TSM_EXPORT int tsm_critic_rows_grad_td(const float *critic_params, int32_t in_di
     const int64_t B = T * E;
     TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(B, kRows - 1), "tsm_critic_rows_grad_td: n_blocks = %d out of range", n_blocks);
     TrainArgs g{};
-    g.P = critic_params; g.obs = joint_rows; g.rows = nullptr; g.first_row = 0; g.Mr = B; g.tm_T = T; g.tm_E = E;
+    g.P = critic_params; g.w1_img = w1_image; g.obs = joint_rows; g.rows = nullptr; g.first_row = 0; g.Mr = B; g.tm_T = T; g.tm_E = E;
     g.K1 = in_dim; g.n_out = n_out; g.N = 1;
     g.rew = rew; g.term = terminated; g.sc_stride = scalar_stride; g.sc_off = scalar_offset; g.v_last = v_last;
     g.v_full = v_next_full; g.use_full = use_full;

@@ -345,19 +345,43 @@ def adam_step(param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9,
 
 
 def _slab_segs(segs, n: int):
-    """[(slabs [n_slab, stride >= n_k], offset, n_k[, scale_dev]), ...] -> ctypes array of tsm_slab_seg.
+    """[(slabs [n_slab, stride >= n_k], offset, n_k[, scale_dev[, frag_image]]), ...] -> ctypes array of tsm_slab_seg.
     A segment's slabs tensor may be wider than its parameter count (a view into joint slabs): stride = its row pitch.
-    scale_dev (optional device f32[1]): the segment's summed gradient is multiplied by it."""
+    scale_dev (optional device f32[1]): the segment's summed gradient is multiplied by it.
+    frag_image (optional, `critic_w1_image` layout): the segment is a [128][n_k / 128] first-layer weight matrix whose
+    updated values the optimizer also stores in fragment order."""
     arr = (_abi.tsm_slab_seg * len(segs))()
     for k, seg in enumerate(segs):
         sl, off, nk = seg[:3]
         sc = seg[3] if len(seg) > 3 else None
+        img = seg[4] if len(seg) > 4 else None
         sl = _chk(sl, torch.float32, "slabs")
         if sl.dim() != 2 or sl.shape[1] < nk:
             raise ValueError("slab segment: expected slabs [n_slab, >= n] for n = %d, got %s" % (nk, tuple(sl.shape)))
-        arr[k] = _abi.tsm_slab_seg(ptr(sl), int(off), int(nk), int(sl.shape[1]), int(sl.shape[0]), 0,
-                                   ptr(None if sc is None else _chk(sc, torch.float32, "scale_dev")))
+        k1 = kj = 0
+        if img is not None:
+            if nk % 128:
+                raise ValueError("slab segment: a fragment image belongs to a [128][K1] weight matrix")
+            k1 = nk // 128
+            kj = call("tsm_critic_rows_w1_image_kj", k1)
+            if _chk(img, torch.float32, "frag_image").numel() != call("tsm_critic_rows_w1_image_elems", k1):
+                raise ValueError("slab segment: frag_image has the wrong size for K1 = %d" % k1)
+        arr[k] = _abi.tsm_slab_seg(ptr(sl), int(off), int(nk), int(sl.shape[1]), int(sl.shape[0]), k1,
+                                   ptr(None if sc is None else _chk(sc, torch.float32, "scale_dev")), ptr(img), kj, 0)
     return arr
+
+
+def critic_w1_image(w0_flat, in_dim: int, out=None):
+    """The first-layer weights w0 [128][in_dim] (the head of a critic's flat parameter vector) in the fragment order the
+    one-launch critic gradient step loads with coalesced 16-B loads (include/tsmarl.h: tsm_critic_rows_w1_image)."""
+    n = call("tsm_critic_rows_w1_image_elems", in_dim)
+    if n < 0:
+        raise ValueError(f"critic_w1_image: in_dim = {in_dim} is not served by the rows kernels")
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=w0_flat.device)
+    call("tsm_critic_rows_w1_image", ptr(_chk(w0_flat, torch.float32, "w0")), in_dim, ptr(_chk(out, torch.float32, "out")),
+         stream_ptr())
+    return out
 
 
 def adam_step_segs(param, segs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
@@ -677,10 +701,11 @@ def _critic_grad_ws(K1: int, hidden: int, n_out: int, Mr: int, td: bool, dev, ws
 
 
 def critic_rows_grad_ppo(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n_agent: int, hidden: int = 128, v_s_old=None,
-                         rows=None, first_row=0, Mr=None, partial=None, ws: dict | None = None):
+                         rows=None, first_row=0, Mr=None, partial=None, ws: dict | None = None, w1_image=None):
     """Critic half of one PPO gradient step on joint rows in two launches -> (w1_slabs [n_chunks, H * in_dim],
     rest_slabs [n_blocks, P - H * in_dim], partial f64 [n_blocks * 4] = {0, sum vf, 0, 0} per workgroup): feed the two slab
-    arrays to `adam_step_segs` as segments (W1 first).  `partial`: where to leave the loss partials (>= n_blocks * 4)."""
+    arrays to `adam_step_segs` as segments (W1 first).  `partial`: where to leave the loss partials (>= n_blocks * 4).
+    w1_image: the first-layer weights in fragment order (`critic_w1_image`; must hold the values of critic_params' w0)."""
     obs_rows = _chk(obs_rows, torch.float32, "obs_rows")
     K1 = obs_rows.shape[-1]
     if Mr is None:
@@ -694,7 +719,7 @@ def critic_rows_grad_ppo(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n_a
     part = w["partial"] if partial is None else partial
     if part.numel() < w["nb"] * 4:
         raise ValueError("critic_rows_grad_ppo: partial is too small")
-    call("tsm_critic_rows_grad_ppo", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_agent,
+    call("tsm_critic_rows_grad_ppo", ptr(_chk(critic_params, torch.float32, "critic_params")), ptr(w1_image), K1, hidden, n_agent,
          ptr(obs_rows), ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old), ptr(rows), first_row, Mr, C.byref(cfg),
          w["nb"], ptr(w["dh1"]), ptr(w["rest"]), ptr(part), stream_ptr())
     call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(obs_rows), K1, ptr(rows), first_row, 0, 0, Mr, w["nc"], ptr(w["w1"]),
@@ -720,7 +745,7 @@ def critic_rows_grad_td(critic_params, joint_store, T: int, E: int, rew, termina
     w = _critic_grad_ws(K1, hidden, n_out, B, True, joint_store.device, ws)
     part = w["partial"] if partial is None else partial
     term = terminated.view(torch.uint8) if terminated.dtype == torch.bool else _chk(terminated, torch.uint8, "terminated")
-    call("tsm_critic_rows_grad_td", ptr(_chk(critic_params, torch.float32, "critic_params")), K1, hidden, n_out,
+    call("tsm_critic_rows_grad_td", ptr(_chk(critic_params, torch.float32, "critic_params")), None, K1, hidden, n_out,
          ptr(joint_store), T, E, ptr(_chk(rew, torch.float32, "rew")), ptr(term), n_agent, agent,
          ptr(_chk(v_last, torch.float32, "v_last")), ptr(None if v_next_full is None else _chk(v_next_full, torch.float32, "v_next_full")),
          ptr(None if use_full is None else _chk(use_full, torch.int32, "use_full")), float(gamma), w["nb"], ptr(w["dh1"]),
@@ -940,7 +965,7 @@ def device_info() -> dict:
     return dict(n_cu=n_cu.value, wave_size=wave.value, hbm_bytes=hbm.value, arch=name.value.decode())
 
 
-KERNEL_OPTIONS = ("actor_tile", "split_bf16")
+KERNEL_OPTIONS = ("actor_tile", "split_bf16", "dbg")
 
 
 def kernel_option(name: str) -> int:

@@ -2,6 +2,7 @@
 """Phase time stamps of the second-generation critic step, kernel A (csrc/critic_train.hip), workgroup 0, 100 MHz wall clock.
 
     python tools/stamp_critic_train.py            # PPO value term, 8192 joint rows of 384 (one tile per workgroup)
+    python tools/stamp_critic_train.py img        # the same PPO step with the first-layer weights from the fragment image
     python tools/stamp_critic_train.py td         # CTDE TD loss, 102 400 rows (13 tiles per workgroup): tiles 0, 1, 2
 """
 import ctypes
@@ -16,6 +17,7 @@ from tianshou_marl_amd.utils.net import FlatMLP  # noqa: E402
 
 dev = "cuda"
 td = len(sys.argv) > 1 and sys.argv[1] == "td"
+use_img = len(sys.argv) > 1 and sys.argv[1] == "img"
 D, N, H = 48, 8, 128
 torch.manual_seed(0)
 st = torch.zeros(1024, dtype=torch.int64, device=dev)
@@ -36,7 +38,8 @@ else:
     rid = torch.randperm(rows, device=dev)[:Mr].contiguous()
     cfg = ops.make_ppo_cfg(value_group=N)
     ws = {}
-    run = lambda: ops.critic_rows_grad_ppo(f.flat.data, joint, ret, cfg, N, H, rows=rid, Mr=Mr, ws=ws)  # noqa: E731
+    img = ops.critic_w1_image(f.flat.data, N * D) if use_img else None
+    run = lambda: ops.critic_rows_grad_ppo(f.flat.data, joint, ret, cfg, N, H, rows=rid, Mr=Mr, ws=ws, w1_image=img)  # noqa: E731
 for _ in range(3):
     run()
 lib.tsm_debug_set_stamps(st.data_ptr())
@@ -44,8 +47,9 @@ run()
 torch.cuda.synchronize()
 lib.tsm_debug_set_stamps(None)
 s = st.cpu().numpy()
-names = ["L1 (W1 in registers, X by ds_read_b128) -> H1", "commit next X + fetch + L2 -> H2", "L3 (MFMA, 2 waves) -> Q", "loss head",
-         "dW3 / db3 / dH2", "dW2 + dH1 -> global"]
+names = ["L1 (W1 in registers, X by ds_read_b128) -> H1", "commit next X + fetch + L2 -> H2 (PPO: + V partials)",
+         "L3 (MFMA, 2 waves; TD only) -> Q", "loss head", "dW3 / db3 / dH2", "dW2 + dH1 -> global"]
+print("PPO value term" + (", W1 from the fragment image" if use_img else ", W1 gathered from the flat vector") if not td else "CTDE TD loss")
 print(f"prologue (W1 fragments, W2 / W3 staging, row ids -> first tile in LDS) {(s[300] - s[298]) / 100.0:.2f} us")
 for it in range(3 if td else 1):
     b = 300 + 16 * it
