@@ -109,6 +109,20 @@ def build_job(a, device, rank):
     return env, net, algo, buf, col
 
 
+def _allreduce_path(sync) -> dict:
+    """Which way the replicas' gradients travel, for the bench line's `config` (parallel.p2p_mode: the first-use handshake
+    decides unless TSM_P2P_ALLREDUCE forces or forbids the peer-memory path)."""
+    if sync is None:
+        return {}
+    from tianshou_marl_amd.parallel import p2p_mode
+
+    if getattr(sync, "p2p", None) is not None:
+        return {"gradient_all_reduce": "peer memory (one-shot LL exchange; handshake passed; TSM_P2P_ALLREDUCE mode %s)" % p2p_mode()}
+    return {"gradient_all_reduce": "process group (%s) all-reduce (peer-memory mode %s%s)"
+                                   % (sync.dist.get_backend(sync.group), p2p_mode(),
+                                      "" if p2p_mode() == "off" else ": setup or handshake declined, see stderr")}
+
+
 def _resolve(stats):
     """Read a statistics object now if it is a lazy one (eager paths return finished objects)."""
     r = getattr(stats, "resolve", None)
@@ -790,8 +804,7 @@ def run_tag(a, device, rank, world, dist, census=None):
                "config": {"workload": "simple_tag_v3 3 adversaries + 1 prey, 2 obstacles, grouped PPO (one policy per team), "
                                       "LeaguePlayTrainer, num_envs=%d per GPU, T=%d" % (n_env, T),
                           "parallelism": "env-shard x%d, one packed gradient all-reduce per step for both teams" % world,
-                          **({"gradient_all_reduce": "peer memory (one-shot)"} if getattr(getattr(mgr, "_grad_sync", None), "p2p", None)
-                             is not None else {})},
+                          **_allreduce_path(getattr(mgr, "_grad_sync", None))},
                "collect_ms": float(np.median([e[0].elapsed_time(e[1]) for e in marks[-a.steps:]])),
                "league_train_step_ms": float(np.median([e[1].elapsed_time(e[2]) for e in marks[-a.steps:]])),
                "losses": {k: float(v["loss"]) for k, v in losses.items()}}
@@ -1013,8 +1026,7 @@ def _main():
                        "minibatch": a.minibatch, "repeat": a.repeat, "dispatch": a.dispatch, "parallelism": "env-shard x%d" % world,
                        **({} if dist is None else {"collectives": "captured in the update hipGraph" if getattr(algo, "graph_collectives", False)
                                                    else "eager, between segmented hipGraphs"}),
-                       **({"gradient_all_reduce": "peer memory (one-shot)"} if getattr(getattr(algo, "_grad_sync", None), "p2p", None)
-                          is not None else {})},
+                       **_allreduce_path(getattr(algo, "_grad_sync", None))},
             "collect_ms": t_col_ms, "ppo_update_ms": t_upd_ms,
             "collect_env_steps_per_s": a.n_env * a.n_agent * a.horizon / (t_col_ms * 1e-3),
             "gradient_steps_per_update": grad_steps,

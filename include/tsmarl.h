@@ -650,8 +650,14 @@ int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim,
  * One-shot write-to-peers over IPC-mapped fine-grained memory (every element one 8-byte store {value, call stamp}: no fences),
  * one launch per call, rank-ordered sum (bit-identical on every rank); csrc/p2p.hip has the protocol.  Setup: every rank tsm_p2p_create -> tsm_p2p_export -> the ranks exchange
  * the tsm_p2p_ipc_handle_bytes()-byte handles by any channel (the host binding uses the process group) -> tsm_p2p_import of
- * every peer.  tsm_p2p_failed: 1 after a peer failed to answer within the bounded spin (no hang).  Opt-in
- * (TSM_P2P_ALLREDUCE=1 in the host binding); RCCL stays the default.
+ * every peer -> tsm_p2p_handshake on every rank (one stamped word per peer each way, bounded spin, outside any capture); the
+ * ranks then AGREE (over their process group) to use this path only if every rank's handshake passed -- otherwise each destroys
+ * its handle and the backend's own all-reduce serves for the rest of the process (the host binding: TSM_P2P_ALLREDUCE unset =
+ * "the handshake decides", 1 = required, 0 = off).
+ * Failure behaviour (fail-stop): a peer whose word does not arrive within the spin limit (tsm_p2p_set_timeout; ~2 s) sets the
+ * handle's error word; the element that timed out is NOT updated (tsm_p2p_adam_step leaves parameter and moments as they
+ * were, tsm_p2p_all_reduce leaves the element), every later launch on the handle is a no-op, and tsm_p2p_failed (synchronises
+ * the device) returns 1: the host raises.  No hang, and no replica ever steps on a partial sum.
  * ------------------------------------------------------------------------------------------- */
 int64_t tsm_p2p_ipc_handle_bytes(void);
 int tsm_p2p_create(int32_t rank, int32_t world, int64_t max_floats, void **handle_out);
@@ -665,6 +671,8 @@ int tsm_p2p_all_reduce(void *handle, float *data, int64_t n, void *stream);
 int tsm_p2p_adam_step(void *handle, float *param, const float *grad_slabs, int32_t n_slab, int64_t n, float *exp_avg,
                       float *exp_avg_sq, int64_t step, const int64_t *step_dev, double lr, const double *lr_dev, double beta1,
                       double beta2, double eps, double weight_decay, float *param_image, const int32_t *image_map, void *stream);
+int tsm_p2p_set_timeout(void *handle, double seconds);
+int tsm_p2p_handshake(void *handle, int32_t *ok_out, void *stream);
 int tsm_p2p_failed(void *handle);
 int tsm_p2p_destroy(void *handle);
 

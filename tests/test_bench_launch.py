@@ -51,13 +51,14 @@ def test_single_gpu_workloads_refuse_more_ranks():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload,p2p", [("c2", "0"), ("tag", "0"), ("c2", "1"), ("tag", "1")])
+@pytest.mark.parametrize("workload,p2p", [("c2", "0"), ("tag", "0"), ("c2", "1"), ("tag", "1"), ("c2", "auto")])
 def test_bench_gpus_2_runs_two_ranks_and_counts_them(workload, p2p):
     """The driver's command shape with N = 2 and nothing around it: two ranks on cuda:0 over gloo; p2p = 1: the gradient
-    sums on the one-shot peer-memory all-reduce (csrc/p2p.hip) instead of the process group's."""
+    sums on the one-shot peer-memory all-reduce (csrc/p2p.hip) instead of the process group's; auto (the default, variable
+    unset): the first-use handshake decides -- it passes here."""
     extra = ["--no-cpu-baseline", "--no-c3-grid"] if workload == "c2" else ["--workload", "tag", "--tag-envs", "64"]
     r = _run(["--gpus", "2", "--steps", "3", "--warmup", "2", *extra],
-             {"TSM_SHARE_GPU": "1", "TSM_DIST_BACKEND": "gloo", "TSM_P2P_ALLREDUCE": p2p})
+             {"TSM_SHARE_GPU": "1", "TSM_DIST_BACKEND": "gloo", **({} if p2p == "auto" else {"TSM_P2P_ALLREDUCE": p2p})})
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout  # ONE JSON line on stdout, nothing else
@@ -65,4 +66,4 @@ def test_bench_gpus_2_runs_two_ranks_and_counts_them(workload, p2p):
     assert out["n_gpus"] == 2 and out["group_ranks"] == 2 and out["ranks_backend"] == "gloo"
     assert out["replicas_identical"] is True
     assert out["steps"] == 3 and out["value"] > 0
-    assert out["config"].get("gradient_all_reduce", "process group") == ("peer memory (one-shot)" if p2p == "1" else "process group")
+    assert out["config"]["gradient_all_reduce"].startswith("process group (gloo)" if p2p == "0" else "peer memory (one-shot")

@@ -43,7 +43,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     from tianshou_marl_amd.parallel import attach_data_parallel
     from tianshou_marl_amd.utils.net import DiscreteActorCritic
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSM_P2P_ALLREDUCE="0")  # (the process group's path)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -246,7 +246,8 @@ def _rccl_worker(rank: int, world: int, port: int, out_dir: str) -> None:
     from tianshou_marl_amd.parallel import attach_data_parallel
     from tianshou_marl_amd.utils.net import DiscreteActorCritic, MLPActorCritic
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSM_FORCE_DIST="1")  # (merge the statistics too)
+    # (merge the statistics too; gradients on RCCL's own all-reduce -- the peer-memory path has its own tests below)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSM_FORCE_DIST="1", TSM_P2P_ALLREDUCE="0")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=rank, world_size=world)
     try:
@@ -355,7 +356,8 @@ def _p2p_worker(rank: int, world: int, port: int, out_dir: str) -> None:
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         n = 11142
-        p2p = P2PAllReduce(dist, None, torch.device("cuda", 0), n)
+        p2p = P2PAllReduce.negotiate(dist, None, torch.device("cuda", 0), n)
+        assert p2p is not None  # setup + first-use handshake passed on both ranks
         gen = [torch.Generator(device=DEV).manual_seed(100 + r) for r in range(world)]
         # (a) 300 back-to-back calls, no host synchronisation in between: both inbox halves are reused many times
         xs = [[torch.randn(n, device=DEV, generator=gen[r]) for _ in range(300)] for r in range(world)]
@@ -397,7 +399,7 @@ def _p2p_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         # several steps with a device-resident step count
         from tianshou_marl_amd import ops
 
-        p2q = P2PAllReduce(dist, None, torch.device("cuda", 0), n)
+        p2q = P2PAllReduce.negotiate(dist, None, torch.device("cuda", 0), n)
         gs = torch.Generator(device=DEV).manual_seed(7)          # the same parameters on both ranks ...
         gr = torch.Generator(device=DEV).manual_seed(70 + rank)  # ... different gradients
         P1 = torch.randn(n, device=DEV, generator=gs)
@@ -472,3 +474,116 @@ def test_peer_memory_all_reduce_with_two_processes_on_one_gpu(tmp_path):
         raise
     p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
     assert np.array_equal(p0, p1) and np.isfinite(p0).all()
+
+
+def _p2p_fail_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    """What the peer-memory path does when a peer does not play along (two processes on cuda:0, gloo for the agreement)."""
+    import time
+
+    import torch.distributed as dist
+
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
+    from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
+    from tianshou_marl_amd.data.collector import Collector
+    from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv
+    from tianshou_marl_amd.parallel import P2PAllReduce, attach_data_parallel, p2p_mode
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TSM_P2P_TIMEOUT_S="0.3")
+    os.environ.pop("TSM_P2P_ALLREDUCE", None)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    try:
+        assert p2p_mode() == "auto"
+        n = 4000
+        # (a) the first-use handshake: rank 1 never sends its word -> rank 0's bounded spin runs out -> BOTH ranks get None
+        # (the agreement is a collective: no rank is left on the other path), nothing raised, nothing hangs
+        os.environ["TSM_P2P_FAIL_HANDSHAKE"] = "1"
+        t0 = time.time()
+        assert P2PAllReduce.negotiate(dist, None, dev, n) is None
+        with open(os.path.join(out_dir, f"handshake_timeout_{rank}.txt"), "w") as f:
+            f.write(f"negotiate with a silent peer (TSM_P2P_TIMEOUT_S=0.3): {time.time() - t0:.2f} s\n")
+        assert time.time() - t0 < 20.0
+        # ... and in "auto" mode a replica then simply trains over the process group (here gloo), identically on both ranks
+        env = DeviceSimpleSpreadVectorEnv(16, 3, device=DEV, seed=50 + rank)
+        bufr = DeviceVectorReplayBuffer(16 * 25, 16, 3, D, device=DEV)
+        algo = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=20 + rank), lr=1e-3, dispatch="pooled", shuffle="device", seed=7)
+        sync = attach_data_parallel(algo, dist)
+        assert sync.p2p is None
+        col = Collector(algo, env, bufr)
+        col.reset()
+        with policy_within_training_step(algo):
+            col.collect(n_step=16 * 25)
+            algo.update(bufr, 256, 1)
+        ref = algo.net.flat.data.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, algo.net.flat.data) and bool(torch.isfinite(ref).all())
+        # "required" mode raises instead (on every rank)
+        os.environ["TSM_P2P_ALLREDUCE"] = "1"
+        with pytest.raises(RuntimeError, match="TSM_P2P_ALLREDUCE=1"):
+            attach_data_parallel(PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=1), use_graph=False), dist)
+        os.environ.pop("TSM_P2P_ALLREDUCE")
+        os.environ.pop("TSM_P2P_FAIL_HANDSHAKE")
+        # (b) a failure during setup on ONE rank (before any handle could be mapped): the same outcome
+        os.environ["TSM_P2P_FAIL_SETUP"] = "0"
+        assert P2PAllReduce.negotiate(dist, None, dev, n) is None
+        os.environ.pop("TSM_P2P_FAIL_SETUP")
+        # (c) a peer that dies MID-RUN: both ranks pass the handshake, then rank 1 stops calling.  Rank 0's fused step
+        # (slab sum + exchange + Adam in one launch) must leave parameters and both moments exactly as they were -- no
+        # replica steps on a partial sum --, `check()` raises, and a later launch on the dead handle returns at once
+        p2p = P2PAllReduce.negotiate(dist, None, dev, n)
+        assert p2p is not None
+        g = torch.Generator(device=DEV).manual_seed(3)
+        P, m, v = torch.randn(n, device=DEV, generator=g), torch.rand(n, device=DEV, generator=g), torch.rand(n, device=DEV, generator=g)
+        slabs = torch.randn(8, n, device=DEV, generator=g)
+        p2p.adam_step(P, slabs, m, v, 1, lr=1e-2)          # a good step first (both ranks)
+        torch.cuda.synchronize()
+        p2p.check()
+        dist.barrier()
+        if rank == 0:
+            P0, m0, v0 = P.clone(), m.clone(), v.clone()
+            p2p.adam_step(P, slabs, m, v, 2, lr=1e-2)      # rank 1 never makes this call
+            torch.cuda.synchronize()
+            assert torch.equal(P, P0) and torch.equal(m, m0) and torch.equal(v, v0)
+            with pytest.raises(RuntimeError, match="did not answer"):
+                p2p.check()
+            t0 = time.time()
+            x = torch.ones(n, device=DEV)
+            p2p.all_reduce_sum_(x)                          # dead handle: a no-op, not another bounded spin
+            p2p.adam_step(P, slabs, m, v, 3, lr=1e-2)
+            torch.cuda.synchronize()
+            assert time.time() - t0 < 0.25 and torch.equal(x, torch.ones(n, device=DEV)) and torch.equal(P, P0)
+        dist.barrier()
+        p2p.close()
+        open(os.path.join(out_dir, f"ok{rank}"), "w").close()
+    except BaseException:
+        import traceback
+
+        with open(os.path.join(out_dir, f"err{rank}.txt"), "w") as f:
+            traceback.print_exc(file=f)
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_peer_memory_path_declines_cleanly_and_never_steps_on_a_partial_sum(tmp_path):
+    """SURVEY.md section 8e / VERDICT r3 item 6: the peer-memory all-reduce is the default only if a first-use handshake passes
+    on EVERY rank (`P2PAllReduce.negotiate`: one stamped word per peer each way with the bounded spin, before any capture; the
+    ranks agree on the outcome with a collective, so none is left on another path); a handshake or setup failure falls back to
+    the process group for the rest of the process ("auto") or raises everywhere ("required"); and a peer lost mid-run leaves
+    the surviving replica's parameters untouched (fail-stop), the error raised at the next check."""
+    import torch.multiprocessing as mp
+
+    try:
+        mp.spawn(_p2p_fail_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    except Exception:
+        for r in range(2):
+            f = tmp_path / f"err{r}.txt"
+            if f.exists():
+                print(f"---- rank {r} ----\n{f.read_text()}")
+        raise
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+    print((tmp_path / "handshake_timeout_0.txt").read_text())

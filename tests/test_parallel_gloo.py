@@ -1,4 +1,4 @@
-"""World-size-2 `gloo` tests (CPU) of the env-sharded data-parallel host logic (tianshou_marl_amd/parallel.py).
+"""World-size-2 and world-size-8 `gloo` tests (CPU) of the env-sharded data-parallel host logic (tianshou_marl_amd/parallel.py).
 
 Covers what the N>1 path adds over N=1: the env shard arithmetic, the replica broadcast at attach time, and the
 flat-gradient mean all-reduce that keeps replicas identical.  The gradient itself comes from the HIP kernels
@@ -71,7 +71,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
             g = torch.full((257,), float(rank + 1)) * step + torch.arange(257) * 1e-3
             sync.all_reduce_mean_(g)
             expect = torch.full((257,), (1 + world) / 2.0) * step + torch.arange(257) * 1e-3
-            assert torch.allclose(g, expect, rtol=0, atol=1e-6)
+            assert torch.allclose(g, expect, rtol=0, atol=2e-5)
             m.mul_(0.9).add_(g, alpha=0.1)
             v.mul_(0.999).addcmul_(g, g, value=0.001)
             p.sub_(1e-3 * (m / (1 - 0.9 ** step)) / ((v / (1 - 0.999 ** step)).sqrt() + 1e-8))
@@ -79,7 +79,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         # inside the slab-reduction kernel)
         g = (torch.full((9,), float(rank + 1)) + torch.arange(9)) / world
         sync.all_reduce_sum_(g)
-        assert torch.allclose(g, torch.full((9,), (1 + world) / 2.0) + torch.arange(9), rtol=0, atol=1e-6)
+        assert torch.allclose(g, torch.full((9,), (1 + world) / 2.0) + torch.arange(9), rtol=0, atol=2e-5)
         # lock-step training of two policy groups (parallel.learn_lockstep): the flat gradients that fall due at the same
         # gradient step are packed into ONE all-reduce; a group with more steps goes on alone.  Generators stand in for
         # PPO.learn_steps: they yield rank-local gradients (pre-scaled by 1 / world) and read them back reduced.
@@ -178,9 +178,13 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-def test_two_rank_replicas_stay_identical(tmp_path):
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 8])
+def test_replicas_stay_identical(tmp_path, world):
+    """world 8 = the node the scaling run uses (BASELINE configs[3] / [4]): the lock-step generator and its packed-reduce layout,
+    the every-call agreement checks (a disagreement on the step count or on the groups raises on EVERY rank, no hang), the
+    merged advantage statistics and the replicas' bit-identity, with eight real processes."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
-    assert np.array_equal(p0, p1)  # bit-identical replicas after synced steps
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ps = [np.load(tmp_path / f"p{r}.npy") for r in range(world)]
+    assert all(np.array_equal(ps[0], p) for p in ps[1:])  # bit-identical replicas after synced steps

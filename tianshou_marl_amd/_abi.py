@@ -198,6 +198,8 @@ SIGNATURES = {
     "tsm_p2p_import": (_int, [_p, _i32, _p]),
     "tsm_p2p_all_reduce": (_int, [_p, _p, _i64, _p]),
     "tsm_p2p_adam_step": (_int, [_p, _p, _p, _i32, _i64, _p, _p, _i64, _p, _f64, _p, _f64, _f64, _f64, _f64, _p, _p, _p]),
+    "tsm_p2p_set_timeout": (_int, [_p, _f64]),
+    "tsm_p2p_handshake": (_int, [_p, C.POINTER(_i32), _p]),
     "tsm_p2p_failed": (_int, [_p]),
     "tsm_p2p_destroy": (_int, [_p]),
     "tsm_reduce_slabs_segs": (_int, [_p, _i32, _i64, _f64, _p, _p]),

@@ -23,8 +23,13 @@
 // An earlier version signalled per 1/32 slice with flags behind system-scope fences (an L2 write-back + invalidate each): ~10 us
 // per call with nobody to wait for, and ~30 us once a fused step used one workgroup per 64 parameters (the fences serialise per
 // XCD).  The LL form has neither.
-// Failure behaviour: a peer that never sends (crashed rank) ends the spin after ~2 s with the handle's error word set;
-// the host reads it at its next synchronisation point and raises -- no hang.
+// Failure behaviour (fail-stop, the last good parameters survive): a peer that never sends (crashed rank) ends the spin after
+// ~2 s with the handle's error word set.  The lane that timed out does NOT use the partial sum: the fused step skips Adam for
+// that element (parameter and moments untouched), the plain all-reduce leaves the element as it was; every LATER launch on the
+// handle sees the error word at its start and does nothing at all (so a captured update does not spin 2 s per step).  The host
+// reads the word at its next synchronisation point (tsm_p2p_failed) and raises -- no hang, no replica stepped on a partial sum.
+// First use: tsm_p2p_handshake exchanges one stamped word per peer with the same bounded spin BEFORE anything is captured;
+// the ranks then agree (over the process group) to use this path or the backend's own collective for the rest of the process.
 #include "adam_dev.h"
 #include <string.h>
 
@@ -43,6 +48,8 @@ struct P2PHandle {
     bool opened[kP2PMaxWorld];
     uint64_t *seq_dev;                 // device: {stamp of the NEXT call (starts at 1), workgroups finished in the running call}
     int *err_dev;                      // device int: set by a timed-out spin
+    float *hs_dev;                     // device: the handshake's one element
+    uint64_t spin_limit;               // polls per missing word (tsm_p2p_set_timeout; default ~2 s)
 };
 
 struct P2PArgs {
@@ -55,6 +62,7 @@ struct P2PArgs {
                                        // launch can be replayed
     char *peer[kP2PMaxWorld];
     int *err;
+    uint64_t spin_limit;               // polls before a missing word counts as a dead peer
 };
 
 // element i of sender `from`, call parity `par`, inside an inbox
@@ -62,21 +70,24 @@ __device__ __forceinline__ uint64_t *ll_slot(char *inbox, int par, int world, in
     return reinterpret_cast<uint64_t *>(inbox) + ((size_t)par * world + from) * max_floats + i;
 }
 
-// send `val` as element i of this call to every peer, receive the peers' element i, return the rank-ordered sum
-__device__ __forceinline__ float ll_exchange(const P2PArgs &a, int par, uint64_t tag, int64_t i, float val) {
+// send `val` as element i of this call to every peer, receive the peers' element i; returns the rank-ordered sum in `sum`
+// and false if a peer's word did not arrive within the spin limit (`sum` is then not to be used)
+__device__ __forceinline__ bool ll_exchange(const P2PArgs &a, int par, uint64_t tag, int64_t i, float val, float &sum) {
     const uint64_t word = tag | (uint64_t)__float_as_uint(val);
     for (int r = 0; r < a.world; ++r)
         if (r != a.rank) __hip_atomic_store(ll_slot(a.peer[r], par, a.world, a.rank, a.max_floats, i), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     float acc = 0.f;
-    for (int r = 0; r < a.world; ++r) {
+    bool ok = true;
+    for (int r = 0; r < a.world && ok; ++r) {
         float vr = val;
         if (r != a.rank) {
             const uint64_t *src = ll_slot(a.peer[a.rank], par, a.world, r, a.max_floats, i);
             uint64_t wv, spins = 0;
             while (((wv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) & 0xFFFFFFFF00000000ull) != tag) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > kSpinLimit) {  // a peer is gone: flag the error, go on with what there is (the host raises at its next sync)
+                if (++spins > a.spin_limit) {  // a peer is gone: flag it, use nothing of this exchange (the host raises at its next sync)
                     atomicExch(a.err, 1);
+                    ok = false;
                     break;
                 }
             }
@@ -84,8 +95,12 @@ __device__ __forceinline__ float ll_exchange(const P2PArgs &a, int par, uint64_t
         }
         acc = r == 0 ? vr : acc + vr;
     }
-    return acc;
+    sum = acc;
+    return ok;
 }
+
+// has an earlier launch on this handle lost a peer?  (then this one does nothing: see "Failure behaviour")
+__device__ __forceinline__ bool ll_dead(const P2PArgs &a) { return __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 
 // the last workgroup to get here advances the stamp for the next call (every workgroup read it at its start)
 __device__ __forceinline__ void ll_finish(const P2PArgs &a, uint64_t seq) {
@@ -104,7 +119,10 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PArgs a) 
     const int par = (int)(seq & 1);
     const uint64_t tag = (seq & 0xFFFFFFFFull) << 32;
     const int64_t i = (int64_t)blockIdx.x * kP2PThreads + threadIdx.x;
-    if (i < a.n) a.data[i] = ll_exchange(a, par, tag, i, a.data[i]);
+    if (i < a.n && !ll_dead(a)) {
+        float sum;
+        if (ll_exchange(a, par, tag, i, a.data[i], sum)) a.data[i] = sum;
+    }
     ll_finish(a, seq);
 }
 
@@ -137,11 +155,13 @@ __global__ __launch_bounds__(256) void p2p_adam_kernel(P2PAdamArgs g) {
     const uint64_t tag = (seq & 0xFFFFFFFFull) << 32;
     const int64_t i = (int64_t)blockIdx.x * kCols + lane;
     const float gsum = slab_sum_block(g.slabs, g.n_slab, a.n, i, sm, a.n);
-    if (sl == 0 && i < a.n) {
-        const float acc = ll_exchange(a, par, tag, i, gsum * g.scale);
-        const float pn = adam_apply(g.p, g.m, g.v, i, acc, g.lr_host, g.lr_dev, g.beta1, g.beta2, g.step_host, g.step_dev, g.eps,
-                                    g.weight_decay);
-        if (g.img) g.img[g.img_map[i]] = pn;
+    if (sl == 0 && i < a.n && !ll_dead(a)) {
+        float acc;
+        if (ll_exchange(a, par, tag, i, gsum * g.scale, acc)) {  // (a timed-out element keeps its last good parameter and moments)
+            const float pn = adam_apply(g.p, g.m, g.v, i, acc, g.lr_host, g.lr_dev, g.beta1, g.beta2, g.step_host, g.step_dev, g.eps,
+                                        g.weight_decay);
+            if (g.img) g.img[g.img_map[i]] = pn;
+        }
     }
     ll_finish(a, seq);
 }
@@ -170,6 +190,8 @@ TSM_EXPORT int tsm_p2p_create(int32_t rank, int32_t world, int64_t max_floats, v
     TSM_HIP(hipMalloc(reinterpret_cast<void **>(&h->seq_dev), 2 * sizeof(uint64_t)));
     const uint64_t init[2] = {1ull, 0ull};
     TSM_HIP(hipMemcpy(h->seq_dev, init, sizeof(init), hipMemcpyHostToDevice));
+    TSM_HIP(hipMalloc(reinterpret_cast<void **>(&h->hs_dev), sizeof(float)));
+    h->spin_limit = kSpinLimit;
     TSM_HIP(hipDeviceSynchronize());
     h->peer[rank] = h->local;
     *handle_out = h;
@@ -206,9 +228,34 @@ TSM_EXPORT int tsm_p2p_all_reduce(void *handle, float *data, int64_t n, void *st
     P2PArgs a{};
     a.data = data; a.n = n; a.rank = h->rank; a.world = h->world; a.max_floats = h->max_floats; a.seq_dev = h->seq_dev;
     for (int r = 0; r < h->world; ++r) a.peer[r] = static_cast<char *>(h->peer[r]);
-    a.err = h->err_dev;
+    a.err = h->err_dev; a.spin_limit = h->spin_limit;
     hipLaunchKernelGGL(p2p_all_reduce_kernel, dim3((unsigned)ceil_div(n, kP2PThreads)), dim3(kP2PThreads), 0, tsm_stream(stream), a);
     TSM_LAUNCH_CHECK();
+    return TSM_OK;
+}
+
+// Polls per missing word ~ seconds x 2e7 (a poll is a system-scope load + s_sleep(1), ~50 ns).  Default ~2 s.
+TSM_EXPORT int tsm_p2p_set_timeout(void *handle, double seconds) {
+    TSM_REQUIRE(handle && seconds > 0.0, "tsm_p2p_set_timeout: null handle or non-positive time");
+    static_cast<P2PHandle *>(handle)->spin_limit = (uint64_t)(seconds * 2.0e7) + 1;
+    return TSM_OK;
+}
+
+// First-use handshake: one all-reduce of ONE element holding rank + 1 -- every peer's inbox is written once and every peer's
+// word is awaited once, with the handle's bounded spin.  Synchronises `stream`.  *ok_out = 1 iff no spin timed out AND the sum
+// is world (world + 1) / 2.  Call it on every rank at the same point, outside any stream capture; on 0 the handle is spent
+// (its error word is set): destroy it and use the process group's collective instead.
+TSM_EXPORT int tsm_p2p_handshake(void *handle, int32_t *ok_out, void *stream) {
+    TSM_REQUIRE(handle && ok_out, "tsm_p2p_handshake: null pointer");
+    P2PHandle *h = static_cast<P2PHandle *>(handle);
+    const float mine = (float)(h->rank + 1);
+    TSM_HIP(hipMemcpyAsync(h->hs_dev, &mine, sizeof(float), hipMemcpyHostToDevice, tsm_stream(stream)));
+    TSM_HIP(hipStreamSynchronize(tsm_stream(stream)));   // (`mine` is a stack variable)
+    if (const int rc = tsm_p2p_all_reduce(handle, h->hs_dev, 1, stream); rc != TSM_OK) return rc;
+    float got = 0.f;
+    TSM_HIP(hipMemcpyAsync(&got, h->hs_dev, sizeof(float), hipMemcpyDeviceToHost, tsm_stream(stream)));
+    TSM_HIP(hipStreamSynchronize(tsm_stream(stream)));
+    *ok_out = !tsm_p2p_failed(handle) && got == (float)(h->world * (h->world + 1) / 2);
     return TSM_OK;
 }
 
@@ -228,7 +275,7 @@ TSM_EXPORT int tsm_p2p_adam_step(void *handle, float *param, const float *grad_s
     P2PAdamArgs g{};
     g.c.data = nullptr; g.c.n = n; g.c.rank = h->rank; g.c.world = h->world; g.c.max_floats = h->max_floats; g.c.seq_dev = h->seq_dev;
     for (int r = 0; r < h->world; ++r) g.c.peer[r] = static_cast<char *>(h->peer[r]);
-    g.c.err = h->err_dev;
+    g.c.err = h->err_dev; g.c.spin_limit = h->spin_limit;
     g.p = param; g.m = exp_avg; g.v = exp_avg_sq; g.slabs = grad_slabs; g.n_slab = n_slab;
     g.lr_host = lr; g.lr_dev = lr_dev; g.beta1 = beta1; g.beta2 = beta2; g.step_host = step; g.step_dev = step_dev;
     g.eps = (float)eps; g.weight_decay = (float)weight_decay; g.scale = 1.0f / (float)h->world;
@@ -256,6 +303,7 @@ TSM_EXPORT int tsm_p2p_destroy(void *handle) {
     (void)hipFree(h->local);
     (void)hipFree(h->err_dev);
     (void)hipFree(h->seq_dev);
+    (void)hipFree(h->hs_dev);
     delete h;
     return TSM_OK;
 }

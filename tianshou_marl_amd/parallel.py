@@ -26,41 +26,105 @@ def shard_range(n_total: int, world_size: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def p2p_mode() -> str:
+    """TSM_P2P_ALLREDUCE: "1" = the peer-memory all-reduce is REQUIRED (setup or handshake failure raises), "0" = off (the
+    process group's all-reduce), anything else / unset = "auto": the first-use handshake decides."""
+    return {"1": "on", "0": "off"}.get(os.environ.get("TSM_P2P_ALLREDUCE", "auto"), "auto")
+
+
 class P2PAllReduce:
     """One-shot all-reduce of a small f32 vector over peer-mapped memory (csrc/p2p.hip): every rank stores each element into
     every peer's IPC-mapped inbox as ONE 8-byte word {value, stamp of the call} (no fences, flags or barriers), polls its own
     inbox for the peers' elements and sums the senders in rank order -- ONE launch per call, no ring, the same bits on every
-    rank; `adam_step` is the replica's whole gradient step (slab sum, exchange, Adam) in one launch.  Setup exchanges the IPC
-    handles through the process group (any backend); any failure raises (a data-parallel job must not limp on with one rank
-    on another path).  Opt-in: TSM_P2P_ALLREDUCE=1."""
+    rank; `adam_step` is the replica's whole gradient step (slab sum, exchange, Adam) in one launch.
+    Build it with `P2PAllReduce.negotiate`: setup, a first-use handshake and the ranks' agreement on the outcome."""
 
     def __init__(self, dist, group, device: torch.device, max_floats: int) -> None:
-        import ctypes as C
-
-        from . import _abi
-
         self.dist, self.group = dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.max_floats = int(max_floats)
         self.device = device
-        torch.cuda.set_device(device)
-        h = C.c_void_p()
-        _abi.call("tsm_p2p_create", self.rank, self.world, self.max_floats, C.byref(h))
-        self._h = h
-        nb = int(_abi.call("tsm_p2p_ipc_handle_bytes"))
-        mine = (C.c_ubyte * nb)()
-        _abi.call("tsm_p2p_export", self._h, mine)
+        self._h = None
+
+    @classmethod
+    def negotiate(cls, dist, group, device: torch.device, max_floats: int, timeout_s: float | None = None):
+        """-> a working P2PAllReduce on EVERY rank, or None on every rank.  The phases below issue the same collectives on
+        every rank whatever happens locally (a rank that raised half-way would leave its peers inside a collective), and the
+        ranks agree on each outcome with one MIN all-reduce:
+          1. create the inbox, export its IPC handle              (local; failure -> ok = 0)
+          2. all-gather the handles + the ok flags                 (always)
+          3. map every peer's inbox                                (only if every rank's phase 1 passed)
+          4. agree; barrier (every inbox mapped before the first store)
+          5. handshake: one stamped word per peer each way, bounded spin, outside any capture (csrc/p2p.hip)
+          6. agree.  Any failure: every rank closes its handle and returns None -- the process group's all-reduce serves for
+             the rest of the process (a decision taken once, before anything is captured; never revisited mid-run)."""
+        import ctypes as C
+        import sys
+
+        from . import _abi
+
+        self = cls(dist, group, device, max_floats)
         on_dev = dist.get_backend(group) == "nccl"
-        t = torch.frombuffer(bytearray(mine), dtype=torch.uint8).clone()
+        why = []
+
+        def agree(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_dev else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t.item()))
+
+        nb, mine, ok = 64, None, True
+        try:  # 1
+            torch.cuda.set_device(device)
+            nb = int(_abi.call("tsm_p2p_ipc_handle_bytes"))
+            h = C.c_void_p()
+            _abi.call("tsm_p2p_create", self.rank, self.world, self.max_floats, C.byref(h))
+            self._h = h
+            if timeout_s or os.environ.get("TSM_P2P_TIMEOUT_S"):
+                _abi.call("tsm_p2p_set_timeout", self._h, float(timeout_s or os.environ["TSM_P2P_TIMEOUT_S"]))
+            mine = (C.c_ubyte * nb)()
+            _abi.call("tsm_p2p_export", self._h, mine)
+            if os.environ.get("TSM_P2P_FAIL_SETUP") == str(self.rank):  # (rehearsal of the fall-back: tests)
+                raise RuntimeError("TSM_P2P_FAIL_SETUP")
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            why.append(f"setup: {type(e).__name__}: {e}")
+        t = torch.zeros(nb + 1, dtype=torch.uint8)  # 2: [handle bytes | ok]
+        if ok:
+            t[:nb] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+            t[nb] = 1
         t = t.to(device) if on_dev else t
         gathered = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(gathered, t, group=group)
-        for r, g in enumerate(gathered):
-            if r == self.rank:
-                continue
-            raw = bytes(g.cpu().numpy().tobytes())
-            _abi.call("tsm_p2p_import", self._h, r, (C.c_ubyte * nb).from_buffer_copy(raw))
-        dist.barrier(group=group)  # every rank has mapped every inbox before the first store
+        gathered = [g.cpu() for g in gathered]
+        all_ok = all(int(g[nb]) == 1 for g in gathered)
+        if all_ok:  # 3
+            try:
+                for r, g in enumerate(gathered):
+                    if r != self.rank:
+                        _abi.call("tsm_p2p_import", self._h, r, (C.c_ubyte * nb).from_buffer_copy(bytes(g[:nb].numpy().tobytes())))
+            except Exception as e:  # noqa: BLE001
+                ok = False
+                why.append(f"mapping a peer's inbox: {type(e).__name__}: {e}")
+        all_ok = agree(ok and all_ok)  # 4
+        dist.barrier(group=group)
+        if all_ok:  # 5
+            try:
+                res = C.c_int32(0)
+                if os.environ.get("TSM_P2P_FAIL_HANDSHAKE") != str(self.rank):  # (rehearsal: this rank never sends)
+                    _abi.call("tsm_p2p_handshake", self._h, C.byref(res), _abi.stream_ptr())
+                ok = bool(res.value)
+                if not ok:
+                    why.append("handshake: a peer's word did not arrive within the time limit (or the sum was wrong)")
+            except Exception as e:  # noqa: BLE001
+                ok = False
+                why.append(f"handshake: {type(e).__name__}: {e}")
+            all_ok = agree(ok)  # 6
+        if all_ok:
+            return self
+        self.close()
+        print(f"[rank {self.rank}] peer-memory all-reduce not used" + (": " + "; ".join(why) if why else " (another rank declined)")
+              + " -- gradients take the process group's all-reduce", file=sys.stderr)
+        return None
 
     def all_reduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
         from . import _abi
@@ -139,9 +203,14 @@ class GradSync:
         return (self.p2p is not None and not max_grad_norm and n <= self.p2p.max_floats
                 and os.environ.get("TSM_P2P_FUSED_ADAM", "1") != "0")
 
-    def enable_p2p(self, device: torch.device, max_floats: int) -> None:
-        """Route f32 gradient sums of up to `max_floats` elements through `P2PAllReduce` (setup failures raise)."""
-        self.p2p = P2PAllReduce(self.dist, self.group, device, max_floats)
+    def enable_p2p(self, device: torch.device, max_floats: int, required: bool = False) -> bool:
+        """Route f32 gradient sums of up to `max_floats` elements through `P2PAllReduce` if every rank's setup and first-use
+        handshake pass (`P2PAllReduce.negotiate`: the same decision on every rank); otherwise the process group's all-reduce
+        stays -- or, with `required`, every rank raises."""
+        self.p2p = P2PAllReduce.negotiate(self.dist, self.group, device, max_floats)
+        if self.p2p is None and required:
+            raise RuntimeError("TSM_P2P_ALLREDUCE=1: the peer-memory all-reduce could not be set up on every rank (see stderr)")
+        return self.p2p is not None
 
     def require_equal(self, value: int, what: str) -> None:
         """Every rank must issue the same number of gradient all-reduces per update, or the job deadlocks: env shards of
@@ -327,10 +396,12 @@ def learn_lockstep_graph(jobs, sync: "GradSync", names: list | None = None) -> l
     return [p._learn_finish(w) for (p, _, _, _), w in zip(jobs, ws)]
 
 
-def _want_p2p() -> bool:
-    import os
-
-    return os.environ.get("TSM_P2P_ALLREDUCE", "0") == "1"
+def _maybe_enable_p2p(sync: "GradSync", device: torch.device, max_floats: int) -> None:
+    """TSM_P2P_ALLREDUCE (p2p_mode): on = required, off, auto = the handshake decides.  Peer memory is a one-node mechanism
+    between GPUs: a CPU-only replica (tests) has nothing to map."""
+    mode = p2p_mode()
+    if mode != "off" and device.type == "cuda":
+        sync.enable_p2p(device, max_floats, required=mode == "on")
 
 
 def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) -> GradSync:
@@ -358,8 +429,8 @@ def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) 
                 pol.graph_collectives = False
         if dist.get_backend(group) == "nccl" and seen:
             sync._probe_device = seen[0].net.flat.device
-        if _want_p2p() and seen:  # the packed gradient of every group that can train in one step
-            sync.enable_p2p(seen[0].net.flat.device, sum(p.net.flat.numel() for p in seen))
+        if seen:  # the packed gradient of every group that can train in one step
+            _maybe_enable_p2p(sync, seen[0].net.flat.device, sum(p.net.flat.numel() for p in seen))
         algo._grad_sync = sync
         return sync
     sync.broadcast_(algo.net.flat.data)
@@ -368,8 +439,7 @@ def attach_data_parallel(algo, dist, group=None, global_adv_stats: bool = True) 
     if hasattr(algo.net, "sync_image"):
         algo.net.sync_image()  # the padded LDS image is a cache of `flat`: refresh it behind the broadcast
     algo._grad_sync = sync
-    if _want_p2p():
-        sync.enable_p2p(algo.net.flat.device, algo.net.flat.numel())
+    _maybe_enable_p2p(sync, algo.net.flat.device, algo.net.flat.numel())
     if dist.get_backend(group) == "nccl":
         sync._probe_device = algo.net.flat.device
     # only RCCL ("nccl") collectives can be captured into a hipGraph; with any other backend the update stays on eager
