@@ -459,6 +459,36 @@ def test_critic_rows_kernel_matches_float64_autograd(D, N, Mr, vclip, gen):
     assert torch.equal(slabs, run()[2])  # deterministic
 
 
+@pytest.mark.parametrize("glob,hidden,opts", [(False, (128, 128), {}), (True, (128, 128), dict(value_clip=True, max_grad_norm=0.5)),
+                                              (False, (32, 32), dict(advantage_normalization=False))])
+def test_generic_learn_as_one_graph_replay_equals_eager_launches(glob, hidden, opts):
+    """`GenericPPO.learn(agent_batch)` (what the MARL trainers call, training_coordinator.py:336) from static buffers: the
+    first call of a shape runs the launch sequence eagerly, the second captures it, later ones replay ONE hipGraph -- the same
+    launches in the same order as `learn_steps`, so parameters, optimizer state and the returned losses are bit-identical to
+    a twin that stays on eager launches, over four calls with changing rows (row kernels, dense path, centralized critic)."""
+    N, Dd, n = 3, 18, 700
+    outs = []
+    for graph in (True, False):
+        net = MLPActorCritic(Dd, 5, hidden, critic_obs_dim=N * Dd if glob else None, device=DEV, seed=3)
+        algo = GenericPPO(net=net, critic_input="global" if glob else "local", n_agent=N if glob else 1, shuffle="device", seed=4,
+                          graph=graph, lr=1e-3, **opts)
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        losses = []
+        for it in range(4):
+            r = lambda *sh: torch.randn(*sh, device=DEV, generator=gen)  # noqa: E731
+            b = Batch(obs=r(n, Dd), act=torch.randint(0, 5, (n,), device=DEV, generator=gen), rew=r(n), obs_next=r(n, Dd),
+                      terminated=torch.rand(n, device=DEV, generator=gen) < 0.02, truncated=torch.zeros(n, dtype=torch.bool, device=DEV))
+            if glob:
+                b.global_obs, b.global_obs_next = r(n, N * Dd), r(n, N * Dd)
+            losses.append(dict(algo.learn(b, 256, 2)))
+        if graph:
+            w = next(v for k, v in algo._ws.items() if isinstance(k, tuple) and k and k[0] == "glearn_graph")
+            assert w["warm"] and "graph" in w
+        outs.append((net.flat.data.clone(), algo.exp_avg_sq.clone(), algo.opt_step, losses, int(algo._perm_ctr.item())))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] == 4 * 2 * 2 and a[3] == b[3] and a[4] == b[4] == 8
+
+
 @pytest.mark.parametrize("K1,Mr", [(384, 8192), (384, 77), (96, 1000), (72, 300), (48, 64), (18, 50)])
 def test_critic_step_from_the_fragment_image_is_bit_identical_and_adam_keeps_the_image(K1, Mr):
     """The critic gradient step may take its first-layer weights from a FRAGMENT-ORDER copy (`ops.critic_w1_image`: coalesced

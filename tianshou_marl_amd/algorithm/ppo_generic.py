@@ -556,8 +556,114 @@ class GenericPPO(PPO):
 
     def learn(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs) -> dict[str, float]:
         """One PPO pass on an explicit agent batch (training_coordinator.py:336); a centralized critic takes
-        `batch.global_obs` / `batch.global_obs_next`."""
+        `batch.global_obs` / `batch.global_obs_next`.  With `graph=True`: the call's launch sequence on static buffers --
+        ONE hipGraph replay per call from the second call of a shape on; for a data-parallel replica with its collectives
+        captured (RCCL) or between segmented graphs (`parallel.learn_lockstep_graph`), as `PPO.learn`."""
+        if self.learn_graph_ok(repeat):
+            if self._grad_sync is None:
+                return self._learn_graph(batch, batch_size, repeat)
+            from ..parallel import learn_lockstep_graph, lockstep_graphs_enabled
+
+            if lockstep_graphs_enabled():
+                return learn_lockstep_graph([(self, batch, batch_size, repeat)], self._grad_sync)[0]
         return drive_steps(self.learn_steps(batch, batch_size, repeat, **kwargs), self._grad_sync)
+
+    def learn_graph_ok(self, repeat: int = 1) -> bool:
+        """Can `learn` run from static buffers inside captured graphs?  (`graph` is this class's capture switch; recompute_advantage
+        re-runs the critic between repeats from the host.)"""
+        return bool(self.graph and not (self.recompute_adv and repeat > 1))
+
+    def _learn_static(self, n: int, batch_size: int | None, repeat: int, has_trunc: bool) -> dict:
+        """`PPO._learn_static` for the wide nets: static HBM buffers + `w["body"]`, a generator that issues `learn_steps`' launches
+        (critic passes, log-probabilities, GAE, permutations, advantage statistics, every gradient step) on them -- the same
+        launches in the same order, hence the same bits -- and yields every tensor that has to be summed over the ranks where
+        `learn_steps` reduces it.  Optimizer step count and permutation counter live in HBM.  `w["warm"]`: the first call of a
+        shape runs the body eagerly (one-time kernel attributes, workspaces), later calls capture / replay."""
+        dev, net = self.device, self.net
+        D, Kc, glob = net.obs_dim, net.critic_obs_dim, self.critic_input == "global"
+        dp = self._grad_sync is not None
+        key = ("glearn_graph", n, batch_size, repeat, has_trunc, self.shuffle, dp, ops.kernel_options())
+        w = self._ws.get(key)
+        if w is not None:
+            return w
+        bounds = split_bounds(n, batch_size or -1, merge_last=True)
+        n_steps = repeat * len(bounds)
+        z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
+        w = dict(n=n, n_steps=n_steps, repeat=repeat, has_trunc=has_trunc, warm=False,
+                 obs=z(n, D), obs_next=z(n, D), act=z(n, dt=torch.int32), rew=z(n, 1), term=z(n, 1, dt=torch.uint8),
+                 trunc=z(n, 1, dt=torch.uint8), scal=z(n_steps, 4), step_dev=z(1, dt=torch.int64), perm=z(repeat, n, dt=torch.int64),
+                 mb_start=torch.as_tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=dev))
+        if glob:
+            w.update(joint=z(n, Kc), joint_next=z(n, Kc))
+        defer = self.fused_actor  # row-kernel steps leave their loss partials behind: ONE launch folds them all (as update())
+        if defer:
+            grids = [sum(self._rows_grids(e - s, e - s, self.fused_critic and not glob)) for s, e in bounds]
+            w.update(partial=z(n_steps, max(grids) * 4, dt=torch.float64),
+                     nb_dev=torch.as_tensor(grids * repeat, dtype=torch.int32, device=dev),
+                     M_dev=torch.as_tensor([e - s for s, e in bounds] * repeat, dtype=torch.int64, device=dev))
+
+        def body():
+            self._w1_img_ok = False  # (the parameters may have changed since the last step this object took)
+            obs, act = w["obs"], w["act"]
+            if glob:
+                joint = w["joint"]
+                v_s, v_next = self._critic_values(joint), self._critic_values(w["joint_next"])
+            else:
+                joint = None
+                v_s, v_next = self._critic_values(obs), self._critic_values(w["obs_next"])
+            logp_old, _ = ops.categorical_logp_entropy(FlatMLP.forward(net.actor, obs, save=False), act)
+            ret, adv = ops.gae_lanes(v_s.view(n, 1), v_next.view(n, 1), w["rew"], w["term"], w["trunc"], self.gamma, self.gae_lambda)
+            pb = dict(T=n, rows=None, obs=obs, act=act, v_s=v_s.contiguous(), ret=ret.reshape(-1), adv=adv.reshape(-1),
+                      logp_old=logp_old, n_env=1, n_agent=1, joint=joint)
+            k = 0
+            for r in range(repeat):
+                if self.shuffle != "numpy":
+                    ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, out=w["perm"][r:r + 1])
+                    ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
+                perm = w["perm"][r]
+                stats = (ops.ppo_adv_stats(pb["adv"], w["mb_start"], perm=perm, max_rows=max(e - s for s, e in bounds))
+                         if self.advantage_normalization else None)
+                yield from self._global_adv_stats_steps(stats, w["mb_start"])
+                for j, (s_, e_) in enumerate(bounds):
+                    sc = yield from self._grad_step_steps(pb, perm[s_:e_], None if stats is None else stats[j],
+                                                          step_dev=w["step_dev"], partial_out=w["partial"][k] if defer else None)
+                    if not defer:
+                        w["scal"][k].copy_(sc)
+                    k += 1
+            if defer:
+                ops.ppo_finalize_many(w["partial"], w["partial"].shape[1], w["nb_dev"], w["M_dev"], self._cfg, w["scal"])
+
+        w["body"] = body
+        self._ws[key] = w
+        return w
+
+    def _learn_load(self, w: dict, batch: Batch) -> None:
+        super()._learn_load(w, batch)
+        if "joint" in w:
+            if "global_obs" not in batch:
+                raise ValueError("GenericPPO(critic_input='global').learn needs batch.global_obs / global_obs_next")
+            t = lambda x: x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))  # noqa: E731
+            w["joint"].copy_(t(batch.global_obs).reshape(w["joint"].shape), non_blocking=True)
+            w["joint_next"].copy_(t(batch.global_obs_next).reshape(w["joint"].shape), non_blocking=True)
+
+    def _learn_graph(self, batch: Batch, batch_size: int | None, repeat: int) -> dict[str, float]:
+        """`learn` of a single replica-less policy: eager launches on the static buffers at the first call of a shape, ONE
+        hipGraph replay from the second on."""
+        w = self._learn_static(len(batch.rew), batch_size, repeat, "truncated" in batch)
+        self._learn_load(w, batch)
+        if not w["warm"]:
+            for _ in w["body"]():
+                raise RuntimeError("a single-GPU learn() has no collectives")
+            w["warm"] = True
+            return self._learn_finish(w)
+        if "graph" not in w:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in w["body"]():
+                    raise RuntimeError("a single-GPU learn() has no collectives")
+            w["graph"] = graph
+        w["graph"].replay()
+        return self._learn_finish(w)
 
     def learn_steps(self, batch: Batch, batch_size: int | None = None, repeat: int = 1, **kwargs):
         """`learn` as a generator of gradient synchronisation points: wide nets take part in the lock-step of grouped /

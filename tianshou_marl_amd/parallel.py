@@ -334,7 +334,7 @@ def lockstep_graphs_enabled() -> bool:
 
 def learn_lockstep_graph(jobs, sync: "GradSync", names: list | None = None) -> list:
     """`learn_lockstep` from captured graphs.  jobs = [(policy, batch, batch_size, repeat)], every policy a replica on `sync`
-    that offers `_learn_static / _learn_load / _learn_finish` (PPO).  Each policy's batch goes into ITS static buffers;
+    that offers `_learn_static / _learn_load / _learn_finish` (PPO, GenericPPO).  Each policy's batch goes into ITS static buffers;
     the lock-step of their launch sequences (`_learn_static(...)["body"]`) -- kernels of all groups interleaved, one packed
     reduction per gradient step -- is captured once per (policies, shapes):
       * collectives capturable (RCCL, probe passed: `policy.graph_collectives`): ONE hipGraph with the all-reduces inside;
@@ -349,6 +349,16 @@ def learn_lockstep_graph(jobs, sync: "GradSync", names: list | None = None) -> l
     ws = [p._learn_static(len(b.rew), bs, rep, "truncated" in b) for p, b, bs, rep in jobs]
     for (p, b, _, _), w in zip(jobs, ws):
         p._learn_load(w, b)
+    if not all(w.get("warm", True) for w in ws):
+        # a policy whose launch sequence has not run on these buffers yet (GenericPPO: one-time kernel attributes and
+        # workspaces are set by the first pass): this call is the eager lock-step on the static buffers -- the same launches and
+        # collectives, hence the same bits --, the next one captures
+        res = [None] * len(jobs)
+        for t in lockstep_steps([w["body"]() for w in ws], res, None):
+            sync.all_reduce_sum_(t)
+        for w in ws:
+            w["warm"] = True
+        return [p._learn_finish(w) for (p, _, _, _), w in zip(jobs, ws)]
     inline = all(getattr(p, "graph_collectives", False) for p, _, _, _ in jobs)
     key = (tuple((id(p), id(w)) for (p, _, _, _), w in zip(jobs, ws)), inline)
     cache = sync.__dict__.setdefault("_lockstep_graphs", {})
