@@ -528,7 +528,7 @@ def c3_rooflines(device):
                 "slab_bytes_per_launch": (wc["rest"].numel() + wc["w1"].numel() + wc["dh1"].numel()) * 4,
                 "traffic": (lambda a_, b_: None if a_ is None or b_ is None else a_ + b_)(
                     pmc_traffic("critic_rows_train_kernel", wc["nb"] * 512),
-                    pmc_traffic("critic_dw1_kernel", -(-N * D // 48) * (-(-wc["nc"] // 8) * 8) * 512))})
+                    pmc_traffic("critic_dw1_kernel", -(-N * D // 48) * (-(-wc["nc"] // 8) * 8) * 512))})  # (48-column blocks at this size)
     # (iv) V(row) of the same critic for every joint row of the buffer (the preprocessing's critic pass), one launch
     vout = torch.empty(rows, device=device)
     tot = graph_time(lambda: ops.critic_rows_forward(net.critic.flat.data, joint, H, out=vout), n_rep=5)

@@ -5,7 +5,7 @@
 //
 // Why a pass of its own: accumulated inside the per-tile kernel, every workgroup wrote a full 128 x K1 slab for a rank-32
 // update (196 KB x 256 workgroups = 50 MB per step at K1 = 384, read back by the optimizer).  Here workgroup (cb, rc) owns
-// the 128 x 48 block of columns [48 cb, 48 cb + 48) and sums over the row chunk rc in registers (3 accumulator tiles per wave:
+// the 128 x 48 (or 128 x 96: dw1_nt) block of columns and sums over the row chunk rc in registers (3 / 6 accumulator tiles per wave:
 // wave w owns outputs [16 w, 16 w + 16)), so the reduction over ROWS happens on chip and only n_chunk partial slabs (32 at
 // 8192 rows, K1 = 384) go to memory.  Sub-chunks of 64 rows are staged through LDS (dH1 [64][128], X [64][48]; row pitches =
 // 16 mod 32 floats: the [k = row][lane = column] operand reads are bank-conflict free), the next sub-chunk's rows are in
@@ -147,7 +147,6 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
 
 }  // namespace
 
-constexpr int kDw1Nt = 3;  // column tiles per workgroup (48 columns)
 constexpr size_t kDw1Lds = (size_t)kSub * (kLdA + 112) * sizeof(float) + kSub * sizeof(int64_t);  // 66 048 B
 
 // one-time function attributes (dynamic LDS above 64 KB): outside any stream capture (tsm_critic_rows_init)
@@ -156,7 +155,7 @@ int tsm_critic_dw1_init() {
     if (!done) {
 #define DW1_ATTR(V, T) TSM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(critic_dw1_kernel<V, T>), \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDw1Lds))
-        DW1_ATTR(true, kDw1Nt); DW1_ATTR(false, kDw1Nt);
+        DW1_ATTR(true, 6); DW1_ATTR(false, 6); DW1_ATTR(true, 3); DW1_ATTR(false, 3);
 #undef DW1_ATTR
         done = true;
     }
@@ -165,12 +164,17 @@ int tsm_critic_dw1_init() {
 
 // rows per chunk / number of chunks (= partial slabs of dW1) for Mr rows: a full chip of workgroups, chunks of whole
 // 64-row sub-chunks
-static int dw1_nt() { return kDw1Nt; }
-static int dw1_per_cu() { return 1; }
+// Column tiles per workgroup.  Few rows per CU (the PPO minibatch: 8192 rows over 256 CUs): the launch is a latency chain
+// whatever the split, so 48-column blocks -- half the slabs.  Many rows (CTDEPolicy.learn: 102 400): the MFMA loop is what
+// counts, and 96-column blocks reuse every dH1 operand read for six products instead of three (117.8 vs 143.4 us).
+static int dw1_nt(int64_t Mr, int32_t in_dim) {
+    const int64_t chunks6 = n_cu_dev() / ceil_div(in_dim, 96) > 0 ? n_cu_dev() / ceil_div(in_dim, 96) : 1;
+    return Mr / chunks6 >= 512 ? 6 : 3;
+}
 
 static void dw1_plan(int64_t Mr, int32_t in_dim, int64_t *RC, int *n_chunk) {
-    const int ncb = (int)ceil_div(in_dim, 16 * dw1_nt());
-    int64_t want = (int64_t)n_cu_dev() * dw1_per_cu() / ncb;
+    const int ncb = (int)ceil_div(in_dim, 16 * dw1_nt(Mr, in_dim));
+    int64_t want = (int64_t)n_cu_dev() / ncb;
     if (want < 1) want = 1;
     const int64_t subs = ceil_div(Mr, kSub);
     if (want > subs) want = subs;
@@ -204,12 +208,13 @@ TSM_EXPORT int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int3
     Dw1Args g{};
     g.dh1 = dh1; g.obs = obs_rows; g.rows = rows; g.first_row = first_row; g.Mr = Mr; g.tm_T = tm_T; g.tm_E = tm_E;
     g.K1 = in_dim; g.RC = RC; g.slabs = w1_slabs_out;
-    const int nt = dw1_nt();
+    const int nt = dw1_nt(Mr, in_dim);
     g.ncb = (int)ceil_div(in_dim, 16 * nt); g.n_chunk = n;
     const dim3 grid((unsigned)(g.ncb * ceil_div(n, 8) * 8));
     const bool vec = (in_dim & 3) == 0;
 #define DW1_LAUNCH(V, T) hipLaunchKernelGGL((critic_dw1_kernel<V, T>), grid, dim3(kThreads), kDw1Lds, tsm_stream(stream), g)
-    if (vec) DW1_LAUNCH(true, kDw1Nt); else DW1_LAUNCH(false, kDw1Nt);
+    if (nt == 6) { if (vec) DW1_LAUNCH(true, 6); else DW1_LAUNCH(false, 6); }
+    else { if (vec) DW1_LAUNCH(true, 3); else DW1_LAUNCH(false, 3); }
 #undef DW1_LAUNCH
     TSM_LAUNCH_CHECK();
     return TSM_OK;

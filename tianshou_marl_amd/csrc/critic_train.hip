@@ -216,7 +216,10 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     __syncthreads();          // every thread has read RID
     if (tid < kRows) rid[tid] = id1;
     __syncthreads();
-    if (tile + gs < n_tiles) fetch_tile(tile + gs, 0);   // (uniform: a workgroup with one tile -- the PPO minibatch -- skips it)
+    // (LOSS 0, uniform: a workgroup with one tile -- the PPO minibatch -- skips the next-tile traffic.  LOSS 1 keeps the
+    // unconditional form: its workgroups always have many tiles, and behind a branch the loads are no longer scheduled into the
+    // MFMA phase in front of them: +1.1 us per tile, measured)
+    if (LOSS != 0 || tile + gs < n_tiles) fetch_tile(tile + gs, 0);
     __syncthreads();          // (RID buffer 0 is rewritten at the top of the loop)
 
     int it = 0;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         }
         __syncthreads();  // (A) H1 complete; every wave is done with X; RID / RIDC published
         TSTAMP(1);
-        if (tile + gs < n_tiles) commit_tile();   // the next tile's rows: requested at the end of the previous tile, they flew during L1
+        if (LOSS != 0 || tile + gs < n_tiles) commit_tile();   // the next tile's rows: requested at the end of the previous tile, they flew during L1
         if constexpr (LOSS == 0) {
             if (tid < kRows) id3 = row_of<LOSS>(g, (tile + 4 * gs) * OWN + tid);  // (three tiles ahead)
         }
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         // (requested HERE and not a phase earlier: 24 registers less across the backward phases)
         // (RID buffer it & 1: written at the top of this iteration, published by its barrier (A); the next iteration writes
         // the other buffer, so these reads need no barrier behind them)
-        if (tile + 2 * gs < n_tiles) fetch_tile(tile + 2 * gs, it & 1);
+        if (LOSS != 0 || tile + 2 * gs < n_tiles) fetch_tile(tile + 2 * gs, it & 1);
         TSTAMP(6);
     }
 
