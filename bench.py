@@ -539,7 +539,7 @@ def c3_rooflines(device):
                 "in_situ_us_rocprof": in_situ_us("critic_rows_forward_kernel", "c3ppo", near_us=tot * 1e6),
                 "us_per_launch": tot * 1e6, "achieved": v_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": v_flop / tot / MFMA_F32_PEAK, "algorithmic_bytes_per_launch": (4 * N * D + 4) * rows,
-                "traffic": pmc_traffic("critic_rows_forward_kernel", min(256, -(-rows // 32)) * 512)})
+                "traffic": pmc_traffic("critic_rows_forward_kernel", min(256, -(-rows // 32)) * 512, expect=(4 * N * D + 4) * rows)})
     return out
 
 
