@@ -640,8 +640,20 @@ int tsm_critic_rows_grad_td(const float *critic_params, const float *w1_image, i
 int tsm_ctde_finalize(const double *critic_partial, int32_t nb_c, const double *actor_partial, int32_t nb_a, int64_t B,
                       float *scalars_out, float *mean_adv_out, void *stream);
 int tsm_critic_rows_dw1_chunks(int64_t Mr, int32_t in_dim);
+/* side (nullable, at most 2): gradient-slab sets of OTHER parameter segments, already complete when this launch starts (the
+ * actor step's slabs, the small-gradient slabs of launch (A)), summed to ONE row each by extra workgroups of this launch while
+ * its main workgroups wait on their loads: out[i] = sum over slabs of slabs[s * stride + i] in tsm_adam_step's own order, so
+ * handing `out` to the optimizer as a one-slab segment gives bit-identical gradients -- and the optimizer launch reads 6 MB
+ * instead of 48 (BASELINE configs[2] step). */
+typedef struct tsm_slab_reduce {
+    const float *slabs;
+    int64_t n, stride;
+    int32_t n_slab, _pad;
+    float *out;
+} tsm_slab_reduce;
 int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim, const int64_t *rows, int64_t first_row,
-                        int64_t tm_T, int64_t tm_E, int64_t Mr, int32_t n_chunks, float *w1_slabs_out, void *stream);
+                        int64_t tm_T, int64_t tm_E, int64_t Mr, int32_t n_chunks, float *w1_slabs_out,
+                        const tsm_slab_reduce *side, int32_t n_side, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Latency-grade all-reduce of a small vector over peer-mapped memory  [SURVEY 8e: the 45 KB shared-policy gradient]

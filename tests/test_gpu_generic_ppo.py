@@ -459,6 +459,46 @@ def test_critic_rows_kernel_matches_float64_autograd(D, N, Mr, vclip, gen):
     assert torch.equal(slabs, run()[2])  # deterministic
 
 
+@pytest.mark.parametrize("K1,Mr,n_a,ns_a", [(384, 8192, 23429, 256), (48, 300, 7000, 37), (384, 70000, 130, 3)])
+def test_side_reductions_of_the_dw1_launch_give_the_optimizers_own_sums(K1, Mr, n_a, ns_a):
+    """Extra workgroups of the dW1 launch sum other kernels' complete gradient slabs -- an actor's, and this step's own
+    small-gradient slabs -- to ONE row each while the main workgroups wait on their loads (csrc/critic_dw1.hip), so that the
+    optimizer launch reads a few MB instead of every slab.  Same additions in the same order as the optimizer's own sum: the
+    rows equal `ops.reduce_slabs` bit for bit, and an Adam step over the one-row segments equals the step over the slabs, bit
+    for bit (parameters and both moments), with and without a gradient-norm clip; the dW1 slabs themselves are untouched."""
+    from tianshou_marl_amd import ops
+    from tianshou_marl_amd.utils.net import FlatMLP
+
+    H = 128
+    rng = np.random.default_rng(K1 + Mr)
+    f = FlatMLP([K1, H, H, 1], device=DEV, seed=6)
+    d = lambda x, dt=None: torch.from_numpy(np.ascontiguousarray(x)).to(DEV, dt)  # noqa: E731
+    obs, ret = d(rng.standard_normal((Mr + 5, K1)).astype(np.float32)), d(rng.standard_normal(Mr + 5).astype(np.float32))
+    rows = d(rng.permutation(Mr + 5)[:Mr])
+    cfg = ops.make_ppo_cfg()
+    slabs_a = d((rng.standard_normal((ns_a, n_a + 3)) * 0.1).astype(np.float32))  # (a pitch wider than the segment)
+    w1_plain, rest_plain, _ = [t.clone() for t in ops.critic_rows_grad_ppo(f.flat.data, obs, ret, cfg, 1, H, rows=rows)]
+    n_rest = rest_plain.shape[1]
+    red_a, red_c = torch.zeros(n_a, device=DEV), torch.zeros(n_rest, device=DEV)
+    w1, rest, _ = ops.critic_rows_grad_ppo(f.flat.data, obs, ret, cfg, 1, H, rows=rows,
+                                           side_reduce=[(slabs_a, red_a), ("rest", red_c)])
+    assert torch.equal(w1, w1_plain) and torch.equal(rest, rest_plain)
+    assert torch.equal(red_a, ops.reduce_slabs(slabs_a[:, :n_a].contiguous()))
+    assert torch.equal(red_c, ops.reduce_slabs(rest_plain))
+    nW1 = H * K1
+    n = n_a + nW1 + n_rest
+    for clip in (None, 0.7):
+        outs = []
+        for one_row in (False, True):
+            p, m, v = torch.linspace(-1, 1, n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+            segs = [(red_a.view(1, -1), 0, n_a), (w1, n_a, nW1), (red_c.view(1, -1), n_a + nW1, n_rest)] if one_row else \
+                [(slabs_a, 0, n_a), (w1, n_a, nW1), (rest, n_a + nW1, n_rest)]
+            for step in range(2):
+                ops.adam_step_segs(p, segs, m, v, step + 1, lr=1e-2, max_grad_norm=clip)
+            outs.append((p, m, v))
+        assert all(torch.equal(x, y) for x, y in zip(*outs)), clip
+
+
 @pytest.mark.parametrize("glob,hidden,opts", [(False, (128, 128), {}), (True, (128, 128), dict(value_clip=True, max_grad_norm=0.5)),
                                               (False, (32, 32), dict(advantage_normalization=False))])
 def test_generic_learn_as_one_graph_replay_equals_eager_launches(glob, hidden, opts):

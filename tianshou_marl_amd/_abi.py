@@ -39,6 +39,11 @@ class tsm_slab_seg(C.Structure):
                 ("frag_kj", C.c_int32), ("_pad", C.c_int32)]
 
 
+class tsm_slab_reduce(C.Structure):
+    _fields_ = [("slabs", C.c_void_p), ("n", C.c_int64), ("stride", C.c_int64), ("n_slab", C.c_int32), ("_pad", C.c_int32),
+                ("out", C.c_void_p)]
+
+
 class tsm_mpe_cfg(C.Structure):
     _fields_ = [("n_env", C.c_int32), ("n_agent", C.c_int32), ("max_cycles", C.c_int32), ("_pad", C.c_int32),
                 ("dt", C.c_double), ("damping", C.c_double), ("contact_force", C.c_double),
@@ -191,7 +196,7 @@ SIGNATURES = {
                                        _p, _p]),
     "tsm_critic_rows_dw1_chunks": (_int, [_i64, _i32]),
     "tsm_ctde_finalize": (_int, [_p, _i32, _p, _i32, _i64, _p, _p, _p]),
-    "tsm_critic_rows_dw1": (_int, [_p, _p, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p]),
+    "tsm_critic_rows_dw1": (_int, [_p, _p, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, C.POINTER(tsm_slab_reduce), _i32, _p]),
     "tsm_p2p_ipc_handle_bytes": (_i64, []),
     "tsm_p2p_create": (_int, [_i32, _i32, _i64, C.POINTER(_p)]),
     "tsm_p2p_export": (_int, [_p, _p]),

@@ -283,7 +283,10 @@ class GenericPPO(PPO):
                 slabs_c=None if (crit_rows and self.critic_gen2) else torch.empty(n_split, P_c, dtype=torch.float32, device=dev),
                 partial=torch.zeros((na + nv) * 4, dtype=torch.float64, device=dev),
                 nb=torch.tensor([na + nv], dtype=torch.int32, device=dev), M=torch.tensor([M], dtype=torch.int64, device=dev),
-                flat_g=torch.empty(P_a + P_c, dtype=torch.float32, device=dev))
+                flat_g=torch.empty(P_a + P_c, dtype=torch.float32, device=dev),
+                # the actor's and the critic's small-gradient slabs summed to one row each inside the dW1 launch (side reductions)
+                red_a=torch.empty(1, P_a, dtype=torch.float32, device=dev),
+                red_c=torch.empty(1, P_c - net.critic.dims[1] * net.critic_obs_dim, dtype=torch.float32, device=dev))
         partial = w["partial"] if partial_out is None else partial_out
         if partial.numel() < (na + nv) * 4:
             raise ValueError(f"loss partials: {partial.numel()} values, this step needs {(na + nv) * 4}")
@@ -299,8 +302,11 @@ class GenericPPO(PPO):
                                                     v_s_old=pb["v_s"] if self.value_clip else None,
                                                     rows=rows if rows is not None else idx, Mr=Mr,
                                                     partial=partial[na * 4:(na + nv) * 4], ws=self._ws,
-                                                    w1_image=img if self._w1_img_ok else None)
-            segs_c = [(w1s, P_a, nW1, None, img), (rest, P_a + nW1, P_c - nW1)]
+                                                    w1_image=img if self._w1_img_ok else None,
+                                                    side_reduce=[(w["slabs_a"][:na], w["red_a"][0]), ("rest", w["red_c"][0])])
+            # (the optimizer reads one row per side-reduced segment: the same bits as summing the slabs itself, ops.py)
+            segs_c = [(w1s, P_a, nW1, None, img), (w["red_c"], P_a + nW1, P_c - nW1)]
+            actor_seg = (w["red_a"], 0, P_a)
         elif crit_rows:
             src, N_c = (pb["joint"], pb["n_agent"]) if rows is not None else (pb["obs"], 1)
             ops.ppo_critic_rows_update(net.critic.flat.data, src, pb["ret"], self._cfg, N_c, net.critic.dims[1],
@@ -319,7 +325,8 @@ class GenericPPO(PPO):
             net.critic.backward(dvalue.view(-1, 1), n_split, slabs=w["slabs_c"], slab_stride=P_c)
         if step_dev is None:
             self.opt_step += 1
-        segs = [(w["slabs_a"][:na], 0, P_a)] + (segs_c or [(w["slabs_c"][:n_split], P_a, P_c)])
+        segs = [actor_seg if crit_rows and self.critic_gen2 else (w["slabs_a"][:na], 0, P_a)] + \
+            (segs_c or [(w["slabs_c"][:n_split], P_a, P_c)])
         hyper = dict(lr=self.lr, lr_dev=self._lr_dev, betas=self.betas, eps=self.adam_eps, weight_decay=self.weight_decay,
                      step_dev=step_dev)
         if self._grad_sync is None:

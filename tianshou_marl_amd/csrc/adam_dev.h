@@ -18,30 +18,37 @@ __device__ __forceinline__ double ipow(double b, int64_t e) {
     return r;
 }
 
-// `n` = parameters covered (bounds), `stride` = floats between two consecutive slabs
+// One lane's share of a parameter's slab sum: slabs sl, sl + 4, sl + 8, ... added sequentially in that order (16 independent
+// loads in flight; 32 measured no faster).  `stride` = floats between two consecutive slabs.
+__device__ __forceinline__ float slab_lane_sum(const float *__restrict__ slabs, int32_t n_slab, int64_t i, int64_t stride, int sl) {
+    float acc = 0.f;
+    int s = sl;
+#pragma unroll 1
+    for (; s + 60 < n_slab; s += 64) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += t[u];
+    }
+    for (; s + 28 < n_slab; s += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; s < n_slab; s += 4) acc += slabs[(int64_t)s * stride + i];
+    return acc;
+}
+
+// `n` = parameters covered (bounds).  256 threads = 64 parameters x 4 slab lanes; the lanes' sums meet in LDS as
+// ((l0 + l1) + l2) + l3 -- ONE summation order for every consumer of gradient slabs (adam.hip, p2p.hip, the side reductions of
+// critic_dw1.hip), so that where a sum is formed does not change its bits.
 __device__ __forceinline__ float slab_sum_block(const float *__restrict__ slabs, int32_t n_slab, int64_t n,
                                                 int64_t i, float *sm /* [4][64] */, int64_t stride) {
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    float acc = 0.f;
-    if (i < n) {
-        int s = sl;
-#pragma unroll 1
-        for (; s + 60 < n_slab; s += 64) {  // 16 independent loads in flight per lane (32 measured no faster)
-            float t[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc += t[u];
-        }
-        for (; s + 28 < n_slab; s += 32) {
-            float t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += t[u];
-        }
-        for (; s < n_slab; s += 4) acc += slabs[(int64_t)s * stride + i];
-    }
+    const float acc = i < n ? slab_lane_sum(slabs, n_slab, i, stride, sl) : 0.f;
     sm[sl * 64 + lane] = acc;
     __syncthreads();
     return sm[lane] + sm[64 + lane] + sm[128 + lane] + sm[192 + lane];

@@ -15,6 +15,7 @@
 // is a latency chain (ids -> rows -> LDS -> 5.6 us of MFMA -> slab) that no split shortens, so the form with the FEWEST slab
 // bytes is the one kept: half the writes here and half the optimizer's reads of them (12.6 -> 6.3 MB each).
 #include "critic_rows_dev.h"
+#include "adam_dev.h"
 
 namespace {
 
@@ -31,7 +32,55 @@ struct Dw1Args {
     int64_t RC;              // rows per chunk (a multiple of 64)
     int ncb, n_chunk;        // column blocks, row chunks
     float *slabs;            // [n_chunk][128 K1]
+    // side reductions (see below): workgroups >= n_main sum gradient slabs of OTHER parameter segments into one row each
+    struct Side { const float *slabs; int64_t n, stride; int32_t n_slab, first_blk; float *out; } side[2];
+    int n_side, n_main;
 };
+
+// Side reductions.  The launch is a latency chain (row ids -> rows -> LDS -> 5.6 us of MFMA -> slab) that leaves most of the
+// memory system idle, while the optimizer launch behind it is bandwidth-bound on reading every kernel's gradient slabs (54 MB
+// at the C3 step: 14 us).  Workgroups behind the main grid therefore sum slab sets that are already complete -- the actor
+// step's and the critic's small-gradient slabs -- down to ONE row each while the main workgroups wait on their loads: the
+// optimizer then reads 6 MB instead of 48.  128 parameters per workgroup as two independent halves of 256 threads; per
+// parameter the additions are slab_sum_block's in the same order, and a one-row "slab set" passes through the optimizer's own
+// sum unchanged (x + 0 + 0 + 0), so the gradient has the same bits wherever the sum is formed.
+__device__ __forceinline__ void dw1_side_reduce(const Dw1Args &g, int b, float *lds) {
+    const int k = (g.n_side > 1 && b >= g.side[1].first_blk) ? 1 : 0;
+    const Dw1Args::Side sr = g.side[k];
+    // 64 parameters per workgroup on its first four waves (the other four have nothing to load): a workgroup's share of HBM bandwidth
+    // is ~17 KB / us when every CU streams, so 64 KB per workgroup keeps two to three of them inside the main workgroups' 13 us
+    // (128 parameters per workgroup: 20.1 us for the launch; this form: measured below)
+    const int tid = threadIdx.x, half = 0, lane = tid & 63, sl = (tid >> 6) & 3;
+    const bool active = tid < 256;   // (waves 4..7 only meet the barrier)
+    const int64_t i = active ? (int64_t)(b - sr.first_blk) * kCols + lane : sr.n;
+    // (slab_lane_sum's additions, sequentially over slabs sl, sl + 4, ..., with 32 loads in flight instead of 16: these
+    // workgroups are few and latency-bound, the optimizer's own loop is bandwidth-bound)
+    float acc = 0.f;
+    if (i < sr.n) {
+        const float *__restrict__ base = sr.slabs + i;
+        int s = sl;
+#pragma unroll 1
+        for (; s + 124 < sr.n_slab; s += 128) {
+            float t[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) t[u] = base[(int64_t)(s + 4 * u) * sr.stride];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += t[u];
+        }
+        for (; s + 28 < sr.n_slab; s += 32) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = base[(int64_t)(s + 4 * u) * sr.stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += t[u];
+        }
+        for (; s < sr.n_slab; s += 4) acc += base[(int64_t)s * sr.stride];
+    }
+    float *sm = lds + half * 256;
+    if (active) sm[sl * 64 + lane] = acc;
+    __syncthreads();
+    if (active && sl == 0 && i < sr.n) sr.out[i] = sm[lane] + sm[64 + lane] + sm[128 + lane] + sm[192 + lane];
+}
 
 __device__ __forceinline__ int64_t dw1_row_of(const Dw1Args &g, int64_t i) {
     const int64_t ic = i < g.Mr ? i : g.Mr - 1;
@@ -49,6 +98,10 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
     // XCD-aware block -> (column block, row chunk) map: workgroups are dealt round-robin over the 8 XCDs (each with an L2 of its
     // own), and the ncb workgroups of one row chunk read the SAME dH1 rows -- give them ids that differ by multiples of 8, so
     // that they share an L2 and the chunk leaves memory once instead of ncb times (speed / traffic only: any placement is correct)
+    if ((int)blockIdx.x >= g.n_main) {   // (uniform per workgroup)
+        dw1_side_reduce(g, (int)blockIdx.x - g.n_main, lds);
+        return;
+    }
     const int ncb = g.ncb, bid = blockIdx.x;
     const int rc_lo = bid & 7, t_ = bid >> 3, cb = t_ % ncb, rc = (t_ / ncb) * 8 + rc_lo;
     if (rc >= g.n_chunk) return;   // (the grid is padded to whole groups of 8 chunks)
@@ -192,7 +245,7 @@ TSM_EXPORT int tsm_critic_rows_dw1_chunks(int64_t Mr, int32_t in_dim) {
 
 TSM_EXPORT int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim, const int64_t *rows,
                                    int64_t first_row, int64_t tm_T, int64_t tm_E, int64_t Mr, int32_t n_chunks,
-                                   float *w1_slabs_out, void *stream) {
+                                   float *w1_slabs_out, const tsm_slab_reduce *side_host, int32_t n_side, void *stream) {
     TSM_REQUIRE(in_dim >= 1 && in_dim <= 384 && ((in_dim & 3) == 0 || in_dim <= 64) && Mr >= 1,
                 "tsm_critic_rows_dw1: in_dim = %d (<= 384, a multiple of 4 above 64), Mr = %lld", in_dim, (long long)Mr);
     TSM_REQUIRE(dh1 && obs_rows && w1_slabs_out, "tsm_critic_rows_dw1: null pointer");
@@ -210,7 +263,18 @@ TSM_EXPORT int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int3
     g.K1 = in_dim; g.RC = RC; g.slabs = w1_slabs_out;
     const int nt = dw1_nt(Mr, in_dim);
     g.ncb = (int)ceil_div(in_dim, 16 * nt); g.n_chunk = n;
-    const dim3 grid((unsigned)(g.ncb * ceil_div(n, 8) * 8));
+    g.n_main = (int)(g.ncb * ceil_div(n, 8) * 8);
+    TSM_REQUIRE(n_side >= 0 && n_side <= 2 && (n_side == 0 || side_host), "tsm_critic_rows_dw1: at most two side reductions");
+    int side_blocks = 0;
+    for (int k = 0; k < n_side; ++k) {
+        const tsm_slab_reduce &r = side_host[k];
+        TSM_REQUIRE(r.slabs && r.out && r.n >= 1 && r.n_slab >= 1 && r.stride >= r.n, "tsm_critic_rows_dw1: bad side reduction %d", k);
+        g.side[k].slabs = r.slabs; g.side[k].n = r.n; g.side[k].stride = r.stride; g.side[k].n_slab = r.n_slab; g.side[k].out = r.out;
+        g.side[k].first_blk = side_blocks;
+        side_blocks += (int)ceil_div(r.n, kCols);
+    }
+    g.n_side = n_side;
+    const dim3 grid((unsigned)(g.n_main + side_blocks));
     const bool vec = (in_dim & 3) == 0;
 #define DW1_LAUNCH(V, T) hipLaunchKernelGGL((critic_dw1_kernel<V, T>), grid, dim3(kThreads), kDw1Lds, tsm_stream(stream), g)
     if (nt == 6) { if (vec) DW1_LAUNCH(true, 6); else DW1_LAUNCH(false, 6); }

@@ -700,12 +700,30 @@ def _critic_grad_ws(K1: int, hidden: int, n_out: int, Mr: int, td: bool, dev, ws
     return w
 
 
+def _side_reductions(side):
+    """[(slabs [n_slab, stride >= n], out [n]), ...] (at most two) -> (ctypes array or None, count): slab sets summed to one
+    row each by extra workgroups of the dW1 launch (include/tsmarl.h: tsm_slab_reduce)."""
+    if not side:
+        return None, 0
+    if len(side) > 2:
+        raise ValueError("at most two side reductions ride on the dW1 launch")
+    arr = (_abi.tsm_slab_reduce * len(side))()
+    for k, (sl, out) in enumerate(side):
+        sl, out = _chk(sl, torch.float32, "side slabs"), _chk(out, torch.float32, "side out")
+        if sl.dim() != 2 or out.numel() > sl.shape[1]:
+            raise ValueError("side reduction: slabs [n_slab, >= n] and out [n] expected")
+        arr[k] = _abi.tsm_slab_reduce(ptr(sl), out.numel(), int(sl.shape[1]), int(sl.shape[0]), 0, ptr(out))
+    return arr, len(side)
+
+
 def critic_rows_grad_ppo(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n_agent: int, hidden: int = 128, v_s_old=None,
-                         rows=None, first_row=0, Mr=None, partial=None, ws: dict | None = None, w1_image=None):
+                         rows=None, first_row=0, Mr=None, partial=None, ws: dict | None = None, w1_image=None, side_reduce=None):
     """Critic half of one PPO gradient step on joint rows in two launches -> (w1_slabs [n_chunks, H * in_dim],
     rest_slabs [n_blocks, P - H * in_dim], partial f64 [n_blocks * 4] = {0, sum vf, 0, 0} per workgroup): feed the two slab
     arrays to `adam_step_segs` as segments (W1 first).  `partial`: where to leave the loss partials (>= n_blocks * 4).
-    w1_image: the first-layer weights in fragment order (`critic_w1_image`; must hold the values of critic_params' w0)."""
+    w1_image: the first-layer weights in fragment order (`critic_w1_image`; must hold the values of critic_params' w0).
+    side_reduce: [(slabs, out), ...] -- other kernels' complete slab sets summed to one row each inside the dW1 launch; an
+    entry whose slabs is the string "rest" names this step's own rest slabs."""
     obs_rows = _chk(obs_rows, torch.float32, "obs_rows")
     K1 = obs_rows.shape[-1]
     if Mr is None:
@@ -722,8 +740,10 @@ def critic_rows_grad_ppo(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n_a
     call("tsm_critic_rows_grad_ppo", ptr(_chk(critic_params, torch.float32, "critic_params")), ptr(w1_image), K1, hidden, n_agent,
          ptr(obs_rows), ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old), ptr(rows), first_row, Mr, C.byref(cfg),
          w["nb"], ptr(w["dh1"]), ptr(w["rest"]), ptr(part), stream_ptr())
+    side = [(w["rest"] if isinstance(sl, str) else sl, out) for sl, out in (side_reduce or [])]
+    arr, n_side = _side_reductions(side)
     call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(obs_rows), K1, ptr(rows), first_row, 0, 0, Mr, w["nc"], ptr(w["w1"]),
-         stream_ptr())
+         arr, n_side, stream_ptr())
     return w["w1"], w["rest"], part
 
 
@@ -750,7 +770,7 @@ def critic_rows_grad_td(critic_params, joint_store, T: int, E: int, rew, termina
          ptr(_chk(v_last, torch.float32, "v_last")), ptr(None if v_next_full is None else _chk(v_next_full, torch.float32, "v_next_full")),
          ptr(None if use_full is None else _chk(use_full, torch.int32, "use_full")), float(gamma), w["nb"], ptr(w["dh1"]),
          ptr(w["rest"]), ptr(part), stream_ptr())
-    call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(joint_store), K1, None, 0, T, E, B, w["nc"], ptr(w["w1"]), stream_ptr())
+    call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(joint_store), K1, None, 0, T, E, B, w["nc"], ptr(w["w1"]), None, 0, stream_ptr())
     return w["w1"], w["rest"], part
 
 

@@ -28,7 +28,7 @@ for dbg, name in ((0, "4 x 96 columns, 64 chunks"), (4, "8 x 48 columns, 32 chun
     ws = {}
     t = gtime(lambda: ops.critic_rows_grad_ppo(f.flat.data, joint, ret, cfg, N, H, rows=rid, Mr=Mr, ws=ws, w1_image=img))
     w = next(iter(ws.values()))
-    t2 = gtime(lambda: ops.call("tsm_critic_rows_dw1", ops.ptr(w["dh1"]), ops.ptr(joint), N * D, ops.ptr(rid), 0, 0, 0, Mr, w["nc"], ops.ptr(w["w1"]), ops.stream_ptr()))
+    t2 = gtime(lambda: ops.call("tsm_critic_rows_dw1", ops.ptr(w["dh1"]), ops.ptr(joint), N * D, ops.ptr(rid), 0, 0, 0, Mr, w["nc"], ops.ptr(w["w1"]), None, 0, ops.stream_ptr()))
     print(f"critic pair with dW1 as {name}: {t:.2f} us; dw1 alone back to back {t2:.2f} us; slabs {w['nc']}")
 ops.set_kernel_option("dbg", 0)
 # segmented Adam at the C3 step's slab sets: actor 256 x 23429, dW1 64 x 49152, rest 256 x 17025
