@@ -71,15 +71,30 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
     const int D = g.D, A = g.A, ld1 = ly.ld1;
     const int64_t n_tiles = (g.M + kRows - 1) / kRows;
     if (g.opt_step_dev && blockIdx.x == 0 && tid == 0) *g.opt_step_dev += 1;  // the gradient step this launch opens
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[200] = (long long)wall_clock64();
     const int oX = opaque_s(ly.X), oH1 = opaque_s(ly.H1), oH2 = opaque_s(ly.H2), oLG = opaque_s(ly.LG), oW1l = opaque_s(ly.W1),
               oW3l = opaque_s(ly.W3);
     const int col = 16 * w + c16;
 
     // ---- stage the weights once (zero pads: W1 columns >= D, W3 rows >= A); W2 passes through LDS into registers ----
     const int oW1 = 0, oB1 = kH * D, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + A * kH;
-    for (int e = tid; e < kH * ld1; e += kThreads) {
-        const int r = e / ld1, c = e - r * ld1;
-        lds[ly.W1 + e] = c < D ? g.P[oW1 + r * D + c] : 0.f;
+    // (W1 and W3 as BATCHES of loads, all in flight before the first LDS store: written as plain load -> store loops they ran
+    // one memory round trip per iteration, 13 + 5 of them -- most of an 8.4 us prologue, tools/stamp_actor_rows.py)
+    constexpr int kLd1 = 16 * NJ + 2, kN1 = (kH * kLd1 + kThreads - 1) / kThreads, kN3 = (16 * kLdh + kThreads - 1) / kThreads;
+    float w1q[kN1], w3q[kN3];
+#pragma unroll
+    for (int u = 0; u < kN1; ++u) {
+        const int e = tid + u * kThreads, r = e / kLd1, c = e - r * kLd1;
+        const bool ok = e < kH * kLd1 && c < D;
+        const float v = g.P[ok ? oW1 + r * D + c : 0];   // (clamped, always-valid address + select: no divergent branch)
+        w1q[u] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kN3; ++u) {
+        const int e = tid + u * kThreads, r = e / kLdh, c = e - r * kLdh;
+        const bool ok = e < 16 * kLdh && r < A && c < kH;
+        const float v = g.P[ok ? oW3 + r * kH + c : 0];
+        w3q[u] = ok ? v : 0.f;
     }
     {
         float *dst = lds + ly.U;
@@ -99,9 +114,15 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
             for (int e = tid; e < kH * kH; e += kThreads) dst[(e >> 7) * kLdh + (e & 127)] = src[e];
         }
     }
-    for (int e = tid; e < 16 * kLdh; e += kThreads) {
-        const int r = e / kLdh, c = e - r * kLdh;
-        lds[ly.W3 + e] = (r < A && c < kH) ? g.P[oW3 + r * kH + c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < kN1; ++u) {
+        const int e = tid + u * kThreads;
+        if (e < kH * kLd1) lds[ly.W1 + e] = w1q[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kN3; ++u) {
+        const int e = tid + u * kThreads;
+        if (e < 16 * kLdh) lds[ly.W3 + e] = w3q[u];
     }
     if (tid < kH) { lds[ly.B1 + tid] = g.P[oB1 + tid]; lds[ly.B2 + tid] = g.P[oB2 + tid]; }
     if (tid < 16) lds[ly.B3 + tid] = tid < A ? g.P[oB3 + tid] : 0.f;
@@ -180,6 +201,7 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
     fetch_ids(tile + gridDim.x);
     __syncthreads();  // every wave holds its W2 fragments: region U is free for the activations
 
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[201] = (long long)wall_clock64();
     for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
         ASTAMP(0);
         // ---- P0: commit the prefetched X tile (the previous tile's readers are behind the loop-end barrier) ----
@@ -371,6 +393,7 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
     }
 
     // ---- the workgroup's gradient slab: written once, streamed (consumed once, by the reduction kernel) ----
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[202] = (long long)wall_clock64();
     float *slab = g.slabs + (size_t)blockIdx.x * (size_t)(oB3 + A);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -413,6 +436,7 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
             g.partial[4 * blockIdx.x + 1] = 0.0;
             g.partial[4 * blockIdx.x + 2] = ee;
             g.partial[4 * blockIdx.x + 3] = 0.0;
+            if (g.stamps && blockIdx.x == 0) g.stamps[203] = (long long)wall_clock64();
         }
     }
 }

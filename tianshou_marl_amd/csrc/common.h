@@ -64,6 +64,31 @@ static inline hipError_t tsm_allow_max_lds(const void *kernel) {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Stage a row-major global matrix (rows_ok x cols_ok, row pitch src_ld) into an LDS array of n_dst floats laid out in rows of
+// `ld` floats; everything outside the matrix is zeroed.  EIGHT loads per thread are in flight before the first LDS store: the
+// plain `for (e = tid; ...) lds[e] = src[...]` form of this loop pays one memory round trip per iteration (the compiler cannot
+// hoist loads over LDS stores it cannot prove disjoint) -- 13 iterations for a 128 x 48 layer, most of an 8 us kernel prologue.
+// All threads of the NT-thread workgroup call it; no barrier inside.
+template <int NT>
+__device__ __forceinline__ void tsm_stage_padded(float *dst, const float *__restrict__ src, int n_dst, int ld, int rows_ok,
+                                                 int cols_ok, int src_ld) {
+    for (int e0 = 0; e0 < n_dst; e0 += 8 * NT) {
+        float q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + (int)threadIdx.x + u * NT, r = e / ld, c = e - r * ld;
+            const bool ok = e < n_dst && r < rows_ok && c < cols_ok;
+            const float v = src[ok ? r * src_ld + c : 0];   // clamped, always-valid address + select: no divergent branch
+            q[u] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + (int)threadIdx.x + u * NT;
+            if (e < n_dst) dst[e] = q[u];
+        }
+    }
+}
+
 // ---- wave / block reductions (64-wide) ----
 // 16-lane rows of a wave are DPP rows: row-wide rotate / broadcast are plain VALU operand modifiers (no LDS crossbar
 // round trip as for ds_bpermute).  dpp_ctrl: row_ror:n = 0x120 + n, row_newbcast:n = 0x150 + n (gfx90a+).

@@ -151,6 +151,19 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     }
     float4 w2q[8];            // W2 requested here, stored to LDS after the first tile's rows have been requested too (requesting
     w2_load(w2q, g.P + oW2);  // it BEHIND the rows was measured 1 us slower: the LDS stores then wait for the rows as well)
+    // W3 (rows >= n_out zero) and the biases as one BATCH of loads in flight (a load -> LDS-store loop pays a memory round trip
+    // per iteration: five of them here)
+    constexpr int kN3 = (16 * kLdh + kThreads - 1) / kThreads;
+    float w3q[kN3], bq1 = 0.f, bq2 = 0.f, bq3 = 0.f;
+#pragma unroll
+    for (int u = 0; u < kN3; ++u) {
+        const int e = tid + u * kThreads, r = e / kLdh, c = e - r * kLdh;
+        const bool ok = e < 16 * kLdh && r < n_out && c < kH;
+        const float v = g.P[ok ? oW3 + r * kH + c : 0];   // (clamped, always-valid address + select)
+        w3q[u] = ok ? v : 0.f;
+    }
+    if (tid < kH) { bq1 = g.P[oB1 + tid]; bq2 = g.P[oB2 + tid]; }
+    if (tid < 16) bq3 = tid < n_out ? g.P[oB3 + tid] : 0.f;
 
     // ---- staging of a tile (as csrc/critic_rows.hip): thread -> chunks q = tid + 512 u of the 32 x (4 KJ) chunk grid ----
     constexpr int CPR = 4 * KJ;
@@ -206,12 +219,13 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     fetch_tile(tile, 0);      // the first tile's rows are in flight behind the weights ...
     // ---- resident weights: W2, W3 (rows >= n_out zero), biases ----
     w2_store(lds + ly.W2, w2q);
-    for (int e = tid; e < 16 * kLdh; e += kThreads) {
-        const int r = e / kLdh, c = e - r * kLdh;
-        lds[ly.W3 + e] = (r < n_out && c < kH) ? g.P[oW3 + r * kH + c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < kN3; ++u) {
+        const int e = tid + u * kThreads;
+        if (e < 16 * kLdh) lds[ly.W3 + e] = w3q[u];
     }
-    if (tid < kH) { lds[ly.B1 + tid] = g.P[oB1 + tid]; lds[ly.B2 + tid] = g.P[oB2 + tid]; }
-    if (tid < 16) lds[ly.B3 + tid] = tid < n_out ? g.P[oB3 + tid] : 0.f;
+    if (tid < kH) { lds[ly.B1 + tid] = bq1; lds[ly.B2 + tid] = bq2; }
+    if (tid < 16) lds[ly.B3 + tid] = bq3;
     commit_tile();
     __syncthreads();          // every thread has read RID
     if (tid < kRows) rid[tid] = id1;

@@ -91,15 +91,9 @@ __global__ __launch_bounds__(kThreads) void ppo_actor_rows_kernel(ActorArgs g) {
 
     // ---- stage the weights once (zero pads: W1 columns >= D, W3 rows >= A) ----
     const int oW1 = 0, oB1 = kH * D, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + A * kH;
-    for (int e = tid; e < kH * ld1; e += kThreads) {
-        const int r = e / ld1, c = e - r * ld1;
-        lds[ly.W1 + e] = c < D ? g.P[oW1 + r * D + c] : 0.f;
-    }
+    tsm_stage_padded<kThreads>(lds + ly.W1, g.P + oW1, kH * ld1, ld1, kH, D, D);
     stage_w2(lds + ly.W2, g.P + oW2, (oW2 & 3) == 0);
-    for (int e = tid; e < 16 * kLdh; e += kThreads) {
-        const int r = e / kLdh, c = e - r * kLdh;
-        lds[ly.W3 + e] = (r < A && c < kH) ? g.P[oW3 + r * kH + c] : 0.f;
-    }
+    tsm_stage_padded<kThreads>(lds + ly.W3, g.P + oW3, 16 * kLdh, kLdh, A, kH, kH);
     if (tid < kH) { lds[ly.B1 + tid] = g.P[oB1 + tid]; lds[ly.B2 + tid] = g.P[oB2 + tid]; }
     if (tid < 16) lds[ly.B3 + tid] = tid < A ? g.P[oB3 + tid] : 0.f;
 

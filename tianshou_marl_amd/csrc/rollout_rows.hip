@@ -118,18 +118,9 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
 
     // ---- weights into LDS once (zero pads: W1 columns >= D, W3 rows >= A) ----
     const int oB1 = kH * D, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + A * kH;
-    for (int e = tid; e < kH * ld1; e += kThreads) {
-        const int r = e / ld1, cc = e - r * ld1;
-        lds[ly.W1 + e] = cc < D ? a.P[r * D + cc] : 0.f;
-    }
-    for (int e = tid; e < kH * kLdh; e += kThreads) {
-        const int r = e / kLdh, cc = e - r * kLdh;
-        lds[ly.W2 + e] = cc < kH ? a.P[oW2 + r * kH + cc] : 0.f;
-    }
-    for (int e = tid; e < 16 * kLdh; e += kThreads) {
-        const int r = e / kLdh, cc = e - r * kLdh;
-        lds[ly.W3 + e] = (r < A && cc < kH) ? a.P[oW3 + r * kH + cc] : 0.f;
-    }
+    tsm_stage_padded<kThreads>(lds + ly.W1, a.P, kH * ld1, ld1, kH, D, D);            // (batched loads: common.h)
+    tsm_stage_padded<kThreads>(lds + ly.W2, a.P + oW2, kH * kLdh, kLdh, kH, kH, kH);
+    tsm_stage_padded<kThreads>(lds + ly.W3, a.P + oW3, 16 * kLdh, kLdh, A, kH, kH);
     if (tid < kH) { lds[ly.B1 + tid] = a.P[oB1 + tid]; lds[ly.B2 + tid] = a.P[oB2 + tid]; }
     if (tid < 16) lds[ly.B3 + tid] = tid < A ? a.P[oB3 + tid] : 0.f;
     for (int i = tid; i < kTile * ld1; i += kThreads) lds[ly.X + i] = 0.f;

@@ -39,7 +39,11 @@ ops.ppo_actor_rows_update(net.actor.flat.data, obs, act, lp, adv, cfg, A, H, adv
                           slabs=slabs, partial=part)
 torch.cuda.synchronize()
 lib.tsm_debug_set_stamps(None)
-s = st.cpu().numpy()[:64].reshape(4, 16)
+sa = st.cpu().numpy()
+if sa[201] > sa[200] > 0:  # (the 64-sample kernel stamps its prologue and epilogue too)
+    print(f"prologue (weights -> LDS / registers, first ids and rows) {(sa[201] - sa[200]) / 100.0:.2f} us; slab + statistics after the last tile "
+          f"{(sa[203] - sa[202]) / 100.0:.2f} us; kernel entry -> exit of workgroup 0 {(sa[203] - sa[200]) / 100.0:.2f} us")
+s = sa[:64].reshape(4, 16)
 names = ["P0 commit X", "P1 layer 1", "P2 layer 2", "P3 logits", "P4 loss head (16 lanes per sample)", "P5 dW3 + dH2 mfma", "dH2 write",
          "P6 dW2 + dH1 mfma", "dH1 write", "P7 dW1"]
 for it in range(1, 4):
