@@ -517,6 +517,8 @@ def c3_rooflines(device):
     out.append({"kernel": "critic_rows_train_kernel<24> + critic_dw1_kernel (centralized critic 384-128-128-1 on joint rows: "
                           "forward + value loss of the row's 8 agents + backward, dW1 as a split-K pass; two launches)",
                 "us_per_launch_w1_gathered": tot_gather * 1e6,
+                "in_situ_note": "in the update the dW1 launch also carries the side reductions (actor + small critic slabs -> one row "
+                                "each) that the optimizer launch shed: dW1 14 -> 20 us, adam_segs 14 -> 5 us per step",
                 "rows": mr, "samples": mb, "bound": "mfma", "flop_per_launch": c_flop,
                 "timing": "back_to_back (graph of 10 launch pairs, HIP events)",
                 "in_situ_us_rocprof": (lambda a_, b_: None if a_ is None or b_ is None else round(a_ + b_, 3))(
