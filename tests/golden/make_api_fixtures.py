@@ -41,9 +41,9 @@ from tianshou.algorithm.multiagent.ctde import CentralizedCritic, CTDEPolicy, De
 from tianshou.algorithm.multiagent.flexible_policy import FlexibleMultiAgentPolicyManager  # noqa: E402
 from tianshou.algorithm.multiagent.marl import MapTrainingStats, MultiAgentPolicy  # noqa: E402
 from tianshou.algorithm.optim import AdamOptimizerFactory, LRSchedulerFactoryLinear  # noqa: E402
-from tianshou.data import Batch, Collector, CollectStats, ReplayBuffer, ReplayBufferManager, VectorReplayBuffer  # noqa: E402
+from tianshou.data import AsyncCollector, Batch, Collector, CollectStats, ReplayBuffer, ReplayBufferManager, VectorReplayBuffer  # noqa: E402
 from tianshou.data.stats import SequenceSummaryStats  # noqa: E402
-from tianshou.env.venvs import BaseVectorEnv  # noqa: E402
+from tianshou.env.venvs import BaseVectorEnv, DummyVectorEnv  # noqa: E402
 from tianshou.trainer.trainer import OnPolicyTrainerParams  # noqa: E402
 from tianshou.utils.net.common import MLP, ActorCritic, Net  # noqa: E402
 from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic  # noqa: E402
@@ -79,6 +79,9 @@ def make_api_surface() -> None:
             "Collector.reset_env": sig(Collector.reset_env),
             "Collector.reset_buffer": sig(Collector.reset_buffer),
             "Collector.reset_stat": sig(Collector.reset_stat),
+            "AsyncCollector.__init__": sig(AsyncCollector.__init__),
+            "AsyncCollector.reset": sig(AsyncCollector.reset),
+            "AsyncCollector.reset_env": sig(AsyncCollector.reset_env),
             "VectorReplayBuffer.__init__": sig(VectorReplayBuffer.__init__),
             "ReplayBufferManager.add": sig(ReplayBufferManager.add),
             "ReplayBufferManager.sample_indices": sig(ReplayBufferManager.sample_indices),
@@ -105,6 +108,7 @@ def make_api_surface() -> None:
             "LRSchedulerFactoryLinear.__init__": sig(LRSchedulerFactoryLinear.__init__),
             "BaseVectorEnv.reset": sig(BaseVectorEnv.reset),
             "BaseVectorEnv.step": sig(BaseVectorEnv.step),
+            "DummyVectorEnv.__init__": sig(DummyVectorEnv.__init__),
             "MultiAgentPolicy.forward": sig(MultiAgentPolicy.forward),
             "FlexibleMultiAgentPolicyManager.__init__": sig(FlexibleMultiAgentPolicyManager.__init__),
             "CTDEPolicy.__init__": sig(CTDEPolicy.__init__),

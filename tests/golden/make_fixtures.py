@@ -23,6 +23,7 @@ Each fixture holds inputs + the reference's outputs for one hot-path function
                    laid out as a time-major store: every agent's learn() in turn, with and without episodes ending mid-store
                    [a16, a17]
   ctde_c3.npz      the same at configs[2]'s own widths: N = 8, D = 48 (critic input 384, 8 outputs)   [a16, a17]
+  async_collector.npz  AsyncCollector over an async vector env with scripted readiness: statistics, ready sets, buffer rows  [(f)4]
   misc.npz         Batch.split bounds, RunningMeanStd, episode_mc_return_to_go   [a11, a14]
 """
 from __future__ import annotations
@@ -632,6 +633,101 @@ def make_ctde_c3() -> None:
 
 
 # ------------------------------------------------------------------------------------------------
+sys.path.insert(0, HERE)
+from async_script import scripted_ready  # noqa: E402  (shared with the replay test)
+
+
+def make_async_collector() -> None:
+    """AsyncCollector (collector.py:1116-1394) over an async vector env whose readiness is SCRIPTED (`scripted_ready`, through the
+    worker class's `wait`, venvs.py:301): four MoveToRight envs of lengths 2..5, wait_num 3, a policy that always moves right.
+    A sequence of collect(n_episode=...) / collect(n_step=...) calls; after each: the statistics and the ready set; at the end
+    the whole buffer."""
+    from tianshou.data import AsyncCollector
+    from tianshou.env import BaseVectorEnv
+    from tianshou.env.worker import DummyEnvWorker
+
+    class MoveToRight(gym.Env):
+        def __init__(self, size):
+            self.size, self.index = size, 0
+            self.action_space = gym.spaces.Discrete(2)
+            self.observation_space = gym.spaces.Box(0, size, (1,))
+
+        def reset(self, seed=None, options=None):
+            self.index = 0
+            return np.array([self.index], np.float32), {"key": 1}
+
+        def step(self, action):
+            self.index = self.index + 1 if int(action) == 1 else max(0, self.index - 1)
+            done = self.index == self.size
+            return np.array([self.index], np.float32), float(done) * (self.size + 1), done, False, {"key": 1}
+
+    calls = [0]
+
+    class ScriptedWorker(DummyEnvWorker):
+        @staticmethod
+        def wait(workers, wait_num, timeout=None):
+            pos = scripted_ready(len(workers), wait_num, calls[0])
+            calls[0] += 1
+            return [workers[p_] for p_ in pos]
+
+    class RightPolicy(Policy):
+        """Always moves right; its `policy` entry tags every action with (forward call number, position in the call): the stored
+        rows then show that act / policy entries are the ones handed out for THAT env, whichever call's step returned it."""
+
+        def __init__(self):
+            super().__init__(action_space=gym.spaces.Discrete(2))
+            self.calls = 0
+
+        def forward(self, batch, state=None, **kw):
+            self.calls += 1
+            n = len(batch.obs)
+            # (a hidden state is returned because the reference's AsyncCollector cannot run without one: collector.py:1337 indexes
+            # `_current_hidden_state_in_all_envs_EH` unconditionally -- quirk Q8; the build's AsyncCollector has no such need)
+            return Batch(act=np.ones(n, np.int64), state=np.zeros((n, 1), np.float32),
+                         policy=Batch(logp=(self.calls * 10.0 + np.arange(n)).astype(np.float32)))
+
+    sizes = [2, 3, 4, 5]
+    venv = BaseVectorEnv([lambda s=s: MoveToRight(s) for s in sizes], ScriptedWorker, wait_num=3)
+    assert venv.is_async
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        col = AsyncCollector(RightPolicy(), venv, VectorReplayBuffer(total_size=240, buffer_num=4))
+    col.reset()
+    trace = []  # env ids handed to / returned by every venv.step call: the interleaving itself
+    orig_step = venv.step
+
+    def logged_step(action, id=None):  # noqa: A002
+        out_ = orig_step(action, id)
+        trace.append((list(np.asarray(id).tolist()) if id is not None else [], [int(i["env_id"]) for i in out_[-1]]))
+        return out_
+
+    venv.step = logged_step
+    plan = [("n_episode", 1), ("n_episode", 3), ("n_step", 1), ("n_step", 5), ("n_episode", 2), ("n_step", 7), ("n_step", 10),
+            ("n_episode", 4)]
+    out = dict(sizes=np.array(sizes), wait_num=np.int64(3), plan_kind=np.array([k for k, _ in plan]),
+               plan_n=np.array([n for _, n in plan]))
+    for i, (kind, n) in enumerate(plan):
+        st = col.collect(**{kind: n})
+        out[f"c{i}_steps"], out[f"c{i}_episodes"] = np.int64(st.n_collected_steps), np.int64(st.n_collected_episodes)
+        out[f"c{i}_lens"], out[f"c{i}_returns"] = np.asarray(st.lens, np.int64), np.asarray(st.returns, np.float64)
+        out[f"c{i}_ready"] = np.asarray(col._ready_env_ids_R, np.int64)
+        out[f"c{i}_len_buf"] = np.int64(len(col.buffer))
+        out[f"c{i}_waiting"] = np.asarray(sorted(venv.waiting_id), np.int64)
+    buf = col.buffer
+    idx = buf.sample_indices(0)
+    b = buf[idx]
+    out.update(indices=idx, obs=np.asarray(b.obs), obs_next=np.asarray(b.obs_next), act=np.asarray(b.act), rew=np.asarray(b.rew),
+               terminated=np.asarray(b.terminated), truncated=np.asarray(b.truncated), done=np.asarray(b.done),
+               env_id=np.asarray(b.info.env_id), policy_tag=np.asarray(b.policy.logp), wait_calls=np.int64(calls[0]),
+               trace_sent=np.array([x for snt, _ in trace for x in snt + [-1]], np.int64),
+               trace_returned=np.array([x for _, ret in trace for x in ret + [-1]], np.int64),
+               collect_step=np.int64(col.collect_step), collect_episode=np.int64(col.collect_episode))
+    save("async_collector.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def make_misc() -> None:
     out = {}
     rows = []
@@ -662,6 +758,6 @@ def make_misc() -> None:
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "ppo_update_wide", "pg_update", "marl_dispatch", "ctde", "ctde_wide",
-                             "ctde_c3", "misc"]
+                             "ctde_c3", "async_collector", "misc"]
     for w in which:
         globals()["make_" + w]()

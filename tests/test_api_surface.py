@@ -36,6 +36,9 @@ MIRROR = {
     "Collector.reset_env": t_collector.Collector.reset_env,
     "Collector.reset_buffer": t_collector.Collector.reset_buffer,
     "Collector.reset_stat": t_collector.Collector.reset_stat,
+    "AsyncCollector.__init__": t_collector.AsyncCollector.__init__,
+    "AsyncCollector.reset": t_collector.AsyncCollector.reset,
+    "AsyncCollector.reset_env": t_collector.AsyncCollector.reset_env,
     "VectorReplayBuffer.__init__": t_buffer.VectorReplayBuffer.__init__,
     "ReplayBufferManager.add": t_buffer.DeviceVectorReplayBuffer.add,
     "ReplayBufferManager.sample_indices": t_buffer.DeviceVectorReplayBuffer.sample_indices,
@@ -62,6 +65,7 @@ MIRROR = {
     "LRSchedulerFactoryLinear.__init__": t_optim.LRSchedulerFactoryLinear.__init__,
     "BaseVectorEnv.reset": t_venvs.BaseVectorEnv.reset,
     "BaseVectorEnv.step": t_venvs.BaseVectorEnv.step,
+    "DummyVectorEnv.__init__": t_venvs.DummyVectorEnv.__init__,
     "MultiAgentPolicy.forward": t_marl.MultiAgentPolicy.forward,
     "FlexibleMultiAgentPolicyManager.__init__": t_flex.FlexibleMultiAgentPolicyManager.__init__,
     "CTDEPolicy.__init__": t_ctde.CTDEPolicy.__init__,

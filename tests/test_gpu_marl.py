@@ -3,6 +3,7 @@ MultiAgentPolicy / FlexibleMultiAgentPolicyManager dispatch vs the reference fix
 algorithms through MARLDispatcher, the trainers' `.learn()` on device batches, and the reference-style HOST
 collect loop (DummyVectorEnv of parallel-mode envs = BASELINE configs[0]) feeding the device buffer."""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -349,6 +350,86 @@ def test_collector_known_answer_layout_of_the_reference():
     assert np.allclose(live.rew[:, 0], [0, 1, 0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1])
     with pytest.raises(ValueError):
         Collector(MaxActionPolicy(), venv, DeviceVectorReplayBuffer(9, 3, n_agent=1, obs_dim=1, device=DEV))
+
+
+def test_async_collector_replays_the_reference_run(golden_dir):
+    """`AsyncCollector` (collector.py:1116-1394) against the REFERENCE's own run (tests/golden/async_collector.npz): four envs of
+    lengths 2..5 behind an async vector env (wait_num 3) whose readiness follows one script on both sides
+    (tests/golden/async_script.py), a policy that tags every action with (forward call, position).  After each of eight
+    collect(n_episode / n_step) calls: collected steps and episodes, episode lengths and returns, the ready set and the envs
+    still stepping; at the end every buffer row -- obs, act, the policy tag handed out for THAT env, obs_next, reward, flags --
+    in the reference's `sample_indices(0)` order, and the collector's counters.  Bit-exact (integers and small floats)."""
+    import sys
+
+    sys.path.insert(0, golden_dir)
+    from async_script import scripted_ready
+
+    from tianshou_marl_amd.data import AsyncCollector
+
+    g = np.load(os.path.join(golden_dir, "async_collector.npz"))
+
+    class Env(MoveToRight):
+        def step(self, action):
+            obs, _, done, trunc, info = super().step(action)
+            return [obs, float(done) * (self.size + 1), done, trunc, info]  # (the fixture's reward: size + 1 at the end)
+
+    class TagPolicy(torch.nn.Module):
+        calls = 0
+
+        def forward(self, batch, state=None, **kw):
+            self.calls += 1
+            n = len(batch.obs)
+            return Batch(act=np.ones(n, np.int64), policy=Batch(logp=(self.calls * 10.0 + np.arange(n)).astype(np.float32).reshape(n, 1)))
+
+    venv = DummyVectorEnv([lambda s=int(s): Env(s) for s in g["sizes"]], wait_num=int(g["wait_num"]))
+    assert venv.is_async
+    calls = [0]
+
+    def selector(waiting, wait_num):
+        pos = scripted_ready(len(waiting), wait_num, calls[0])
+        calls[0] += 1
+        return pos
+
+    venv.ready_selector = selector
+    sent, returned, orig_step = [], [], venv.step
+
+    def logged_step(action, id=None):  # noqa: A002  (the interleaving itself: env ids handed to / returned by every step call)
+        out = orig_step(action, id)
+        sent.extend([*(np.asarray(id).tolist() if id is not None else []), -1])
+        returned.extend([*(int(i["env_id"]) for i in out[-1]), -1])
+        return out
+
+    venv.step = logged_step
+    buf = DeviceVectorReplayBuffer(240, 4, n_agent=1, obs_dim=1, device=DEV)
+    with pytest.warns(UserWarning, match="extra transitions"):
+        col = AsyncCollector(TagPolicy(), venv, buf)
+    col.reset()
+    with pytest.raises(ValueError):
+        col.collect()
+    for i, (kind, n) in enumerate(zip(g["plan_kind"], g["plan_n"])):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # (n_step not a multiple of the env count: as in the reference run)
+            st = col.collect(**{str(kind): int(n)})
+        assert (st.n_collected_steps, st.n_collected_episodes) == (int(g[f"c{i}_steps"]), int(g[f"c{i}_episodes"])), i
+        assert np.array_equal(st.lens, g[f"c{i}_lens"]) and np.array_equal(st.returns, g[f"c{i}_returns"]), i
+        assert np.array_equal(col._ready, g[f"c{i}_ready"]) and sorted(venv.waiting_id) == g[f"c{i}_waiting"].tolist(), i
+        assert len(buf) == int(g[f"c{i}_len_buf"]), i
+    assert calls[0] == int(g["wait_calls"])
+    assert sent == g["trace_sent"].tolist() and returned == g["trace_returned"].tolist()
+    assert (col.collect_step, col.collect_episode) == (int(g["collect_step"]), int(g["collect_episode"]))
+    idx = buf.sample_indices(0)
+    assert np.array_equal(idx, g["indices"])
+    b = buf[idx]
+    assert np.array_equal(b.obs[:, 0, 0], g["obs"][:, 0]) and np.array_equal(b.obs_next[:, 0, 0], g["obs_next"][:, 0])
+    assert np.array_equal(b.act[:, 0], g["act"]) and np.array_equal(b.rew[:, 0], g["rew"])
+    assert np.array_equal(b.terminated[:, 0], g["terminated"]) and np.array_equal(b.truncated[:, 0], g["truncated"])
+    assert np.array_equal(b.done, g["done"])
+    assert np.array_equal(b.policy.logp[:, 0], g["policy_tag"])          # the entry handed out for that env at action time
+    assert np.array_equal(idx // (240 // 4), g["env_id"])                # rows sit in their env's sub-buffer
+    # a fresh reset fetches the env that is still stepping before it resets (collector.py:1188-1196)
+    assert venv.waiting_id
+    col.reset()
+    assert venv.waiting_id == [] and np.array_equal(col._ready, np.arange(4)) and len(buf) == 0
 
 
 @pytest.mark.parametrize("shuffle,batch_size,repeat,opts", [

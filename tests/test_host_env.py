@@ -176,8 +176,37 @@ def test_dummy_vector_env_contract():
     venv.close()
     with pytest.raises(AssertionError):
         venv.reset()
-    with pytest.raises(NotImplementedError):
-        DummyVectorEnv([TinyParallel, TinyParallel], wait_num=1)
+
+
+def test_vector_env_async_protocol():
+    """venvs.py:269-309 with the in-process worker: `step(action, id)` hands actions to the envs in `id` and returns the results
+    of whichever envs are ready (`ready_selector`: all of them by default, as the reference's DummyEnvWorker.wait; scripted here),
+    `step(None)` fetches unfinished calls, envs that are stepping may not be touched."""
+    mk = lambda: EnhancedPettingZooEnv(TinyParallel(), mode="parallel")  # noqa: E731
+    av = DummyVectorEnv([mk, mk, mk], wait_num=2)
+    assert av.is_async and av.wait_num == 2 and DummyVectorEnv([mk, mk]).is_async is False
+    av.reset()
+    act = np.tile(np.array([1, 1, 1]), (3, 1))
+    obs, rew, term, trunc, info = av.step(act, [0, 1, 2])           # default selector: every waiting env returns
+    assert [i["env_id"] for i in info] == [0, 1, 2] and av.waiting_id == [] and rew.shape == (3, 3)
+    av.ready_selector = lambda waiting, k: list(range(min(k, len(waiting))))  # script: the first wait_num waiting envs return
+    obs, rew, term, trunc, info = av.step(act, [0, 1, 2])
+    assert [i["env_id"] for i in info] == [0, 1] and av.waiting_id == [2] and sorted(av.ready_id) == [0, 1]
+    with pytest.raises(AssertionError, match="stepping now"):
+        av.reset(env_id=[2])
+    with pytest.raises(AssertionError, match="stepping now"):
+        av.step(act[:1], [2])
+    obs, rew, term, trunc, info = av.step(act[:1], [1])             # env 1 steps again; env 2 (waiting longer) + env 1 return
+    assert [i["env_id"] for i in info] == [2, 1] and av.waiting_id == [] and sorted(av.ready_id) == [0, 1, 2]
+    av.ready_selector = lambda waiting, k: [len(waiting) - 1]       # script: only the env that has waited least returns
+    out = av.step(act[:2], [0, 2])
+    assert [i["env_id"] for i in out[-1]] == [2] and av.waiting_id == [0]
+    out = av.step(None)                                              # fetch unfinished calls only
+    assert [i["env_id"] for i in out[-1]] == [0] and av.waiting_id == [] and sorted(av.ready_id) == [0, 1, 2]
+    with pytest.raises(RuntimeError):
+        av.step(None)                                                # nothing is stepping
+    with pytest.raises(AssertionError):
+        DummyVectorEnv([mk, mk], wait_num=3)
 
 
 def test_vector_env_aec_rows_stack():
