@@ -593,6 +593,11 @@ class GenericPPO(PPO):
         w = self._ws.get(key)
         if w is not None:
             return w
+        # (callers whose batch length changes from call to call -- n_episode collection -- would otherwise grow one set of static
+        # buffers and one graph per length without bound: keep the eight most recent shapes)
+        old = [k for k in self._ws if isinstance(k, tuple) and k and k[0] == "glearn_graph"]
+        for k in old[:-7]:
+            del self._ws[k]
         bounds = split_bounds(n, batch_size or -1, merge_last=True)
         n_steps = repeat * len(bounds)
         z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
