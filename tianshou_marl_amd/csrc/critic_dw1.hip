@@ -10,7 +10,7 @@
 // 8192 rows, K1 = 384) go to memory.  Sub-chunks of 64 rows are staged through LDS (dH1 [64][128], X [64][48]; row pitches =
 // 16 mod 32 floats: the [k = row][lane = column] operand reads are bank-conflict free), the next sub-chunk's rows are in
 // flight in registers meanwhile, their ids one sub-chunk further ahead.
-// Round 4 (tools/dbg/pair_time.py, 8192 rows of 384, launch alone back to back): 4 x 96 columns x 64 chunks 13.4 us; 8 x 48
+// Round 4 (an experiment build of tools/critic_pair_time.py, 8192 rows of 384, launch alone back to back): 4 x 96 columns x 64 chunks 13.4 us; 8 x 48
 // columns x 32 chunks 13.6 us; the same x 64 chunks (two workgroups per CU) 12.9 us; 4 x 96 x 128 chunks 13.5 us -- the launch
 // is a latency chain (ids -> rows -> LDS -> 5.6 us of MFMA -> slab) that no split shortens, so the form with the FEWEST slab
 // bytes is the one kept: half the writes here and half the optimizer's reads of them (12.6 -> 6.3 MB each).

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     }
     // ---- this wave's fragment of W1, once, into registers: from the fragment image when there is one (1 KB of consecutive
     // bytes per wave instruction; the gather from the row-major matrix touches sixteen 1.5 KB rows per 16-lane group and
-    // costs 3.8 us more at K1 = 384: tools/dbg/critic_prologue.py) ----
+    // costs 3.8 us more at K1 = 384: profiles/r04_critic_prologue_experiment.txt) ----
     f4 w1f[KJ];
     if (g.w1_img) {
 #pragma unroll

@@ -1,3 +1,6 @@
+#!/usr/bin/env bash
+# (GPU box, from the repo root) rocprofv3 kernel trace of a few steps of the C3 PPO job -> the in-situ timeline of its gradient
+# steps (tools/step_timeline.py) and of one whole step.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/tl
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o t -- python3 bench.py --workload c3ppo --steps 5 --warmup 3 > /dev/null 2> gpurun_out/tl.err
