@@ -298,7 +298,7 @@ int tsm_adam_step(float *param, const float *grad_slabs, int32_t n_slab, int64_t
  * parameter offset + i, i < n, in slab s is slabs[s * stride + i].  One launch for the whole vector; with
  * max_grad_norm > 0 one reduction launch in front and ONE norm over all segments (clip_grad_norm_ over
  * ActorCritic.parameters(), algorithm_base.py:485-498). */
-#define TSM_MAX_SLAB_SEGS 4
+#define TSM_MAX_SLAB_SEGS 6
 typedef struct tsm_slab_seg {
     const float *slabs;
     int64_t offset, n, stride;
@@ -595,6 +595,9 @@ int tsm_critic_rows_forward(const float *critic_params, int32_t in_dim, int32_t 
  *     the layer-1 weights resident in registers and the observation tile in LDS (csrc/critic_train.hip).
  *       dh1_out [Mr][128] (minibatch row order); rest_slabs_out [n_blocks][P - 128 in_dim]: the gradients of
  *       b1 | W2 | b2 | W3 | b3 (parameter order), one slab per workgroup; n_blocks = tsm_critic_rows_grad_grid(Mr, td).
+ *       _ppo with h1_out / dh2_out (nullable pair, [Mr][128] each): the launch PUBLISHES the layer-1 activations and
+ *       d loss / d (layer-2 pre-activation) instead of forming dW2 itself -- the W2 part of every rest slab is then NOT written
+ *       (hand the optimizer b1 and b2 | W3 | b3 as views into the slabs, and dW2 from launch (B)).
  *     _ppo  Replaces  the value term of PPO._update_with_batch (ppo.py:198-212) on joint rows, as tsm_ppo_critic_rows_update:
  *           loss_partial_out f64 [n_blocks][4] = {0, sum of the value-loss terms, 0, 0}.
  *     _td   Replaces  values = critic(global_obs).mean(1); values_next = critic(global_obs_next).mean(1);
@@ -626,7 +629,7 @@ int tsm_critic_rows_grad_grid(int64_t Mr, int32_t td);
 int tsm_critic_rows_grad_ppo(const float *critic_params, const float *w1_image, int32_t in_dim, int32_t hidden, int32_t n_agent,
                              const float *obs_rows, const float *returns, const float *v_s_old, const int64_t *rows,
                              int64_t first_row, int64_t Mr, const tsm_ppo_cfg *cfg, int32_t n_blocks, float *dh1_out,
-                             float *rest_slabs_out, double *loss_partial_out, void *stream);
+                             float *h1_out, float *dh2_out, float *rest_slabs_out, double *loss_partial_out, void *stream);
 int tsm_critic_rows_grad_td(const float *critic_params, const float *w1_image, int32_t in_dim, int32_t hidden, int32_t n_out,
                             const float *joint_rows, int64_t T, int64_t E, const float *rew, const uint8_t *terminated,
                             int64_t scalar_stride, int64_t scalar_offset, const float *v_last, const float *v_next_full,
@@ -651,8 +654,13 @@ typedef struct tsm_slab_reduce {
     int32_t n_slab, _pad;
     float *out;
 } tsm_slab_reduce;
+/* dh2 / h1 / w2_slabs_out (nullable triple): the SECOND layer's weight gradient as extra column blocks of the same launch,
+ * dW2 = dH2^T H1 over the same row chunks, from the activations launch (A) published in minibatch order
+ * (tsm_critic_rows_grad_ppo: h1_out, dh2_out): w2_slabs_out [n_chunks][128 x 128].  Launch (A) then keeps no W2 gradient --
+ * a rank-32 update per 32-row tile stored as a 64 KB slab (17 MB per BASELINE configs[2] step) becomes 32 chunk slabs (2 MB). */
 int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim, const int64_t *rows, int64_t first_row,
                         int64_t tm_T, int64_t tm_E, int64_t Mr, int32_t n_chunks, float *w1_slabs_out,
+                        const float *dh2, const float *h1, float *w2_slabs_out,
                         const tsm_slab_reduce *side, int32_t n_side, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -400,14 +400,15 @@ def test_actor_rows_kernel_matches_float64_autograd(D, A, M, variant):
     assert torch.equal(slabs, slabs2)
 
 
-@pytest.mark.parametrize("gen", [1, 2])
+@pytest.mark.parametrize("gen", [1, 2, 3])
 @pytest.mark.parametrize("D,N,Mr,vclip", [(48, 8, 1000, True), (18, 1, 300, False), (18, 3, 77, True), (48, 8, 8192, False),
                                           (6, 2, 32, False), (20, 4, 2100, True)])
 def test_critic_rows_kernel_matches_float64_autograd(D, N, Mr, vclip, gen):
     """Critic: value = MLP(joint row), value term (with / without clipping) for the row's N agents and the critic's backward
     pass vs float64 autograd.  gen 1: csrc/ppo_rows.hip, one launch, layer-1 weights streamed in 32-column slices, a full
     gradient slab per workgroup; gen 2: csrc/critic_train.hip + critic_dw1.hip (weights in registers, dW1 as a split-K
-    pass over the published dH1): two slab arrays, W1 | rest."""
+    pass over the published dH1): two slab arrays, W1 | rest; gen 3 (round 4, opt-in: less traffic, 2 us slower): dW2 in the split-K pass too
+    (published H1 / dH2), three slab arrays."""
     from tianshou_marl_amd import ops
     from tianshou_marl_amd.utils.net import FlatMLP
 
@@ -426,10 +427,22 @@ def test_critic_rows_kernel_matches_float64_autograd(D, N, Mr, vclip, gen):
             sl, part = ops.ppo_critic_rows_update(f.flat.data, d(obs), d(ret), cfg, N, H, v_s_old=d(v_old) if vclip else None,
                                                   rows=d(rows))
             return sl.double().sum(0), part, sl
+        ws: dict = {}
         w1, rest, part = ops.critic_rows_grad_ppo(f.flat.data, d(obs), d(ret), cfg, N, H, v_s_old=d(v_old) if vclip else None,
-                                                  rows=d(rows))
+                                                  rows=d(rows), ws=ws, split_dw2=gen == 3)
         assert w1.shape[1] == H * K1 and w1.shape[1] + rest.shape[1] == f.flat.numel()
-        return torch.cat([w1.double().sum(0), rest.double().sum(0)]), part, torch.cat([w1.reshape(-1), rest.reshape(-1)]).clone()
+        g_rest, extra = rest.double().sum(0), []
+        if gen == 3:  # gen 3: dW2 from the split-K pass (published H1 / dH2); the W2 columns of the rest slabs are never written
+            w2 = next(iter(ws.values()))["w2"]
+            assert torch.count_nonzero(rest[:, H:H + H * H]) == 0 and w2.shape[1] == H * H
+            g_rest[H:H + H * H] += w2.double().sum(0)
+            extra = [w2.reshape(-1)]
+            # the optimizer's segments for this mode tile the critic's parameters exactly once
+            segs = ops.critic_grad_segs(next(iter(ws.values())), 0, K1, H, 1)
+            assert [sg[1] for sg in segs] == [0, H * K1, H * K1 + H, H * K1 + H + H * H] and sum(sg[2] for sg in segs) == f.flat.numel()
+            flat_g = ops.reduce_slabs_segs(segs, f.flat.numel())
+            assert torch.allclose(flat_g.double(), torch.cat([w1.double().sum(0), g_rest]), rtol=1e-4, atol=1e-7)
+        return torch.cat([w1.double().sum(0), g_rest]), part, torch.cat([w1.reshape(-1), rest.reshape(-1), *extra]).clone()
 
     g_sum, partial, slabs = run()
     lins = []

@@ -191,12 +191,13 @@ SIGNATURES = {
     "tsm_critic_rows_w1_image_kj": (_int, [_i32]),
     "tsm_critic_rows_w1_image_elems": (_i64, [_i32]),
     "tsm_critic_rows_w1_image": (_int, [_p, _i32, _p, _p]),
-    "tsm_critic_rows_grad_ppo": (_int, [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i64, C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p, _p]),
+    "tsm_critic_rows_grad_ppo": (_int, [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _i64, C.POINTER(tsm_ppo_cfg), _i32, _p, _p, _p,
+                                        _p, _p, _p]),
     "tsm_critic_rows_grad_td": (_int, [_p, _p, _i32, _i32, _i32, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _p, _f64, _i32, _p, _p,
                                        _p, _p]),
     "tsm_critic_rows_dw1_chunks": (_int, [_i64, _i32]),
     "tsm_ctde_finalize": (_int, [_p, _i32, _p, _i32, _i64, _p, _p, _p]),
-    "tsm_critic_rows_dw1": (_int, [_p, _p, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, C.POINTER(tsm_slab_reduce), _i32, _p]),
+    "tsm_critic_rows_dw1": (_int, [_p, _p, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, C.POINTER(tsm_slab_reduce), _i32, _p]),
     "tsm_p2p_ipc_handle_bytes": (_i64, []),
     "tsm_p2p_create": (_int, [_i32, _i32, _i64, C.POINTER(_p)]),
     "tsm_p2p_export": (_int, [_p, _p]),

@@ -76,6 +76,10 @@ class GenericPPO(PPO):
         # second generation of the critic step (csrc/critic_train.hip + critic_dw1.hip: two launches, dW1 as a split-K pass)
         self.critic_gen2 = self.fused_critic and os.environ.get("TSM_CRITIC_GEN", "2") != "1" and \
             ops.critic_rows_grad_supported(net.critic_obs_dim, net.critic.dims[1:-1], 1, net.critic.act)
+        # ... optionally with dW2 formed by the split-K pass too (round 4 experiment, TSM_CRITIC_SPLIT_DW2=1: 14 MB less HBM
+        # traffic per step but 2 us SLOWER -- the latency-bound dW1 launch grows by more than the tile kernel shrinks; DESIGN.md
+        # section 4), default: a rank-32 dW2 slab per tile, side-reduced inside the dW1 launch
+        self.split_dw2 = self.critic_gen2 and os.environ.get("TSM_CRITIC_SPLIT_DW2", "0") == "1"
         # ... and V(row) of such a critic for all rows of a pass in one launch (csrc/critic_rows.hip) instead of three GEMMs
         self.fused_values = bool(fused_actor) and net.critic.dims[-1] == 1 and ops.critic_rows_forward_supported(
             net.critic_obs_dim, net.critic.dims[1:-1], 1, net.critic.act)
@@ -298,14 +302,19 @@ class GenericPPO(PPO):
             src, N_c = (pb["joint"], pb["n_agent"]) if rows is not None else (pb["obs"], 1)
             nW1 = net.critic.dims[1] * net.critic_obs_dim
             img = self._w1_img if self._grad_sync is None else None  # (kept in step by the segmented Adam launch only)
-            w1s, rest, _ = ops.critic_rows_grad_ppo(net.critic.flat.data, src, pb["ret"], self._cfg, N_c, net.critic.dims[1],
-                                                    v_s_old=pb["v_s"] if self.value_clip else None,
-                                                    rows=rows if rows is not None else idx, Mr=Mr,
-                                                    partial=partial[na * 4:(na + nv) * 4], ws=self._ws,
-                                                    w1_image=img if self._w1_img_ok else None,
-                                                    side_reduce=[(w["slabs_a"][:na], w["red_a"][0]), ("rest", w["red_c"][0])])
+            split = self.split_dw2
+            # side reductions inside the dW1 launch: the actor's slabs always; the critic's small-gradient slabs only while they
+            # still carry dW2 (split mode leaves 385 floats per slab: the optimizer reads those directly)
+            side = [(w["slabs_a"][:na], w["red_a"][0])] + ([] if split else [("rest", w["red_c"][0])])
+            ops.critic_rows_grad_ppo(net.critic.flat.data, src, pb["ret"], self._cfg, N_c, net.critic.dims[1],
+                                     v_s_old=pb["v_s"] if self.value_clip else None,
+                                     rows=rows if rows is not None else idx, Mr=Mr,
+                                     partial=partial[na * 4:(na + nv) * 4], ws=self._ws,
+                                     w1_image=img if self._w1_img_ok else None, side_reduce=side, split_dw2=split)
+            cw = self._ws[("critic_grad", net.critic_obs_dim, net.critic.dims[1], 1, Mr, False, split)]
             # (the optimizer reads one row per side-reduced segment: the same bits as summing the slabs itself, ops.py)
-            segs_c = [(w1s, P_a, nW1, None, img), (w["red_c"], P_a + nW1, P_c - nW1)]
+            segs_c = ops.critic_grad_segs(cw, P_a, net.critic_obs_dim, net.critic.dims[1], 1, w1_image=img,
+                                          rest_row=None if split else w["red_c"])
             actor_seg = (w["red_a"], 0, P_a)
         elif crit_rows:
             src, N_c = (pb["joint"], pb["n_agent"]) if rows is not None else (pb["obs"], 1)

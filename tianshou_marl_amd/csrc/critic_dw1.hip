@@ -32,6 +32,11 @@ struct Dw1Args {
     int64_t RC;              // rows per chunk (a multiple of 64)
     int ncb, n_chunk;        // column blocks, row chunks
     float *slabs;            // [n_chunk][128 K1]
+    // second product of the same launch (nullable): dW2[o][k] = sum_i dH2[i][o] H1[i][k] over the same row chunks, from the
+    // activations kernel A published in MINIBATCH order (no row-id indirection) -- column blocks ncb1 .. ncb - 1
+    const float *dh2, *h1;   // [Mr][128] each
+    float *slabs2;           // [n_chunk][128 x 128]
+    int ncb1;                // column blocks of the first product
     // side reductions (see below): workgroups >= n_main sum gradient slabs of OTHER parameter segments into one row each
     struct Side { const float *slabs; int64_t n, stride; int32_t n_slab, first_blk; float *out; } side[2];
     int n_side, n_main;
@@ -105,7 +110,10 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
     const int ncb = g.ncb, bid = blockIdx.x;
     const int rc_lo = bid & 7, t_ = bid >> 3, cb = t_ % ncb, rc = (t_ / ncb) * 8 + rc_lo;
     if (rc >= g.n_chunk) return;   // (the grid is padded to whole groups of 8 chunks)
-    const int K1 = g.K1, c0 = kCB * cb;
+    const bool second = cb >= g.ncb1;                       // (uniform) this workgroup belongs to the dW2 product
+    const float *__restrict__ Asrc = second ? g.dh2 : g.dh1;
+    const float *__restrict__ Bsrc = second ? g.h1 : g.obs;
+    const int K1 = second ? kH : g.K1, c0 = kCB * (second ? cb - g.ncb1 : cb);   // K1: row length of the B operand / output
     const int64_t i_lo = (int64_t)rc * g.RC, i_hi = i_lo + g.RC < g.Mr ? i_lo + g.RC : g.Mr;
     const int n_sub = (int)((i_hi - i_lo + kSub - 1) / kSub);
 
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
             const int q = tid + kThreads * u, r = q >> 5, c = q & 31;
             const int64_t i = i0 + r;
             const int64_t ic = i < i_hi ? i : i_hi - 1;
-            const float4 v = *reinterpret_cast<const float4 *>(g.dh1 + ic * kH + 4 * c);
+            const float4 v = *reinterpret_cast<const float4 *>(Asrc + ic * kH + 4 * c);
             ra[u] = i < i_hi ? f4{v.x, v.y, v.z, v.w} : f4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
@@ -134,12 +142,12 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
             const int64_t row = rid[r];
             if constexpr (VEC) {
                 const int kc = k < K1 ? k : K1 - 4;
-                const float4 v = *reinterpret_cast<const float4 *>(g.obs + row * K1 + kc);
+                const float4 v = *reinterpret_cast<const float4 *>(Bsrc + row * K1 + kc);
                 rb[u] = ok ? f4{v.x, v.y, v.z, v.w} : f4{0.f, 0.f, 0.f, 0.f};
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = g.obs[row * K1 + (k + e < K1 ? k + e : K1 - 1)];
+                    const float v = Bsrc[row * K1 + (k + e < K1 ? k + e : K1 - 1)];
                     rb[u][e] = (ok && k + e < K1) ? v : 0.f;
                 }
             }
@@ -158,21 +166,24 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
         }
     };
 
+    // B-operand row of minibatch row i: the observation row it names (first product), or i itself (H1 is in minibatch order)
+    auto row_id = [&](int64_t i) -> int64_t {
+        const int64_t ic = i < i_hi ? i : i_hi - 1;
+        return second ? ic : dw1_row_of(g, ic);
+    };
     int64_t my_id = 0;
-    if (tid < kSub) rid[tid] = dw1_row_of(g, i_lo + tid < i_hi ? i_lo + tid : i_hi - 1);
+    if (tid < kSub) rid[tid] = row_id(i_lo + tid);
     __syncthreads();
     fetch(0);
     if (tid < kSub) {
-        const int64_t i = i_lo + kSub + tid;
-        my_id = dw1_row_of(g, i < i_hi ? i : i_hi - 1);
+        my_id = row_id(i_lo + kSub + tid);
     }
     for (int s = 0; s < n_sub; ++s) {
         commit();             // sub-chunk s: registers -> LDS (the previous one's readers are behind the loop-end barrier)
         __syncthreads();      // ... and every thread has read RID for it
         if (tid < kSub) {
             rid[tid] = my_id;  // ids of sub-chunk s + 1; those of s + 2 fly during this one
-            const int64_t i = i_lo + (int64_t)(s + 2) * kSub + tid;
-            my_id = dw1_row_of(g, i < i_hi ? i : i_hi - 1);
+            my_id = row_id(i_lo + (int64_t)(s + 2) * kSub + tid);
         }
         __syncthreads();
         if (s + 1 < n_sub) fetch(s + 1);
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void critic_dw1_kernel(Dw1Args g) {
         }
         __syncthreads();
     }
-    float *slab = g.slabs + (size_t)rc * (size_t)kH * K1;
+    float *slab = (second ? g.slabs2 : g.slabs) + (size_t)rc * (size_t)kH * K1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 16 * w + kq * 4 + r;
@@ -245,7 +256,8 @@ TSM_EXPORT int tsm_critic_rows_dw1_chunks(int64_t Mr, int32_t in_dim) {
 
 TSM_EXPORT int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int32_t in_dim, const int64_t *rows,
                                    int64_t first_row, int64_t tm_T, int64_t tm_E, int64_t Mr, int32_t n_chunks,
-                                   float *w1_slabs_out, const tsm_slab_reduce *side_host, int32_t n_side, void *stream) {
+                                   float *w1_slabs_out, const float *dh2, const float *h1, float *w2_slabs_out,
+                                   const tsm_slab_reduce *side_host, int32_t n_side, void *stream) {
     TSM_REQUIRE(in_dim >= 1 && in_dim <= 384 && ((in_dim & 3) == 0 || in_dim <= 64) && Mr >= 1,
                 "tsm_critic_rows_dw1: in_dim = %d (<= 384, a multiple of 4 above 64), Mr = %lld", in_dim, (long long)Mr);
     TSM_REQUIRE(dh1 && obs_rows && w1_slabs_out, "tsm_critic_rows_dw1: null pointer");
@@ -262,7 +274,11 @@ TSM_EXPORT int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int3
     g.dh1 = dh1; g.obs = obs_rows; g.rows = rows; g.first_row = first_row; g.Mr = Mr; g.tm_T = tm_T; g.tm_E = tm_E;
     g.K1 = in_dim; g.RC = RC; g.slabs = w1_slabs_out;
     const int nt = dw1_nt(Mr, in_dim);
-    g.ncb = (int)ceil_div(in_dim, 16 * nt); g.n_chunk = n;
+    TSM_REQUIRE((dh2 == nullptr) == (h1 == nullptr) && (dh2 == nullptr) == (w2_slabs_out == nullptr),
+                "tsm_critic_rows_dw1: dh2, h1 and w2_slabs_out come together");
+    g.ncb1 = (int)ceil_div(in_dim, 16 * nt);
+    g.ncb = g.ncb1 + (dh2 ? (int)ceil_div(kH, 16 * nt) : 0); g.n_chunk = n;
+    g.dh2 = dh2; g.h1 = h1; g.slabs2 = w2_slabs_out;
     g.n_main = (int)(g.ncb * ceil_div(n, 8) * 8);
     TSM_REQUIRE(n_side >= 0 && n_side <= 2 && (n_side == 0 || side_host), "tsm_critic_rows_dw1: at most two side reductions");
     int side_blocks = 0;

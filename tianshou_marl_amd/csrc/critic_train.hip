@@ -84,6 +84,8 @@ struct TrainArgs {
     const int32_t *use_full; //   *use_full != 0 (an episode ended before the last slot: rows there are not chained)
     float gamma;
     float *dh1;              // [Mr][128]: d loss / d (layer-1 pre-activation) of minibatch row i (kernel B's A operand)
+    float *h1_out, *dh2_out; // nullable pair [Mr][128]: PUBLISH layer-1 activations and d loss / d (layer-2 pre-activation) of
+                             // row i -- dW2 = dH2^T H1 is then kernel B's too (split-K) and this launch keeps no W2 gradient
     float *slabs;            // [grid][P - 128 K1]: b1 | W2 | b2 | W3 | b3 gradients of the workgroup
     double *partial;         // [grid][4]: LOSS 0 {0, sum vf, 0, 0}; LOSS 1 {sum (td - v), sum (v - td)^2, 0, 0}
     long long *stamps;
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     const int64_t n_tiles = (g.Mr + OWN - 1) / OWN;
     const int oB1 = kH * K1, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + n_out * kH;
     const int col = 16 * w + c16;
+    const bool pub = g.h1_out != nullptr;   // (LOSS 0 only; uniform)
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[298] = (long long)wall_clock64();
 
     // row-id pipeline of threads < 32: ids of row tid of the tiles t (being computed) .. t + 3.  Requested FIRST: id -> row is
@@ -268,7 +271,15 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lds[ly.H1 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mt * 16 + kq * 4 + r;
+                    const float h = fmaxf(acc[mt][r] + bb, 0.f);
+                    lds[ly.H1 + row * kLdh + col] = h;
+                    if (pub) {   // (uniform) kernel B's B operand of dW2: row-major [Mr][128], 64-B segments per row and wave
+                        const int64_t i = tile * OWN + row;
+                        if (row < OWN && i < g.Mr) g.h1_out[i * kH + col] = h;
+                    }
+                }
         }
         __syncthreads();  // (A) H1 complete; every wave is done with X; RID / RIDC published
         TSTAMP(1);
@@ -424,7 +435,12 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
                     const int row = mt * 16 + kq * 4 + r;
                     const float dq = lds[ly.Q + row * kLdo];
                     gW3s += dq * h2r[mt][r];
-                    lds[ly.H2 + row * kLdh + col] = h2r[mt][r] > 0.f ? dq * w3c : 0.f;
+                    const float d2v = h2r[mt][r] > 0.f ? dq * w3c : 0.f;
+                    lds[ly.H2 + row * kLdh + col] = d2v;
+                    if (pub) {   // kernel B's A operand of dW2
+                        const int64_t i = tile * OWN + row;
+                        if (row < OWN && i < g.Mr) g.dh2_out[i * kH + col] = d2v;
+                    }
                 }
         } else {
             {
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         __syncthreads();
         TSTAMP(5);
         // ---- P6: dW2 += dH2^T H1 ; db2 ; dH1 = (dH2 W2) * relu'(H1) -> global (kernel B), db1 ----
-        {
+        if (!pub) {   // (published H1 / dH2: dW2 is formed by kernel B over row chunks instead of as a rank-32 slab per tile)
             const float *a = lds + ly.H2 + kq * kLdh + col;            // A[i = out o][k = row]
             const float *b = lds + ly.H1 + kq * kLdh + c16;            // B[k = row][j = in col]
 #pragma unroll 2
@@ -516,8 +532,10 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 16 * w + kq * 4 + r;
+        if (!pub) {
 #pragma unroll
-        for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + sW2 + o * kH + 16 * ti + c16);
+            for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + sW2 + o * kH + 16 * ti + c16);
+        }
         if constexpr (LOSS != 0) {
             const int a = kq * 4 + r;
             if (a < n_out) __builtin_nontemporal_store(gW3[r], slab + sW3 + a * kH + 16 * w + c16);
@@ -669,8 +687,8 @@ TSM_EXPORT int tsm_critic_rows_w1_image(const float *w1, int32_t in_dim, float *
 TSM_EXPORT int tsm_critic_rows_grad_ppo(const float *critic_params, const float *w1_image, int32_t in_dim, int32_t hidden, int32_t n_agent,
                                         const float *obs_rows, const float *returns, const float *v_s_old,
                                         const int64_t *rows, int64_t first_row, int64_t Mr, const tsm_ppo_cfg *cfg,
-                                        int32_t n_blocks, float *dh1_out, float *rest_slabs_out, double *loss_partial_out,
-                                        void *stream) {
+                                        int32_t n_blocks, float *dh1_out, float *h1_out, float *dh2_out, float *rest_slabs_out,
+                                        double *loss_partial_out, void *stream) {
     TSM_REQUIRE(hidden == kH && pick_kj(in_dim) != 0 && ((in_dim & 3) == 0 || in_dim <= 64) && n_agent >= 1 && n_agent <= 16,
                 "tsm_critic_rows_grad_ppo supports hidden == 128, in_dim <= 384 (a multiple of 4 above 64), n_agent <= 16 "
                 "(got %d / %d / %d)", hidden, in_dim, n_agent);
@@ -681,6 +699,8 @@ TSM_EXPORT int tsm_critic_rows_grad_ppo(const float *critic_params, const float 
     TSM_REQUIRE(n_blocks >= 1 && n_blocks <= ceil_div(Mr, kRows), "tsm_critic_rows_grad_ppo: n_blocks = %d out of range", n_blocks);
     TrainArgs g{};
     g.P = critic_params; g.w1_img = w1_image; g.obs = obs_rows; g.rows = rows; g.first_row = first_row; g.Mr = Mr; g.K1 = in_dim; g.n_out = 1;
+    TSM_REQUIRE((h1_out == nullptr) == (dh2_out == nullptr), "tsm_critic_rows_grad_ppo: h1_out and dh2_out come as a pair");
+    g.h1_out = h1_out; g.dh2_out = dh2_out;
     g.returns = returns; g.v_s_old = v_s_old; g.N = n_agent;
     g.eps_clip = (float)cfg->eps_clip; g.vf_coef = (float)cfg->vf_coef; g.value_clip = cfg->value_clip;
     g.dh1 = dh1_out; g.slabs = rest_slabs_out; g.partial = loss_partial_out; g.stamps = g_tsm_stamps;

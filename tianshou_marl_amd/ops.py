@@ -345,7 +345,8 @@ def adam_step(param, grad_slabs, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9,
 
 
 def _slab_segs(segs, n: int):
-    """[(slabs [n_slab, stride >= n_k], offset, n_k[, scale_dev[, frag_image]]), ...] -> ctypes array of tsm_slab_seg.
+    """[(slabs [n_slab, stride >= n_k], offset, n_k[, scale_dev[, frag_image[, col0]]]), ...] -> ctypes array of tsm_slab_seg.
+    col0: the segment's gradients are columns [col0, col0 + n_k) of every slab row (a view into joint slabs).
     A segment's slabs tensor may be wider than its parameter count (a view into joint slabs): stride = its row pitch.
     scale_dev (optional device f32[1]): the segment's summed gradient is multiplied by it.
     frag_image (optional, `critic_w1_image` layout): the segment is a [128][n_k / 128] first-layer weight matrix whose
@@ -355,9 +356,10 @@ def _slab_segs(segs, n: int):
         sl, off, nk = seg[:3]
         sc = seg[3] if len(seg) > 3 else None
         img = seg[4] if len(seg) > 4 else None
+        col0 = int(seg[5]) if len(seg) > 5 else 0   # the segment's gradients start at this column of every slab row
         sl = _chk(sl, torch.float32, "slabs")
-        if sl.dim() != 2 or sl.shape[1] < nk:
-            raise ValueError("slab segment: expected slabs [n_slab, >= n] for n = %d, got %s" % (nk, tuple(sl.shape)))
+        if sl.dim() != 2 or sl.shape[1] < col0 + nk:
+            raise ValueError("slab segment: expected slabs [n_slab, >= col0 + n] for n = %d, got %s" % (nk, tuple(sl.shape)))
         k1 = kj = 0
         if img is not None:
             if nk % 128:
@@ -366,7 +368,7 @@ def _slab_segs(segs, n: int):
             kj = call("tsm_critic_rows_w1_image_kj", k1)
             if _chk(img, torch.float32, "frag_image").numel() != call("tsm_critic_rows_w1_image_elems", k1):
                 raise ValueError("slab segment: frag_image has the wrong size for K1 = %d" % k1)
-        arr[k] = _abi.tsm_slab_seg(ptr(sl), int(off), int(nk), int(sl.shape[1]), int(sl.shape[0]), k1,
+        arr[k] = _abi.tsm_slab_seg(ptr(sl) + 4 * col0, int(off), int(nk), int(sl.shape[1]), int(sl.shape[0]), k1,
                                    ptr(None if sc is None else _chk(sc, torch.float32, "scale_dev")), ptr(img), kj, 0)
     return arr
 
@@ -682,19 +684,24 @@ def critic_rows_grad_supported(in_dim: int, hidden_sizes, n_out: int = 1, act: s
     return critic_rows_forward_supported(in_dim, hidden_sizes, n_out, act) and (in_dim % 4 == 0 or in_dim <= 64)
 
 
-def _critic_grad_ws(K1: int, hidden: int, n_out: int, Mr: int, td: bool, dev, ws: dict | None):
+def _critic_grad_ws(K1: int, hidden: int, n_out: int, Mr: int, td: bool, dev, ws: dict | None, split_dw2: bool = False):
     """(n_blocks, n_chunks, dh1, rest slabs, w1 slabs, partial) for a gradient step of Mr rows; cached in `ws` (the
-    buffers are what captured graphs hold on to)."""
+    buffers are what captured graphs hold on to).  split_dw2: + the published H1 / dH2 and the dW2 chunk slabs; the rest slabs
+    start as zeros (their W2 columns are never written in that mode)."""
     nb = call("tsm_critic_rows_grad_grid", Mr, int(td))
     nc = call("tsm_critic_rows_dw1_chunks", Mr, K1)
-    key = ("critic_grad", K1, hidden, n_out, Mr, td)
+    key = ("critic_grad", K1, hidden, n_out, Mr, td, bool(split_dw2))
     w = None if ws is None else ws.get(key)
     if w is None:
         n_rest = hidden + hidden * hidden + hidden + n_out * hidden + n_out
         w = dict(nb=nb, nc=nc, dh1=torch.empty(Mr, hidden, dtype=torch.float32, device=dev),
-                 rest=torch.empty(nb, n_rest, dtype=torch.float32, device=dev),
+                 rest=(torch.zeros if split_dw2 else torch.empty)(nb, n_rest, dtype=torch.float32, device=dev),
                  w1=torch.empty(nc, hidden * K1, dtype=torch.float32, device=dev),
                  partial=torch.zeros(nb * 4, dtype=torch.float64, device=dev))
+        if split_dw2:
+            w.update(h1=torch.empty(Mr, hidden, dtype=torch.float32, device=dev),
+                     dh2=torch.empty(Mr, hidden, dtype=torch.float32, device=dev),
+                     w2=torch.empty(nc, hidden * hidden, dtype=torch.float32, device=dev))
         if ws is not None:
             ws[key] = w
     return w
@@ -717,13 +724,17 @@ def _side_reductions(side):
 
 
 def critic_rows_grad_ppo(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n_agent: int, hidden: int = 128, v_s_old=None,
-                         rows=None, first_row=0, Mr=None, partial=None, ws: dict | None = None, w1_image=None, side_reduce=None):
+                         rows=None, first_row=0, Mr=None, partial=None, ws: dict | None = None, w1_image=None, side_reduce=None,
+                         split_dw2: bool = False):
     """Critic half of one PPO gradient step on joint rows in two launches -> (w1_slabs [n_chunks, H * in_dim],
     rest_slabs [n_blocks, P - H * in_dim], partial f64 [n_blocks * 4] = {0, sum vf, 0, 0} per workgroup): feed the two slab
     arrays to `adam_step_segs` as segments (W1 first).  `partial`: where to leave the loss partials (>= n_blocks * 4).
     w1_image: the first-layer weights in fragment order (`critic_w1_image`; must hold the values of critic_params' w0).
     side_reduce: [(slabs, out), ...] -- other kernels' complete slab sets summed to one row each inside the dW1 launch; an
-    entry whose slabs is the string "rest" names this step's own rest slabs."""
+    entry whose slabs is the string "rest" names this step's own rest slabs.
+    split_dw2: the first launch publishes H1 / dH2 instead of forming dW2 (a rank-32 update per tile as a 64 KB slab) and the
+    second forms dW2 = dH2^T H1 over its row chunks beside dW1: the W2 gradient is then `ws[...]["w2"]` [n_chunks, H * H] and the
+    W2 columns of `rest` stay zero -- `critic_grad_segs` lists the optimizer's segments for either mode."""
     obs_rows = _chk(obs_rows, torch.float32, "obs_rows")
     K1 = obs_rows.shape[-1]
     if Mr is None:
@@ -733,18 +744,32 @@ def critic_rows_grad_ppo(critic_params, obs_rows, returns, cfg: tsm_ppo_cfg, n_a
     if rows is not None and rows.numel() < Mr:
         raise ValueError("critic_rows_grad_ppo: rows holds fewer ids than Mr")
     _critic_rows_init(K1, hidden)
-    w = _critic_grad_ws(K1, hidden, 1, Mr, False, obs_rows.device, ws)
+    w = _critic_grad_ws(K1, hidden, 1, Mr, False, obs_rows.device, ws, split_dw2)
     part = w["partial"] if partial is None else partial
     if part.numel() < w["nb"] * 4:
         raise ValueError("critic_rows_grad_ppo: partial is too small")
     call("tsm_critic_rows_grad_ppo", ptr(_chk(critic_params, torch.float32, "critic_params")), ptr(w1_image), K1, hidden, n_agent,
          ptr(obs_rows), ptr(_chk(returns, torch.float32, "returns")), ptr(v_s_old), ptr(rows), first_row, Mr, C.byref(cfg),
-         w["nb"], ptr(w["dh1"]), ptr(w["rest"]), ptr(part), stream_ptr())
+         w["nb"], ptr(w["dh1"]), ptr(w.get("h1")), ptr(w.get("dh2")), ptr(w["rest"]), ptr(part), stream_ptr())
     side = [(w["rest"] if isinstance(sl, str) else sl, out) for sl, out in (side_reduce or [])]
     arr, n_side = _side_reductions(side)
     call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(obs_rows), K1, ptr(rows), first_row, 0, 0, Mr, w["nc"], ptr(w["w1"]),
-         arr, n_side, stream_ptr())
+         ptr(w.get("dh2")), ptr(w.get("h1")), ptr(w.get("w2")), arr, n_side, stream_ptr())
     return w["w1"], w["rest"], part
+
+
+def critic_grad_segs(w: dict, offset: int, K1: int, hidden: int = 128, n_out: int = 1, w1_image=None, rest_row=None) -> list:
+    """The optimizer's slab segments (`adam_step_segs` / `reduce_slabs_segs`) for the critic gradients a `critic_rows_grad_*`
+    call left in workspace `w`, the critic's parameters starting at `offset` of the flat vector.  Plain mode: W1 chunk slabs |
+    rest slabs (or `rest_row`, their side-reduced sum [1, n_rest]).  split_dw2 mode: W1 chunks | b1 (a column view of the rest
+    slabs) | W2 chunks | b2, W3, b3 (another view)."""
+    nW1, H = hidden * K1, hidden
+    if "w2" not in w:
+        rest = w["rest"] if rest_row is None else rest_row
+        return [(w["w1"], offset, nW1, None, w1_image), (rest, offset + nW1, w["rest"].shape[1])]
+    tail = H + n_out * H + n_out
+    return [(w["w1"], offset, nW1, None, w1_image), (w["rest"], offset + nW1, H),
+            (w["w2"], offset + nW1 + H, H * H), (w["rest"], offset + nW1 + H + H * H, tail, None, None, H + H * H)]
 
 
 def critic_rows_grad_td(critic_params, joint_store, T: int, E: int, rew, terminated, agent: int, n_agent: int, v_last,
@@ -770,7 +795,8 @@ def critic_rows_grad_td(critic_params, joint_store, T: int, E: int, rew, termina
          ptr(_chk(v_last, torch.float32, "v_last")), ptr(None if v_next_full is None else _chk(v_next_full, torch.float32, "v_next_full")),
          ptr(None if use_full is None else _chk(use_full, torch.int32, "use_full")), float(gamma), w["nb"], ptr(w["dh1"]),
          ptr(w["rest"]), ptr(part), stream_ptr())
-    call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(joint_store), K1, None, 0, T, E, B, w["nc"], ptr(w["w1"]), None, 0, stream_ptr())
+    call("tsm_critic_rows_dw1", ptr(w["dh1"]), ptr(joint_store), K1, None, 0, T, E, B, w["nc"], ptr(w["w1"]), None, None, None,
+         None, 0, stream_ptr())
     return w["w1"], w["rest"], part
 
 

@@ -28,9 +28,12 @@ img = ops.critic_w1_image(f.flat.data, N * D)
 ws = {}
 t = gtime(lambda: ops.critic_rows_grad_ppo(f.flat.data, joint, ret, cfg, N, H, rows=rid, Mr=Mr, ws=ws, w1_image=img))
 w = next(iter(ws.values()))
-t2 = gtime(lambda: ops.call("tsm_critic_rows_dw1", ops.ptr(w["dh1"]), ops.ptr(joint), N * D, ops.ptr(rid), 0, 0, 0, Mr, w["nc"], ops.ptr(w["w1"]), None, 0, ops.stream_ptr()))
+t2 = gtime(lambda: ops.call("tsm_critic_rows_dw1", ops.ptr(w["dh1"]), ops.ptr(joint), N * D, ops.ptr(rid), 0, 0, 0, Mr, w["nc"], ops.ptr(w["w1"]), None, None, None, None, 0, ops.stream_ptr()))
 t3 = gtime(lambda: ops.critic_rows_grad_ppo(f.flat.data, joint, ret, cfg, N, H, rows=rid, Mr=Mr, ws=ws))
-print(f"critic pair, W1 from the fragment image: {t:.2f} us; W1 gathered: {t3:.2f} us; dW1 launch alone: {t2:.2f} us; dW1 chunk slabs {w['nc']}")
+ws2 = {}
+t4 = gtime(lambda: ops.critic_rows_grad_ppo(f.flat.data, joint, ret, cfg, N, H, rows=rid, Mr=Mr, ws=ws2, w1_image=img, split_dw2=True))
+print(f"critic pair, W1 from the fragment image: {t:.2f} us; W1 gathered: {t3:.2f} us; dW1 launch alone: {t2:.2f} us; dW1 chunk slabs {w['nc']}; "
+      f"pair with dW2 in the split-K pass: {t4:.2f} us")
 # segmented Adam at the C3 step's slab sets: actor 256 x 23429, dW1 64 x 49152, rest 256 x 17025
 P_a, nW1, nr = 23429, 49152, 17025
 n = P_a + nW1 + nr
