@@ -13,7 +13,9 @@
 // Round 4 (an experiment build of tools/critic_pair_time.py, 8192 rows of 384, launch alone back to back): 4 x 96 columns x 64 chunks 13.4 us; 8 x 48
 // columns x 32 chunks 13.6 us; the same x 64 chunks (two workgroups per CU) 12.9 us; 4 x 96 x 128 chunks 13.5 us -- the launch
 // is a latency chain (ids -> rows -> LDS -> 5.6 us of MFMA -> slab) that no split shortens, so the form with the FEWEST slab
-// bytes is the one kept: half the writes here and half the optimizer's reads of them (12.6 -> 6.3 MB each).
+// bytes is the one kept: half the writes here and half the optimizer's reads of them (12.6 -> 6.3 MB each).  32-row sub-chunks
+// (33 KB of LDS: four workgroups per CU, more room for the side reductions below) were measured too: 17.2 vs 14.6 us alone,
+// 22.5 vs 20.3 us in situ -- twice the barriers per row cost more than the extra residency gives.
 #include "critic_rows_dev.h"
 #include "adam_dev.h"
 
