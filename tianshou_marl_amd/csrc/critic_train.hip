@@ -110,7 +110,7 @@ __device__ __forceinline__ int64_t row_of(const TrainArgs &g, int64_t i) {
     }
 }
 
-template <int KJ, bool VEC, int LOSS>
+template <int KJ, bool VEC, int LOSS, bool PUB>
 __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     TrainLay ly(KJ);
@@ -122,7 +122,9 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     const int64_t n_tiles = (g.Mr + OWN - 1) / OWN;
     const int oB1 = kH * K1, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + n_out * kH;
     const int col = 16 * w + c16;
-    const bool pub = g.h1_out != nullptr;   // (LOSS 0 only; uniform)
+    // H1 / dH2 published for kernel B's dW2 (LOSS 0 only).  A template parameter: as a run-time branch its two stores cost the
+    // default form 31 spilled registers at K1 = 384 (25.0 -> 26.9 us per launch).
+    constexpr bool pub = PUB;
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[298] = (long long)wall_clock64();
 
     // row-id pipeline of threads < 32: ids of row tid of the tiles t (being computed) .. t + 3.  Requested FIRST: id -> row is
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
                     const int row = mt * 16 + kq * 4 + r;
                     const float h = fmaxf(acc[mt][r] + bb, 0.f);
                     lds[ly.H1 + row * kLdh + col] = h;
-                    if (pub) {   // (uniform) kernel B's B operand of dW2: row-major [Mr][128], 64-B segments per row and wave
+                    if constexpr (pub) {   // (uniform) kernel B's B operand of dW2: row-major [Mr][128], 64-B segments per row and wave
                         const int64_t i = tile * OWN + row;
                         if (row < OWN && i < g.Mr) g.h1_out[i * kH + col] = h;
                     }
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
                     gW3s += dq * h2r[mt][r];
                     const float d2v = h2r[mt][r] > 0.f ? dq * w3c : 0.f;
                     lds[ly.H2 + row * kLdh + col] = d2v;
-                    if (pub) {   // kernel B's A operand of dW2
+                    if constexpr (pub) {   // kernel B's A operand of dW2
                         const int64_t i = tile * OWN + row;
                         if (row < OWN && i < g.Mr) g.dh2_out[i * kH + col] = d2v;
                     }
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
         __syncthreads();
         TSTAMP(5);
         // ---- P6: dW2 += dH2^T H1 ; db2 ; dH1 = (dH2 W2) * relu'(H1) -> global (kernel B), db1 ----
-        if (!pub) {   // (published H1 / dH2: dW2 is formed by kernel B over row chunks instead of as a rank-32 slab per tile)
+        if constexpr (!pub) {   // (published H1 / dH2: dW2 is formed by kernel B over row chunks instead of as a rank-32 slab per tile)
             const float *a = lds + ly.H2 + kq * kLdh + col;            // A[i = out o][k = row]
             const float *b = lds + ly.H1 + kq * kLdh + c16;            // B[k = row][j = in col]
 #pragma unroll 2
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 16 * w + kq * 4 + r;
-        if (!pub) {
+        if constexpr (!pub) {
 #pragma unroll
             for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + sW2 + o * kH + 16 * ti + c16);
         }
@@ -580,18 +582,18 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     }
 }
 
-template <int KJ, bool VEC, int LOSS>
+template <int KJ, bool VEC, int LOSS, bool PUB = false>
 int launch_train_v(const TrainArgs &g, int grid, hipStream_t st) {
     const TrainLay ly(KJ);
     const size_t shmem = (size_t)ly.total * sizeof(float);
     TSM_REQUIRE(shmem <= kMaxLds, "critic gradient step: LDS layout of %zu bytes does not fit", shmem);
     static bool attr_set = false;  // (set before any capture: tsm_critic_rows_init)
     if (!attr_set) {
-        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(critic_rows_train_kernel<KJ, VEC, LOSS>)));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(critic_rows_train_kernel<KJ, VEC, LOSS, PUB>)));
         attr_set = true;
     }
     if (grid > 0) {
-        hipLaunchKernelGGL((critic_rows_train_kernel<KJ, VEC, LOSS>), dim3((unsigned)grid), dim3(kThreads), shmem, st, g);
+        hipLaunchKernelGGL((critic_rows_train_kernel<KJ, VEC, LOSS, PUB>), dim3((unsigned)grid), dim3(kThreads), shmem, st, g);
         TSM_LAUNCH_CHECK();
     }
     return TSM_OK;
@@ -602,18 +604,23 @@ int launch_train(const TrainArgs &g, int loss, int grid, hipStream_t st) {
     if (g.K1 == 0) {  // tsm_critic_rows_init: the attributes of every form
         int rc = launch_train_v<KJ, true, 0>(g, 0, st);
         if (rc == TSM_OK) rc = launch_train_v<KJ, true, 1>(g, 0, st);
+        if (rc == TSM_OK) rc = launch_train_v<KJ, true, 0, true>(g, 0, st);
         if constexpr (KJ <= 4) {
             if (rc == TSM_OK) rc = launch_train_v<KJ, false, 0>(g, 0, st);
             if (rc == TSM_OK) rc = launch_train_v<KJ, false, 1>(g, 0, st);
+            if (rc == TSM_OK) rc = launch_train_v<KJ, false, 0, true>(g, 0, st);
         }
         return rc;
     }
     const bool vec = (g.K1 & 3) == 0;
+    if (g.h1_out) TSM_REQUIRE(loss == 0, "critic gradient step: H1 / dH2 are published by the PPO form only");
     if constexpr (KJ <= 4) {
+        if (!vec && g.h1_out) return launch_train_v<KJ, false, 0, true>(g, grid, st);
         if (!vec) return loss == 0 ? launch_train_v<KJ, false, 0>(g, grid, st) : launch_train_v<KJ, false, 1>(g, grid, st);
     } else {
         TSM_REQUIRE(vec, "critic gradient step: input widths above 64 must be multiples of 4 (got %d)", g.K1);
     }
+    if (g.h1_out) return launch_train_v<KJ, true, 0, true>(g, grid, st);
     return loss == 0 ? launch_train_v<KJ, true, 0>(g, grid, st) : launch_train_v<KJ, true, 1>(g, grid, st);
 }
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Registers, spills and occupancy of every gfx950 kernel in csrc/ (hipcc -Rpass-analysis=kernel-resource-usage; no GPU needed).
+
+    python tools/resource_usage.py [file.hip ...]        # default: every csrc/*.hip; prints kernels with spilled VGPRs first
+
+A run-time branch added to a kernel that sits at the 256-register limit can spill its DEFAULT form (round 4: the published
+H1 / dH2 stores of critic_rows_train_kernel cost the K1 = 384 PPO form 31 spilled registers and 1.9 us per launch until the
+switch became a template parameter) -- run this after touching a hot kernel."""
+import glob
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tianshou_marl_amd import _build  # noqa: E402
+
+
+def usage(src: str) -> list:
+    r = subprocess.run([_build.HIPCC, *_build.FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull],
+                       capture_output=True, text=True)
+    if r.returncode:
+        raise SystemExit(r.stderr[-2000:])
+    out, cur = [], None
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark: \s*(Function Name|VGPRs|AGPRs|VGPRs Spill|SGPRs Spill|Occupancy \[waves/SIMD\]|ScratchSize \[bytes/lane\]): (\S+)", line)
+        if not m:
+            continue
+        k, v = m.groups()
+        if k == "Function Name":
+            name = subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()
+            cur = dict(kernel=re.sub(r"\(anonymous namespace\)::|\(.*\)$|^void ", "", name), file=os.path.basename(src))
+            out.append(cur)
+        elif cur is not None:
+            cur[k.split(" [")[0]] = int(v)
+    return out
+
+
+if __name__ == "__main__":
+    files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "tianshou_marl_amd", "csrc", "*.hip")))
+    rows = [r for f in files for r in usage(f)]
+    rows.sort(key=lambda r: (-r.get("VGPRs Spill", 0), -r.get("VGPRs", 0)))
+    print(f"{'kernel':70s} {'file':22s} vgpr agpr spill scratch occ")
+    for r in rows:
+        print(f"{r['kernel'][:70]:70s} {r['file'][:22]:22s} {r.get('VGPRs', 0):4d} {r.get('AGPRs', 0):4d} {r.get('VGPRs Spill', 0):5d} "
+              f"{r.get('ScratchSize', 0):7d} {r.get('Occupancy', 0):3d}")
+    print(f"{sum(1 for r in rows if r.get('VGPRs Spill', 0))} of {len(rows)} kernels spill vector registers")
