@@ -105,14 +105,21 @@ def _job128(n_env, N, T, fused, glob, seed=3, slots=None):
 # (40, 5) / (21, 7): observation widths 30 / 42 -- a thread's observation elements straddle the 32-row tiles
 @pytest.mark.parametrize("n_env,N,T,steps,glob", [(600, 8, 4, 6, True), (50, 3, 6, 15, False), (5, 1, 4, 9, False),
                                                   (33, 8, 25, 25, True), (4096, 8, 25, 25, True), (40, 5, 5, 8, False),
-                                                  (21, 7, 4, 6, True)])
-def test_actor_rollout_is_bit_identical_to_unfused(n_env, N, T, steps, glob):
+                                                  (21, 7, 4, 6, True), (37, 6, 5, 7, False), (9, 2, 3, 7, False),
+                                                  (130, 4, 6, 8, True)])
+@pytest.mark.parametrize("form", ["wave", "tile"])
+def test_actor_rollout_is_bit_identical_to_unfused(n_env, N, T, steps, glob, form):
+    """Both forms of the actor-only rollout (option "rollout_rows": the wave-autonomous default -- a wave owns 16 // N whole
+    envs, transposed products, no workgroup barrier in the step loop -- and round 2's tile form) against the unfused launch
+    sequence.  (37, 6) / (9, 2) / (130, 4): 2 / 8 / 4 envs per wave with 12 / 16 / 16 live rows, partial last waves."""
+    from tianshou_marl_amd import ops
+
     slots = steps + 3 + 1
     outs = []
     for fused in (False, True):
         env, net, algo, buf, col = _job128(n_env, N, T, fused, glob, slots=slots)
         assert col._can_fuse() == fused and col._can_fuse_actor() == fused
-        with policy_within_training_step(algo):
+        with policy_within_training_step(algo), ops.kernel_override(rollout_rows=1 if form == "tile" else 2):
             st1 = col.collect(n_step=n_env * steps)
             st2 = col.collect(n_step=n_env * 3)
         outs.append(dict(

@@ -90,6 +90,8 @@ struct RrArgs {
     uint64_t *offset_dev_rw;
     uint32_t *done_ctr;
     long long *stamps;  // diagnostics only (tsm_debug_set_stamps): phase time stamps of workgroup 0, steps 0..3
+    int dbg;            // diagnostics only (option "dbg", wave form): 1 = skip the matrix products, 2 = skip heads + env step,
+                        // 16 = waves 0-3 only (timing probes of tools/time_rollout_rows.py; results are garbage under them)
 };
 
 // slot t * 32 + k of the stamp buffer: k = 0 step start, 1 index algebra, 2 obs(0), 3 + 3 i .. 5 + 3 i layers 1 / 2 / 3 of
@@ -466,6 +468,438 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
     }
 }
 
+
+// ---- wave-autonomous form ------------------------------------------------------------------------------------------------
+// The tile form above is a chain of workgroup-wide phases with 2 + 2 x tiles + 7 barriers per step: every phase waits for its
+// slowest wave, the single-wave phases (logits on waves 0-1, heads on two waves, bookkeeping on one) leave the others idle, and
+// a step costs 25.2 us at configs[2].  Here a WAVE owns 16 / N whole environments (<= 16 agent rows) for all T steps and runs
+// every phase of a step by itself: no workgroup barrier inside the step loop: 20.3 us per step (collect 631 -> 507 us).
+// What this form does NOT buy (measured, tools/time_rollout_rows.sh + tools/probes/mfma_valu_overlap.hip): one wave's VALU phase
+// does not run under the f32 MFMAs of the other wave of its SIMD -- on gfx950 an f32 MFMA and another wave's VALU instructions
+// take turns (times add: 10.9 us of MFMAs + 8.5 us of everything else per step, with or without a phase offset between the two
+// waves, with or without s_setprio), so the step's floor is the sum of the two instruction streams, not their maximum.
+//   * Products are formed TRANSPOSED: the weights are the A operand (m = output unit, fragments read from LDS in the same
+//     [unit][k] layout as above), the wave's samples are the B operand (n = sample, k = lane >> 4) held in REGISTERS.  Each
+//     output element is the same chain c + sum_k a_k b_k over the same k order as in the tile form (the roles of the factors
+//     are exchanged, the products are not): bit-identical activations.
+//   * The accumulator layout (lane: sample = lane & 15, units 16 mb + 4 (lane >> 4) + i) becomes the next layer's B fragments
+//     (unit 4 kb + (lane >> 4)) by a 4 x 4 transpose between register index and lane group: v_permlane32_swap +
+//     v_permlane16_swap (gfx950), four instructions per 16 units, no LDS round trip (tools/probes/permlane_swap.hip).
+//   * Env state, logits, pair forces and the per-env bookkeeping live in a 3 KB LDS block private to the wave; LDS accesses of
+//     one wave execute in program order, so a value written by one lane is seen by the later read of another lane.
+constexpr int kWaves = kThreads / 64, kRowsWave = 16;
+
+struct RwLay {  // LDS layout in floats: weights as in RrLay, then one private block per wave
+    int nJ, ld1, W1, W2, W3, B1, B2, B3, WV, wv;
+    int AP, AV, LP, LG, CX, CY, CV, MIN, REW, LOGP, ACT, STEPS, DONE, ROW, EP;  // offsets inside a wave's block
+    int total;
+    __host__ __device__ explicit RwLay(int D) {
+        nJ = (D + 15) / 16;
+        ld1 = 16 * nJ + 2;
+        int o = 0;
+        W1 = o; o += kH * ld1;
+        W2 = o; o += kH * kLdh;
+        W3 = o; o += 16 * kLdh;
+        B1 = o; o += kH;
+        B2 = o; o += kH;
+        B3 = o; o += 16;
+        o = (o + 3) & ~3;
+        WV = o;
+        int q = 0;
+        AP = q; q += 2 * kRowsWave;
+        AV = q; q += 2 * kRowsWave;
+        LP = q; q += 2 * kRowsWave;
+        LG = q; q += kRowsWave * kLdo;
+        CX = q; q += kRowsWave * 8;
+        CY = q; q += kRowsWave * 8;
+        CV = q; q += kRowsWave * 8;   // int
+        MIN = q; q += kRowsWave;
+        REW = q; q += kRowsWave;
+        LOGP = q; q += kRowsWave;
+        ACT = q; q += kRowsWave;      // int
+        STEPS = q; q += kRowsWave;    // int [envs of the wave]
+        DONE = q; q += kRowsWave;     // int
+        ROW = q; q += 2 * kRowsWave;  // int64
+        EP = q; q += 2 * kRowsWave;   // uint64
+        wv = (q + 3) & ~3;
+        total = WV + kWaves * wv;
+    }
+};
+
+// 4 x 4 transpose between the register index and the lane group (lane >> 4): afterwards r[j] of group g holds what r[g] of
+// group j held.  (Inline asm: with this compiler the second result of __builtin_amdgcn_permlane*_swap aliases the first.)
+__device__ __forceinline__ void lane_group_transpose(f4 &r) {
+    float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+    r = f4{r0, r1, r2, r3};
+}
+
+// one layer on the wave's 16 samples: out[unit][sample] = sum_k W[unit][k] x[k][sample]; xb[kb] = the B fragment of k-step kb
+template <int KB>
+__device__ __forceinline__ void wave_layer(const float *__restrict__ wfrag /* W + c16 * ld + kq */, int ld, const float (&xb)[KB],
+                                           f4 (&acc)[8]) {
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[mb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) acc[mb] = mfma4(wfrag[16 * mb * ld + 4 * kb], xb[kb], acc[mb]);
+}
+
+// bias + ReLU in the accumulator layout, then the accumulators of 16 units become four B fragments of the next layer
+__device__ __forceinline__ void wave_relu_to_frags(const float *__restrict__ bias /* b + 4 * kq */, f4 (&acc)[8], float (&hb)[32]) {
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+        const f4 b = *reinterpret_cast<const f4 *>(bias + 16 * mb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = acc[mb][i] + b[i];
+            acc[mb][i] = v > 0.f ? v : 0.f;
+        }
+        lane_group_transpose(acc[mb]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hb[4 * mb + j] = acc[mb][j];
+    }
+}
+
+#define WSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && t < 4) a.stamps[t * 32 + (k)] = (long long)wall_clock64(); } while (0)
+
+template <int NJ>
+__global__ __launch_bounds__(kThreads) void rollout_wave_kernel(RrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MpeCfg c = a.c;
+    const RwLay ly(a.D);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
+    constexpr int ld1 = 16 * NJ + 2;                     // (== ly.ld1: compile-time, so fragment offsets are immediates)
+    const int N = c.N, D = a.D, A = a.A, st = 2 * N;
+    const int EPW = kRowsWave / N;                       // whole environments per wave
+    const int e0 = (blockIdx.x * kWaves + w) * EPW;      // first env of this wave
+    const int n_here = max(0, min(EPW, c.n_env - e0));
+    const int rows_here = n_here * N;
+    const int64_t B = c.n_env;
+    float *wv = lds + ly.WV + w * ly.wv;
+    float *s_ap = wv + ly.AP, *s_av = wv + ly.AV, *s_lp = wv + ly.LP, *s_lg = wv + ly.LG, *s_cx = wv + ly.CX, *s_cy = wv + ly.CY,
+          *s_m = wv + ly.MIN, *s_rew = wv + ly.REW, *s_logp = wv + ly.LOGP;
+    int *s_cv = reinterpret_cast<int *>(wv + ly.CV), *s_act = reinterpret_cast<int *>(wv + ly.ACT),
+        *s_steps = reinterpret_cast<int *>(wv + ly.STEPS), *s_done = reinterpret_cast<int *>(wv + ly.DONE);
+    int64_t *s_row = reinterpret_cast<int64_t *>(wv + ly.ROW);
+    uint64_t *s_ep = reinterpret_cast<uint64_t *>(wv + ly.EP);
+
+    // ---- weights into LDS once (zero pads: W1 columns >= D, W3 rows >= A) ----
+    const int oB1 = kH * D, oW2 = oB1 + kH, oB2 = oW2 + kH * kH, oW3 = oB2 + kH, oB3 = oW3 + A * kH;
+    tsm_stage_padded<kThreads>(lds + ly.W1, a.P, kH * ld1, ld1, kH, D, D);
+    tsm_stage_padded<kThreads>(lds + ly.W2, a.P + oW2, kH * kLdh, kLdh, kH, kH, kH);
+    tsm_stage_padded<kThreads>(lds + ly.W3, a.P + oW3, 16 * kLdh, kLdh, A, kH, kH);
+    if (tid < kH) { lds[ly.B1 + tid] = a.P[oB1 + tid]; lds[ly.B2 + tid] = a.P[oB2 + tid]; }
+    if (tid < 16) lds[ly.B3 + tid] = tid < A ? a.P[oB3 + tid] : 0.f;
+
+    const VrbState vs = vrb_view(a.vrb_state, B, N);
+    // agent lane r = lane < rows_here <-> (env el, agent ai) of the wave; env lane 16 + bel owns env bel's bookkeeping
+    const int r = lane, el = r / N, ai = r - el * N;
+    const bool lane_live = r < rows_here;
+    const int e = e0 + el;
+    const int bel = lane - 16;
+    const bool env_lane = bel >= 0 && bel < n_here;
+    const int be = e0 + bel;
+    int64_t v_ins = 0, v_size = 0, v_eplen = 0, v_epstart = 0, v_last = 0;
+    int n_fin = 0;
+    double v_epret[kMpeMaxN];
+#pragma unroll
+    for (int k = 0; k < kMpeMaxN; ++k) v_epret[k] = 0.0;
+    if (env_lane) {
+        v_ins = vs.ins[be]; v_size = vs.size[be]; v_eplen = vs.ep_len[be]; v_epstart = vs.ep_start[be];
+        v_last = vs.last_index[be];
+#pragma unroll
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) v_epret[k] = vs.ep_return[(int64_t)be * N + k];
+        s_steps[bel] = a.steps[be];
+        s_done[bel] = 0;
+        s_row[bel] = 0;
+    }
+    if (lane < n_here * st) {   // (n_here * st <= 32)
+        s_ap[lane] = a.apos[(int64_t)e0 * st + lane];
+        s_av[lane] = a.avel[(int64_t)e0 * st + lane];
+        s_lp[lane] = a.lpos[(int64_t)e0 * st + lane];
+    }
+    const uint64_t off0 = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
+
+    // ---- the observation elements this lane holds as B fragments: element k = 4 kb + kq of sample c16 (as in the tile form:
+    //      one LDS value or the difference of two, the two offsets worked out once; a zero cell stands in where there is no
+    //      subtrahend and for the pads k >= D / samples >= rows_here) ----
+    constexpr int KB1 = 4 * NJ;
+    const int zoff = ly.B3 + 15;  // always 0.f (A <= 8 < 16)
+    uint32_t el_ab[KB1];
+    const int sn_el = c16 / N, sn_ai = c16 - sn_el * N;   // (env, agent) of the lane's sample
+    const bool sn_live = c16 < rows_here;
+    const int wvo = ly.WV + w * ly.wv;
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb) {
+        const int k = 4 * kb + kq;
+        int oa = zoff, ob = zoff;
+        if (sn_live && k < D) {
+            const int base = sn_el * st, i_ = sn_ai;
+            if (k < 2) oa = wvo + ly.AV + base + 2 * i_ + k;
+            else if (k < 4) oa = wvo + ly.AP + base + 2 * i_ + (k - 2);
+            else {
+                int kk = k - 4;
+                if (kk < 2 * N) { oa = wvo + ly.LP + base + kk; ob = wvo + ly.AP + base + 2 * i_ + (kk & 1); }
+                else {
+                    kk -= 2 * N;
+                    if (kk < 2 * (N - 1)) {
+                        int jj = kk >> 1;
+                        const int x = kk & 1;
+                        if (jj >= i_) ++jj;  // others in increasing index, skipping self
+                        oa = wvo + ly.AP + base + 2 * jj + x; ob = wvo + ly.AP + base + 2 * i_ + x;
+                    }
+                }
+            }
+        }
+        el_ab[kb] = ((uint32_t)oa << 16) | (uint32_t)ob;
+    }
+    const int ND = N * D;
+    const int obs_col = sn_ai * D + kq;   // + 4 kb: the element's place inside its env's row block
+    // all 2 x KB1 LDS reads in flight, then the subtractions (written as one loop the reads are waited for pair by pair)
+    auto obs_frags = [&](float (&x)[KB1]) {
+        float xa[KB1], xs[KB1];
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) { xa[kb] = lds[el_ab[kb] >> 16]; xs[kb] = lds[el_ab[kb] & 0xFFFFu]; }
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) x[kb] = xa[kb] - xs[kb];
+    };
+    // elements k = 4 kb + kq < D of the lane's sample to row memory: whole k-steps under a wave-uniform test, the one
+    // partial k-step of an odd agent count (D = 6 N, D & 3 == 2) under a lane test
+    const int kb_full = D >> 2, k_rem = D & 3;
+    auto obs_rows_out = [&](float *dst, const float (&x)[KB1]) {
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+            if (kb < kb_full) dst[4 * kb] = x[kb];
+            else if (kb == kb_full && kq < k_rem) dst[4 * kb] = x[kb];
+        }
+    };
+    // the pair (agent row, other agent) tasks of the env step: task p = lane + 64 q -> agent row p >> 3, other p & 7
+    int pair_ei[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rp = (lane + 64 * q) >> 3, ep = rp / N;
+        pair_ei[q] = rp < rows_here ? (ep << 3) | (rp - ep * N) : -1;
+    }
+    const float *w1f = lds + ly.W1 + c16 * ld1 + kq, *w2f = lds + ly.W2 + c16 * kLdh + kq, *w3f = lds + ly.W3 + c16 * kLdh + kq;
+    __syncthreads();   // weights staged; every wave has read the sampling counter.  The only workgroup barrier.
+    if (n_here == 0) return;  // a wave without environments (never wave 0, whose thread 0 updates the counter below)
+    if ((a.dbg & 16) && w >= kWaves / 2) return;   // (probe: one wave per SIMD -- half of the envs are not stepped)
+    for (int t = 0; t < a.n_steps; ++t) {
+        // ---- A. buffer index algebra of this step on the env lanes (as in the tile form) ----
+        WSTAMP(0);
+        bool tr = false, rec = false;
+        int64_t o = 0;
+        if (env_lane) {
+            const int stp = s_steps[bel] + 1;
+            tr = stp >= c.max_cycles;
+            s_steps[bel] = stp;
+            o = (int64_t)t * B + be;
+            const int64_t cur = v_ins;
+            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
+            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
+            const int64_t elen = v_eplen + 1;
+            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
+            rec = tr && a.ep_rec && n_fin < a.max_ep;
+            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | elen;
+            a.ep_len_out[o] = tr ? elen : 0;
+            a.ptr_out[o] = cur + (int64_t)be * a.S;
+            a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
+            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
+            v_last = cur + (int64_t)be * a.S;
+            a.done_store[cur * B + be] = tr ? 1 : 0;
+            s_row[bel] = cur * B + be;
+            s_done[bel] = tr ? 1 : 0;
+        }
+        // ---- B. observation fragments (also the buffer's obs rows), the actor forward, the Categorical heads ----
+        float xb[KB1];
+        obs_frags(xb);
+        if (sn_live) obs_rows_out(a.obs_store + s_row[sn_el] * ND + obs_col, xb);
+        WSTAMP(1);
+        f4 acc[8];
+        float hb[32];
+        if (a.dbg & 1) {   // (timing probe: no matrix products)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) hb[i] = xb[i % KB1];
+            if (kq < kLdo / 4) *reinterpret_cast<f4 *>(s_lg + c16 * kLdo + 4 * kq) = f4{hb[0], hb[1], hb[2], hb[3]};
+        } else {
+        wave_layer<KB1>(w1f, ld1, xb, acc);
+        wave_relu_to_frags(lds + ly.B1 + 4 * kq, acc, hb);
+        WSTAMP(2);
+        wave_layer<32>(w2f, kLdh, hb, acc);
+        wave_relu_to_frags(lds + ly.B2 + 4 * kq, acc, hb);
+        WSTAMP(3);
+        {   // logits (A padded to 16): lane holds actions 4 kq + i of sample c16
+            f4 lg = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 32; ++kb) lg = mfma4(w3f[4 * kb], hb[kb], lg);
+            if (kq < kLdo / 4) {
+                const f4 b = *reinterpret_cast<const f4 *>(lds + ly.B3 + 4 * kq);
+                *reinterpret_cast<f4 *>(s_lg + c16 * kLdo + 4 * kq) = f4{lg[0] + b[0], lg[1] + b[1], lg[2] + b[2], lg[3] + b[3]};
+            }
+        }
+        }
+        WSTAMP(4);
+        if (a.dbg & 2) continue;   // (timing probe: no heads, no env step)
+        if (lane_live) {  // heads: one lane per row, the arithmetic of categorical.hip (all logits in registers first; the
+                          // sampler re-uses the exponentials of the normaliser: the same inputs, the same values)
+            float lg[kLdo], ex[kLdo];
+            {
+                const f4 l0 = *reinterpret_cast<const f4 *>(s_lg + lane * kLdo), l1 = *reinterpret_cast<const f4 *>(s_lg + lane * kLdo + 4);
+                lg[0] = l0[0]; lg[1] = l0[1]; lg[2] = l0[2]; lg[3] = l0[3]; lg[4] = l1[0]; lg[5] = l1[1]; lg[6] = l1[2]; lg[7] = l1[3];
+            }
+            float m = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int j = 0; j < kLdo; ++j) if (j < A && lg[j] > m) { m = lg[j]; arg = j; }
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < kLdo; ++j) { ex[j] = 0.f; if (j < A) { ex[j] = expf(lg[j] - m); s += ex[j]; } }
+            const float lse = m + logf(s);
+            int act = arg;
+            if (a.mode == 1) {
+                const uint64_t gi = (uint64_t)e0 * N + (uint64_t)lane;  // global row env * N + agent
+                const float u = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)t * B * N + gi) * s;
+                float cs = 0.f;
+                bool found = false;
+                act = A - 1;
+#pragma unroll
+                for (int j = 0; j < kLdo; ++j)
+                    if (j < A) {
+                        cs += ex[j];
+                        if (!found && u < cs) { act = j; found = true; }
+                    }
+            }
+            float la = lg[0];
+#pragma unroll
+            for (int j = 1; j < kLdo; ++j) la = act == j ? lg[j] : la;
+            s_act[lane] = act;
+            s_logp[lane] = la - lse;
+        }
+        WSTAMP(5);
+        // ---- C. env step (mpe_dev.h): 16 x 8 pair tasks over the 64 lanes, folded by the agent lanes in partner order ----
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = lane + 64 * q, jp = p & 7;
+            float sx = 0.f, sy = 0.f;
+            int ok = 0;
+            if (pair_ei[q] >= 0 && jp < N) {
+                const int ip = pair_ei[q] & 7;
+                const float *ap = s_ap + (pair_ei[q] >> 3) * st;
+                if (jp != ip) ok = mpe_pair_force(c, ap[2 * ip], ap[2 * ip + 1], ap[2 * jp], ap[2 * jp + 1], ip, jp, sx, sy) ? 1 : 0;
+            }
+            s_cx[p] = sx; s_cy[p] = sy; s_cv[p] = ok;
+        }
+        WSTAMP(6);
+        if (lane_live) {
+            const float px = s_ap[el * st + 2 * ai], py = s_ap[el * st + 2 * ai + 1];
+            const float vx = s_av[el * st + 2 * ai], vy = s_av[el * st + 2 * ai + 1];
+            float fx = mpe_action_force(c, s_act[r], 0);
+            float fy = mpe_action_force(c, s_act[r], 1);
+            {   // the row's 8 pair terms in six 16-byte reads, folded in partner order
+                typedef int i4 __attribute__((ext_vector_type(4)));
+                const i4 v0 = *reinterpret_cast<const i4 *>(s_cv + 8 * r), v1 = *reinterpret_cast<const i4 *>(s_cv + 8 * r + 4);
+                const f4 x0 = *reinterpret_cast<const f4 *>(s_cx + 8 * r), x1 = *reinterpret_cast<const f4 *>(s_cx + 8 * r + 4);
+                const f4 y0 = *reinterpret_cast<const f4 *>(s_cy + 8 * r), y1 = *reinterpret_cast<const f4 *>(s_cy + 8 * r + 4);
+#pragma unroll
+                for (int j = 0; j < kMpeMaxN; ++j) {
+                    const int ok = j < 4 ? v0[j & 3] : v1[j & 3];
+                    if (j < N && ok) { fx += j < 4 ? x0[j & 3] : x1[j & 3]; fy += j < 4 ? y0[j & 3] : y1[j & 3]; }
+                }
+            }
+            float npx, npy, nvx, nvy;
+            mpe_integrate(c, px, py, vx, vy, fx, fy, npx, npy, nvx, nvy);
+            s_ap[el * st + 2 * ai] = npx; s_ap[el * st + 2 * ai + 1] = npy;
+            s_av[el * st + 2 * ai] = nvx; s_av[el * st + 2 * ai + 1] = nvy;
+        }
+        WSTAMP(7);
+        float local = 0.f;
+        if (lane_live) {
+            const MpePos pos = mpe_load_pos(c, s_ap + el * st);
+            s_m[r] = mpe_landmark_min_dist(c, pos, s_lp + el * st, ai);
+            local = mpe_local_penalty(c, pos, s_ap + el * st, ai);
+        }
+        // obs_next rows (the terminal observation for finished episodes) straight into the buffer
+        if (a.obs_next_store) {
+            float xn[KB1];
+            obs_frags(xn);
+            if (sn_live) obs_rows_out(a.obs_next_store + s_row[sn_el] * ND + obs_col, xn);
+        }
+        if (lane_live) {   // mpe_reward's fold in landmark order, the N minima read back to back
+            float mv[kMpeMaxN];
+#pragma unroll
+            for (int l = 0; l < kMpeMaxN; ++l) mv[l] = s_m[el * N + (l < N ? l : N - 1)];
+            float global = 0.f;
+#pragma unroll
+            for (int l = 0; l < kMpeMaxN; ++l) if (l < N) global -= mv[l];
+            s_rew[r] = global * (1.f - c.local_ratio) + local * c.local_ratio;
+        }
+        WSTAMP(8);
+        if (env_lane) {  // episode returns
+            double *rec_rew = rec ? reinterpret_cast<double *>(a.ep_rec + B + (int64_t)B * a.max_ep) +
+                                        ((int64_t)be * a.max_ep + n_fin) * N : nullptr;
+#pragma unroll
+            for (int k = 0; k < kMpeMaxN; ++k) {
+                if (k < N) {
+                    const double ac = v_epret[k] + (double)s_rew[bel * N + k];
+                    a.ep_rew_out[o * N + k] = tr ? ac : 0.0;
+                    if (rec) rec_rew[k] = ac;
+                    v_epret[k] = tr ? 0.0 : ac;
+                }
+            }
+            n_fin += tr ? 1 : 0;
+        }
+        if (lane_live) {
+            const int64_t dst = s_row[el] * N + ai;
+            a.act_store[dst] = s_act[r];
+            a.rew_store[dst] = s_rew[r];
+            a.term_store[dst] = 0;
+            a.trunc_store[dst] = (uint8_t)s_done[el];
+            if (a.logp_store) a.logp_store[dst] = s_logp[r];
+        }
+        // ---- D. finished episodes: re-initialise the env (the next step's observation fragments see the new state) ----
+        if (a.auto_reset) {
+            if (env_lane && s_done[bel]) {
+                const uint64_t ep = a.episode_ctr[be];
+                s_ep[bel] = ep;
+                a.episode_ctr[be] = ep + 1;
+                s_steps[bel] = 0;
+            }
+            if (lane_live && s_done[el])
+                mpe_reset_agent(c, e, a.env_seed, s_ep[el], ai, s_ap + el * st, s_av + el * st, s_lp + el * st);
+        }
+        WSTAMP(9);
+    }
+    // the observation of the next collect() call, env state and sub-buffer bookkeeping back to HBM
+    if (a.obs_cur_out) {
+        float xn[KB1];
+        obs_frags(xn);
+        if (sn_live) obs_rows_out(a.obs_cur_out + ((int64_t)e0 * N + c16) * D + kq, xn);
+    }
+    if (lane < n_here * st) {
+        a.apos[(int64_t)e0 * st + lane] = s_ap[lane];
+        a.avel[(int64_t)e0 * st + lane] = s_av[lane];
+        a.lpos[(int64_t)e0 * st + lane] = s_lp[lane];
+    }
+    if (env_lane) {
+        a.steps[be] = s_steps[bel];
+        vs.ins[be] = v_ins; vs.size[be] = v_size; vs.ep_len[be] = v_eplen; vs.ep_start[be] = v_epstart;
+        vs.last_index[be] = v_last; vs.lengths[be] = v_size;
+        if (a.ep_rec) a.ep_rec[be] = n_fin;
+#pragma unroll
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) vs.ep_return[(int64_t)be * N + k] = v_epret[k];
+    }
+    if (a.done_ctr && tid == 0) {  // the last workgroup advances the sampling counter (every wave has read it: the barrier above)
+        if (atomicAdd(a.done_ctr, 1u) == gridDim.x - 1) {
+            *a.offset_dev_rw += a.offset_inc;
+            *a.done_ctr = 0u;
+        }
+    }
+}
+
 }  // namespace
 
 // Same descriptor as tsm_rollout_spread; `params` = the ACTOR's parameters (hidden == 128), vs_store / vnext_store are
@@ -500,13 +934,38 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
     a.offset_inc = h.offset_inc; a.done_ctr = h.done_ctr;
     a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
     a.stamps = g_tsm_stamps;
+    a.dbg = tsm_opt(TSM_OPT_DBG);
+    hipStream_t st = tsm_stream(stream);
+    if (tsm_opt(TSM_OPT_ROLLOUT_ROWS) != 1) {   // the wave-autonomous form (default); "rollout_rows" = 1 selects the tile form
+        const RwLay ly(h.obs_dim);
+        const size_t shmem = (size_t)ly.total * sizeof(float);
+        TSM_REQUIRE(shmem <= kTsmMaxLds, "tsm_rollout_spread_actor: LDS layout of %zu bytes does not fit", shmem);
+        const unsigned n_wg = (unsigned)ceil_div(a.c.n_env, kWaves * (kRowsWave / a.c.N));
+        static bool attr_w[4] = {false, false, false, false};
+#define LAUNCHW(NJ)                                                                                                    \
+    do {                                                                                                               \
+        if (!attr_w[NJ - 1]) {                                                                                         \
+            TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_wave_kernel<NJ>)));                      \
+            attr_w[NJ - 1] = true;                                                                                     \
+        }                                                                                                              \
+        hipLaunchKernelGGL((rollout_wave_kernel<NJ>), dim3(n_wg), dim3(kThreads), shmem, st, a);                       \
+    } while (0)
+        switch (ly.nJ) {
+            case 1: LAUNCHW(1); break;
+            case 2: LAUNCHW(2); break;
+            case 3: LAUNCHW(3); break;
+            default: LAUNCHW(4); break;
+        }
+#undef LAUNCHW
+        TSM_LAUNCH_CHECK();
+        return TSM_OK;
+    }
     const RrLay ly(h.obs_dim);
     const size_t shmem = (size_t)ly.total * sizeof(float);
     TSM_REQUIRE(shmem <= kTsmMaxLds, "tsm_rollout_spread_actor: LDS layout of %zu bytes does not fit", shmem);
     const int EPB = kRowsWg / a.c.N;
     const unsigned n_wg = (unsigned)ceil_div(a.c.n_env, EPB);
     static bool attr_set[4] = {false, false, false, false};
-    hipStream_t st = tsm_stream(stream);
 #define LAUNCH(NJ)                                                                                                     \
     do {                                                                                                               \
         if (!attr_set[NJ - 1]) {                                                                                       \

@@ -2,7 +2,7 @@
 """Phase time stamps of the actor-only persistent rollout (csrc/rollout_rows.hip) at BASELINE configs[2]: 4096 envs x 8
 agents, actor 48-128-128-5.  Workgroup 0, vector steps 1-3 (100 MHz wall clock).
 
-    python tools/stamp_rollout_rows.py
+    python tools/stamp_rollout_rows.py [wave|tile]      # default: the wave-autonomous form (stamps of wave 0)
 """
 import ctypes
 import os
@@ -18,6 +18,12 @@ from tianshou_marl_amd.data.collector import Collector  # noqa: E402
 from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv  # noqa: E402
 from tianshou_marl_amd.utils.net import MLPActorCritic  # noqa: E402
 
+from tianshou_marl_amd import ops  # noqa: E402
+
+form = sys.argv[1] if len(sys.argv) > 1 else "wave"
+ops.set_kernel_option("rollout_rows", 1 if form == "tile" else 2)
+if len(sys.argv) > 2:   # timing probes of the wave form (1: no matrix products, 2: no heads / env step)
+    ops.set_kernel_option("dbg", int(sys.argv[2]))
 dev = "cuda"
 E, N, T = 4096, 8, 25
 env = DeviceSimpleSpreadVectorEnv(E, N, max_cycles=T, device=dev, seed=1)
@@ -37,6 +43,15 @@ with policy_within_training_step(algo):
 torch.cuda.synchronize()
 lib.tsm_debug_set_stamps(None)
 s = st.cpu().numpy()[:128].reshape(4, 32)
+if form != "tile":
+    names = ["index algebra", "obs fragments + obs store", "layer 1", "layer 2", "logits", "heads", "pair forces",
+             "fold + integrate + publish", "reward terms + reward", "episode returns + stores + reset"]
+    for t in range(1, 4):
+        d = [(s[t][k + 1] - s[t][k]) / 100.0 for k in range(9)] + [(s[t + 1][0] - s[t][9]) / 100.0 if t < 3 else 0.0]
+        print(f"step {t}: total {(s[t][9] - s[t][0]) / 100.0:.2f} us (wave 0 of workgroup 0; the other wave of its SIMD runs beside it)")
+        print("   " + ", ".join(f"{n} {x:.2f}" for n, x in zip(names, d[:9])))
+        print(f"   forward {sum(d[2:5]):.2f}, heads + env step {sum(d[5:9]):.2f}")
+    sys.exit(0)
 names = ["index algebra", "obs rows -> buffer + X(0)"] + \
         [f"tile {i} {l}" for i in range(4) for l in ("layer 1 (+ logits of the previous tile)", "X(next) + layer 2", "logits")] + \
         ["heads + pair forces", "-", "fold + integrate + publish", "reward terms + obs_next store", "reward", "stores", "reset / end"]
