@@ -199,6 +199,20 @@ def pmc_traffic(kernel: str, grid_threads: int, expect: float | None = None):
     return min(hits, key=lambda t: abs(math.log(max(t, 1.0) / expect)))
 
 
+def pmc_issue(kernel: str, grid_threads: int) -> dict:
+    """Matrix-pipe busy share and VALU instructions per MFMA of `kernel` from the committed issue-slot accounting
+    (profiles/*pmc_issue_*.json, tools/pmc_issue.py: one rocprofv3 --pmc pass of this command).  pipe_busy is clock-independent:
+    SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles); `frac` (achieved / the 2.4 GHz peak) is pipe_busy x sustained clock / 2.4
+    (the part runs at ~1.8 GHz under sustained f32 MFMA load: profiles/r04_probe_mfma_valu_overlap.txt).  {} when no profile covers it."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_issue_*.json")), reverse=True):
+        for r in json.load(open(f))["kernels"]:
+            if kernel in r["kernel"] and r["grid"] == grid_threads:
+                return {"mfma_pipe_busy": round(r["pipe_busy"], 3), "other_valu_per_mfma": round(r["other_valu_per_mfma"], 2)}
+    return {}
+
+
 def gae_grid_threads(T: int, L: int, ch: int = 4) -> int:
     """Launch shape of tsm_gae_lanes (csrc/gae.hip pick_waves): 64 lanes x W waves per workgroup."""
     blocks = -(-L // 64)
@@ -355,6 +369,8 @@ def kernel_rooflines(a, algo, buf):
                      "achieved": upd_flop / upd_s / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": upd_flop / upd_s / MFMA_F32_PEAK,
                      "traffic": pmc_traffic("ppo_update_split_kernel", nb * 2 * 256),
+                     **pmc_issue("ppo_update_split_kernel", nb * 2 * 256),
+                     "peak_note": "the f32-MFMA peak assumes 2.4 GHz; under sustained f32-MFMA load the part measures ~1.8 GHz (profiles/r04_probe_mfma_valu_overlap.txt), so frac = matrix-pipe busy share x ~0.74; f32 MFMAs and other VALU instructions of a SIMD take turns (no overlap)",
                      "traffic_note": "HBM bytes per launch (PMC): dominated by the per-workgroup gradient slabs "
                                      "(n_blocks x n_param x 4 B written, read back by adam_kernel)",
                      "flop_per_launch": upd_flop, "flop_per_sample": fa + ba + fc + bc,
@@ -479,7 +495,8 @@ def c3_rooflines(device):
                 "in_situ_us_rocprof": in_situ_us(a_kernel, "c3ppo"), "us_per_launch": tot * 1e6,
                 "achieved": a_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": a_flop / tot / MFMA_F32_PEAK, "n_blocks": nb, "algorithmic_bytes_per_launch": a_bytes,
-                "slab_bytes_per_launch": nb * net.n_actor * 4, "traffic": pmc_traffic(a_kernel, nb * 512)})
+                "slab_bytes_per_launch": nb * net.n_actor * 4, "traffic": pmc_traffic(a_kernel, nb * 512),
+                **pmc_issue(a_kernel, nb * 512)})
     # (iii) the critic step alone: the same minibatch as whole joint rows (mb / N rows of N * D floats); two launches
     # (csrc/critic_train.hip: forward + value loss + backward to dH1; csrc/critic_dw1.hip: dW1 as a split-K pass)
     mr = mb // N
@@ -530,7 +547,8 @@ def c3_rooflines(device):
                 "slab_bytes_per_launch": (wc["rest"].numel() + wc["w1"].numel() + wc["dh1"].numel()) * 4,
                 "traffic": (lambda a_, b_: None if a_ is None or b_ is None else a_ + b_)(
                     pmc_traffic("critic_rows_train_kernel", wc["nb"] * 512),
-                    pmc_traffic("critic_dw1_kernel", -(-N * D // 48) * (-(-wc["nc"] // 8) * 8) * 512))})  # (48-column blocks at this size)
+                    pmc_traffic("critic_dw1_kernel", -(-N * D // 48) * (-(-wc["nc"] // 8) * 8) * 512)),  # (48-column blocks at this size)
+                **pmc_issue("critic_rows_train_kernel", wc["nb"] * 512)})
     # (iv) V(row) of the same critic for every joint row of the buffer (the preprocessing's critic pass), one launch
     vout = torch.empty(rows, device=device)
     tot = graph_time(lambda: ops.critic_rows_forward(net.critic.flat.data, joint, H, out=vout), n_rep=5)
@@ -541,7 +559,8 @@ def c3_rooflines(device):
                 "in_situ_us_rocprof": in_situ_us("critic_rows_forward_kernel", "c3ppo", near_us=tot * 1e6),
                 "us_per_launch": tot * 1e6, "achieved": v_flop / tot / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": v_flop / tot / MFMA_F32_PEAK, "algorithmic_bytes_per_launch": (4 * N * D + 4) * rows,
-                "traffic": pmc_traffic("critic_rows_forward_kernel", min(256, -(-rows // 32)) * 512, expect=(4 * N * D + 4) * rows)})
+                "traffic": pmc_traffic("critic_rows_forward_kernel", min(256, -(-rows // 32)) * 512, expect=(4 * N * D + 4) * rows),
+                **pmc_issue("critic_rows_forward_kernel", min(256, -(-rows // 32)) * 512)})
     return out
 
 
@@ -711,7 +730,8 @@ def run_c3ppo(a, device):
         # the kernels' own entries)
         "roofline": (lambda fl, s_: {"bound": "mfma", "kernel": "C3 whole GAE + PPO update (GenericPPO.update, one hipGraph replay)",
                                      "achieved": fl / s_ / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                                     "frac": fl / s_ / MFMA_F32_PEAK, "traffic": None, "flop_per_update": fl})(
+                                     "frac": fl / s_ / MFMA_F32_PEAK, "traffic": None, "flop_per_update": fl,
+                                     "peak_note": "the f32-MFMA peak assumes 2.4 GHz; under sustained f32-MFMA load the part measures ~1.8 GHz (profiles/r04_probe_mfma_valu_overlap.txt), so frac = matrix-pipe busy share x ~0.74; f32 MFMAs and other VALU instructions of a SIMD take turns (no overlap)"})(
             (n_env * T + n_env) * mlp_flops((N * D, 128, 128, 1))[0]
             + n_env * T * N * sum(mlp_flops((D, 128, 128, 5))) + n_env * T * sum(mlp_flops((N * D, 128, 128, 1))),
             e1.elapsed_time(e2) * 1e-3),

@@ -8,9 +8,14 @@
 Why it matters (tools/probes/mfma_valu_overlap.hip): on gfx950 an f32 MFMA and the floating-point VALU instructions of another
 wave of the same SIMD do NOT run side by side (times add; integer VALU overlaps about half, nothing is hidden for free) -- every
 VALU instruction of a kernel is time the matrix pipe does not get.  SQ_INSTS_VALU counts MFMAs too (they issue through the VALU
-port); "other VALU" below is the difference.  Counter values are summed over the device's SEs/XCDs as rocprofv3 reports them."""
+port); "other VALU" below is the difference.  Counter values are summed over the device as rocprofv3 reports them:
+SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (calibrated on the probe: exactly 32 cycles per v_mfma_f32_16x16x4_f32),
+SQ_BUSY_CYCLES over the 32 SQ instances (8 XCDs x 4 SEs), so the matrix pipe's busy share of a launch is
+MFMA_BUSY / (32 x SQ_BUSY) -- a clock-independent utilisation (the f32-MFMA peak of the roofline assumes 2.4 GHz; under
+sustained MFMA load the part runs at ~1.8 GHz, profiles/r04_probe_mfma_valu_overlap.txt)."""
 import csv
 import glob
+import json
 import re
 import sys
 from collections import defaultdict
@@ -39,13 +44,15 @@ def main(d: str, out: str) -> None:
     rows.sort(key=lambda r: -r["mfma"] * r["calls"])
     with open(out, "w") as o:
         o.write("# issue-slot accounting (rocprofv3 --pmc, per launch averages; wave-level instruction counts)\n\n")
-        o.write("| kernel | grid threads | calls | MFMA | other VALU | other VALU per MFMA | SALU | LDS | MFMA-busy / busy cycles |\n")
+        o.write("| kernel | grid threads | calls | MFMA | other VALU | other VALU per MFMA | SALU | LDS | matrix pipe busy |\n")
         o.write("|---|---:|---:|---:|---:|---:|---:|---:|---:|\n")
         for r in rows[:30]:
             per_m = r["other_valu"] / r["mfma"] if r["mfma"] else float("nan")
-            share = r["mfma_busy"] / r["busy"] if r["busy"] else float("nan")
+            share = r["mfma_busy"] / (32.0 * r["busy"]) if r["busy"] else float("nan")
+            r["pipe_busy"], r["other_valu_per_mfma"] = share, per_m
             o.write(f"| {r['kernel']} | {r['grid']} | {r['calls']} | {r['mfma']:.0f} | {r['other_valu']:.0f} | {per_m:.2f} | {r['salu']:.0f} | "
                     f"{r['lds']:.0f} | {share:.3f} |\n")
+    json.dump(dict(kernels=[r for r in rows[:30] if r["mfma"]]), open(re.sub(r"\.md$", "", out) + ".json", "w"), indent=1)
     print(open(out).read())
 
 
