@@ -55,7 +55,7 @@ int tsm_device_info(int *n_cu, int *wave_size, int64_t *hbm_bytes, char *name_ou
  *   "actor_tile"   0 = by minibatch size | 32 | 64 (tsm_ppo_actor_rows_update / _grid)            TSM_ACTOR_TILE
  *   "split_bf16"   0 | 1 = layer 1 of tsm_critic_rows_forward on the bf16 matrix pipe, three-way split operands, f32
  *                  accumulation (experimental, never the default)                                   TSM_SPLIT_BF16
- *   "rollout_rows" 0 / 2 = the wave-autonomous form of tsm_rollout_spread_actor | 1 = its tile form   TSM_ROLLOUT_ROWS */
+ *   "rollout_form" tsm_rollout_spread / tsm_rollout_spread_actor: 0 = by rule | 1 = tile form | 2 = wave-autonomous form   TSM_ROLLOUT_FORM */
 int tsm_kernel_option_get(const char *name, int32_t *value_out);
 int tsm_kernel_option_set(const char *name, int32_t value);
 

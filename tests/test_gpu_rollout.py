@@ -31,14 +31,19 @@ def _job(n_env, N, T, fused, seed=3, slots=None, **ppo_kw):
 # (1024, 3): 205 workgroups -> the eight-wave form of the kernel; (1400, 3): 280 workgroups of 70 KB LDS -> the four-wave
 # form (two workgroups per CU); (600, 8): 300 workgroups of 91 KB LDS -> eight waves again
 @pytest.mark.parametrize("n_env,N,T,steps", [(64, 3, 25, 25), (7, 3, 6, 15), (33, 8, 5, 12), (5, 1, 4, 9), (10, 2, 7, 7),
-                                             (1024, 3, 25, 25), (1400, 3, 5, 7), (600, 8, 4, 6)])
-def test_fused_rollout_is_bit_identical_to_unfused(n_env, N, T, steps):
+                                             (1024, 3, 25, 25), (1400, 3, 5, 7), (600, 8, 4, 6), (37, 6, 5, 7), (41, 5, 4, 6),
+                                             (130, 4, 6, 8), (300, 3, 5, 6), (600, 3, 5, 6)])
+@pytest.mark.parametrize("form", ["wave", "tile"])
+def test_fused_rollout_is_bit_identical_to_unfused(n_env, N, T, steps, form):
+    """Both forms of the 64-wide persistent rollout (option "rollout_form": the wave-autonomous one -- a wave owns 16 // N whole envs
+    and runs actor, critic, heads, env step and buffer rows by itself; workgroups of 1, 2 or 4 such waves: (300, 3) / (600, 3) /
+    (1024, 3) -- and the eight- / four-wave tile form) against the unfused launch sequence."""
     slots = steps + 3 + 1  # both collects fit without wrap-around
     outs = []
     for fused in (False, True):
         env, net, algo, buf, col = _job(n_env, N, T, fused, slots=slots)
         assert col._can_fuse() == fused
-        with policy_within_training_step(algo):
+        with policy_within_training_step(algo), ops.kernel_override(rollout_form=1 if form == "tile" else 2):
             st1 = col.collect(n_step=n_env * steps)
             st2 = col.collect(n_step=n_env * 3)  # continues mid-episode, crosses resets for short horizons
         outs.append(dict(
@@ -109,7 +114,7 @@ def _job128(n_env, N, T, fused, glob, seed=3, slots=None):
                                                   (130, 4, 6, 8, True)])
 @pytest.mark.parametrize("form", ["wave", "tile"])
 def test_actor_rollout_is_bit_identical_to_unfused(n_env, N, T, steps, glob, form):
-    """Both forms of the actor-only rollout (option "rollout_rows": the wave-autonomous default -- a wave owns 16 // N whole
+    """Both forms of the actor-only rollout (option "rollout_form": the wave-autonomous default -- a wave owns 16 // N whole
     envs, transposed products, no workgroup barrier in the step loop -- and round 2's tile form) against the unfused launch
     sequence.  (37, 6) / (9, 2) / (130, 4): 2 / 8 / 4 envs per wave with 12 / 16 / 16 live rows, partial last waves."""
     from tianshou_marl_amd import ops
@@ -119,7 +124,7 @@ def test_actor_rollout_is_bit_identical_to_unfused(n_env, N, T, steps, glob, for
     for fused in (False, True):
         env, net, algo, buf, col = _job128(n_env, N, T, fused, glob, slots=slots)
         assert col._can_fuse() == fused and col._can_fuse_actor() == fused
-        with policy_within_training_step(algo), ops.kernel_override(rollout_rows=1 if form == "tile" else 2):
+        with policy_within_training_step(algo), ops.kernel_override(rollout_form=1 if form == "tile" else 2):
             st1 = col.collect(n_step=n_env * steps)
             st2 = col.collect(n_step=n_env * 3)
         outs.append(dict(

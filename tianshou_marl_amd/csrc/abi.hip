@@ -82,15 +82,16 @@ TSM_EXPORT int tsm_stream_abort_capture(void *stream) {
 //   "actor_tile"  0: by minibatch size (tsm_ppo_actor_rows_grid) | 32 | 64      env TSM_ACTOR_TILE
 //   "split_bf16"  0: f32 matrix pipe | 1: layer 1 of the critic forward on the bf16 pipe with three-way split operands
 //                 (experimental, never the default)                              env TSM_SPLIT_BF16
-//   "rollout_rows" 0 / 2: the wave-autonomous actor rollout (csrc/rollout_rows.hip) | 1: its tile form (round 2)
-//                                                                                   env TSM_ROLLOUT_ROWS
+//   "rollout_form" the persistent rollouts (tsm_rollout_spread, tsm_rollout_spread_actor): 0 by rule (wave-autonomous form where
+//                 all its waves are resident at once) | 1: tile form | 2: wave-autonomous form
+//                                                                                   env TSM_ROLLOUT_FORM
 namespace {
 struct KernelOption { const char *name, *env; int value; bool resolved; };
 KernelOption g_opts[TSM_OPT_COUNT] = {{"actor_tile", "TSM_ACTOR_TILE", 0, false}, {"split_bf16", "TSM_SPLIT_BF16", 0, false},
-                                      {"dbg", "TSM_DBG", 0, false}, {"rollout_rows", "TSM_ROLLOUT_ROWS", 0, false}};
+                                      {"dbg", "TSM_DBG", 0, false}, {"rollout_form", "TSM_ROLLOUT_FORM", 0, false}};
 bool opt_valid(int id, int v) {
     if (id == TSM_OPT_DBG) return v >= 0;   // diagnostics bit mask (tools/ only; kernels compute garbage under it)
-    if (id == TSM_OPT_ROLLOUT_ROWS) return v >= 0 && v <= 2;
+    if (id == TSM_OPT_ROLLOUT_FORM) return v >= 0 && v <= 2;
     return id == TSM_OPT_ACTOR_TILE ? (v == 0 || v == 32 || v == 64) : (v == 0 || v == 1);
 }
 }  // namespace

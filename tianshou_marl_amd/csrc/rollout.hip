@@ -21,6 +21,7 @@
 #include "mpe_dev.h"
 #include "philox.h"
 #include "vrb_dev.h"
+#include "wave_mlp.h"
 
 int tsm_mpe_check_cfg(const tsm_mpe_cfg *h, MpeCfg *c);  // mpe.hip
 extern long long *g_tsm_stamps;                               // abi.hip (diagnostics)
@@ -365,6 +366,405 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     }
 }
 
+// ---- wave-autonomous form ------------------------------------------------------------------------------------------------
+// rollout_kernel above runs one 16-row tile per workgroup on eight waves: every phase of a vector step (forward layer by layer,
+// heads, env step, scatter) is a workgroup-wide phase behind a barrier, ~10 barriers and 8.8 us per step at BASELINE configs[1]
+// (1024 envs x 3 agents: 205 workgroups), with the matrix pipe busy 7 % of the time.  Here ONE WAVE owns the 16 / N environments
+// (<= 16 agent rows) for all T steps and runs a step from the observation to the buffer rows by itself, with no barrier and no
+// cross-wave hand-over: both nets' layers as transposed products on the wave's samples (wave_mlp.h: weights = A operand read
+// from the very LDS image the tile form stages, samples = B operand in registers), the critic's value as the tile form's 64-long
+// fmaf chain on one lane per row, heads one lane per row (the arithmetic of categorical.hip, as in rollout_rows.hip), pair
+// forces as 16 x 8 tasks over the 64 lanes folded in partner order.  Bit-identical to the tile form and to the unfused launch
+// sequence (tests/test_gpu_pipeline.py, tests/test_gpu_rollout.py).  A workgroup is 1, 2 or 4 such waves sharing one weight image.
+struct Rw64Lay {  // offsets (floats) inside a wave's private LDS block
+    static constexpr int kLdc = 68;  // critic layer-2 row: 64 + 4 (16-byte aligned rows, conflict-free 16-byte reads)
+    int AP, AV, LP, LG, H2C, VAL, CX, CY, CV, MIN, REW, LOGP, ACT, STEPS, DONE, ROW, EP, size;
+    __host__ __device__ Rw64Lay() {
+        int q = 0;
+        AP = q; q += 2 * R;
+        AV = q; q += 2 * R;
+        LP = q; q += 2 * R;
+        LG = q; q += R * 16;          // logits [16 rows][16]
+        H2C = q; q += R * kLdc;       // critic layer-2 activations [16 rows][64]
+        VAL = q; q += R;
+        CX = q; q += R * 8;
+        CY = q; q += R * 8;
+        CV = q; q += R * 8;           // int
+        MIN = q; q += R;
+        REW = q; q += R;
+        LOGP = q; q += R;
+        ACT = q; q += R;              // int
+        STEPS = q; q += R;            // int [envs of the wave]
+        DONE = q; q += R;             // int
+        ROW = q; q += 2 * R;          // int64
+        EP = q; q += 2 * R;           // uint64
+        size = (q + 3) & ~3;
+    }
+};
+
+template <int NJ>
+__global__ __launch_bounds__(NT) void rollout_wave64_kernel(RolloutArgs a) {
+    constexpr int H = 64, MB = H / 16, KB1 = 4 * NJ, KBH = H / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Dims d = a.d;
+    const MpeCfg c = a.c;
+    const Lay<H> ly(d, false);
+    const Rw64Lay wl;
+    constexpr int ld1 = 16 * NJ + 2;   // == d.ld1
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n_waves = blockDim.x >> 6, c16 = lane & 15, kq = lane >> 4;
+    const int N = c.N, D = d.D, A = d.A, st = 2 * N;
+    const int EPW = R / N;                                   // whole environments per wave
+    const int e0 = (blockIdx.x * n_waves + w) * EPW;         // first env of this wave
+    const int n_here = max(0, min(EPW, c.n_env - e0));
+    const int rows_here = n_here * N;
+    const int64_t B = c.n_env;
+    // ---- the weight image (exactly Lay<64>'s [0, X): W1 actor | critic, W2a, W2c, W3a, W3c, biases) ----
+    const int img_floats = image_f4_padded(ly.X) * 4;        // the DMA copies whole chunks (zeros behind ly.X)
+    if (a.img) {
+        const int n4p = img_floats / 4, wave_base = w * 64;
+        for (int e = 0; e < n4p; e += blockDim.x)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.img + (size_t)(e + tid) * 4),
+                                             (__attribute__((address_space(3))) void *)(lds + (size_t)(e + wave_base) * 4), 16, 0, 0);
+    } else {
+        for (int v = tid; v < NT; v += blockDim.x) stage_weights<H>(lds, ly, d, a.P, v);   // (the work of virtual thread v of NT)
+    }
+    const int wvo = img_floats + w * wl.size;
+    float *wv = lds + wvo;
+    float *s_ap = wv + wl.AP, *s_av = wv + wl.AV, *s_lp = wv + wl.LP, *s_lg = wv + wl.LG, *s_h2c = wv + wl.H2C, *s_val = wv + wl.VAL,
+          *s_cx = wv + wl.CX, *s_cy = wv + wl.CY, *s_m = wv + wl.MIN, *s_rew = wv + wl.REW, *s_logp = wv + wl.LOGP;
+    int *s_cv = reinterpret_cast<int *>(wv + wl.CV), *s_act = reinterpret_cast<int *>(wv + wl.ACT),
+        *s_steps = reinterpret_cast<int *>(wv + wl.STEPS), *s_done = reinterpret_cast<int *>(wv + wl.DONE);
+    int64_t *s_row = reinterpret_cast<int64_t *>(wv + wl.ROW);
+    uint64_t *s_ep = reinterpret_cast<uint64_t *>(wv + wl.EP);
+
+    const VrbState vs = vrb_view(a.vrb_state, B, N);
+    // agent lane r = lane < rows_here <-> (env el, agent ai) of the wave; env lane 16 + bel owns env bel's bookkeeping
+    const int r = lane, el = r / N, ai = r - el * N;
+    const bool lane_live = r < rows_here;
+    const int e = e0 + el;
+    const int bel = lane - 16;
+    const bool env_lane = bel >= 0 && bel < n_here;
+    const int be = e0 + bel;
+    int64_t v_ins = 0, v_size = 0, v_eplen = 0, v_epstart = 0, v_last = 0;
+    int n_fin = 0;
+    double v_epret[kMpeMaxN];
+#pragma unroll
+    for (int k = 0; k < kMpeMaxN; ++k) v_epret[k] = 0.0;
+    if (env_lane) {
+        v_ins = vs.ins[be]; v_size = vs.size[be]; v_eplen = vs.ep_len[be]; v_epstart = vs.ep_start[be];
+        v_last = vs.last_index[be];
+#pragma unroll
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) v_epret[k] = vs.ep_return[(int64_t)be * N + k];
+    }
+    float st_ap = 0.f, st_av = 0.f, st_lp = 0.f;   // (the wave's env state: loaded here, stored to LDS behind the barrier)
+    if (lane < n_here * st) {
+        st_ap = a.apos[(int64_t)e0 * st + lane]; st_av = a.avel[(int64_t)e0 * st + lane]; st_lp = a.lpos[(int64_t)e0 * st + lane];
+    }
+    const int steps0 = env_lane ? a.steps[be] : 0;
+    const uint64_t off0 = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
+    __syncthreads();   // weights staged (the DMA may have written zeros past the image: private blocks are initialised below);
+                       // every wave has read the sampling counter.  The only workgroup barrier.
+    if (n_here == 0) return;  // a wave without environments (never wave 0, whose thread 0 updates the counter at the end)
+    if (env_lane) { s_steps[bel] = steps0; s_done[bel] = 1; s_row[bel] = 0; }   // done = 1: "no pending V(obs_next)"
+    if (lane < n_here * st) { s_ap[lane] = st_ap; s_av[lane] = st_av; s_lp[lane] = st_lp; }
+    if (lane < 16) s_lg[16 * 16 - 1 - lane] = 0.f;   // (the zero cell of the observation fragments lives in the last logits row pad)
+
+    // ---- observation fragments: element k = 4 kb + kq of sample c16 (one LDS value or the difference of two; the two offsets
+    //      are worked out once; a zero cell stands in where there is no subtrahend, for k >= D and for samples >= rows_here) ----
+    const int zoff = wvo + wl.LG + 16 * 15 + 15;   // row 15, column 15 of the logits block: rows_here <= 15 whenever N does not
+                                                   // divide 16 ... and for N | 16 column 15 >= A is never written: always 0.f
+    uint32_t el_ab[KB1];
+    const int sn_el = c16 / N, sn_ai = c16 - sn_el * N;
+    const bool sn_live = c16 < rows_here;
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb) {
+        const int k = 4 * kb + kq;
+        int oa = zoff, ob = zoff;
+        if (sn_live && k < D) {
+            const int base = sn_el * st, i_ = sn_ai;
+            if (k < 2) oa = wvo + wl.AV + base + 2 * i_ + k;
+            else if (k < 4) oa = wvo + wl.AP + base + 2 * i_ + (k - 2);
+            else {
+                int kk = k - 4;
+                if (kk < 2 * N) { oa = wvo + wl.LP + base + kk; ob = wvo + wl.AP + base + 2 * i_ + (kk & 1); }
+                else {
+                    kk -= 2 * N;
+                    if (kk < 2 * (N - 1)) {
+                        int jj = kk >> 1;
+                        const int x = kk & 1;
+                        if (jj >= i_) ++jj;  // others in increasing index, skipping self
+                        oa = wvo + wl.AP + base + 2 * jj + x; ob = wvo + wl.AP + base + 2 * i_ + x;
+                    }
+                }
+            }
+        }
+        el_ab[kb] = ((uint32_t)oa << 16) | (uint32_t)ob;
+    }
+    const int ND = N * D;
+    const int obs_col = sn_ai * D + kq;
+    auto obs_frags = [&](float (&x)[KB1]) {
+        float xa[KB1], xs[KB1];
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) { xa[kb] = lds[el_ab[kb] >> 16]; xs[kb] = lds[el_ab[kb] & 0xFFFFu]; }
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) x[kb] = xa[kb] - xs[kb];
+    };
+    const int kb_full = D >> 2, k_rem = D & 3;
+    auto obs_rows_out = [&](float *dst, const float (&x)[KB1]) {
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+            if (kb < kb_full) dst[4 * kb] = x[kb];
+            else if (kb == kb_full && kq < k_rem) dst[4 * kb] = x[kb];
+        }
+    };
+    int pair_ei[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rp = (lane + 64 * q) >> 3, ep = rp / N;
+        pair_ei[q] = rp < rows_here ? (ep << 3) | (rp - ep * N) : -1;
+    }
+    const int kb1_n = d.Kp1 >> 2;   // k-steps of layer 1 (the tile form's k extent: D rounded up to 4)
+    const float *w1a = lds + ly.W1 + c16 * ld1 + kq, *w1c = w1a + H * ld1;
+    const float *w2a = lds + ly.W2a + c16 * ly.ldh + kq, *w2c = lds + ly.W2c + c16 * ly.ldh + kq, *w3a = lds + ly.W3a + c16 * ly.ldh + kq;
+    // V(row) of the wave's samples from the observation fragments: layers 1, 2 as products, layer 3 as mlp_tile.h's fmaf chain
+    // (s = fmaf(h[j], w3[j], s), j = 0 .. 63, + b3) on lane `row`; returned on lanes < 16
+    auto critic_value = [&](const float (&x)[KB1]) -> float {
+        wf4 acc[MB];
+        float hb[4 * MB];
+        wave_layer<MB, KB1>(w1c, ld1, x, kb1_n, acc);
+        wave_bias_relu<MB, true>(lds + ly.B1 + H + 4 * kq, acc);
+        wave_to_frags<MB>(acc, hb);
+        wave_layer<MB, KBH>(w2c, ly.ldh, hb, KBH, acc);
+        wave_bias_relu<MB, true>(lds + ly.B2 + H + 4 * kq, acc);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) *reinterpret_cast<wf4 *>(s_h2c + c16 * Rw64Lay::kLdc + 16 * mb + 4 * kq) = acc[mb];
+        float s = 0.f;
+        if (lane < R) {
+            wf4 hv[H / 4], wq[H / 4];
+#pragma unroll
+            for (int q = 0; q < H / 4; ++q) {
+                hv[q] = *reinterpret_cast<const wf4 *>(s_h2c + lane * Rw64Lay::kLdc + 4 * q);
+                wq[q] = *reinterpret_cast<const wf4 *>(lds + ly.W3c + 4 * q);
+            }
+#pragma unroll
+            for (int j = 0; j < H; ++j) s = fmaf(hv[j >> 2][j & 3], wq[j >> 2][j & 3], s);
+            s += lds[ly.B3c];
+        }
+        return s;
+    };
+
+    for (int t = 0; t <= a.n_steps; ++t) {
+        const bool last = t == a.n_steps;  // extra pass: bootstrap value of the final observation only
+        // the previous step's row slot / done flag of this lane's env (V(obs_next) of step t - 1 == V(obs) of step t)
+        int64_t p_row = 0;
+        int p_done = 1;
+        if (lane_live) { p_row = s_row[el]; p_done = s_done[el]; }
+        // ---- A. buffer index algebra of this step on the env lanes ----
+        bool tr = false, rec = false;
+        int64_t o = 0;
+        if (env_lane && !last) {
+            const int stp = s_steps[bel] + 1;
+            tr = stp >= c.max_cycles;
+            s_steps[bel] = stp;
+            o = (int64_t)t * B + be;
+            const int64_t cur = v_ins;
+            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
+            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
+            const int64_t elen = v_eplen + 1;
+            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
+            rec = tr && a.ep_rec && n_fin < a.max_ep;
+            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | elen;
+            a.ep_len_out[o] = tr ? elen : 0;
+            a.ptr_out[o] = cur + (int64_t)be * a.S;
+            a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
+            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
+            v_last = cur + (int64_t)be * a.S;
+            a.done_store[cur * B + be] = tr ? 1 : 0;
+            s_row[bel] = cur * B + be;
+            s_done[bel] = tr ? 1 : 0;
+        }
+        // ---- B. observation fragments (also the buffer's obs rows), critic value, actor logits ----
+        float xb[KB1];
+        obs_frags(xb);
+        if (last) {
+            if (a.obs_cur_out && sn_live) obs_rows_out(a.obs_cur_out + ((int64_t)e0 * N + c16) * D + kq, xb);
+        } else if (sn_live) {
+            obs_rows_out(a.obs_store + s_row[sn_el] * ND + obs_col, xb);
+        }
+        const float val = critic_value(xb);
+        if (lane_live && !p_done && a.vnext_store) a.vnext_store[p_row * N + ai] = val;
+        if (last) break;
+        {
+            wf4 acc[MB];
+            float hb[4 * MB];
+            wave_layer<MB, KB1>(w1a, ld1, xb, kb1_n, acc);
+            wave_bias_relu<MB, true>(lds + ly.B1 + 4 * kq, acc);
+            wave_to_frags<MB>(acc, hb);
+            wave_layer<MB, KBH>(w2a, ly.ldh, hb, KBH, acc);
+            wave_bias_relu<MB, true>(lds + ly.B2 + 4 * kq, acc);
+            wave_to_frags<MB>(acc, hb);
+            wf4 lg = wf4{0.f, 0.f, 0.f, 0.f};   // logits (A padded to 16): lane holds actions 4 kq + i of sample c16
+#pragma unroll
+            for (int kb = 0; kb < KBH; ++kb) lg = wave_mfma4(w3a[4 * kb], hb[kb], lg);
+            const wf4 b = *reinterpret_cast<const wf4 *>(lds + ly.B3a + 4 * kq);
+            // (row 15 / column 15 holds the zero cell: never a live logit -- A <= 8 here; the write below keeps it 0 + 0)
+            if (!(c16 == 15 && kq == 3))
+                *reinterpret_cast<wf4 *>(s_lg + c16 * 16 + 4 * kq) = wf4{lg[0] + b[0], lg[1] + b[1], lg[2] + b[2], lg[3] + b[3]};
+        }
+        // ---- C. heads: one lane per row, the arithmetic of categorical.hip ----
+        if (lane_live) {
+            float lgv[8], ex[8];
+            {
+                const wf4 l0 = *reinterpret_cast<const wf4 *>(s_lg + lane * 16), l1 = *reinterpret_cast<const wf4 *>(s_lg + lane * 16 + 4);
+                lgv[0] = l0[0]; lgv[1] = l0[1]; lgv[2] = l0[2]; lgv[3] = l0[3]; lgv[4] = l1[0]; lgv[5] = l1[1]; lgv[6] = l1[2]; lgv[7] = l1[3];
+            }
+            float m = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < A && lgv[j] > m) { m = lgv[j]; arg = j; }
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ex[j] = 0.f; if (j < A) { ex[j] = expf(lgv[j] - m); s += ex[j]; } }
+            const float lse = m + logf(s);
+            int act = arg;
+            if (a.mode == 1) {
+                const uint64_t gi = (uint64_t)e0 * N + (uint64_t)lane;  // global row env * N + agent
+                const float u = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)t * B * N + gi) * s;
+                float cs = 0.f;
+                bool found = false;
+                act = A - 1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < A) {
+                        cs += ex[j];
+                        if (!found && u < cs) { act = j; found = true; }
+                    }
+            }
+            float la = lgv[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) la = act == j ? lgv[j] : la;
+            s_act[lane] = act;
+            s_logp[lane] = la - lse;
+            s_val[lane] = val;
+        }
+        // ---- D. env step (mpe_dev.h): 16 x 8 pair tasks over the 64 lanes, folded by the agent lanes in partner order ----
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = lane + 64 * q, jp = p & 7;
+            float sx = 0.f, sy = 0.f;
+            int ok = 0;
+            if (pair_ei[q] >= 0 && jp < N) {
+                const int ip = pair_ei[q] & 7;
+                const float *ap = s_ap + (pair_ei[q] >> 3) * st;
+                if (jp != ip) ok = mpe_pair_force(c, ap[2 * ip], ap[2 * ip + 1], ap[2 * jp], ap[2 * jp + 1], ip, jp, sx, sy) ? 1 : 0;
+            }
+            s_cx[p] = sx; s_cy[p] = sy; s_cv[p] = ok;
+        }
+        if (lane_live) {
+            const float px = s_ap[el * st + 2 * ai], py = s_ap[el * st + 2 * ai + 1];
+            const float vx = s_av[el * st + 2 * ai], vy = s_av[el * st + 2 * ai + 1];
+            float fx = mpe_action_force(c, s_act[r], 0);
+            float fy = mpe_action_force(c, s_act[r], 1);
+            {
+                typedef int i4 __attribute__((ext_vector_type(4)));
+                const i4 v0 = *reinterpret_cast<const i4 *>(s_cv + 8 * r), v1 = *reinterpret_cast<const i4 *>(s_cv + 8 * r + 4);
+                const wf4 x0 = *reinterpret_cast<const wf4 *>(s_cx + 8 * r), x1 = *reinterpret_cast<const wf4 *>(s_cx + 8 * r + 4);
+                const wf4 y0 = *reinterpret_cast<const wf4 *>(s_cy + 8 * r), y1 = *reinterpret_cast<const wf4 *>(s_cy + 8 * r + 4);
+#pragma unroll
+                for (int j = 0; j < kMpeMaxN; ++j) {
+                    const int ok = j < 4 ? v0[j & 3] : v1[j & 3];
+                    if (j < N && ok) { fx += j < 4 ? x0[j & 3] : x1[j & 3]; fy += j < 4 ? y0[j & 3] : y1[j & 3]; }
+                }
+            }
+            float npx, npy, nvx, nvy;
+            mpe_integrate(c, px, py, vx, vy, fx, fy, npx, npy, nvx, nvy);
+            s_ap[el * st + 2 * ai] = npx; s_ap[el * st + 2 * ai + 1] = npy;
+            s_av[el * st + 2 * ai] = nvx; s_av[el * st + 2 * ai + 1] = nvy;
+        }
+        float local = 0.f;
+        if (lane_live) {
+            const MpePos pos = mpe_load_pos(c, s_ap + el * st);
+            s_m[r] = mpe_landmark_min_dist(c, pos, s_lp + el * st, ai);
+            local = mpe_local_penalty(c, pos, s_ap + el * st, ai);
+        }
+        // obs_next fragments (the terminal observation for finished episodes): into the buffer, and kept for F
+        float xn[KB1];
+        const unsigned long long done_mask = __ballot(lane_live && s_done[el]);
+        if (a.obs_next_store || (done_mask && a.vnext_store)) obs_frags(xn);
+        if (a.obs_next_store && sn_live) obs_rows_out(a.obs_next_store + s_row[sn_el] * ND + obs_col, xn);
+        if (lane_live) {
+            float mv[kMpeMaxN];
+#pragma unroll
+            for (int l = 0; l < kMpeMaxN; ++l) mv[l] = s_m[el * N + (l < N ? l : N - 1)];
+            float global = 0.f;
+#pragma unroll
+            for (int l = 0; l < kMpeMaxN; ++l) if (l < N) global -= mv[l];
+            s_rew[r] = global * (1.f - c.local_ratio) + local * c.local_ratio;
+        }
+        if (env_lane) {  // episode returns
+            double *rec_rew = rec ? reinterpret_cast<double *>(a.ep_rec + B + (int64_t)B * a.max_ep) +
+                                        ((int64_t)be * a.max_ep + n_fin) * N : nullptr;
+#pragma unroll
+            for (int k = 0; k < kMpeMaxN; ++k) {
+                if (k < N) {
+                    const double ac = v_epret[k] + (double)s_rew[bel * N + k];
+                    a.ep_rew_out[o * N + k] = tr ? ac : 0.0;
+                    if (rec) rec_rew[k] = ac;
+                    v_epret[k] = tr ? 0.0 : ac;
+                }
+            }
+            n_fin += tr ? 1 : 0;
+        }
+        // ---- E. payload ----
+        if (lane_live) {
+            const int64_t dst = s_row[el] * N + ai;
+            a.act_store[dst] = s_act[r];
+            a.rew_store[dst] = s_rew[r];
+            a.term_store[dst] = 0;
+            a.trunc_store[dst] = (uint8_t)s_done[el];
+            if (a.logp_store) a.logp_store[dst] = s_logp[r];
+            if (a.vs_store) a.vs_store[dst] = s_val[r];
+        }
+        // ---- F. finished episodes: critic value of the terminal observation, then re-initialise the env ----
+        if (done_mask) {   // (wave-uniform)
+            if (a.vnext_store) {
+                const float vt = critic_value(xn);
+                if (lane_live && s_done[el]) a.vnext_store[s_row[el] * N + ai] = vt;
+            }
+            if (a.auto_reset) {
+                if (env_lane && s_done[bel]) {
+                    const uint64_t ep = a.episode_ctr[be];
+                    s_ep[bel] = ep;
+                    a.episode_ctr[be] = ep + 1;
+                    s_steps[bel] = 0;
+                }
+                if (lane_live && s_done[el])
+                    mpe_reset_agent(c, e, a.env_seed, s_ep[el], ai, s_ap + el * st, s_av + el * st, s_lp + el * st);
+            }
+        }
+    }
+    // env state + sub-buffer bookkeeping back to HBM
+    if (lane < n_here * st) {
+        a.apos[(int64_t)e0 * st + lane] = s_ap[lane];
+        a.avel[(int64_t)e0 * st + lane] = s_av[lane];
+        a.lpos[(int64_t)e0 * st + lane] = s_lp[lane];
+    }
+    if (env_lane) {
+        a.steps[be] = s_steps[bel];
+        vs.ins[be] = v_ins; vs.size[be] = v_size; vs.ep_len[be] = v_eplen; vs.ep_start[be] = v_epstart;
+        vs.last_index[be] = v_last; vs.lengths[be] = v_size;
+        if (a.ep_rec) a.ep_rec[be] = n_fin;  // may exceed max_ep: the host treats that as an overflow
+#pragma unroll
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) vs.ep_return[(int64_t)be * N + k] = v_epret[k];
+    }
+    if (a.done_ctr && tid == 0) {  // the last workgroup advances the sampling counter (every wave has read it: the barrier above)
+        if (atomicAdd(a.done_ctr, 1u) == gridDim.x - 1) {
+            *a.offset_dev_rw += a.offset_inc;
+            *a.done_ctr = 0u;
+        }
+    }
+}
+
 __global__ void u64_add_kernel(uint64_t *p, uint64_t inc) { *p += inc; }
 
 }  // namespace
@@ -409,6 +809,40 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
     a.stamps = g_tsm_stamps;
     const Lay<64> ly(a.d, false);
+    {   // Which form (option "rollout_form": 0 by rule, 1 tile, 2 wave).  Rule: the tile form while its workgroups (one 16-row tile
+        // each) fit the CUs in one round, the wave-autonomous form above that.  Measured (us per 25-step collect + reset_buffer,
+        // tile / wave, tools/time_rollout64.py): 512 envs x 3 agents 315 / 385; 1024 x 3 336 / 406; 1536 x 3 1041 / 421;
+        // 2048 x 3 412 / 438; 4096 x 3 1221 / 516; 1024 x 8 696 / 501; 4096 x 8 2400 / 966 -- one wave running a step by
+        // itself takes 12.8 us against the eight cooperating waves' 9.7, but it does not queue behind a second round of workgroups.
+        const int form = tsm_opt(TSM_OPT_ROLLOUT_FORM);
+        const int64_t total_waves = ceil_div(a.c.n_env, R / a.c.N);
+        if (form == 2 || (form == 0 && total_waves > 256)) {
+            int n_waves = 1;
+            while (n_waves < 4 && ceil_div(total_waves, n_waves) > 256) n_waves *= 2;
+            const Rw64Lay wl;
+            const size_t shmem_w = ((size_t)image_f4_padded(ly.X) * 4 + (size_t)n_waves * wl.size) * sizeof(float);
+            TSM_REQUIRE(shmem_w <= kTsmMaxLds, "tsm_rollout_spread: LDS layout of %zu bytes does not fit", shmem_w);
+            const unsigned n_wg_w = (unsigned)ceil_div(total_waves, n_waves);
+            static bool attr_w[4] = {false, false, false, false};
+#define LAUNCHW(NJ)                                                                                                    \
+    do {                                                                                                               \
+        if (!attr_w[NJ - 1]) {                                                                                         \
+            TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_wave64_kernel<NJ>)));                    \
+            attr_w[NJ - 1] = true;                                                                                     \
+        }                                                                                                              \
+        hipLaunchKernelGGL((rollout_wave64_kernel<NJ>), dim3(n_wg_w), dim3(64 * n_waves), shmem_w, tsm_stream(stream), a); \
+    } while (0)
+            switch (a.d.nJ) {
+                case 1: LAUNCHW(1); break;
+                case 2: LAUNCHW(2); break;
+                case 3: LAUNCHW(3); break;
+                default: LAUNCHW(4); break;
+            }
+#undef LAUNCHW
+            TSM_LAUNCH_CHECK();
+            return TSM_OK;
+        }
+    }
     const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8;
     const size_t shmem = ((size_t)ly.total + extra) * sizeof(float);
     static bool attr_set = false;

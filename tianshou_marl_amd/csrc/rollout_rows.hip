@@ -19,6 +19,7 @@
 #include "mpe_dev.h"
 #include "philox.h"
 #include "vrb_dev.h"
+#include "wave_mlp.h"
 
 int tsm_mpe_check_cfg(const tsm_mpe_cfg *h, MpeCfg *c);  // mpe.hip
 extern long long *g_tsm_stamps;                               // abi.hip (diagnostics, tools/stamp_rollout_rows.py)
@@ -478,13 +479,7 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
 // does not run under the f32 MFMAs of the other wave of its SIMD -- on gfx950 an f32 MFMA and another wave's VALU instructions
 // take turns (times add: 10.9 us of MFMAs + 8.5 us of everything else per step, with or without a phase offset between the two
 // waves, with or without s_setprio), so the step's floor is the sum of the two instruction streams, not their maximum.
-//   * Products are formed TRANSPOSED: the weights are the A operand (m = output unit, fragments read from LDS in the same
-//     [unit][k] layout as above), the wave's samples are the B operand (n = sample, k = lane >> 4) held in REGISTERS.  Each
-//     output element is the same chain c + sum_k a_k b_k over the same k order as in the tile form (the roles of the factors
-//     are exchanged, the products are not): bit-identical activations.
-//   * The accumulator layout (lane: sample = lane & 15, units 16 mb + 4 (lane >> 4) + i) becomes the next layer's B fragments
-//     (unit 4 kb + (lane >> 4)) by a 4 x 4 transpose between register index and lane group: v_permlane32_swap +
-//     v_permlane16_swap (gfx950), four instructions per 16 units, no LDS round trip (tools/probes/permlane_swap.hip).
+//   * The layers run on the wave's 16 samples as transposed products with register-resident activations (wave_mlp.h).
 //   * Env state, logits, pair forces and the per-env bookkeeping live in a 3 KB LDS block private to the wave; LDS accesses of
 //     one wave execute in program order, so a value written by one lane is seen by the later read of another lane.
 constexpr int kWaves = kThreads / 64, kRowsWave = 16;
@@ -525,44 +520,6 @@ struct RwLay {  // LDS layout in floats: weights as in RrLay, then one private b
         total = WV + kWaves * wv;
     }
 };
-
-// 4 x 4 transpose between the register index and the lane group (lane >> 4): afterwards r[j] of group g holds what r[g] of
-// group j held.  (Inline asm: with this compiler the second result of __builtin_amdgcn_permlane*_swap aliases the first.)
-__device__ __forceinline__ void lane_group_transpose(f4 &r) {
-    float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1\n\t"
-                 "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
-                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-    r = f4{r0, r1, r2, r3};
-}
-
-// one layer on the wave's 16 samples: out[unit][sample] = sum_k W[unit][k] x[k][sample]; xb[kb] = the B fragment of k-step kb
-template <int KB>
-__device__ __forceinline__ void wave_layer(const float *__restrict__ wfrag /* W + c16 * ld + kq */, int ld, const float (&xb)[KB],
-                                           f4 (&acc)[8]) {
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc[mb] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) acc[mb] = mfma4(wfrag[16 * mb * ld + 4 * kb], xb[kb], acc[mb]);
-}
-
-// bias + ReLU in the accumulator layout, then the accumulators of 16 units become four B fragments of the next layer
-__device__ __forceinline__ void wave_relu_to_frags(const float *__restrict__ bias /* b + 4 * kq */, f4 (&acc)[8], float (&hb)[32]) {
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-        const f4 b = *reinterpret_cast<const f4 *>(bias + 16 * mb);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float v = acc[mb][i] + b[i];
-            acc[mb][i] = v > 0.f ? v : 0.f;
-        }
-        lane_group_transpose(acc[mb]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) hb[4 * mb + j] = acc[mb][j];
-    }
-}
 
 #define WSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && t < 4) a.stamps[t * 32 + (k)] = (long long)wall_clock64(); } while (0)
 
@@ -726,11 +683,13 @@ __global__ __launch_bounds__(kThreads) void rollout_wave_kernel(RrArgs a) {
             for (int i = 0; i < 32; ++i) hb[i] = xb[i % KB1];
             if (kq < kLdo / 4) *reinterpret_cast<f4 *>(s_lg + c16 * kLdo + 4 * kq) = f4{hb[0], hb[1], hb[2], hb[3]};
         } else {
-        wave_layer<KB1>(w1f, ld1, xb, acc);
-        wave_relu_to_frags(lds + ly.B1 + 4 * kq, acc, hb);
+        wave_layer<8, KB1>(w1f, ld1, xb, KB1, acc);
+        wave_bias_relu<8, false>(lds + ly.B1 + 4 * kq, acc);
+        wave_to_frags<8>(acc, hb);
         WSTAMP(2);
-        wave_layer<32>(w2f, kLdh, hb, acc);
-        wave_relu_to_frags(lds + ly.B2 + 4 * kq, acc, hb);
+        wave_layer<8, 32>(w2f, kLdh, hb, 32, acc);
+        wave_bias_relu<8, false>(lds + ly.B2 + 4 * kq, acc);
+        wave_to_frags<8>(acc, hb);
         WSTAMP(3);
         {   // logits (A padded to 16): lane holds actions 4 kq + i of sample c16
             f4 lg = f4{0.f, 0.f, 0.f, 0.f};
@@ -936,7 +895,7 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
     a.stamps = g_tsm_stamps;
     a.dbg = tsm_opt(TSM_OPT_DBG);
     hipStream_t st = tsm_stream(stream);
-    if (tsm_opt(TSM_OPT_ROLLOUT_ROWS) != 1) {   // the wave-autonomous form (default); "rollout_rows" = 1 selects the tile form
+    if (tsm_opt(TSM_OPT_ROLLOUT_FORM) != 1) {   // the wave-autonomous form (default); "rollout_form" = 1 selects the tile form
         const RwLay ly(h.obs_dim);
         const size_t shmem = (size_t)ly.total * sizeof(float);
         TSM_REQUIRE(shmem <= kTsmMaxLds, "tsm_rollout_spread_actor: LDS layout of %zu bytes does not fit", shmem);

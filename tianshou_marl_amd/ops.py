@@ -1011,7 +1011,7 @@ def device_info() -> dict:
     return dict(n_cu=n_cu.value, wave_size=wave.value, hbm_bytes=hbm.value, arch=name.value.decode())
 
 
-KERNEL_OPTIONS = ("actor_tile", "split_bf16", "dbg", "rollout_rows")
+KERNEL_OPTIONS = ("actor_tile", "split_bf16", "dbg", "rollout_form")
 
 
 def kernel_option(name: str) -> int:

@@ -12,7 +12,7 @@ for f in glob.glob("gpurun_out/tl/**/*kernel_trace.csv", recursive=True): rows+=
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 def short(n):
     m=re.search(r"(\w+_kernel)",n); return m.group(1) if m else n[:50]
-idx=[i for i,r in enumerate(rows) if "rollout_rows" in r["Kernel_Name"]]
+idx=[i for i,r in enumerate(rows) if "rollout_" in r["Kernel_Name"]]
 a,b=idx[-2],idx[-1]
 t0=int(rows[a]["Start_Timestamp"])
 print("one whole step (rollout -> next rollout): %.1f us" % ((int(rows[b]["Start_Timestamp"])-t0)/1e3))

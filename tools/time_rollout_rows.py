@@ -32,7 +32,7 @@ col.reset()
 
 
 def run(form: int, dbg: int, reps: int = 20) -> float:
-    ops.set_kernel_option("rollout_rows", form)
+    ops.set_kernel_option("rollout_form", form)
     ops.set_kernel_option("dbg", dbg)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     with policy_within_training_step(algo):
