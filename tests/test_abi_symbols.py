@@ -54,6 +54,28 @@ def test_argument_validation_maps_to_python_errors(lib):
         _abi.call("tsm_ppo_loss_fwd_bwd", 1, 1, 1, 1, 1, 1, None, None, 0, 8, 5, 1, C.byref(cfg), 1, 1, 1, None)
 
 
+def test_kernel_options_are_host_state_with_validated_values(lib):
+    """tsm_kernel_option_get / _set need no device: every option ops.KERNEL_OPTIONS names exists, starts at its rule value 0
+    (no TSM_* override in the test environment), takes its documented values and refuses others and unknown names."""
+    from tianshou_marl_amd import ops
+
+    assert set(ops.KERNEL_OPTIONS) == {"actor_tile", "split_bf16", "dbg", "rollout_form"}
+    for name, good, bad in [("actor_tile", (32, 64, 0), 48), ("split_bf16", (1, 0), 2), ("rollout_form", (1, 2, 0), 3)]:
+        if os.environ.get("TSM_" + name.upper()) is None:
+            assert ops.kernel_option(name) == 0
+        for v in good:
+            ops.set_kernel_option(name, v)
+            assert ops.kernel_option(name) == v
+        with pytest.raises(ValueError):
+            ops.set_kernel_option(name, bad)
+        assert ops.kernel_option(name) == 0
+    with pytest.raises(ValueError, match="unknown option"):
+        ops.kernel_option("no_such_option")
+    with ops.kernel_override(rollout_form=2, actor_tile=64):
+        assert ops.kernel_options() == (64, 0, 0, 2)
+    assert ops.kernel_options() == (0, 0, 0, 0)
+
+
 def test_product_has_no_oracle_import():
     """The product package must never import the oracle (test infrastructure)."""
     root = os.path.dirname(os.path.abspath(_abi.__file__))
