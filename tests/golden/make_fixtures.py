@@ -24,6 +24,8 @@ Each fixture holds inputs + the reference's outputs for one hot-path function
                    [a16, a17]
   ctde_c3.npz      the same at configs[2]'s own widths: N = 8, D = 48 (critic input 384, 8 outputs)   [a16, a17]
   async_collector.npz  AsyncCollector over an async vector env with scripted readiness: statistics, ready sets, buffer rows  [(f)4]
+  collector.npz    the synchronous Collector through ten scripted collect / reset calls (truncating envs, surplus-env removal,
+                   reset_before_collect / reset_buffer / reset_stat): statistics, counters, next observations, buffer rows   [a4]
   misc.npz         Batch.split bounds, RunningMeanStd, episode_mc_return_to_go   [a11, a14]
 """
 from __future__ import annotations
@@ -727,6 +729,77 @@ def make_async_collector() -> None:
     save("async_collector.npz", **out)
 
 
+def make_collector() -> None:
+    """The synchronous Collector (collector.py:770-1098) through a scripted sequence of calls (collector_script.PLAN): five
+    MoveToRight envs, two of them with a step limit (truncation), a policy whose actions follow `scripted_action` and whose
+    `policy` entry tags every action with (forward call, position).  n_step calls (a multiple of the env count and not),
+    n_episode calls with fewer and with more episodes than envs (the surplus-env removal of Step 13, the env reset after an
+    n_episode call), reset_before_collect, reset_buffer, reset_stat.  After each call: the statistics, the counters, the
+    observations the next call starts from; at the end every buffer row."""
+    from collector_script import LIMITS, PLAN, SIZES, env_step, scripted_action
+    from tianshou.data import Collector
+    from tianshou.env import DummyVectorEnv
+
+    class MoveToRight(gym.Env):
+        def __init__(self, size, limit):
+            self.size, self.limit, self.index, self.steps = size, limit, 0, 0
+            self.action_space = gym.spaces.Discrete(2)
+            self.observation_space = gym.spaces.Box(0, size, (1,))
+
+        def reset(self, seed=None, options=None):
+            self.index, self.steps = 0, 0
+            return np.array([self.index], np.float32), {"key": 1}
+
+        def step(self, action):
+            self.index, self.steps, rew, term, trunc = env_step(self.index, self.steps, self.size, self.limit, action)
+            return np.array([self.index], np.float32), rew, term, trunc, {"key": 1}
+
+    class ScriptPolicy(Policy):
+        def __init__(self):
+            super().__init__(action_space=gym.spaces.Discrete(2))
+            self.calls = 0
+
+        def forward(self, batch, state=None, **kw):
+            self.calls += 1
+            obs = np.asarray(batch.obs)
+            return Batch(act=scripted_action(self.calls, obs),
+                         policy=Batch(logp=(self.calls * 10.0 + np.arange(len(obs))).astype(np.float32)))
+
+    venv = DummyVectorEnv([lambda s=s, l=l: MoveToRight(s, l) for s, l in zip(SIZES, LIMITS)])
+    pol = ScriptPolicy()
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        col = Collector(pol, venv, VectorReplayBuffer(total_size=400, buffer_num=len(SIZES)))
+        col.reset()
+        out = dict(sizes=np.array(SIZES), limits=np.array(LIMITS))
+        for i, (kind, n, extra) in enumerate(PLAN):
+            kw = {}
+            if extra == "reset_before_collect":
+                kw["reset_before_collect"] = True
+            elif extra == "reset_buffer":
+                col.reset_buffer()
+            elif extra == "reset_stat":
+                col.reset_stat()
+            st = col.collect(**{kind: n}, **kw)
+            out[f"c{i}_steps"], out[f"c{i}_episodes"] = np.int64(st.n_collected_steps), np.int64(st.n_collected_episodes)
+            out[f"c{i}_lens"], out[f"c{i}_returns"] = np.asarray(st.lens, np.int64), np.asarray(st.returns, np.float64)
+            out[f"c{i}_len_buf"] = np.int64(len(col.buffer))
+            out[f"c{i}_counters"] = np.array([col.collect_step, col.collect_episode, pol.calls], np.int64)
+            out[f"c{i}_pre_obs"] = np.asarray(col._pre_collect_obs_RO, np.float32).reshape(-1)
+            if st.returns_stat is not None:
+                out[f"c{i}_ret_stat"] = np.array([st.returns_stat.mean, st.returns_stat.std, st.returns_stat.max, st.returns_stat.min])
+                out[f"c{i}_len_stat"] = np.array([st.lens_stat.mean, st.lens_stat.std, st.lens_stat.max, st.lens_stat.min])
+    buf = col.buffer
+    idx = buf.sample_indices(0)
+    b = buf[idx]
+    out.update(indices=idx, obs=np.asarray(b.obs), obs_next=np.asarray(b.obs_next), act=np.asarray(b.act), rew=np.asarray(b.rew),
+               terminated=np.asarray(b.terminated), truncated=np.asarray(b.truncated), done=np.asarray(b.done),
+               policy_tag=np.asarray(b.policy.logp), last_index=np.asarray(buf.last_index, np.int64))
+    save("collector.npz", **out)
+
+
 # ------------------------------------------------------------------------------------------------
 def make_misc() -> None:
     out = {}
@@ -758,6 +831,6 @@ def make_misc() -> None:
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "ppo_update_wide", "pg_update", "marl_dispatch", "ctde", "ctde_wide",
-                             "ctde_c3", "async_collector", "misc"]
+                             "ctde_c3", "async_collector", "collector", "misc"]
     for w in which:
         globals()["make_" + w]()

@@ -352,6 +352,86 @@ def test_collector_known_answer_layout_of_the_reference():
         Collector(MaxActionPolicy(), venv, DeviceVectorReplayBuffer(9, 3, n_agent=1, obs_dim=1, device=DEV))
 
 
+def test_collector_replays_the_reference_run(golden_dir):
+    """The synchronous `Collector` (collector.py:770-1098) against the REFERENCE's own run (tests/golden/collector.npz, made by
+    make_fixtures.py::make_collector): five MoveToRight envs, two of them truncated by a step limit, a policy whose actions and
+    `policy` tags follow one script on both sides (tests/golden/collector_script.py).  Ten calls -- n_step (a multiple of the env
+    count and not), n_episode with fewer and with more episodes than envs (surplus-env removal, the env reset after an n_episode
+    call), reset_before_collect, reset_buffer, reset_stat -- and after each: collected steps / episodes, episode lengths and
+    returns in the reference's order, their statistics, the buffer length, the lifetime counters, the number of policy calls and
+    the observations the next call starts from; at the end every buffer row.  Bit-exact."""
+    import sys
+
+    sys.path.insert(0, golden_dir)
+    from collector_script import PLAN, env_step, scripted_action
+
+    g = np.load(os.path.join(golden_dir, "collector.npz"))
+
+    class Env:
+        def __init__(self, size, limit):
+            self.size, self.limit, self.index, self.steps = size, limit, 0, 0
+            self.action_space, self.observation_space = Discrete(2), Box(0, size, (1,))
+
+        def reset(self, seed=None, **kw):
+            self.index, self.steps = 0, 0
+            return np.array([self.index], np.float32), {"key": 1}
+
+        def step(self, action):
+            self.index, self.steps, rew, term, trunc = env_step(self.index, self.steps, self.size, self.limit, action)
+            return np.array([self.index], np.float32), rew, term, trunc, {"key": 1}
+
+        def close(self):
+            pass
+
+    class ScriptPolicy(torch.nn.Module):
+        calls = 0
+
+        def forward(self, batch, state=None, **kw):
+            self.calls += 1
+            obs = np.asarray(batch.obs)
+            n = len(obs)
+            return Batch(act=scripted_action(self.calls, obs),
+                         policy=Batch(logp=(self.calls * 10.0 + np.arange(n)).astype(np.float32).reshape(n, 1)))
+
+    n_env = len(g["sizes"])
+    venv = DummyVectorEnv([lambda s=int(s), l=int(l): Env(s, l) for s, l in zip(g["sizes"], g["limits"])])
+    buf = DeviceVectorReplayBuffer(400, n_env, n_agent=1, obs_dim=1, device=DEV)
+    pol = ScriptPolicy()
+    col = Collector(pol, venv, buf)
+    col.reset()
+    for i, (kind, n, extra) in enumerate(PLAN):
+        kw = {}
+        if extra == "reset_before_collect":
+            kw["reset_before_collect"] = True
+        elif extra == "reset_buffer":
+            col.reset_buffer()
+        elif extra == "reset_stat":
+            col.reset_stat()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # (n_step not a multiple of the env count, fewer episodes than envs: as in the reference run)
+            st = col.collect(**{kind: n}, **kw)
+        assert (st.n_collected_steps, st.n_collected_episodes) == (int(g[f"c{i}_steps"]), int(g[f"c{i}_episodes"])), i
+        assert np.array_equal(st.lens, g[f"c{i}_lens"]) and np.array_equal(st.returns, g[f"c{i}_returns"]), i
+        assert len(buf) == int(g[f"c{i}_len_buf"]), i
+        assert [col.collect_step, col.collect_episode, pol.calls] == g[f"c{i}_counters"].tolist(), i
+        assert np.array_equal(np.asarray(col._pre_obs, np.float32).reshape(-1), g[f"c{i}_pre_obs"]), i
+        if f"c{i}_ret_stat" in g:
+            rs, ls = st.returns_stat, st.lens_stat
+            assert np.allclose([rs.mean, rs.std, rs.max, rs.min], g[f"c{i}_ret_stat"], rtol=1e-12, atol=0), i
+            assert np.allclose([ls.mean, ls.std, ls.max, ls.min], g[f"c{i}_len_stat"], rtol=1e-12, atol=0), i
+        else:
+            assert st.returns_stat is None and st.lens_stat is None, i
+    idx = buf.sample_indices(0)
+    assert np.array_equal(idx, g["indices"])
+    b = buf[idx]
+    assert np.array_equal(b.obs[:, 0, 0], g["obs"][:, 0]) and np.array_equal(b.obs_next[:, 0, 0], g["obs_next"][:, 0])
+    assert np.array_equal(b.act[:, 0], g["act"]) and np.array_equal(b.rew[:, 0], g["rew"])
+    assert np.array_equal(b.terminated[:, 0], g["terminated"]) and np.array_equal(b.truncated[:, 0], g["truncated"])
+    assert np.array_equal(b.done, g["done"]) and g["truncated"].sum() >= 4 and g["terminated"].sum() >= 4
+    assert np.array_equal(b.policy.logp[:, 0], g["policy_tag"])
+    assert np.array_equal(np.asarray(buf.last_index), g["last_index"])
+
+
 def test_async_collector_replays_the_reference_run(golden_dir):
     """`AsyncCollector` (collector.py:1116-1394) against the REFERENCE's own run (tests/golden/async_collector.npz): four envs of
     lengths 2..5 behind an async vector env (wait_num 3) whose readiness follows one script on both sides

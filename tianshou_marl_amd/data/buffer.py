@@ -196,6 +196,11 @@ class DeviceVectorReplayBuffer:
     def unfinished_index(self) -> np.ndarray:
         return self.index.unfinished_index().cpu().numpy()
 
+    @property
+    def last_index(self) -> np.ndarray:
+        """Flat index of the row added last in every sub-buffer (manager.py:66, buffer_base.py `last_index`)."""
+        return self.index.last_index.cpu().numpy()
+
     def prev(self, index) -> np.ndarray:
         scalar = np.isscalar(index)
         out = self.index.prev(torch.as_tensor(np.atleast_1d(index), dtype=torch.int64)).cpu().numpy()
