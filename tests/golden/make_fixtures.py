@@ -26,6 +26,8 @@ Each fixture holds inputs + the reference's outputs for one hot-path function
   async_collector.npz  AsyncCollector over an async vector env with scripted readiness: statistics, ready sets, buffer rows  [(f)4]
   collector.npz    the synchronous Collector through ten scripted collect / reset calls (truncating envs, surplus-env removal,
                    reset_before_collect / reset_buffer / reset_stat): statistics, counters, next observations, buffer rows   [a4]
+  trainers.npz     the training coordinators as a trace under seeded numpy randomness: who learns, which snapshot is sampled,
+                   every Elo / performance / win rate, promotion and relegation lists   [a17]
   misc.npz         Batch.split bounds, RunningMeanStd, episode_mc_return_to_go   [a11, a14]
 """
 from __future__ import annotations
@@ -800,6 +802,100 @@ def make_collector() -> None:
     save("collector.npz", **out)
 
 
+def make_trainers() -> None:
+    """The training coordinators (training_coordinator.py:27-760) as a TRACE: mock policies that count `learn` calls, seeded numpy
+    randomness.  SimultaneousTrainer with per-agent frequencies, SequentialTrainer with a custom order, SelfPlayTrainer (snapshot
+    pool, the three opponent-sampling rules in turn, win-rate updates) and LeaguePlayTrainer (the three matchmaking rules in turn,
+    Elo / performance updates, promotion / relegation lists) -- who learns at every step, which snapshot is sampled, every rating.
+    The replay must draw from numpy's global generator call for call as the reference does."""
+    import trainer_script as ts
+    from tianshou.algorithm.multiagent.flexible_policy import FlexibleMultiAgentPolicyManager
+    from tianshou.algorithm.multiagent.training_coordinator import (LeaguePlayTrainer, SelfPlayTrainer, SequentialTrainer,
+                                                                    SimultaneousTrainer)
+
+    class MockPolicy(Policy):
+        def __init__(self):
+            super().__init__(observation_space=gym.spaces.Box(-1, 1, (4,)), action_space=gym.spaces.Discrete(2))
+            self.learn_count, self.version = 0, -1
+
+        def forward(self, batch, state=None, **kw):
+            return Batch(act=np.zeros(len(batch.obs), np.int64), state=state)
+
+        def learn(self, batch, **kw):
+            self.learn_count += 1
+            return {"loss": float(self.learn_count)}
+
+    class Env:
+        def __init__(self, n):
+            self.agents = [f"agent_{i}" for i in range(n)]
+            self.observation_space, self.action_space = gym.spaces.Box(-1, 1, (4,)), gym.spaces.Discrete(2)
+
+    def ma_batch(env):
+        return Batch({a: Batch(obs=np.zeros((4, 4), np.float32), act=np.zeros(4, np.int64), rew=np.ones(4),
+                               terminated=np.zeros(4, bool), truncated=np.zeros(4, bool), obs_next=np.zeros((4, 4), np.float32),
+                               info=Batch()) for a in env.agents})
+
+    out = {}
+    # -- simultaneous / sequential: who learned at each step
+    env = Env(3)
+    pols = {a: MockPolicy() for a in env.agents}
+    tr = SimultaneousTrainer(FlexibleMultiAgentPolicyManager(pols, env, mode="independent"), agent_train_freq={"agent_1": 2, "agent_2": 3})
+    rows = []
+    for _ in range(ts.SIMULTANEOUS_STEPS):
+        losses = tr.train_step(ma_batch(env))
+        rows.append([int(a in losses) for a in env.agents] + [pols[a].learn_count for a in env.agents])
+    out["simultaneous"] = np.array(rows, np.int64)
+    pols = {a: MockPolicy() for a in env.agents}
+    tr = SequentialTrainer(FlexibleMultiAgentPolicyManager(pols, env, mode="independent"), agent_order=["agent_2", "agent_0", "agent_1"],
+                           steps_per_agent=2)
+    rows = []
+    for _ in range(ts.SEQUENTIAL_STEPS):
+        losses = tr.train_step(ma_batch(env))
+        rows.append([env.agents.index(next(iter(losses)))] + [int(pols[a].training) for a in env.agents])
+    out["sequential"] = np.array(rows, np.int64)
+    # -- self-play
+    env = Env(2)
+    pols = {a: MockPolicy() for a in env.agents}
+    tr = SelfPlayTrainer(FlexibleMultiAgentPolicyManager(pols, env, mode="independent"), main_agent_id="agent_0",
+                         snapshot_interval=ts.SNAPSHOT_INTERVAL, opponent_pool_size=ts.POOL_SIZE)
+    np.random.seed(ts.SEED)
+    rows, rates = [], []
+    for i in range(ts.SELFPLAY_STEPS):
+        pols["agent_0"].version = i
+        tr.opponent_sampling = ts.selfplay_sampling(i)
+        losses = tr.train_step(ma_batch(env))
+        opp = tr._sample_opponent()
+        if opp is not None:
+            tr.update_win_rate(id(opp), ts.selfplay_won(i))
+        pool = [p.version for p in tr.opponent_pool] + [-1] * (ts.POOL_SIZE - len(tr.opponent_pool))
+        rows.append([int("agent_0" in losses), pols["agent_0"].learn_count, pols["agent_1"].learn_count,
+                     -1 if opp is None else opp.version, len(tr.opponent_win_rates), *pool])
+        rates.append([tr.opponent_win_rates.get(id(p), -1.0) for p in tr.opponent_pool] + [-1.0] * (ts.POOL_SIZE - len(tr.opponent_pool)))
+    out["selfplay"], out["selfplay_rates"] = np.array(rows, np.int64), np.array(rates, np.float64)
+    # -- league
+    env = Env(ts.LEAGUE_AGENTS)
+    pols = {a: MockPolicy() for a in env.agents}
+    tr = LeaguePlayTrainer(FlexibleMultiAgentPolicyManager(pols, env, mode="independent"), games_per_evaluation=ts.GAMES_PER_EVALUATION)
+    np.random.seed(ts.SEED)
+    rows, elo, perf, lists = [], [], [], []
+    for i in range(ts.LEAGUE_STEPS):
+        tr.matchmaking = ts.league_matchmaking(i)
+        before = [pols[a].learn_count for a in env.agents]
+        losses = tr.train_step(ma_batch(env))
+        match = [a for a in env.agents if pols[a].learn_count > before[env.agents.index(a)]]
+        order = list(losses)  # (the match, in the order the trainer walked it)
+        w, l = (order[0], order[1]) if ts.league_winner_first(i) else (order[1], order[0])
+        tr.update_match_result(w, l)
+        rows.append([env.agents.index(order[0]), env.agents.index(order[1]), len(match), tr.game_count, len(tr.match_history)])
+        elo.append([tr.elo_ratings[a] for a in env.agents])
+        perf.append([tr.agent_performance[a] for a in env.agents])
+        pr, rl = tr._update_league()
+        lists.append([int(a in pr) for a in env.agents] + [int(a in rl) for a in env.agents])
+    out.update(league=np.array(rows, np.int64), league_elo=np.array(elo, np.float64), league_perf=np.array(perf, np.float64),
+               league_lists=np.array(lists, np.int64))
+    save("trainers.npz", **out)
+
+
 # ------------------------------------------------------------------------------------------------
 def make_misc() -> None:
     out = {}
@@ -831,6 +927,6 @@ def make_misc() -> None:
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "ppo_update_wide", "pg_update", "marl_dispatch", "ctde", "ctde_wide",
-                             "ctde_c3", "async_collector", "collector", "misc"]
+                             "ctde_c3", "async_collector", "collector", "trainers", "misc"]
     for w in which:
         globals()["make_" + w]()

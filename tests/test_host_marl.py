@@ -237,6 +237,80 @@ def test_league_matchmaking_elo_and_promotion():
     assert tr._make_match() == ["agent_0"]
 
 
+def test_trainers_replay_the_reference_trace():
+    """The four coordinators against a trace of the REFERENCE's own (tests/golden/trainers.npz, make_fixtures.py::make_trainers):
+    mock policies, numpy's global generator seeded alike, the schedules of tests/golden/trainer_script.py.  Who learns at every
+    step and how often, the sequential order and train / eval flags, which snapshot self-play samples under its three rules
+    (the draws must come call for call as the reference's), win rates, every league match, Elo and performance value (exact
+    float equality), promotion / relegation lists."""
+    import os
+    import sys
+
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gd)
+    import trainer_script as ts
+
+    g = np.load(os.path.join(gd, "trainers.npz"))
+
+    class P(CountingPolicy):
+        version = -1
+
+    env = Env(3)
+    pols = {a: P() for a in env.agents}
+    tr = SimultaneousTrainer(FlexibleMultiAgentPolicyManager(pols, env, mode="independent"), agent_train_freq={"agent_1": 2, "agent_2": 3})
+    rows = []
+    for _ in range(ts.SIMULTANEOUS_STEPS):
+        losses = tr.train_step(ma_batch(env))
+        rows.append([int(a in losses) for a in env.agents] + [pols[a].learn_calls for a in env.agents])
+    assert np.array_equal(rows, g["simultaneous"])
+    pols = {a: P() for a in env.agents}
+    tr = SequentialTrainer(FlexibleMultiAgentPolicyManager(pols, env, mode="independent"), agent_order=["agent_2", "agent_0", "agent_1"],
+                           steps_per_agent=2)
+    rows = []
+    for _ in range(ts.SEQUENTIAL_STEPS):
+        losses = tr.train_step(ma_batch(env))
+        rows.append([env.agents.index(next(iter(losses)))] + [int(pols[a].training) for a in env.agents])
+    assert np.array_equal(rows, g["sequential"])
+    # self-play
+    env = Env(2)
+    pols = {a: P() for a in env.agents}
+    tr = SelfPlayTrainer(FlexibleMultiAgentPolicyManager(pols, env, mode="independent"), main_agent_id="agent_0",
+                         snapshot_interval=ts.SNAPSHOT_INTERVAL, opponent_pool_size=ts.POOL_SIZE)
+    np.random.seed(ts.SEED)
+    for i in range(ts.SELFPLAY_STEPS):
+        pols["agent_0"].version = i
+        tr.opponent_sampling = ts.selfplay_sampling(i)
+        losses = tr.train_step(ma_batch(env))
+        opp = tr._sample_opponent()
+        if opp is not None:
+            tr.update_win_rate(id(opp), ts.selfplay_won(i))
+        pool = [p.version for p in tr.opponent_pool] + [-1] * (ts.POOL_SIZE - len(tr.opponent_pool))
+        row = [int("agent_0" in losses), pols["agent_0"].learn_calls, pols["agent_1"].learn_calls,
+               -1 if opp is None else opp.version, len(tr.opponent_win_rates), *pool]
+        assert row == g["selfplay"][i].tolist(), (i, row, g["selfplay"][i].tolist())
+        rates = [tr.opponent_win_rates.get(id(p), -1.0) for p in tr.opponent_pool] + [-1.0] * (ts.POOL_SIZE - len(tr.opponent_pool))
+        assert rates == g["selfplay_rates"][i].tolist(), i
+    # league
+    env = Env(ts.LEAGUE_AGENTS)
+    pols = {a: P() for a in env.agents}
+    tr = LeaguePlayTrainer(FlexibleMultiAgentPolicyManager(pols, env, mode="independent"), games_per_evaluation=ts.GAMES_PER_EVALUATION)
+    np.random.seed(ts.SEED)
+    for i in range(ts.LEAGUE_STEPS):
+        tr.matchmaking = ts.league_matchmaking(i)
+        before = [pols[a].learn_calls for a in env.agents]
+        losses = tr.train_step(ma_batch(env))
+        match = [a for a in env.agents if pols[a].learn_calls > before[env.agents.index(a)]]
+        order = list(losses)
+        w, l = (order[0], order[1]) if ts.league_winner_first(i) else (order[1], order[0])
+        tr.update_match_result(w, l)
+        row = [env.agents.index(order[0]), env.agents.index(order[1]), len(match), tr.game_count, len(tr.match_history)]
+        assert row == g["league"][i].tolist(), (i, row, g["league"][i].tolist())
+        assert [tr.elo_ratings[a] for a in env.agents] == g["league_elo"][i].tolist(), i
+        assert [tr.agent_performance[a] for a in env.agents] == g["league_perf"][i].tolist(), i
+        pr, rl = tr._update_league()
+        assert [int(a in pr) for a in env.agents] + [int(a in rl) for a in env.agents] == g["league_lists"][i].tolist(), i
+
+
 def test_trainer_checkpoint_roundtrip(tmp_path):
     env = Env(2)
     pols = {a: CountingPolicy(i + 1) for i, a in enumerate(env.agents)}
