@@ -109,6 +109,25 @@ int tsm_rms_update(const float *returns, const int64_t *ids, int64_t n, double *
 int tsm_mc_return_to_go_lanes(const float *rew, int64_t T, int64_t n_lane, double gamma,
                               float *out, void *stream);
 
+/* Several row-gathers with element conversion in ONE launch: field k copies n_rows rows of `width` elements,
+ *   dst[r][c] = convert(src[src_row(r) * src_row_stride + src_offset + c]),
+ * src_row(r) = r (T == 0) or, with T > 0 and n_rows == T * E, the time-major slot of env-major row r = e * T + t:
+ * src_row = t * E + e -- the reference's flat index order (manager.py:131-193) read out of a [T][E][...] store; src_offset
+ * picks an agent's column of a joint row.  Kinds: f32 -> f32; i32 / i64 / u8 -> i32 / i64 / f32 / u8 (u8: 0 / 1, torch.bool's
+ * storage).  Replaces the per-field torch copies of the MARL trainers' per-agent batches (training_coordinator.py:118,154,336) and
+ * of learn()'s static buffers.  No reference counterpart. */
+#define TSM_MAX_GATHER_FIELDS 8
+enum { TSM_KIND_F32 = 0, TSM_KIND_I32 = 1, TSM_KIND_I64 = 2, TSM_KIND_U8 = 3 };
+typedef struct tsm_gather_field {
+    const void *src;
+    void *dst;
+    int64_t n_rows;
+    int64_t T, E;
+    int64_t src_row_stride, src_offset;   /* in elements of the source type */
+    int32_t width, src_kind, dst_kind, _pad;
+} tsm_gather_field;
+int tsm_gather_fields(const tsm_gather_field *fields_host, int32_t n_fields, void *stream);
+
 /* V(obs_next) (a2c.py:124) without a second critic pass over every row.  Rows written by a Collector are chained:
  * obs_next of slot t is obs of slot t + 1 unless the episode ended at t (collector.py:1040-1069), so for T unrotated,
  * equally filled slots of U units (lanes, or joint rows for a centralized critic)

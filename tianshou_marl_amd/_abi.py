@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtsmarl_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tsmarl.h")
 
+MAX_GATHER_FIELDS = 8  # include/tsmarl.h TSM_MAX_GATHER_FIELDS
 ABI_VERSION = 3  # include/tsmarl.h TSM_ABI_VERSION: bumped whenever a signature or a struct layout changes
 TSM_OK, TSM_ERR_INVALID, TSM_ERR_HIP, TSM_ERR_MALFORMED_BUFFER, TSM_ERR_UNSUPPORTED = range(5)
 
@@ -42,6 +43,12 @@ class tsm_slab_seg(C.Structure):
 class tsm_slab_reduce(C.Structure):
     _fields_ = [("slabs", C.c_void_p), ("n", C.c_int64), ("stride", C.c_int64), ("n_slab", C.c_int32), ("_pad", C.c_int32),
                 ("out", C.c_void_p)]
+
+
+class tsm_gather_field(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n_rows", C.c_int64), ("T", C.c_int64), ("E", C.c_int64),
+                ("src_row_stride", C.c_int64), ("src_offset", C.c_int64), ("width", C.c_int32), ("src_kind", C.c_int32),
+                ("dst_kind", C.c_int32), ("_pad", C.c_int32)]
 
 
 class tsm_mpe_cfg(C.Structure):
@@ -156,6 +163,7 @@ SIGNATURES = {
     "tsm_mlp_forward": (_int, [C.POINTER(tsm_mlp_desc), _p, _p, _i64, _p, _p]),
     "tsm_mlp_forward_cond": (_int, [C.POINTER(tsm_mlp_desc), _p, _p, _i64, _p, _p, _p]),
     "tsm_any_nonzero_u8": (_int, [_p, _i64, _p, _p]),
+    "tsm_gather_fields": (_int, [C.POINTER(tsm_gather_field), C.c_int32, _p]),
     "tsm_value_next_select": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _p]),
     "tsm_value_next_index": (_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "tsm_value_next_select_env_major": (_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p]),

@@ -419,12 +419,30 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
         cd.chain_T, cd.store = int(T), store
         out["chain_done"] = cd
         return out
+    fused = T is not None and T > 0 and all(getattr(buffer, s).is_contiguous() for s in
+                                             ("obs_store", "act_store", "rew_store", "obs_next_store", "term_store", "trunc_store"))
     for a, name in enumerate(agents):
         if only is not None and name not in only:
             continue
-        out[name] = Batch(obs=col(d["obs"], a), act=col(d["act"], a).to(torch.int64),
-                          rew=col(d["rew"], a), obs_next=col(d["obs_next"], a),
-                          terminated=col(d["terminated"], a).bool(), truncated=col(d["truncated"], a).bool())
+        if fused:
+            # the agent's six fields as env-major rows in ONE launch (csrc/gather_fields.hip) instead of six strided torch copies
+            # and three dtype conversions: the same values in the same dtypes
+            from ... import ops
+
+            n, N = E * T, buffer.n_agent
+            Dd = buffer.obs_store.shape[-1]
+            dev = buffer.device
+            o = dict(obs=torch.empty(n, Dd, dtype=torch.float32, device=dev), act=torch.empty(n, dtype=torch.int64, device=dev),
+                     rew=torch.empty(n, dtype=buffer.rew_store.dtype, device=dev), obs_next=torch.empty(n, Dd, dtype=torch.float32, device=dev),
+                     terminated=torch.empty(n, dtype=torch.bool, device=dev), truncated=torch.empty(n, dtype=torch.bool, device=dev))
+            ops.gather_fields([(buffer.obs_store, o["obs"], T, E, N * Dd, a * Dd), (buffer.act_store, o["act"], T, E, N, a),
+                               (buffer.rew_store, o["rew"], T, E, N, a), (buffer.obs_next_store, o["obs_next"], T, E, N * Dd, a * Dd),
+                               (buffer.term_store, o["terminated"], T, E, N, a), (buffer.trunc_store, o["truncated"], T, E, N, a)])
+            out[name] = Batch(**o)
+        else:
+            out[name] = Batch(obs=col(d["obs"], a), act=col(d["act"], a).to(torch.int64),
+                              rew=col(d["rew"], a), obs_next=col(d["obs_next"], a),
+                              terminated=col(d["terminated"], a).bool(), truncated=col(d["truncated"], a).bool())
         if store is not None:
             out[name]["agent_index"] = np.int64(a)
     if global_state:

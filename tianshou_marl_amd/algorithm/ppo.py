@@ -832,6 +832,15 @@ class PPO(nn.Module):
         call's host-drawn permutations, and the device-side step count if it went stale."""
         n, D, repeat = w["n"], self.net.obs_dim, w["repeat"]
         t = lambda x: x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))  # noqa: E731
+        names = ["obs", "obs_next", "act", "rew", "terminated"] + (["truncated"] if "truncated" in batch else [])
+        leaves = [batch[k] for k in names]
+        if all(isinstance(x, torch.Tensor) and x.is_cuda and x.is_contiguous() and x.dtype in ops._GATHER_KINDS for x in leaves) \
+                and leaves[0].dtype == leaves[1].dtype == leaves[3].dtype == torch.float32:
+            # device batches (the trainers' per-agent batches): all fields into the static buffers in ONE launch
+            dst = [w["obs"], w["obs_next"], w["act"], w["rew"], w["term"]] + ([w["trunc"]] if "truncated" in batch else [])
+            ops.gather_fields(list(zip(leaves, dst)))
+            self._learn_load_rest(w, n, repeat)
+            return
         w["obs"].copy_(t(batch.obs).reshape(n, D), non_blocking=True)
         w["obs_next"].copy_(t(batch.obs_next).reshape(n, D), non_blocking=True)
         w["act"].copy_(t(batch.act).reshape(n), non_blocking=True)
@@ -839,6 +848,9 @@ class PPO(nn.Module):
         w["term"].copy_(t(batch.terminated).reshape(n, 1), non_blocking=True)
         if "truncated" in batch:
             w["trunc"].copy_(t(batch.truncated).reshape(n, 1), non_blocking=True)
+        self._learn_load_rest(w, n, repeat)
+
+    def _learn_load_rest(self, w: dict, n: int, repeat: int) -> None:
         if self.shuffle == "numpy":  # Batch.split draws np.random.permutation per repeat (batch.py:1219)
             for r in range(repeat):
                 w["perm"][r].copy_(torch.as_tensor(np.random.permutation(n)), non_blocking=True)

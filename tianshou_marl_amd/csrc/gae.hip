@@ -369,8 +369,10 @@ static int gae_impl(const float *v_s, const float *v_s_next, const float *rew, c
         const dim3 grid((unsigned)n_lane), block(1024);
 #define LONG(F, C) hipLaunchKernelGGL((gae_long_kernel<F, C>), grid, block, 0, st, v_s, v_s_next, rew, terminated, truncated, T, \
                                       n_lane, lanes_per_env, gamma, gl, v_scale, rms, rms_eps, returns_out, adv_out)
-        if (T > 4096) { if (flags_per_lane) LONG(true, 16); else LONG(false, 16); }
-        else { if (flags_per_lane) LONG(true, 4); else LONG(false, 4); }
+        // CH = 4 steps per thread whatever T: with 16 (one super-chunk up to 16 384 steps) the f64 scan state spills 404 VGPRs at the
+        // 128 registers a 1024-thread workgroup leaves per lane -- 122.6 us for the trainers' 12 800-row lane against 27.3 us as four
+        // super-chunks of 4096 steps (8 steps: 100 spills, 71.4 us); the same bits in all three (tools/gae_long_time.py, round 4)
+        if (flags_per_lane) LONG(true, 4); else LONG(false, 4);
 #undef LONG
         TSM_LAUNCH_CHECK();
         return TSM_OK;

@@ -940,6 +940,38 @@ def mlp_forward_cond(desc, params, x, run_if, acts=None):
     return acts[n - B * O:].view(B, O), acts
 
 
+_GATHER_KINDS = {torch.float32: 0, torch.int32: 1, torch.int64: 2, torch.uint8: 3, torch.bool: 3}
+
+
+def gather_fields(fields: list) -> None:
+    """Several row-gathers with element conversion in ONE launch (include/tsmarl.h: tsm_gather_fields).  A field is
+    `(src, dst)` -- both contiguous, equal numel: a converting copy -- or `(src, dst, T, E, src_row_stride, src_offset)`: dst row
+    r = e * T + t (env-major) reads `width = dst.numel() // (T * E)` elements at src row t * E + e (`src` a contiguous time-major
+    store, strides in elements).  f32 -> f32; int32 / int64 / uint8 / bool -> int32 / int64 / float32 / uint8 / bool."""
+    for k0 in range(0, len(fields), _abi.MAX_GATHER_FIELDS):
+        chunk = fields[k0:k0 + _abi.MAX_GATHER_FIELDS]
+        arr = (_abi.tsm_gather_field * len(chunk))()
+        for k, fd in enumerate(chunk):
+            src, dst = fd[0], fd[1]
+            if not (src.is_contiguous() and dst.is_contiguous() and src.is_cuda and dst.is_cuda):
+                raise ValueError("gather_fields: contiguous device tensors only")
+            if src.dtype not in _GATHER_KINDS or dst.dtype not in _GATHER_KINDS:
+                raise TypeError(f"gather_fields: {src.dtype} -> {dst.dtype} is not supported")
+            if len(fd) == 2:
+                if src.numel() != dst.numel():
+                    raise ValueError("gather_fields: a converting copy needs equal sizes")
+                n_rows, width, T, E, stride, off = dst.numel(), 1, 0, 0, 1, 0
+            else:
+                T, E, stride, off = (int(x) for x in fd[2:6])
+                n_rows = T * E
+                width = dst.numel() // max(n_rows, 1)
+                if width * n_rows != dst.numel() or (n_rows and ((T * E - 1) * stride + off + width) > src.numel()):
+                    raise ValueError("gather_fields: the mapping leaves the source or does not tile the destination")
+            arr[k] = _abi.tsm_gather_field(src.data_ptr(), dst.data_ptr(), n_rows, T, E, stride, off, width,
+                                           _GATHER_KINDS[src.dtype], _GATHER_KINDS[dst.dtype], 0)
+        call("tsm_gather_fields", arr, len(chunk), stream_ptr())
+
+
 def any_nonzero_u8(x, out=None):
     """Device flag i32[1] = 1 if any byte of `x` (u8 / bool, contiguous) is non-zero."""
     x = _chk(x, torch.uint8, "x")
