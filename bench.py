@@ -234,7 +234,7 @@ def kernel_rooflines(a, algo, buf):
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with ops.graph_capture(g):
             for _ in range(n):
                 fn()
         g.replay()
@@ -472,7 +472,7 @@ def c3_rooflines(device):
     fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         for _ in range(10):
             fn()
     g.replay()
@@ -509,7 +509,7 @@ def c3_rooflines(device):
         fn_()
         torch.cuda.synchronize()
         g_ = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_):
+        with ops.graph_capture(g_):
             for _ in range(n_rep):
                 fn_()
         g_.replay()

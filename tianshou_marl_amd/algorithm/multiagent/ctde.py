@@ -274,7 +274,7 @@ class CTDEPolicy(nn.Module):
                 w["step_dev"].fill_(self.optim_actor.step_count)
             if k not in w["graphs"]:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with ops.graph_capture(g):
                     body(slot, w["step_dev"])
                 w["graphs"][k] = g
             w["graphs"][k].replay()

@@ -294,25 +294,34 @@ class PPO(nn.Module):
         collective on it dies (hipErrorStreamCaptureInvalidated) -- there is no in-process fall-back; the job is started
         again with TSM_GRAPH_COLLECTIVES=0 (collectives outside the graphs)."""
         if self._grad_sync is None:
-            with torch.cuda.graph(graph):
+            with ops.graph_capture(graph):
                 fn()
             return
         dev = self.device
         err = None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            graph.capture_begin(capture_error_mode="thread_local")
-            try:
-                fn()
-            except Exception as e:  # noqa: BLE001
-                err = e
-            try:
-                graph.capture_end()
-            except Exception as e:  # noqa: BLE001
-                err = err or e
-            if err is not None:
-                ops.call("tsm_stream_abort_capture", side.cuda_stream)
+        import gc
+
+        gc_was = gc.isenabled()
+        gc.collect()
+        gc.disable()  # (no collection inside a capture: see ops.graph_capture)
+        try:
+            with torch.cuda.stream(side):
+                graph.capture_begin(capture_error_mode="thread_local")
+                try:
+                    fn()
+                except Exception as e:  # noqa: BLE001
+                    err = e
+                try:
+                    graph.capture_end()
+                except Exception as e:  # noqa: BLE001
+                    err = err or e
+                if err is not None:
+                    ops.call("tsm_stream_abort_capture", side.cuda_stream)
+        finally:
+            if gc_was:
+                gc.enable()
         if err is not None:
             raise RuntimeError(
                 "capturing the gradient all-reduce into the update hipGraph failed "
@@ -593,7 +602,7 @@ class PPO(nn.Module):
                 while more:
                     g_ = torch.cuda.CUDAGraph()
                     t_ = None
-                    with torch.cuda.graph(g_, pool=pool):
+                    with ops.graph_capture(g_, pool=pool):
                         try:
                             t_ = next(gen)
                         except StopIteration:
@@ -891,7 +900,7 @@ class PPO(nn.Module):
         self._learn_load(w, batch)
         if "graph" not in w:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with ops.graph_capture(graph):
                 for _ in w["body"]():  # (no replica: nothing is yielded)
                     raise RuntimeError("a single-GPU learn() has no collectives")
             w["graph"] = graph

@@ -679,7 +679,7 @@ class GenericPPO(PPO):
             return self._learn_finish(w)
         if "graph" not in w:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with ops.graph_capture(graph):
                 for _ in w["body"]():
                     raise RuntimeError("a single-GPU learn() has no collectives")
             w["graph"] = graph

@@ -1065,6 +1065,39 @@ def kernel_options() -> tuple:
     return tuple(kernel_option(n) for n in KERNEL_OPTIONS)
 
 
+class graph_capture:
+    """`with ops.graph_capture(graph[, pool=...]):` -- torch.cuda.graph with Python's cyclic garbage collector held off while the
+    stream is capturing.  A collection that happens to run inside a capture and frees a device tensor or destroys another
+    hipGraph is an operation the capturing stream does not permit: the process aborts ("Fatal Python error: Aborted ...
+    Garbage-collecting", seen in the test suite once enough graph-holding objects had become garbage)."""
+
+    def __init__(self, graph, pool=None):
+        self._cm = torch.cuda.graph(graph) if pool is None else torch.cuda.graph(graph, pool=pool)
+        self._was = False
+
+    def __enter__(self):
+        import gc
+
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            return self._cm.__enter__()
+        except BaseException:
+            if self._was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+
+        try:
+            return self._cm.__exit__(*exc)
+        finally:
+            if self._was:
+                gc.enable()
+
+
 class kernel_override:
     """`with ops.kernel_override(actor_tile=64): ...` -- options set inside, restored on exit."""
 

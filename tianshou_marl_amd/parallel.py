@@ -388,7 +388,9 @@ def learn_lockstep_graph(jobs, sync: "GradSync", names: list | None = None) -> l
             while more:
                 g_ = torch.cuda.CUDAGraph()
                 t_ = None
-                with torch.cuda.graph(g_, pool=pool):
+                from . import ops as _ops
+
+                with _ops.graph_capture(g_, pool=pool):
                     try:
                         t_ = next(gen)
                     except StopIteration:
