@@ -96,6 +96,13 @@ int tsm_gae_lanes_rms(const float *v_s, const float *v_s_next, const float *rew,
                       int64_t T, int64_t n_lane, int64_t lanes_per_env, const int32_t *env_start,
                       const int32_t *env_len, double gamma, double gae_lambda, const double *rms,
                       double rms_eps, float *returns_out, float *adv_out, void *stream);
+/* The few-lanes / long-series form of tsm_gae_lanes (n_lane <= 64, T >= 1024: the MARL trainers' one time-ordered lane of
+ * n_env * T rows, training_coordinator.py:118,154,336) runs its super-chunks of 4096 steps on different workgroups when the
+ * host has registered a ZEROED device workspace of tsm_gae_scan_workspace_bytes() bytes for this process's device (the memory
+ * stays the caller's; nullptr withdraws it): same bits as the one-workgroup-per-lane form, 12 800 rows 27 -> 9 us. */
+int64_t tsm_gae_scan_workspace_bytes(void);
+int tsm_gae_set_scan_workspace(void *workspace, int64_t bytes);
+
 /* RunningMeanStd.update (utils/statistics.py:97-114) with the UNNORMALISED returns of a2c.py:144-146:
  * x[i] = returns[ids ? ids[i] : i] * sqrt(rms[1] + rms_eps), i < n; batch mean / population variance in f64
  * (two-level fixed-order sums), then the parallel-variance merge into rms = {mean, var, count} in place.

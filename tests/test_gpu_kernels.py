@@ -75,6 +75,47 @@ def test_gae_few_long_lanes_take_the_time_parallel_kernel(oracle, T, L, per_env)
         np.testing.assert_allclose(ret.cpu().numpy(), ret_o, rtol=1e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("T,L,per_env", [(4097, 1, False), (12800, 1, False), (12800, 2, True), (20000, 5, False), (33000, 3, False)])
+def test_gae_long_lanes_super_chunks_side_by_side_equal_the_sequential_scan(oracle, T, L, per_env):
+    """Above 4096 steps a long lane is several super-chunks.  With the scan workspace registered (ops.ensure_scan_workspace) they run
+    on different workgroups and hand their affine maps over through device memory; without it one workgroup walks them in turn.
+    Same recurrence, same order: identical bits -- also on repeated launches (the workspace's generation word advances per launch)
+    and as a hipGraph replay -- and both within 1e-6 of the f64 oracle."""
+    from tianshou_marl_amd import _abi
+
+    rng = np.random.default_rng(T + L)
+    v_s, v_n, rew, term, trunc = _rand_gae_inputs(rng, T, L, 0.01, 0.01)
+    kw = {}
+    term_l, trunc_l = term, trunc
+    if per_env:
+        term, trunc = term[:, :1].copy(), trunc[:, :1].copy()
+        term_l, trunc_l = np.repeat(term, L, axis=1), np.repeat(trunc, L, axis=1)
+        kw = dict(lanes_per_env=L)
+    args = (t(v_s), t(v_n), t(rew), t(term), t(trunc), 0.99, 0.95)
+    assert ops.ensure_scan_workspace(DEV)
+    n = int(_abi.call("tsm_gae_scan_workspace_bytes"))
+    try:
+        _abi.call("tsm_gae_set_scan_workspace", None, 0)  # withdrawn: the sequential form
+        ret_s, adv_s = ops.gae_lanes(*args, v_scale=1.7, **kw)
+    finally:
+        _abi.call("tsm_gae_set_scan_workspace", ops._scan_ws.data_ptr(), n)
+    for _ in range(3):
+        ret_p, adv_p = ops.gae_lanes(*args, v_scale=1.7, **kw)
+        assert torch.equal(ret_p, ret_s) and torch.equal(adv_p, adv_s)
+    out = (torch.empty_like(ret_s), torch.empty_like(adv_s))
+    ops.gae_lanes(*args, v_scale=1.7, out=out, **kw)
+    g = torch.cuda.CUDAGraph()
+    with ops.graph_capture(g):
+        ops.gae_lanes(*args, v_scale=1.7, out=out, **kw)
+    for _ in range(3):
+        out[0].zero_(); out[1].zero_()
+        g.replay()
+        assert torch.equal(out[0], ret_s) and torch.equal(out[1], adv_s)
+    ret_o, adv_o = oracle.gae_lanes(v_s, v_n, rew, term_l, trunc_l, 0.99, 0.95, v_scale=1.7)
+    np.testing.assert_allclose(adv_p.cpu().numpy(), adv_o, rtol=1e-6, atol=2e-6)
+    np.testing.assert_allclose(ret_p.cpu().numpy(), ret_o, rtol=1e-6, atol=2e-6)
+
+
 def test_gae_env_level_flags_and_return_scaling(oracle):
     rng = np.random.default_rng(3)
     T, n_env, N = 25, 37, 3

@@ -119,6 +119,8 @@ SIGNATURES = {
     "tsm_stream_sync": (_int, [_p]),
     "tsm_stream_abort_capture": (_int, [_p]),
     "tsm_gae_lanes": (_int, [_p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _p, _p, _f64, _f64, _f64, _p, _p, _p]),
+    "tsm_gae_scan_workspace_bytes": (_i64, []),
+    "tsm_gae_set_scan_workspace": (_int, [_p, _i64]),
     "tsm_gae_lanes_rms": (_int, [_p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _p, _p, _f64, _f64, _p, _f64, _p, _p, _p]),
     "tsm_rms_update_work_elems": (_i64, [_i64]),
     "tsm_rms_update": (_int, [_p, _p, _i64, _p, _f64, _p, _p]),
@@ -228,7 +230,8 @@ _NO_STATUS = {"tsm_critic_rows_w1_image_kj", "tsm_critic_rows_w1_image_elems", "
               "tsm_ppo_actor_rows_supported", "tsm_ppo_actor_rows_param_count", "tsm_ppo_actor_rows_grid",
               "tsm_rms_update_work_elems", "tsm_ppo_adv_stats_work_elems", "tsm_abi_version", "tsm_last_error", "tsm_stream_abort_capture", "tsm_vrb_state_bytes", "tsm_ppo_loss_partial_elems",
               "tsm_policy_param_count", "tsm_ppo_update_grid", "tsm_adam_work_elems", "tsm_policy_image_elems",
-              "tsm_mlp_param_count", "tsm_mlp_act_elems", "tsm_ctde_head_partial_elems", "tsm_mpe_tag_obs_dim"}
+              "tsm_mlp_param_count", "tsm_mlp_act_elems", "tsm_ctde_head_partial_elems", "tsm_mpe_tag_obs_dim",
+              "tsm_gae_scan_workspace_bytes"}
 
 _lib = None
 

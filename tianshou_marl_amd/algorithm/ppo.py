@@ -434,6 +434,7 @@ class PPO(nn.Module):
         if self._ws.get("warm"):
             return
         dev, D, A, H = self.device, self.net.obs_dim, self.net.n_act, self.net.hidden
+        ops.ensure_scan_workspace(dev)  # (learn() on one long lane: the parallel scan's workspace must exist before any capture)
         P = self.net.flat.data.clone()
         obs = torch.zeros(32, D, device=dev)
         act = torch.zeros(32, dtype=torch.int32, device=dev)

@@ -239,6 +239,8 @@ __global__ __launch_bounds__(64) void rms_merge_kernel(const double *__restrict_
 // (carry -> B + P * carry) are combined by a parallel suffix scan in LDS (10 doubling steps), every thread then replays its
 // chunk from its true carry-in.  Same f64 recurrence per step; the maps are composed in a different association order than
 // in gae_lanes_kernel (differences at the 1e-16 level, before the one rounding to f32).
+constexpr int kScanMaxWg = 128;   // workgroups of the parallel form (all resident at once)
+
 template <bool FLAGS_PER_LANE, int CH>
 __global__ __launch_bounds__(1024) void gae_long_kernel(
     const float *__restrict__ v_s, const float *__restrict__ v_n, const float *__restrict__ rew,
@@ -317,6 +319,116 @@ __global__ __launch_bounds__(1024) void gae_long_kernel(
     }
 }
 
+// The same scan with the super-chunks of a lane on DIFFERENT workgroups (grid n_lane x n_sc): the affine map of a whole
+// super-chunk (carry -> B + P * carry) does not depend on the other super-chunks, so every workgroup forms its own, publishes it,
+// waits for the maps of the LATER super-chunks of its lane and folds them in the sequential kernel's order -- the same additions
+// and products, the same bits -- instead of one workgroup walking the super-chunks one after the other (12 800 rows: 27 -> 9 us).
+// All workgroups must be resident at once (the host checks n_lane * n_sc <= 128).  Hand-over through a small device workspace
+// (tsm_gae_set_scan_workspace): word 0 = generation g of the launch, word 1 = finished workgroups; a map is published as two
+// agent-scope atomic f64 stores followed by a release store of g + 1 into its flag, read by agent-scope atomic loads (the L2s of
+// different XCDs are not coherent for plain loads); the last workgroup to finish advances the generation, so graph replays work.
+struct ScanWs { unsigned gen, done; unsigned flag[kScanMaxWg]; double agg[kScanMaxWg][2]; };
+
+template <bool FLAGS_PER_LANE>
+__global__ __launch_bounds__(1024) void gae_long_par_kernel(
+    const float *__restrict__ v_s, const float *__restrict__ v_n, const float *__restrict__ rew,
+    const uint8_t *__restrict__ term, const uint8_t *__restrict__ trunc, int64_t T, int64_t L, int64_t lanes_per_env,
+    double gamma, double gl, double v_scale_arg, const double *__restrict__ rms, double rms_eps,
+    float *__restrict__ ret_out, float *__restrict__ adv_out, ScanWs *__restrict__ ws) {
+    constexpr int CH = 4;
+    __shared__ double sP[2][1024], sB[2][1024];
+    __shared__ double s_carry;
+    const int t = threadIdx.x;
+    const int64_t lane = blockIdx.x;
+    const int n_sc = (int)gridDim.y, s = (int)blockIdx.y;
+    const int64_t env = lane / lanes_per_env, n_env = L / lanes_per_env;
+    const double v_scale = rms ? sqrt(rms[1] + rms_eps) : v_scale_arg;
+    const double inv_scale = 1.0 / v_scale;
+    const unsigned gen = __hip_atomic_load(&ws->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t k0 = (int64_t)s * 1024 * CH + (int64_t)t * CH;
+    double delta[CH], vs_[CH];
+    unsigned keep = 0, valid = 0;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int64_t kk = k0 + k;
+        delta[k] = 0.0; vs_[k] = 0.0;
+        if (kk < T) {
+            const int64_t i = kk * L + lane;
+            const uint8_t te = FLAGS_PER_LANE ? term[i] : term[kk * n_env + env];
+            const uint8_t tr = FLAGS_PER_LANE ? trunc[i] : trunc[kk * n_env + env];
+            const double vs = (double)v_s[i] * v_scale;
+            const double vn = te ? 0.0 : (double)v_n[i] * v_scale;
+            delta[k] = (double)rew[i] + vn * gamma - vs;
+            vs_[k] = vs;
+            const bool end = te | tr | (kk == T - 1);
+            keep |= (end ? 0u : 1u) << k;
+            valid |= 1u << k;
+        }
+    }
+    double P = 1.0, B = 0.0;
+#pragma unroll
+    for (int k = CH - 1; k >= 0; --k) {
+        const double d = ((valid >> k) & 1u) ? (((keep >> k) & 1u) ? gl : 0.0) : 1.0;
+        B = delta[k] + d * B;
+        P *= d;
+    }
+    int cur = 0;
+    sP[0][t] = P; sB[0][t] = B;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        double p = sP[cur][t], b = sB[cur][t];
+        if (t + off < 1024) {
+            const double p2 = sP[cur][t + off], b2 = sB[cur][t + off];
+            b = b + p * b2;
+            p = p * p2;
+        }
+        sP[cur ^ 1][t] = p; sB[cur ^ 1][t] = b;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (t == 0) {
+        const int me = (int)lane * n_sc + s;
+        __hip_atomic_store(&ws->agg[me][0], sP[cur][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->agg[me][1], sB[cur][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->flag[me], gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // carry into this super-chunk: the later ones folded from the last one down (the sequential kernel's recurrence)
+        double carry = 0.0;
+        for (int s2 = n_sc - 1; s2 > s; --s2) {
+            const int o = (int)lane * n_sc + s2;
+            int spins = 0;
+            while (__hip_atomic_load(&ws->flag[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen + 1u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 22)) { carry = NAN; break; }   // (never seen; a lost workgroup must not hang the device)
+            }
+            const double p2 = __hip_atomic_load(&ws->agg[o][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double b2 = __hip_atomic_load(&ws->agg[o][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            carry = b2 + p2 * carry;
+        }
+        s_carry = carry;
+    }
+    __syncthreads();
+    const double carry_super = s_carry;
+    double g = carry_super;
+    if (t + 1 < 1024) g = sB[cur][t + 1] + sP[cur][t + 1] * carry_super;
+#pragma unroll
+    for (int k = CH - 1; k >= 0; --k) {
+        if ((valid >> k) & 1u) {
+            const double d = ((keep >> k) & 1u) ? gl : 0.0;
+            g = delta[k] + d * g;
+            const int64_t i = (k0 + k) * L + lane;
+            adv_out[i] = (float)g;
+            ret_out[i] = (float)((g + vs_[k]) * inv_scale);
+        }
+    }
+    if (t == 0) {   // the last workgroup to finish opens the next generation (every workgroup has read its flags by now)
+        const unsigned total = gridDim.x * gridDim.y;
+        if (__hip_atomic_fetch_add(&ws->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+            __hip_atomic_store(&ws->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws->gen, gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 int pick_waves(int64_t T, int64_t L, int vec, int ch) {
     // enough waves to fill 256 CUs x 8, but no more chunks than the series has
     int64_t blocks = ceil_div(L, 64 * vec);
@@ -340,6 +452,18 @@ void launch_gae(int W, const float *v_s, const float *v_s_next, const float *rew
 }
 
 }  // namespace
+
+static void *g_scan_ws = nullptr;   // tsm_gae_set_scan_workspace
+
+TSM_EXPORT int64_t tsm_gae_scan_workspace_bytes(void) { return (int64_t)sizeof(ScanWs); }
+
+// Register (or, with nullptr, withdraw) the ZEROED device workspace of the parallel long-series scan for this process's device.
+// Without one the sequential form runs.  The memory stays the caller's.
+TSM_EXPORT int tsm_gae_set_scan_workspace(void *workspace, int64_t bytes) {
+    TSM_REQUIRE(!workspace || bytes >= (int64_t)sizeof(ScanWs), "tsm_gae_set_scan_workspace: needs %zu bytes", sizeof(ScanWs));
+    g_scan_ws = workspace;
+    return TSM_OK;
+}
 
 extern "C" __attribute__((visibility("default"))) void tsm_debug_gae_config(int vec, int ch, int w) {
     g_force_vec = vec; g_force_ch = ch; g_force_w = w;
@@ -372,6 +496,19 @@ static int gae_impl(const float *v_s, const float *v_s_next, const float *rew, c
         // CH = 4 steps per thread whatever T: with 16 (one super-chunk up to 16 384 steps) the f64 scan state spills 404 VGPRs at the
         // 128 registers a 1024-thread workgroup leaves per lane -- 122.6 us for the trainers' 12 800-row lane against 27.3 us as four
         // super-chunks of 4096 steps (8 steps: 100 spills, 71.4 us); the same bits in all three (tools/gae_long_time.py, round 4)
+        const int64_t n_sc = ceil_div(T, 4096);
+        if (g_scan_ws && n_sc > 1 && n_lane * n_sc <= kScanMaxWg) {   // super-chunks side by side (see gae_long_par_kernel)
+            const dim3 grid2((unsigned)n_lane, (unsigned)n_sc);
+            ScanWs *ws = reinterpret_cast<ScanWs *>(g_scan_ws);
+            if (flags_per_lane)
+                hipLaunchKernelGGL((gae_long_par_kernel<true>), grid2, block, 0, st, v_s, v_s_next, rew, terminated, truncated, T, n_lane,
+                                   lanes_per_env, gamma, gl, v_scale, rms, rms_eps, returns_out, adv_out, ws);
+            else
+                hipLaunchKernelGGL((gae_long_par_kernel<false>), grid2, block, 0, st, v_s, v_s_next, rew, terminated, truncated, T, n_lane,
+                                   lanes_per_env, gamma, gl, v_scale, rms, rms_eps, returns_out, adv_out, ws);
+            TSM_LAUNCH_CHECK();
+            return TSM_OK;
+        }
         if (flags_per_lane) LONG(true, 4); else LONG(false, 4);
 #undef LONG
         TSM_LAUNCH_CHECK();

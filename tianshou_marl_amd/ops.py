@@ -32,6 +32,8 @@ def gae_lanes(v_s, v_s_next, rew, terminated, truncated, gamma=0.99, gae_lambda=
     v_s = _chk(v_s, torch.float32, "v_s")
     T = v_s.shape[0]
     L = v_s[0].numel() if T > 0 else 0
+    if T > 4096 and L <= 64:
+        ensure_scan_workspace(v_s.device)
     v_s_next = _chk(v_s_next, torch.float32, "v_s_next")
     rew = _chk(rew, torch.float32, "rew")
     term = terminated.contiguous().view(torch.uint8) if terminated.dtype == torch.bool else _chk(terminated, torch.uint8, "terminated")
@@ -56,6 +58,21 @@ def gae_lanes(v_s, v_s_next, rew, terminated, truncated, gamma=0.99, gae_lambda=
          lanes_per_env, ptr(env_start), ptr(env_len), float(gamma), float(gae_lambda), float(v_scale),
          ptr(ret), ptr(adv), stream_ptr())
     return ret, adv
+
+
+_scan_ws = None
+
+
+def ensure_scan_workspace(device) -> bool:
+    """Register the device workspace of the parallel long-series GAE scan (include/tsmarl.h: tsm_gae_set_scan_workspace) once per
+    process; not while a stream is capturing (the allocation would belong to that graph's pool).  Callers that capture graphs
+    call it beforehand (PPO._warm_kernels)."""
+    global _scan_ws
+    if _scan_ws is None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        n = int(call("tsm_gae_scan_workspace_bytes"))
+        _scan_ws = torch.zeros(n, dtype=torch.uint8, device=device)
+        call("tsm_gae_set_scan_workspace", _scan_ws.data_ptr(), n)
+    return _scan_ws is not None
 
 
 def rms_update(returns, rms, rms_eps=1e-8, ids=None, work=None):
