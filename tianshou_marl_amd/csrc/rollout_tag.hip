@@ -146,6 +146,8 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         float *XN = lds + xnxt;
         // B. both teams' actor + critic forward of the 16-row tile (same X, separate OUT)
         lyf.X = xcur; lyg.X = xcur;
+        // (round 4: both teams' nets side by side -- waves 0-3 team 0, waves 4-7 team 1, two chains per wave, three barriers instead
+        //  of six -- was built, bit-identical, and changed nothing: collect 0.276 ms either way; the two passes stay)
         tile_forward_split<H>(lds, lyf, d);
         tile_forward_split<H>(lds, lyg, d);
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
