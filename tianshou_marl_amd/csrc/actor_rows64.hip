@@ -41,8 +41,8 @@ __device__ __forceinline__ int opaque_s(int x) {
 }
 
 struct Lay64 {  // LDS layout in floats
-    int nJ, ld1, W1, W3, B1, B2, B3, U, X, H1, H2, LG, total;
-    __host__ __device__ explicit Lay64(int D) {
+    int nJ = 0, ld1 = 0, W1 = 0, W3 = 0, B1 = 0, B2 = 0, B3 = 0, U = 0, X = 0, H1 = 0, H2 = 0, LG = 0, total = 0;
+    __host__ __device__ constexpr explicit Lay64(int D) {
         nJ = (D + 15) / 16;
         ld1 = 16 * nJ + 2;
         int o = 0;
@@ -66,9 +66,12 @@ struct Lay64 {  // LDS layout in floats
 template <int NJ>
 __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const Lay64 ly(g.D);
+    // the layout is a function of NJ alone (ld1 = 16 NJ + 2): compile-time, so every LDS offset is an immediate instead of one of
+    // ~12 scalar registers (the kernel spilled 43 SGPRs to VGPR lanes: 124 v_readlane per tile) and of a v_add per access
+    constexpr Lay64 ly(16 * NJ);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
-    const int D = g.D, A = g.A, ld1 = ly.ld1;
+    const int D = g.D, A = g.A;
+    constexpr int ld1 = ly.ld1;
     const int64_t n_tiles = (g.M + kRows - 1) / kRows;
     if (g.opt_step_dev && blockIdx.x == 0 && tid == 0) *g.opt_step_dev += 1;  // the gradient step this launch opens
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[200] = (long long)wall_clock64();
