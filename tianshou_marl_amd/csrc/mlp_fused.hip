@@ -812,14 +812,18 @@ __device__ __forceinline__ void ppo_update_net(
     }
 }
 
-template <int H, int ST>
+// DS: 0 = dimensions from the launch arguments; else the observation width this instantiation is compiled for (5 actions): the
+// headline job's 18 -- its index arithmetic (divisions by ld1 and D, layout offsets) then costs constants instead of ~35-instruction
+// integer divisions and scalar registers.
+template <int H, int ST, int DS>
 __global__ __launch_bounds__(NT) void ppo_update_split_kernel(
-    const float *__restrict__ P, const float *__restrict__ img, Dims d, const float *__restrict__ obs,
+    const float *__restrict__ P, const float *__restrict__ img, Dims d_arg, const float *__restrict__ obs,
     const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
     const float *__restrict__ returns, const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first,
     int64_t M, const float *__restrict__ adv_stats, LossCfg cfg, float *__restrict__ slabs,
     double *__restrict__ loss_partial, int64_t *__restrict__ opt_step_dev) {
     extern __shared__ float lds[];
+    const Dims d = DS ? dims_const(DS, 5) : d_arg;
     // device-resident optimizer step count (hipGraph replay): bumped here, read by the Adam kernel that follows
     if (opt_step_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *opt_step_dev += 1;
     if (blockIdx.y == 0)
@@ -1025,8 +1029,10 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
     if (g_update_variant == 0 && !g_tsm_stamps) {
         // one net per workgroup (grid.y = actor | critic): see ppo_update_split_kernel
         const LayN<64> ln(d);
-        auto kern = g_slab_store == 1 ? ppo_update_split_kernel<64, 1>
-                    : g_slab_store == 2 ? ppo_update_split_kernel<64, 2> : ppo_update_split_kernel<64, 0>;
+        const bool c18 = d.D == 18 && d.A == 5 && !(tsm_opt(TSM_OPT_DBG) & 128);   // (dbg 128: the generic instantiation, for A/B timing)
+        auto kern = g_slab_store == 1 ? ppo_update_split_kernel<64, 1, 0>
+                    : g_slab_store == 2 ? ppo_update_split_kernel<64, 2, 0>
+                    : c18 ? ppo_update_split_kernel<64, 0, 18> : ppo_update_split_kernel<64, 0, 0>;
         hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks, 2), dim3(NT),
                            (size_t)ln.total * sizeof(float), st, params, param_image, d, obs, act, logp_old, adv, returns,
                            v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out, loss_partial_out, opt_step_dev);

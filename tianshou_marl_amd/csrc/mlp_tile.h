@@ -18,6 +18,14 @@ struct Dims {
     int ld1;        // 16*nJ + 2
 };
 
+// Dims of a network whose observation width and action count are known at compile time (kernel specialisations for BASELINE
+// configs[1]: obs_dim 18, 5 actions): every derived offset, loop bound and division by ld1 / D becomes a constant.
+__host__ __device__ constexpr Dims dims_const(int D, int A) {
+    Dims d{};
+    d.D = D; d.A = A; d.Kp1 = (D + 3) / 4 * 4; d.nJ = (D + 15) / 16; d.ld1 = 16 * ((D + 15) / 16) + 2;
+    return d;
+}
+
 template <int H>
 struct Lay {  // LDS layout in floats
     static constexpr int ldh = H + 2;       // 66: 2*33

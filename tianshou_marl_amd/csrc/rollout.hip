@@ -75,11 +75,16 @@ struct RolloutArgs {
 // chains altogether, as an experiment, gave 1.3 us): the tile forward is MFMA-issue bound at 16 rows per CU.
 // NT2 = 256 is the four-wave form (both chains on every wave, tile_forward): its workgroups need half the registers, so
 // two of them share a CU when their LDS fits twice -- the better choice once there are more workgroups than CUs.
-template <int H, int NT2>
+// DS / NS: 0 = obs width / agent count from the launch arguments, else the values this instantiation is compiled for (BASELINE
+// configs[1]: 18 / 3): the per-step element loops divide by D, N and ld1 -- ~35-instruction integer divisions when those are run-time
+// values, a multiply and a shift when they are constants.
+template <int H, int NT2, int DS = 0, int NS = 0>
 __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     extern __shared__ float lds[];
-    const Dims d = a.d;
-    const MpeCfg c = a.c;
+    const Dims d = DS ? dims_const(DS, 5) : a.d;
+    MpeCfg c_ = a.c;
+    if (NS) { c_.N = NS; c_.obs_dim = DS; }
+    const MpeCfg c = c_;
     const Lay<H> ly(d, false);
     const int N = c.N, D = d.D, st = 2 * N;
     const int EPB = R / N;                    // envs per workgroup
@@ -849,6 +854,7 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     if (!attr_set) {
         TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_kernel<64, NT>)));
         TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_kernel<64, 2 * NT>)));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_kernel<64, 2 * NT, 18, 3>)));
         attr_set = true;
     }
     const int EPB = R / a.c.N;
@@ -857,7 +863,9 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     // CU); four waves otherwise, so that two workgroups fit the register file of a CU.  Measured (us per 25-step
     // collect, 4 / 8 waves): 1024 envs x 3 agents 242 / 234; 4096 x 3: 505 / 775; 4096 x 8 (91 KB of LDS): 7100 / 2250.
     const bool eight = n_wg <= 256 || shmem > 80 * 1024;
-    if (eight) hipLaunchKernelGGL((rollout_kernel<64, 2 * NT>), dim3(n_wg), dim3(2 * NT), shmem, tsm_stream(stream), a);
+    const bool c18 = a.d.D == 18 && a.d.A == 5 && a.c.N == 3 && !(tsm_opt(TSM_OPT_DBG) & 128);   // (dbg 128: generic form, for A/B timing)
+    if (eight && c18) hipLaunchKernelGGL((rollout_kernel<64, 2 * NT, 18, 3>), dim3(n_wg), dim3(2 * NT), shmem, tsm_stream(stream), a);
+    else if (eight) hipLaunchKernelGGL((rollout_kernel<64, 2 * NT>), dim3(n_wg), dim3(2 * NT), shmem, tsm_stream(stream), a);
     else hipLaunchKernelGGL((rollout_kernel<64, NT>), dim3(n_wg), dim3(NT), shmem, tsm_stream(stream), a);
     TSM_LAUNCH_CHECK();
     return TSM_OK;
