@@ -32,14 +32,15 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // rollout / inference: logits, value, optional sampling + log-prob
 // ------------------------------------------------------------------------------------------------
-template <int H>
+template <int H, int DS = 0>   // DS: obs width this instantiation is compiled for (5 actions); 0 = from the arguments
 __global__ __launch_bounds__(NT) void policy_forward_kernel(
-    const float *__restrict__ P, const float *__restrict__ img, Dims d, const float *__restrict__ obs, int64_t B,
+    const float *__restrict__ P, const float *__restrict__ img, Dims d_arg, const float *__restrict__ obs, int64_t B,
     uint64_t seed,
     uint64_t offset, const uint64_t *__restrict__ offset_dev, int mode /*0 none, 1 sample, 2 argmax, 3 given*/,
     float *__restrict__ logits_out,
     float *__restrict__ value_out, int32_t *__restrict__ act_io, float *__restrict__ logp_out) {
     extern __shared__ float lds[];
+    const Dims d = DS ? dims_const(DS, 5) : d_arg;
     const Lay<H> ly(d, false);
     if (img) stage_image<H>(lds, ly, img);
     else stage_weights<H>(lds, ly, d, P);
@@ -954,9 +955,13 @@ TSM_EXPORT int tsm_policy_forward(const float *params, const float *param_image,
     static bool attr_set = false;
     if (!attr_set) {
         TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(policy_forward_kernel<64>)));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(policy_forward_kernel<64, 18>)));
+        TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(policy_forward_kernel<64, 16>)));
         attr_set = true;
     }
-    hipLaunchKernelGGL((policy_forward_kernel<64>), dim3(grid), dim3(NT), shmem, tsm_stream(stream), params,
+    const bool spec = d.A == 5 && !(tsm_opt(TSM_OPT_DBG) & 128);
+    auto kern = (spec && d.D == 18) ? policy_forward_kernel<64, 18> : (spec && d.D == 16) ? policy_forward_kernel<64, 16> : policy_forward_kernel<64>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), shmem, tsm_stream(stream), params,
                        param_image, d, obs,
                        B, seed, offset, offset_dev, mode, logits_out, value_out, act_io, logp_out);
     TSM_LAUNCH_CHECK();
@@ -1029,10 +1034,12 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
     if (g_update_variant == 0 && !g_tsm_stamps) {
         // one net per workgroup (grid.y = actor | critic): see ppo_update_split_kernel
         const LayN<64> ln(d);
-        const bool c18 = d.D == 18 && d.A == 5 && !(tsm_opt(TSM_OPT_DBG) & 128);   // (dbg 128: the generic instantiation, for A/B timing)
+        const bool spec = d.A == 5 && !(tsm_opt(TSM_OPT_DBG) & 128);   // (dbg 128: the generic instantiation, for A/B timing)
         auto kern = g_slab_store == 1 ? ppo_update_split_kernel<64, 1, 0>
                     : g_slab_store == 2 ? ppo_update_split_kernel<64, 2, 0>
-                    : c18 ? ppo_update_split_kernel<64, 0, 18> : ppo_update_split_kernel<64, 0, 0>;
+                    : (spec && d.D == 18) ? ppo_update_split_kernel<64, 0, 18>     // BASELINE configs[1] (simple_spread, N = 3)
+                    : (spec && d.D == 16) ? ppo_update_split_kernel<64, 0, 16>     // configs[4] (simple_tag 3 v 1)
+                    : ppo_update_split_kernel<64, 0, 0>;
         hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks, 2), dim3(NT),
                            (size_t)ln.total * sizeof(float), st, params, param_image, d, obs, act, logp_old, adv, returns,
                            v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out, loss_partial_out, opt_step_dev);

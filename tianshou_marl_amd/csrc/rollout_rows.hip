@@ -523,14 +523,20 @@ struct RwLay {  // LDS layout in floats: weights as in RrLay, then one private b
 
 #define WSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0 && t < 4) a.stamps[t * 32 + (k)] = (long long)wall_clock64(); } while (0)
 
-template <int NJ>
+// NS: 0 = agent count from the launch arguments, else the count this instantiation is compiled for (BASELINE configs[2]: 8, obs
+// width 48): the `j < N` predicates of the unrolled partner / landmark loops and the divisions by N and D become constants -- this
+// kernel's floor is its instruction count (DESIGN.md section 4 "Issue slots and clocks").
+template <int NJ, int NS = 0>
 __global__ __launch_bounds__(kThreads) void rollout_wave_kernel(RrArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const MpeCfg c = a.c;
+    MpeCfg c_ = a.c;
+    if (NS) { c_.N = NS; c_.obs_dim = 6 * NS; }
+    const MpeCfg c = c_;
     const RwLay ly(a.D);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, kq = lane >> 4;
     constexpr int ld1 = 16 * NJ + 2;                     // (== ly.ld1: compile-time, so fragment offsets are immediates)
-    const int N = c.N, D = a.D, A = a.A, st = 2 * N;
+    const int N = c.N, D = NS ? 6 * NS : a.D, st = 2 * N;
+    constexpr int A = 5;   // (tsm_rollout_spread_actor requires the 5 actions of simple_spread)
     const int EPW = kRowsWave / N;                       // whole environments per wave
     const int e0 = (blockIdx.x * kWaves + w) * EPW;      // first env of this wave
     const int n_here = max(0, min(EPW, c.n_env - e0));
@@ -909,11 +915,20 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
         }                                                                                                              \
         hipLaunchKernelGGL((rollout_wave_kernel<NJ>), dim3(n_wg), dim3(kThreads), shmem, st, a);                       \
     } while (0)
-        switch (ly.nJ) {
-            case 1: LAUNCHW(1); break;
-            case 2: LAUNCHW(2); break;
-            case 3: LAUNCHW(3); break;
-            default: LAUNCHW(4); break;
+        if (a.c.N == 8 && h.obs_dim == 48 && !(tsm_opt(TSM_OPT_DBG) & 128)) {   // BASELINE configs[2] (dbg 128: the generic form)
+            static bool attr_8 = false;
+            if (!attr_8) {
+                TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_wave_kernel<3, 8>)));
+                attr_8 = true;
+            }
+            hipLaunchKernelGGL((rollout_wave_kernel<3, 8>), dim3(n_wg), dim3(kThreads), shmem, st, a);
+        } else {
+            switch (ly.nJ) {
+                case 1: LAUNCHW(1); break;
+                case 2: LAUNCHW(2); break;
+                case 3: LAUNCHW(3); break;
+                default: LAUNCHW(4); break;
+            }
         }
 #undef LAUNCHW
         TSM_LAUNCH_CHECK();
