@@ -7,6 +7,10 @@
 namespace {
 
 constexpr int kCols = 64;  // parameters per workgroup
+#ifndef TSM_ADAM_DEEP
+#define TSM_ADAM_DEEP 0
+#endif
+constexpr bool tsm_adam_deep = TSM_ADAM_DEEP;
 
 __device__ __forceinline__ double ipow(double b, int64_t e) {
     double r = 1.0;
@@ -19,10 +23,20 @@ __device__ __forceinline__ double ipow(double b, int64_t e) {
 }
 
 // One lane's share of a parameter's slab sum: slabs sl, sl + 4, sl + 8, ... added sequentially in that order (16 independent
-// loads in flight; 32 measured no faster).  `stride` = floats between two consecutive slabs.
+// loads in flight; 32 measured no faster on the 54 MB of the C3 step -- the headline's 11 MB are latency-bound: TSM_ADAM_DEEP).  `stride` = floats between two consecutive slabs.
 __device__ __forceinline__ float slab_lane_sum(const float *__restrict__ slabs, int32_t n_slab, int64_t i, int64_t stride, int sl) {
     float acc = 0.f;
     int s = sl;
+    if (tsm_adam_deep) {   // (TSM_ADAM_DEEP, set by csrc/adam.hip: 64 loads in flight -- the same additions in the same order)
+#pragma unroll 1
+        for (; s + 252 < n_slab; s += 256) {
+            float t[64];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) t[u] = slabs[(int64_t)(s + 4 * u) * stride + i];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) acc += t[u];
+        }
+    }
 #pragma unroll 1
     for (; s + 60 < n_slab; s += 64) {
         float t[16];
