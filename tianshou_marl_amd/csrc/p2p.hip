@@ -30,6 +30,7 @@
 // reads the word at its next synchronisation point (tsm_p2p_failed) and raises -- no hang, no replica stepped on a partial sum.
 // First use: tsm_p2p_handshake exchanges one stamped word per peer with the same bounded spin BEFORE anything is captured;
 // the ranks then agree (over the process group) to use this path or the backend's own collective for the rest of the process.
+#define TSM_ADAM_DEEP 1   // as in csrc/adam.hip: 64 slab loads in flight per lane (same order of additions)
 #include "adam_dev.h"
 #include <string.h>
 
