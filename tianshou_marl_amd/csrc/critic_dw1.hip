@@ -91,7 +91,12 @@ __device__ __forceinline__ void dw1_side_reduce(const Dw1Args &g, int b, float *
 
 __device__ __forceinline__ int64_t dw1_row_of(const Dw1Args &g, int64_t i) {
     const int64_t ic = i < g.Mr ? i : g.Mr - 1;
-    return g.rows ? g.rows[ic] : (g.tm_T > 0 ? (ic % g.tm_T) * g.tm_E + ic / g.tm_T : g.first_row + ic);
+    if (g.rows) return g.rows[ic];
+    if (g.tm_T > 0) {   // env-major view of a time-major store (32-bit arithmetic, Mr < 2^31: a 64-bit division is ~100 instructions)
+        const int t_ = (int)g.tm_T, ii = (int)ic;
+        return (int64_t)(ii % t_) * g.tm_E + ii / t_;
+    }
+    return g.first_row + ic;
 }
 
 template <bool VEC, int NT>
@@ -262,6 +267,7 @@ TSM_EXPORT int tsm_critic_rows_dw1(const float *dh1, const float *obs_rows, int3
                                    const tsm_slab_reduce *side_host, int32_t n_side, void *stream) {
     TSM_REQUIRE(in_dim >= 1 && in_dim <= 384 && ((in_dim & 3) == 0 || in_dim <= 64) && Mr >= 1,
                 "tsm_critic_rows_dw1: in_dim = %d (<= 384, a multiple of 4 above 64), Mr = %lld", in_dim, (long long)Mr);
+    TSM_REQUIRE(tm_T <= 0 || Mr < (1ll << 31), "tsm_critic_rows_dw1: the time-major row mapping is 32-bit (Mr < 2^31)");
     TSM_REQUIRE(dh1 && obs_rows && w1_slabs_out, "tsm_critic_rows_dw1: null pointer");
     TSM_REQUIRE(tm_T == 0 || (tm_T > 0 && tm_E > 0 && tm_T * tm_E == Mr), "tsm_critic_rows_dw1: T x E must equal Mr");
     {
