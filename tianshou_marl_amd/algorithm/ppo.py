@@ -541,6 +541,9 @@ class PPO(nn.Module):
                     # every permutation of this update (one per agent group and repeat, batch.py:1219) in ONE launch;
                     # the draw counter is the device-resident optimizer step count (it advances by >= one per permutation
                     # and update), so each replay of the graph draws fresh permutations without a counter kernel
+                    # (round 4: as a PARALLEL branch of the graph -- a side stream beside preprocess(), it depends on the step
+                    #  count alone -- the job got slower, 0.558 -> 0.583 ms per step: a two-stream graph pays more at launch
+                    #  than the 6 us kernel it takes off the chain)
                     ops.random_permutations(n_g, len(groups) * repeat, self.seed ^ 0x5DEECE66D, counter_dev=w["step_dev"],
                                             scale=N if per_agent else 1, group_size=repeat,
                                             offset_mul=1 if per_agent else 0, out=w["perm"])
