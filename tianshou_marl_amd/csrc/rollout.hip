@@ -407,12 +407,14 @@ struct Rw64Lay {  // offsets (floats) inside a wave's private LDS block
     }
 };
 
-template <int NJ>
+template <int NJ, int DS = 0, int NS = 0>   // DS / NS: as in rollout_kernel (compiled for obs width 18 / 3 agents)
 __global__ __launch_bounds__(NT) void rollout_wave64_kernel(RolloutArgs a) {
     constexpr int H = 64, MB = H / 16, KB1 = 4 * NJ, KBH = H / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const Dims d = a.d;
-    const MpeCfg c = a.c;
+    const Dims d = DS ? dims_const(DS, 5) : a.d;
+    MpeCfg c_ = a.c;
+    if (NS) { c_.N = NS; c_.obs_dim = DS; }
+    const MpeCfg c = c_;
     const Lay<H> ly(d, false);
     const Rw64Lay wl;
     constexpr int ld1 = 16 * NJ + 2;   // == d.ld1
@@ -816,9 +818,10 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     const Lay<64> ly(a.d, false);
     {   // Which form (option "rollout_form": 0 by rule, 1 tile, 2 wave).  Rule: the tile form while its workgroups (one 16-row tile
         // each) fit the CUs in one round, the wave-autonomous form above that.  Measured (us per 25-step collect + reset_buffer,
-        // tile / wave, tools/time_rollout64.py): 512 envs x 3 agents 315 / 385; 1024 x 3 336 / 406; 1536 x 3 1041 / 421;
-        // 2048 x 3 412 / 438; 4096 x 3 1221 / 516; 1024 x 8 696 / 501; 4096 x 8 2400 / 966 -- one wave running a step by
-        // itself takes 12.8 us against the eight cooperating waves' 9.7, but it does not queue behind a second round of workgroups.
+        // tile / wave, tools/time_rollout64.py, kernels compiled for obs width 18 / 3 agents where they apply): 512 envs x 3 agents
+        // 276 / 316; 1024 x 3 299 / 336; 1536 x 3 422 / 354; 2048 x 3 408 / 373; 4096 x 3 681 / 490; 1024 x 8 697 / 506;
+        // 4096 x 8 2423 / 989 -- one wave running a step by itself is slower than eight cooperating ones, but it does not queue
+        // behind a second round of workgroups.
         const int form = tsm_opt(TSM_OPT_ROLLOUT_FORM);
         const int64_t total_waves = ceil_div(a.c.n_env, R / a.c.N);
         if (form == 2 || (form == 0 && total_waves > 256)) {
@@ -837,6 +840,14 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
         }                                                                                                              \
         hipLaunchKernelGGL((rollout_wave64_kernel<NJ>), dim3(n_wg_w), dim3(64 * n_waves), shmem_w, tsm_stream(stream), a); \
     } while (0)
+            if (a.d.D == 18 && a.d.A == 5 && a.c.N == 3 && !(tsm_opt(TSM_OPT_DBG) & 128)) {
+                static bool attr_18 = false;
+                if (!attr_18) {
+                    TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_wave64_kernel<2, 18, 3>)));
+                    attr_18 = true;
+                }
+                hipLaunchKernelGGL((rollout_wave64_kernel<2, 18, 3>), dim3(n_wg_w), dim3(64 * n_waves), shmem_w, tsm_stream(stream), a);
+            } else
             switch (a.d.nJ) {
                 case 1: LAUNCHW(1); break;
                 case 2: LAUNCHW(2); break;
