@@ -21,10 +21,11 @@ __device__ __forceinline__ double load_as(const void *p, int64_t i) { return (do
 __global__ __launch_bounds__(256) void gather_fields_kernel(GatherArgs a) {
     const tsm_gather_field f = a.f[blockIdx.y];
     const int64_t total = f.n_rows * f.width;
+    const unsigned width = (unsigned)f.width, T32 = (unsigned)f.T;   // (the host checks total < 2^31: 32-bit divisions, not ~100-instruction 64-bit ones)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / f.width, c = i - r * f.width;
-        int64_t sr = r;
-        if (f.T > 0) { const int64_t e = r / f.T, t = r - e * f.T; sr = t * f.E + e; }   // env-major row <- time-major slot
+        const unsigned iu = (unsigned)i, ru = iu / width, c = iu - ru * width;
+        int64_t sr = ru;
+        if (T32 > 0) { const unsigned e = ru / T32, t = ru - e * T32; sr = (int64_t)t * f.E + e; }   // env-major row <- time-major slot
         const int64_t s = sr * f.src_row_stride + f.src_offset + c;
         if (f.src_kind == TSM_KIND_F32 && f.dst_kind == TSM_KIND_F32) {
             reinterpret_cast<float *>(f.dst)[i] = reinterpret_cast<const float *>(f.src)[s];
@@ -59,6 +60,7 @@ TSM_EXPORT int tsm_gather_fields(const tsm_gather_field *fields_host, int32_t n_
                     "tsm_gather_fields: unknown element kind in field %d", k);
         TSM_REQUIRE(f.src_kind != TSM_KIND_F32 || f.dst_kind == TSM_KIND_F32, "tsm_gather_fields: f32 sources convert to f32 only (field %d)", k);
         TSM_REQUIRE(f.T == 0 || (f.T > 0 && f.E > 0 && f.n_rows == f.T * f.E), "tsm_gather_fields: n_rows != T * E in field %d", k);
+        TSM_REQUIRE(f.n_rows * f.width < (1ll << 31), "tsm_gather_fields: field %d has 2^31 elements or more", k);
         a.f[k] = f;
         if (f.n_rows * f.width > most) most = f.n_rows * f.width;
     }
