@@ -582,3 +582,36 @@ def test_random_permutations_affine_map_device_counter_and_uniformity():
     assert abs(frac - 0.5) < 0.04
     with pytest.raises(ValueError):
         ops.random_permutations(-1, 1, seed=0)
+
+
+def test_gather_fields_maps_and_converts_like_torch():
+    """tsm_gather_fields (csrc/gather_fields.hip): env-major rows out of a time-major store with an agent's column offset, and
+    converting copies, several fields per launch -- against the torch expressions they replace (exact: moves and integer / flag
+    conversions only)."""
+    T, E, N, D = 7, 5, 3, 6
+    g = torch.Generator(device="cpu").manual_seed(0)
+    obs = torch.randn(T, E, N, D, generator=g).to(DEV)
+    act = torch.randint(0, 5, (T, E, N), generator=g, dtype=torch.int32).to(DEV)
+    flag = (torch.rand(T, E, N, generator=g) < 0.3).to(torch.uint8).to(DEV)
+    for a in range(N):
+        o = torch.empty(E * T, D, device=DEV)
+        ac = torch.empty(E * T, dtype=torch.int64, device=DEV)
+        fb = torch.empty(E * T, dtype=torch.bool, device=DEV)
+        ff = torch.empty(E * T, dtype=torch.float32, device=DEV)
+        ops.gather_fields([(obs, o, T, E, N * D, a * D), (act, ac, T, E, N, a), (flag, fb, T, E, N, a), (flag, ff, T, E, N, a)])
+        em = lambda x: x.transpose(0, 1)[:, :, a].reshape(E * T, *x.shape[3:])  # noqa: E731
+        assert torch.equal(o, em(obs)) and torch.equal(ac, em(act).to(torch.int64))
+        assert torch.equal(fb, em(flag).bool()) and torch.equal(ff, em(flag).float())
+    # converting copies (what learn() does with a device batch): int64 -> int32, bool -> uint8, f32 -> f32; ten fields = two launches
+    a64 = torch.randint(0, 5, (33,), generator=g).to(DEV)
+    b = (torch.rand(33, generator=g) < 0.5).to(DEV)
+    x = torch.randn(33, 4, generator=g).to(DEV)
+    outs = [(a64, torch.empty(33, dtype=torch.int32, device=DEV)), (b, torch.empty(33, 1, dtype=torch.uint8, device=DEV)),
+            (x, torch.empty(33, 4, device=DEV))] * 3 + [(a64, torch.empty(33, dtype=torch.int64, device=DEV))]
+    ops.gather_fields(outs)
+    for src, dst in outs:
+        assert torch.equal(dst.reshape(src.shape).to(src.dtype), src)
+    with pytest.raises(TypeError):
+        ops.gather_fields([(x.double(), torch.empty(33, 4, device=DEV))])
+    with pytest.raises(ValueError):
+        ops.gather_fields([(obs, torch.empty(E * T, D, device=DEV), T, E, N * D, N * D)])  # the last agent's column + D leaves the store
