@@ -76,6 +76,34 @@ def test_kernel_options_are_host_state_with_validated_values(lib):
     assert ops.kernel_options() == (0, 0, 0, 0)
 
 
+def test_new_host_entry_points_validate_without_a_device(lib):
+    """tsm_gather_fields / tsm_gae_set_scan_workspace check their arguments on the host; the Python wrappers refuse CPU tensors
+    (no CPU fallback) and do not register a scan workspace without a GPU."""
+    import torch
+
+    from tianshou_marl_amd import ops
+
+    assert lib.tsm_gae_scan_workspace_bytes() >= 8 + 128 * 4 + 128 * 16
+    with pytest.raises(ValueError):
+        _abi.call("tsm_gae_set_scan_workspace", 1, 8)           # too small
+    _abi.call("tsm_gae_set_scan_workspace", None, 0)            # withdrawing is always allowed
+    fields = (_abi.tsm_gather_field * 1)(_abi.tsm_gather_field(None, None, 4, 0, 0, 1, 0, 1, 0, 0, 0))
+    with pytest.raises(ValueError, match="null pointer"):
+        _abi.call("tsm_gather_fields", fields, 1, None)
+    with pytest.raises(ValueError, match="1..8 fields"):
+        _abi.call("tsm_gather_fields", fields, 9, None)
+    fields[0] = _abi.tsm_gather_field(1, 1, 6, 2, 2, 1, 0, 1, 0, 0, 0)   # n_rows != T * E
+    with pytest.raises(ValueError, match="T \\* E"):
+        _abi.call("tsm_gather_fields", fields, 1, None)
+    fields[0] = _abi.tsm_gather_field(1, 1, 4, 0, 0, 1, 0, 1, 0, 1, 0)   # f32 -> i32 is not a conversion it does
+    with pytest.raises(ValueError, match="f32 sources"):
+        _abi.call("tsm_gather_fields", fields, 1, None)
+    with pytest.raises(ValueError, match="device tensors"):
+        ops.gather_fields([(torch.zeros(4), torch.zeros(4))])
+    if not torch.cuda.is_available():
+        assert ops.ensure_scan_workspace("cpu") is False
+
+
 def test_product_has_no_oracle_import():
     """The product package must never import the oracle (test infrastructure)."""
     root = os.path.dirname(os.path.abspath(_abi.__file__))
