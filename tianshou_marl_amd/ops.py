@@ -6,6 +6,7 @@ kernels through `_abi.call` on torch's current stream.  Nothing here computes on
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -509,6 +510,8 @@ def ppo_finalize_many(partial, stride_elems: int, n_blocks_dev, M_dev, cfg: tsm_
 
 
 def ppo_update_grid(M: int, max_blocks: int = 0) -> int:
+    if not max_blocks:
+        max_blocks = int(os.environ.get("TSM_UPDATE_MAX_BLOCKS", "0"))  # (A/B timing of the slab count; default: the rule)
     return call("tsm_ppo_update_grid", M, max_blocks)
 
 
