@@ -373,7 +373,8 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
 
 // ---- wave-autonomous form ------------------------------------------------------------------------------------------------
 // rollout_kernel above runs one 16-row tile per workgroup on eight waves: every phase of a vector step (forward layer by layer,
-// heads, env step, scatter) is a workgroup-wide phase behind a barrier, ~10 barriers and 8.8 us per step at BASELINE configs[1]
+// heads, env step, scatter) is a workgroup-wide phase behind a barrier, ~10 barriers and 8.8 us per step (6.8 us once compiled for the
+// job's dimensions) at BASELINE configs[1]
 // (1024 envs x 3 agents: 205 workgroups), with the matrix pipe busy 7 % of the time.  Here ONE WAVE owns the 16 / N environments
 // (<= 16 agent rows) for all T steps and runs a step from the observation to the buffer rows by itself, with no barrier and no
 // cross-wave hand-over: both nets' layers as transposed products on the wave's samples (wave_mlp.h: weights = A operand read
