@@ -126,7 +126,7 @@ def soak_tag(n: int) -> None:
     for i in range(n):
         with policy_within_training_step(mgr):
             cs = col.collect(n_step=n_env * T)
-            batch = agent_batches_from_buffer(buf, env.agents, only=["agent_0", "adversary_0"])
+            batch = agent_batches_from_buffer(buf, env.agents, only=["agent_0", "adversary_0"], global_state=False)
             batch["good"], batch["adversaries"] = batch["agent_0"], batch["adversary_0"]
             trainer.train_step(batch)
         col.reset_buffer(keep_statistics=True)
