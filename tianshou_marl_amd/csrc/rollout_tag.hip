@@ -25,6 +25,8 @@
 
 int tsm_mpe_tag_check_cfg(const tsm_mpe_tag_cfg *h, TagCfg *c);  // mpe_tag.hip
 
+extern long long *g_tsm_stamps;  // abi.hip (diagnostics)
+
 namespace {
 
 struct TagRolloutArgs {
@@ -60,8 +62,11 @@ struct TagRolloutArgs {
     uint64_t offset_inc;
     uint64_t *offset_dev_rw;
     uint32_t *done_ctr;
+    long long *stamps;  // diagnostics only (tsm_debug_set_stamps, tools/stamp_rollout_tag.py): phase time stamps of workgroup 0
 };
 
+
+#define TSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && t < 4) a.stamps[t * 8 + (k)] = (long long)wall_clock64(); } while (0)
 
 constexpr int NT2 = 2 * NT;  // eight waves: actor chains on waves 0-3, critic chains on waves 4-7 (tile_forward_split)
 
@@ -144,12 +149,14 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
 
     for (int t = 0; t < a.n_steps; ++t) {
         float *XN = lds + xnxt;
+        TSTAMP(0);
         // B. both teams' actor + critic forward of the 16-row tile (same X, separate OUT)
         lyf.X = xcur; lyg.X = xcur;
         // (round 4: both teams' nets side by side -- waves 0-3 team 0, waves 4-7 team 1, two chains per wave, three barriers instead
         //  of six -- was built, bit-identical, and changed nothing: collect 0.276 ms either way; the two passes stay)
         tile_forward_split<H>(lds, lyf, d);
         tile_forward_split<H>(lds, lyg, d);
+        TSTAMP(1);
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
         if (threadIdx.x < NT) {
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             }
         }
         __syncthreads();
+        TSTAMP(2);
         // D. env step, one lane per agent (mpe_tag_dev.h): move -> barrier -> publish -> barrier -> reward terms.
         //    Beside the move, the env lanes do the buffer index algebra on their register-resident sub-buffer state
         //    (buffer_base.py:373-410 + manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h).
@@ -251,6 +259,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             }
             n_fin += tr ? 1 : 0;
         }
+        TSTAMP(3);
         // E. payload scatter into the time-major SoA store (rows of consecutive envs are adjacent)
         for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
             const int rr = i / D, k = i - rr * D, ee = rr / NA;
@@ -267,6 +276,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             if (a.logp_store) a.logp_store[dst] = s_logp[r];
             if (a.vs_store) a.vs_store[dst] = s_val[r];
         }
+        TSTAMP(4);
         // F. finished episodes: re-initialise the env, first observation of the new episode
         if (a.auto_reset) {
             int any_done = lane_live ? s_done[el] : 0;
@@ -291,6 +301,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             }
         }
         __syncthreads();  // the next forward (or the epilogue) reads the tile at once; s_* of this step are free again
+        TSTAMP(5);
         { const int tmp = xcur; xcur = xnxt; xnxt = tmp; }
     }
     // the observation of the next collect() call
@@ -367,6 +378,7 @@ TSM_EXPORT int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stre
     TSM_REQUIRE(!h.done_ctr || h.offset_dev, "tsm_rollout_tag: done_ctr needs offset_dev");
     a.offset_inc = h.offset_inc; a.done_ctr = h.done_ctr;
     a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
+    a.stamps = g_tsm_stamps;
     const size_t shmem = tag_rollout_lds_floats(a.d) * sizeof(float);
     TSM_REQUIRE(shmem <= kTsmMaxLds, "tsm_rollout_tag: %zu bytes of LDS needed", shmem);
     static bool attr_set = false;
