@@ -103,6 +103,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         (reinterpret_cast<uintptr_t>(s_done + R) + 7) & ~(uintptr_t)7);
     uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + R);        // [EPB] episode counter of finished envs
 
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[40] = (long long)wall_clock64();
     // waves 0-3 stage team 0's weights, waves 4-7 team 1's (batches of 4 loads per thread: ~1 us per workgroup)
     if (threadIdx.x < NT) stage_weights<H>(lds, ly, d, a.P[0]);
     else stage_weights<H>(lds + wB, ly, d, a.P[1], (int)threadIdx.x - NT);
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     }
     __syncthreads();
 
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[41] = (long long)wall_clock64();
     for (int t = 0; t < a.n_steps; ++t) {
         float *XN = lds + xnxt;
         TSTAMP(0);
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         TSTAMP(5);
         { const int tmp = xcur; xcur = xnxt; xnxt = tmp; }
     }
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[42] = (long long)wall_clock64();
     // the observation of the next collect() call
     if (a.obs_cur_out)
         for (int i = threadIdx.x; i < rows_here * D; i += NT2) {

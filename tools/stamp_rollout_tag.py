@@ -36,7 +36,10 @@ with policy_within_training_step(mgr):
         col.reset_buffer(keep_statistics=True)
 torch.cuda.synchronize()
 lib.tsm_debug_set_stamps(None)
-s = st.cpu().numpy()[:32].reshape(4, 8)
+full = st.cpu().numpy()
+print(f"workgroup 0: prologue (weights of both teams, env state, first observation rows) {(full[41] - full[40]) / 100.0:.2f} us, "
+      f"{T} steps {(full[42] - full[41]) / 100.0:.2f} us")
+s = full[:32].reshape(4, 8)
 names = ["forward x 2 teams", "heads", "env step (move, publish, rewards, obs_next)", "payload scatter", "done / reset"]
 for t in range(1, 4):
     d = [(s[t][k + 1] - s[t][k]) / 100.0 for k in range(5)]
