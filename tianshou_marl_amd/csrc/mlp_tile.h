@@ -75,8 +75,9 @@ template <int H>
 __device__ void stage_weights(float *lds, const Lay<H> &ly, const Dims &d, const float *__restrict__ P, int tid_in = -1) {
     const POff<H> po(d.D, d.A);
     const int tid = tid_in < 0 ? (int)threadIdx.x : tid_in;  // NT threads take part (rollout_tag.hip: waves 4-7 pass tid - NT)
-    // loads are issued in batches of U per thread before any LDS write, so a batch costs one memory round trip
-    constexpr int U = 4;
+    // loads are issued in batches of U per thread before any LDS write, so a batch costs one memory round trip (U = 4 until round 4:
+    // 13 round trips, 7 us of the tag rollout's prologue and ~4 us of every policy_forward launch that reads the flat parameters)
+    constexpr int U = 12;
     for (int e0 = tid; e0 < 2 * H * d.ld1; e0 += U * NT) {  // W1 actor|critic, zero padded
         float v[U];
 #pragma unroll
@@ -106,16 +107,25 @@ __device__ void stage_weights(float *lds, const Lay<H> &ly, const Dims &d, const
             if (e < H * ly.ldh) { lds[ly.W2a + e] = va[u]; lds[ly.W2c + e] = vc[u]; }
         }
     }
-    for (int e = tid; e < 16 * ly.ldh; e += NT) {
-        const int row = e / ly.ldh, c = e - row * ly.ldh;
-        lds[ly.W3a + e] = (row < d.A && c < H) ? P[po.aW3 + row * H + c] : 0.f;
-    }
-    for (int e = tid; e < H; e += NT) {
-        lds[ly.W3c + e] = P[po.cW3 + e];
-        lds[ly.B1 + e] = P[po.ab1 + e];
-        lds[ly.B1 + H + e] = P[po.cb1 + e];
-        lds[ly.B2 + e] = P[po.ab2 + e];
-        lds[ly.B2 + H + e] = P[po.cb2 + e];
+    {   // W3 (actor, rows >= A zero) and the five H-long vectors: all loads of a thread first, then the LDS writes
+        constexpr int N3 = (16 * Lay<H>::ldh + NT - 1) / NT;
+        float v3[N3], vv[5];
+#pragma unroll
+        for (int u = 0; u < N3; ++u) {
+            const int e = tid + u * NT, row = e / ly.ldh, c = e - row * ly.ldh;
+            v3[u] = (e < 16 * ly.ldh && row < d.A && c < H) ? P[po.aW3 + row * H + c] : 0.f;
+        }
+        const int e5 = tid < H ? tid : 0;
+        vv[0] = P[po.cW3 + e5]; vv[1] = P[po.ab1 + e5]; vv[2] = P[po.cb1 + e5]; vv[3] = P[po.ab2 + e5]; vv[4] = P[po.cb2 + e5];
+#pragma unroll
+        for (int u = 0; u < N3; ++u) {
+            const int e = tid + u * NT;
+            if (e < 16 * ly.ldh) lds[ly.W3a + e] = v3[u];
+        }
+        if (tid < H) {
+            lds[ly.W3c + tid] = vv[0]; lds[ly.B1 + tid] = vv[1]; lds[ly.B1 + H + tid] = vv[2]; lds[ly.B2 + tid] = vv[3];
+            lds[ly.B2 + H + tid] = vv[4];
+        }
     }
     if (tid < 16) lds[ly.B3a + tid] = tid < d.A ? P[po.ab3 + tid] : 0.f;
     if (tid == 0) lds[ly.B3c] = P[po.cb3];
