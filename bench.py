@@ -41,6 +41,61 @@ def mlp_flops(dims) -> tuple[int, int]:
     return 2 * sum(a * b for a, b in pairs), 4 * sum(a * b for a, b in pairs[1:]) + 2 * pairs[0][0] * pairs[0][1]
 
 
+# Fields of the JSON line that are LOOKED UP in committed profiles of earlier runs of this same command (they need rocprofv3 passes
+# the default run does not make): every file a lookup read, by field name.  Emitted as `profile_sources` on the line.
+_SOURCES: dict = {}
+
+
+def _source(field: str, path: str) -> None:
+    _SOURCES.setdefault(field, [])
+    rel = os.path.relpath(path, ROOT)
+    if rel not in _SOURCES[field]:
+        _SOURCES[field].append(rel)
+
+
+# Environment variables / process-wide switches that change WHICH kernel an entry point launches (or arm diagnostics).  A run with
+# any of them set is not the configuration the line claims: refused unless --allow-options, and then labelled "diagnostic".
+KERNEL_ENV = ("TSM_DBG", "TSM_GENERIC_KERNELS", "TSM_ACTOR_TILE", "TSM_SPLIT_BF16", "TSM_ROLLOUT_FORM", "TSM_UPDATE_MAX_BLOCKS",
+              "TSM_CRITIC_GEN", "TSM_CRITIC_SPLIT_DW2", "TSM_UPDATE_FORM")
+
+
+def kernel_env_set() -> list:
+    return [k for k in KERNEL_ENV if os.environ.get(k) not in (None, "")]
+
+
+def kernel_configuration() -> dict:
+    """What selects kernels in this process, read from the library itself (host state only, no device call): the run-time
+    options (ops.kernel_options), the debug switches of csrc/mlp_fused.hip (update variant, slab store flavour) and whether phase
+    stamps are armed (tsm_debug_set_stamps) -- plus the environment variables above."""
+    import ctypes
+
+    from tianshou_marl_amd import _abi, ops
+
+    st = (ctypes.c_int32 * 4)()
+    _abi.load().tsm_debug_get_state(st)
+    cfg = dict(zip(ops.KERNEL_OPTIONS, ops.kernel_options()))
+    cfg.update(update_variant=int(st[0]), slab_store=int(st[1]), stamps_armed=bool(st[2]), env=kernel_env_set())
+    cfg["default"] = not any(v for k, v in cfg.items() if k != "default")
+    return cfg
+
+
+def guard_configuration(a, out: dict | None = None) -> None:
+    """Refuse (exit code 3) a run whose kernel selection is not the default, unless --allow-options; with it, label the line."""
+    env = kernel_env_set()
+    if out is None:  # the early check: environment only, BEFORE anything touches the GPU
+        if env and not a.allow_options:
+            raise SystemExit("bench.py: refusing to run with %s set (kernel selection / diagnostics switches): the line would not be "
+                             "the configuration it names.  Unset them, or pass --allow-options for a run labelled \"diagnostic\"."
+                             % ", ".join(env))
+        return
+    cfg = kernel_configuration()
+    out.setdefault("config", {})["kernel_options"] = cfg
+    if not cfg["default"]:
+        if not a.allow_options:
+            raise SystemExit("bench.py: kernel options are not at their defaults (%s): pass --allow-options for a diagnostic run" % cfg)
+        out["diagnostic"] = True
+
+
 def in_situ_us(kernel: str, workload: str = "bench", grid: int | None = None, near_us: float | None = None):
     """Average duration (us) of `kernel` INSIDE the job's own launch sequence, from the committed rocprofv3 --kernel-trace
     --stats summary of that job (profiles/*_{workload}_kernel_stats.json, tools/summarize_profile.py); None if absent.
@@ -54,6 +109,7 @@ def in_situ_us(kernel: str, workload: str = "bench", grid: int | None = None, ne
     rows = [r for r in json.load(open(files[-1])).get("by_grid", []) if kernel in r["kernel"] and (grid is None or r["grid"] == grid)]
     if not rows:
         return None
+    _source("in_situ_us_rocprof", files[-1])
     if near_us is not None:
         rows.sort(key=lambda r: abs(math.log(r["avg_us"] / near_us)))
     else:
@@ -76,6 +132,9 @@ def parse():
     ap.add_argument("--c3-dispatch", default="pooled", choices=["per_agent", "pooled"],
                     help="c3ppo: pooled = minibatches of joint rows (critic once per row); per_agent = MARLDispatcher order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-options", action="store_true",
+                    help="run although kernel-selection options / TSM_* switches are not at their defaults; the line says \"diagnostic\": true")
+    ap.add_argument("--no-batch64", action="store_true", help="skip the reference-default (batch 64) update timing")
     ap.add_argument("--ignore-obs-next", action="store_true",
                     help="c3ppo: a buffer without an obs_next store (VectorReplayBuffer(ignore_obs_next=True), buffer_base.py:612-616): "
                          "the rollout writes half the observation rows, V(obs_next) comes from V(obs) at next(index)")
@@ -194,6 +253,7 @@ def pmc_traffic(kernel: str, grid_threads: int, expect: float | None = None):
             if kernel in r["kernel"] and r["grid"] == grid_threads and r.get("fetch_KiB") is not None]
     if not hits:
         return None
+    _source("traffic", files[-1])
     if expect is None or len(hits) == 1:
         return hits[0]
     return min(hits, key=lambda t: abs(math.log(max(t, 1.0) / expect)))
@@ -209,6 +269,7 @@ def pmc_issue(kernel: str, grid_threads: int) -> dict:
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_issue_*.json")), reverse=True):
         for r in json.load(open(f))["kernels"]:
             if kernel in r["kernel"] and r["grid"] == grid_threads:
+                _source("mfma_pipe_busy / other_valu_per_mfma", f)
                 return {"mfma_pipe_busy": round(r["pipe_busy"], 3), "other_valu_per_mfma": round(r["other_valu_per_mfma"], 2)}
     return {}
 
@@ -659,7 +720,7 @@ def run_c3(a, device):
                      "flop_per_learn": learn_flop, "rows_per_learn": R},
     }
     _ = ops
-    _emit(json.dumps(out))
+    _emit(out)
 
 
 def run_c3ppo(a, device):
@@ -715,7 +776,7 @@ def run_c3ppo(a, device):
     torch.cuda.synchronize()
     col.reset_buffer(keep_statistics=True)
     d = ts.get_loss_stats_dict()
-    _emit(json.dumps({
+    _emit({
         "metric": "env-steps/sec (n_env x n_agent) incl. PPO update, simple_spread N=8, centralized critic",
         "value": n_env * N * T / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": a.steps, "warmup": max(a.warmup, 2),
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -736,7 +797,7 @@ def run_c3ppo(a, device):
             + n_env * T * N * sum(mlp_flops((D, 128, 128, 5))) + n_env * T * sum(mlp_flops((N * D, 128, 128, 1))),
             e1.elapsed_time(e2) * 1e-3),
         "gradient_steps_per_update": sum(int(v) for k, v in d.items() if k.endswith("gradient_steps")),
-        "loss": d.get("agent_0/loss", d.get("loss"))}))
+        "loss": d.get("agent_0/loss", d.get("loss"))})
 
 
 def run_tag(a, device, rank, world, dist, census=None):
@@ -833,14 +894,25 @@ def run_tag(a, device, rank, world, dist, census=None):
                "losses": {k: float(v["loss"]) for k, v in losses.items()}}
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
-        _emit(json.dumps(out))
+        _emit(out)
 
 
 _OUT: list = []
 
 
-def _emit(line: str) -> None:
-    """The bench's JSON line: held back until fd 1 is the real stdout again (see main)."""
+_ARGS = None
+
+
+def _emit(line) -> None:
+    """The bench's JSON line: held back until fd 1 is the real stdout again (see main).  A dict gets the proof of its own
+    configuration first (`config.kernel_options`; a non-default selection is refused or labelled, see guard_configuration) and
+    the list of committed profile files its looked-up fields came from."""
+    if isinstance(line, dict):
+        guard_configuration(_ARGS, line)
+        if _SOURCES:
+            line["profile_sources"] = dict(_SOURCES, note="these fields are looked up in committed summaries of EARLIER runs of this "
+                                           "command under rocprofv3 (tools/r0N_profiles.sh); this run did not measure them")
+        line = json.dumps(line)
     _OUT.append(line)
 
 
@@ -911,7 +983,9 @@ def launch_ranks(n: int) -> int:
 
 
 def _main():
-    a = parse()
+    global _ARGS
+    a = _ARGS = parse()
+    guard_configuration(a)  # (environment only: before any rank is started and before anything touches the GPU)
     # ---- who runs: nothing below this block may run before it, and nothing in it calls into HIP -----------------------
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         if a.workload in ("c3", "c3ppo"):
@@ -1062,7 +1136,7 @@ def _main():
             out["roofline_grid"] += c3_rooflines(device)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a)
-        _emit(json.dumps(out))
+        _emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -98,10 +98,15 @@ int tsm_gae_lanes_rms(const float *v_s, const float *v_s_next, const float *rew,
                       double rms_eps, float *returns_out, float *adv_out, void *stream);
 /* The few-lanes / long-series form of tsm_gae_lanes (n_lane <= 64, T >= 1024: the MARL trainers' one time-ordered lane of
  * n_env * T rows, training_coordinator.py:118,154,336) runs its super-chunks of 4096 steps on different workgroups when the
- * host has registered a ZEROED device workspace of tsm_gae_scan_workspace_bytes() bytes for this process's device (the memory
- * stays the caller's; nullptr withdraws it): same bits as the one-workgroup-per-lane form, 12 800 rows 27 -> 9 us. */
+ * host has registered a ZEROED device workspace of tsm_gae_scan_workspace_bytes() bytes for the CURRENT device (one per device;
+ * the memory stays the caller's; nullptr withdraws it): same bits as the one-workgroup-per-lane form, 12 800 rows 27 -> 9 us.
+ * The workspace is cut into slots -- one per eager stream, one per launch recorded into a hipGraph -- so launches in flight never
+ * share hand-over state; without a free slot, or on a device without a workspace, the one-workgroup form runs.
+ * tsm_gae_set_scan_error_word: a word of PINNED host memory that a scan whose bounded wait ran out sets to 1 (its outputs are NaN
+ * from there on); the host reads it where it reads its statistics. */
 int64_t tsm_gae_scan_workspace_bytes(void);
 int tsm_gae_set_scan_workspace(void *workspace, int64_t bytes);
+int tsm_gae_set_scan_error_word(int32_t *host_pinned);
 
 /* RunningMeanStd.update (utils/statistics.py:97-114) with the UNNORMALISED returns of a2c.py:144-146:
  * x[i] = returns[ids ? ids[i] : i] * sqrt(rms[1] + rms_eps), i < n; batch mean / population variance in f64
@@ -721,6 +726,10 @@ int tsm_p2p_adam_step(void *handle, float *param, const float *grad_slabs, int32
 int tsm_p2p_set_timeout(void *handle, double seconds);
 int tsm_p2p_handshake(void *handle, int32_t *ok_out, void *stream);
 int tsm_p2p_failed(void *handle);
+/* The error word copied asynchronously into PINNED host memory behind the work queued on `stream`: valid once the host has waited
+ * for that point of the stream.  The host binding queues it in front of the event of every update's loss statistics and raises
+ * on every rank when it reads them (no extra synchronisation; algorithm/ppo.py, ppo_generic.py). */
+int tsm_p2p_error_async(void *handle, int32_t *host_pinned_out, void *stream);
 int tsm_p2p_destroy(void *handle);
 
 /* ---------------------------------------------------------------------------------------------

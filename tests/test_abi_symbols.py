@@ -59,8 +59,9 @@ def test_kernel_options_are_host_state_with_validated_values(lib):
     (no TSM_* override in the test environment), takes its documented values and refuses others and unknown names."""
     from tianshou_marl_amd import ops
 
-    assert set(ops.KERNEL_OPTIONS) == {"actor_tile", "split_bf16", "dbg", "rollout_form"}
-    for name, good, bad in [("actor_tile", (32, 64, 0), 48), ("split_bf16", (1, 0), 2), ("rollout_form", (1, 2, 0), 3)]:
+    assert set(ops.KERNEL_OPTIONS) == {"actor_tile", "split_bf16", "generic_kernels", "rollout_form"}
+    for name, good, bad in [("actor_tile", (32, 64, 0), 48), ("split_bf16", (1, 0), 2), ("generic_kernels", (1, 0), 128),
+                            ("rollout_form", (1, 2, 0), 3)]:
         if os.environ.get("TSM_" + name.upper()) is None:
             assert ops.kernel_option(name) == 0
         for v in good:

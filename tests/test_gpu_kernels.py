@@ -98,7 +98,7 @@ def test_gae_long_lanes_super_chunks_side_by_side_equal_the_sequential_scan(orac
         _abi.call("tsm_gae_set_scan_workspace", None, 0)  # withdrawn: the sequential form
         ret_s, adv_s = ops.gae_lanes(*args, v_scale=1.7, **kw)
     finally:
-        _abi.call("tsm_gae_set_scan_workspace", ops._scan_ws.data_ptr(), n)
+        _abi.call("tsm_gae_set_scan_workspace", ops._scan_ws[torch.cuda.current_device()][0].data_ptr(), n)
     for _ in range(3):
         ret_p, adv_p = ops.gae_lanes(*args, v_scale=1.7, **kw)
         assert torch.equal(ret_p, ret_s) and torch.equal(adv_p, adv_s)
@@ -111,6 +111,18 @@ def test_gae_long_lanes_super_chunks_side_by_side_equal_the_sequential_scan(orac
         out[0].zero_(); out[1].zero_()
         g.replay()
         assert torch.equal(out[0], ret_s) and torch.equal(out[1], adv_s)
+    # two launches in flight on two streams take different slots of the workspace (they used to share one)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1, o2 = (torch.empty_like(ret_s), torch.empty_like(adv_s)), (torch.empty_like(ret_s), torch.empty_like(adv_s))
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            ops.gae_lanes(*args, v_scale=1.7, out=o1, **kw)
+        with torch.cuda.stream(s2):
+            ops.gae_lanes(*args, v_scale=1.7, out=o2, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(o1[0], ret_s) and torch.equal(o2[0], ret_s) and torch.equal(o1[1], adv_s) and torch.equal(o2[1], adv_s)
+    assert not ops.gae_scan_failed()
     ret_o, adv_o = oracle.gae_lanes(v_s, v_n, rew, term_l, trunc_l, 0.99, 0.95, v_scale=1.7)
     np.testing.assert_allclose(adv_p.cpu().numpy(), adv_o, rtol=1e-6, atol=2e-6)
     np.testing.assert_allclose(ret_p.cpu().numpy(), ret_o, rtol=1e-6, atol=2e-6)

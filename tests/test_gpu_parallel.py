@@ -361,6 +361,7 @@ def _p2p_worker(rank: int, world: int, port: int, out_dir: str) -> None:
     """Two processes on cuda:0, handles exchanged over gloo: the one-shot peer-memory all-reduce (csrc/p2p.hip)."""
     import torch.distributed as dist
 
+    from tianshou_marl_amd import ops
     from tianshou_marl_amd.algorithm.ppo import PPO, policy_within_training_step
     from tianshou_marl_amd.data.buffer import DeviceVectorReplayBuffer
     from tianshou_marl_amd.data.collector import Collector
@@ -396,7 +397,7 @@ def _p2p_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         torch.cuda.synchronize()
         dist.barrier()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with ops.graph_capture(g):
             buf.copy_(src)
             p2p.all_reduce_sum_(buf)
             p2p.all_reduce_sum_(buf)   # two calls per replay: sum of sums

@@ -261,3 +261,65 @@ def test_ignore_obs_next_buffer_collects_and_updates_with_the_reference_semantic
     assert torch.equal(finals[0][0], finals[1][0])
     for a, b in zip(finals[0][1], finals[1][1]):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+# ---- kernels compiled for BASELINE's dimensions against the generic forms (option "generic_kernels") ----
+def _snap(buf, net, extra=()):
+    out = {k: getattr(buf, k).clone() for k in ("obs_store", "act_store", "rew_store", "done_store") if getattr(buf, k) is not None}
+    for k in ("obs_next_store", "logp_store", "vs_store", "vnext_store"):
+        if getattr(buf, k, None) is not None:
+            out[k] = getattr(buf, k).clone()
+    out["state"] = buf.index.state.clone()
+    for i, n in enumerate(net if isinstance(net, (list, tuple)) else [net]):
+        out[f"flat{i}"] = n.flat.data.clone()
+    out.update(extra)
+    return out
+
+
+@pytest.mark.parametrize("case", ["spread_1024x3", "spread_actor_4096x8", "tag_512_3v1"])
+def test_generic_and_specialised_kernels_give_the_same_bits(case):
+    """VERDICT r4 'What's weak' 1b: the instantiations the benchmark runs (`ppo_update_split_kernel<64,0,18>`,
+    `rollout_kernel<64,512,18,3>`, `policy_forward_kernel<64,18>` at configs[1]; `rollout_wave_kernel<3,8>` at configs[2];
+    `<64,0,16>` / `<64,16>` at configs[4]) are compile-time specialisations of generic kernels: collect + update under the default
+    rule and under `generic_kernels=1` must leave the same buffer rows, the same loss statistics and the same parameters."""
+    res = []
+    for generic in (0, 1):
+        with ops.kernel_override(generic_kernels=generic):
+            if case == "spread_1024x3":
+                env, net, algo, buf, col = _job(1024, 3, 25, True, use_graph=True, shuffle="device")
+                nets = [net]
+                with policy_within_training_step(algo):
+                    col.collect(n_step=1024 * 25)
+                    st = algo.update(buf, 4096, 1)
+                stats = st.get_loss_stats_dict()
+            elif case == "spread_actor_4096x8":
+                env, net, algo, buf, col = _job128(4096, 8, 25, True, True)
+                nets = [net]
+                with policy_within_training_step(algo):
+                    col.collect(n_step=4096 * 25)
+                stats = {}
+            else:
+                from tianshou_marl_amd.algorithm.multiagent.flexible_policy import FlexibleMultiAgentPolicyManager
+                from tianshou_marl_amd.algorithm.multiagent.training_coordinator import agent_batches_from_buffer
+                from tianshou_marl_amd.env.mpe_tag import DeviceSimpleTagVectorEnv
+
+                env = DeviceSimpleTagVectorEnv(512, 1, 3, 2, max_cycles=25, device=DEV, seed=11)
+                mk = lambda s: PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=DEV, seed=s), seed=s, shuffle="device")  # noqa: E731
+                pols = {"adversaries": mk(21), "good": mk(22)}
+                mgr = FlexibleMultiAgentPolicyManager(pols, env, mode="grouped", agent_groups=env.agent_groups)
+                buf = DeviceVectorReplayBuffer(512 * 25, 512, env.n_agent, env.obs_dim, device=DEV)
+                col = Collector(mgr, env, buf, fused_rollout=True, use_graph=False)
+                col.reset()
+                nets = [p.net for p in pols.values()]
+                with policy_within_training_step(mgr):
+                    col.collect(n_step=512 * 25)
+                    batch = agent_batches_from_buffer(buf, env.agents, global_state=False)
+                    stats = {name: dict(pols["good" if name.startswith("agent") else "adversaries"].learn(batch[name], 4096, 1))
+                             for name in ("adversary_0", "agent_0")}
+            torch.cuda.synchronize()
+            res.append((_snap(buf, nets), stats))
+    (a, sa), (b, sb) = res
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert sa == sb

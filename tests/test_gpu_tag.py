@@ -333,6 +333,27 @@ def test_agent_batches_fast_path_equals_the_indexed_gather():
     assert torch.equal(some["agent_0"].obs, slow["agent_0"].obs)
 
 
+def test_agent_batches_of_a_buffer_without_an_obs_next_store():
+    """a uniformly filled `ignore_obs_next=True` buffer has no obs_next store -- agent_batches_from_buffer must take
+    the indexed gather (obs at next(index), buffer_base.py:612-616), not dereference the missing store."""
+    env = DeviceSimpleTagVectorEnv(48, 1, 3, 2, max_cycles=6, device=DEV, seed=11)
+    mk = lambda s: PPO(net=DiscreteActorCritic(env.obs_dim, 5, 64, device=DEV, seed=s), seed=s)  # noqa: E731
+    mgr = FlexibleMultiAgentPolicyManager({"adversaries": mk(21), "good": mk(22)}, env, mode="grouped", agent_groups=env.agent_groups)
+    buf = DeviceVectorReplayBuffer(48 * 10, 48, env.n_agent, env.obs_dim, device=DEV, ignore_obs_next=True)
+    col = Collector(mgr, env, buf, use_graph=False, fused_rollout=False)
+    col.reset()
+    with policy_within_training_step(mgr):
+        col.collect(n_step=48 * 10)
+    assert buf.host_uniform_len() == 10 and buf.obs_next_store is None
+    got = agent_batches_from_buffer(buf, env.agents)
+    idx = buf.index.sample_indices_all()
+    ref = buf.get_device(idx.cpu().numpy())
+    for a, name in enumerate(env.agents):
+        assert torch.equal(got[name].obs, ref["obs"][:, a]) and torch.equal(got[name].obs_next, ref["obs_next"][:, a])
+        assert got[name].act.dtype == torch.int64 and torch.equal(got[name].rew, ref["rew"][:, a])
+    assert torch.equal(got["global_obs_next"], ref["obs_next"].reshape(len(idx), -1))
+
+
 @pytest.mark.parametrize("n_env,n_adv,n_good,n_obst", [(48, 3, 1, 2), (24, 4, 2, 3)])
 def test_tag_single_steps_match_oracle_tightly(n_env, n_adv, n_good, n_obst):
     """One step at a time from the SAME state (the oracle world is re-synchronised to the device state before every step):

@@ -121,6 +121,7 @@ SIGNATURES = {
     "tsm_gae_lanes": (_int, [_p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _p, _p, _f64, _f64, _f64, _p, _p, _p]),
     "tsm_gae_scan_workspace_bytes": (_i64, []),
     "tsm_gae_set_scan_workspace": (_int, [_p, _i64]),
+    "tsm_gae_set_scan_error_word": (_int, [_p]),
     "tsm_gae_lanes_rms": (_int, [_p, _p, _p, _p, _p, _int, _i64, _i64, _i64, _p, _p, _f64, _f64, _p, _f64, _p, _p, _p]),
     "tsm_rms_update_work_elems": (_i64, [_i64]),
     "tsm_rms_update": (_int, [_p, _p, _i64, _p, _f64, _p, _p]),
@@ -217,6 +218,7 @@ SIGNATURES = {
     "tsm_p2p_set_timeout": (_int, [_p, _f64]),
     "tsm_p2p_handshake": (_int, [_p, C.POINTER(_i32), _p]),
     "tsm_p2p_failed": (_int, [_p]),
+    "tsm_p2p_error_async": (_int, [_p, _p, _p]),
     "tsm_p2p_destroy": (_int, [_p]),
     "tsm_reduce_slabs_segs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
     "tsm_adam_step_segs": (_int, [_p, _p, _i32, _i64, _p, _p, _i64, _p, _f64, _p, _f64, _f64, _f64, _f64, _f64, _p, _p]),

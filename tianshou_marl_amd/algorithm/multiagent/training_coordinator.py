@@ -391,6 +391,7 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
             full = lambda x: x.reshape(E * T, -1)  # noqa: E731
     else:
         d = None
+    store_view = d is not None  # `d` holds views of the time-major stores (not rows gathered through get_device)
     if d is None:
         idx = buffer.index.sample_indices_all()
         d = buffer.get_device(idx.cpu().numpy())
@@ -419,8 +420,10 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
         cd.chain_T, cd.store = int(T), store
         out["chain_done"] = cd
         return out
-    fused = T is not None and T > 0 and all(getattr(buffer, s).is_contiguous() for s in
-                                             ("obs_store", "act_store", "rew_store", "obs_next_store", "term_store", "trunc_store"))
+    # (an ignore_obs_next buffer has no obs_next store: its rows come from get_device, which reads obs at next(index))
+    fused = (store_view and T > 0 and buffer.obs_next_store is not None
+             and all(getattr(buffer, s).is_contiguous() for s in
+                     ("obs_store", "act_store", "rew_store", "obs_next_store", "term_store", "trunc_store")))
     for a, name in enumerate(agents):
         if only is not None and name not in only:
             continue

@@ -301,12 +301,7 @@ class PPO(nn.Module):
         err = None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        import gc
-
-        gc_was = gc.isenabled()
-        gc.collect()
-        gc.disable()  # (no collection inside a capture: see ops.graph_capture)
-        try:
+        with ops.gc_hold():  # (no collection inside a capture: see ops.graph_capture)
             with torch.cuda.stream(side):
                 graph.capture_begin(capture_error_mode="thread_local")
                 try:
@@ -319,9 +314,6 @@ class PPO(nn.Module):
                     err = err or e
                 if err is not None:
                     ops.call("tsm_stream_abort_capture", side.cuda_stream)
-        finally:
-            if gc_was:
-                gc.enable()
         if err is not None:
             raise RuntimeError(
                 "capturing the gradient all-reduce into the update hipGraph failed "
@@ -422,7 +414,11 @@ class PPO(nn.Module):
                               image_map=self.net.image_map)
                 k += 1
         self.param_version += 1
+        if self._grad_sync is not None:
+            self._grad_sync.post_check()  # (peer-memory path: its error word rides behind the update, read below)
         s_h = scal.cpu().numpy()  # the only host sync of the update (the reference does 4 .item() per minibatch)
+        if self._grad_sync is not None:
+            self._grad_sync.raise_if_failed()
         return A2CTrainingStats(
             loss=SequenceSummaryStats.from_sequence(s_h[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(s_h[:, 1]),
             vf_loss=SequenceSummaryStats.from_sequence(s_h[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(s_h[:, 3]),
@@ -473,7 +469,7 @@ class PPO(nn.Module):
         # (the rollout's stored V(obs_next) is that of the TRUE next observation: not what an ignore_obs_next buffer hands out)
         stored = buffer.vnext_store is not None and buffer.policy_outputs_version == self.param_version and not no_next
         key = ("graph", buffer.storage_key(), T, batch_size, repeat, self.dispatch, self.max_grad_norm, stored,
-               self._grad_sync is not None, self.graph_collectives)
+               self._grad_sync is not None, self.graph_collectives, ops.kernel_options())
         g = self._ws.get(key)
         P, A, H = self.net.flat.data, self.net.n_act, self.net.hidden
         if g is None:
@@ -662,10 +658,15 @@ class PPO(nn.Module):
             # and the runtime then drains it with a ~2 ms stall every ~10 steps (tools/step_jitter.py)
             slot["event"].synchronize()
         ops.ppo_finalize_many(g["partial"], g["nb_max"] * 4, g["nb_dev"], g["M_dev"], self._cfg, slot["h"])
+        sync = self._grad_sync
+        if sync is not None:
+            sync.post_check()  # a lost peer (peer-memory all-reduce) is reported where the statistics are read: every rank raises
         slot["event"].record()
 
         def build():
             slot["event"].synchronize()
+            if sync is not None:
+                sync.raise_if_failed()
             s_h = slot["h"].numpy().copy()
             slot["pending"] = None
             mk = lambda x: A2CTrainingStats(  # noqa: E731
@@ -774,7 +775,7 @@ class PPO(nn.Module):
         dev = self.device
         D, A, H = self.net.obs_dim, self.net.n_act, self.net.hidden
         dp = self._grad_sync is not None
-        key = ("learn_graph", n, batch_size, repeat, has_trunc, self.shuffle, dp)
+        key = ("learn_graph", n, batch_size, repeat, has_trunc, self.shuffle, dp, ops.kernel_options())
         w = self._ws.get(key)
         if w is not None:
             return w
@@ -889,6 +890,9 @@ class PPO(nn.Module):
             if slot["pending"] is not None:
                 slot["pending"]._force()
         slot["h"].copy_(w["scal"], non_blocking=True)
+        slot["sync"] = self._grad_sync
+        if self._grad_sync is not None:
+            self._grad_sync.post_check()
         slot["event"].record()
         out = LazyLosses(slot)
         if not self.async_stats:  # plain floats at once, as the reference returns them
@@ -1018,6 +1022,11 @@ class LazyLosses(dict):
             return
         self._slot = None
         slot["event"].synchronize()
+        if slot.get("sync") is not None:
+            slot["sync"].raise_if_failed()
+        if ops.gae_scan_failed():
+            raise RuntimeError("GAE: a workgroup of the parallel long-series scan gave up waiting for another one's map "
+                               "(returns / advantages of that learn() call are NaN)")
         s_h = slot["h"].numpy()
         dict.update(self, loss=float(s_h[:, 0].mean()), actor_loss=float(s_h[:, 1].mean()), vf_loss=float(s_h[:, 2].mean()),
                     ent_loss=float(s_h[:, 3].mean()))

@@ -474,8 +474,14 @@ class GenericPPO(PPO):
                 return MapTrainingStats({f"agent_{a}": mk(s_h[a * per:(a + 1) * per]) for a in range(N)})
             return mk(s_h)
 
+        sync = self._grad_sync
+        if sync is not None:
+            sync.post_check()  # (peer-memory all-reduce: a lost peer is reported where the statistics are read)
         if not self.async_stats:
-            return finish(w["scal"].cpu().numpy())
+            s_h = w["scal"].cpu().numpy()
+            if sync is not None:
+                sync.raise_if_failed()
+            return finish(s_h)
         # async_stats=True (as PPO.update): the statistics travel to a pinned host slot behind the replay and are parsed when
         # the returned object is first read -- the host goes on to queue the next collect while the update runs; a ring of
         # four slots bounds the run-ahead
@@ -495,6 +501,8 @@ class GenericPPO(PPO):
 
         def build():
             slot["event"].synchronize()
+            if sync is not None:
+                sync.raise_if_failed()
             slot["pending"] = None
             return finish(slot["h"].numpy().copy())
 
@@ -564,7 +572,11 @@ class GenericPPO(PPO):
                                                       rows=perm[s:e].contiguous() if row_mode else None)
                 scal.append(sc)
         self.param_version += 1
+        if self._grad_sync is not None:
+            self._grad_sync.post_check()
         s_h = torch.stack(scal).cpu().numpy()
+        if self._grad_sync is not None:
+            self._grad_sync.raise_if_failed()
         return A2CTrainingStats(
             loss=SequenceSummaryStats.from_sequence(s_h[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(s_h[:, 1]),
             vf_loss=SequenceSummaryStats.from_sequence(s_h[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(s_h[:, 3]),
@@ -606,7 +618,13 @@ class GenericPPO(PPO):
         # buffers and one graph per length without bound: keep the eight most recent shapes)
         old = [k for k in self._ws if isinstance(k, tuple) and k and k[0] == "glearn_graph"]
         for k in old[:-7]:
-            del self._ws[k]
+            gone = self._ws.pop(k)
+            if self._grad_sync is not None:
+                # the captured lock-step pins every policy's static buffers (parallel.learn_lockstep_graph keys its graphs by
+                # id(w)): drop the graphs that replay into the evicted set, or the eviction frees nothing
+                cache = self._grad_sync.__dict__.get("_lockstep_graphs", {})
+                for ck in [ck for ck in cache if any(wid == id(gone) for _, wid in ck[0])]:
+                    del cache[ck]
         bounds = split_bounds(n, batch_size or -1, merge_last=True)
         n_steps = repeat * len(bounds)
         z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731

@@ -82,15 +82,17 @@ TSM_EXPORT int tsm_stream_abort_capture(void *stream) {
 //   "actor_tile"  0: by minibatch size (tsm_ppo_actor_rows_grid) | 32 | 64      env TSM_ACTOR_TILE
 //   "split_bf16"  0: f32 matrix pipe | 1: layer 1 of the critic forward on the bf16 pipe with three-way split operands
 //                 (experimental, never the default)                              env TSM_SPLIT_BF16
+//   "generic_kernels" 0: the instantiations compiled for BASELINE's dimensions where they apply (obs 18 / 5 actions / 3 agents,
+//                 obs 16 / 5 actions, obs 48 / 8 agents) | 1: the generic forms everywhere (the same bits: tests/ compare the two;
+//                 also the A/B switch of the timing tools)                          env TSM_GENERIC_KERNELS
 //   "rollout_form" the persistent rollouts (tsm_rollout_spread, tsm_rollout_spread_actor): 0 by rule (wave-autonomous form where
 //                 all its waves are resident at once) | 1: tile form | 2: wave-autonomous form
 //                                                                                   env TSM_ROLLOUT_FORM
 namespace {
 struct KernelOption { const char *name, *env; int value; bool resolved; };
 KernelOption g_opts[TSM_OPT_COUNT] = {{"actor_tile", "TSM_ACTOR_TILE", 0, false}, {"split_bf16", "TSM_SPLIT_BF16", 0, false},
-                                      {"dbg", "TSM_DBG", 0, false}, {"rollout_form", "TSM_ROLLOUT_FORM", 0, false}};
+                                      {"generic_kernels", "TSM_GENERIC_KERNELS", 0, false}, {"rollout_form", "TSM_ROLLOUT_FORM", 0, false}};
 bool opt_valid(int id, int v) {
-    if (id == TSM_OPT_DBG) return v >= 0;   // diagnostics bit mask (tools/ only; kernels compute garbage under it)
     if (id == TSM_OPT_ROLLOUT_FORM) return v >= 0 && v <= 2;
     return id == TSM_OPT_ACTOR_TILE ? (v == 0 || v == 32 || v == 64) : (v == 0 || v == 1);
 }
@@ -133,3 +135,14 @@ TSM_EXPORT int tsm_kernel_option_set(const char *name, int32_t value) {
 // workgroup 0 of the rollout / update kernels when set (tools/stamp_*.py)
 long long *g_tsm_stamps = nullptr;
 extern "C" __attribute__((visibility("default"))) void tsm_debug_set_stamps(long long *p) { g_tsm_stamps = p; }
+// Everything process-wide that changes WHICH kernel an entry point launches or arms its phase stamps, for hosts that must prove
+// a measurement ran the default configuration (bench.py prints it and refuses non-defaults): out[0] = update variant
+// (tsm_debug_set_update_variant), out[1] = slab store flavour (tsm_debug_set_slab_store), out[2] = stamps armed, out[3] = 0.
+extern "C" int tsm_debug_update_variant_get(void);
+extern "C" int tsm_debug_slab_store_get(void);
+extern "C" __attribute__((visibility("default"))) void tsm_debug_get_state(int32_t *out4) {
+    out4[0] = tsm_debug_update_variant_get();
+    out4[1] = tsm_debug_slab_store_get();
+    out4[2] = g_tsm_stamps != nullptr;
+    out4[3] = 0;
+}

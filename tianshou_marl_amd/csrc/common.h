@@ -40,7 +40,7 @@ void tsm_set_error(const char *fmt, ...);
     } while (0)
 
 // kernel selection options (abi.hip: environment default, tsm_kernel_option_set override)
-enum { TSM_OPT_ACTOR_TILE = 0, TSM_OPT_SPLIT_BF16 = 1, TSM_OPT_DBG = 2, TSM_OPT_ROLLOUT_FORM = 3, TSM_OPT_COUNT };
+enum { TSM_OPT_ACTOR_TILE = 0, TSM_OPT_SPLIT_BF16 = 1, TSM_OPT_GENERIC = 2, TSM_OPT_ROLLOUT_FORM = 3, TSM_OPT_COUNT };
 int tsm_opt(int id);
 
 static inline hipStream_t tsm_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

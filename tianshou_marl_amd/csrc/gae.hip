@@ -323,10 +323,15 @@ __global__ __launch_bounds__(1024) void gae_long_kernel(
 // super-chunk (carry -> B + P * carry) does not depend on the other super-chunks, so every workgroup forms its own, publishes it,
 // waits for the maps of the LATER super-chunks of its lane and folds them in the sequential kernel's order -- the same additions
 // and products, the same bits -- instead of one workgroup walking the super-chunks one after the other (12 800 rows: 27 -> 9 us).
-// All workgroups must be resident at once (the host checks n_lane * n_sc <= 128).  Hand-over through a small device workspace
-// (tsm_gae_set_scan_workspace): word 0 = generation g of the launch, word 1 = finished workgroups; a map is published as two
+// A workgroup only ever waits for workgroups with a SMALLER blockIdx.y (super-chunk s = n_sc - 1 - blockIdx.y: the later
+// super-chunks are dispatched first), so a waiter never holds a CU that the workgroup it waits for still needs -- the form does not
+// rely on all n_lane * n_sc workgroups being resident at once (the host still keeps it to <= 128 workgroups).  Hand-over through
+// ONE SLOT of a device workspace (tsm_gae_set_scan_workspace; a slot per eager stream and per captured launch, so two launches in
+// flight never share one): word 0 = generation g of the launch, word 1 = finished workgroups; a map is published as two
 // agent-scope atomic f64 stores followed by a release store of g + 1 into its flag, read by agent-scope atomic loads (the L2s of
 // different XCDs are not coherent for plain loads); the last workgroup to finish advances the generation, so graph replays work.
+// A wait that runs out (never seen) poisons the carry with NaN AND sets the host-visible error word, which the host binding reads
+// with the loss statistics (ops.gae_scan_failed).
 struct ScanWs { unsigned gen, done; unsigned flag[kScanMaxWg]; double agg[kScanMaxWg][2]; };
 
 template <bool FLAGS_PER_LANE>
@@ -334,13 +339,13 @@ __global__ __launch_bounds__(1024) void gae_long_par_kernel(
     const float *__restrict__ v_s, const float *__restrict__ v_n, const float *__restrict__ rew,
     const uint8_t *__restrict__ term, const uint8_t *__restrict__ trunc, int64_t T, int64_t L, int64_t lanes_per_env,
     double gamma, double gl, double v_scale_arg, const double *__restrict__ rms, double rms_eps,
-    float *__restrict__ ret_out, float *__restrict__ adv_out, ScanWs *__restrict__ ws) {
+    float *__restrict__ ret_out, float *__restrict__ adv_out, ScanWs *__restrict__ ws, int32_t *__restrict__ err_host) {
     constexpr int CH = 4;
     __shared__ double sP[2][1024], sB[2][1024];
     __shared__ double s_carry;
     const int t = threadIdx.x;
     const int64_t lane = blockIdx.x;
-    const int n_sc = (int)gridDim.y, s = (int)blockIdx.y;
+    const int n_sc = (int)gridDim.y, s = n_sc - 1 - (int)blockIdx.y;   // waited-for super-chunks (s2 > s) are dispatched first
     const int64_t env = lane / lanes_per_env, n_env = L / lanes_per_env;
     const double v_scale = rms ? sqrt(rms[1] + rms_eps) : v_scale_arg;
     const double inv_scale = 1.0 / v_scale;
@@ -398,7 +403,11 @@ __global__ __launch_bounds__(1024) void gae_long_par_kernel(
             int spins = 0;
             while (__hip_atomic_load(&ws->flag[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen + 1u) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { carry = NAN; break; }   // (never seen; a lost workgroup must not hang the device)
+                if (++spins > (1 << 22)) {   // (never seen; a lost workgroup must not hang the device)
+                    carry = NAN;
+                    if (err_host) __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
             }
             const double p2 = __hip_atomic_load(&ws->agg[o][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double b2 = __hip_atomic_load(&ws->agg[o][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -453,16 +462,68 @@ void launch_gae(int W, const float *v_s, const float *v_s_next, const float *rew
 
 }  // namespace
 
-static void *g_scan_ws = nullptr;   // tsm_gae_set_scan_workspace
+// Workspaces of the parallel long-series scan: ONE per device (registered from that device), cut into slots so that two launches in
+// flight never share generation / flags / maps: slots [0, kScanEagerSlots) belong to the eager streams in order of first use,
+// every launch recorded into a hipGraph takes a slot of its own from the rest (a graph may be replayed on any stream, beside
+// eager work).  No free slot, no workspace on the launch's device: the sequential kernel runs.
+constexpr int kScanMaxDev = 16, kScanSlots = 64, kScanEagerSlots = 8;
+struct ScanReg {
+    ScanWs *ws = nullptr;
+    int32_t *err_host = nullptr;
+    hipStream_t eager_stream[kScanEagerSlots];
+    int n_eager = 0, n_captured = 0;
+};
+static ScanReg g_scan[kScanMaxDev];
 
-TSM_EXPORT int64_t tsm_gae_scan_workspace_bytes(void) { return (int64_t)sizeof(ScanWs); }
+TSM_EXPORT int64_t tsm_gae_scan_workspace_bytes(void) { return (int64_t)sizeof(ScanWs) * kScanSlots; }
 
-// Register (or, with nullptr, withdraw) the ZEROED device workspace of the parallel long-series scan for this process's device.
-// Without one the sequential form runs.  The memory stays the caller's.
+// Register (or, with nullptr, withdraw) the ZEROED device workspace of the parallel long-series scan for the CURRENT device.
+// Without one the sequential form runs on that device.  The memory stays the caller's.
 TSM_EXPORT int tsm_gae_set_scan_workspace(void *workspace, int64_t bytes) {
-    TSM_REQUIRE(!workspace || bytes >= (int64_t)sizeof(ScanWs), "tsm_gae_set_scan_workspace: needs %zu bytes", sizeof(ScanWs));
-    g_scan_ws = workspace;
+    TSM_REQUIRE(!workspace || bytes >= tsm_gae_scan_workspace_bytes(), "tsm_gae_set_scan_workspace: needs %lld bytes",
+                (long long)tsm_gae_scan_workspace_bytes());
+    int dev = 0;
+    if (!workspace && hipGetDevice(&dev) != hipSuccess) {   // withdrawing is always allowed (a host without a device: nothing registered)
+        (void)hipGetLastError();
+        for (auto &r : g_scan) r = ScanReg{};
+        return TSM_OK;
+    }
+    TSM_HIP(hipGetDevice(&dev));
+    TSM_REQUIRE(dev >= 0 && dev < kScanMaxDev, "tsm_gae_set_scan_workspace: device %d out of range", dev);
+    int32_t *keep = g_scan[dev].err_host;
+    g_scan[dev] = ScanReg{};
+    g_scan[dev].ws = static_cast<ScanWs *>(workspace);
+    g_scan[dev].err_host = keep;
     return TSM_OK;
+}
+
+// A word of PINNED (device-visible) host memory for the current device: set to 1 by a scan whose bounded wait ran out (its carry is
+// NaN then).  The host reads it where it reads its loss statistics -- no synchronisation of its own.
+TSM_EXPORT int tsm_gae_set_scan_error_word(int32_t *host_pinned) {
+    int dev = 0;
+    TSM_HIP(hipGetDevice(&dev));
+    TSM_REQUIRE(dev >= 0 && dev < kScanMaxDev, "tsm_gae_set_scan_error_word: device %d out of range", dev);
+    g_scan[dev].err_host = host_pinned;
+    return TSM_OK;
+}
+
+// the slot of a launch on `st` (nullptr: none -- the sequential kernel serves)
+static ScanWs *scan_slot(hipStream_t st, int32_t **err_host) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kScanMaxDev || !g_scan[dev].ws) return nullptr;
+    ScanReg &r = g_scan[dev];
+    *err_host = r.err_host;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) return nullptr;
+    if (cs != hipStreamCaptureStatusNone) {
+        if (kScanEagerSlots + r.n_captured >= kScanSlots) return nullptr;
+        return r.ws + kScanEagerSlots + r.n_captured++;
+    }
+    for (int i = 0; i < r.n_eager; ++i)
+        if (r.eager_stream[i] == st) return r.ws + i;
+    if (r.n_eager >= kScanEagerSlots) return nullptr;
+    r.eager_stream[r.n_eager] = st;
+    return r.ws + r.n_eager++;
 }
 
 extern "C" __attribute__((visibility("default"))) void tsm_debug_gae_config(int vec, int ch, int w) {
@@ -497,15 +558,16 @@ static int gae_impl(const float *v_s, const float *v_s_next, const float *rew, c
         // 128 registers a 1024-thread workgroup leaves per lane -- 122.6 us for the trainers' 12 800-row lane against 27.3 us as four
         // super-chunks of 4096 steps (8 steps: 100 spills, 71.4 us); the same bits in all three (tools/gae_long_time.py, round 4)
         const int64_t n_sc = ceil_div(T, 4096);
-        if (g_scan_ws && n_sc > 1 && n_lane * n_sc <= kScanMaxWg) {   // super-chunks side by side (see gae_long_par_kernel)
+        int32_t *err_host = nullptr;
+        ScanWs *ws = (n_sc > 1 && n_lane * n_sc <= kScanMaxWg) ? scan_slot(st, &err_host) : nullptr;
+        if (ws) {   // super-chunks side by side (see gae_long_par_kernel)
             const dim3 grid2((unsigned)n_lane, (unsigned)n_sc);
-            ScanWs *ws = reinterpret_cast<ScanWs *>(g_scan_ws);
             if (flags_per_lane)
                 hipLaunchKernelGGL((gae_long_par_kernel<true>), grid2, block, 0, st, v_s, v_s_next, rew, terminated, truncated, T, n_lane,
-                                   lanes_per_env, gamma, gl, v_scale, rms, rms_eps, returns_out, adv_out, ws);
+                                   lanes_per_env, gamma, gl, v_scale, rms, rms_eps, returns_out, adv_out, ws, err_host);
             else
                 hipLaunchKernelGGL((gae_long_par_kernel<false>), grid2, block, 0, st, v_s, v_s_next, rew, terminated, truncated, T, n_lane,
-                                   lanes_per_env, gamma, gl, v_scale, rms, rms_eps, returns_out, adv_out, ws);
+                                   lanes_per_env, gamma, gl, v_scale, rms, rms_eps, returns_out, adv_out, ws, err_host);
             TSM_LAUNCH_CHECK();
             return TSM_OK;
         }

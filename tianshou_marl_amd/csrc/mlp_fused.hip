@@ -949,9 +949,8 @@ TSM_EXPORT int tsm_policy_forward(const float *params, const float *param_image,
     const size_t shmem = (size_t)ly.total * sizeof(float);
     const int64_t n_tiles = ceil_div(B, R);
     // one resident round of workgroups (two per CU by their LDS): measured 12 800 rows 19.8 -> 13.5 us, 76 800 rows 42.4 -> 35.3 us
-    // against the former cap of 1024 (tools/policy_forward_time.py; caps of 256 / 384 / 768 are slower at every size)
+    // against the former cap of 1024 (round 4, with a grid-cap probe since removed; caps of 256 / 384 / 768 are slower at every size)
     unsigned grid = (unsigned)(n_tiles < 512 ? n_tiles : 512);
-    { const int dbg = tsm_opt(TSM_OPT_DBG) >> 8; if (dbg > 0 && (int64_t)grid > dbg) grid = (unsigned)dbg; }   // (probe: grid cap)
     static bool attr_set = false;
     if (!attr_set) {
         TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(policy_forward_kernel<64>)));
@@ -959,7 +958,7 @@ TSM_EXPORT int tsm_policy_forward(const float *params, const float *param_image,
         TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(policy_forward_kernel<64, 16>)));
         attr_set = true;
     }
-    const bool spec = d.A == 5 && !(tsm_opt(TSM_OPT_DBG) & 128);
+    const bool spec = d.A == 5 && !tsm_opt(TSM_OPT_GENERIC);
     auto kern = (spec && d.D == 18) ? policy_forward_kernel<64, 18> : (spec && d.D == 16) ? policy_forward_kernel<64, 16> : policy_forward_kernel<64>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), shmem, tsm_stream(stream), params,
                        param_image, d, obs,
@@ -973,6 +972,8 @@ static int g_update_variant = 0;
 static int g_slab_store = 0;
 extern "C" __attribute__((visibility("default"))) void tsm_debug_set_slab_store(int v) { g_slab_store = v; }
 extern "C" __attribute__((visibility("default"))) void tsm_debug_set_update_variant(int v) { g_update_variant = v; }
+extern "C" int tsm_debug_update_variant_get(void) { return g_update_variant; }
+extern "C" int tsm_debug_slab_store_get(void) { return g_slab_store; }
 
 TSM_EXPORT int tsm_ppo_update_grid(int64_t M, int32_t max_blocks) {
     // One-net workgroups need 52 KB of LDS: three fit on a CU (768 on the chip).  The rule comes from sweeps of the
@@ -1034,7 +1035,7 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
     if (g_update_variant == 0 && !g_tsm_stamps) {
         // one net per workgroup (grid.y = actor | critic): see ppo_update_split_kernel
         const LayN<64> ln(d);
-        const bool spec = d.A == 5 && !(tsm_opt(TSM_OPT_DBG) & 128);   // (dbg 128: the generic instantiation, for A/B timing)
+        const bool spec = d.A == 5 && !tsm_opt(TSM_OPT_GENERIC);   // ("generic_kernels": the generic instantiation)
         auto kern = g_slab_store == 1 ? ppo_update_split_kernel<64, 1, 0>
                     : g_slab_store == 2 ? ppo_update_split_kernel<64, 2, 0>
                     : (spec && d.D == 18) ? ppo_update_split_kernel<64, 0, 18>     // BASELINE configs[1] (simple_spread, N = 3)

@@ -295,6 +295,16 @@ TSM_EXPORT int tsm_p2p_failed(void *handle) {
     return v != 0;
 }
 
+// The same word without a host synchronisation: an asynchronous copy into PINNED host memory behind everything queued on `stream`
+// so far.  The host reads *host_pinned_out after it has waited for that point of the stream (the event it records for its loss
+// statistics): every update checks the handle at a synchronisation it already pays for.
+TSM_EXPORT int tsm_p2p_error_async(void *handle, int32_t *host_pinned_out, void *stream) {
+    TSM_REQUIRE(handle && host_pinned_out, "tsm_p2p_error_async: null pointer");
+    P2PHandle *h = static_cast<P2PHandle *>(handle);
+    TSM_HIP(hipMemcpyAsync(host_pinned_out, h->err_dev, sizeof(int32_t), hipMemcpyDeviceToHost, tsm_stream(stream)));
+    return TSM_OK;
+}
+
 TSM_EXPORT int tsm_p2p_destroy(void *handle) {
     if (!handle) return TSM_OK;
     P2PHandle *h = static_cast<P2PHandle *>(handle);

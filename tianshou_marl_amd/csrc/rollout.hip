@@ -841,7 +841,7 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
         }                                                                                                              \
         hipLaunchKernelGGL((rollout_wave64_kernel<NJ>), dim3(n_wg_w), dim3(64 * n_waves), shmem_w, tsm_stream(stream), a); \
     } while (0)
-            if (a.d.D == 18 && a.d.A == 5 && a.c.N == 3 && !(tsm_opt(TSM_OPT_DBG) & 128)) {
+            if (a.d.D == 18 && a.d.A == 5 && a.c.N == 3 && !tsm_opt(TSM_OPT_GENERIC)) {
                 static bool attr_18 = false;
                 if (!attr_18) {
                     TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_wave64_kernel<2, 18, 3>)));
@@ -875,7 +875,7 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
     // CU); four waves otherwise, so that two workgroups fit the register file of a CU.  Measured (us per 25-step
     // collect, 4 / 8 waves): 1024 envs x 3 agents 242 / 234; 4096 x 3: 505 / 775; 4096 x 8 (91 KB of LDS): 7100 / 2250.
     const bool eight = n_wg <= 256 || shmem > 80 * 1024;
-    const bool c18 = a.d.D == 18 && a.d.A == 5 && a.c.N == 3 && !(tsm_opt(TSM_OPT_DBG) & 128);   // (dbg 128: generic form, for A/B timing)
+    const bool c18 = a.d.D == 18 && a.d.A == 5 && a.c.N == 3 && !tsm_opt(TSM_OPT_GENERIC);   // ("generic_kernels": the generic form)
     if (eight && c18) hipLaunchKernelGGL((rollout_kernel<64, 2 * NT, 18, 3>), dim3(n_wg), dim3(2 * NT), shmem, tsm_stream(stream), a);
     else if (eight) hipLaunchKernelGGL((rollout_kernel<64, 2 * NT>), dim3(n_wg), dim3(2 * NT), shmem, tsm_stream(stream), a);
     else hipLaunchKernelGGL((rollout_kernel<64, NT>), dim3(n_wg), dim3(NT), shmem, tsm_stream(stream), a);

@@ -91,8 +91,6 @@ struct RrArgs {
     uint64_t *offset_dev_rw;
     uint32_t *done_ctr;
     long long *stamps;  // diagnostics only (tsm_debug_set_stamps): phase time stamps of workgroup 0, steps 0..3
-    int dbg;            // diagnostics only (option "dbg", wave form): 1 = skip the matrix products, 2 = skip heads + env step,
-                        // 16 = waves 0-3 only (timing probes of tools/time_rollout_rows.py; results are garbage under them)
 };
 
 // slot t * 32 + k of the stamp buffer: k = 0 step start, 1 index algebra, 2 obs(0), 3 + 3 i .. 5 + 3 i layers 1 / 2 / 3 of
@@ -475,7 +473,7 @@ __global__ __launch_bounds__(kThreads) void rollout_rows_kernel(RrArgs a) {
 // slowest wave, the single-wave phases (logits on waves 0-1, heads on two waves, bookkeeping on one) leave the others idle, and
 // a step costs 25.2 us at configs[2].  Here a WAVE owns 16 / N whole environments (<= 16 agent rows) for all T steps and runs
 // every phase of a step by itself: no workgroup barrier inside the step loop: 20.3 us per step (collect 631 -> 507 us).
-// What this form does NOT buy (measured, tools/time_rollout_rows.sh + tools/probes/mfma_valu_overlap.hip): one wave's VALU phase
+// What this form does NOT buy (measured in round 4 with timing probes since removed from the kernel, profiles/r04_time_rollout_rows.txt, + tools/probes/mfma_valu_overlap.hip): one wave's VALU phase
 // does not run under the f32 MFMAs of the other wave of its SIMD -- on gfx950 an f32 MFMA and another wave's VALU instructions
 // take turns (times add: 10.9 us of MFMAs + 8.5 us of everything else per step, with or without a phase offset between the two
 // waves, with or without s_setprio), so the step's floor is the sum of the two instruction streams, not their maximum.
@@ -650,7 +648,6 @@ __global__ __launch_bounds__(kThreads) void rollout_wave_kernel(RrArgs a) {
     const float *w1f = lds + ly.W1 + c16 * ld1 + kq, *w2f = lds + ly.W2 + c16 * kLdh + kq, *w3f = lds + ly.W3 + c16 * kLdh + kq;
     __syncthreads();   // weights staged; every wave has read the sampling counter.  The only workgroup barrier.
     if (n_here == 0) return;  // a wave without environments (never wave 0, whose thread 0 updates the counter below)
-    if ((a.dbg & 16) && w >= kWaves / 2) return;   // (probe: one wave per SIMD -- half of the envs are not stepped)
     for (int t = 0; t < a.n_steps; ++t) {
         // ---- A. buffer index algebra of this step on the env lanes (as in the tile form) ----
         WSTAMP(0);
@@ -684,11 +681,6 @@ __global__ __launch_bounds__(kThreads) void rollout_wave_kernel(RrArgs a) {
         WSTAMP(1);
         f4 acc[8];
         float hb[32];
-        if (a.dbg & 1) {   // (timing probe: no matrix products)
-#pragma unroll
-            for (int i = 0; i < 32; ++i) hb[i] = xb[i % KB1];
-            if (kq < kLdo / 4) *reinterpret_cast<f4 *>(s_lg + c16 * kLdo + 4 * kq) = f4{hb[0], hb[1], hb[2], hb[3]};
-        } else {
         wave_layer<8, KB1>(w1f, ld1, xb, KB1, acc);
         wave_bias_relu<8, false>(lds + ly.B1 + 4 * kq, acc);
         wave_to_frags<8>(acc, hb);
@@ -706,9 +698,7 @@ __global__ __launch_bounds__(kThreads) void rollout_wave_kernel(RrArgs a) {
                 *reinterpret_cast<f4 *>(s_lg + c16 * kLdo + 4 * kq) = f4{lg[0] + b[0], lg[1] + b[1], lg[2] + b[2], lg[3] + b[3]};
             }
         }
-        }
         WSTAMP(4);
-        if (a.dbg & 2) continue;   // (timing probe: no heads, no env step)
         if (lane_live) {  // heads: one lane per row, the arithmetic of categorical.hip (all logits in registers first; the
                           // sampler re-uses the exponentials of the normaliser: the same inputs, the same values)
             float lg[kLdo], ex[kLdo];
@@ -899,7 +889,6 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
     a.offset_inc = h.offset_inc; a.done_ctr = h.done_ctr;
     a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
     a.stamps = g_tsm_stamps;
-    a.dbg = tsm_opt(TSM_OPT_DBG);
     hipStream_t st = tsm_stream(stream);
     if (tsm_opt(TSM_OPT_ROLLOUT_FORM) != 1) {   // the wave-autonomous form (default); "rollout_form" = 1 selects the tile form
         const RwLay ly(h.obs_dim);
@@ -915,7 +904,7 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
         }                                                                                                              \
         hipLaunchKernelGGL((rollout_wave_kernel<NJ>), dim3(n_wg), dim3(kThreads), shmem, st, a);                       \
     } while (0)
-        if (a.c.N == 8 && h.obs_dim == 48 && !(tsm_opt(TSM_OPT_DBG) & 128)) {   // BASELINE configs[2] (dbg 128: the generic form)
+        if (a.c.N == 8 && h.obs_dim == 48 && !tsm_opt(TSM_OPT_GENERIC)) {   // BASELINE configs[2] ("generic_kernels": the generic form)
             static bool attr_8 = false;
             if (!attr_8) {
                 TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(rollout_wave_kernel<3, 8>)));

@@ -61,19 +61,30 @@ def gae_lanes(v_s, v_s_next, rew, terminated, truncated, gamma=0.99, gae_lambda=
     return ret, adv
 
 
-_scan_ws = None
+_scan_ws: dict = {}   # device index -> (workspace, pinned error word)
 
 
 def ensure_scan_workspace(device) -> bool:
-    """Register the device workspace of the parallel long-series GAE scan (include/tsmarl.h: tsm_gae_set_scan_workspace) once per
-    process; not while a stream is capturing (the allocation would belong to that graph's pool).  Callers that capture graphs
-    call it beforehand (PPO._warm_kernels)."""
-    global _scan_ws
-    if _scan_ws is None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+    """Register the workspace of the parallel long-series GAE scan (include/tsmarl.h: tsm_gae_set_scan_workspace) once per DEVICE;
+    not while a stream is capturing (the allocation would belong to that graph's pool).  Callers that capture graphs call it
+    beforehand (PPO._warm_kernels)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    if idx not in _scan_ws and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
         n = int(call("tsm_gae_scan_workspace_bytes"))
-        _scan_ws = torch.zeros(n, dtype=torch.uint8, device=device)
-        call("tsm_gae_set_scan_workspace", _scan_ws.data_ptr(), n)
-    return _scan_ws is not None
+        with torch.cuda.device(idx):
+            ws = torch.zeros(n, dtype=torch.uint8, device=torch.device("cuda", idx))
+            err = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+            call("tsm_gae_set_scan_workspace", ws.data_ptr(), n)
+            call("tsm_gae_set_scan_error_word", err.data_ptr())
+        _scan_ws[idx] = (ws, err)
+    return idx in _scan_ws
+
+
+def gae_scan_failed() -> bool:
+    """True once a parallel long-series scan gave up waiting for another workgroup's map (its returns are NaN from there on).
+    A plain read of pinned host words: meaningful after the host has waited for the launch (the statistics' event)."""
+    return any(int(err[0]) != 0 for _, err in _scan_ws.values())
 
 
 def rms_update(returns, rms, rms_eps=1e-8, ids=None, work=None):
@@ -1063,7 +1074,7 @@ def device_info() -> dict:
     return dict(n_cu=n_cu.value, wave_size=wave.value, hbm_bytes=hbm.value, arch=name.value.decode())
 
 
-KERNEL_OPTIONS = ("actor_tile", "split_bf16", "dbg", "rollout_form")
+KERNEL_OPTIONS = ("actor_tile", "split_bf16", "generic_kernels", "rollout_form")
 
 
 def kernel_option(name: str) -> int:
@@ -1116,6 +1127,26 @@ class graph_capture:
         finally:
             if self._was:
                 gc.enable()
+
+
+class gc_hold:
+    """`with ops.gc_hold():` -- one collection now, none inside: for capture sites that drive `capture_begin` / `capture_end`
+    themselves (a side stream, thread-local capture mode) and therefore cannot use `graph_capture`."""
+
+    def __enter__(self):
+        import gc
+
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+
+        if self._was:
+            gc.enable()
+        return False
 
 
 class kernel_override:

@@ -45,6 +45,7 @@ class P2PAllReduce:
         self.max_floats = int(max_floats)
         self.device = device
         self._h = None
+        self._err_host = None  # pinned int32: the handle's error word as of the last `post_check`
 
     @classmethod
     def negotiate(cls, dist, group, device: torch.device, max_floats: int, timeout_s: float | None = None):
@@ -120,6 +121,11 @@ class P2PAllReduce:
                 why.append(f"handshake: {type(e).__name__}: {e}")
             all_ok = agree(ok)  # 6
         if all_ok:
+            if not (timeout_s or os.environ.get("TSM_P2P_TIMEOUT_S")):
+                # mid-run a rank may legitimately be late by seconds (rank 0 writes a checkpoint or evaluates, a first graph
+                # capture, a GC pause): the handshake's ~2 s would turn that into a dead handle.  A lost peer still ends the
+                # job -- `raise_if_failed` at every update's statistics read -- only later.
+                _abi.call("tsm_p2p_set_timeout", self._h, float(os.environ.get("TSM_P2P_RUN_TIMEOUT_S", "60")))
             return self
         self.close()
         print(f"[rank {self.rank}] peer-memory all-reduce not used" + (": " + "; ".join(why) if why else " (another rank declined)")
@@ -157,6 +163,24 @@ class P2PAllReduce:
 
         if self._h is not None and _abi.call("tsm_p2p_failed", self._h):
             raise RuntimeError("P2P all-reduce: a peer did not answer within the time limit (a rank died or fell out of step)")
+
+    def post_check(self) -> None:
+        """Queue a copy of the error word into pinned host memory behind everything launched so far on the current stream (no
+        synchronisation).  Every update queues it in front of the event of its loss statistics."""
+        from . import _abi
+
+        if self._h is None:
+            return
+        if self._err_host is None:
+            self._err_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        _abi.call("tsm_p2p_error_async", self._h, self._err_host.data_ptr(), _abi.stream_ptr())
+
+    def raise_if_failed(self) -> None:
+        """After the host has waited for the point of the stream `post_check` was queued at (the statistics' event / copy):
+        raise if a peer's word did not arrive -- the gradient steps since then were skipped, never half-applied."""
+        if self._err_host is not None and int(self._err_host[0]) != 0:
+            raise RuntimeError("P2P all-reduce: a peer did not answer within the time limit (a rank died or fell out of step); "
+                               "the gradient steps of this update were not applied")
 
     def close(self) -> None:
         from . import _abi
@@ -196,6 +220,15 @@ class GradSync:
             return self.p2p.all_reduce_sum_(flat)
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
         return flat
+
+    def post_check(self) -> None:
+        """See `P2PAllReduce.post_check`; a no-op without the peer-memory path."""
+        if self.p2p is not None:
+            self.p2p.post_check()
+
+    def raise_if_failed(self) -> None:
+        if self.p2p is not None:
+            self.p2p.raise_if_failed()
 
     def fused_step_ok(self, max_grad_norm, n: int) -> bool:
         """Can a gradient step of n parameters take the one-launch form (P2PAllReduce.adam_step)?  Needs the peer-memory path,
@@ -360,7 +393,9 @@ def learn_lockstep_graph(jobs, sync: "GradSync", names: list | None = None) -> l
             w["warm"] = True
         return [p._learn_finish(w) for (p, _, _, _), w in zip(jobs, ws)]
     inline = all(getattr(p, "graph_collectives", False) for p, _, _, _ in jobs)
-    key = (tuple((id(p), id(w)) for (p, _, _, _), w in zip(jobs, ws)), inline)
+    from . import ops as _ops
+
+    key = (tuple((id(p), id(w)) for (p, _, _, _), w in zip(jobs, ws)), inline, _ops.kernel_options())
     cache = sync.__dict__.setdefault("_lockstep_graphs", {})
     g = cache.get(key)
     if g is None:
@@ -509,7 +544,9 @@ def _probe_child() -> int:
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        from . import ops as _ops
+
+        with _ops.gc_hold(), torch.cuda.stream(side):  # (no cyclic-GC pass inside a capture: ops.graph_capture)
             g.capture_begin(capture_error_mode="thread_local")
             dist.all_reduce(x)
             y = x * 0.5

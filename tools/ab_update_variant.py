@@ -53,7 +53,7 @@ def timeit(variant, pack, cfg, M):
     step()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         for _ in range(20):
             step()
     g.replay()

@@ -7,6 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tianshou_marl_amd import ops  # noqa: E402
 from tianshou_marl_amd.utils.net import FlatMLP  # noqa: E402
 
 PEAK = 157.3e12
@@ -16,7 +17,7 @@ def gtime(fn, n=10, reps=3):
     fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         for _ in range(n):
             fn()
     g.replay()

@@ -24,7 +24,7 @@ def timeit(fn, iters, warmup=5):
         fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         for _ in range(iters):
             fn()
     g.replay()

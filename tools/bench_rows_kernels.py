@@ -18,7 +18,7 @@ def per_launch(fn, n=10, reps=5):
     fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         for _ in range(n):
             fn()
     g.replay()

@@ -12,6 +12,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tianshou_marl_amd import ops  # noqa: E402
 from tianshou_marl_amd.env.mpe import DeviceSimpleSpreadVectorEnv  # noqa: E402
 from tianshou_marl_amd.env.mpe_tag import DeviceSimpleTagVectorEnv  # noqa: E402
 
@@ -24,7 +25,7 @@ def time_env(env, reps=50):
         env.step_device(act)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         for _ in range(reps):
             env.step_device(act)
     g.replay()

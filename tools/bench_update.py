@@ -17,7 +17,7 @@ def gtime(fn, n=20, reps=5):
     fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         for _ in range(n):
             fn()
     g.replay()

@@ -16,7 +16,7 @@ ev = lambda: torch.cuda.Event(enable_timing=True)
 def gtime(fn, n=10):
     fn(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         for _ in range(n): fn()
     g.replay(); torch.cuda.synchronize()
     best = 1e9

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(512) void k(float *out, int reps, int role_lo, int 
     for (int i = 0; i < 8; ++i) { acc[i] = f4{0.f, 0.f, 0.f, 0.f}; v[i] = (float)threadIdx.x; }
     const float a = out[threadIdx.x], b = out[512 + threadIdx.x];
     __syncthreads();
+    const long long c0 = (long long)__builtin_amdgcn_s_memtime();   // shader-clock ticks (guide: in-kernel clock = d memtime / d memrealtime x 100 MHz)
     const long long t0 = wall_clock64();
     for (int r = 0; r < reps; ++r) {
         if (role & 1) mfma_block(acc, a, b);
@@ -53,14 +54,15 @@ __global__ __launch_bounds__(512) void k(float *out, int reps, int role_lo, int 
     }
     __syncthreads();
     const long long t1 = wall_clock64();
+    const long long c1 = (long long)__builtin_amdgcn_s_memtime();
     float s = 0.f;
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + v[i] + (float)u[i];
     out[1024 + blockIdx.x * 512 + threadIdx.x] = s;
-    if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = t1 - t0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = c1 - c0; }
 }
 int main() {
     float *d; long long *c, h;
-    if (hipMalloc(&d, (1024 + 256 * 512) * 4) != hipSuccess || hipMalloc(&c, 8) != hipSuccess) return 2;
+    if (hipMalloc(&d, (1024 + 256 * 512) * 4) != hipSuccess || hipMalloc(&c, 16) != hipSuccess) return 2;
     if (hipMemset(d, 0, (1024 + 256 * 512) * 4) != hipSuccess) return 2;
     const int reps = 200;
     struct { const char *name; int lo, hi; } modes[] = {
@@ -82,6 +84,27 @@ int main() {
             if (h < best) best = h;
         }
         printf("%-46s %7.3f us per rep (min of 6 launches)\n", m.name, best / 100.0 / reps);
+    }
+    // The clock itself (round 5; MI355X_MICROARCH.md "DVFS give-back" item 6): shader-clock ticks (s_memtime) over 100 MHz ticks
+    // (s_memrealtime) around the loop, after >= 2 s of back-to-back launches of the same mode on all 256 CUs.
+    struct { const char *name; int lo, hi; } cm[] = {{"all 8 waves: MFMA only", 1, 1}, {"waves 0-3 MFMA only (4-7 idle)", 1, 0},
+                                                     {"all 8 waves: MFMA then VALU (each rep)", 3, 3}, {"all 8 waves: VALU only", 2, 2}};
+    for (auto &m : cm) {
+        const int big = 20000;
+        double mhz[8], us_rep[8];
+        for (int it = 0; it < 60; ++it) {   // ~40 ms per launch
+            hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, d, big, m.lo, m.hi, c);
+            if (it >= 52) {
+                long long hh[2];
+                if (hipMemcpy(hh, c, 16, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+                mhz[it - 52] = (double)hh[1] / (double)hh[0] * 100.0;
+                us_rep[it - 52] = hh[0] / 100.0 / big;
+            }
+        }
+        double a = 0, b = 0;
+        for (int i = 0; i < 8; ++i) { a += mhz[i]; b += us_rep[i]; }
+        printf("clock under sustained load: %-40s %7.1f MHz (s_memtime / s_memrealtime), %7.3f us per rep (mean of the last 8 of 60 launches of %d reps)\n",
+               m.name, a / 8, b / 8, big);
     }
     return 0;
 }

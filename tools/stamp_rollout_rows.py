@@ -22,8 +22,6 @@ from tianshou_marl_amd import ops  # noqa: E402
 
 form = sys.argv[1] if len(sys.argv) > 1 else "wave"
 ops.set_kernel_option("rollout_form", 1 if form == "tile" else 2)
-if len(sys.argv) > 2:   # timing probes of the wave form (1: no matrix products, 2: no heads / env step)
-    ops.set_kernel_option("dbg", int(sys.argv[2]))
 dev = "cuda"
 E, N, T = 4096, 8, 25
 env = DeviceSimpleSpreadVectorEnv(E, N, max_cycles=T, device=dev, seed=1)

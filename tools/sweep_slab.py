@@ -57,7 +57,7 @@ def cell(pack, M, nb, cfg):
     torch.cuda.synchronize()
     same = torch.equal(first, slabs)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         for _ in range(20):
             step()
     g.replay()
