@@ -229,6 +229,33 @@ def phase_times(a, algo, buf, col, reps=5):
     return t_col / reps, t_upd / reps
 
 
+def batch64_update(a, algo, buf, col, reps: int = 3) -> dict:
+    """`PPO.update` at the REFERENCE's own defaults (trainer.py:287,295, ppo.py:25-36: batch_size 64, repeat 1) on the rows of one
+    collect of this job -- 400 gradient steps of 64 rows per agent, 1 200 per update at the default size -- outside the timed region:
+    the GPU counterpart of `cpu_baseline.update_reference_default_batch64`.  Device time by HIP events around
+    the update (one hipGraph replay after the first, capturing call)."""
+    from tianshou_marl_amd.algorithm.ppo import policy_within_training_step
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    times, steps = [], None
+    with policy_within_training_step(algo):
+        for k in range(reps + 1):
+            col.collect(n_step=a.n_env * a.horizon)
+            e0, e1 = ev(), ev()
+            e0.record()
+            ts = algo.update(buf, 64, 1)
+            e1.record()
+            torch.cuda.synchronize()
+            _resolve(ts)
+            col.reset_buffer(keep_statistics=True)
+            if k:  # (call 0 captures the graph)
+                times.append(e0.elapsed_time(e1))
+            steps = getattr(ts, "gradient_steps", None) or sum(s_.gradient_steps for s_ in getattr(ts, "_agent_id_to_stats", {}).values())
+    return {"ms": float(np.median(times)), "ms_all": [round(t, 3) for t in times], "gradient_steps": int(steps), "batch_size": 64,
+            "repeat": 1, "rows": a.n_env * a.horizon * a.n_agent, "us_per_gradient_step": float(np.median(times)) * 1e3 / max(int(steps), 1),
+            "timing": "HIP events around PPO.update (hipGraph replay), outside the timed region"}
+
+
 def loss_grid_threads(M: int) -> int:
     """Grid of loss_kernel for M samples (csrc/ppo_loss.hip loss_blocks): 256-sample tiles, at most 2048 workgroups, every
     workgroup the same number of tiles."""
@@ -1130,6 +1157,8 @@ def _main():
         }
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
+        if world == 1 and not a.no_batch64:
+            out["update_reference_default_batch64"] = batch64_update(a, algo, buf, col)
         out.update(kernel_rooflines(a, algo, buf))
         if world == 1 and not a.no_c3_grid:
             del algo, buf, col, env  # (free the headline job's graphs before the 4096-env job is built)

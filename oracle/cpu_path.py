@@ -37,6 +37,64 @@ def _mlp(d_in, h, d_out):
     return net
 
 
+class PortStores:
+    """The row stores of the port: one row per joint step, flat reference index = env * S + slot (manager.py:38-46)."""
+
+    def __init__(self, n_env: int, slots: int, n_agent: int, obs_shape: tuple) -> None:
+        rows = n_env * slots
+        self.obs = np.zeros((rows, n_agent, *obs_shape), np.float32)
+        self.obs_next = np.zeros_like(self.obs)
+        self.act = np.zeros((rows, n_agent), np.int64)
+        self.rew = np.zeros((rows, n_agent), np.float64)
+        self.term = np.zeros((rows, n_agent), bool)
+        self.trunc = np.zeros((rows, n_agent), bool)
+        self.index = oracle.VectorReplayBufferIndex(rows, n_env, n_agent)
+
+
+class PortCollector:
+    """`Collector._collect` for `collect(n_step=...)` with every env ready (collector.py:854-1069), as `run_baseline` times it:
+    envs are objects with `reset() -> obs [N, ...]` and `step(act [N]) -> (obs, rew [N], terminated [N], truncated [N])`, stepped
+    one after the other and stacked (DummyVectorEnv, venvs.py:281-322).  Pinned to the REFERENCE's own Collector +
+    VectorReplayBuffer by tests/test_oracle_golden.py::test_cpu_port_collect_leg_matches_the_reference_collector
+    (tests/golden/collector_port.npz: rows, lengths, returns and counters of three n_step calls)."""
+
+    def __init__(self, envs: list, stores: PortStores) -> None:
+        self.envs, self.st = envs, stores
+        self.last_obs = np.stack([e.reset() for e in envs]).astype(np.float32)
+        self.collect_step = self.collect_episode = 0
+
+    def collect(self, act_fn, n_step: int) -> dict:
+        """Steps the envs until at least n_step transitions are stored (a multiple of the env count, collector.py:1046-1051);
+        returns the statistics of this call in the reference's episode order (by vector step, then by env id)."""
+        st, envs = self.st, self.envs
+        n_env = len(envs)
+        sub = st.obs.shape[0] // n_env
+        steps, lens, rets = 0, [], []
+        while steps < n_step:
+            act = act_fn(self.last_obs)
+            res = [envs[i].step(act[i]) for i in range(n_env)]            # venvs.py:281-287
+            obs_next = np.stack([r[0] for r in res]).astype(np.float32)   # venvs.py:311-322
+            rew = np.stack([r[1] for r in res])
+            term = np.stack([r[2] for r in res])
+            trunc = np.stack([r[3] for r in res])
+            done = (term | trunc).any(1)
+            ptr, ep_rew, _, ep_idx = st.index.add(rew, done)
+            st.obs[ptr], st.obs_next[ptr], st.act[ptr] = self.last_obs, obs_next, act
+            st.rew[ptr], st.term[ptr], st.trunc[ptr] = rew, term, trunc
+            steps += n_env
+            self.last_obs = obs_next.copy()
+            for i in np.where(done)[0]:
+                # CollectStats.lens is len(episode_batch), the episode's rows IN THE BUFFER (collector.py:203,990-993): an episode
+                # that began before a reset_buffer(keep_statistics=True) counts its rows since the reset, its return is whole
+                lens.append(int((ptr[i] - ep_idx[i]) % sub + 1))
+                rets.append(np.asarray(ep_rew[i], np.float64).copy())
+                self.last_obs[i] = envs[i].reset()
+        self.collect_step += steps
+        self.collect_episode += len(lens)
+        return {"n_collected_steps": steps, "n_collected_episodes": len(lens), "lens": np.asarray(lens, np.int64),
+                "returns": np.asarray(rets, np.float64)}
+
+
 def run_baseline(n_env=64, n_agent=3, horizon=25, minibatch=4096, repeat=1, dispatch="per_agent", budget_s=15.0,
                  seed=1626, ref_default_leg=False):
     torch.manual_seed(seed)
@@ -47,38 +105,23 @@ def run_baseline(n_env=64, n_agent=3, horizon=25, minibatch=4096, repeat=1, disp
     actor, critic = _mlp(D, 64, A), _mlp(D, 64, 1)
     opt = torch.optim.Adam(list(actor.parameters()) + list(critic.parameters()), lr=3e-4)
     S = T
-    obs_buf = np.zeros((n_env * S, N, D), np.float32)
-    obs_next_buf = np.zeros_like(obs_buf)
-    act_buf = np.zeros((n_env * S, N), np.int64)
-    rew_buf = np.zeros((n_env * S, N), np.float64)
-    term_buf = np.zeros((n_env * S, N), bool)
-    trunc_buf = np.zeros((n_env * S, N), bool)
-    index = oracle.VectorReplayBufferIndex(n_env * S, n_env, N)
-    last_obs = np.stack([e.reset() for e in envs]).astype(np.float32)
+    st = PortStores(n_env, S, N, (D,))
+    obs_buf, obs_next_buf, act_buf = st.obs, st.obs_next, st.act
+    rew_buf, term_buf, trunc_buf, index = st.rew, st.term, st.trunc, st.index
+    col = PortCollector(envs, st)
+
+    def act_fn(obs):
+        with torch.no_grad():
+            logits = actor(torch.from_numpy(obs.reshape(n_env * N, D)))
+            return torch.distributions.Categorical(logits=logits).sample().numpy().reshape(n_env, N)
 
     def one_step(minibatch=minibatch, dispatch=dispatch, collect=True):
-        nonlocal last_obs
         if not collect:  # update only, on the rows of the last collect (the reference-default leg below)
             t_c1 = time.perf_counter()
             return (0.0, *update(minibatch, dispatch, t_c1)[1:])
         t_c0 = time.perf_counter()
         index.reset(keep_statistics=True)
-        for _ in range(T):
-            with torch.no_grad():
-                logits = actor(torch.from_numpy(last_obs.reshape(n_env * N, D)))
-                act = torch.distributions.Categorical(logits=logits).sample().numpy().reshape(n_env, N)
-            res = [envs[i].step(act[i]) for i in range(n_env)]            # venvs.py:281-287
-            obs_next = np.stack([r[0] for r in res]).astype(np.float32)   # venvs.py:311-322
-            rew = np.stack([r[1] for r in res])
-            term = np.stack([r[2] for r in res])
-            trunc = np.stack([r[3] for r in res])
-            done = (term | trunc).any(1)
-            ptr, _, _, _ = index.add(rew, done)
-            obs_buf[ptr], obs_next_buf[ptr], act_buf[ptr] = last_obs, obs_next, act
-            rew_buf[ptr], term_buf[ptr], trunc_buf[ptr] = rew, term, trunc
-            last_obs = obs_next.copy()
-            for i in np.where(done)[0]:
-                last_obs[i] = envs[i].reset()
+        col.collect(act_fn, n_env * T)
         t_c1 = time.perf_counter()
         return (t_c1 - t_c0, *update(minibatch, dispatch, t_c1)[1:])
 

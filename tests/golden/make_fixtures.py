@@ -26,6 +26,8 @@ Each fixture holds inputs + the reference's outputs for one hot-path function
   async_collector.npz  AsyncCollector over an async vector env with scripted readiness: statistics, ready sets, buffer rows  [(f)4]
   collector.npz    the synchronous Collector through ten scripted collect / reset calls (truncating envs, surplus-env removal,
                    reset_before_collect / reset_buffer / reset_stat): statistics, counters, next observations, buffer rows   [a4]
+  collector_port.npz  the Collector in the one mode the CPU baseline port restates (oracle/cpu_path.py::PortCollector: n_step calls,
+                   reset_buffer(keep_statistics=True) between them): statistics and every buffer row per call   [a4, SURVEY 8d(iv)]
   trainers.npz     the training coordinators as a trace under seeded numpy randomness: who learns, which snapshot is sampled,
                    every Elo / performance / win rate, promotion and relegation lists   [a17]
   misc.npz         Batch.split bounds, RunningMeanStd, episode_mc_return_to_go   [a11, a14]
@@ -802,6 +804,63 @@ def make_collector() -> None:
     save("collector.npz", **out)
 
 
+def make_collector_port() -> None:
+    """The synchronous Collector + VectorReplayBuffer in the ONE mode bench.py's CPU baseline port restates
+    (oracle/cpu_path.py::PortCollector: collect(n_step) with every env ready, reset_buffer(keep_statistics=True) between calls as
+    the trainer does, trainer.py:1104): the truncating MoveToRight envs and the scripted policy of collector_script.py, three
+    n_step calls.  After each call: the statistics and every buffer row in sample_indices(0) order."""
+    from collector_script import LIMITS, SIZES, env_step, scripted_action
+    from tianshou.data import Collector
+    from tianshou.env import DummyVectorEnv
+
+    class MoveToRight(gym.Env):
+        def __init__(self, size, limit):
+            self.size, self.limit, self.index, self.steps = size, limit, 0, 0
+            self.action_space = gym.spaces.Discrete(2)
+            self.observation_space = gym.spaces.Box(0, size, (1,))
+
+        def reset(self, seed=None, options=None):
+            self.index, self.steps = 0, 0
+            return np.array([self.index], np.float32), {}
+
+        def step(self, action):
+            self.index, self.steps, rew, term, trunc = env_step(self.index, self.steps, self.size, self.limit, action)
+            return np.array([self.index], np.float32), rew, term, trunc, {}
+
+    class ScriptPolicy(Policy):
+        def __init__(self):
+            super().__init__(action_space=gym.spaces.Discrete(2))
+            self.calls = 0
+
+        def forward(self, batch, state=None, **kw):
+            self.calls += 1
+            return Batch(act=scripted_action(self.calls, np.asarray(batch.obs)))
+
+    venv = DummyVectorEnv([lambda s=s, l=l: MoveToRight(s, l) for s, l in zip(SIZES, LIMITS)])
+    pol = ScriptPolicy()
+    import warnings
+
+    out = dict(sizes=np.array(SIZES), limits=np.array(LIMITS), n_steps=np.array([10, 15, 20]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        col = Collector(pol, venv, VectorReplayBuffer(total_size=len(SIZES) * 8, buffer_num=len(SIZES)))
+        col.reset()
+        for i, n in enumerate(out["n_steps"]):
+            if i:
+                col.reset_buffer(keep_statistics=True)
+            st = col.collect(n_step=int(n))
+            buf = col.buffer
+            idx = buf.sample_indices(0)
+            b = buf[idx]
+            out.update({f"c{i}_steps": np.int64(st.n_collected_steps), f"c{i}_episodes": np.int64(st.n_collected_episodes),
+                        f"c{i}_lens": np.asarray(st.lens, np.int64), f"c{i}_returns": np.asarray(st.returns, np.float64),
+                        f"c{i}_counters": np.array([col.collect_step, col.collect_episode, pol.calls], np.int64),
+                        f"c{i}_indices": idx, f"c{i}_obs": np.asarray(b.obs), f"c{i}_obs_next": np.asarray(b.obs_next),
+                        f"c{i}_act": np.asarray(b.act), f"c{i}_rew": np.asarray(b.rew),
+                        f"c{i}_terminated": np.asarray(b.terminated), f"c{i}_truncated": np.asarray(b.truncated)})
+    save("collector_port.npz", **out)
+
+
 def make_trainers() -> None:
     """The training coordinators (training_coordinator.py:27-760) as a TRACE: mock policies that count `learn` calls, seeded numpy
     randomness.  SimultaneousTrainer with per-agent frequencies, SequentialTrainer with a custom order, SelfPlayTrainer (snapshot
@@ -927,6 +986,6 @@ def make_misc() -> None:
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gae", "vrb_trace", "ppo_update", "ppo_update_wide", "pg_update", "marl_dispatch", "ctde", "ctde_wide",
-                             "ctde_c3", "async_collector", "collector", "trainers", "misc"]
+                             "ctde_c3", "async_collector", "collector", "collector_port", "trainers", "misc"]
     for w in which:
         globals()["make_" + w]()

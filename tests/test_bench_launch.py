@@ -50,6 +50,49 @@ def test_single_gpu_workloads_refuse_more_ranks():
     assert r.returncode != 0 and "single-GPU job" in r.stderr
 
 
+@pytest.mark.parametrize("var,val", [("TSM_DBG", "1"), ("TSM_GENERIC_KERNELS", "1"), ("TSM_ACTOR_TILE", "64"), ("TSM_ROLLOUT_FORM", "1"),
+                                     ("TSM_SPLIT_BF16", "1"), ("TSM_UPDATE_MAX_BLOCKS", "128")])
+def test_bench_refuses_kernel_selection_switches_before_touching_the_gpu(var, val):
+    """a measurement must prove its configuration.  With any kernel-selection / diagnostics switch set in the
+    environment bench.py exits non-zero BEFORE anything touches the GPU (here: a host without one -- the message is the refusal, not
+    "needs a GPU") and prints no JSON line; `--allow-options` lifts the refusal (and the run then goes on to need a GPU)."""
+    r = _run(["--steps", "1", "--warmup", "0"], {var: val})
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "refusing to run with " + var in r.stderr and "needs a GPU" not in r.stderr
+    if _no_gpu():
+        r = _run(["--steps", "1", "--warmup", "0", "--allow-options"], {var: val})
+        assert r.returncode != 0 and "refusing" not in r.stderr and "needs a GPU" in r.stderr
+
+
+def test_bench_reads_its_kernel_configuration_from_the_library():
+    """`config.kernel_options` of the line: run-time options, the debug switches of csrc/mlp_fused.hip and the stamps hook, read from
+    the library's host state (no device call).  Defaults -> "default": true; an option set at run time -> refused unless allowed."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from tianshou_marl_amd import ops
+
+    cfg = bench.kernel_configuration()
+    assert cfg["default"] is True and cfg["stamps_armed"] is False and cfg["update_variant"] == 0 and cfg["slab_store"] == 0
+    assert set(ops.KERNEL_OPTIONS) <= set(cfg)
+
+    class A:
+        allow_options = False
+
+    out = {}
+    bench.guard_configuration(A, out)
+    assert out["config"]["kernel_options"]["default"] is True and "diagnostic" not in out
+    with ops.kernel_override(generic_kernels=1):
+        with pytest.raises(SystemExit):
+            bench.guard_configuration(A, {})
+        A.allow_options = True
+        out = {}
+        bench.guard_configuration(A, out)
+        assert out["diagnostic"] is True and out["config"]["kernel_options"]["generic_kernels"] == 1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,p2p", [("c2", "0"), ("tag", "0"), ("c2", "1"), ("tag", "1"), ("c2", "auto")])
 def test_bench_gpus_2_runs_two_ranks_and_counts_them(workload, p2p):

@@ -352,6 +352,67 @@ def test_collector_known_answer_layout_of_the_reference():
         Collector(MaxActionPolicy(), venv, DeviceVectorReplayBuffer(9, 3, n_agent=1, obs_dim=1, device=DEV))
 
 
+def test_collector_lens_count_the_rows_in_the_buffer_as_the_reference_does(golden_dir):
+    """`CollectStats.lens` is `len(episode_batch)` in the reference (collector.py:203,990-993): the episode's rows IN THE BUFFER.
+    Behind `reset_buffer(keep_statistics=True)` -- what the trainer calls after every update (trainer.py:1104) -- an episode that
+    was running counts its rows since the reset while its return stays whole.  The REFERENCE's own run (collector_port.npz:
+    three collect(n_step) calls on the truncating MoveToRight envs with that reset in between) replayed by the host path of
+    `Collector`: statistics, counters and every buffer row after each call.  (The CPU baseline port is pinned to the same
+    fixture: tests/test_oracle_golden.py.)"""
+    import sys
+
+    sys.path.insert(0, golden_dir)
+    from collector_script import env_step, scripted_action
+
+    g = np.load(os.path.join(golden_dir, "collector_port.npz"))
+
+    class Env:
+        def __init__(self, size, limit):
+            self.size, self.limit, self.index, self.steps = size, limit, 0, 0
+            self.action_space, self.observation_space = Discrete(2), Box(0, size, (1,))
+
+        def reset(self, seed=None, **kw):
+            self.index, self.steps = 0, 0
+            return np.array([self.index], np.float32), {}
+
+        def step(self, action):
+            self.index, self.steps, rew, term, trunc = env_step(self.index, self.steps, self.size, self.limit, action)
+            return np.array([self.index], np.float32), rew, term, trunc, {}
+
+        def close(self):
+            pass
+
+    class ScriptPolicy(torch.nn.Module):
+        calls = 0
+
+        def forward(self, batch, state=None, **kw):
+            self.calls += 1
+            return Batch(act=scripted_action(self.calls, np.asarray(batch.obs)))
+
+    n_env = len(g["sizes"])
+    venv = DummyVectorEnv([lambda s=int(s), l=int(l): Env(s, l) for s, l in zip(g["sizes"], g["limits"])])
+    buf = DeviceVectorReplayBuffer(n_env * 8, n_env, n_agent=1, obs_dim=1, device=DEV)
+    pol = ScriptPolicy()
+    col = Collector(pol, venv, buf)
+    col.reset()
+    straddled = 0
+    for i, n in enumerate(g["n_steps"]):
+        if i:
+            col.reset_buffer(keep_statistics=True)
+        st = col.collect(n_step=int(n))
+        assert (st.n_collected_steps, st.n_collected_episodes) == (int(g[f"c{i}_steps"]), int(g[f"c{i}_episodes"])), i
+        assert np.array_equal(st.lens, g[f"c{i}_lens"]) and np.array_equal(st.returns, g[f"c{i}_returns"]), i
+        assert [col.collect_step, col.collect_episode, pol.calls] == g[f"c{i}_counters"].tolist(), i
+        idx = buf.sample_indices(0)
+        assert np.array_equal(idx, g[f"c{i}_indices"]), i
+        b = buf[idx]
+        assert np.array_equal(b.obs[:, 0, 0], g[f"c{i}_obs"][:, 0]) and np.array_equal(b.obs_next[:, 0, 0], g[f"c{i}_obs_next"][:, 0]), i
+        assert np.array_equal(b.act[:, 0], g[f"c{i}_act"]) and np.array_equal(b.rew[:, 0], g[f"c{i}_rew"]), i
+        assert np.array_equal(b.terminated[:, 0], g[f"c{i}_terminated"]) and np.array_equal(b.truncated[:, 0], g[f"c{i}_truncated"]), i
+        straddled += int((g[f"c{i}_lens"] == 1).sum())
+    assert straddled >= 2   # (episodes of one buffered row exist only because of the reset: MoveToRight needs >= 2 steps)
+
+
 def test_collector_replays_the_reference_run(golden_dir):
     """The synchronous `Collector` (collector.py:770-1098) against the REFERENCE's own run (tests/golden/collector.npz, made by
     make_fixtures.py::make_collector): five MoveToRight envs, two of them truncated by a step limit, a policy whose actions and

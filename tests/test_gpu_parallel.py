@@ -575,6 +575,29 @@ def _p2p_fail_worker(rank: int, world: int, port: int, out_dir: str) -> None:
             assert time.time() - t0 < 0.25 and torch.equal(x, torch.ones(n, device=DEV)) and torch.equal(P, P0)
         dist.barrier()
         p2p.close()
+        # (d) ADVICE r4 (high): the same loss of a peer seen from the PRODUCT -- rank 1 stops after the collect, rank 0 calls
+        # PPO.update: its gradient steps time out inside the fused kernels (nothing is half-applied), and the update RAISES where
+        # it reads its loss statistics -- nobody has to call p2p.check()
+        env = DeviceSimpleSpreadVectorEnv(16, 3, device=DEV, seed=50 + rank)
+        bufr = DeviceVectorReplayBuffer(16 * 25, 16, 3, D, device=DEV)
+        algo = PPO(net=DiscreteActorCritic(D, A, H, device=DEV, seed=20 + rank), lr=1e-3, dispatch="pooled", shuffle="device", seed=7,
+                   use_graph=False)
+        sync = attach_data_parallel(algo, dist, global_adv_stats=False)
+        assert sync.p2p is not None and sync.fused_step_ok(None, algo.net.flat.numel())
+        col = Collector(algo, env, bufr)
+        col.reset()
+        with policy_within_training_step(algo):
+            col.collect(n_step=16 * 25)
+            torch.cuda.synchronize()
+            dist.barrier()
+            if rank == 0:
+                before = algo.net.flat.data.clone()
+                with pytest.raises(RuntimeError, match="did not answer"):
+                    algo.update(bufr, 256, 1)        # 4 gradient steps; rank 1 takes none of them
+                assert torch.equal(algo.net.flat.data, before)   # fail-stop: no step was applied
+            else:
+                sync.require_equal(4, "the number of gradient steps per update")  # (the one host collective of an eager update)
+        dist.barrier()
         open(os.path.join(out_dir, f"ok{rank}"), "w").close()
     except BaseException:
         import traceback

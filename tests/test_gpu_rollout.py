@@ -74,6 +74,28 @@ def test_fused_rollout_is_bit_identical_to_unfused(n_env, N, T, steps, form):
             assert a[k] == b[k], k
 
 
+@pytest.mark.parametrize("path", ["fused", "graph", "eager"])
+def test_lens_behind_a_statistics_keeping_buffer_reset_count_buffered_rows(path):
+    """collector.py:203: `lens` = the episode's rows in the buffer.  Episodes of 7 steps, collects of 5 vector steps with
+    `reset_buffer(keep_statistics=True)` in between (the trainer's sequence): the episodes that end in the second collect have 2 rows
+    in the buffer and their WHOLE return -- on the persistent rollout (compact episode record), the captured three-launch loop and
+    the eager one (dense per-step arrays) alike.  (The host path meets the reference's own run: test_gpu_marl.py.)"""
+    env, net, algo, buf, col = _job(64, 3, 7, path == "fused", slots=8)
+    col.use_graph = path == "graph"
+    outs = []
+    with policy_within_training_step(algo):
+        for k in range(4):   # (the graph path captures on its second call of a shape)
+            st = col.collect(n_step=64 * 5)
+            outs.append((np.asarray(st.lens).copy(), np.asarray(st.returns).copy(), buf.rew_store[:5].clone()))
+            col.reset_buffer(keep_statistics=True)
+    assert len(outs[0][0]) == 0                                   # 5 steps: no episode has ended
+    assert np.array_equal(outs[1][0], np.full(64, 2))             # ends at step 7 = row 2 of the second collect; 7 - 5 rows buffered
+    assert np.array_equal(outs[2][0], np.full(64, 4))             # next episode: steps 8..14, rows 3..5 of collect 2 are gone: 4 rows
+    # ... while the return is the whole episode's: rows 0..4 of the first collect + rows 0..1 of the second
+    want = (outs[0][2].double().sum(0) + outs[1][2][:2].double().sum(0)).cpu().numpy()
+    np.testing.assert_allclose(outs[1][1], want, rtol=1e-12)
+
+
 def test_update_from_stored_rollout_outputs_equals_recomputed():
     """PPO.update fed by the rollout kernel's stored logp / v_s / V(obs_next) == update that recomputes them."""
     res = []

@@ -213,7 +213,9 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             const int64_t elen = v_eplen + 1;
             if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
             rec = tr && a.ep_rec && n_fin < a.max_ep;
-            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | elen;
+            // (the record carries CollectStats.lens = len(episode_batch): the episode's rows IN THE BUFFER, collector.py:203,990-993 --
+            //  after a reset_buffer(keep_statistics=True) an episode counts its rows since the reset; ep_len_out stays add()'s ep_len)
+            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | ((cur >= v_epstart ? cur - v_epstart : cur - v_epstart + a.S) + 1);
             a.ep_len_out[o] = tr ? elen : 0;
             a.ptr_out[o] = cur + (int64_t)be * a.S;
             a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;

@@ -122,9 +122,10 @@ __global__ __launch_bounds__(kThreads) void exchange_kernel(Ws w, int E, int n_s
                 const f4 p = ((*reinterpret_cast<f4 *>(lds + (0 * Es4 + t) * 4) + *reinterpret_cast<f4 *>(lds + (1 * Es4 + t) * 4)) +
                               *reinterpret_cast<f4 *>(lds + (2 * Es4 + t) * 4)) + *reinterpret_cast<f4 *>(lds + (3 * Es4 + t) * 4);
                 u64 *g = w.part + ((size_t)(par * kGroups + c) * E + sl * Es + 4 * t);
+                const float pe[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    __hip_atomic_store(g + u, ((u64)(unsigned)n << 32) | __builtin_bit_cast(unsigned, p[u]), __ATOMIC_RELAXED,
+                    __hip_atomic_store(g + u, ((u64)(unsigned)n << 32) | (u64)__float_as_uint(pe[u]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();   // (the fold buffer is reused below)
