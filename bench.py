@@ -866,7 +866,8 @@ def run_tag(a, device, rank, world, dist, census=None):
             e[0].record()
             cs = col.collect(n_step=n_env * T)
             e[1].record()
-            batch = agent_batches_from_buffer(buf, env.agents, only=["agent_0", "adversary_0"], global_state=False)  # one learner per team;
+            # one learner per team; copies=False: PPO.learn gathers its column straight from the stores into its graph buffers
+            batch = agent_batches_from_buffer(buf, env.agents, only=["agent_0", "adversary_0"], global_state=False, copies=False)
             # (no joint rows: grouped PPO has no centralized critic -- the reference's job builds per-agent batches only)
             batch["good"], batch["adversaries"] = batch["agent_0"], batch["adversary_0"]
             losses = trainer.train_step(batch)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TSM_ABI_VERSION 3  /* 3: tsm_slab_seg.frag_image, tsm_critic_rows_grad_*(w1_image), tsm_kernel_option_* */
+#define TSM_ABI_VERSION 4  /* 4: tsm_rollout_tag_desc.vnext_store, TSM_MAX_GATHER_FIELDS 12, tsm_random_permutations_advance; 3: tsm_slab_seg.frag_image, tsm_critic_rows_grad_*(w1_image), tsm_kernel_option_* */
 
 enum {
     TSM_OK = 0,
@@ -128,7 +128,7 @@ int tsm_mc_return_to_go_lanes(const float *rew, int64_t T, int64_t n_lane, doubl
  * picks an agent's column of a joint row.  Kinds: f32 -> f32; i32 / i64 / u8 -> i32 / i64 / f32 / u8 (u8: 0 / 1, torch.bool's
  * storage).  Replaces the per-field torch copies of the MARL trainers' per-agent batches (training_coordinator.py:118,154,336) and
  * of learn()'s static buffers.  No reference counterpart. */
-#define TSM_MAX_GATHER_FIELDS 8
+#define TSM_MAX_GATHER_FIELDS 12
 enum { TSM_KIND_F32 = 0, TSM_KIND_I32 = 1, TSM_KIND_I64 = 2, TSM_KIND_U8 = 3 };
 typedef struct tsm_gather_field {
     const void *src;
@@ -529,7 +529,9 @@ int tsm_u64_add(uint64_t *counter, uint64_t inc, void *stream);
  * per step, tsm_policy_forward on each team's agent-major rows (sampling counter of step t, column a, env e:
  * offset[team] + *offset_dev + t n_env NA + a n_env + e, as MultiAgentPolicy hands a team's columns to its policy)
  * -> tsm_mpe_tag_step -> tsm_vrb_add.  logp_store / vs_store receive each row's own policy outputs (nullable);
- * V(obs_next) is not produced.  Everything else as tsm_rollout_spread. */
+ * vnext_store (nullable) V(obs_next) by the row's own team's critic, as tsm_rollout_spread produces it: the next step's V(obs)
+ * where the episode goes on, a forward pass of the terminal observation where it ended, a last pass behind the loop for the rows
+ * of the final step -- bit-identical to tsm_policy_forward on the stored obs_next rows.  Everything else as tsm_rollout_spread. */
 typedef struct {
     const float *params[2];
     uint64_t policy_seed[2], offset[2];
@@ -558,6 +560,7 @@ typedef struct {
     int32_t max_ep, _pad2;
     uint64_t offset_inc; /* added to *offset_dev by the last workgroup to finish (done_ctr: zeroed u32 in HBM; NULL = off) */
     uint32_t *done_ctr;
+    float *vnext_store; /* [S][n_env][NA] V(obs_next) of every added row (nullable) */
 } tsm_rollout_tag_desc;
 int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stream);
 
@@ -752,6 +755,12 @@ int tsm_global_state(const float *const *obs_by_agent_host, int32_t n_agent, int
  * (advance it with tsm_u64_add). */
 int tsm_random_permutations(int64_t n, int32_t n_perm, uint64_t seed, uint64_t counter, const uint64_t *counter_dev,
                             int64_t scale, int32_t group_size, int64_t offset_mul, int64_t *out, void *stream);
+/* The same draw keyed by *counter_dev alone, after which the LAST workgroup to finish adds counter_inc to *counter_dev (every
+ * workgroup has read it by then): a captured graph needs no tsm_u64_add launch behind its draws.  done_ctr: a zeroed u32 in HBM
+ * owned by this call site (left at zero again). */
+int tsm_random_permutations_advance(int64_t n, int32_t n_perm, uint64_t seed, uint64_t *counter_dev, uint64_t counter_inc,
+                                    uint32_t *done_ctr, int64_t scale, int32_t group_size, int64_t offset_mul, int64_t *out,
+                                    void *stream);
 
 /* CTDEPolicy.learn loss head  [a16]
  * Replaces  the TD target / critic MSE / policy-gradient arithmetic of CTDEPolicy.learn

@@ -29,7 +29,7 @@ def test_abi_version_and_sizes(lib):
     import re
 
     hdr = int(re.search(r"#define\s+TSM_ABI_VERSION\s+(\d+)", open(_abi.HEADER_PATH).read()).group(1))
-    assert lib.tsm_abi_version() == hdr == _abi.ABI_VERSION == 3
+    assert lib.tsm_abi_version() == hdr == _abi.ABI_VERSION == 4
     # ctypes mirrors of the header's structs keep their layout
     import ctypes
 
@@ -91,8 +91,8 @@ def test_new_host_entry_points_validate_without_a_device(lib):
     fields = (_abi.tsm_gather_field * 1)(_abi.tsm_gather_field(None, None, 4, 0, 0, 1, 0, 1, 0, 0, 0))
     with pytest.raises(ValueError, match="null pointer"):
         _abi.call("tsm_gather_fields", fields, 1, None)
-    with pytest.raises(ValueError, match="1..8 fields"):
-        _abi.call("tsm_gather_fields", fields, 9, None)
+    with pytest.raises(ValueError, match="1..12 fields"):
+        _abi.call("tsm_gather_fields", fields, 13, None)
     fields[0] = _abi.tsm_gather_field(1, 1, 6, 2, 2, 1, 0, 1, 0, 0, 0)   # n_rows != T * E
     with pytest.raises(ValueError, match="T \\* E"):
         _abi.call("tsm_gather_fields", fields, 1, None)

@@ -291,6 +291,19 @@ def test_fused_tag_rollout_is_bit_identical_to_unfused(n_env, n_adv, n_good, n_o
             lpos=env.landmark_pos.clone(), steps=env.steps.clone(), ep=env.episode_ctr.clone(), obs_cur=env.obs_cur.clone(),
             tick=env.rng_tick.clone(), ret1=st1.returns, len1=st1.lens, n1=st1.n_collected_episodes,
             ret2=st2.returns, n2=st2.n_collected_episodes))
+        if fused:
+            # V(obs_next) as the kernel stores it (next step's V(obs) / the terminal observation's own pass / the pass behind the
+            # loop) == the row's own team's critic on the stored obs_next rows, bit for bit (a2c.py:124)
+            from tianshou_marl_amd import ops
+
+            n_rows, N = steps + 3, env.n_agent
+            for ai in range(N):
+                pol = mgr.policy_map[env.agents[ai]]
+                rows = buf.obs_next_store[:n_rows, :, ai].reshape(-1, env.obs_dim).contiguous()
+                ref = ops.policy_forward(pol.net.flat.data, rows, 5, 64, mode="none")["value"].reshape(n_rows, n_env)
+                assert torch.equal(buf.vnext_store[:n_rows, :, ai], ref), ai
+            cols = buf.column_outputs
+            assert isinstance(cols, list) and len(cols) == N and cols[0][0] == id(mgr.policy_map[env.agents[0]])
     a, b = outs
     assert a["n1"] == n_env * (steps // T) and a["n1"] + a["n2"] == n_env * ((steps + 3) // T)
     for k in a:
@@ -312,6 +325,59 @@ def test_fused_tag_rollout_takes_the_mode_outside_training_steps():
         outs.append((buf.act_store.clone(), buf.logp_store.clone(), buf.obs_store.clone()))
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_learn_on_stored_rollout_outputs_equals_learn_that_recomputes(shared):
+    """the agent batches of a fused tag rollout carry each column's stored logp_old / V(obs) / V(obs_next),
+    tagged with the policy and parameter version that produced them; `PPO.learn` takes them when it IS that policy at that version
+    (no policy_forward launches) and recomputes otherwise -- a shared policy's second learn() of a step has moved on, as in the
+    reference, where every learn() evaluates its own rows afresh (ppo.py:157-161).  Losses and parameters after two training steps:
+    identical to learners that always recompute; graph and eager alike."""
+    from tianshou_marl_amd import ops
+
+    res = []
+    # (reuse stored outputs, learn() as a graph replay, agent batches as env-major copies / as handles on the stores)
+    for reuse, graph, copies in ((True, True, True), (False, True, True), (True, False, True), (True, True, False), (True, False, False)):
+        env, mgr, buf, col = _tag_job(64, 3, 1, 2, 25, True, 25, shared=shared)
+        pols = {id(p): p for p in mgr.policy_map.values()}
+        for p in pols.values():
+            p.reuse_rollout_outputs, p.use_graph, p.shuffle = reuse, graph, "device"
+        losses = []
+        launches = []
+        orig = ops.policy_forward
+        for step in range(3):
+            with policy_within_training_step(mgr):
+                col.collect(n_step=64 * 25)
+                batch = agent_batches_from_buffer(buf, env.agents, global_state=False, copies=copies)
+                if copies:
+                    assert "v_next" in batch["agent_0"] and "outputs_version" in batch["adversary_0"]
+                else:
+                    assert "obs" not in batch["agent_0"] and batch["agent_0"].store_rows.store.column_outputs is not None
+                count = [0]
+
+                def counting(*a, **k):
+                    count[0] += 1
+                    return orig(*a, **k)
+
+                ops.policy_forward = counting
+                try:
+                    for name in ("adversary_0", "adversary_1", "agent_0"):
+                        losses.append(dict(mgr.policy_map[name].learn(batch[name], 800, 1)))
+                finally:
+                    ops.policy_forward = orig
+                launches.append(count[0])
+            col.reset_buffer(keep_statistics=True)
+        torch.cuda.synchronize()
+        res.append((losses, [p.net.flat.data.clone() for p in pols.values()], launches))
+    (l0, p0, n0), (l1, p1, n1), (l2, p2, n2), (l3, p3, n3), (l4, p4, n4) = res
+    assert l0 == l1 == l2 == l3 == l4
+    for x, *rest in zip(p0, p1, p2, p3, p4):
+        assert all(torch.equal(x, y) for y in rest)
+    assert n4 == n2
+    # eager learners (the third run) show what was launched: with stored outputs only a policy that has ALREADY learned this step
+    # recomputes -- grouped: adversary_1 (its policy moved at adversary_0's call): 2 forwards; one shared policy: calls 2 and 3: 4
+    assert n2 == ([4, 4, 4] if shared else [2, 2, 2])
 
 
 def test_agent_batches_fast_path_equals_the_indexed_gather():

@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtsmarl_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tsmarl.h")
 
-MAX_GATHER_FIELDS = 8  # include/tsmarl.h TSM_MAX_GATHER_FIELDS
-ABI_VERSION = 3  # include/tsmarl.h TSM_ABI_VERSION: bumped whenever a signature or a struct layout changes
+MAX_GATHER_FIELDS = 12  # include/tsmarl.h TSM_MAX_GATHER_FIELDS
+ABI_VERSION = 4  # include/tsmarl.h TSM_ABI_VERSION: bumped whenever a signature or a struct layout changes
 TSM_OK, TSM_ERR_INVALID, TSM_ERR_HIP, TSM_ERR_MALFORMED_BUFFER, TSM_ERR_UNSUPPORTED = range(5)
 
 
@@ -95,7 +95,7 @@ class tsm_rollout_tag_desc(C.Structure):
                 ("act_store", C.c_void_p), ("term_store", C.c_void_p), ("trunc_store", C.c_void_p),
                 ("ptr_out", C.c_void_p), ("ep_rew_out", C.c_void_p), ("ep_len_out", C.c_void_p),
                 ("ep_idx_out", C.c_void_p), ("ep_rec", C.c_void_p), ("max_ep", C.c_int32), ("_pad2", C.c_int32),
-                ("offset_inc", C.c_uint64), ("done_ctr", C.c_void_p)]
+                ("offset_inc", C.c_uint64), ("done_ctr", C.c_void_p), ("vnext_store", C.c_void_p)]
 
 
 class tsm_mlp_desc(C.Structure):
@@ -159,6 +159,7 @@ SIGNATURES = {
     "tsm_reduce_slabs": (_int, [_p, _i32, _i64, _f64, _p, _p]),
     "tsm_global_state": (_int, [C.POINTER(_p), _i32, _i64, _i32, _int, _p, _p]),
     "tsm_random_permutations": (_int, [_i64, _i32, _u64, _u64, _p, _i64, _i32, _i64, _p, _p]),
+    "tsm_random_permutations_advance": (_int, [_i64, _i32, _u64, _p, _u64, _p, _i64, _i32, _i64, _p, _p]),
     "tsm_ctde_head_partial_elems": (_i64, [_i64]),
     "tsm_ctde_td_head": (_int, [_p, _p, _i32, _p, _p, C.c_float, _p, _p, _i32, _i64, _p, _p, _p, _p, _p]),
     "tsm_mlp_param_count": (_i64, [C.POINTER(tsm_mlp_desc)]),

@@ -359,8 +359,45 @@ class DeviceStoreRows:
         self.early_done = early_done
         self.T, self.E, self.N, self.D = int(T), buffer.buffer_num, buffer.n_agent, buffer.obs_dim
         self.obs, self.obs_next, self.act = buffer.obs_store, buffer.obs_next_store, buffer.act_store
-        self.rew, self.term = buffer.rew_store, buffer.term_store
+        self.rew, self.term, self.trunc = buffer.rew_store, buffer.term_store, buffer.trunc_store
+        # what the rollout stored beside the rows: logp / V(obs) / V(obs_next) of every column's own policy, and which policy at
+        # which parameter version that was (DeviceVectorReplayBuffer.column_outputs) -- None where not stored / unknown
+        self.logp, self.vs, self.vnext = buffer.logp_store, buffer.vs_store, buffer.vnext_store
+        cols = getattr(buffer, "column_outputs", None)
+        self.column_outputs = list(cols) if isinstance(cols, list) else None
         self.key = buffer.storage_key()
+        self._buffer = buffer
+
+    def agent_batch(self, a: int) -> Batch:
+        """Agent column `a` as env-major copies (the `copies=True` format): for learners that do not read the stores in place."""
+        return _agent_rows(self._buffer, a, self.T)
+
+
+def _agent_rows(buffer, a: int, T: int) -> Batch:
+    """Agent column `a` of a uniformly filled device buffer as env-major rows: the agent's fields in ONE launch
+    (csrc/gather_fields.hip) instead of six strided torch copies and three dtype conversions -- the same values in the same dtypes;
+    the column's stored policy outputs ride along, tagged (see below)."""
+    from ... import ops
+
+    E, N = buffer.buffer_num, buffer.n_agent
+    n, Dd, dev = E * T, buffer.obs_store.shape[-1], buffer.device
+    o = dict(obs=torch.empty(n, Dd, dtype=torch.float32, device=dev), act=torch.empty(n, dtype=torch.int64, device=dev),
+             rew=torch.empty(n, dtype=buffer.rew_store.dtype, device=dev), obs_next=torch.empty(n, Dd, dtype=torch.float32, device=dev),
+             terminated=torch.empty(n, dtype=torch.bool, device=dev), truncated=torch.empty(n, dtype=torch.bool, device=dev))
+    fields = [(buffer.obs_store, o["obs"], T, E, N * Dd, a * Dd), (buffer.act_store, o["act"], T, E, N, a),
+              (buffer.rew_store, o["rew"], T, E, N, a), (buffer.obs_next_store, o["obs_next"], T, E, N * Dd, a * Dd),
+              (buffer.term_store, o["terminated"], T, E, N, a), (buffer.trunc_store, o["truncated"], T, E, N, a)]
+    cols = getattr(buffer, "column_outputs", None)
+    if isinstance(cols, list) and cols[a][1] is not None and buffer.vnext_store is not None and buffer.logp_store is not None:
+        # the rollout stored this column's log-probabilities, V(obs) and V(obs_next), computed by ITS policy at a known
+        # parameter version: they ride along (same launch), tagged, and a learner that is that policy at that version
+        # takes them instead of recomputing three forward passes over the rows (PPO.learn; ppo.py:157-161, a2c.py:121-127)
+        for key, src_ in (("logp_old", buffer.logp_store), ("v_s", buffer.vs_store), ("v_next", buffer.vnext_store)):
+            o[key] = torch.empty(n, dtype=torch.float32, device=dev)
+            fields.append((src_, o[key], T, E, N, a))
+        o["outputs_policy"], o["outputs_version"] = np.int64(cols[a][0]), np.int64(cols[a][1])
+    ops.gather_fields(fields)
+    return Batch(**o)
 
 
 def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, only: list | None = None,
@@ -376,7 +413,10 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
     strided views of the time-major store -- one copy per field and agent, no index kernel and no host round trip.
     copies=False (chained rows whose episodes end at the last slot only): no env-major copies at all -- every agent's
     batch is `Batch(agent_index=a)` and the stores travel as `batch.chain_done.store` (`DeviceStoreRows`); for learners that
-    read the stores in place (CTDEPolicy).  Falls back to the copies when the rows do not qualify."""
+    read the stores in place (CTDEPolicy).  Falls back to the copies when the rows do not qualify.
+    copies=False with global_state=False: every agent's batch is `Batch(agent_index=a, store_rows=<handle>)` whose
+    `store_rows.store` is the `DeviceStoreRows`: `PPO.learn` gathers the column straight into its static graph buffers (one launch,
+    nothing allocated per call) and takes the stored policy outputs where they are its own (`PPO._stored_outputs_ok`)."""
     T = buffer.host_uniform_len()
     if T is not None:
         E = buffer.buffer_num
@@ -412,6 +452,16 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
         else:
             early.zero_()
         store = DeviceStoreRows(buffer, T, early)
+    if (not copies and not global_state and store_view and T > 0 and buffer.obs_next_store is not None
+            and all(getattr(buffer, s_).is_contiguous() for s_ in ("obs_store", "act_store", "rew_store", "obs_next_store", "term_store",
+                                                                    "trunc_store"))):
+        rows = DeviceStoreRows(buffer, T, None)
+        for a, name in enumerate(agents):
+            if only is None or name in only:
+                handle = buffer.done_store[:0]  # (an empty view: no launch; it only carries the handle through the Batch)
+                handle.store = rows
+                out[name] = Batch(agent_index=np.int64(a), store_rows=handle)
+        return out
     if store is not None and not copies:
         for a, name in enumerate(agents):
             if only is None or name in only:
@@ -428,20 +478,7 @@ def agent_batches_from_buffer(buffer, agents: list, global_state: bool = True, o
         if only is not None and name not in only:
             continue
         if fused:
-            # the agent's six fields as env-major rows in ONE launch (csrc/gather_fields.hip) instead of six strided torch copies
-            # and three dtype conversions: the same values in the same dtypes
-            from ... import ops
-
-            n, N = E * T, buffer.n_agent
-            Dd = buffer.obs_store.shape[-1]
-            dev = buffer.device
-            o = dict(obs=torch.empty(n, Dd, dtype=torch.float32, device=dev), act=torch.empty(n, dtype=torch.int64, device=dev),
-                     rew=torch.empty(n, dtype=buffer.rew_store.dtype, device=dev), obs_next=torch.empty(n, Dd, dtype=torch.float32, device=dev),
-                     terminated=torch.empty(n, dtype=torch.bool, device=dev), truncated=torch.empty(n, dtype=torch.bool, device=dev))
-            ops.gather_fields([(buffer.obs_store, o["obs"], T, E, N * Dd, a * Dd), (buffer.act_store, o["act"], T, E, N, a),
-                               (buffer.rew_store, o["rew"], T, E, N, a), (buffer.obs_next_store, o["obs_next"], T, E, N * Dd, a * Dd),
-                               (buffer.term_store, o["terminated"], T, E, N, a), (buffer.trunc_store, o["truncated"], T, E, N, a)])
-            out[name] = Batch(**o)
+            out[name] = _agent_rows(buffer, a, T)
         else:
             out[name] = Batch(obs=col(d["obs"], a), act=col(d["act"], a).to(torch.int64),
                               rew=col(d["rew"], a), obs_next=col(d["obs_next"], a),

@@ -99,6 +99,7 @@ class PPO(nn.Module):
         self.gae_lambda, self.gamma, self.max_batchsize = gae_lambda, gamma, max_batchsize
         self.return_scaling, self.ret_rms, self._eps = return_scaling, DeviceRunningMeanStd(net.flat.device), 1e-8
         self.deterministic_eval = deterministic_eval
+        self.reuse_rollout_outputs = True  # learn(): take logp_old / V(obs) / V(obs_next) the rollout stored (_stored_outputs_ok)
         self.is_within_training_step = False
         self.dispatch, self.shuffle = dispatch, shuffle
         self.use_graph = use_graph
@@ -729,13 +730,21 @@ class PPO(nn.Module):
         dev = self.device
         t = lambda x, dt: (x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))).to(dev, dt).contiguous()  # noqa: E731
         self.net.sync_image()
+        if self._batch_store(batch) is not None:  # rows read in place by the graph path: the eager path takes the copies
+            batch = self._batch_store(batch).agent_batch(int(batch.agent_index))
         obs = t(batch.obs, torch.float32)
         n = obs.shape[0]
         act = t(batch.act, torch.int32).reshape(n)
         P = self.net.flat.data
-        cur = ops.policy_forward(P, obs, self.net.n_act, self.net.hidden, image=self.net.image, mode="given", act=act, want_logits=False)
-        nxt = ops.policy_forward(P, t(batch.obs_next, torch.float32), self.net.n_act, self.net.hidden, image=self.net.image, mode="none",
-                                 want_logits=False)
+        if self._stored_outputs_ok(batch):
+            # the rollout kernel stored these rows' logp / V(obs) / V(obs_next), computed by this policy at this parameter version:
+            # the same bits as the three passes below (tests/test_gpu_tag.py), without them
+            cur = dict(logp=t(batch.logp_old, torch.float32).reshape(n), value=t(batch.v_s, torch.float32).reshape(n))
+            nxt = dict(value=t(batch.v_next, torch.float32).reshape(n))
+        else:
+            cur = ops.policy_forward(P, obs, self.net.n_act, self.net.hidden, image=self.net.image, mode="given", act=act, want_logits=False)
+            nxt = ops.policy_forward(P, t(batch.obs_next, torch.float32), self.net.n_act, self.net.hidden, image=self.net.image, mode="none",
+                                     want_logits=False)
         term = t(batch.terminated, torch.uint8).reshape(n, 1)
         trunc = t(batch.truncated, torch.uint8).reshape(n, 1) if "truncated" in batch else torch.zeros_like(term)
         ret, adv = ops.gae_lanes(cur["value"].view(n, 1), nxt["value"].view(n, 1), t(batch.rew, torch.float32).view(n, 1),
@@ -760,12 +769,37 @@ class PPO(nn.Module):
                 return learn_lockstep_graph([(self, batch, batch_size, repeat)], self._grad_sync)[0]
         return drive_steps(self.learn_steps(batch, batch_size, repeat, **kwargs), self._grad_sync)
 
+    @staticmethod
+    def _batch_store(batch: Batch):
+        """The `DeviceStoreRows` behind an agent batch built with `agent_batches_from_buffer(copies=False, global_state=False)`
+        (the rows are read from the device buffer's stores in place), else None."""
+        return getattr(batch["store_rows"], "store", None) if "store_rows" in batch else None
+
+    def _learn_rows(self, batch: Batch) -> int:
+        st = self._batch_store(batch)
+        return st.T * st.E if st is not None else len(batch.rew)
+
+    def _stored_outputs_ok(self, batch: Batch) -> bool:
+        """Does `batch` (training_coordinator.agent_batches_from_buffer) carry logp_old / v_s / v_next that THIS policy computed at
+        its CURRENT parameters?  (A shared policy that learns once per agent has moved on after its first call: the later calls
+        recompute, as the reference does, ppo.py:157-161.)"""
+        if not self.reuse_rollout_outputs:
+            return False
+        st = self._batch_store(batch)
+        if st is not None:
+            cols = st.column_outputs
+            return bool(cols is not None and st.vnext is not None and st.logp is not None
+                        and cols[int(batch.agent_index)] == (id(self), self.param_version))
+        return bool("v_next" in batch and "logp_old" in batch and "v_s" in batch
+                    and "outputs_policy" in batch and int(batch.outputs_policy) == id(self)
+                    and int(batch.outputs_version) == self.param_version)
+
     def learn_graph_ok(self, repeat: int = 1) -> bool:
         """Can `learn` run from static buffers inside captured graphs?  (recompute_advantage re-runs the critic between
         repeats from the host.)"""
         return bool(self.use_graph and not (self.recompute_adv and repeat > 1))
 
-    def _learn_static(self, n: int, batch_size: int | None, repeat: int, has_trunc: bool) -> dict:
+    def _learn_static(self, n: int, batch_size: int | None, repeat: int, has_trunc: bool, stored: bool = False) -> dict:
         """Static HBM buffers + the launch sequence of one `learn` call on n rows (cached per shape): `w["body"]()` is a
         generator that issues the critic passes, GAE, the permutations, advantage statistics and every gradient step on
         the static buffers -- the same launches in the same order as `learn_steps`, hence the same bits -- and, for a
@@ -775,7 +809,7 @@ class PPO(nn.Module):
         dev = self.device
         D, A, H = self.net.obs_dim, self.net.n_act, self.net.hidden
         dp = self._grad_sync is not None
-        key = ("learn_graph", n, batch_size, repeat, has_trunc, self.shuffle, dp, ops.kernel_options())
+        key = ("learn_graph", n, batch_size, repeat, has_trunc, self.shuffle, dp, ops.kernel_options(), stored)
         w = self._ws.get(key)
         if w is not None:
             return w
@@ -785,28 +819,38 @@ class PPO(nn.Module):
         P = self.net.flat.data
         z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
         nb_max = max(ops.ppo_update_grid(e - s) for s, e in bounds)
-        w = dict(n=n, n_steps=n_steps, repeat=repeat, has_trunc=has_trunc,
-                 obs=z(n, D), obs_next=z(n, D), act=z(n, dt=torch.int32), rew=z(n, 1), term=z(n, 1, dt=torch.uint8),
-                 trunc=z(n, 1, dt=torch.uint8), scal=z(n_steps, 4), step_dev=z(1, dt=torch.int64),
+        w = dict(n=n, n_steps=n_steps, repeat=repeat, has_trunc=has_trunc, stored=stored,
+                 obs=z(n, D), obs_next=None if stored else z(n, D), act=z(n, dt=torch.int32), rew=z(n, 1), term=z(n, 1, dt=torch.uint8),
+                 trunc=z(n, 1, dt=torch.uint8), step_dev=z(1, dt=torch.int64),
                  slabs=torch.empty(nb_max, P.numel(), dtype=torch.float32, device=dev),
-                 partial=torch.empty(nb_max * 4, dtype=torch.float64, device=dev),
-                 perm=z(repeat, n, dt=torch.int64),
+                 # the loss partials of EVERY gradient step stay until ONE launch behind the replay folds them, straight into the
+                 # pinned slot the host reads (as update() does): no per-step finalize launch, no device -> host copy
+                 partial=torch.zeros(n_steps, nb_max * 4, dtype=torch.float64, device=dev), nb_max=nb_max,
+                 nb_dev=torch.as_tensor([ops.ppo_update_grid(e - s) for s, e in bounds] * repeat, dtype=torch.int32, device=dev),
+                 M_dev=torch.as_tensor([e - s for s, e in bounds] * repeat, dtype=torch.int64, device=dev),
+                 perm=z(repeat, n, dt=torch.int64), perm_done=z(1, dt=torch.int32),
                  mb_start=torch.as_tensor([b[0] for b in bounds] + [n], dtype=torch.int64, device=dev))
+        if stored:  # logp_old / V(obs) / V(obs_next) as the rollout stored them (see _stored_outputs_ok)
+            w.update(logp=z(n), v_s=z(n), v_next=z(n))
         if dp:
             w["flat_g"] = z(P.numel())
 
         def body():
-            # `flat` is the source of truth before the first Adam step of this call (the image may be stale)
-            cur = ops.policy_forward(P, w["obs"], A, H, image=None, mode="given", act=w["act"], want_logits=False)
-            nxt = ops.policy_forward(P, w["obs_next"], A, H, image=None, mode="none", want_logits=False)
+            if stored:
+                cur, nxt = dict(logp=w["logp"], value=w["v_s"]), dict(value=w["v_next"])
+            else:
+                # `flat` is the source of truth before the first Adam step of this call (the image may be stale)
+                cur = ops.policy_forward(P, w["obs"], A, H, image=None, mode="given", act=w["act"], want_logits=False)
+                nxt = ops.policy_forward(P, w["obs_next"], A, H, image=None, mode="none", want_logits=False)
             ret, adv = ops.gae_lanes(cur["value"].view(n, 1), nxt["value"].view(n, 1), w["rew"], w["term"], w["trunc"],
                                      self.gamma, self.gae_lambda)
             ret, adv = ret.reshape(-1), adv.reshape(-1)
             k = 0
             for r in range(repeat):
                 if self.shuffle != "numpy":
-                    ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, out=w["perm"][r:r + 1])
-                    ops.call("tsm_u64_add", ops.ptr(self._perm_ctr), 1, ops.stream_ptr())
+                    # (the launch advances the draw counter itself: the draws of `_device_perm`, one launch fewer)
+                    ops.random_permutations(n, 1, self.seed ^ 0x5DEECE66D, counter_dev=self._perm_ctr, out=w["perm"][r:r + 1],
+                                            advance=1, done_ctr=w["perm_done"])
                 perm = w["perm"][r]
                 stats = (ops.ppo_adv_stats(adv, w["mb_start"], perm=perm, max_rows=max(e - s for s, e in bounds))
                          if self.advantage_normalization else None)
@@ -818,7 +862,7 @@ class PPO(nn.Module):
                                          adv_stats=None if stats is None else stats[j],
                                          v_s_old=cur["value"] if self.value_clip else None, perm=perm[s_:e_],
                                          image=self.net.image if k > 0 else None, M=e_ - s_, n_blocks=nb,
-                                         slabs=w["slabs"][:nb], partial=w["partial"], scalars=w["scal"][k],
+                                         slabs=w["slabs"][:nb], partial=w["partial"][k], want_scalars=False,
                                          opt_step_dev=w["step_dev"])
                     grads = w["slabs"][:nb]
                     if dp and self._grad_sync.fused_step_ok(self.max_grad_norm, P.numel()):
@@ -846,17 +890,42 @@ class PPO(nn.Module):
         call's host-drawn permutations, and the device-side step count if it went stale."""
         n, D, repeat = w["n"], self.net.obs_dim, w["repeat"]
         t = lambda x: x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))  # noqa: E731
-        names = ["obs", "obs_next", "act", "rew", "terminated"] + (["truncated"] if "truncated" in batch else [])
+        stored = w.get("stored", False)
+        st = self._batch_store(batch)
+        if st is not None:
+            # the agent's column straight from the time-major stores into the static buffers: ONE launch whose descriptors are
+            # built once per (store, column) -- every pointer in them is a static allocation
+            a = int(batch.agent_index)
+            cache = w.setdefault("store_gathers", {})
+            prep = cache.get((st.key, a))
+            if prep is None:
+                T_, E_, N_, D_ = st.T, st.E, st.N, st.D
+                fields = [(st.obs, w["obs"], T_, E_, N_ * D_, a * D_), (st.act, w["act"], T_, E_, N_, a), (st.rew, w["rew"], T_, E_, N_, a),
+                          (st.term, w["term"], T_, E_, N_, a), (st.trunc, w["trunc"], T_, E_, N_, a)]
+                fields += ([(st.logp, w["logp"], T_, E_, N_, a), (st.vs, w["v_s"], T_, E_, N_, a), (st.vnext, w["v_next"], T_, E_, N_, a)]
+                           if stored else [(st.obs_next, w["obs_next"], T_, E_, N_ * D_, a * D_)])
+                cache[(st.key, a)] = ops.gather_fields(fields)
+            else:
+                ops.gather_fields(None, prepared=prep)
+            self._learn_load_rest(w, n, repeat)
+            return
+        names = ["obs", "act", "rew", "terminated"] + (["truncated"] if "truncated" in batch else []) + \
+            (["logp_old", "v_s", "v_next"] if stored else ["obs_next"])
         leaves = [batch[k] for k in names]
         if all(isinstance(x, torch.Tensor) and x.is_cuda and x.is_contiguous() and x.dtype in ops._GATHER_KINDS for x in leaves) \
-                and leaves[0].dtype == leaves[1].dtype == leaves[3].dtype == torch.float32:
+                and all(batch[k].dtype == torch.float32 for k in names if k not in ("act", "terminated", "truncated")):
             # device batches (the trainers' per-agent batches): all fields into the static buffers in ONE launch
-            dst = [w["obs"], w["obs_next"], w["act"], w["rew"], w["term"]] + ([w["trunc"]] if "truncated" in batch else [])
+            dst = [w["obs"], w["act"], w["rew"], w["term"]] + ([w["trunc"]] if "truncated" in batch else []) + \
+                ([w["logp"], w["v_s"], w["v_next"]] if stored else [w["obs_next"]])
             ops.gather_fields(list(zip(leaves, dst)))
             self._learn_load_rest(w, n, repeat)
             return
         w["obs"].copy_(t(batch.obs).reshape(n, D), non_blocking=True)
-        w["obs_next"].copy_(t(batch.obs_next).reshape(n, D), non_blocking=True)
+        if stored:
+            for k_, d_ in (("logp_old", "logp"), ("v_s", "v_s"), ("v_next", "v_next")):
+                w[d_].copy_(t(batch[k_]).reshape(n), non_blocking=True)
+        else:
+            w["obs_next"].copy_(t(batch.obs_next).reshape(n, D), non_blocking=True)
         w["act"].copy_(t(batch.act).reshape(n), non_blocking=True)
         w["rew"].copy_(t(batch.rew).reshape(n, 1), non_blocking=True)
         w["term"].copy_(t(batch.terminated).reshape(n, 1), non_blocking=True)
@@ -889,7 +958,10 @@ class PPO(nn.Module):
             w["ring_pos"] = w.get("ring_pos", 0) + 1
             if slot["pending"] is not None:
                 slot["pending"]._force()
-        slot["h"].copy_(w["scal"], non_blocking=True)
+        if "scal" in w:  # (GenericPPO._learn_static folds its statistics inside the graph)
+            slot["h"].copy_(w["scal"], non_blocking=True)
+        else:
+            ops.ppo_finalize_many(w["partial"], w["nb_max"] * 4, w["nb_dev"], w["M_dev"], self._cfg, slot["h"])
         slot["sync"] = self._grad_sync
         if self._grad_sync is not None:
             self._grad_sync.post_check()
@@ -904,7 +976,8 @@ class PPO(nn.Module):
         """`learn` as ONE hipGraph replay per call (the MARL trainers call it once per policy and step,
         training_coordinator.py:118,154,336): the batch is copied into static HBM buffers, then `_learn_static`'s body
         replays as captured."""
-        w = self._learn_static(len(batch.rew), batch_size, repeat, "truncated" in batch)
+        w = self._learn_static(self._learn_rows(batch), batch_size, repeat, "truncated" in batch or self._batch_store(batch) is not None,
+                               stored=self._stored_outputs_ok(batch))
         self._learn_load(w, batch)
         if "graph" not in w:
             graph = torch.cuda.CUDAGraph()

@@ -49,7 +49,7 @@ struct TagRolloutArgs {
     void *vrb_state;
     int64_t S;
     uint8_t *done_store;
-    float *obs_store, *obs_next_store, *rew_store, *logp_store, *vs_store;
+    float *obs_store, *obs_next_store, *rew_store, *logp_store, *vs_store, *vnext_store;
     int32_t *act_store;
     uint8_t *term_store, *trunc_store;
     // per-step outputs [n_steps][n_env]...
@@ -191,6 +191,9 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
                 s_val[hr] = lg[16];
                 s_act[hr] = act;
                 s_logp[hr] = la - (m + logf(ssum));
+                // V(obs_next) of the previous step's row == V(obs) of this one where the episode goes on (s_row / s_done still hold
+                // the previous step: D rewrites them behind the barrier below)
+                if (a.vnext_store && t > 0 && !s_done[hel]) a.vnext_store[s_row[hel] * NA + hai] = lg[16];
             }
         }
         __syncthreads();
@@ -281,11 +284,19 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             if (a.vs_store) a.vs_store[dst] = s_val[r];
         }
         TSTAMP(4);
-        // F. finished episodes: re-initialise the env, first observation of the new episode
-        if (a.auto_reset) {
+        // F. finished episodes: the critic value of the terminal observation (both teams' nets on the obs_next tile, every row takes
+        //    its own team's), then re-initialise the env, first observation of the new episode
+        if (a.auto_reset || a.vnext_store) {
             int any_done = lane_live ? s_done[el] : 0;
             any_done = __syncthreads_or(any_done);
-            if (any_done) {
+            if (any_done && a.vnext_store) {
+                lyf.X = xnxt; lyg.X = xnxt;
+                tile_forward_split<H>(lds, lyf, d);
+                tile_forward_split<H>(lds, lyg, d);
+                if (lane_live && s_done[el])
+                    a.vnext_store[s_row[el] * NA + ai] = lds[(ai >= c.n_adv ? lyB.OUT : ly.OUT) + r * ly.ldo + 16];
+            }
+            if (any_done && a.auto_reset) {
                 if (env_lane && s_done[bel]) {
                     const uint64_t ep = a.episode_ctr[be];
                     s_ep[bel] = ep;
@@ -309,6 +320,18 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         { const int tmp = xcur; xcur = xnxt; xnxt = tmp; }
     }
     if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[42] = (long long)wall_clock64();
+    // V(obs_next) of the final step's rows whose episode goes on: one more pass over the observation the next collect starts from
+    if (a.vnext_store) {
+        int open_rows = lane_live ? !s_done[el] : 0;
+        open_rows = __syncthreads_or(open_rows);
+        if (open_rows) {
+            lyf.X = xcur; lyg.X = xcur;
+            tile_forward_split<H>(lds, lyf, d);
+            tile_forward_split<H>(lds, lyg, d);
+            if (lane_live && !s_done[el])
+                a.vnext_store[s_row[el] * NA + ai] = lds[(ai >= c.n_adv ? lyB.OUT : ly.OUT) + r * ly.ldo + 16];
+        }
+    }
     // the observation of the next collect() call
     if (a.obs_cur_out)
         for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
@@ -374,7 +397,7 @@ TSM_EXPORT int tsm_rollout_tag(const tsm_rollout_tag_desc *desc_host, void *stre
     a.auto_reset = h.auto_reset; a.obs_cur_out = h.obs_cur_out;
     a.vrb_state = h.vrb_state; a.S = h.sub_size; a.done_store = h.done_store;
     a.obs_store = h.obs_store; a.obs_next_store = h.obs_next_store; a.rew_store = h.rew_store;
-    a.logp_store = h.logp_store; a.vs_store = h.vs_store;
+    a.logp_store = h.logp_store; a.vs_store = h.vs_store; a.vnext_store = h.vnext_store;
     a.act_store = h.act_store; a.term_store = h.term_store; a.trunc_store = h.trunc_store;
     a.ptr_out = h.ptr_out; a.ep_len_out = h.ep_len_out; a.ep_idx_out = h.ep_idx_out; a.ep_rew_out = h.ep_rew_out;
     a.n_steps = h.n_steps;

@@ -55,6 +55,10 @@ class DeviceVectorReplayBuffer:
         # the same for logp / v_s alone (rows added by the unfused device collect path carry them but no V(obs_next))
         self.behaviour_outputs_version = "empty"
         self.logp_outputs_version = "empty"  # ... and for logp alone (the actor-only persistent rollout)
+        # per AGENT COLUMN (grouped policies: a team's rows carry its own policy's outputs): "empty", None (unknown / mixed), or a
+        # list of (policy token, parameter version) -- logp / v_s / v_next of every row of column a were computed by that policy
+        # at that version (mark_column_outputs; csrc/rollout_tag.hip)
+        self.column_outputs = "empty"
         # "empty" | True | False: every row since the last reset came from collects that continue one another
         # (mark_rows_chained); any add() from elsewhere clears it
         self.rows_chained = "empty"
@@ -85,6 +89,7 @@ class DeviceVectorReplayBuffer:
         self.policy_outputs_version = "empty"
         self.behaviour_outputs_version = "empty"
         self.logp_outputs_version = "empty"
+        self.column_outputs = "empty"
         self.rows_chained = "empty"
         self._host_rows = 0
 
@@ -116,6 +121,13 @@ class DeviceVectorReplayBuffer:
         self.behaviour_outputs_version = version if (version is not None and cur in ("empty", version)) else None
         self.mark_logp_outputs(version)
 
+    def mark_column_outputs(self, columns) -> None:
+        """Called by a collect path whose every added row carried logp / v_s / v_next of its column's own policy:
+        `columns[a]` = (policy token, parameter version); None: not stored / unknown.  Rows of several collects keep the mark only
+        while every column stays with one policy at one version."""
+        cur = self.column_outputs
+        self.column_outputs = list(columns) if (columns is not None and cur in ("empty", list(columns))) else None
+
     def mark_logp_outputs(self, version) -> None:
         cur = self.logp_outputs_version
         self.logp_outputs_version = version if (version is not None and cur in ("empty", version)) else None
@@ -144,6 +156,7 @@ class DeviceVectorReplayBuffer:
         if v_s is not None and self.vs_store is not None:
             fields.append((v_s, self.vs_store))
         self.policy_outputs_version = None  # rows added without V(obs_next): the update recomputes critic passes
+        self.column_outputs = None
         self.rows_chained = False  # (a Collector that knows its rows continue one another re-marks them afterwards)
         if logp is None or v_s is None or self.logp_store is None:
             self.behaviour_outputs_version = None

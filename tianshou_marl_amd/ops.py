@@ -888,15 +888,24 @@ def global_state(obs_by_agent, mode: str = "concatenate") -> torch.Tensor:
 
 
 def random_permutations(n: int, n_perm: int, seed: int, counter: int = 0, counter_dev=None, scale: int = 1,
-                        group_size: int = 1, offset_mul: int = 0, out=None, device="cuda"):
+                        group_size: int = 1, offset_mul: int = 0, out=None, device="cuda", advance: int = 0, done_ctr=None):
     """n_perm pseudo-random permutations of range(n) in one launch -> i64 [n_perm, n] (batch.py:1219 on device).
-    out[p, i] = pi_p(i) * scale + (p // group_size) * offset_mul."""
+    out[p, i] = pi_p(i) * scale + (p // group_size) * offset_mul.
+    advance > 0 (with counter_dev and done_ctr, a zeroed u32[1] of this call site): the launch itself adds `advance` to
+    *counter_dev once every workgroup has read it -- the draws of counter = 0 followed by tsm_u64_add, in one launch."""
     if n < 0 or n_perm < 0:
         raise ValueError("random_permutations: negative size")
     if out is None:
         out = torch.empty(n_perm, n, dtype=torch.int64, device=device)
     if out.numel() != n_perm * n:
         raise ValueError("random_permutations: out has the wrong size")
+    if advance:
+        if counter or counter_dev is None or done_ctr is None:
+            raise ValueError("random_permutations: advance needs counter_dev and done_ctr, and no host counter")
+        call("tsm_random_permutations_advance", n, n_perm, seed & (2**64 - 1), ptr(counter_dev), int(advance),
+             ptr(_chk(done_ctr, torch.int32, "done_ctr")), scale, group_size, offset_mul, ptr(_chk(out, torch.int64, "out")),
+             stream_ptr())
+        return out
     call("tsm_random_permutations", n, n_perm, seed & (2**64 - 1), counter & (2**64 - 1), ptr(counter_dev), scale,
          group_size, offset_mul, ptr(_chk(out, torch.int64, "out")), stream_ptr())
     return out
@@ -974,11 +983,19 @@ def mlp_forward_cond(desc, params, x, run_if, acts=None):
 _GATHER_KINDS = {torch.float32: 0, torch.int32: 1, torch.int64: 2, torch.uint8: 3, torch.bool: 3}
 
 
-def gather_fields(fields: list) -> None:
+def gather_fields(fields: list, prepared: list | None = None) -> list:
     """Several row-gathers with element conversion in ONE launch (include/tsmarl.h: tsm_gather_fields).  A field is
     `(src, dst)` -- both contiguous, equal numel: a converting copy -- or `(src, dst, T, E, src_row_stride, src_offset)`: dst row
     r = e * T + t (env-major) reads `width = dst.numel() // (T * E)` elements at src row t * E + e (`src` a contiguous time-major
-    store, strides in elements).  f32 -> f32; int32 / int64 / uint8 / bool -> int32 / int64 / float32 / uint8 / bool."""
+    store, strides in elements).  f32 -> f32; int32 / int64 / uint8 / bool -> int32 / int64 / float32 / uint8 / bool.
+    Returns the prepared descriptor arrays: pass them back as `prepared` (with fields=None) to launch the SAME gathers again
+    without rebuilding them -- for call sites whose sources and destinations are static allocations (per-call host cost: one
+    ctypes call instead of ~30 us of descriptor building)."""
+    if prepared is not None:
+        for arr, n in prepared:
+            call("tsm_gather_fields", arr, n, stream_ptr())
+        return prepared
+    done = []
     for k0 in range(0, len(fields), _abi.MAX_GATHER_FIELDS):
         chunk = fields[k0:k0 + _abi.MAX_GATHER_FIELDS]
         arr = (_abi.tsm_gather_field * len(chunk))()
@@ -1001,6 +1018,8 @@ def gather_fields(fields: list) -> None:
             arr[k] = _abi.tsm_gather_field(src.data_ptr(), dst.data_ptr(), n_rows, T, E, stride, off, width,
                                            _GATHER_KINDS[src.dtype], _GATHER_KINDS[dst.dtype], 0)
         call("tsm_gather_fields", arr, len(chunk), stream_ptr())
+        done.append((arr, len(chunk)))
+    return done
 
 
 def any_nonzero_u8(x, out=None):
@@ -1077,6 +1096,10 @@ def device_info() -> dict:
 KERNEL_OPTIONS = ("actor_tile", "split_bf16", "generic_kernels", "rollout_form")
 
 
+_options_cache = None  # kernel_options() as last read: options change only through set_kernel_option (the environment defaults
+                       # are resolved once, at first use), and the tuple is part of every per-call graph key
+
+
 def kernel_option(name: str) -> int:
     """Value of a kernel selection option (include/tsmarl.h: tsm_kernel_option_get)."""
     v = C.c_int32()
@@ -1086,14 +1109,19 @@ def kernel_option(name: str) -> int:
 
 def set_kernel_option(name: str, value: int) -> int:
     """Override a kernel selection rule for this process; returns the previous value."""
+    global _options_cache
     old = kernel_option(name)
+    _options_cache = None
     call("tsm_kernel_option_set", name.encode(), int(value))
     return old
 
 
 def kernel_options() -> tuple:
     """All option values in KERNEL_OPTIONS order: part of every launch-cache (hipGraph) key."""
-    return tuple(kernel_option(n) for n in KERNEL_OPTIONS)
+    global _options_cache
+    if _options_cache is None:
+        _options_cache = tuple(kernel_option(n) for n in KERNEL_OPTIONS)
+    return _options_cache
 
 
 class graph_capture:

@@ -376,10 +376,12 @@ def learn_lockstep_graph(jobs, sync: "GradSync", names: list | None = None) -> l
     The same launches in the same order as the eager lock-step, hence the same bits.  Every call first makes sure that all
     ranks submit the same groups (`names`) with the same row counts, minibatch sizes and repeats -- they select the graph,
     and ranks replaying different graphs would pair different collectives (one tiny all-reduce, never cached)."""
-    sync.check_same([f"{nm}:{len(b.rew)}:{bs}:{rep}:{int('truncated' in b)}"
-                     for nm, (_, b, bs, rep) in zip(names or range(len(jobs)), jobs)],
+    rows = lambda p, b: p._learn_rows(b) if hasattr(p, "_learn_rows") else len(b.rew)  # noqa: E731  (store handles: PPO._batch_store)
+    has_tr = lambda p, b: "truncated" in b or (hasattr(p, "_batch_store") and p._batch_store(b) is not None)  # noqa: E731
+    sync.check_same([f"{nm}:{rows(p, b)}:{bs}:{rep}:{int(has_tr(p, b))}"
+                     for nm, (p, b, bs, rep) in zip(names or range(len(jobs)), jobs)],
                     "the policy groups that train in this step (and their row counts)")
-    ws = [p._learn_static(len(b.rew), bs, rep, "truncated" in b) for p, b, bs, rep in jobs]
+    ws = [p._learn_static(rows(p, b), bs, rep, has_tr(p, b)) for p, b, bs, rep in jobs]
     for (p, b, _, _), w in zip(jobs, ws):
         p._learn_load(w, b)
     if not all(w.get("warm", True) for w in ws):
