@@ -30,6 +30,12 @@ import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 MFMA_F32_PEAK = 157.3e12  # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix) 157.3 TFLOPS" (f32-input MFMA)
+# (round 5, measured: profiles/r05_probe_mfma_valu_overlap.txt -- the clock read directly, s_memtime / s_memrealtime around the loop)
+PEAK_NOTE = ("the f32-MFMA peak is 2.4 GHz x 256 flop/clk/CU; the part HOLDS 2.40 GHz under sustained f32-MFMA load on all 256 CUs "
+             "(s_memtime / s_memrealtime, profiles/r05_probe_mfma_valu_overlap.txt); back-to-back independent v_mfma_f32_16x16x4_f32 "
+             "issue at 0.86 of the nominal rate with two waves per SIMD (1.988 us per 128 MFMAs per SIMD) and 0.74 with one wave -- an "
+             "issue effect, not a clock; f32 MFMAs and the other VALU instructions of a SIMD take turns (no overlap), so frac ~= "
+             "matrix-pipe busy share x 0.86 at best")
 
 
 def mlp_flops(dims) -> tuple[int, int]:
@@ -289,8 +295,8 @@ def pmc_traffic(kernel: str, grid_threads: int, expect: float | None = None):
 def pmc_issue(kernel: str, grid_threads: int) -> dict:
     """Matrix-pipe busy share and VALU instructions per MFMA of `kernel` from the committed issue-slot accounting
     (profiles/*pmc_issue_*.json, tools/pmc_issue.py: one rocprofv3 --pmc pass of this command).  pipe_busy is clock-independent:
-    SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles); `frac` (achieved / the 2.4 GHz peak) is pipe_busy x sustained clock / 2.4
-    (the part runs at ~1.8 GHz under sustained f32 MFMA load: profiles/r04_probe_mfma_valu_overlap.txt).  {} when no profile covers it."""
+    SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch cycles); `frac` (achieved / the 2.4 GHz peak) is pipe_busy x useful / issued flops
+    (the clock itself holds 2.40 GHz under sustained f32-MFMA load, profiles/r05_probe_mfma_valu_overlap.txt; see PEAK_NOTE).  {} when no profile covers it."""
     import glob
 
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_issue_*.json")), reverse=True):
@@ -458,7 +464,7 @@ def kernel_rooflines(a, algo, buf):
                      "frac": upd_flop / upd_s / MFMA_F32_PEAK,
                      "traffic": pmc_traffic("ppo_update_split_kernel", nb * 2 * 256),
                      **pmc_issue("ppo_update_split_kernel", nb * 2 * 256),
-                     "peak_note": "the f32-MFMA peak assumes 2.4 GHz; under sustained f32-MFMA load the part measures ~1.8 GHz (profiles/r04_probe_mfma_valu_overlap.txt), so frac = matrix-pipe busy share x ~0.74; f32 MFMAs and other VALU instructions of a SIMD take turns (no overlap)",
+                     "peak_note": PEAK_NOTE,
                      "traffic_note": "HBM bytes per launch (PMC): dominated by the per-workgroup gradient slabs "
                                      "(n_blocks x n_param x 4 B written, read back by adam_kernel)",
                      "flop_per_launch": upd_flop, "flop_per_sample": fa + ba + fc + bc,
@@ -819,7 +825,7 @@ def run_c3ppo(a, device):
         "roofline": (lambda fl, s_: {"bound": "mfma", "kernel": "C3 whole GAE + PPO update (GenericPPO.update, one hipGraph replay)",
                                      "achieved": fl / s_ / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                                      "frac": fl / s_ / MFMA_F32_PEAK, "traffic": None, "flop_per_update": fl,
-                                     "peak_note": "the f32-MFMA peak assumes 2.4 GHz; under sustained f32-MFMA load the part measures ~1.8 GHz (profiles/r04_probe_mfma_valu_overlap.txt), so frac = matrix-pipe busy share x ~0.74; f32 MFMAs and other VALU instructions of a SIMD take turns (no overlap)"})(
+                                     "peak_note": PEAK_NOTE})(
             (n_env * T + n_env) * mlp_flops((N * D, 128, 128, 1))[0]
             + n_env * T * N * sum(mlp_flops((D, 128, 128, 5))) + n_env * T * sum(mlp_flops((N * D, 128, 128, 1))),
             e1.elapsed_time(e2) * 1e-3),
@@ -872,13 +878,16 @@ def run_tag(a, device, rank, world, dist, census=None):
             batch["good"], batch["adversaries"] = batch["agent_0"], batch["adversary_0"]
             losses = trainer.train_step(batch)
             e[2].record()
-        _resolve(cs)  # read every step's collect statistics (see one_step); the losses are read one step late, below
+        # Both statistics objects of a step are lazy and are read ONE STEP LATE (the timed loop below): here the GPU work behind the
+        # rollout is short (~0.16 ms of learn() graphs), so a host that waited for THIS rollout's statistics before it prepared
+        # the next collect left the GPU idle ~60 us per step (gpurun_out/r05: collect_ms 0.32 for a 0.265 ms kernel).  The host
+        # still never runs more than one step ahead: it blocks on step k - 1's events while step k executes.
         col.reset_buffer(keep_statistics=True)
         marks.append(e)
         return cs, losses
 
     for _ in range(a.warmup):
-        step()
+        _resolve(step()[0])
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -886,10 +895,12 @@ def run_tag(a, device, rank, world, dist, census=None):
     prev = None
     for _ in range(a.steps):
         cs, losses = step()
-        if prev is not None:  # every step's training statistics are read, one step late (as a logger would)
-            for v in prev.values():
+        if prev is not None:  # every step's collect AND training statistics are read, one step late (as a logger would)
+            _resolve(prev[0])
+            for v in prev[1].values():
                 float(v["loss"])
-        prev = losses
+        prev = (cs, losses)
+    _resolve(prev[0])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
