@@ -492,7 +492,7 @@ int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *stream);
  * (w0 b0 w1 b1 w2 b2), desc.hidden = 128, param_image unused; vs_store / vnext_store are NOT written -- the update
  * computes V(obs) / V(obs_next) for all rows in two batched passes (a2c.py:121-127).  Everything else as
  * tsm_rollout_spread; results are bit-identical to tsm_mlp_forward -> tsm_categorical_sample -> tsm_mpe_spread_step ->
- * tsm_vrb_add step by step. */
+ * tsm_vrb_add step by step.  Up to eight agents (obs_dim <= 48; TSM_ERR_INVALID above: hosts keep the three-launch loop). */
 int tsm_rollout_spread_actor(const tsm_rollout_desc *desc, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

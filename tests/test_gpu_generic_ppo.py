@@ -413,6 +413,8 @@ def test_critic_rows_kernel_matches_float64_autograd(D, N, Mr, vclip, gen):
     from tianshou_marl_amd.utils.net import FlatMLP
 
     H, K1 = 128, N * D
+    if gen == 1 and not ops.ppo_critic_rows_supported(K1, [H, H], N, "relu"):
+        pytest.skip("the one-launch critic step of round 2 serves input widths up to 96 (wider ones: gen 2)")
     rng = np.random.default_rng(D + N + Mr)
     f = FlatMLP([K1, H, H, 1], device=DEV, seed=4)
     n_rows = Mr + 13

@@ -70,12 +70,13 @@ class GenericPPO(PPO):
                                                                               net.actor.act)
         # ... and the critic in its own single launch when it is in_dim -> 128 -> 128 -> 1 (row minibatches or a local
         # critic: the samples of a row are adjacent lanes)
-        self.fused_critic = self.fused_actor and ops.ppo_critic_rows_supported(
-            net.critic_obs_dim, net.critic.dims[1:-1], self.n_agent if critic_input == "global" else 1, net.critic.act) \
-            and net.critic.dims[-1] == 1
+        n_val = self.n_agent if critic_input == "global" else 1
+        gen1_ok = ops.ppo_critic_rows_supported(net.critic_obs_dim, net.critic.dims[1:-1], n_val, net.critic.act)  # (widths <= 96)
+        gen2_ok = (1 <= n_val <= 16 and os.environ.get("TSM_CRITIC_GEN", "2") != "1"
+                   and ops.critic_rows_grad_supported(net.critic_obs_dim, net.critic.dims[1:-1], 1, net.critic.act))
+        self.fused_critic = bool(self.fused_actor and net.critic.dims[-1] == 1 and (gen1_ok or gen2_ok))
         # second generation of the critic step (csrc/critic_train.hip + critic_dw1.hip: two launches, dW1 as a split-K pass)
-        self.critic_gen2 = self.fused_critic and os.environ.get("TSM_CRITIC_GEN", "2") != "1" and \
-            ops.critic_rows_grad_supported(net.critic_obs_dim, net.critic.dims[1:-1], 1, net.critic.act)
+        self.critic_gen2 = self.fused_critic and gen2_ok
         # ... optionally with dW2 formed by the split-K pass too (round 4 experiment, TSM_CRITIC_SPLIT_DW2=1: 14 MB less HBM
         # traffic per step but 2 us SLOWER -- the latency-bound dW1 launch grows by more than the tile kernel shrinks; DESIGN.md
         # section 4), default: a rank-32 dW2 slab per tile, side-reduced inside the dW1 launch

@@ -586,7 +586,6 @@ static int gae_impl(const float *v_s, const float *v_s_next, const float *rew, c
 #define BY_CH(G, F)                                          \
     do {                                                     \
         if (ch == 2) launch_gae<G, F, 1, 2>(ARGS);           \
-        else if (ch == 8) launch_gae<G, F, 1, 8>(ARGS);      \
         else launch_gae<G, F, 1, 4>(ARGS);                   \
     } while (0)
     if (generic) { if (flags_per_lane) BY_CH(true, true); else BY_CH(true, false); }

@@ -773,8 +773,7 @@ TSM_EXPORT int tsm_ppo_rows_init(void) {
     if (done) return TSM_OK;
 #define ALLOW(k) TSM_HIP(tsm_allow_max_lds(reinterpret_cast<const void *>(k)))
     ALLOW(ppo_actor_rows_kernel<1>); ALLOW(ppo_actor_rows_kernel<2>); ALLOW(ppo_actor_rows_kernel<3>); ALLOW(ppo_actor_rows_kernel<4>);
-    ALLOW(ppo_critic_rows_kernel<1>); ALLOW(ppo_critic_rows_kernel<2>); ALLOW(ppo_critic_rows_kernel<3>); ALLOW(ppo_critic_rows_kernel<4>);
-    ALLOW(ppo_critic_rows_kernel<6>); ALLOW(ppo_critic_rows_kernel<8>); ALLOW(ppo_critic_rows_kernel<12>);
+    ALLOW(ppo_critic_rows_kernel<1>); ALLOW(ppo_critic_rows_kernel<2>); ALLOW(ppo_critic_rows_kernel<3>);
 #undef ALLOW
     if (const int rc = tsm_actor_rows64_init(); rc != TSM_OK) return rc;
     done = true;
@@ -831,7 +830,10 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
 
 // ---- critic ----
 TSM_EXPORT int tsm_ppo_critic_rows_supported(int32_t in_dim, int32_t hidden, int32_t n_agent) {
-    return hidden == kH && in_dim >= 1 && in_dim <= 12 * kKs && n_agent >= 1 && n_agent <= 16;
+    // Up to three 32-column slices of the input (round 5): the instantiations for 4 / 6 / 8 / 12 slices spilled 7-14 vector registers
+    // (tools/resource_usage.py) and nothing selects them any more -- wider critics take the two-launch step of csrc/critic_train.hip
+    // (every width that is a multiple of 4, up to 384), odd widths above 96 the dense kernels.
+    return hidden == kH && in_dim >= 1 && in_dim <= 3 * kKs && n_agent >= 1 && n_agent <= 16;
 }
 
 TSM_EXPORT int64_t tsm_ppo_critic_rows_param_count(int32_t in_dim, int32_t hidden) {
@@ -877,10 +879,9 @@ TSM_EXPORT int tsm_ppo_critic_rows_update(const float *critic_params, int32_t in
         hipLaunchKernelGGL((ppo_critic_rows_kernel<NS>), dim3((unsigned)n_blocks), dim3(kThreads), shmem, st, g);      \
         break;
     switch (ns) {
-        LAUNCHC(1) LAUNCHC(2) LAUNCHC(3) LAUNCHC(4) LAUNCHC(6) LAUNCHC(8) LAUNCHC(12)
+        LAUNCHC(1) LAUNCHC(2) LAUNCHC(3)
         default:
-            TSM_REQUIRE(false, "tsm_ppo_critic_rows_update: in_dim = %d needs %d slices of 32 (instantiated: 1, 2, 3, 4, 6, 8, 12)",
-                        in_dim, ns);
+            TSM_REQUIRE(false, "tsm_ppo_critic_rows_update: in_dim = %d needs %d slices of 32 (instantiated: 1, 2, 3)", in_dim, ns);
     }
 #undef LAUNCHC
     TSM_LAUNCH_CHECK();

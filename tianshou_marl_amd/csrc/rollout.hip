@@ -829,7 +829,9 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
         // behind a second round of workgroups.
         const int form = tsm_opt(TSM_OPT_ROLLOUT_FORM);
         const int64_t total_waves = ceil_div(a.c.n_env, R / a.c.N);
-        if (form == 2 || (form == 0 && total_waves > 256)) {
+        // (observation widths above 48 -- nine or ten agents -- stay on the tile form: the wave form's four-block instantiation
+        //  spilled ten vector registers, tools/resource_usage.py, and was dropped in round 5)
+        if (a.d.nJ <= 3 && (form == 2 || (form == 0 && total_waves > 256))) {
             int n_waves = 1;
             while (n_waves < 4 && ceil_div(total_waves, n_waves) > 256) n_waves *= 2;
             const Rw64Lay wl;
@@ -856,8 +858,7 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
             switch (a.d.nJ) {
                 case 1: LAUNCHW(1); break;
                 case 2: LAUNCHW(2); break;
-                case 3: LAUNCHW(3); break;
-                default: LAUNCHW(4); break;
+                default: LAUNCHW(3); break;
             }
 #undef LAUNCHW
             TSM_LAUNCH_CHECK();

@@ -869,7 +869,9 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
     RrArgs a{};
     if (int rc = tsm_mpe_check_cfg(&h.env, &a.c)) return rc;
     TSM_REQUIRE(h.hidden == kH, "tsm_rollout_spread_actor: hidden must be 128 (got %d)", h.hidden);
-    TSM_REQUIRE(a.c.obs_dim == h.obs_dim && h.obs_dim <= 64, "tsm_rollout_spread_actor: obs_dim %d != 6 * n_agent (<= 64)", h.obs_dim);
+    // (up to eight agents: the four-block instantiations for observation widths 49..64 spilled 10-59 vector registers,
+    //  tools/resource_usage.py, and were dropped in round 5; the host collects such jobs through the three-launch loop)
+    TSM_REQUIRE(a.c.obs_dim == h.obs_dim && h.obs_dim <= 48, "tsm_rollout_spread_actor: obs_dim %d != 6 * n_agent (<= 48)", h.obs_dim);
     TSM_REQUIRE(h.n_act == 5, "tsm_rollout_spread_actor: simple_spread has 5 discrete actions");
     TSM_REQUIRE(a.c.N >= 1 && a.c.N <= kMpeMaxN, "tsm_rollout_spread_actor: n_agent out of range");
     TSM_REQUIRE(h.n_steps >= 1 && h.sub_size >= 1, "tsm_rollout_spread_actor: bad n_steps / sub_size");
@@ -894,7 +896,9 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
     a.offset_dev_rw = const_cast<uint64_t *>(reinterpret_cast<const uint64_t *>(h.offset_dev));
     a.stamps = g_tsm_stamps;
     hipStream_t st = tsm_stream(stream);
-    if (tsm_opt(TSM_OPT_ROLLOUT_FORM) != 1) {   // the wave-autonomous form (default); "rollout_form" = 1 selects the tile form
+    // the wave-autonomous form (default); "rollout_form" = 1 selects the tile form where it has a spill-free instantiation (widths
+    // up to 32: its three-block form spilled ten registers)
+    if (tsm_opt(TSM_OPT_ROLLOUT_FORM) != 1 || RrLay(h.obs_dim).nJ > 2) {
         const RwLay ly(h.obs_dim);
         const size_t shmem = (size_t)ly.total * sizeof(float);
         TSM_REQUIRE(shmem <= kTsmMaxLds, "tsm_rollout_spread_actor: LDS layout of %zu bytes does not fit", shmem);
@@ -919,8 +923,7 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
             switch (ly.nJ) {
                 case 1: LAUNCHW(1); break;
                 case 2: LAUNCHW(2); break;
-                case 3: LAUNCHW(3); break;
-                default: LAUNCHW(4); break;
+                default: LAUNCHW(3); break;
             }
         }
 #undef LAUNCHW
@@ -943,9 +946,7 @@ TSM_EXPORT int tsm_rollout_spread_actor(const tsm_rollout_desc *desc_host, void 
     } while (0)
     switch (ly.nJ) {
         case 1: LAUNCH(1); break;
-        case 2: LAUNCH(2); break;
-        case 3: LAUNCH(3); break;
-        default: LAUNCH(4); break;
+        default: LAUNCH(2); break;
     }
 #undef LAUNCH
     TSM_LAUNCH_CHECK();

@@ -619,7 +619,7 @@ def ppo_critic_rows_supported(in_dim: int, hidden_sizes, n_agent: int, act: str 
     """Does the one-launch critic step (csrc/ppo_rows.hip) cover this critic?  in_dim -> 128 -> 128 -> 1, ReLU."""
     hs = list(hidden_sizes)
     n_slice = -(-in_dim // 32)
-    ok = (act == "relu" and len(hs) == 2 and hs[0] == hs[1] and n_slice in (1, 2, 3, 4, 6, 8, 12)
+    ok = (act == "relu" and len(hs) == 2 and hs[0] == hs[1] and n_slice in (1, 2, 3)
           and bool(call("tsm_ppo_critic_rows_supported", in_dim, hs[0], n_agent)))
     if ok:
         _ppo_rows_init()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Registers, spills and occupancy of every gfx950 kernel in csrc/ (hipcc -Rpass-analysis=kernel-resource-usage; no GPU needed).
 
-    python tools/resource_usage.py [file.hip ...]        # default: every csrc/*.hip; prints kernels with spilled VGPRs first
+    python tools/resource_usage.py [--fail-on-spill] [file.hip ...]   # default: every csrc/*.hip; kernels with spilled VGPRs first
+                                                                      # --fail-on-spill: exit 1 if any kernel spills or uses scratch
 
 A run-time branch added to a kernel that sits at the 256-register limit can spill its DEFAULT form (round 4: the published
 H1 / dH2 stores of critic_rows_train_kernel cost the K1 = 384 PPO form 31 spilled registers and 1.9 us per launch until the
@@ -37,12 +38,26 @@ def usage(src: str) -> list:
     return out
 
 
+def spilling(rows: list) -> list:
+    """Kernels with spilled vector registers, or with a scratch frame at all (an array the compiler could not keep in registers
+    counts too) -- except `loss_kernel<0>`, whose run-time action count indexes a 16-entry local array by design (the stand-alone
+    loss for hosts that own the network, any A <= 16: 528 B of scratch, no spill; the instantiation for A = 5 has none)."""
+    return [r for r in rows if (r.get("VGPRs Spill", 0) or r.get("ScratchSize", 0)) and r["kernel"] != "loss_kernel<0>"]
+
+
 if __name__ == "__main__":
-    files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "tianshou_marl_amd", "csrc", "*.hip")))
-    rows = [r for f in files for r in usage(f)]
+    from concurrent.futures import ThreadPoolExecutor
+
+    args = [a for a in sys.argv[1:] if a != "--fail-on-spill"]
+    files = args or sorted(glob.glob(os.path.join(ROOT, "tianshou_marl_amd", "csrc", "*.hip")))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        rows = [r for rs in ex.map(usage, files) for r in rs]
     rows.sort(key=lambda r: (-r.get("VGPRs Spill", 0), -r.get("VGPRs", 0)))
     print(f"{'kernel':70s} {'file':22s} vgpr agpr spill scratch occ")
     for r in rows:
         print(f"{r['kernel'][:70]:70s} {r['file'][:22]:22s} {r.get('VGPRs', 0):4d} {r.get('AGPRs', 0):4d} {r.get('VGPRs Spill', 0):5d} "
               f"{r.get('ScratchSize', 0):7d} {r.get('Occupancy', 0):3d}")
     print(f"{sum(1 for r in rows if r.get('VGPRs Spill', 0))} of {len(rows)} kernels spill vector registers")
+    if "--fail-on-spill" in sys.argv[1:] and spilling(rows):
+        print("spills / scratch in: " + ", ".join(r["kernel"] for r in spilling(rows)))
+        raise SystemExit(1)
