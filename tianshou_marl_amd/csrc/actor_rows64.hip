@@ -166,15 +166,20 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
         xon[p] = e < kRows * n_piece;
     }
     float xv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    int64_t idx_x[2] = {-1, -1}, idx_h[2] = {-1, -1};
+    // Row ids as 32-bit integers (the host checks first_row + M and every permutation entry against 2^31: tsm_ppo_actor_rows_update):
+    // a row address is then ONE v_mad_u64_u32 off the base pointer instead of a 64 x 32-bit multiply chain, and a whole-width row
+    // piece (D == 16 NJ: 48 at BASELINE configs[2]) ONE 16-byte load instead of four predicated 4-byte loads -- the id / row fetches
+    // were ~300 of the ~820 non-MFMA vector instructions of a tile (round 5; f32 MFMAs and VALU instructions take turns on a SIMD)
+    int idx_x[2] = {-1, -1}, idx_h[2] = {-1, -1};
+    const bool full_rows = D == 16 * NJ;
     auto fetch_ids = [&](int64_t tile_) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             idx_x[p] = -1; idx_h[p] = -1;
             if (tile_ >= n_tiles) continue;
             const int64_t ix = tile_ * kRows + xr[p], ih = tile_ * kRows + hs + 32 * p;
-            if (xon[p] && ix < g.M) idx_x[p] = g.perm ? g.perm[ix] : g.first_row + ix;
-            if (ih < g.M) idx_h[p] = g.perm ? g.perm[ih] : g.first_row + ih;
+            if (xon[p] && ix < g.M) idx_x[p] = (int)(g.perm ? g.perm[ix] : g.first_row + ix);
+            if (ih < g.M) idx_h[p] = (int)(g.perm ? g.perm[ih] : g.first_row + ih);
         }
     };
     int h_act[2] = {0, 0}, n_act[2] = {0, 0};
@@ -184,16 +189,22 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
         for (int p = 0; p < 2; ++p) {
             xv[p][0] = xv[p][1] = xv[p][2] = xv[p][3] = 0.f;
             if (idx_x[p] >= 0) {
-                const float *src = g.obs + idx_x[p] * D + 4 * xp[p];
+                const float *src = g.obs + ((uint64_t)(uint32_t)idx_x[p] * (uint32_t)D + (uint32_t)(4 * xp[p]));
+                if (full_rows) {   // (uniform: rows are a whole number of 16-byte pieces, 16-byte aligned off a 256-byte aligned base)
+                    const float4 q = *reinterpret_cast<const float4 *>(src);
+                    xv[p][0] = q.x; xv[p][1] = q.y; xv[p][2] = q.z; xv[p][3] = q.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * xp[p] + j < D) xv[p][j] = src[j];
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * xp[p] + j < D) xv[p][j] = src[j];
+                }
             }
             n_act[p] = 0; n_adv[p] = 0.f; n_lpo[p] = 0.f;
             if (idx_h[p] >= 0) {
-                n_act[p] = g.act[idx_h[p]];
-                n_adv[p] = g.adv ? g.adv[idx_h[p]] : 1.f;
-                if (g.kind != 1) n_lpo[p] = g.logp_old[idx_h[p]];
+                const uint32_t ih = (uint32_t)idx_h[p];
+                n_act[p] = g.act[ih];
+                n_adv[p] = g.adv ? g.adv[ih] : 1.f;
+                if (g.kind != 1) n_lpo[p] = g.logp_old[ih];
             }
         }
     };

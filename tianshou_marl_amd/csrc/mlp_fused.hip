@@ -510,7 +510,15 @@ __device__ __forceinline__ void slab_store(float v, float *p) {
     else if (ST == 1) *p = v;
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int H, int NET, int ST>
+// PUB (round 5 experiment, VERDICT r4 item 1: "kernel A" of a two-kernel gradient step whose second kernel would form the weight
+// gradients as a K = M product and apply Adam): forward + loss + input-gradient backward only -- no weight-gradient MFMAs, no
+// bias sums, no slab; instead the tile's H1, H2, dH2, dH1 (16 x 64 each), X and d loss / d out go to `slabs` as 16-byte rows
+// (19.7 KB per tile and net instead of a 22.3 KB slab).  Reachable only through tsm_debug_set_update_variant(2): it produces
+// no gradient, it exists to TIME kernel A (tools/ab_kernel_a.py, profiles/r05_ab_kernel_a.txt).
+template <int H>
+constexpr int pub_floats(int ld1) { return 4 * R * H + R * ld1 + R * LayN<H>::ldo; }
+
+template <int H, int NET, int ST, bool PUB = false>
 __device__ __forceinline__ void ppo_update_net(
     float *lds, const float *__restrict__ P, const float *__restrict__ img, const Dims &d, const float *__restrict__ obs,
     const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
@@ -686,8 +694,10 @@ __device__ __forceinline__ void ppo_update_net(
         if (NET == 0) {
             const float *dA = lds + ln.D3 + kq * ln.ldo + r16;
             const float *hB = lds + ln.H2 + kq * ln.ldh + 16 * w + r16;
+            if constexpr (!PUB) {
 #pragma unroll
-            for (int k0 = 0; k0 < R; k0 += 4) g_W3 = mfma(dA[k0 * ln.ldo], hB[k0 * ln.ldh], g_W3);
+                for (int k0 = 0; k0 < R; k0 += 4) g_W3 = mfma(dA[k0 * ln.ldo], hB[k0 * ln.ldh], g_W3);
+            }
             f4 acc = zero;
             const float *dR = lds + ln.D3 + r16 * ln.ldo + kq;
             const float *wB = lds + ln.W3 + kq * ln.ldh + 16 * w + r16;
@@ -699,7 +709,7 @@ __device__ __forceinline__ void ppo_update_net(
                 const int row = kq * 4 + r;
                 lds[ln.D2 + row * ln.ldh + col] = lds[ln.H2 + row * ln.ldh + col] > 0.f ? acc[r] : 0.f;
             }
-            if (threadIdx.x < 16) {
+            if (!PUB && threadIdx.x < 16) {
                 float s = 0.f;
                 for (int r = 0; r < R; ++r) s += lds[ln.D3 + r * ln.ldo + threadIdx.x];
                 g_b3 += s;
@@ -710,12 +720,12 @@ __device__ __forceinline__ void ppo_update_net(
                 const float hv = lds[ln.H2 + r * ln.ldh + j];
                 lds[ln.D2 + r * ln.ldh + j] = hv > 0.f ? lds[ln.D3 + r * ln.ldo + 16] * lds[ln.W3 + j] : 0.f;
             }
-            if (threadIdx.x < H) {
+            if (!PUB && threadIdx.x < H) {
                 float s = 0.f;
                 for (int r = 0; r < R; ++r) s = fmaf(lds[ln.D3 + r * ln.ldo + 16], lds[ln.H2 + r * ln.ldh + threadIdx.x], s);
                 g_W3c += s;
             }
-            if (threadIdx.x == 0) {
+            if (!PUB && threadIdx.x == 0) {
                 float s = 0.f;
                 for (int r = 0; r < R; ++r) s += lds[ln.D3 + r * ln.ldo + 16];
                 g_b3 += s;
@@ -725,16 +735,18 @@ __device__ __forceinline__ void ppo_update_net(
         // ---- hidden layer 2 gradients + dh1 ----
         {
             const float *dA = lds + ln.D2 + kq * ln.ldh + 16 * w + r16;
+            if constexpr (!PUB) {
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                const float *hB = lds + ln.H1 + kq * ln.ldh + 16 * jb + r16;
+                for (int jb = 0; jb < 4; ++jb) {
+                    const float *hB = lds + ln.H1 + kq * ln.ldh + 16 * jb + r16;
 #pragma unroll
-                for (int k0 = 0; k0 < R; k0 += 4) g_W2[jb] = mfma(dA[k0 * ln.ldh], hB[k0 * ln.ldh], g_W2[jb]);
-            }
-            if (threadIdx.x < H) {
-                float s = 0.f;
-                for (int r = 0; r < R; ++r) s += lds[ln.D2 + r * ln.ldh + threadIdx.x];
-                g_b2 += s;
+                    for (int k0 = 0; k0 < R; k0 += 4) g_W2[jb] = mfma(dA[k0 * ln.ldh], hB[k0 * ln.ldh], g_W2[jb]);
+                }
+                if (threadIdx.x < H) {
+                    float s = 0.f;
+                    for (int r = 0; r < R; ++r) s += lds[ln.D2 + r * ln.ldh + threadIdx.x];
+                    g_b2 += s;
+                }
             }
             f4 acc = zero;
             const float *dR = lds + ln.D2 + r16 * ln.ldh + kq;
@@ -749,6 +761,19 @@ __device__ __forceinline__ void ppo_update_net(
             }
         }
         __syncthreads();
+        if constexpr (PUB) {   // ---- publish the tile instead of layer-1 gradients (rows as 16-byte pieces: 8-byte aligned in LDS) ----
+            float *pub = slabs + ((int64_t)t * 2 + NET) * pub_floats<H>(d.ld1);
+            const int pr = threadIdx.x >> 4, pc = (threadIdx.x & 15) * 4;
+            const int src[4] = {ln.H1, ln.H2, ln.D2, ln.D1};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float2 a0 = *reinterpret_cast<const float2 *>(lds + src[m] + pr * ln.ldh + pc);
+                const float2 a1 = *reinterpret_cast<const float2 *>(lds + src[m] + pr * ln.ldh + pc + 2);
+                __builtin_nontemporal_store(f4{a0.x, a0.y, a1.x, a1.y}, reinterpret_cast<f4 *>(pub + m * R * H + pr * H + pc));
+            }
+            for (int e = threadIdx.x; e < R * d.ld1; e += NT) __builtin_nontemporal_store(lds[ln.X + e], pub + 4 * R * H + e);
+            for (int e = threadIdx.x; e < R * ln.ldo; e += NT) __builtin_nontemporal_store(lds[ln.D3 + e], pub + 4 * R * H + R * d.ld1 + e);
+        } else
         // ---- layer 1 gradients ----
         {
             const float *dA = lds + ln.D1 + kq * ln.ldh + 16 * w + r16;
@@ -769,6 +794,7 @@ __device__ __forceinline__ void ppo_update_net(
     }
 
     // ---- this net's half of the workgroup's gradient slab ----
+    if constexpr (!PUB) {
     float *S = slabs + (int64_t)blockIdx.x * po.total;
     const int oW1 = NET ? po.cW1 : po.aW1, oW2 = NET ? po.cW2 : po.aW2;
     const int colq = r16;
@@ -793,6 +819,7 @@ __device__ __forceinline__ void ppo_update_net(
     }
     if (NET == 0 && threadIdx.x < d.A) slab_store<ST>(g_b3, &S[po.ab3 + threadIdx.x]);
     if (NET == 1 && threadIdx.x == 0) slab_store<ST>(g_b3, &S[po.cb3]);
+    }
     // loss partial sums: actor -> clip objective [0], entropy [2]; critic -> value loss [1]
     {
         __shared__ double s_red[2][NT / 64];
@@ -816,7 +843,7 @@ __device__ __forceinline__ void ppo_update_net(
 // DS: 0 = dimensions from the launch arguments; else the observation width this instantiation is compiled for (5 actions): the
 // headline job's 18 -- its index arithmetic (divisions by ld1 and D, layout offsets) then costs constants instead of ~35-instruction
 // integer divisions and scalar registers.
-template <int H, int ST, int DS>
+template <int H, int ST, int DS, bool PUB = false>
 __global__ __launch_bounds__(NT) void ppo_update_split_kernel(
     const float *__restrict__ P, const float *__restrict__ img, Dims d_arg, const float *__restrict__ obs,
     const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
@@ -828,11 +855,11 @@ __global__ __launch_bounds__(NT) void ppo_update_split_kernel(
     // device-resident optimizer step count (hipGraph replay): bumped here, read by the Adam kernel that follows
     if (opt_step_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *opt_step_dev += 1;
     if (blockIdx.y == 0)
-        ppo_update_net<H, 0, ST>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
-                             loss_partial);
+        ppo_update_net<H, 0, ST, PUB>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
+                                      loss_partial);
     else
-        ppo_update_net<H, 1, ST>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
-                             loss_partial);
+        ppo_update_net<H, 1, ST, PUB>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
+                                      loss_partial);
 }
 
 __global__ __launch_bounds__(256) void update_finalize_kernel(const double *__restrict__ partial, int n_blocks,
@@ -1032,7 +1059,14 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
         attr_set = true;
     }
     hipStream_t st = tsm_stream(stream);
-    if (g_update_variant == 0 && !g_tsm_stamps) {
+    if (g_update_variant == 2) {   // (experiment: kernel A alone, see ppo_update_net<..., PUB>; no gradient comes out of it)
+        TSM_REQUIRE(d.D == 18 && d.A == 5 && (int64_t)n_blocks == ceil_div(M, R) && param_image,
+                    "update variant 2 (kernel A timing) serves the headline shape only: obs 18, 5 actions, one tile per workgroup, image");
+        const LayN<64> ln(d);
+        hipLaunchKernelGGL((ppo_update_split_kernel<64, 0, 18, true>), dim3((unsigned)n_blocks, 2), dim3(NT),
+                           (size_t)ln.total * sizeof(float), st, params, param_image, d, obs, act, logp_old, adv, returns,
+                           v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out, loss_partial_out, opt_step_dev);
+    } else if (g_update_variant == 0 && !g_tsm_stamps) {
         // one net per workgroup (grid.y = actor | critic): see ppo_update_split_kernel
         const LayN<64> ln(d);
         const bool spec = d.A == 5 && !tsm_opt(TSM_OPT_GENERIC);   // ("generic_kernels": the generic instantiation)

@@ -789,6 +789,7 @@ TSM_EXPORT int tsm_ppo_actor_rows_update(const float *actor_params, int32_t obs_
                 "tsm_ppo_actor_rows_update supports hidden == 128, obs_dim <= 64, n_act <= 16 (got %d / %d / %d)", hidden,
                 obs_dim, n_act);
     TSM_REQUIRE(M >= 1 && cfg, "tsm_ppo_actor_rows_update: empty minibatch or null cfg");
+    TSM_REQUIRE(first_row >= 0 && first_row + M < ((int64_t)1 << 31), "tsm_ppo_actor_rows_update: row ids must stay below 2^31");
     TSM_REQUIRE(actor_params && obs && act && grad_slabs_out && loss_partial_out, "tsm_ppo_actor_rows_update: null pointer");
     TSM_REQUIRE(cfg->loss_kind == 1 || (logp_old && adv), "tsm_ppo_actor_rows_update: the clip objective needs logp_old and adv");
     TSM_REQUIRE(adv || !cfg->adv_norm, "tsm_ppo_actor_rows_update: adv_norm without adv");
