@@ -474,7 +474,7 @@ def kernel_rooflines(a, algo, buf):
                      "hbm_frac": upd_bytes / upd_s / HBM_PEAK,
                      "us_per_launch": upd_s * 1e6, "rows_per_launch": M,
                      "timing": "back_to_back: gap-inclusive (graph of 20 x (update, adam) minus 20 x adam, HIP events)",
-                     "in_situ_us_rocprof": in_situ_us("ppo_update_split_kernel"),
+                     "in_situ_us_rocprof": in_situ_us("ppo_update_split_kernel", grid=nb * 2 * 256),
                      "how": "graph of 20 x (ppo_update_kernel, adam_kernel) timed with HIP events, minus the same graph "
                             "of adam_kernel alone", "grad_step_us": step_s * 1e6, "adam_us": adam_s * 1e6},
         "roofline_gae": {"bound": "hbm", "kernel": "gae_lanes_kernel", "achieved": gae_bytes / gae_s / 1e9,
