@@ -3,7 +3,7 @@
 # next rollout), aggregated by name: count, total and per-launch duration.      bash tools/job_step_kernels.sh <default|c3ppo|c3|tag>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 wl=${1:-default}
-args="--steps 8 --warmup 4"; [ $wl != default ] && args="--workload $wl $args"; [ $wl = default ] && args="--no-cpu-baseline --no-c3-grid $args"
+args="--steps 8 --warmup 4"; [ $wl != default ] && args="--workload $wl $args"; [ $wl = default ] && args="--no-cpu-baseline --no-c3-grid --no-batch64 $args"
 rm -rf gpurun_out/tl
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o t -- python3 bench.py $args > /dev/null 2> gpurun_out/tl.err
 python - <<'PY'
