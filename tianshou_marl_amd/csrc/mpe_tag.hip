@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kTagThreads) void tag_step_kernel(
     TagCfg c, uint64_t seed, uint64_t *episode_ctr, const int32_t *__restrict__ act, float *apos, float *avel,
     float *lpos, int32_t *steps, float *obs_next, float *obs_cur, float *rew, uint8_t *term, uint8_t *trunc,
     uint8_t *done_env, int auto_reset, uint64_t *tick, uint64_t tick_inc) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int NA = c.n_adv + c.n_good;
     const int st = 2 * NA, lst = 2 * c.n_obst, row = NA * c.obs_dim;
     float *s_ap = sm;                                   // [16][NA][2]
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(kTagThreads) void tag_step_kernel(
     float *s_lp = s_av + kTagEnvPerBlock * st;          // [16][n_obst][2]
     float *s_hit = s_lp + kTagEnvPerBlock * (lst > 0 ? lst : 2);  // [16][NA] 10 * (adversaries touching good agent g)
     int *s_tr = reinterpret_cast<int *>(s_hit + kTagEnvPerBlock * NA);  // [16]
-    uint64_t *s_ep = reinterpret_cast<uint64_t *>(
-        (reinterpret_cast<uintptr_t>(s_tr + kTagEnvPerBlock) + 7) & ~(uintptr_t)7);  // [16]
+    uint64_t *s_ep = reinterpret_cast<uint64_t *>(   // [16]  (aligned by index arithmetic: keeps the pointer an LDS pointer)
+        sm + (((int)(reinterpret_cast<float *>(s_tr + kTagEnvPerBlock) - sm) + 1) & ~1));
     float *s_next = reinterpret_cast<float *>(s_ep + kTagEnvPerBlock);  // [16][row]
     const int e0 = blockIdx.x * kTagEnvPerBlock;
     const int n_here = min(kTagEnvPerBlock, c.n_env - e0);

@@ -80,7 +80,7 @@ struct RolloutArgs {
 // values, a multiply and a shift when they are constants.
 template <int H, int NT2, int DS = 0, int NS = 0>
 __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const Dims d = DS ? dims_const(DS, 5) : a.d;
     MpeCfg c_ = a.c;
     if (NS) { c_.N = NS; c_.obs_dim = DS; }
@@ -104,8 +104,11 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     int *s_act = reinterpret_cast<int *>(s_m + R);          // [R]
     int *s_steps = s_act + R;                               // [EPB]
     int *s_done = s_steps + R;                              // [EPB] done flag of the step just taken
+    // (8-byte alignment by INDEX arithmetic off the 16-byte aligned LDS base: rounding the address through uintptr_t made s_row /
+    //  s_ep generic pointers, every access to them a FLAT instruction, and every flat load waits for vmcnt(0) -- i.e. for all of the
+    //  step's outstanding global stores: round 5, 24 flat operations in this file)
     int64_t *s_row = reinterpret_cast<int64_t *>(                    // [EPB] slot*B + env of the step just added
-        (reinterpret_cast<uintptr_t>(s_done + R) + 7) & ~(uintptr_t)7);
+        lds + (((int)(reinterpret_cast<float *>(s_done + R) - lds) + 1) & ~1));
     uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + R);        // [EPB] episode counter of finished envs
     // s_done / s_row keep the values of step t until phase D of step t + 1 overwrites them, so phase C of step t + 1
     // reads them as "the previous step" (pending V(obs_next) stores) without a copy

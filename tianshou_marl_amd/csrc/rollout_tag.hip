@@ -72,7 +72,7 @@ constexpr int NT2 = 2 * NT;  // eight waves: actor chains on waves 0-3, critic c
 
 template <int H>
 __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const Dims d = a.d;
     const TagCfg c = a.c;
     const Lay<H> ly(d, false);                    // team 0: weights + the shared activation buffers
@@ -99,8 +99,10 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     int *s_act = reinterpret_cast<int *>(s_val + R);        // [R]
     int *s_steps = s_act + R;                               // [EPB]
     int *s_done = s_steps + R;                              // [EPB] done flag of the step just taken
+    // (aligned by index arithmetic off the 16-byte aligned base: an address rounded through uintptr_t is a generic pointer, its
+    //  accesses FLAT instructions that wait for every outstanding global store -- see csrc/rollout.hip)
     int64_t *s_row = reinterpret_cast<int64_t *>(                    // [EPB] slot*B + env of the step just added
-        (reinterpret_cast<uintptr_t>(s_done + R) + 7) & ~(uintptr_t)7);
+        lds + (((int)(reinterpret_cast<float *>(s_done + R) - lds) + 1) & ~1));
     uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + R);        // [EPB] episode counter of finished envs
 
     if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[40] = (long long)wall_clock64();
