@@ -432,6 +432,51 @@ struct LayN {  // LDS layout in floats of one net
 
 // weights of one net from the padded image (csrc/adam.hip keeps it current): every piece is a contiguous, 16-B aligned
 // run of the image; all loads are issued before the first LDS write (one memory round trip)
+template <int H>
+struct NetImageRegs {   // one net's weight image in flight: global loads issued by stage_net_image_load, LDS stores by _store
+    static constexpr int kIt1 = (H * (16 * kMaxJ + 2) / 4 + NT - 1) / NT, kIt2 = (H * LayN<H>::ldh / 4 + NT - 1) / NT;
+    static constexpr int kIt3 = (16 * LayN<H>::ldh / 4 + NT - 1) / NT;
+    f4 r1[kIt1], r2[kIt2], r3[kIt3];
+    float b1, b2, b3;
+};
+
+template <int H, int NET>
+__device__ __forceinline__ void stage_net_image_load(NetImageRegs<H> &q, const Lay<H> &ly, const Dims &d, const float *__restrict__ img) {
+    constexpr int kIt1 = NetImageRegs<H>::kIt1, kIt2 = NetImageRegs<H>::kIt2, kIt3 = NetImageRegs<H>::kIt3;
+    const f4 *s1 = reinterpret_cast<const f4 *>(img + ly.W1 + NET * H * d.ld1);
+    const f4 *s2 = reinterpret_cast<const f4 *>(img + (NET ? ly.W2c : ly.W2a));
+    const f4 *s3 = reinterpret_cast<const f4 *>(img + (NET ? ly.W3c : ly.W3a));
+    const int n1 = H * d.ld1 / 4, n2 = H * LayN<H>::ldh / 4, n3 = NET ? H / 4 : 16 * LayN<H>::ldh / 4;
+    // (unconditional loads at clamped indices -- the stores are predicated: no branch, so no wait, between two loads)
+#pragma unroll
+    for (int it = 0; it < kIt1; ++it) { const int i = threadIdx.x + it * NT; q.r1[it] = s1[i < n1 ? i : 0]; }
+#pragma unroll
+    for (int it = 0; it < kIt2; ++it) { const int i = threadIdx.x + it * NT; q.r2[it] = s2[i < n2 ? i : 0]; }
+#pragma unroll
+    for (int it = 0; it < kIt3; ++it) { const int i = threadIdx.x + it * NT; q.r3[it] = s3[i < n3 ? i : 0]; }
+    const int tb = threadIdx.x < H ? (int)threadIdx.x : 0, t3 = threadIdx.x < 16 ? (int)threadIdx.x : 0;
+    q.b1 = img[ly.B1 + NET * H + tb];
+    q.b2 = img[ly.B2 + NET * H + tb];
+    const float b3v = img[NET ? ly.B3c : ly.B3a + t3];
+    q.b3 = NET ? (threadIdx.x == 0 ? b3v : 0.f) : b3v;
+}
+
+template <int H, int NET>
+__device__ __forceinline__ void stage_net_image_store(float *lds, const NetImageRegs<H> &q, const LayN<H> &ln, const Dims &d) {
+    constexpr int kIt1 = NetImageRegs<H>::kIt1, kIt2 = NetImageRegs<H>::kIt2, kIt3 = NetImageRegs<H>::kIt3;
+    const int n1 = H * d.ld1 / 4, n2 = H * LayN<H>::ldh / 4, n3 = NET ? H / 4 : 16 * LayN<H>::ldh / 4;
+    f4 *d1 = reinterpret_cast<f4 *>(lds + ln.W1), *d2 = reinterpret_cast<f4 *>(lds + ln.W2);
+    f4 *d3 = reinterpret_cast<f4 *>(lds + ln.W3);
+#pragma unroll
+    for (int it = 0; it < kIt1; ++it) { const int i = threadIdx.x + it * NT; if (i < n1) d1[i] = q.r1[it]; }
+#pragma unroll
+    for (int it = 0; it < kIt2; ++it) { const int i = threadIdx.x + it * NT; if (i < n2) d2[i] = q.r2[it]; }
+#pragma unroll
+    for (int it = 0; it < kIt3; ++it) { const int i = threadIdx.x + it * NT; if (i < n3) d3[i] = q.r3[it]; }
+    if (threadIdx.x < H) { lds[ln.B1 + threadIdx.x] = q.b1; lds[ln.B2 + threadIdx.x] = q.b2; }
+    if (threadIdx.x < 16) lds[ln.B3 + threadIdx.x] = q.b3;
+}
+
 template <int H, int NET>
 __device__ __forceinline__ void stage_net_image(float *lds, const LayN<H> &ln, const Lay<H> &ly, const Dims &d,
                                                 const float *__restrict__ img) {
@@ -530,26 +575,55 @@ __device__ __forceinline__ void ppo_update_net(
     const int64_t n_tiles = (M + R - 1) / R;
     float xr[kXRegs];
     struct RowIn { int a_idx; float adv, logp_old, ret, v_old; } rin;
+    // (row ids: an unconditional load at a clamped index + a select, see prefetch_tile_ids)
     auto row_id = [&](int64_t row0) -> int64_t {
         const int64_t i = row0 + (threadIdx.x >> 4);
-        return i < M ? (perm ? perm[i] : first + i) : -1;
+        const int64_t v = perm ? perm[i < M ? i : row0] : first + i;
+        return i < M ? v : -1;
     };
-    auto prefetch_row = [&](int64_t src) {
+    auto prefetch_row = [&](int64_t src) {   // (unconditional loads at a clamped row + selects: one batch)
+        const int64_t s0 = src >= 0 ? src : 0;
+        const bool on = src >= 0;
         rin.a_idx = 0; rin.adv = 0.f; rin.logp_old = 0.f; rin.ret = 0.f; rin.v_old = 0.f;
-        if (src >= 0) {
-            if (NET == 0) { rin.a_idx = act[src]; rin.adv = adv[src]; rin.logp_old = logp_old[src]; }
-            else { rin.ret = returns[src]; if (cfg.value_clip) rin.v_old = v_s_old[src]; }
+        if (NET == 0) {
+            const int a_ = act[s0]; const float ad_ = adv[s0], lp_ = logp_old[s0];
+            rin.a_idx = on ? a_ : 0; rin.adv = on ? ad_ : 0.f; rin.logp_old = on ? lp_ : 0.f;
+        } else {
+            const float r_ = returns[s0];
+            rin.ret = on ? r_ : 0.f;
+            const float vo_ = (cfg.value_clip ? v_s_old : returns)[s0];   // (no branch around a load: its wait would be for everything)
+            rin.v_old = on && cfg.value_clip ? vo_ : 0.f;
         }
     };
-    int64_t xs[kXRegs];
-    if ((int64_t)blockIdx.x < n_tiles) {
-        prefetch_tile_ids(xs, d, perm, first, (int64_t)blockIdx.x * R, M);
-        const int64_t rsrc = row_id((int64_t)blockIdx.x * R);
-        prefetch_tile_vals(xr, xs, obs);
+    // Two dependent memory round trips in front of the first tile (round 5; five before): (1) the row ids AND the weight image,
+    // which depends on nothing, in one batch; (2) the id-dependent gathers.  Loads return in issue order, so the ids -- issued
+    // first -- are usable while the image is still in flight.
+    // The common case -- a permutation, the weight image, a first tile for every workgroup -- as ONE straight-line sequence: any
+    // branch between a load and its first use makes hipcc's wait conservative (it waited for the image before it used the ids).
+    if (perm && img && (int64_t)blockIdx.x < n_tiles) {
+        int64_t xs[kXRegs], id0[kXRegs + 1];
+        prefetch_tile_ids_load<1>(id0, d, perm, first, (int64_t)blockIdx.x * R, M);
+        NetImageRegs<H> wq;
+        const Lay<H> ly_img(d, true);
+        stage_net_image_load<H, NET>(wq, ly_img, d, img);
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the gathers below the image's LDS stores: a third round trip)
+        unsigned ok;
+        const int64_t rsrc = prefetch_tile_ids_done_nb(xs, ok, id0, d, (int64_t)blockIdx.x * R, M);
+        prefetch_tile_vals_nb(xr, xs, ok, obs);
         prefetch_row(rsrc);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_net_image_store<H, NET>(lds, wq, ln, d);
+    } else {
+        int64_t xs[kXRegs];
+        if ((int64_t)blockIdx.x < n_tiles) {
+            prefetch_tile_ids(xs, d, perm, first, (int64_t)blockIdx.x * R, M);
+            const int64_t rsrc = row_id((int64_t)blockIdx.x * R);
+            prefetch_tile_vals(xr, xs, obs);
+            prefetch_row(rsrc);
+        }
+        if (img) { const Lay<H> ly(d, true); stage_net_image<H, NET>(lds, ln, ly, d, img); }
+        else stage_net_flat<H, NET>(lds, ln, d, P);
     }
-    if (img) { const Lay<H> ly(d, true); stage_net_image<H, NET>(lds, ln, ly, d, img); }
-    else stage_net_flat<H, NET>(lds, ln, d, P);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const float invM = 1.0f / (float)M;

@@ -273,26 +273,78 @@ constexpr int kXRegs = (R * (16 * kMaxJ + 2) + NT - 1) / NT;  // X tile elements
 
 // Gather one X tile into registers in two phases so that other loads can be issued in between:
 //   phase A  row ids (perm)   -> xs[]      phase B  obs values (dependent on the row ids) -> xr[]
+// (Round 5: the row-id loads are UNCONDITIONAL loads at a clamped index, all issued before the first use.  Written with the load
+//  inside `if (c < D && i < M)` every iteration was its own basic block and hipcc waited for each id before issuing the next: three
+//  to five dependent memory round trips in front of the gathers of every launch of the update kernels -- the ISA showed
+//  load / s_waitcnt vmcnt(0) / load / s_waitcnt vmcnt(0) ...; row0 < M holds for every tile that is launched.)
+// phase A as two halves, so that a caller can put independent loads between the id loads and their first use:
+//   _load : id[it] = row id of X element threadIdx.x + it * NT (garbage where the element does not exist); id[kXRegs] = row id of
+//           tile row threadIdx.x >> 4 (the row whose loss-head inputs this thread fetches)
+//   _done : xs[it] = source offset of the element or -1; returns the row id of tile row threadIdx.x >> 4 or -1
+template <int HAS_PERM = -1>   // -1: decided at run time (a branch: the waits behind its join are conservative); 0 / 1: the caller knows
+__device__ __forceinline__ void prefetch_tile_ids_load(int64_t (&id)[kXRegs + 1], const Dims &d, const int64_t *__restrict__ perm,
+                                                       int64_t first, int64_t row0, int64_t M) {
+    const int64_t ir = row0 + (threadIdx.x >> 4);
+    if (HAS_PERM == 1 || (HAS_PERM == -1 && perm)) {
+#pragma unroll
+        for (int it = 0; it < kXRegs; ++it) {
+            const int e = threadIdx.x + it * NT, r = e / d.ld1;
+            const int64_t i = row0 + r;
+            id[it] = perm[(e < R * d.ld1 && i < M) ? i : row0];
+        }
+        id[kXRegs] = perm[ir < M ? ir : row0];
+    } else {
+#pragma unroll
+        for (int it = 0; it < kXRegs; ++it) id[it] = first + row0 + (threadIdx.x + it * NT) / d.ld1;
+        id[kXRegs] = first + ir;
+    }
+}
+__device__ __forceinline__ int64_t prefetch_tile_ids_done(int64_t (&xs)[kXRegs], const int64_t (&id)[kXRegs + 1], const Dims &d,
+                                                          int64_t row0, int64_t M) {
+#pragma unroll
+    for (int it = 0; it < kXRegs; ++it) {
+        const int e = threadIdx.x + it * NT, r = e / d.ld1, c = e - r * d.ld1;
+        xs[it] = (e < R * d.ld1 && c < d.D && row0 + r < M) ? id[it] * d.D + c : -1;
+    }
+    return row0 + (threadIdx.x >> 4) < M ? id[kXRegs] : -1;
+}
+// The same without a branch anywhere: every id was loaded at a clamped (valid) row, so id * D + min(c, D - 1) is a readable element
+// whatever the lane; `ok` keeps which of them the tile really holds.  (With the -1 form above hipcc turns the select around the
+// 64-bit multiply into a branch and SINKS the id's load into it, behind whatever was issued in between.)
+__device__ __forceinline__ int64_t prefetch_tile_ids_done_nb(int64_t (&xs)[kXRegs], unsigned &ok, const int64_t (&id)[kXRegs + 1],
+                                                             const Dims &d, int64_t row0, int64_t M) {
+    ok = 0;
+#pragma unroll
+    for (int it = 0; it < kXRegs; ++it) {
+        const int e = threadIdx.x + it * NT, r = e / d.ld1, c = e - r * d.ld1;
+        xs[it] = id[it] * d.D + (c < d.D ? c : 0);
+        ok |= (unsigned)(e < R * d.ld1 && c < d.D && row0 + r < M) << it;
+    }
+    return row0 + (threadIdx.x >> 4) < M ? id[kXRegs] : -1;
+}
+__device__ __forceinline__ void prefetch_tile_vals_nb(float (&xr)[kXRegs], const int64_t (&xs)[kXRegs], unsigned ok,
+                                                      const float *__restrict__ obs) {
+#pragma unroll
+    for (int it = 0; it < kXRegs; ++it) {
+        const float v = obs[xs[it]];
+        xr[it] = (ok >> it & 1u) ? v : 0.f;
+    }
+}
 __device__ __forceinline__ void prefetch_tile_ids(int64_t (&xs)[kXRegs], const Dims &d,
                                                   const int64_t *__restrict__ perm, int64_t first, int64_t row0,
                                                   int64_t M) {
-#pragma unroll
-    for (int it = 0; it < kXRegs; ++it) {
-        const int e = threadIdx.x + it * NT;
-        int64_t src = -1;
-        if (e < R * d.ld1) {
-            const int r = e / d.ld1, c = e - r * d.ld1;
-            const int64_t i = row0 + r;
-            if (c < d.D && i < M) src = (perm ? perm[i] : first + i) * d.D + c;
-        }
-        xs[it] = src;
-    }
+    int64_t id[kXRegs + 1];
+    prefetch_tile_ids_load(id, d, perm, first, row0, M);
+    (void)prefetch_tile_ids_done(xs, id, d, row0, M);
 }
 
 __device__ __forceinline__ void prefetch_tile_vals(float (&xr)[kXRegs], const int64_t (&xs)[kXRegs],
                                                    const float *__restrict__ obs) {
 #pragma unroll
-    for (int it = 0; it < kXRegs; ++it) xr[it] = xs[it] >= 0 ? obs[xs[it]] : 0.f;
+    for (int it = 0; it < kXRegs; ++it) {   // (unconditional loads at a clamped offset + a select: one batch, no branches)
+        const float v = obs[xs[it] >= 0 ? xs[it] : 0];
+        xr[it] = xs[it] >= 0 ? v : 0.f;
+    }
 }
 
 __device__ __forceinline__ void prefetch_tile_x(float (&xr)[kXRegs], const Dims &d, const float *__restrict__ obs,
