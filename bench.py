@@ -30,12 +30,12 @@ import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 MFMA_F32_PEAK = 157.3e12  # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix) 157.3 TFLOPS" (f32-input MFMA)
-# (round 5, measured: profiles/r05_probe_mfma_valu_overlap.txt -- the clock read directly, s_memtime / s_memrealtime around the loop)
-PEAK_NOTE = ("the f32-MFMA peak is 2.4 GHz x 256 flop/clk/CU; the part HOLDS 2.40 GHz under sustained f32-MFMA load on all 256 CUs "
-             "(s_memtime / s_memrealtime, profiles/r05_probe_mfma_valu_overlap.txt); back-to-back independent v_mfma_f32_16x16x4_f32 "
-             "issue at 0.86 of the nominal rate with two waves per SIMD (1.988 us per 128 MFMAs per SIMD) and 0.74 with one wave -- an "
-             "issue effect, not a clock; f32 MFMAs and the other VALU instructions of a SIMD take turns (no overlap), so frac ~= "
-             "matrix-pipe busy share x 0.86 at best")
+# (round 5, measured: profiles/r05_probe_mfma_f32_issue.txt -- the clock read directly, s_memtime / s_memrealtime around the loop)
+PEAK_NOTE = ("the f32-MFMA peak is 2.4 GHz x 256 flop/clk/CU; the part holds 2.39-2.40 GHz under sustained f32-MFMA load on all 256 "
+             "CUs, zero or random operands, and back-to-back v_mfma_f32_16x16x4_f32 / 32x32x2 issue at 0.99 of the nominal rate with 1, 2 "
+             "or 4 waves per SIMD (profiles/r05_probe_mfma_f32_issue.txt; the 0.86 / 0.74 of r05_probe_mfma_valu_overlap.txt were that "
+             "probe's own accumulator copies); f32 MFMAs and the f32 VALU instructions of the other wave of a SIMD take turns (0.856 us + "
+             "0.360 us alone -> 1.200 us together), so frac = the share of SIMD cycles that issue useful MFMAs: no clock or issue discount")
 
 
 def mlp_flops(dims) -> tuple[int, int]:

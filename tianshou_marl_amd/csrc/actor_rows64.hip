@@ -31,6 +31,7 @@ constexpr int kRT = 4;
 constexpr int kThreads = 512;  // 8 waves
 constexpr int kLdh = kH + 2;   // 130 = 2 x odd: conflict-free [lane & 15][lane >> 4] operand reads
 constexpr int kLdo = 18;
+constexpr int kPF = 1;         // steps (of <= 4 MFMAs) an MFMA stream's LDS operands are read ahead, mfma_stream
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -40,8 +41,28 @@ __device__ __forceinline__ int opaque_s(int x) {
     return x;
 }
 
+// An MFMA stream whose LDS operands are fetched PF steps ahead of the MFMAs that use them (round 5).  Written as the plain loop
+// "read the step's operands, issue its MFMAs", hipcc emits ds_read -> s_waitcnt lgkmcnt(0) -> MFMAs per step: the wave sits out one
+// LDS latency (100+ cycles under load) per 2-8 MFMAs (64-256 cycles), and the partner wave of the SIMD, in the same phase of
+// the same loop, cannot cover all of it -- the big phases ran at 0.77-0.81 of the matrix pipe's rate.  ld(s, r) reads step s's NR
+// operand values, mm(s, r) issues its MFMAs; both are unrolled, the ring of PF + 1 register sets is renaming, not copying.
+// The order of the MFMAs, and with it every sum, is the plain loop's.
+template <int N, int PF, int NR, typename L, typename C>
+__device__ __forceinline__ void mfma_stream(L ld, C mm) {
+    float r[PF + 1][NR];
+#pragma unroll
+    for (int s = 0; s < PF && s < N; ++s) ld(s, r[s % (PF + 1)]);
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        if (s + PF < N) ld(s + PF, r[(s + PF) % (PF + 1)]);
+        __builtin_amdgcn_sched_barrier(0);   // (without it the scheduler sinks the reads back to their first use)
+        mm(s, r[s % (PF + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 struct Lay64 {  // LDS layout in floats
-    int nJ = 0, ld1 = 0, W1 = 0, W3 = 0, B1 = 0, B2 = 0, B3 = 0, U = 0, X = 0, H1 = 0, H2 = 0, LG = 0, total = 0;
+    int nJ = 0, ld1 = 0, W1 = 0, W3 = 0, B1 = 0, B2 = 0, B3 = 0, U = 0, X = 0, H1 = 0, H2 = 0, LG = 0, HI = 0, total = 0;
     __host__ __device__ constexpr explicit Lay64(int D) {
         nJ = (D + 15) / 16;
         ld1 = 16 * nJ + 2;
@@ -52,10 +73,11 @@ struct Lay64 {  // LDS layout in floats
         B2 = o; o += kH;
         B3 = o; o += 16;
         U = o;                       // W2 [128][kLdh] while the fragments are loaded; the tile's activations afterwards
-        X = o; o += kRows * ld1;
+        X = o; o += 2 * kRows * ld1;     // two buffers: the next tile's rows land in the other one while this tile is computed
         H1 = o; o += kRows * kLdh;
         H2 = o; o += kRows * kLdh;
         LG = o; o += 2 * kRows * kLdo;   // the two k-halves of the logits; d loss / d logits in the first half afterwards
+        HI = o; o += 2 * kRows * 4;      // loss-head inputs [buffer][sample]{action, advantage, old log-prob, -}
         const int w2_end = U + kH * kLdh;
         total = o > w2_end ? o : w2_end;
     }
@@ -75,8 +97,7 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
     const int64_t n_tiles = (g.M + kRows - 1) / kRows;
     if (g.opt_step_dev && blockIdx.x == 0 && tid == 0) *g.opt_step_dev += 1;  // the gradient step this launch opens
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[200] = (long long)wall_clock64();
-    const int oX = opaque_s(ly.X), oH1 = opaque_s(ly.H1), oH2 = opaque_s(ly.H2), oLG = opaque_s(ly.LG), oW1l = opaque_s(ly.W1),
-              oW3l = opaque_s(ly.W3);
+    if (g.stamps && tid == 0 && blockIdx.x < 512) g.stamps[1024 + 2 * blockIdx.x] = (long long)wall_clock64();   // (>= 2048 slots) start / end of every workgroup
     const int col = 16 * w + c16;
 
     // ---- stage the weights once (zero pads: W1 columns >= D, W3 rows >= A); W2 passes through LDS into registers ----
@@ -150,7 +171,13 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
     // The partials are folded once, after the last tile.
     float gB1 = 0.f, gB2 = 0.f, gB3 = 0.f;
     const int bc = tid & 127, bq = tid >> 7;
-    double t_clip = 0.0, t_ent = 0.0;  // sample leaders (lane 0 of every 16-lane group)
+    // loss statistics of the sample leaders (lane 0 of every 16-lane group), in LDS between the tiles (four registers the loop
+    // does not have; only P4 touches them)
+    __shared__ double s_tstat[kThreads / 16][2];
+    if ((tid & 15) == 0) { s_tstat[tid >> 4][0] = 0.0; s_tstat[tid >> 4][1] = 0.0; }
+    // relu'(H1), relu'(H2) of the 16 elements this lane writes (bit mt * 4 + r): the backward pass masks with them instead of
+    // reading each element back (16 dependent LDS read -> write pairs per phase, 0.55-0.6 us per tile each, profiles/r04_stamp_actor_rows.txt)
+    unsigned live1 = 0, live2 = 0;
 
     // X tile: 64 samples x (4 NJ) 16-B pieces = two (sample, piece) slots per thread; loss-head inputs: samples hs, hs + 32
     // of the tile on the 16 lanes of group hs.  Ids are fetched TWO tiles ahead, rows / head inputs one tile ahead (id -> row
@@ -182,8 +209,8 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
             if (ih < g.M) idx_h[p] = (int)(g.perm ? g.perm[ih] : g.first_row + ih);
         }
     };
-    int h_act[2] = {0, 0}, n_act[2] = {0, 0};
-    float h_adv[2] = {0.f, 0.f}, h_lpo[2] = {0.f, 0.f}, n_adv[2] = {0.f, 0.f}, n_lpo[2] = {0.f, 0.f};
+    int n_act[2] = {0, 0};
+    float n_adv[2] = {0.f, 0.f}, n_lpo[2] = {0.f, 0.f};
     auto fetch_rows = [&]() {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -209,47 +236,70 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
         }
     };
     const float adv_mean = g.adv_norm ? g.adv_stats[0] : 0.f, adv_std = g.adv_norm ? g.adv_stats[1] : 1.f;
+    // The fetched rows and head inputs go to LDS buffer `buf` (round 5: they were held in 20 registers for a whole tile and
+    // committed in a phase of their own, P0, 0.4-1.0 us and a barrier per tile): fetched between the forward and the backward pass of
+    // tile t, written before its P6, read from P1 of tile t + 1 on -- behind the loop-end barrier.
+    auto commit_rows = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (xon[p]) {
+                float *dst = lds + ly.X + buf * (kRows * ld1) + xr[p] * ld1 + 4 * xp[p];   // (8-byte aligned: ld1 is even)
+                *reinterpret_cast<float2 *>(dst) = make_float2(xv[p][0], xv[p][1]);
+                *reinterpret_cast<float2 *>(dst + 2) = make_float2(xv[p][2], xv[p][3]);
+            }
+            if (hj == 0) {
+                float *hi = lds + ly.HI + (buf * kRows + hs + 32 * p) * 4;
+                *reinterpret_cast<float2 *>(hi) = make_float2(__int_as_float(n_act[p]), n_adv[p]);
+                hi[2] = n_lpo[p];
+            }
+        }
+    };
     int64_t tile = blockIdx.x;
     fetch_ids(tile);
     fetch_rows();
     fetch_ids(tile + gridDim.x);
     __syncthreads();  // every wave holds its W2 fragments: region U is free for the activations
+    commit_rows(0);
+    __syncthreads();
 
-    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[201] = (long long)wall_clock64();
+    if (g.stamps && blockIdx.x == 0 && tid == 0) { g.stamps[201] = (long long)wall_clock64(); g.stamps[204] = (long long)__builtin_amdgcn_s_memtime(); }
     for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+        // (made opaque INSIDE the loop: as loop invariants the phase base addresses built from them were hoisted and held ~30
+        // VGPRs for the whole loop -- the kernel sits at the 256-register cap of two waves per SIMD)
+        const int oX = opaque_s(ly.X), oH1 = opaque_s(ly.H1), oH2 = opaque_s(ly.H2), oLG = opaque_s(ly.LG), oW1l = opaque_s(ly.W1),
+                  oW3l = opaque_s(ly.W3);
+        const int cur = it & 1;
+        const int oXc = oX + cur * (kRows * ld1);   // this tile's rows
         ASTAMP(0);
-        // ---- P0: commit the prefetched X tile (the previous tile's readers are behind the loop-end barrier) ----
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            if (xon[p]) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) lds[oX + xr[p] * ld1 + 4 * xp[p] + j] = xv[p][j];
-            }
-            h_act[p] = n_act[p]; h_adv[p] = n_adv[p]; h_lpo[p] = n_lpo[p];
-        }
-        __syncthreads();
-        fetch_rows();                              // next tile's rows (its ids arrived during the previous tile) ...
-        fetch_ids(tile + 2 * (int64_t)gridDim.x);  // ... and the ids of the tile after it: both fly during the whole tile
-
         ASTAMP(1);
         // ---- P1: H1 = relu(X W1^T + b1) ----
         {
             f4 acc[kRT];
 #pragma unroll
             for (int mt = 0; mt < kRT; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
-            const float *a = lds + oX + c16 * ld1 + kq;
+            const float *a = lds + oXc + c16 * ld1 + kq;
             const float *b = lds + oW1l + col * ld1 + kq;
+            mfma_stream<4 * NJ, kPF, kRT + 1>(
+                [&](int s, float (&x)[kRT + 1]) {
+                    x[kRT] = b[4 * s];
 #pragma unroll
-            for (int k0 = 0; k0 < 16 * NJ; k0 += 4) {
-                const float bv = b[k0];
+                    for (int mt = 0; mt < kRT; ++mt) x[mt] = a[mt * 16 * ld1 + 4 * s];
+                },
+                [&](int, const float (&x)[kRT + 1]) {
 #pragma unroll
-                for (int mt = 0; mt < kRT; ++mt) acc[mt] = mfma4(a[mt * 16 * ld1 + k0], bv, acc[mt]);
-            }
+                    for (int mt = 0; mt < kRT; ++mt) acc[mt] = mfma4(x[mt], x[kRT], acc[mt]);
+                });
             const float bb = lds[ly.B1 + col];
+            live1 = 0;
 #pragma unroll
             for (int mt = 0; mt < kRT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lds[oH1 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    const float h = fmaxf(acc[mt][r] + bb, 0.f);
+                    live1 |= (unsigned)(h > 0.f) << (mt * 4 + r);
+                    lds[oH1 + (mt * 16 + kq * 4 + r) * kLdh + col] = h;
+                }
+            asm volatile("" : "+v"(live1));   // (one register of bits, not sixteen compare results held as lane masks until the backward pass)
         }
         __syncthreads();
         ASTAMP(2);
@@ -259,18 +309,33 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
 #pragma unroll
             for (int mt = 0; mt < kRT; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
             const float *a = lds + oH1 + c16 * kLdh + kq;
+            mfma_stream<32, kPF, kRT>(
+                [&](int ks, float (&x)[kRT]) {
 #pragma unroll
-            for (int ks = 0; ks < 32; ++ks) {
+                    for (int mt = 0; mt < kRT; ++mt) x[mt] = a[mt * 16 * kLdh + 4 * ks];
+                },
+                [&](int ks, const float (&x)[kRT]) {
 #pragma unroll
-                for (int mt = 0; mt < kRT; ++mt) acc[mt] = mfma4(a[mt * 16 * kLdh + 4 * ks], w2f[ks], acc[mt]);
-            }
+                    for (int mt = 0; mt < kRT; ++mt) acc[mt] = mfma4(x[mt], w2f[ks], acc[mt]);
+                });
+            ASTAMP(11);
             const float bb = lds[ly.B2 + col];
+            live2 = 0;
 #pragma unroll
             for (int mt = 0; mt < kRT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lds[oH2 + (mt * 16 + kq * 4 + r) * kLdh + col] = fmaxf(acc[mt][r] + bb, 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    const float h = fmaxf(acc[mt][r] + bb, 0.f);
+                    live2 |= (unsigned)(h > 0.f) << (mt * 4 + r);
+                    lds[oH2 + (mt * 16 + kq * 4 + r) * kLdh + col] = h;
+                }
+            asm volatile("" : "+v"(live2));
+            ASTAMP(12);
         }
         __syncthreads();
+        // the next tile's rows and head inputs (its ids arrived during the previous tile): issued where no 16-register accumulator set
+        // is live, in flight during the logits, the loss head and dW3 / dH2
+        fetch_rows();
         ASTAMP(3);
         // ---- P3: logits = H2 W3^T + b3 (A padded to 16) on all eight waves: wave w takes row block w & 3 and the k half
         //         w >> 2; the head adds the two halves and the bias ----
@@ -279,8 +344,9 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
             f4 acc = f4{0.f, 0.f, 0.f, 0.f};
             const float *a = lds + oH2 + (16 * mt + c16) * kLdh + kq + 64 * kh;
             const float *b = lds + oW3l + c16 * kLdh + kq + 64 * kh;
-#pragma unroll
-            for (int k0 = 0; k0 < 64; k0 += 4) acc = mfma4(a[k0], b[k0], acc);
+            mfma_stream<8, kPF, 4>(
+                [&](int s, float (&x)[4]) { x[0] = a[8 * s]; x[1] = b[8 * s]; x[2] = a[8 * s + 4]; x[3] = b[8 * s + 4]; },
+                [&](int, const float (&x)[4]) { acc = mfma4(x[0], x[1], acc); acc = mfma4(x[2], x[3], acc); });
 #pragma unroll
             for (int r = 0; r < 4; ++r) lds[oLG + (kh * kRows + 16 * mt + kq * 4 + r) * kLdo + c16] = acc[r];
         }
@@ -298,12 +364,14 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
                 logit[p] = (lg[hj] + lg[kRows * kLdo + hj]) + lds[ly.B3 + hj];
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                outv[p] = tsm_actor_head(g, live[p] ? logit[p] : 0.f, hj, lane, h_act[p], h_adv[p], h_lpo[p], adv_mean, adv_std, obj[p],
-                                         ent[p]);
+            for (int p = 0; p < 2; ++p) {
+                const float *hi = lds + ly.HI + (cur * kRows + hs + 32 * p) * 4;   // (one address per 16-lane group: a broadcast read)
+                outv[p] = tsm_actor_head(g, live[p] ? logit[p] : 0.f, hj, lane, __float_as_int(hi[0]), hi[1], hi[2], adv_mean, adv_std,
+                                         obj[p], ent[p]);
+            }
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                if (live[p] && hj == 0) { t_clip += obj[p]; t_ent += ent[p]; }
+                if (live[p] && hj == 0) { s_tstat[hs][0] += obj[p]; s_tstat[hs][1] += ent[p]; }
                 lds[oLG + (hs + 32 * p) * kLdo + hj] = live[p] ? outv[p] : 0.f;  // rows beyond M and actions beyond A: zero
             }
         }
@@ -313,8 +381,11 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
         {
             const float *a = lds + oLG + kq * kLdo + c16;            // A[i = a][k = row]
             const float *b = lds + oH2 + kq * kLdh + col;            // B[k = row][j = hidden col]
-#pragma unroll
-            for (int r0 = 0; r0 < kRows; r0 += 4) gW3 = mfma4(a[r0 * kLdo], b[r0 * kLdh], gW3);
+            mfma_stream<kRows / 8, kPF, 4>(
+                [&](int s, float (&x)[4]) {
+                    x[0] = a[8 * s * kLdo]; x[1] = b[8 * s * kLdh]; x[2] = a[(8 * s + 4) * kLdo]; x[3] = b[(8 * s + 4) * kLdh];
+                },
+                [&](int, const float (&x)[4]) { gW3 = mfma4(x[0], x[1], gW3); gW3 = mfma4(x[2], x[3], gW3); });
         }
         if (tid < 256) {
             const float *q = lds + oLG + 4 * (tid >> 4) * kLdo + (tid & 15);
@@ -326,35 +397,44 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
             for (int mt = 0; mt < kRT; ++mt) d2[mt] = f4{0.f, 0.f, 0.f, 0.f};
             const float *a = lds + oLG + c16 * kLdo + kq;            // A[i = row][k = a]
             const float *b = lds + oW3l + kq * kLdh + col;           // B[k = a][j = hidden col]
+            mfma_stream<4, kPF, kRT + 1>(
+                [&](int s, float (&x)[kRT + 1]) {
+                    x[kRT] = b[4 * s * kLdh];
 #pragma unroll
-            for (int k0 = 0; k0 < 16; k0 += 4) {
-                const float bv = b[k0 * kLdh];
+                    for (int mt = 0; mt < kRT; ++mt) x[mt] = a[mt * 16 * kLdo + 4 * s];
+                },
+                [&](int, const float (&x)[kRT + 1]) {
 #pragma unroll
-                for (int mt = 0; mt < kRT; ++mt) d2[mt] = mfma4(a[mt * 16 * kLdo + k0], bv, d2[mt]);
-            }
+                    for (int mt = 0; mt < kRT; ++mt) d2[mt] = mfma4(x[mt], x[kRT], d2[mt]);
+                });
             __syncthreads();  // every wave has read H2 for dW3
             ASTAMP(6);
 #pragma unroll
             for (int mt = 0; mt < kRT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float *p = lds + oH2 + (mt * 16 + kq * 4 + r) * kLdh + col;
-                    *p = *p > 0.f ? d2[mt][r] : 0.f;
-                }
+                for (int r = 0; r < 4; ++r)   // relu'(H2) from the bits this lane kept when it wrote the same elements of H2
+                    lds[oH2 + (mt * 16 + kq * 4 + r) * kLdh + col] = (live2 >> (mt * 4 + r) & 1u) ? d2[mt][r] : 0.f;
         }
+        commit_rows(cur ^ 1);
+        fetch_ids(tile + 2 * (int64_t)gridDim.x);   // the ids of the tile after the next: in flight until the next tile's P3
         __syncthreads();
         ASTAMP(7);
         // ---- P6: dW2 += dH2^T H1 ; db2 ; dH1 = (dH2 W2) * relu'(H1), W2 fragments from registers ----
         {
             const float *a = lds + oH2 + kq * kLdh + col;            // A[i = out o][k = row]
             const float *b = lds + oH1 + kq * kLdh + c16;            // B[k = row][j = in col]
-#pragma unroll 4
-            for (int r0 = 0; r0 < kRows; r0 += 4) {
-                const float av = a[r0 * kLdh];
+            mfma_stream<kRows / 4, 1, 9>(
+                [&](int s, float (&x)[9]) {
+                    x[8] = a[4 * s * kLdh];
 #pragma unroll
-                for (int ti = 0; ti < 8; ++ti) gW2[ti] = mfma4(av, b[r0 * kLdh + 16 * ti], gW2[ti]);
-            }
+                    for (int ti = 0; ti < 8; ++ti) x[ti] = b[4 * s * kLdh + 16 * ti];
+                },
+                [&](int, const float (&x)[9]) {
+#pragma unroll
+                    for (int ti = 0; ti < 8; ++ti) gW2[ti] = mfma4(x[8], x[ti], gW2[ti]);
+                });
         }
+        ASTAMP(13);
         {
             const float *q = lds + oH2 + 16 * bq * kLdh + bc;
             float s0 = 0.f, s1 = 0.f;
@@ -363,37 +443,45 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
             gB2 += s0 + s1;
         }
         {
+            ASTAMP(14);
             f4 d1[kRT];
 #pragma unroll
             for (int mt = 0; mt < kRT; ++mt) d1[mt] = f4{0.f, 0.f, 0.f, 0.f};
             const float *a = lds + oH2 + c16 * kLdh + kq;            // A[i = row][k = o]
+            mfma_stream<32, kPF, kRT>(
+                [&](int ks, float (&x)[kRT]) {
 #pragma unroll
-            for (int ks = 0; ks < 32; ++ks) {
+                    for (int mt = 0; mt < kRT; ++mt) x[mt] = a[mt * 16 * kLdh + 4 * ks];
+                },
+                [&](int ks, const float (&x)[kRT]) {
 #pragma unroll
-                for (int mt = 0; mt < kRT; ++mt) d1[mt] = mfma4(a[mt * 16 * kLdh + 4 * ks], w2b[ks], d1[mt]);
-            }
+                    for (int mt = 0; mt < kRT; ++mt) d1[mt] = mfma4(x[mt], w2b[ks], d1[mt]);
+                });
+            ASTAMP(15);
             __syncthreads();  // every wave has read H1 for dW2
             ASTAMP(8);
 #pragma unroll
             for (int mt = 0; mt < kRT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float *p = lds + oH1 + (mt * 16 + kq * 4 + r) * kLdh + col;
-                    *p = *p > 0.f ? d1[mt][r] : 0.f;
-                }
+                for (int r = 0; r < 4; ++r)
+                    lds[oH1 + (mt * 16 + kq * 4 + r) * kLdh + col] = (live1 >> (mt * 4 + r) & 1u) ? d1[mt][r] : 0.f;
         }
         __syncthreads();
         ASTAMP(9);
         // ---- P7: dW1 += dH1^T X ; db1 ----
         {
             const float *a = lds + oH1 + kq * kLdh + col;            // A[i = out o][k = row]
-            const float *b = lds + oX + kq * ld1 + c16;              // B[k = row][j = obs col]
-#pragma unroll 4
-            for (int r0 = 0; r0 < kRows; r0 += 4) {
-                const float av = a[r0 * kLdh];
+            const float *b = lds + oXc + kq * ld1 + c16;             // B[k = row][j = obs col]
+            mfma_stream<kRows / 4, kPF, NJ + 1>(
+                [&](int s, float (&x)[NJ + 1]) {
+                    x[NJ] = a[4 * s * kLdh];
 #pragma unroll
-                for (int ti = 0; ti < NJ; ++ti) gW1[ti] = mfma4(av, b[r0 * ld1 + 16 * ti], gW1[ti]);
-            }
+                    for (int ti = 0; ti < NJ; ++ti) x[ti] = b[4 * s * ld1 + 16 * ti];
+                },
+                [&](int, const float (&x)[NJ + 1]) {
+#pragma unroll
+                    for (int ti = 0; ti < NJ; ++ti) gW1[ti] = mfma4(x[NJ], x[ti], gW1[ti]);
+                });
         }
         {
             const float *q = lds + oH1 + 16 * bq * kLdh + bc;
@@ -407,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
     }
 
     // ---- the workgroup's gradient slab: written once, streamed (consumed once, by the reduction kernel) ----
-    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[202] = (long long)wall_clock64();
+    if (g.stamps && blockIdx.x == 0 && tid == 0) { g.stamps[202] = (long long)wall_clock64(); g.stamps[205] = (long long)__builtin_amdgcn_s_memtime(); }
     float *slab = g.slabs + (size_t)blockIdx.x * (size_t)(oB3 + A);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -423,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
         if (a < A) __builtin_nontemporal_store(gW3[r], slab + oW3 + a * kH + 16 * w + c16);
     }
     {   // fold the bias partials (fixed order) through the now idle activation region
-        float *sc = lds + oX;   // [4][128] db1 | [4][128] db2 | [16][16] db3
+        float *sc = lds + ly.X;   // [4][128] db1 | [4][128] db2 | [16][16] db3
         sc[bq * 128 + bc] = gB1;
         sc[512 + bq * 128 + bc] = gB2;
         if (tid < 256) sc[1024 + tid] = gB3;
@@ -440,6 +528,7 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
     }
     {   // loss statistics: the sample leaders (lane 0 of each 16-lane group) hold the terms; fixed order: wave sums, then waves
         __shared__ double s_stat[2][kThreads / 64];
+        const double t_clip = hj == 0 ? s_tstat[hs][0] : 0.0, t_ent = hj == 0 ? s_tstat[hs][1] : 0.0;   // (written by this thread)
         const double c = wave_sum(t_clip), e = wave_sum(t_ent);
         if (lane == 0) { s_stat[0][w] = c; s_stat[1][w] = e; }
         __syncthreads();
@@ -451,6 +540,7 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
             g.partial[4 * blockIdx.x + 2] = ee;
             g.partial[4 * blockIdx.x + 3] = 0.0;
             if (g.stamps && blockIdx.x == 0) g.stamps[203] = (long long)wall_clock64();
+            if (g.stamps && blockIdx.x < 512) g.stamps[1025 + 2 * blockIdx.x] = (long long)wall_clock64();
         }
     }
 }

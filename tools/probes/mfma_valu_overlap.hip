@@ -1,3 +1,7 @@
+// NOTE (round 5): the MFMA lines of this probe contain 64 v_accvgpr copies per 64 MFMAs -- the role of a wave is chosen INSIDE the
+// loop, so the accumulators cross a branch every repetition.  Its "all 8 waves: MFMA only" 1.98 us (37 cycles per MFMA) is therefore
+// NOT the pipe's issue rate: tools/probes/mfma_f32_issue.hip measures 32.2 cycles at 1, 2 and 4 waves per SIMD and repeats the
+// overlap question in clean loops (0.856 + 0.360 -> 1.200 us: the conclusion stands).
 // (also: the same question for a bf16 MFMA, v_mfma_f32_16x16x16_bf16)
 // Probe: do the MFMAs of one wave and the VALU instructions of ANOTHER wave of the same SIMD overlap on gfx950?
 // One workgroup of 512 threads per CU (two waves per SIMD).  Modes: every wave runs `mf` blocks of 64 MFMAs
