@@ -110,6 +110,9 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     int64_t *s_row = reinterpret_cast<int64_t *>(                    // [EPB] slot*B + env of the step just added
         lds + (((int)(reinterpret_cast<float *>(s_done + R) - lds) + 1) & ~1));
     uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + R);        // [EPB] episode counter of finished envs
+    float *s_cx = lds + (((int)(reinterpret_cast<float *>(s_ep + R) - lds) + 3) & ~3);   // [R][8] pair forces of (row, other agent), phase D; 16-byte rows
+    float *s_cy = s_cx + R * 8;
+    int *s_cv = reinterpret_cast<int *>(s_cy + R * 8);               // [R][8] "the pair is in range"
     // s_done / s_row keep the values of step t until phase D of step t + 1 overwrites them, so phase C of step t + 1
     // reads them as "the previous step" (pending V(obs_next) stores) without a copy
 
@@ -123,12 +126,12 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     }
     for (int i = threadIdx.x; i < R * d.ld1; i += NT2) { lds[ly.X + i] = 0.f; XN0[i] = 0.f; }
     const VrbState vs = vrb_view(a.vrb_state, B, N);
-    // agent lane r < rows_here (wave 0) <-> (env el, agent i); env lane 64 + q (wave 1) owns env q's bookkeeping, so
-    // the buffer index algebra runs beside the agent lanes' physics instead of after it
+    // agent lane r < rows_here (wave 0) <-> (env el, agent i); env lane 128 + q (wave 2) owns env q's bookkeeping, so
+    // the buffer index algebra runs beside the physics (the pair forces on waves 0-1) instead of after it
     const int r = threadIdx.x, el = r / N, ai = r - el * N;
     const bool lane_live = r < rows_here;
     const int e = e0 + el;
-    const int bel = (int)threadIdx.x - 64;  // env lane: local env index
+    const int bel = (int)threadIdx.x - 128;  // env lane: local env index
     const bool env_lane = bel >= 0 && bel < n_here;
     const int be = e0 + bel;
     // sub-buffer bookkeeping of "my" env lives in registers for the whole rollout: the per-step index algebra
@@ -229,8 +232,21 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         // D. env step, one lane per agent (mpe_dev.h): move -> barrier -> publish -> barrier -> reward terms.
         //    Beside the move, the env lanes do the buffer index algebra on their register-resident sub-buffer state
         //    (buffer_base.py:373-410 + manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h).
-        float npx = 0.f, npy = 0.f, nvx = 0.f, nvy = 0.f;
-        if (lane_live) mpe_agent_move(c, s_ap + el * st, s_av + el * st, ai, s_act[r], npx, npy, nvx, nvy);
+        // (round 5: the pair forces as one (agent row, other agent) task per thread of waves 0-1, folded by the agent lanes in partner
+        //  order -- mpe_agent_move's sums, rollout_wave64_kernel's scheme.  One lane per agent ran its N - 1 pair evaluations -- sqrt,
+        //  exp, log1p, a division each when the pair is in range -- one after the other: 1.3-1.7 us of a 5.6 us step,
+        //  profiles/r05_stamp_rollout.txt.)
+        if (threadIdx.x < R * 8) {
+            const int rp = threadIdx.x >> 3, jp = threadIdx.x & 7;
+            float sx = 0.f, sy = 0.f;
+            int ok = 0;
+            if (rp < rows_here && jp < N) {
+                const int ep = rp / N, ip = rp - ep * N;
+                const float *ap = s_ap + ep * st;
+                if (jp != ip) ok = mpe_pair_force(c, ap[2 * ip], ap[2 * ip + 1], ap[2 * jp], ap[2 * jp + 1], ip, jp, sx, sy) ? 1 : 0;
+            }
+            s_cx[threadIdx.x] = sx; s_cy[threadIdx.x] = sy; s_cv[threadIdx.x] = ok;
+        }
         bool tr = false, rec = false;
         int64_t o = 0;
         if (env_lane) {
@@ -256,9 +272,25 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
             s_row[bel] = cur * B + be;
             s_done[bel] = tr ? 1 : 0;
         }
+        XSTAMP(5);   // (wave 0 is through its own part: the pair forces)
         __syncthreads();
         XSTAMP(0);
-        if (lane_live) {
+        if (lane_live) {   // fold, integrate, publish: a lane reads and writes its own agent's position / velocity only
+            const float px = s_ap[el * st + 2 * ai], py = s_ap[el * st + 2 * ai + 1];
+            const float vx = s_av[el * st + 2 * ai], vy = s_av[el * st + 2 * ai + 1];
+            float fx = mpe_action_force(c, s_act[r], 0);
+            float fy = mpe_action_force(c, s_act[r], 1);
+            typedef int i4 __attribute__((ext_vector_type(4)));
+            const i4 v0 = *reinterpret_cast<const i4 *>(s_cv + 8 * r), v1 = *reinterpret_cast<const i4 *>(s_cv + 8 * r + 4);
+            const f4 x0 = *reinterpret_cast<const f4 *>(s_cx + 8 * r), x1 = *reinterpret_cast<const f4 *>(s_cx + 8 * r + 4);
+            const f4 y0 = *reinterpret_cast<const f4 *>(s_cy + 8 * r), y1 = *reinterpret_cast<const f4 *>(s_cy + 8 * r + 4);
+#pragma unroll
+            for (int j = 0; j < kMpeMaxN; ++j) {
+                const int ok = j < 4 ? v0[j & 3] : v1[j & 3];
+                if (j < N && ok) { fx += j < 4 ? x0[j & 3] : x1[j & 3]; fy += j < 4 ? y0[j & 3] : y1[j & 3]; }
+            }
+            float npx, npy, nvx, nvy;
+            mpe_integrate(c, px, py, vx, vy, fx, fy, npx, npy, nvx, nvy);
             s_ap[el * st + 2 * ai] = npx; s_ap[el * st + 2 * ai + 1] = npy;
             s_av[el * st + 2 * ai] = nvx; s_av[el * st + 2 * ai + 1] = nvy;
         }
@@ -868,7 +900,7 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
             return TSM_OK;
         }
     }
-    const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8;
+    const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8 + 3 * R * 8 + 4;
     const size_t shmem = ((size_t)ly.total + extra) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
