@@ -89,40 +89,59 @@ __device__ __forceinline__ float tag_obs_elem(const TagCfg &c, const float *ap, 
     return 0.f;  // padding of the good agents' rows
 }
 
-// One step of agent i (action a): soft contact forces from every other entity in increasing entity index -- the order in
-// which the serial pair loop (lo < hi) accumulates into f[i] -- then damping, speed clamp and integration.
-__device__ __forceinline__ void tag_agent_move(const TagCfg &c, const float *ap, const float *av, const float *lp, int i,
-                                               int a, float &npx, float &npy, float &nvx, float &nvy) {
-    const int NA = c.n_adv + c.n_good, NE = NA + c.n_obst;
-    const bool is_adv = i < c.n_adv;
-    const float my_size = is_adv ? c.adv_size : c.good_size;
-    const float accel = is_adv ? c.adv_accel : c.good_accel;
-    float fx = (a == 1 ? -1.f : (a == 2 ? 1.f : 0.f)) * accel;
-    float fy = (a == 3 ? -1.f : (a == 4 ? 1.f : 0.f)) * accel;
+// The soft contact force entity j (agent or obstacle) exerts on agent i: false when the pair is out of range (the force is exactly
+// 0 there).  Pair (lo, hi) = (min, max) of (i, j): d = p_lo - p_hi; f_lo += s d, f_hi -= s d -- returned as the term ADDED to f[i]
+// (a - b == a + (-b) bit for bit).  One call per (i, j): the fused rollout spreads the calls over threads (rollout_tag.hip, phase D).
+__device__ __forceinline__ bool tag_pair_force(const TagCfg &c, const float *ap, const float *lp, int i, int j, float &sx, float &sy) {
+    const int NA = c.n_adv + c.n_good;
+    const float my_size = i < c.n_adv ? c.adv_size : c.good_size;
     const float px = ap[2 * i], py = ap[2 * i + 1];
-    for (int j = 0; j < NE; ++j) {  // wave-uniform trip count
-        if (j == i) continue;
-        const float qx = j < NA ? ap[2 * j] : lp[2 * (j - NA)], qy = j < NA ? ap[2 * j + 1] : lp[2 * (j - NA) + 1];
-        const float sj = j < NA ? (j < c.n_adv ? c.adv_size : c.good_size) : c.obst_size;
-        // pair (lo, hi) = (min, max) of (i, j): d = p_lo - p_hi; f_lo += s d, f_hi -= s d
-        const float dx = i < j ? px - qx : qx - px, dy = i < j ? py - qy : qy - py;
-        const float dmin = i < j ? my_size + sj : sj + my_size;
-        const float d2 = dx * dx + dy * dy;
-        const float far = dmin + 105.f * c.contact_margin;  // beyond it expf underflows: the force is exactly 0
-        if (d2 > far * far) continue;
-        const float dist = sqrtf(d2);
-        const float pen = softplus_k(-(dist - dmin) / c.contact_margin, c.contact_margin);
-        const float s = c.contact_force * pen / dist;
-        if (i < j) { fx += s * dx; fy += s * dy; }
-        else { fx -= s * dx; fy -= s * dy; }
-    }
-    nvx = av[2 * i] * (1.f - c.damping) + fx * c.dt;
-    nvy = av[2 * i + 1] * (1.f - c.damping) + fy * c.dt;
-    const float vmax = is_adv ? c.adv_speed : c.good_speed;
+    const float qx = j < NA ? ap[2 * j] : lp[2 * (j - NA)], qy = j < NA ? ap[2 * j + 1] : lp[2 * (j - NA) + 1];
+    const float sj = j < NA ? (j < c.n_adv ? c.adv_size : c.good_size) : c.obst_size;
+    const float dx = i < j ? px - qx : qx - px, dy = i < j ? py - qy : qy - py;
+    const float dmin = i < j ? my_size + sj : sj + my_size;
+    const float d2 = dx * dx + dy * dy;
+    const float far = dmin + 105.f * c.contact_margin;  // beyond it expf underflows: the force is exactly 0
+    if (d2 > far * far) return false;
+    const float dist = sqrtf(d2);
+    const float pen = softplus_k(-(dist - dmin) / c.contact_margin, c.contact_margin);
+    const float s = c.contact_force * pen / dist;
+    const float tx = s * dx, ty = s * dy;
+    sx = i < j ? tx : -tx;
+    sy = i < j ? ty : -ty;
+    return true;
+}
+
+__device__ __forceinline__ void tag_action_force(const TagCfg &c, int i, int a, float &fx, float &fy) {
+    const float accel = i < c.n_adv ? c.adv_accel : c.good_accel;
+    fx = (a == 1 ? -1.f : (a == 2 ? 1.f : 0.f)) * accel;
+    fy = (a == 3 ? -1.f : (a == 4 ? 1.f : 0.f)) * accel;
+}
+
+// Damping, speed clamp and explicit Euler step of agent i under the total force (fx, fy).
+__device__ __forceinline__ void tag_integrate(const TagCfg &c, int i, float px, float py, float vx, float vy, float fx, float fy,
+                                              float &npx, float &npy, float &nvx, float &nvy) {
+    nvx = vx * (1.f - c.damping) + fx * c.dt;
+    nvy = vy * (1.f - c.damping) + fy * c.dt;
+    const float vmax = i < c.n_adv ? c.adv_speed : c.good_speed;
     const float sp = sqrtf(nvx * nvx + nvy * nvy);
     if (sp > vmax) { nvx = nvx / sp * vmax; nvy = nvy / sp * vmax; }
     npx = px + nvx * c.dt;
     npy = py + nvy * c.dt;
+}
+
+// One step of agent i (action a): soft contact forces from every other entity in increasing entity index -- the order in
+// which the serial pair loop (lo < hi) accumulates into f[i] -- then damping, speed clamp and integration.
+__device__ __forceinline__ void tag_agent_move(const TagCfg &c, const float *ap, const float *av, const float *lp, int i,
+                                               int a, float &npx, float &npy, float &nvx, float &nvy) {
+    const int NE = c.n_adv + c.n_good + c.n_obst;
+    float fx, fy;
+    tag_action_force(c, i, a, fx, fy);
+    for (int j = 0; j < NE; ++j) {  // wave-uniform trip count
+        float sx, sy;
+        if (j != i && tag_pair_force(c, ap, lp, i, j, sx, sy)) { fx += sx; fy += sy; }
+    }
+    tag_integrate(c, i, ap[2 * i], ap[2 * i + 1], av[2 * i], av[2 * i + 1], fx, fy, npx, npy, nvx, nvy);
 }
 
 // Own reward terms of agent i on the NEW positions (ap) -- a good agent: -10 per adversary touching it, minus the boundary

@@ -104,6 +104,10 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     int64_t *s_row = reinterpret_cast<int64_t *>(                    // [EPB] slot*B + env of the step just added
         lds + (((int)(reinterpret_cast<float *>(s_done + R) - lds) + 1) & ~1));
     uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + R);        // [EPB] episode counter of finished envs
+    constexpr int kPS = 16;                                          // pair slots per row (entities: <= 8 agents + 4 obstacles)
+    float *s_cx = lds + (((int)(reinterpret_cast<float *>(s_ep + R) - lds) + 3) & ~3);   // [R][kPS] pair forces, phase D; 16-byte rows
+    float *s_cy = s_cx + R * kPS;
+    int *s_cv = reinterpret_cast<int *>(s_cy + R * kPS);             // [R][kPS] "the pair is in range"
 
     if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[40] = (long long)wall_clock64();
     // waves 0-3 stage team 0's weights, waves 4-7 team 1's (batches of 4 loads per thread: ~1 us per workgroup)
@@ -111,11 +115,12 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     else stage_weights<H>(lds + wB, ly, d, a.P[1], (int)threadIdx.x - NT);
     for (int i = threadIdx.x; i < R * d.ld1; i += NT2) { lds[ly.X + i] = 0.f; lds[xn0 + i] = 0.f; }
     const VrbState vs = vrb_view(a.vrb_state, B, NA);
-    // agent lane r < rows_here (wave 0) <-> (env el, agent ai); env lane 64 + q (wave 1) owns env q's bookkeeping
+    // agent lane r < rows_here (wave 0) <-> (env el, agent ai); env lane 256 + q (wave 4) owns env q's bookkeeping (beside the pair
+    // forces on waves 0-3)
     const int r = threadIdx.x, el = r / NA, ai = r - el * NA;
     const bool lane_live = r < rows_here;
     const int e = e0 + el;
-    const int bel = (int)threadIdx.x - 64;  // env lane: local env index
+    const int bel = (int)threadIdx.x - 256;  // env lane: local env index
     const bool env_lane = bel >= 0 && bel < n_here;
     const int be = e0 + bel;
     int64_t v_ins = 0, v_size = 0, v_eplen = 0, v_epstart = 0, v_last = 0;
@@ -203,8 +208,20 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         // D. env step, one lane per agent (mpe_tag_dev.h): move -> barrier -> publish -> barrier -> reward terms.
         //    Beside the move, the env lanes do the buffer index algebra on their register-resident sub-buffer state
         //    (buffer_base.py:373-410 + manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h).
-        float npx = 0.f, npy = 0.f, nvx = 0.f, nvy = 0.f;
-        if (lane_live) tag_agent_move(c, s_ap + el * st, s_av + el * st, s_lp + el * lst, ai, s_act[r], npx, npy, nvx, nvy);
+        // (round 5: the pair forces as one (agent row, other entity) task per thread of waves 0-3, folded by the agent lanes in entity
+        //  order -- tag_agent_move's sums.  One lane per agent ran its 5 pair evaluations -- sqrt, exp, log1p, a division each when the
+        //  pair is in range -- one after the other; csrc/rollout.hip has the measurement.)
+        if (threadIdx.x < R * kPS) {
+            const int rp = threadIdx.x / kPS, jp = threadIdx.x % kPS;
+            float sx = 0.f, sy = 0.f;
+            int ok = 0;
+            if (rp < rows_here && jp < NA + c.n_obst) {
+                const int ep = rp / NA, ip = rp - ep * NA;
+                if (jp != ip) ok = tag_pair_force(c, s_ap + ep * st, s_lp + ep * lst, ip, jp, sx, sy) ? 1 : 0;
+            }
+            s_cx[threadIdx.x] = sx; s_cy[threadIdx.x] = sy; s_cv[threadIdx.x] = ok;
+        }
+        float npx = 0.f, npy = 0.f;
         bool tr = false, rec = false;
         int64_t o = 0;
         if (env_lane) {
@@ -231,7 +248,21 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             s_done[bel] = tr ? 1 : 0;
         }
         __syncthreads();
-        if (lane_live) {
+        if (lane_live) {   // fold, integrate, publish: a lane reads and writes its own agent's position / velocity only
+            float fx, fy, nvx, nvy;
+            tag_action_force(c, ai, s_act[r], fx, fy);
+            const int NE = NA + c.n_obst;
+#pragma unroll
+            for (int q = 0; q < kPS / 4; ++q) {
+                typedef int i4 __attribute__((ext_vector_type(4)));
+                const i4 v = *reinterpret_cast<const i4 *>(s_cv + kPS * r + 4 * q);
+                const f4 x = *reinterpret_cast<const f4 *>(s_cx + kPS * r + 4 * q), y = *reinterpret_cast<const f4 *>(s_cy + kPS * r + 4 * q);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (4 * q + u < NE && v[u]) { fx += x[u]; fy += y[u]; }
+            }
+            tag_integrate(c, ai, s_ap[el * st + 2 * ai], s_ap[el * st + 2 * ai + 1], s_av[el * st + 2 * ai], s_av[el * st + 2 * ai + 1], fx, fy,
+                          npx, npy, nvx, nvy);
             s_ap[el * st + 2 * ai] = npx; s_ap[el * st + 2 * ai + 1] = npy;
             s_av[el * st + 2 * ai] = nvx; s_av[el * st + 2 * ai + 1] = nvy;
         }
@@ -367,7 +398,7 @@ size_t tag_rollout_lds_floats(const Dims &d) {
     const Lay<64> ly(d, false);
     const size_t w_size = (size_t)((ly.X + 3) & ~3);
     return (size_t)ly.total + w_size + (size_t)R * ly.ldo + (size_t)R * d.ld1 + 2 * R * 2 + 2 * 8 * kTagMaxObst + 4 * R +
-           3 * R + 2 * 2 * R + 8;
+           3 * R + 2 * 2 * R + 8 + 3 * R * 16 + 4;
 }
 
 }  // namespace
