@@ -103,18 +103,18 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     float *s_m = s_val + R;                   // [R] landmark minima
     int *s_act = reinterpret_cast<int *>(s_m + R);          // [R]
     int *s_steps = s_act + R;                               // [EPB]
-    int *s_done = s_steps + R;                              // [EPB] done flag of the step just taken
+    int *s_done = s_steps + R;                              // [2][EPB] done flag of the step just taken (generation t & 1)
     // (8-byte alignment by INDEX arithmetic off the 16-byte aligned LDS base: rounding the address through uintptr_t made s_row /
     //  s_ep generic pointers, every access to them a FLAT instruction, and every flat load waits for vmcnt(0) -- i.e. for all of the
     //  step's outstanding global stores: round 5, 24 flat operations in this file)
-    int64_t *s_row = reinterpret_cast<int64_t *>(                    // [EPB] slot*B + env of the step just added
-        lds + (((int)(reinterpret_cast<float *>(s_done + R) - lds) + 1) & ~1));
-    uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + R);        // [EPB] episode counter of finished envs
+    int64_t *s_row = reinterpret_cast<int64_t *>(                    // [2][EPB] slot*B + env of the step just added (generation t & 1)
+        lds + (((int)(reinterpret_cast<float *>(s_done + 2 * R) - lds) + 1) & ~1));
+    uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + 2 * R);    // [EPB] episode counter of finished envs
     float *s_cx = lds + (((int)(reinterpret_cast<float *>(s_ep + R) - lds) + 3) & ~3);   // [R][8] pair forces of (row, other agent), phase D; 16-byte rows
     float *s_cy = s_cx + R * 8;
     int *s_cv = reinterpret_cast<int *>(s_cy + R * 8);               // [R][8] "the pair is in range"
-    // s_done / s_row keep the values of step t until phase D of step t + 1 overwrites them, so phase C of step t + 1
-    // reads them as "the previous step" (pending V(obs_next) stores) without a copy
+    // s_done / s_row in two generations: step t's index algebra (wave 4, beside the head of phase C) writes generation t & 1 while
+    // the head reads generation (t - 1) & 1 as "the previous step" (pending V(obs_next) stores)
 
     // diagnostics (tsm_debug_set_stamps, >= 1024 slots): [64 + 2b], [65 + 2b] = start / end of workgroup b;
     // [640 + t] = start of step t in workgroup 0
@@ -126,12 +126,12 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     }
     for (int i = threadIdx.x; i < R * d.ld1; i += NT2) { lds[ly.X + i] = 0.f; XN0[i] = 0.f; }
     const VrbState vs = vrb_view(a.vrb_state, B, N);
-    // agent lane r < rows_here (wave 0) <-> (env el, agent i); env lane 128 + q (wave 2) owns env q's bookkeeping, so
-    // the buffer index algebra runs beside the physics (the pair forces on waves 0-1) instead of after it
+    // agent lane r < rows_here (wave 0) <-> (env el, agent i); env lane 256 + q (wave 4) owns env q's bookkeeping: the buffer
+    // index algebra of a step runs beside its head (phase C: waves 0-3), off the step's dependent chain
     const int r = threadIdx.x, el = r / N, ai = r - el * N;
     const bool lane_live = r < rows_here;
     const int e = e0 + el;
-    const int bel = (int)threadIdx.x - 128;  // env lane: local env index
+    const int bel = (int)threadIdx.x - 256;  // env lane: local env index
     const bool env_lane = bel >= 0 && bel < n_here;
     const int be = e0 + bel;
     // sub-buffer bookkeeping of "my" env lives in registers for the whole rollout: the per-step index algebra
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
 #pragma unroll
         for (int k = 0; k < kMpeMaxN; ++k) if (k < N) v_epret[k] = vs.ep_return[(int64_t)be * N + k];
         s_steps[bel] = a.steps[be];
-        s_done[bel] = 1;  // "no pending v_next" before the first step
-        s_row[bel] = 0;
+        s_done[bel] = 1; s_done[R + bel] = 1;  // "no pending v_next" before the first step
+        s_row[bel] = 0; s_row[R + bel] = 0;
     }
     for (int i = threadIdx.x; i < n_here * st; i += NT2) {
         s_ap[i] = a.apos[(int64_t)e0 * st + i];
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     __syncthreads();
 
     for (int t = 0; t <= a.n_steps; ++t) {
+        const int g = (t & 1) * R;   // this step's generation of s_row / s_done; g ^ R: the previous step's
         const bool last = t == a.n_steps;  // extra pass: bootstrap value of the final observation only
         float *XN = lds + xnxt;
         STAMP(0);
@@ -179,6 +180,31 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         if constexpr (NT2 == 2 * NT) tile_forward_split<H>(lds, lyf, d);
         else tile_forward<H>(lds, lyf, d);
         STAMP(2);
+        bool tr = false, rec = false;
+        int64_t o = 0;
+        if (env_lane && !last) {   // the buffer index algebra of this step (beside the head; D .. F read generation t & 1)
+            const int stp = s_steps[bel] + 1;
+            tr = stp >= c.max_cycles;
+            s_steps[bel] = stp;
+            o = (int64_t)t * B + be;
+            const int64_t cur = v_ins;
+            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
+            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
+            const int64_t elen = v_eplen + 1;
+            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
+            rec = tr && a.ep_rec && n_fin < a.max_ep;
+            // (the record carries CollectStats.lens = len(episode_batch): the episode's rows IN THE BUFFER, collector.py:203,990-993 --
+            //  after a reset_buffer(keep_statistics=True) an episode counts its rows since the reset; ep_len_out stays add()'s ep_len)
+            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | ((cur >= v_epstart ? cur - v_epstart : cur - v_epstart + a.S) + 1);
+            a.ep_len_out[o] = tr ? elen : 0;
+            a.ptr_out[o] = cur + (int64_t)be * a.S;
+            a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
+            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
+            v_last = cur + (int64_t)be * a.S;
+            a.done_store[cur * B + be] = tr ? 1 : 0;
+            s_row[g + bel] = cur * B + be;
+            s_done[g + bel] = tr ? 1 : 0;
+        }
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
         if (main_t) {
@@ -194,8 +220,8 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
             if (j == 0 && hr < rows_here) {
                 const float val = lg[16];
                 const int hel = hr / N;
-                if (!s_done[hel] && a.vnext_store)  // V(obs_next) of the previous step == V(obs) of this one
-                    a.vnext_store[s_row[hel] * N + (hr - hel * N)] = val;
+                if (!s_done[(g ^ R) + hel] && a.vnext_store)  // V(obs_next) of the previous step == V(obs) of this one
+                    a.vnext_store[s_row[(g ^ R) + hel] * N + (hr - hel * N)] = val;
                 if (!last) s_val[hr] = val;
             }
             if (!last) {
@@ -246,31 +272,6 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
                 if (jp != ip) ok = mpe_pair_force(c, ap[2 * ip], ap[2 * ip + 1], ap[2 * jp], ap[2 * jp + 1], ip, jp, sx, sy) ? 1 : 0;
             }
             s_cx[threadIdx.x] = sx; s_cy[threadIdx.x] = sy; s_cv[threadIdx.x] = ok;
-        }
-        bool tr = false, rec = false;
-        int64_t o = 0;
-        if (env_lane) {
-            const int stp = s_steps[bel] + 1;
-            tr = stp >= c.max_cycles;
-            s_steps[bel] = stp;
-            o = (int64_t)t * B + be;
-            const int64_t cur = v_ins;
-            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
-            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
-            const int64_t elen = v_eplen + 1;
-            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
-            rec = tr && a.ep_rec && n_fin < a.max_ep;
-            // (the record carries CollectStats.lens = len(episode_batch): the episode's rows IN THE BUFFER, collector.py:203,990-993 --
-            //  after a reset_buffer(keep_statistics=True) an episode counts its rows since the reset; ep_len_out stays add()'s ep_len)
-            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | ((cur >= v_epstart ? cur - v_epstart : cur - v_epstart + a.S) + 1);
-            a.ep_len_out[o] = tr ? elen : 0;
-            a.ptr_out[o] = cur + (int64_t)be * a.S;
-            a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
-            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
-            v_last = cur + (int64_t)be * a.S;
-            a.done_store[cur * B + be] = tr ? 1 : 0;
-            s_row[bel] = cur * B + be;
-            s_done[bel] = tr ? 1 : 0;
         }
         XSTAMP(5);   // (wave 0 is through its own part: the pair forces)
         __syncthreads();
@@ -333,45 +334,45 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         // E. payload scatter into the time-major SoA store (rows of consecutive envs are adjacent)
         for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
             const int rr = i / D, k = i - rr * D, ee = rr / N;
-            const int64_t dst = (s_row[ee] * N + (rr - ee * N)) * D + k;
+            const int64_t dst = (s_row[g + ee] * N + (rr - ee * N)) * D + k;
             a.obs_store[dst] = lds[xcur + rr * d.ld1 + k];
             if (a.obs_next_store) a.obs_next_store[dst] = XN[rr * d.ld1 + k];
         }
         if (lane_live) {
-            const int64_t dst = s_row[el] * N + ai;
+            const int64_t dst = s_row[g + el] * N + ai;
             a.act_store[dst] = s_act[r];
             a.rew_store[dst] = s_rew[r];
             a.term_store[dst] = 0;
-            a.trunc_store[dst] = (uint8_t)s_done[el];
+            a.trunc_store[dst] = (uint8_t)s_done[g + el];
             if (a.logp_store) a.logp_store[dst] = s_logp[r];
             if (a.vs_store) a.vs_store[dst] = s_val[r];
         }
         STAMP(5);
         // F. finished episodes: critic value of the terminal observation, then re-initialise the env
-        int any_done = lane_live ? s_done[el] : 0;
+        int any_done = lane_live ? s_done[g + el] : 0;
         any_done = __syncthreads_or(any_done);
         if (any_done) {
             if (a.vnext_store) {
                 lyf.X = xnxt;
                 if constexpr (NT2 == 2 * NT) tile_forward_split<H>(lds, lyf, d);
                 else tile_forward<H>(lds, lyf, d);
-                if (lane_live && s_done[el]) a.vnext_store[s_row[el] * N + ai] = lds[ly.OUT + r * ly.ldo + 16];
+                if (lane_live && s_done[g + el]) a.vnext_store[s_row[g + el] * N + ai] = lds[ly.OUT + r * ly.ldo + 16];
             }
             if (a.auto_reset) {
-                if (env_lane && s_done[bel]) {
+                if (env_lane && s_done[g + bel]) {
                     const uint64_t ep = a.episode_ctr[be];
                     s_ep[bel] = ep;
                     a.episode_ctr[be] = ep + 1;
                     s_steps[bel] = 0;
                 }
                 __syncthreads();
-                if (lane_live && s_done[el])
+                if (lane_live && s_done[g + el])
                     mpe_reset_agent(c, e, a.env_seed, s_ep[el], ai, s_ap + el * st, s_av + el * st, s_lp + el * st);
                 __syncthreads();
                 // first observation of the new episodes
                 for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
                     const int rr = i / D, k = i - rr * D, ee = rr / N;
-                    if (s_done[ee])
+                    if (s_done[g + ee])
                         XN[rr * d.ld1 + k] =
                             mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
                 }
@@ -900,7 +901,7 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
             return TSM_OK;
         }
     }
-    const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8 + 3 * R * 8 + 4;
+    const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8 + 3 * R * 8 + 4 + 3 * R;
     const size_t shmem = ((size_t)ly.total + extra) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

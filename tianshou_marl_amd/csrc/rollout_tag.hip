@@ -98,12 +98,12 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     float *s_val = s_logp + R;                    // [R]
     int *s_act = reinterpret_cast<int *>(s_val + R);        // [R]
     int *s_steps = s_act + R;                               // [EPB]
-    int *s_done = s_steps + R;                              // [EPB] done flag of the step just taken
+    int *s_done = s_steps + R;                              // [2][EPB] done flag of the step just taken (generation t & 1)
     // (aligned by index arithmetic off the 16-byte aligned base: an address rounded through uintptr_t is a generic pointer, its
     //  accesses FLAT instructions that wait for every outstanding global store -- see csrc/rollout.hip)
     int64_t *s_row = reinterpret_cast<int64_t *>(                    // [EPB] slot*B + env of the step just added
-        lds + (((int)(reinterpret_cast<float *>(s_done + R) - lds) + 1) & ~1));
-    uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + R);        // [EPB] episode counter of finished envs
+        lds + (((int)(reinterpret_cast<float *>(s_done + 2 * R) - lds) + 1) & ~1));   // (two generations, see csrc/rollout.hip)
+    uint64_t *s_ep = reinterpret_cast<uint64_t *>(s_row + 2 * R);    // [EPB] episode counter of finished envs
     constexpr int kPS = 16;                                          // pair slots per row (entities: <= 8 agents + 4 obstacles)
     float *s_cx = lds + (((int)(reinterpret_cast<float *>(s_ep + R) - lds) + 3) & ~3);   // [R][kPS] pair forces, phase D; 16-byte rows
     float *s_cy = s_cx + R * kPS;
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
 #pragma unroll
         for (int k = 0; k < kTagMaxAgents; ++k) if (k < NA) v_epret[k] = vs.ep_return[(int64_t)be * NA + k];
         s_steps[bel] = a.steps[be];
-        s_done[bel] = 0;
-        s_row[bel] = 0;
+        s_done[bel] = 0; s_done[R + bel] = 0;
+        s_row[bel] = 0; s_row[R + bel] = 0;
     }
     for (int i = threadIdx.x; i < n_here * st; i += NT2) {
         s_ap[i] = a.apos[(int64_t)e0 * st + i];
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
 
     if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[41] = (long long)wall_clock64();
     for (int t = 0; t < a.n_steps; ++t) {
+        const int g = (t & 1) * R;   // this step's generation of s_row / s_done; g ^ R: the previous step's
         float *XN = lds + xnxt;
         TSTAMP(0);
         // B. both teams' actor + critic forward of the 16-row tile (same X, separate OUT)
@@ -166,6 +167,31 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         tile_forward_split<H>(lds, lyf, d);
         tile_forward_split<H>(lds, lyg, d);
         TSTAMP(1);
+        bool tr = false, rec = false;
+        int64_t o = 0;
+        if (env_lane) {   // the buffer index algebra of this step: wave 4, beside the head on waves 0-3 (D .. F read generation t & 1)
+            const int stp = s_steps[bel] + 1;
+            tr = stp >= c.max_cycles;
+            s_steps[bel] = stp;
+            o = (int64_t)t * B + be;
+            const int64_t cur = v_ins;
+            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
+            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
+            const int64_t elen = v_eplen + 1;
+            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
+            rec = tr && a.ep_rec && n_fin < a.max_ep;
+            // (the record carries CollectStats.lens = len(episode_batch): the episode's rows IN THE BUFFER, collector.py:203,990-993 --
+            //  after a reset_buffer(keep_statistics=True) an episode counts its rows since the reset; ep_len_out stays add()'s ep_len)
+            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | ((cur >= v_epstart ? cur - v_epstart : cur - v_epstart + a.S) + 1);
+            a.ep_len_out[o] = tr ? elen : 0;
+            a.ptr_out[o] = cur + (int64_t)be * a.S;
+            a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
+            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
+            v_last = cur + (int64_t)be * a.S;
+            a.done_store[cur * B + be] = tr ? 1 : 0;
+            s_row[g + bel] = cur * B + be;
+            s_done[g + bel] = tr ? 1 : 0;
+        }
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
         if (threadIdx.x < NT) {
@@ -200,7 +226,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
                 s_logp[hr] = la - (m + logf(ssum));
                 // V(obs_next) of the previous step's row == V(obs) of this one where the episode goes on (s_row / s_done still hold
                 // the previous step: D rewrites them behind the barrier below)
-                if (a.vnext_store && t > 0 && !s_done[hel]) a.vnext_store[s_row[hel] * NA + hai] = lg[16];
+                if (a.vnext_store && t > 0 && !s_done[(g ^ R) + hel]) a.vnext_store[s_row[(g ^ R) + hel] * NA + hai] = lg[16];
             }
         }
         __syncthreads();
@@ -222,31 +248,6 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             s_cx[threadIdx.x] = sx; s_cy[threadIdx.x] = sy; s_cv[threadIdx.x] = ok;
         }
         float npx = 0.f, npy = 0.f;
-        bool tr = false, rec = false;
-        int64_t o = 0;
-        if (env_lane) {
-            const int stp = s_steps[bel] + 1;
-            tr = stp >= c.max_cycles;
-            s_steps[bel] = stp;
-            o = (int64_t)t * B + be;
-            const int64_t cur = v_ins;
-            int64_t sz = v_size + 1; if (sz > a.S) sz = a.S;
-            int64_t nxt = cur + 1; if (nxt >= a.S) nxt -= a.S;
-            const int64_t elen = v_eplen + 1;
-            if (v_epstart > sz) atomicExch((unsigned long long *)vs.error_flag, 1ull);
-            rec = tr && a.ep_rec && n_fin < a.max_ep;
-            // (the record carries CollectStats.lens = len(episode_batch): the episode's rows IN THE BUFFER, collector.py:203,990-993 --
-            //  after a reset_buffer(keep_statistics=True) an episode counts its rows since the reset; ep_len_out stays add()'s ep_len)
-            if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | ((cur >= v_epstart ? cur - v_epstart : cur - v_epstart + a.S) + 1);
-            a.ep_len_out[o] = tr ? elen : 0;
-            a.ptr_out[o] = cur + (int64_t)be * a.S;
-            a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
-            v_ins = nxt; v_size = sz; v_eplen = tr ? 0 : elen; v_epstart = tr ? nxt : v_epstart;
-            v_last = cur + (int64_t)be * a.S;
-            a.done_store[cur * B + be] = tr ? 1 : 0;
-            s_row[bel] = cur * B + be;
-            s_done[bel] = tr ? 1 : 0;
-        }
         __syncthreads();
         if (lane_live) {   // fold, integrate, publish: a lane reads and writes its own agent's position / velocity only
             float fx, fy, nvx, nvy;
@@ -303,16 +304,16 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         // E. payload scatter into the time-major SoA store (rows of consecutive envs are adjacent)
         for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
             const int rr = i / D, k = i - rr * D, ee = rr / NA;
-            const int64_t dst = (s_row[ee] * NA + (rr - ee * NA)) * D + k;
+            const int64_t dst = (s_row[g + ee] * NA + (rr - ee * NA)) * D + k;
             a.obs_store[dst] = lds[xcur + rr * d.ld1 + k];
             if (a.obs_next_store) a.obs_next_store[dst] = XN[rr * d.ld1 + k];
         }
         if (lane_live) {
-            const int64_t dst = s_row[el] * NA + ai;
+            const int64_t dst = s_row[g + el] * NA + ai;
             a.act_store[dst] = s_act[r];
             a.rew_store[dst] = s_rew[r];
             a.term_store[dst] = 0;
-            a.trunc_store[dst] = (uint8_t)s_done[el];
+            a.trunc_store[dst] = (uint8_t)s_done[g + el];
             if (a.logp_store) a.logp_store[dst] = s_logp[r];
             if (a.vs_store) a.vs_store[dst] = s_val[r];
         }
@@ -320,29 +321,29 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         // F. finished episodes: the critic value of the terminal observation (both teams' nets on the obs_next tile, every row takes
         //    its own team's), then re-initialise the env, first observation of the new episode
         if (a.auto_reset || a.vnext_store) {
-            int any_done = lane_live ? s_done[el] : 0;
+            int any_done = lane_live ? s_done[g + el] : 0;
             any_done = __syncthreads_or(any_done);
             if (any_done && a.vnext_store) {
                 lyf.X = xnxt; lyg.X = xnxt;
                 tile_forward_split<H>(lds, lyf, d);
                 tile_forward_split<H>(lds, lyg, d);
-                if (lane_live && s_done[el])
-                    a.vnext_store[s_row[el] * NA + ai] = lds[(ai >= c.n_adv ? lyB.OUT : ly.OUT) + r * ly.ldo + 16];
+                if (lane_live && s_done[g + el])
+                    a.vnext_store[s_row[g + el] * NA + ai] = lds[(ai >= c.n_adv ? lyB.OUT : ly.OUT) + r * ly.ldo + 16];
             }
             if (any_done && a.auto_reset) {
-                if (env_lane && s_done[bel]) {
+                if (env_lane && s_done[g + bel]) {
                     const uint64_t ep = a.episode_ctr[be];
                     s_ep[bel] = ep;
                     a.episode_ctr[be] = ep + 1;
                     s_steps[bel] = 0;
                 }
                 __syncthreads();
-                if (lane_live && s_done[el])
+                if (lane_live && s_done[g + el])
                     tag_reset_lane(c, e, a.env_seed, s_ep[el], ai, s_ap + el * st, s_av + el * st, s_lp + el * lst);
                 __syncthreads();
                 for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
                     const int rr = i / D, k = i - rr * D, ee = rr / NA;
-                    if (s_done[ee])
+                    if (s_done[g + ee])
                         XN[rr * d.ld1 + k] =
                             tag_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * lst, rr - ee * NA, k);
                 }
@@ -355,14 +356,15 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[42] = (long long)wall_clock64();
     // V(obs_next) of the final step's rows whose episode goes on: one more pass over the observation the next collect starts from
     if (a.vnext_store) {
-        int open_rows = lane_live ? !s_done[el] : 0;
+        const int gl = ((a.n_steps - 1) & 1) * R;   // the final step's generation
+        int open_rows = lane_live ? !s_done[gl + el] : 0;
         open_rows = __syncthreads_or(open_rows);
         if (open_rows) {
             lyf.X = xcur; lyg.X = xcur;
             tile_forward_split<H>(lds, lyf, d);
             tile_forward_split<H>(lds, lyg, d);
-            if (lane_live && !s_done[el])
-                a.vnext_store[s_row[el] * NA + ai] = lds[(ai >= c.n_adv ? lyB.OUT : ly.OUT) + r * ly.ldo + 16];
+            if (lane_live && !s_done[gl + el])
+                a.vnext_store[s_row[gl + el] * NA + ai] = lds[(ai >= c.n_adv ? lyB.OUT : ly.OUT) + r * ly.ldo + 16];
         }
     }
     // the observation of the next collect() call
@@ -398,7 +400,7 @@ size_t tag_rollout_lds_floats(const Dims &d) {
     const Lay<64> ly(d, false);
     const size_t w_size = (size_t)((ly.X + 3) & ~3);
     return (size_t)ly.total + w_size + (size_t)R * ly.ldo + (size_t)R * d.ld1 + 2 * R * 2 + 2 * 8 * kTagMaxObst + 4 * R +
-           3 * R + 2 * 2 * R + 8 + 3 * R * 16 + 4;
+           3 * R + 2 * 2 * R + 8 + 3 * R * 16 + 4 + 3 * R;
 }
 
 }  // namespace
