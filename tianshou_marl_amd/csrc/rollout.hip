@@ -113,6 +113,8 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     float *s_cx = lds + (((int)(reinterpret_cast<float *>(s_ep + R) - lds) + 3) & ~3);   // [R][8] pair forces of (row, other agent), phase D; 16-byte rows
     float *s_cy = s_cx + R * 8;
     int *s_cv = reinterpret_cast<int *>(s_cy + R * 8);               // [R][8] "the pair is in range"
+    float *s_u = reinterpret_cast<float *>(s_cv + R * 8);            // [2][R] the sampling uniforms of step t (generation t & 1)
+    int *s_any = reinterpret_cast<int *>(s_u + 2 * R);               // [2] "an episode of this tile ends at step t"
     // s_done / s_row in two generations: step t's index algebra (wave 4, beside the head of phase C) writes generation t & 1 while
     // the head reads generation (t - 1) & 1 as "the previous step" (pending V(obs_next) stores)
 
@@ -156,6 +158,11 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         s_lp[i] = a.lpos[(int64_t)e0 * st + i];
     }
     const uint64_t off0 = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
+    // The sampling uniform of (step, row) depends on nothing the step computes: ten Philox rounds (~0.25 us of dependent
+    // instructions) that the head used to run between the logits and the sample.  Wave 5 draws step t + 1's beside step t's head.
+    const int ur = (int)threadIdx.x - 320;   // uniform lane: row
+    const bool u_lane = a.mode == 1 && ur >= 0 && ur < rows_here;
+    if (u_lane) s_u[ur] = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)e0 * N + (uint64_t)ur);
     __syncthreads();
     // two observation tiles, swapped every step: obs_next of step t IS obs of step t + 1 (rows of re-initialised
     // envs are rebuilt in F), so the observation function runs once per step, not twice
@@ -204,7 +211,10 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
             a.done_store[cur * B + be] = tr ? 1 : 0;
             s_row[g + bel] = cur * B + be;
             s_done[g + bel] = tr ? 1 : 0;
+            const unsigned long long ends = __ballot(tr);   // (the env lanes share wave 4)
+            if (bel == 0) s_any[t & 1] = ends != 0ull;
         }
+        if (u_lane && !last) s_u[((t + 1) & 1) * R + ur] = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)(t + 1) * B * N + (uint64_t)e0 * N + (uint64_t)ur);
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
         if (main_t) {
@@ -227,8 +237,8 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
             if (!last) {
                 int act = 0;
                 if (a.mode == 1) {
-                    const uint64_t gi = (uint64_t)e0 * N + hr;  // global row index env*N + agent
-                    const float u = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)t * B * N + gi) * ssum;
+                    // (the uniform of global row e0 * N + hr at step t: tsm_philox_uniform(pol_seed, off0 + t * B * N + row), drawn ahead)
+                    const float u = s_u[(t & 1) * R + (hr < rows_here ? hr : 0)] * ssum;
                     float cs = 0.f;
                     act = d.A - 1;
                     bool found = false;
@@ -349,8 +359,8 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         }
         STAMP(5);
         // F. finished episodes: critic value of the terminal observation, then re-initialise the env
-        int any_done = lane_live ? s_done[g + el] : 0;
-        any_done = __syncthreads_or(any_done);
+        // (the env lanes left the flag beside the index algebra: a workgroup-wide OR here cost two barriers per step, 0.36 us)
+        const int any_done = s_any[t & 1];
         if (any_done) {
             if (a.vnext_store) {
                 lyf.X = xnxt;
@@ -901,7 +911,7 @@ TSM_EXPORT int tsm_rollout_spread(const tsm_rollout_desc *desc_host, void *strea
             return TSM_OK;
         }
     }
-    const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8 + 3 * R * 8 + 4 + 3 * R;
+    const size_t extra = (size_t)R * a.d.ld1 + 3 * R * 2 + 4 * R + 4 * R + 3 * 2 * R + 8 + 3 * R * 8 + 4 + 3 * R + 2 * R + 4;
     const size_t shmem = ((size_t)ly.total + extra) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

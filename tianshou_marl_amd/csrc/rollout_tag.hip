@@ -108,6 +108,8 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     float *s_cx = lds + (((int)(reinterpret_cast<float *>(s_ep + R) - lds) + 3) & ~3);   // [R][kPS] pair forces, phase D; 16-byte rows
     float *s_cy = s_cx + R * kPS;
     int *s_cv = reinterpret_cast<int *>(s_cy + R * kPS);             // [R][kPS] "the pair is in range"
+    float *s_u = reinterpret_cast<float *>(s_cv + R * kPS);          // [2][R] the sampling uniforms of step t (generation t & 1)
+    int *s_any = reinterpret_cast<int *>(s_u + 2 * R);               // [2] "an episode of this tile ends at step t"
 
     if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[40] = (long long)wall_clock64();
     // waves 0-3 stage team 0's weights, waves 4-7 team 1's (batches of 4 loads per thread: ~1 us per workgroup)
@@ -143,6 +145,12 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     }
     for (int i = threadIdx.x; i < n_here * lst; i += NT2) s_lp[i] = a.lpos[(int64_t)e0 * lst + i];
     const uint64_t off0 = a.offset_dev ? *a.offset_dev : 0ull;
+    // the sampling uniform of (step, row) drawn one step ahead by wave 5, beside the head (csrc/rollout.hip has the story)
+    const int ur = (int)threadIdx.x - 320, u_el = ur / NA, u_ai = ur - u_el * NA;
+    const int u_team = u_ai >= c.n_adv ? 1 : 0;
+    const bool u_lane = ur >= 0 && ur < rows_here && a.mode[u_team] == 1;
+    const uint64_t u_gi = a.env_major ? (uint64_t)(e0 + u_el) * NA + u_ai : (uint64_t)u_ai * B + (uint64_t)(e0 + u_el);
+    if (u_lane) s_u[ur] = tsm_philox_uniform(a.pol_seed[u_team], a.offset[u_team] + off0 + u_gi);
     __syncthreads();
     // two observation tiles, swapped every step: obs_next of step t IS obs of step t + 1 (rows of re-initialised
     // envs are rebuilt in F), so the observation function runs once per step, not twice
@@ -191,7 +199,11 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             a.done_store[cur * B + be] = tr ? 1 : 0;
             s_row[g + bel] = cur * B + be;
             s_done[g + bel] = tr ? 1 : 0;
+            const unsigned long long ends = __ballot(tr);   // (the env lanes share wave 4)
+            if (bel == 0) s_any[t & 1] = ends != 0ull;
         }
+        if (u_lane && t + 1 < a.n_steps)
+            s_u[((t + 1) & 1) * R + ur] = tsm_philox_uniform(a.pol_seed[u_team], a.offset[u_team] + off0 + (uint64_t)(t + 1) * B * NA + u_gi);
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
         if (threadIdx.x < NT) {
@@ -208,9 +220,9 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             row_prefix_sum<0>(ex, d.A, ssum);
             int act = 0;
             if (a.mode[team] == 1) {
-                const uint64_t gi = a.env_major ? (uint64_t)(e0 + hel) * NA + hai  // one policy call over [n_env][NA] rows
-                                                : (uint64_t)hai * B + (uint64_t)(e0 + hel);  // column * n_env + env
-                const float u = tsm_philox_uniform(a.pol_seed[team], a.offset[team] + off0 + (uint64_t)t * B * NA + gi) * ssum;
+                // (tsm_philox_uniform(pol_seed[team], offset[team] + off0 + t * B * NA + gi), gi = (e0 + hel) * NA + hai for one policy
+                //  call over [n_env][NA] rows, hai * B + e0 + hel for one call per column: drawn ahead, s_u)
+                const float u = s_u[(t & 1) * R + (hr < rows_here ? hr : 0)] * ssum;
                 float cs = 0.f;
                 act = d.A - 1;
                 bool found = false;
@@ -321,8 +333,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         // F. finished episodes: the critic value of the terminal observation (both teams' nets on the obs_next tile, every row takes
         //    its own team's), then re-initialise the env, first observation of the new episode
         if (a.auto_reset || a.vnext_store) {
-            int any_done = lane_live ? s_done[g + el] : 0;
-            any_done = __syncthreads_or(any_done);
+            const int any_done = s_any[t & 1];   // (left by the env lanes beside the index algebra: no workgroup-wide OR)
             if (any_done && a.vnext_store) {
                 lyf.X = xnxt; lyg.X = xnxt;
                 tile_forward_split<H>(lds, lyf, d);
@@ -400,7 +411,7 @@ size_t tag_rollout_lds_floats(const Dims &d) {
     const Lay<64> ly(d, false);
     const size_t w_size = (size_t)((ly.X + 3) & ~3);
     return (size_t)ly.total + w_size + (size_t)R * ly.ldo + (size_t)R * d.ld1 + 2 * R * 2 + 2 * 8 * kTagMaxObst + 4 * R +
-           3 * R + 2 * 2 * R + 8 + 3 * R * 16 + 4 + 3 * R;
+           3 * R + 2 * 2 * R + 8 + 3 * R * 16 + 4 + 3 * R + 2 * R + 4;
 }
 
 }  // namespace
