@@ -569,7 +569,12 @@ __device__ __forceinline__ void ppo_update_net(
     const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
     const float *__restrict__ returns, const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first,
     int64_t M, const float *__restrict__ adv_stats, const LossCfg &cfg, float *__restrict__ slabs,
-    double *__restrict__ loss_partial) {
+    double *__restrict__ loss_partial, long long *stamps) {
+    // diagnostics (tsm_debug_set_stamps, >= 2048 slots): [16 + 24 NET + k] = phase k of workgroup (0, NET);
+    // [1024 + 2 (b + 256 NET)], [.. + 1] = start / end of workgroup (b, NET)   (tools/stamp_update.py)
+#define NSTAMP(k) do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[16 + 24 * NET + (k)] = (long long)wall_clock64(); } while (0)
+    NSTAMP(0);
+    if (stamps && threadIdx.x == 0 && blockIdx.x < 256) stamps[1024 + 2 * (blockIdx.x + 256 * NET)] = (long long)wall_clock64();
     const LayN<H> ln(d);
     const POff<H> po(d.D, d.A);
     const int64_t n_tiles = (M + R - 1) / R;
@@ -642,12 +647,14 @@ __device__ __forceinline__ void ppo_update_net(
     float g_b3 = 0.f;              // actor: threads 0..A-1; critic: thread 0
     double s_a = 0.0, s_b = 0.0;   // threads 16*r: actor (clip objective, entropy) | critic (value loss, -)
 
+    NSTAMP(1);
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int64_t row0 = t * R;
         __syncthreads();
         commit_tile_x(lds, ln.X, d, xr);
         const RowIn cur = rin;
         __syncthreads();
+        NSTAMP(2);
         // ---- forward ----
         {
             f4 acc = zero;
@@ -660,6 +667,7 @@ __device__ __forceinline__ void ppo_update_net(
             for (int r = 0; r < 4; ++r) lds[ln.H1 + (kq * 4 + r) * ln.ldh + col] = fmaxf(acc[r] + b, 0.f);
         }
         __syncthreads();
+        NSTAMP(3);
         {
             f4 acc = zero;
             const float *ha = lds + ln.H1 + r16 * ln.ldh + kq;
@@ -672,6 +680,7 @@ __device__ __forceinline__ void ppo_update_net(
             for (int r = 0; r < 4; ++r) lds[ln.H2 + (kq * 4 + r) * ln.ldh + col] = fmaxf(acc[r] + b, 0.f);
         }
         __syncthreads();
+        NSTAMP(4);
         if (NET == 0) {
             if (w == 0) {
                 f4 acc = zero;
@@ -690,6 +699,7 @@ __device__ __forceinline__ void ppo_update_net(
             lds[ln.OUT + threadIdx.x * ln.ldo + 16] = sv + lds[ln.B3];
         }
         __syncthreads();
+        NSTAMP(5);
 
         // ---- loss head: 16 lanes per row ----
         {
@@ -759,6 +769,7 @@ __device__ __forceinline__ void ppo_update_net(
             else if (j == 0) d3[16] = dv;
         }
         __syncthreads();
+        NSTAMP(6);
 
         if (t + gridDim.x < n_tiles) {  // next tile's gathers fly under this tile's backward pass
             prefetch_tile_x(xr, d, obs, perm, first, (t + gridDim.x) * R, M);
@@ -806,6 +817,7 @@ __device__ __forceinline__ void ppo_update_net(
             }
         }
         __syncthreads();
+        NSTAMP(7);
         // ---- hidden layer 2 gradients + dh1 ----
         {
             const float *dA = lds + ln.D2 + kq * ln.ldh + 16 * w + r16;
@@ -835,6 +847,7 @@ __device__ __forceinline__ void ppo_update_net(
             }
         }
         __syncthreads();
+        NSTAMP(8);
         if constexpr (PUB) {   // ---- publish the tile instead of layer-1 gradients (rows as 16-byte pieces: 8-byte aligned in LDS) ----
             float *pub = slabs + ((int64_t)t * 2 + NET) * pub_floats<H>(d.ld1);
             const int pr = threadIdx.x >> 4, pc = (threadIdx.x & 15) * 4;
@@ -867,6 +880,7 @@ __device__ __forceinline__ void ppo_update_net(
         }
     }
 
+    NSTAMP(9);
     // ---- this net's half of the workgroup's gradient slab ----
     if constexpr (!PUB) {
     float *S = slabs + (int64_t)blockIdx.x * po.total;
@@ -894,6 +908,7 @@ __device__ __forceinline__ void ppo_update_net(
     if (NET == 0 && threadIdx.x < d.A) slab_store<ST>(g_b3, &S[po.ab3 + threadIdx.x]);
     if (NET == 1 && threadIdx.x == 0) slab_store<ST>(g_b3, &S[po.cb3]);
     }
+    NSTAMP(10);
     // loss partial sums: actor -> clip objective [0], entropy [2]; critic -> value loss [1]
     {
         __shared__ double s_red[2][NT / 64];
@@ -910,8 +925,11 @@ __device__ __forceinline__ void ppo_update_net(
             } else {
                 loss_partial[4 * blockIdx.x + 1] = ta;
             }
+            NSTAMP(11);
+            if (stamps && blockIdx.x < 256) stamps[1025 + 2 * (blockIdx.x + 256 * NET)] = (long long)wall_clock64();
         }
     }
+#undef NSTAMP
 }
 
 // DS: 0 = dimensions from the launch arguments; else the observation width this instantiation is compiled for (5 actions): the
@@ -923,17 +941,17 @@ __global__ __launch_bounds__(NT) void ppo_update_split_kernel(
     const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
     const float *__restrict__ returns, const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first,
     int64_t M, const float *__restrict__ adv_stats, LossCfg cfg, float *__restrict__ slabs,
-    double *__restrict__ loss_partial, int64_t *__restrict__ opt_step_dev) {
+    double *__restrict__ loss_partial, int64_t *__restrict__ opt_step_dev, long long *stamps) {
     extern __shared__ float lds[];
     const Dims d = DS ? dims_const(DS, 5) : d_arg;
     // device-resident optimizer step count (hipGraph replay): bumped here, read by the Adam kernel that follows
     if (opt_step_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *opt_step_dev += 1;
     if (blockIdx.y == 0)
         ppo_update_net<H, 0, ST, PUB>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
-                                      loss_partial);
+                                      loss_partial, stamps);
     else
         ppo_update_net<H, 1, ST, PUB>(lds, P, img, d, obs, act, logp_old, adv, returns, v_s_old, perm, first, M, adv_stats, cfg, slabs,
-                                      loss_partial);
+                                      loss_partial, stamps);
 }
 
 __global__ __launch_bounds__(256) void update_finalize_kernel(const double *__restrict__ partial, int n_blocks,
@@ -1139,8 +1157,8 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
         const LayN<64> ln(d);
         hipLaunchKernelGGL((ppo_update_split_kernel<64, 0, 18, true>), dim3((unsigned)n_blocks, 2), dim3(NT),
                            (size_t)ln.total * sizeof(float), st, params, param_image, d, obs, act, logp_old, adv, returns,
-                           v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out, loss_partial_out, opt_step_dev);
-    } else if (g_update_variant == 0 && !g_tsm_stamps) {
+                           v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out, loss_partial_out, opt_step_dev, g_tsm_stamps);
+    } else if (g_update_variant == 0) {
         // one net per workgroup (grid.y = actor | critic): see ppo_update_split_kernel
         const LayN<64> ln(d);
         const bool spec = d.A == 5 && !tsm_opt(TSM_OPT_GENERIC);   // ("generic_kernels": the generic instantiation)
@@ -1151,8 +1169,8 @@ TSM_EXPORT int tsm_ppo_update_fused(const float *params, const float *param_imag
                     : ppo_update_split_kernel<64, 0, 0>;
         hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks, 2), dim3(NT),
                            (size_t)ln.total * sizeof(float), st, params, param_image, d, obs, act, logp_old, adv, returns,
-                           v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out, loss_partial_out, opt_step_dev);
-    } else {  // both nets in one workgroup (kept for the phase stamps of tools/stamp_update.py and as an A/B reference)
+                           v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out, loss_partial_out, opt_step_dev, g_tsm_stamps);
+    } else {  // both nets in one workgroup (update variant 1: an A/B reference, tools/ab_update_variant.py)
         hipLaunchKernelGGL((ppo_update_kernel<64>), dim3((unsigned)n_blocks), dim3(NT), shmem, st, params, param_image, d,
                            obs, act,
                            logp_old, adv, returns, v_s_old, perm, first_row, M, adv_stats, cfg, grad_slabs_out,
