@@ -647,9 +647,53 @@ __device__ __forceinline__ void ppo_update_net(
     float g_b3 = 0.f;              // actor: threads 0..A-1; critic: thread 0
     double s_a = 0.0, s_b = 0.0;   // threads 16*r: actor (clip objective, entropy) | critic (value loss, -)
 
+    // The workgroup's gradient slab, a piece at a time: each piece is stored as soon as the LAST tile has added to it (round 5) -- the
+    // output layer's after its phase, layer 2's after its phase, layer 1's at the end -- instead of all 22 KB behind the backward pass:
+    // the stores fly under the remaining phases and the launch ends with a quarter of the bytes still on their way.
+    float *const S = slabs + (int64_t)blockIdx.x * po.total;
+    auto store_out_layer = [&]() {
+        if constexpr (!PUB) {
+            if (NET == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = kq * 4 + r;
+                    if (row < d.A) slab_store<ST>(g_W3[r], &S[po.aW3 + row * H + 16 * w + r16]);
+                }
+                if (threadIdx.x < d.A) slab_store<ST>(g_b3, &S[po.ab3 + threadIdx.x]);
+            } else {
+                if (threadIdx.x < H) slab_store<ST>(g_W3c, &S[po.cW3 + threadIdx.x]);
+                if (threadIdx.x == 0) slab_store<ST>(g_b3, &S[po.cb3]);
+            }
+        }
+    };
+    auto store_layer2 = [&]() {
+        if constexpr (!PUB) {
+            const int oW2 = NET ? po.cW2 : po.aW2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) slab_store<ST>(g_W2[jb][r], &S[oW2 + (16 * w + kq * 4 + r) * H + 16 * jb + r16]);
+            if (threadIdx.x < H) slab_store<ST>(g_b2, &S[(NET ? po.cb2 : po.ab2) + threadIdx.x]);
+        }
+    };
+    auto store_layer1 = [&]() {
+        if constexpr (!PUB) {
+            const int oW1 = NET ? po.cW1 : po.aW1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jb = 0; jb < kMaxJ; ++jb) {
+                    const int c = 16 * jb + r16;
+                    if (jb < d.nJ && c < d.D) slab_store<ST>(g_W1[jb][r], &S[oW1 + (16 * w + kq * 4 + r) * d.D + c]);
+                }
+            if (threadIdx.x < H) slab_store<ST>(g_b1, &S[(NET ? po.cb1 : po.ab1) + threadIdx.x]);
+        }
+    };
+    bool stored = false;   // (a workgroup without a tile -- grid larger than the tile count -- stores its zeros at the end)
     NSTAMP(1);
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int64_t row0 = t * R;
+        const bool last_tile = t + gridDim.x >= n_tiles;
         __syncthreads();
         commit_tile_x(lds, ln.X, d, xr);
         const RowIn cur = rin;
@@ -816,6 +860,7 @@ __device__ __forceinline__ void ppo_update_net(
                 g_b3 += s;
             }
         }
+        if (last_tile) { store_out_layer(); stored = true; }
         __syncthreads();
         NSTAMP(7);
         // ---- hidden layer 2 gradients + dh1 ----
@@ -846,6 +891,7 @@ __device__ __forceinline__ void ppo_update_net(
                 lds[ln.D1 + row * ln.ldh + col] = lds[ln.H1 + row * ln.ldh + col] > 0.f ? acc[r] : 0.f;
             }
         }
+        if (last_tile) store_layer2();
         __syncthreads();
         NSTAMP(8);
         if constexpr (PUB) {   // ---- publish the tile instead of layer-1 gradients (rows as 16-byte pieces: 8-byte aligned in LDS) ----
@@ -881,33 +927,9 @@ __device__ __forceinline__ void ppo_update_net(
     }
 
     NSTAMP(9);
-    // ---- this net's half of the workgroup's gradient slab ----
-    if constexpr (!PUB) {
-    float *S = slabs + (int64_t)blockIdx.x * po.total;
-    const int oW1 = NET ? po.cW1 : po.aW1, oW2 = NET ? po.cW2 : po.aW2;
-    const int colq = r16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = kq * 4 + r;
-        if (NET == 0 && row < d.A) slab_store<ST>(g_W3[r], &S[po.aW3 + row * H + 16 * w + colq]);
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-            slab_store<ST>(g_W2[jb][r], &S[oW2 + (16 * w + row) * H + 16 * jb + colq]);
-#pragma unroll
-        for (int jb = 0; jb < kMaxJ; ++jb) {
-            const int c = 16 * jb + colq;
-            if (jb < d.nJ && c < d.D) slab_store<ST>(g_W1[jb][r], &S[oW1 + (16 * w + row) * d.D + c]);
-        }
-    }
-    if (threadIdx.x < H) {
-        const int c = threadIdx.x;
-        slab_store<ST>(g_b1, &S[(NET ? po.cb1 : po.ab1) + c]);
-        slab_store<ST>(g_b2, &S[(NET ? po.cb2 : po.ab2) + c]);
-        if (NET) slab_store<ST>(g_W3c, &S[po.cW3 + c]);
-    }
-    if (NET == 0 && threadIdx.x < d.A) slab_store<ST>(g_b3, &S[po.ab3 + threadIdx.x]);
-    if (NET == 1 && threadIdx.x == 0) slab_store<ST>(g_b3, &S[po.cb3]);
-    }
+    // ---- what is left of this net's half of the workgroup's gradient slab ----
+    if (!stored) { store_out_layer(); store_layer2(); }
+    store_layer1();
     NSTAMP(10);
     // loss partial sums: actor -> clip objective [0], entropy [2]; critic -> value loss [1]
     {
