@@ -563,6 +563,55 @@ __device__ __forceinline__ void slab_store(float v, float *p) {
 template <int H>
 constexpr int pub_floats(int ld1) { return 4 * R * H + R * ld1 + R * LayN<H>::ldo; }
 
+// s = 0; s = fmaf(h[j], w[j], s) for j = 0 .. N - 1 in this order (the critic's output layer on one lane per row) with the operands read
+// from LDS eight steps at a time, a group ahead of their use.  The plain loop read four values, waited, used them: 0.84-0.88 us for a
+// 64-long chain against 0.52 us this way (tools/stamp_update.py).  Here only: in the rollout kernels the 32 registers it holds
+// cost spills.
+template <int N>
+__device__ __forceinline__ float fmaf_chain_ahead(const float *h, const float *w) {
+    constexpr int Q = 8;
+    static_assert(N % (2 * Q) == 0, "pairs of whole groups");
+    float h0[Q], w0[Q], h1[Q], w1[Q], s = 0.f;
+    int off = 0;   // always 0, but opaque: ties each group's reads to the chain (see `pin` below)
+    // (Ordering by data, not by __builtin_amdgcn_sched_barrier: the reads have no dependence on the barrier intrinsic, instruction
+    //  selection hoists all 128 of them to the top of the block and the machine scheduler may then not move them back across the
+    //  barriers -- 128 live registers, measured: 149 -> 256 + spills.  The empty asm reads and writes BOTH the running sum and the
+    //  offset the next group's addresses use: it cannot move above the fmas before it, nor the next group's reads above it.)
+    auto pin = [&]() { asm volatile("" : "+v"(s), "+v"(off)); };
+#pragma unroll
+    for (int p = 0; p < Q; ++p) { h0[p] = h[p]; w0[p] = w[p]; }
+#pragma unroll
+    for (int j0 = 0; j0 < N; j0 += 2 * Q) {
+        pin();
+#pragma unroll
+        for (int p = 0; p < Q; ++p) { h1[p] = h[off + j0 + Q + p]; w1[p] = w[off + j0 + Q + p]; }
+#pragma unroll
+        for (int p = 0; p < Q; ++p) s = fmaf(h0[p], w0[p], s);
+        pin();
+        if (j0 + 2 * Q < N) {
+#pragma unroll
+            for (int p = 0; p < Q; ++p) { h0[p] = h[off + j0 + 2 * Q + p]; w0[p] = w[off + j0 + 2 * Q + p]; }
+        }
+#pragma unroll
+        for (int p = 0; p < Q; ++p) s = fmaf(h1[p], w1[p], s);
+    }
+    return s;
+}
+
+// sum over the R tile rows of one column (row pitch `ld`), rows in increasing order -- s = 0; s += v[0]; ... -- with all R reads issued
+// before the first addition (the plain loop read a few values, waited, added: 0.3-0.4 us per bias vector on wave 0, which the other
+// waves then waited for at the phase's barrier)
+__device__ __forceinline__ float column_sum(const float *col, int ld) {
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = col[r * ld];
+    __builtin_amdgcn_sched_barrier(0);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) s += v[r];
+    return s;
+}
+
 template <int H, int NET, int ST, bool PUB = false>
 __device__ __forceinline__ void ppo_update_net(
     float *lds, const float *__restrict__ P, const float *__restrict__ img, const Dims &d, const float *__restrict__ obs,
@@ -737,9 +786,7 @@ __device__ __forceinline__ void ppo_update_net(
                 for (int r = 0; r < 4; ++r) lds[ln.OUT + (kq * 4 + r) * ln.ldo + r16] = acc[r] + b;
             }
         } else if (threadIdx.x < R) {
-            const float *hc = lds + ln.H2 + threadIdx.x * ln.ldh;
-            float sv = 0.f;
-            for (int j = 0; j < H; ++j) sv = fmaf(hc[j], lds[ln.W3 + j], sv);
+            const float sv = fmaf_chain_ahead<H>(lds + ln.H2 + threadIdx.x * ln.ldh, lds + ln.W3);
             lds[ln.OUT + threadIdx.x * ln.ldo + 16] = sv + lds[ln.B3];
         }
         __syncthreads();
@@ -838,26 +885,36 @@ __device__ __forceinline__ void ppo_update_net(
                 const int row = kq * 4 + r;
                 lds[ln.D2 + row * ln.ldh + col] = lds[ln.H2 + row * ln.ldh + col] > 0.f ? acc[r] : 0.f;
             }
-            if (!PUB && threadIdx.x < 16) {
-                float s = 0.f;
-                for (int r = 0; r < R; ++r) s += lds[ln.D3 + r * ln.ldo + threadIdx.x];
-                g_b3 += s;
-            }
+            if (!PUB && threadIdx.x < 16) g_b3 += column_sum(lds + ln.D3 + threadIdx.x, ln.ldo);
         } else {
-            for (int e = threadIdx.x; e < R * H; e += NT) {
-                const int r = e / H, j = e - r * H;
-                const float hv = lds[ln.H2 + r * ln.ldh + j];
-                lds[ln.D2 + r * ln.ldh + j] = hv > 0.f ? lds[ln.D3 + r * ln.ldo + 16] * lds[ln.W3 + j] : 0.f;
+            // (round 5: every LDS read of the phase is issued before the first use.  Written as three loops -- dH2 elements, the W3
+            //  column chain, the b3 sum -- each iteration read, waited and computed: 1.2-1.3 us of the critic workgroup, which is the
+            //  slower of the two nets, tools/stamp_update.py.  Thread (w, j = tid & 63) owns dH2 rows w, w + 4, w + 8, w + 12 of column j;
+            //  wave 0 the W3 chain of column j over all 16 rows, in row order as before; thread 0 the b3 sum.)
+            static_assert(NT == 4 * H && R == 16, "one column per lane, four rows per wave");
+            const int j = threadIdx.x & (H - 1);
+            float d4[4], h4[4], dv[R], hcol[R];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { d4[k] = lds[ln.D3 + (4 * k + w) * ln.ldo + 16]; h4[k] = lds[ln.H2 + (4 * k + w) * ln.ldh + j]; }
+            const float w3j = lds[ln.W3 + j];
+            if (!PUB && w == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) { dv[r] = lds[ln.D3 + r * ln.ldo + 16]; hcol[r] = lds[ln.H2 + r * ln.ldh + j]; }
             }
-            if (!PUB && threadIdx.x < H) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds[ln.D2 + (4 * k + w) * ln.ldh + j] = h4[k] > 0.f ? d4[k] * w3j : 0.f;
+            if (!PUB && w == 0) {
                 float s = 0.f;
-                for (int r = 0; r < R; ++r) s = fmaf(lds[ln.D3 + r * ln.ldo + 16], lds[ln.H2 + r * ln.ldh + threadIdx.x], s);
+#pragma unroll
+                for (int r = 0; r < R; ++r) s = fmaf(dv[r], hcol[r], s);
                 g_W3c += s;
-            }
-            if (!PUB && threadIdx.x == 0) {
-                float s = 0.f;
-                for (int r = 0; r < R; ++r) s += lds[ln.D3 + r * ln.ldo + 16];
-                g_b3 += s;
+                if (threadIdx.x == 0) {
+                    float sb = 0.f;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) sb += dv[r];
+                    g_b3 += sb;
+                }
             }
         }
         if (last_tile) { store_out_layer(); stored = true; }
@@ -873,11 +930,7 @@ __device__ __forceinline__ void ppo_update_net(
 #pragma unroll
                     for (int k0 = 0; k0 < R; k0 += 4) g_W2[jb] = mfma(dA[k0 * ln.ldh], hB[k0 * ln.ldh], g_W2[jb]);
                 }
-                if (threadIdx.x < H) {
-                    float s = 0.f;
-                    for (int r = 0; r < R; ++r) s += lds[ln.D2 + r * ln.ldh + threadIdx.x];
-                    g_b2 += s;
-                }
+                if (threadIdx.x < H) g_b2 += column_sum(lds + ln.D2 + threadIdx.x, ln.ldh);
             }
             f4 acc = zero;
             const float *dR = lds + ln.D2 + r16 * ln.ldh + kq;
@@ -918,11 +971,7 @@ __device__ __forceinline__ void ppo_update_net(
                     for (int k0 = 0; k0 < R; k0 += 4) g_W1[jb] = mfma(dA[k0 * ln.ldh], xB[k0 * d.ld1], g_W1[jb]);
                 }
             }
-            if (threadIdx.x < H) {
-                float s = 0.f;
-                for (int r = 0; r < R; ++r) s += lds[ln.D1 + r * ln.ldh + threadIdx.x];
-                g_b1 += s;
-            }
+            if (threadIdx.x < H) g_b1 += column_sum(lds + ln.D1 + threadIdx.x, ln.ldh);
         }
     }
 
@@ -958,7 +1007,8 @@ __device__ __forceinline__ void ppo_update_net(
 // headline job's 18 -- its index arithmetic (divisions by ld1 and D, layout offsets) then costs constants instead of ~35-instruction
 // integer divisions and scalar registers.
 template <int H, int ST, int DS, bool PUB = false>
-__global__ __launch_bounds__(NT) void ppo_update_split_kernel(
+__global__ __launch_bounds__(NT, 2) void ppo_update_split_kernel(   // (2: waves per SIMD at least -- both nets' workgroups of a tile share a CU)
+
     const float *__restrict__ P, const float *__restrict__ img, Dims d_arg, const float *__restrict__ obs,
     const int32_t *__restrict__ act, const float *__restrict__ logp_old, const float *__restrict__ adv,
     const float *__restrict__ returns, const float *__restrict__ v_s_old, const int64_t *__restrict__ perm, int64_t first,
