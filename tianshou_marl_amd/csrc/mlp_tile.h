@@ -59,6 +59,40 @@ __device__ __forceinline__ f4 mfma(float a, float b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// s = 0; s = fmaf(h[j], w[j], s) for j = 0 .. N - 1 in this order (the critic's output layer on one lane per row) with the operands read
+// from LDS eight steps at a time, a group ahead of their use.  The plain loop read four values, waited, used them: 0.84-0.88 us for a
+// 64-long chain against 0.52 us this way (tools/stamp_update.py).
+template <int N>
+__device__ __forceinline__ float fmaf_chain_ahead(const float *h, const float *w) {
+    constexpr int Q = 8;
+    static_assert(N % (2 * Q) == 0, "pairs of whole groups");
+    float h0[Q], w0[Q], h1[Q], w1[Q], s = 0.f;
+    int off = 0;   // always 0, but opaque: ties each group's reads to the chain (see `pin` below)
+    // (Ordering by data, not by __builtin_amdgcn_sched_barrier: the reads have no dependence on the barrier intrinsic, instruction
+    //  selection hoists all 128 of them to the top of the block and the machine scheduler may then not move them back across the
+    //  barriers -- 128 live registers, measured: 149 -> 256 + spills.  The empty asm reads and writes BOTH the running sum and the
+    //  offset the next group's addresses use: it cannot move above the fmas before it, nor the next group's reads above it.)
+    auto pin = [&]() { asm volatile("" : "+v"(s), "+v"(off)); };
+#pragma unroll
+    for (int p = 0; p < Q; ++p) { h0[p] = h[p]; w0[p] = w[p]; }
+#pragma unroll
+    for (int j0 = 0; j0 < N; j0 += 2 * Q) {
+        pin();
+#pragma unroll
+        for (int p = 0; p < Q; ++p) { h1[p] = h[off + j0 + Q + p]; w1[p] = w[off + j0 + Q + p]; }
+#pragma unroll
+        for (int p = 0; p < Q; ++p) s = fmaf(h0[p], w0[p], s);
+        pin();
+        if (j0 + 2 * Q < N) {
+#pragma unroll
+            for (int p = 0; p < Q; ++p) { h0[p] = h[off + j0 + 2 * Q + p]; w0[p] = w[off + j0 + 2 * Q + p]; }
+        }
+#pragma unroll
+        for (int p = 0; p < Q; ++p) s = fmaf(h1[p], w1[p], s);
+    }
+    return s;
+}
+
 // parameter offsets in the flat vector
 template <int H>
 struct POff {
@@ -261,6 +295,7 @@ __device__ __forceinline__ void tile_forward_split(float *lds, const Lay<H> &ly,
 #pragma unroll
         for (int r = 0; r < 4; ++r) lds[ly.OUT + (kq * 4 + r) * ly.ldo + r16] = acc[r] + b;
     } else if (w8 == 4 && lane < R) {  // value (VALU dot)
+        // (fmaf_chain_ahead here changed nothing in the rollouts: their forward 1.60 -> 1.64 us, round 5)
         const float *hc = lds + ly.H2 + lane * ly.ld2 + H;
         float s = 0.f;
         for (int j = 0; j < H; ++j) s = fmaf(hc[j], lds[ly.W3c + j], s);
