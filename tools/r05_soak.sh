@@ -1,8 +1,9 @@
 #!/usr/bin/env bash
 # Round-5 soak / determinism record (run through gpurun from the repo root): every job twice, the two hash lines must agree.
-# Jobs: the paths this round changed -- the C3 PPO job (critic step from the W1 fragment image, one-output loss head, 48-column dW1
-# blocks with side reductions, one-row optimizer segments, batched weight staging) with and without a gradient-norm clip, the CTDE
-# job (96-column dW1 blocks, TD form of the tile kernel), and the headline / tag jobs again.
+# Jobs: the paths this round changed -- the headline job (update kernel: prologue in two round trips, per-layer slab stores, the critic's
+# phases read ahead; rollout: pair-force tasks, index algebra beside the head, uniforms drawn ahead), the tag job (the same rollout
+# changes, learners on the stored rollout outputs), the C3 PPO job (actor kernel: operands read ahead, ReLU bits, LDS-buffered rows)
+# with and without a gradient-norm clip, and the CTDE job.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r05_soak_determinism.txt
 echo "# tools/soak_determinism.py, two independent runs per job (MI355X, round 5): equal sha256 lines = bit-reproducible" > $out
