@@ -348,14 +348,15 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
             a.obs_store[dst] = lds[xcur + rr * d.ld1 + k];
             if (a.obs_next_store) a.obs_next_store[dst] = XN[rr * d.ld1 + k];
         }
-        if (lane_live) {
-            const int64_t dst = s_row[g + el] * N + ai;
-            a.act_store[dst] = s_act[r];
-            a.rew_store[dst] = s_rew[r];
+        if (ur >= 0 && ur < rows_here) {   // (the rows' payload on wave 5: wave 0 has its observation elements to store)
+            const int pel = ur / N, pai = ur - pel * N;
+            const int64_t dst = s_row[g + pel] * N + pai;
+            a.act_store[dst] = s_act[ur];
+            a.rew_store[dst] = s_rew[ur];
             a.term_store[dst] = 0;
-            a.trunc_store[dst] = (uint8_t)s_done[g + el];
-            if (a.logp_store) a.logp_store[dst] = s_logp[r];
-            if (a.vs_store) a.vs_store[dst] = s_val[r];
+            a.trunc_store[dst] = (uint8_t)s_done[g + pel];
+            if (a.logp_store) a.logp_store[dst] = s_logp[ur];
+            if (a.vs_store) a.vs_store[dst] = s_val[ur];
         }
         STAMP(5);
         // F. finished episodes: critic value of the terminal observation, then re-initialise the env
