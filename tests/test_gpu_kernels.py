@@ -627,3 +627,45 @@ def test_gather_fields_maps_and_converts_like_torch():
         ops.gather_fields([(x.double(), torch.empty(33, 4, device=DEV))])
     with pytest.raises(ValueError):
         ops.gather_fields([(obs, torch.empty(E * T, D, device=DEV), T, E, N * D, N * D)])  # the last agent's column + D leaves the store
+
+
+@pytest.mark.parametrize("case", [
+    (18, 5, 76800, 4096, {}, True, False),                                   # the job's gradient step: one tile per workgroup
+    (18, 5, 76800, 5120, {}, True, False),                                   # two tiles on some workgroups (last-tile stores)
+    (18, 5, 5000, 1000, {}, False, False),                                   # weights from the flat vector
+    (48, 5, 9000, 4099, dict(dual_clip=2.0, value_clip=True), True, True),  # ragged tail, value clip
+    (33, 9, 3000, 257, dict(adv_norm=False), True, False),
+    (18, 5, 819200, 65536, {}, True, False),                                 # 16 tiles per workgroup
+])
+def test_update_kernel_one_net_per_workgroup_equals_both_nets_bit_for_bit(case):
+    """ppo_update_split_kernel (what every job runs: staging in two round trips, per-layer slab stores on the last tile, the critic's
+    phases reading LDS ahead, round 5) against ppo_update_kernel (both nets in one workgroup, the plain loops): equal gradient slabs
+    and loss statistics, bit for bit -- every sum keeps its order whatever the kernel waits for."""
+    import ctypes
+
+    from tianshou_marl_amd import _abi
+    from tianshou_marl_amd.utils.net import DiscreteActorCritic
+
+    D, A, n, M, kw, use_image, vclip = case
+    lib = _abi.load()
+    lib.tsm_debug_set_update_variant.argtypes = [ctypes.c_int]
+    cfg = ops.make_ppo_cfg(**kw)
+    out = []
+    try:
+        for variant in (0, 1):
+            lib.tsm_debug_set_update_variant(variant)
+            torch.manual_seed(0)
+            net = DiscreteActorCritic(D, A, 64, device=DEV, seed=0)
+            obs = torch.randn(n, D, device=DEV)
+            act = torch.randint(0, A, (n,), dtype=torch.int32, device=DEV)
+            logp, adv, ret, v_old = (torch.randn(n, device=DEV) for _ in range(4))
+            logp = logp * 0.3 - 1.5
+            perm = torch.randperm(n, device=DEV)[:M].contiguous()
+            stats = ops.ppo_adv_stats(adv, torch.tensor([0, M], device=DEV), perm=perm)
+            slabs, sc = ops.ppo_update_fused(net.flat.data, obs, act, logp, adv, ret, cfg, A, 64, adv_stats=stats[0], perm=perm, M=M,
+                                             v_s_old=v_old if vclip else None, image=net.image if use_image else None)
+            torch.cuda.synchronize()
+            out.append((slabs.clone(), sc.clone()))
+    finally:
+        lib.tsm_debug_set_update_variant(0)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
