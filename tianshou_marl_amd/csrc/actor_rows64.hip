@@ -468,6 +468,18 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
         }
         __syncthreads();
         ASTAMP(9);
+        // (round 5) the last tile has added to dW2: its 64 KB of the slab go out now, under layer 1's gradients, instead of with
+        // everything else behind the loop -- all 256 workgroups store at once there.  (Here, not right behind the dW2 stream: the dH1
+        // accumulators are dead.)
+        if (tile + gridDim.x >= n_tiles) {
+            int lo = (16 * w + kq * 4) * kH + c16;
+            asm volatile("" : "+v"(lo));   // (computed here: as a loop invariant the address pair is hoisted and spills two registers)
+            float *slab_ = g.slabs + (size_t)blockIdx.x * (size_t)(oB3 + A) + oW2 + lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab_ + r * kH + 16 * ti);
+        }
         // ---- P7: dW1 += dH1^T X ; db1 ----
         {
             const float *a = lds + oH1 + kq * kLdh + col;            // A[i = out o][k = row]
@@ -505,8 +517,10 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
             const int i = 16 * ti + c16;
             if (i < D) __builtin_nontemporal_store(gW1[ti][r], slab + oW1 + o * D + i);
         }
+        if ((int64_t)blockIdx.x >= n_tiles) {   // (a workgroup with tiles stored dW2 behind its last tile's P6; one without stores its zeros)
 #pragma unroll
-        for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + oW2 + o * kH + 16 * ti + c16);
+            for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + oW2 + o * kH + 16 * ti + c16);
+        }
         const int a = kq * 4 + r;
         if (a < A) __builtin_nontemporal_store(gW3[r], slab + oW3 + a * kH + 16 * w + c16);
     }
@@ -530,7 +544,9 @@ __global__ __launch_bounds__(kThreads) void actor_rows64_kernel(TsmActorArgs g) 
         __shared__ double s_stat[2][kThreads / 64];
         const double t_clip = hj == 0 ? s_tstat[hs][0] : 0.0, t_ent = hj == 0 ? s_tstat[hs][1] : 0.0;   // (written by this thread)
         const double c = wave_sum(t_clip), e = wave_sum(t_ent);
-        if (lane == 0) { s_stat[0][w] = c; s_stat[1][w] = e; }
+        int t_ = threadIdx.x;
+        asm volatile("" : "+v"(t_));   // (lane and wave index re-derived here: kept from the prologue they cost the kernel's 257th register)
+        if ((t_ & 63) == 0) { s_stat[0][t_ >> 6] = c; s_stat[1][t_ >> 6] = e; }
         __syncthreads();
         if (tid == 0) {
             double cc = 0.0, ee = 0.0;
