@@ -487,6 +487,17 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
 #pragma unroll
                 for (int ti = 0; ti < 8; ++ti) gW2[ti] = mfma4(av, b[r0 * kLdh + 16 * ti], gW2[ti]);
             }
+            // (round 5) the last tile has added to dW2: its 64 KB of the slab go out now, under the dH1 products, instead of behind
+            // the loop where all 256 workgroups store at once (csrc/actor_rows64.hip: the same move was worth 5 us of a 103 us launch)
+            if (tile + gs >= n_tiles) {
+                int lo = (16 * w + kq * 4) * kH + c16;
+                asm volatile("" : "+v"(lo));   // (computed here, not hoisted out of the loop: registers)
+                float *sl_ = g.slabs + (size_t)blockIdx.x * (size_t)(oB3 + n_out - oB1) + (oW2 - oB1) + lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], sl_ + r * kH + 16 * ti);
+            }
         }
         {
             const float *q = lds + ly.H2 + 8 * (tid >> 7) * kLdh + (tid & 127);
@@ -535,8 +546,10 @@ __global__ __launch_bounds__(kThreads) void critic_rows_train_kernel(TrainArgs g
     for (int r = 0; r < 4; ++r) {
         const int o = 16 * w + kq * 4 + r;
         if constexpr (!pub) {
+            if ((int64_t)blockIdx.x >= n_tiles) {   // (a workgroup with tiles stored dW2 behind its last tile's products; one without: zeros)
 #pragma unroll
-            for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + sW2 + o * kH + 16 * ti + c16);
+                for (int ti = 0; ti < 8; ++ti) __builtin_nontemporal_store(gW2[ti][r], slab + sW2 + o * kH + 16 * ti + c16);
+            }
         }
         if constexpr (LOSS != 0) {
             const int a = kq * 4 + r;

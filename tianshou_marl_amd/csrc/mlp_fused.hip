@@ -896,6 +896,7 @@ __device__ __forceinline__ void ppo_update_net(
                     for (int k0 = 0; k0 < R; k0 += 4) g_W2[jb] = mfma(dA[k0 * ln.ldh], hB[k0 * ln.ldh], g_W2[jb]);
                 }
                 if (threadIdx.x < H) g_b2 += column_sum(lds + ln.D2 + threadIdx.x, ln.ldh);
+                if (last_tile) store_layer2();   // (before the dH1 chain: the stores fly under its 16 dependent MFMAs)
             }
             f4 acc = zero;
             const float *dR = lds + ln.D2 + r16 * ln.ldh + kq;
@@ -909,7 +910,6 @@ __device__ __forceinline__ void ppo_update_net(
                 lds[ln.D1 + row * ln.ldh + col] = lds[ln.H1 + row * ln.ldh + col] > 0.f ? acc[r] : 0.f;
             }
         }
-        if (last_tile) store_layer2();
         __syncthreads();
         NSTAMP(8);
         if constexpr (PUB) {   // ---- publish the tile instead of layer-1 gradients (rows as 16-byte pieces: 8-byte aligned in LDS) ----
