@@ -265,9 +265,9 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         }
         __syncthreads();
         STAMP(3);
-        // D. env step, one lane per agent (mpe_dev.h): move -> barrier -> publish -> barrier -> reward terms.
-        //    Beside the move, the env lanes do the buffer index algebra on their register-resident sub-buffer state
-        //    (buffer_base.py:373-410 + manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h).
+        // D. env step (mpe_dev.h): pair forces -> barrier -> fold, integrate, publish -> barrier -> reward terms.
+        //    (The env lanes' buffer index algebra on their register-resident sub-buffer state -- buffer_base.py:373-410 +
+        //    manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h -- runs beside the head, above.)
         // (round 5: the pair forces as one (agent row, other agent) task per thread of waves 0-1, folded by the agent lanes in partner
         //  order -- mpe_agent_move's sums, rollout_wave64_kernel's scheme.  One lane per agent ran its N - 1 pair evaluations -- sqrt,
         //  exp, log1p, a division each when the pair is in range -- one after the other: 1.3-1.7 us of a 5.6 us step,
@@ -423,7 +423,8 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
 // ---- wave-autonomous form ------------------------------------------------------------------------------------------------
 // rollout_kernel above runs one 16-row tile per workgroup on eight waves: every phase of a vector step (forward layer by layer,
 // heads, env step, scatter) is a workgroup-wide phase behind a barrier, ~10 barriers and 8.8 us per step (6.8 us once compiled for the
-// job's dimensions) at BASELINE configs[1]
+// job's dimensions, 4.4-4.8 us since round 5 took the pair forces, the index algebra and the sampling uniforms off its dependent
+// chain) at BASELINE configs[1]
 // (1024 envs x 3 agents: 205 workgroups), with the matrix pipe busy 7 % of the time.  Here ONE WAVE owns the 16 / N environments
 // (<= 16 agent rows) for all T steps and runs a step from the observation to the buffer rows by itself, with no barrier and no
 // cross-wave hand-over: both nets' layers as transposed products on the wave's samples (wave_mlp.h: weights = A operand read

@@ -243,9 +243,9 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         }
         __syncthreads();
         TSTAMP(2);
-        // D. env step, one lane per agent (mpe_tag_dev.h): move -> barrier -> publish -> barrier -> reward terms.
-        //    Beside the move, the env lanes do the buffer index algebra on their register-resident sub-buffer state
-        //    (buffer_base.py:373-410 + manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h).
+        // D. env step (mpe_tag_dev.h): pair forces -> barrier -> fold, integrate, publish -> barrier -> reward terms.
+        //    (The env lanes' buffer index algebra on their register-resident sub-buffer state -- buffer_base.py:373-410 +
+        //    manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h -- runs beside the head, above.)
         // (round 5: the pair forces as one (agent row, other entity) task per thread of waves 0-3, folded by the agent lanes in entity
         //  order -- tag_agent_move's sums.  One lane per agent ran its 5 pair evaluations -- sqrt, exp, log1p, a division each when the
         //  pair is in range -- one after the other; csrc/rollout.hip has the measurement.)

@@ -41,5 +41,5 @@ x = full[900:964].reshape(8, 8)
 for t in range(1, 3):
     seq = [s[t][3]] + [x[t][k] for k in range(5)] + [s[t][4]]
     if x[t][5] > 0:
-        print("  move: wave 0's own part %.2f us, then %.2f us at the barrier (wave 1: the buffer index algebra)" % ((x[t][5] - s[t][3]) / 100.0, (x[t][0] - x[t][5]) / 100.0))
+        print("  move: wave 0's own part %.2f us, then %.2f us at the barrier (the other wave's pair tasks)" % ((x[t][5] - s[t][3]) / 100.0, (x[t][0] - x[t][5]) / 100.0))
     print("D sub-phases", [round((seq[i + 1] - seq[i]) / 100.0, 2) for i in range(6)], "(move, publish, min-dist+penalty, obs_next, reward, index algebra)")
