@@ -35,7 +35,7 @@ lib = _abi.load()
 lib.tsm_debug_set_stamps.argtypes = [ctypes.c_void_p]
 lib.tsm_debug_set_stamps(st.data_ptr())
 with policy_within_training_step(algo):
-    for _ in range(3):
+    for _ in range(int(os.environ.get("STAMP_COLLECTS", "200"))):   # (the stamps kept are the last collect's: warm clocks)
         col.collect(n_step=E * T)
         col.reset_buffer(keep_statistics=True)
 torch.cuda.synchronize()
