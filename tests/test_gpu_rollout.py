@@ -28,11 +28,12 @@ def _job(n_env, N, T, fused, seed=3, slots=None, **ppo_kw):
     return env, net, algo, buf, col
 
 
-# (1024, 3): 205 workgroups -> the eight-wave form of the kernel; (1400, 3): 280 workgroups of 70 KB LDS -> the four-wave
-# form (two workgroups per CU); (600, 8): 300 workgroups of 91 KB LDS -> eight waves again
+# (1024, 3): 205 workgroups -> the eight-wave form of the kernel; (1400, 3): 280 workgroups of 82 KB LDS -> eight waves (70 KB and the
+# four-wave form until round 5's pair-force scratch); (2100, 2): 263 workgroups of < 80 KB -> the four-wave form (two workgroups per
+# CU: its env / uniform / payload lanes sit on waves 1 and 2); (600, 8): 300 workgroups of 91 KB LDS -> eight waves again
 @pytest.mark.parametrize("n_env,N,T,steps", [(64, 3, 25, 25), (7, 3, 6, 15), (33, 8, 5, 12), (5, 1, 4, 9), (10, 2, 7, 7),
                                              (1024, 3, 25, 25), (1400, 3, 5, 7), (600, 8, 4, 6), (37, 6, 5, 7), (41, 5, 4, 6),
-                                             (130, 4, 6, 8), (300, 3, 5, 6), (600, 3, 5, 6)])
+                                             (130, 4, 6, 8), (300, 3, 5, 6), (600, 3, 5, 6), (2100, 2, 4, 6)])
 @pytest.mark.parametrize("form", ["wave", "tile"])
 def test_fused_rollout_is_bit_identical_to_unfused(n_env, N, T, steps, form):
     """Both forms of the 64-wide persistent rollout (option "rollout_form": the wave-autonomous one -- a wave owns 16 // N whole envs

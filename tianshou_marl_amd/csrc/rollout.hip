@@ -133,7 +133,9 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     const int r = threadIdx.x, el = r / N, ai = r - el * N;
     const bool lane_live = r < rows_here;
     const int e = e0 + el;
-    const int bel = (int)threadIdx.x - 256;  // env lane: local env index
+    // (the four-wave form has no waves 4 and 5: its env lanes sit on wave 1, its uniform / payload lanes on wave 2)
+    constexpr int kEnvBase = NT2 >= 512 ? 256 : 64, kUBase = NT2 >= 512 ? 320 : 128;
+    const int bel = (int)threadIdx.x - kEnvBase;  // env lane: local env index
     const bool env_lane = bel >= 0 && bel < n_here;
     const int be = e0 + bel;
     // sub-buffer bookkeeping of "my" env lives in registers for the whole rollout: the per-step index algebra
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     const uint64_t off0 = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
     // The sampling uniform of (step, row) depends on nothing the step computes: ten Philox rounds (~0.25 us of dependent
     // instructions) that the head used to run between the logits and the sample.  Wave 5 draws step t + 1's beside step t's head.
-    const int ur = (int)threadIdx.x - 320;   // uniform lane: row
+    const int ur = (int)threadIdx.x - kUBase;   // uniform lane: row
     const bool u_lane = a.mode == 1 && ur >= 0 && ur < rows_here;
     if (u_lane) s_u[ur] = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)e0 * N + (uint64_t)ur);
     __syncthreads();
