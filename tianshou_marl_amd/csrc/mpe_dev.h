@@ -165,3 +165,11 @@ __device__ __forceinline__ float mpe_reward(const MpeCfg &c, const float *m, flo
     for (int l = 0; l < c.N; ++l) global -= m[l];
     return global * (1.f - c.local_ratio) + local * c.local_ratio;
 }
+// ... the same fold on minima held in registers (gathered from other lanes)
+__device__ __forceinline__ float mpe_reward_regs(const MpeCfg &c, const float (&m)[kMpeMaxN], float local) {
+    float global = 0.f;
+#pragma unroll
+    for (int l = 0; l < kMpeMaxN; ++l)
+        if (l < c.N) global -= m[l];
+    return global * (1.f - c.local_ratio) + local * c.local_ratio;
+}

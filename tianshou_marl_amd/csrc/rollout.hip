@@ -138,18 +138,54 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
     const int bel = (int)threadIdx.x - kEnvBase;  // env lane: local env index
     const bool env_lane = bel >= 0 && bel < n_here;
     const int be = e0 + bel;
+    // DEFER (eight-wave form): the reward terms of a step that ends no episode -- landmark minima, collision penalty, reward, the
+    // episode returns and the rew_store row -- are not needed by the next step's forward pass: wave 6, idle during the head
+    // (phase C), computes them ONE STEP LATE from the positions the env step left in LDS (they move again only in the next
+    // step's phase D, behind two barriers).  A step that ends an episode keeps them in place, before the reset (phase F).
+    // Same functions on the same inputs: the same bits.  The episode-return accumulators live on wave 6's lanes then.
+    constexpr bool DEFER = NT2 >= 512;
+    constexpr int kRewBase = 384;
+    const int wl = (int)threadIdx.x - kRewBase;           // reward lane: agent row wl; for wl < n_here also env wl's returns
+    const bool rew_lane = DEFER && wl >= 0 && wl < rows_here;
+    // (the episode returns of a step follow on wave 7, one phase later still: beside the next step's pair forces)
+    constexpr int kRetBase = 448;
+    const int rl = (int)threadIdx.x - kRetBase;
+    const bool ret_lane = DEFER ? (rl >= 0 && rl < n_here) : env_lane;
+    const int rq = DEFER ? rl : bel;                      // the return lane's local env
+    bool pending = false;                                 // (uniform) the previous step's reward terms are still to do
     // sub-buffer bookkeeping of "my" env lives in registers for the whole rollout: the per-step index algebra
     // then has no dependent global loads, only fire-and-forget stores
     int64_t v_ins = 0, v_size = 0, v_eplen = 0, v_epstart = 0, v_last = 0;
-    int n_fin = 0;  // episodes this env finished during the rollout
+    int n_fin = 0;    // episodes this env finished during the rollout (env lanes)
+    int n_fin_r = 0;  // the same count on the return lanes
     double v_epret[kMpeMaxN];
 #pragma unroll
     for (int k = 0; k < kMpeMaxN; ++k) v_epret[k] = 0.0;
+    if (ret_lane) {
+#pragma unroll
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) v_epret[k] = vs.ep_return[(int64_t)(e0 + rq) * N + k];
+    }
+    // episode returns of step tt on the return lanes from the rewards in s_rew: trq = the env's episode ends at that step
+    auto step_returns = [&](int tt, bool trq) {
+        const int64_t bq = e0 + rq;
+        const bool recq = trq && a.ep_rec && n_fin_r < a.max_ep;
+        const int64_t oq = (int64_t)tt * B + bq;
+        double *rec_rew = recq ? reinterpret_cast<double *>(a.ep_rec + B + (int64_t)B * a.max_ep) +
+                                     ((int64_t)bq * a.max_ep + n_fin_r) * N : nullptr;
+#pragma unroll
+        for (int k = 0; k < kMpeMaxN; ++k) {
+            if (k < N) {
+                const double acc = v_epret[k] + (double)s_rew[rq * N + k];
+                a.ep_rew_out[oq * N + k] = trq ? acc : 0.0;
+                if (recq) rec_rew[k] = acc;
+                v_epret[k] = trq ? 0.0 : acc;
+            }
+        }
+        n_fin_r += trq ? 1 : 0;
+    };
     if (env_lane) {
         v_ins = vs.ins[be]; v_size = vs.size[be]; v_eplen = vs.ep_len[be]; v_epstart = vs.ep_start[be];
         v_last = vs.last_index[be];
-#pragma unroll
-        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) v_epret[k] = vs.ep_return[(int64_t)be * N + k];
         s_steps[bel] = a.steps[be];
         s_done[bel] = 1; s_done[R + bel] = 1;  // "no pending v_next" before the first step
         s_row[bel] = 0; s_row[R + bel] = 0;
@@ -205,6 +241,7 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
             // (the record carries CollectStats.lens = len(episode_batch): the episode's rows IN THE BUFFER, collector.py:203,990-993 --
             //  after a reset_buffer(keep_statistics=True) an episode counts its rows since the reset; ep_len_out stays add()'s ep_len)
             if (rec) a.ep_rec[B + (int64_t)be * a.max_ep + n_fin] = ((int64_t)t << 32) | ((cur >= v_epstart ? cur - v_epstart : cur - v_epstart + a.S) + 1);
+            n_fin += tr ? 1 : 0;
             a.ep_len_out[o] = tr ? elen : 0;
             a.ptr_out[o] = cur + (int64_t)be * a.S;
             a.ep_idx_out[o] = v_epstart + (int64_t)be * a.S;
@@ -217,6 +254,25 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
             if (bel == 0) s_any[t & 1] = ends != 0ull;
         }
         if (u_lane && !last) s_u[((t + 1) & 1) * R + ur] = tsm_philox_uniform(a.pol_seed, off0 + (uint64_t)(t + 1) * B * N + (uint64_t)e0 * N + (uint64_t)ur);
+        if (DEFER && pending) {
+            // wave 6, beside the head: the reward terms of step t - 1, which ended no episode (generation g ^ R)
+            if (wl >= 0 && wl < 64) {
+                // (all 64 lanes run it: the minima travel between lanes by ds_bpermute -- one round trip, where an LDS write -> read pair
+                //  costs two; idle lanes work on row 0 and store nothing)
+                const int wr = wl < rows_here ? wl : 0;
+                const int wel = wr / N, wai = wr - wel * N;
+                const int64_t rowq = s_row[(g ^ R) + wel];      // (read ahead of the chain below)
+                const MpePos pos = mpe_load_pos(c, s_ap + wel * st);
+                const float md = mpe_landmark_min_dist(c, pos, s_lp + wel * st, wai);
+                const float local = mpe_local_penalty(c, pos, s_ap + wel * st, wai);
+                float mv[kMpeMaxN];
+#pragma unroll
+                for (int l = 0; l < kMpeMaxN; ++l) mv[l] = l < N ? __shfl(md, wel * N + l, 64) : 0.f;
+                const float rw = mpe_reward_regs(c, mv, local);
+                if (wl < rows_here) { s_rew[wl] = rw; a.rew_store[rowq * N + wai] = rw; }
+            }
+            pending = false;
+        }
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
         if (main_t) {
@@ -256,6 +312,12 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
                 }
             }
         }
+        __syncthreads();
+        STAMP(3);
+        // the episode returns of step t - 1 from s_rew (written by that step's reward phase, or by wave 6 just above): wave 7, beside the pair forces
+        if (DEFER && t > 0 && ret_lane) {
+            step_returns(t - 1, s_done[(g ^ R) + rq] != 0);
+        }
         if (last) {
             // the observation of the next collect() call
             if (a.obs_cur_out)
@@ -265,8 +327,6 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
                 }
             break;
         }
-        __syncthreads();
-        STAMP(3);
         // D. env step (mpe_dev.h): pair forces -> barrier -> fold, integrate, publish -> barrier -> reward terms.
         //    (The env lanes' buffer index algebra on their register-resident sub-buffer state -- buffer_base.py:373-410 +
         //    manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h -- runs beside the head, above.)
@@ -309,61 +369,63 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         }
         __syncthreads();
         XSTAMP(1);
-        float local = 0.f;
-        if (lane_live) {
-            const MpePos pos = mpe_load_pos(c, s_ap + el * st);
-            s_m[r] = mpe_landmark_min_dist(c, pos, s_lp + el * st, ai);
-            local = mpe_local_penalty(c, pos, s_ap + el * st, ai);
-        }
-        XSTAMP(2);
-        // obs_next rows (terminal observation for finished episodes) on waves 1-7 while wave 0 works on the reward terms
-        if (threadIdx.x >= 64)
-            for (int i = threadIdx.x - 64; i < rows_here * D; i += NT2 - 64) {
-                const int rr = i / D, k = i - rr * D, ee = rr / N;
-                XN[rr * d.ld1 + k] =
-                    mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
+        // (the env lanes left the flag beside the index algebra: a workgroup-wide OR here cost two barriers per step, 0.36 us)
+        const int any_done = s_any[t & 1];
+        const bool now = !DEFER || any_done;   // (uniform) this step's reward terms in place: an episode ends, the envs are about to be reset
+        if (now) {
+            float local = 0.f;
+            if (lane_live) {
+                const MpePos pos = mpe_load_pos(c, s_ap + el * st);
+                s_m[r] = mpe_landmark_min_dist(c, pos, s_lp + el * st, ai);
+                local = mpe_local_penalty(c, pos, s_ap + el * st, ai);
             }
-        __syncthreads();
-        XSTAMP(3);
-        if (lane_live) s_rew[r] = mpe_reward(c, s_m + el * N, local);
-        __syncthreads();
-        XSTAMP(4);
-        if (env_lane) {  // episode returns (needs the rewards); runs beside the payload scatter below
-            double *rec_rew = rec ? reinterpret_cast<double *>(a.ep_rec + B + (int64_t)B * a.max_ep) +
-                                        ((int64_t)be * a.max_ep + n_fin) * N : nullptr;
-#pragma unroll
-            for (int k = 0; k < kMpeMaxN; ++k) {
-                if (k < N) {
-                    const double acc = v_epret[k] + (double)s_rew[bel * N + k];
-                    a.ep_rew_out[o * N + k] = tr ? acc : 0.0;
-                    if (rec) rec_rew[k] = acc;
-                    v_epret[k] = tr ? 0.0 : acc;
+            XSTAMP(2);
+            // (four-wave form) obs_next rows (terminal observation for finished episodes) on waves 1-3 while wave 0 works on the reward terms
+            if (!DEFER && threadIdx.x >= 64)
+                for (int i = threadIdx.x - 64; i < rows_here * D; i += NT2 - 64) {
+                    const int rr = i / D, k = i - rr * D, ee = rr / N;
+                    XN[rr * d.ld1 + k] =
+                        mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
                 }
+            __syncthreads();
+            XSTAMP(3);
+            if (lane_live) s_rew[r] = mpe_reward(c, s_m + el * N, local);
+            __syncthreads();
+            XSTAMP(4);
+            if (!DEFER && ret_lane) {  // episode returns (needs the rewards); runs beside the payload scatter below
+                step_returns(t, s_done[g + rq] != 0);
             }
-            n_fin += tr ? 1 : 0;
         }
         STAMP(4);
-        // E. payload scatter into the time-major SoA store (rows of consecutive envs are adjacent)
+        // E. payload scatter into the time-major SoA store (rows of consecutive envs are adjacent).  A step that ends no episode has
+        //    no reward phase: the thread that stores an obs_next element builds it here (no barrier between the build and the scatter)
         for (int i = threadIdx.x; i < rows_here * D; i += NT2) {
             const int rr = i / D, k = i - rr * D, ee = rr / N;
+            float v;
+            if constexpr (DEFER) {
+                v = mpe_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * st, rr - ee * N, k);
+                XN[rr * d.ld1 + k] = v;
+            } else {
+                v = XN[rr * d.ld1 + k];
+            }
             const int64_t dst = (s_row[g + ee] * N + (rr - ee * N)) * D + k;
             a.obs_store[dst] = lds[xcur + rr * d.ld1 + k];
-            if (a.obs_next_store) a.obs_next_store[dst] = XN[rr * d.ld1 + k];
+            if (a.obs_next_store) a.obs_next_store[dst] = v;
         }
         if (ur >= 0 && ur < rows_here) {   // (the rows' payload on wave 5: wave 0 has its observation elements to store)
             const int pel = ur / N, pai = ur - pel * N;
             const int64_t dst = s_row[g + pel] * N + pai;
             a.act_store[dst] = s_act[ur];
-            a.rew_store[dst] = s_rew[ur];
+            if (now) a.rew_store[dst] = s_rew[ur];
             a.term_store[dst] = 0;
             a.trunc_store[dst] = (uint8_t)s_done[g + pel];
             if (a.logp_store) a.logp_store[dst] = s_logp[ur];
             if (a.vs_store) a.vs_store[dst] = s_val[ur];
         }
+        if constexpr (DEFER) __syncthreads();   // the next forward (or F's) reads the obs_next rows at once
+        pending = !now;
         STAMP(5);
         // F. finished episodes: critic value of the terminal observation, then re-initialise the env
-        // (the env lanes left the flag beside the index algebra: a workgroup-wide OR here cost two barriers per step, 0.36 us)
-        const int any_done = s_any[t & 1];
         if (any_done) {
             if (a.vnext_store) {
                 lyf.X = xnxt;
@@ -410,8 +472,10 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         vs.ins[be] = v_ins; vs.size[be] = v_size; vs.ep_len[be] = v_eplen; vs.ep_start[be] = v_epstart;
         vs.last_index[be] = v_last; vs.lengths[be] = v_size;
         if (a.ep_rec) a.ep_rec[be] = n_fin;  // may exceed max_ep: the host treats that as an overflow
+    }
+    if (ret_lane) {
 #pragma unroll
-        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) vs.ep_return[(int64_t)be * N + k] = v_epret[k];
+        for (int k = 0; k < kMpeMaxN; ++k) if (k < N) vs.ep_return[(int64_t)(e0 + rq) * N + k] = v_epret[k];
     }
     // the last workgroup to get here advances the sampling counter: every workgroup read it (off0) before finishing
     if (a.done_ctr && threadIdx.x == 0) {
