@@ -1,4 +1,5 @@
-"""CPU check (no GPU needed: hipcc cross-compiles): no shipped gfx950 kernel spills vector registers or needs a scratch frame.
+"""CPU check (no GPU needed: hipcc cross-compiles): no shipped gfx950 kernel spills vector registers or touches a scratch frame
+(a frame the backend reserves and no instruction of the kernel's ISA loads from or stores to does not count: the tool counts them).
 
 VERDICT r4 item 8.  A register spill in a kernel that sits at the 256-register limit costs microseconds per launch and nothing in
 the results shows it (round 4 found a 404-register spill in `gae_long_kernel`: 122 -> 11 us once fixed; a run-time branch added

@@ -273,6 +273,26 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
             }
             pending = false;
         }
+        // pair force task p = (agent row p >> 3, other agent p & 7) -> s_cx / s_cy / s_cv[p]
+        auto pair_task = [&](int p) {
+            const int rp = p >> 3, jp = p & 7;
+            float sx = 0.f, sy = 0.f;
+            int ok = 0;
+            if (rp < rows_here && jp < N) {
+                const int ep = rp / N, ip = rp - ep * N;
+                const float *ap = s_ap + ep * st;
+                if (jp != ip) ok = mpe_pair_force(c, ap[2 * ip], ap[2 * ip + 1], ap[2 * jp], ap[2 * jp + 1], ip, jp, sx, sy) ? 1 : 0;
+            }
+            s_cx[p] = sx; s_cy[p] = sy; s_cv[p] = ok;
+        };
+        if (DEFER && !last) {
+            // The pair forces of THIS step depend on the positions alone, not on the actions the head is sampling: wave 7 evaluates them
+            // beside the head (up to four agents: 16 rows x 4 partners on its 64 lanes; more: waves 7 and 5 share the 128 tasks), and
+            // phase D starts at the fold.  (They ran as a phase of their own behind the head: 0.6-0.76 us of a 3.9 us step.)
+            if (N <= 4) { if (rl >= 0 && rl < 64) pair_task(((rl >> 2) << 3) | (rl & 3)); }
+            else if (rl >= 0 && rl < 64) pair_task(rl);
+            else if (ur >= 0 && ur < 64) pair_task(64 + ur);
+        }
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
         if (main_t) {
@@ -334,19 +354,11 @@ __global__ __launch_bounds__(NT2) void rollout_kernel(RolloutArgs a) {
         //  order -- mpe_agent_move's sums, rollout_wave64_kernel's scheme.  One lane per agent ran its N - 1 pair evaluations -- sqrt,
         //  exp, log1p, a division each when the pair is in range -- one after the other: 1.3-1.7 us of a 5.6 us step,
         //  profiles/r05_stamp_rollout.txt.)
-        if (threadIdx.x < R * 8) {
-            const int rp = threadIdx.x >> 3, jp = threadIdx.x & 7;
-            float sx = 0.f, sy = 0.f;
-            int ok = 0;
-            if (rp < rows_here && jp < N) {
-                const int ep = rp / N, ip = rp - ep * N;
-                const float *ap = s_ap + ep * st;
-                if (jp != ip) ok = mpe_pair_force(c, ap[2 * ip], ap[2 * ip + 1], ap[2 * jp], ap[2 * jp + 1], ip, jp, sx, sy) ? 1 : 0;
-            }
-            s_cx[threadIdx.x] = sx; s_cy[threadIdx.x] = sy; s_cv[threadIdx.x] = ok;
+        if constexpr (!DEFER) {
+            if (threadIdx.x < R * 8) pair_task(threadIdx.x);
+            XSTAMP(5);   // (wave 0 is through its own part: the pair forces)
+            __syncthreads();
         }
-        XSTAMP(5);   // (wave 0 is through its own part: the pair forces)
-        __syncthreads();
         XSTAMP(0);
         if (lane_live) {   // fold, integrate, publish: a lane reads and writes its own agent's position / velocity only
             const float px = s_ap[el * st + 2 * ai], py = s_ap[el * st + 2 * ai + 1];
