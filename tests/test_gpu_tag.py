@@ -267,10 +267,11 @@ def _tag_job(n_env, n_adv, n_good, n_obst, T, fused, slots, shared=False, determ
 
 
 # (512, 3, 1, 2): the configs[4] shard (128 workgroups); (300, 2, 2, 1): two good agents; (9, 1, 1, 0): no obstacles, a
-# ragged last workgroup; (40, 4, 2, 3): six agents -> two worlds per workgroup, four dead tile rows
+# ragged last workgroup; (40, 4, 2, 3): six agents -> two worlds per workgroup, four dead tile rows; (14, 3, 2, 4): 15 rows x 9
+# entities = 135 pair force tasks -> the second pass of the two waves that evaluate them beside the head, and a ragged last workgroup
 @pytest.mark.parametrize("n_env,n_adv,n_good,n_obst,T,steps,shared", [
     (512, 3, 1, 2, 25, 25, False), (300, 2, 2, 1, 5, 12, False), (9, 1, 1, 0, 4, 9, False), (40, 4, 2, 3, 6, 7, False),
-    (64, 3, 1, 2, 7, 10, True)])
+    (14, 3, 2, 4, 5, 8, False), (64, 3, 1, 2, 7, 10, True)])
 def test_fused_tag_rollout_is_bit_identical_to_unfused(n_env, n_adv, n_good, n_obst, T, steps, shared):
     """csrc/rollout_tag.hip: ONE launch per collect() must reproduce, bit for bit, the unfused Collector loop under grouped
     policies (per team policy_forward on agent-major rows -> tag step -> buffer add), across episode ends / re-initialised

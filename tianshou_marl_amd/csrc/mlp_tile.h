@@ -294,7 +294,8 @@ __device__ __forceinline__ void tile_forward_split(float *lds, const Lay<H> &ly,
         const float b = lds[ly.B3a + r16];
 #pragma unroll
         for (int r = 0; r < 4; ++r) lds[ly.OUT + (kq * 4 + r) * ly.ldo + r16] = acc[r] + b;
-    } else if (w8 == 4 && lane < R) {  // value (VALU dot)
+    } else if (w8 == 5 && lane < R) {  // value (VALU dot) -- on wave 5: wave 4 shares its SIMD with wave 0, and the f32 FMAs of one
+        // wave of a SIMD take turns with the MFMAs of the other (profiles/r05_probe_mfma_f32_issue.txt); tag rollout 185.4 -> 182.4 us
         // (fmaf_chain_ahead here changed nothing in the rollouts: their forward 1.60 -> 1.64 us, round 5)
         const float *hc = lds + ly.H2 + lane * ly.ld2 + H;
         float s = 0.f;

@@ -92,8 +92,7 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     float *s_ap = lds + xn0 + R * d.ld1;          // [EPB][NA][2]
     float *s_av = s_ap + R * 2;
     float *s_lp = s_av + R * 2;                   // [EPB][n_obst][2]  (EPB * n_obst <= 8 * 4)
-    float *s_hit = s_lp + 2 * 8 * kTagMaxObst;    // [R] 10 * (adversaries touching the good agent of this row)
-    float *s_rew = s_hit + R;                     // [R]
+    float *s_rew = s_lp + 2 * 8 * kTagMaxObst + R;  // [R]  (R floats in front of it are unused: the team's hit terms travel by shuffle)
     float *s_logp = s_rew + R;                    // [R]
     float *s_val = s_logp + R;                    // [R]
     int *s_act = reinterpret_cast<int *>(s_val + R);        // [R]
@@ -117,8 +116,8 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
     else stage_weights<H>(lds + wB, ly, d, a.P[1], (int)threadIdx.x - NT);
     for (int i = threadIdx.x; i < R * d.ld1; i += NT2) { lds[ly.X + i] = 0.f; lds[xn0 + i] = 0.f; }
     const VrbState vs = vrb_view(a.vrb_state, B, NA);
-    // agent lane r < rows_here (wave 0) <-> (env el, agent ai); env lane 256 + q (wave 4) owns env q's bookkeeping (beside the pair
-    // forces on waves 0-3)
+    // agent lane r < rows_here (wave 0) <-> (env el, agent ai); env lane 256 + q (wave 4) owns env q's bookkeeping; beside the head on
+    // waves 0-3 run the index algebra (wave 4), the next step's uniforms (wave 5) and this step's pair forces (waves 6, 7)
     const int r = threadIdx.x, el = r / NA, ai = r - el * NA;
     const bool lane_live = r < rows_here;
     const int e = e0 + el;
@@ -144,6 +143,16 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         s_av[i] = a.avel[(int64_t)e0 * st + i];
     }
     for (int i = threadIdx.x; i < n_here * lst; i += NT2) s_lp[i] = a.lpos[(int64_t)e0 * lst + i];
+    // the pair force tasks (agent row, other entity) of a step, NE per row, compacted over the 128 lanes of waves 6 and 7 (two passes
+    // cover 16 rows x 12 entities): packed (env << 8) | (agent << 4) | entity, -1 = no task
+    const int NE = NA + c.n_obst;
+    int pair_id[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = (int)threadIdx.x - 384 + 128 * q;
+        const int rp = p / NE, ep = rp / NA;
+        pair_id[q] = (threadIdx.x >= 384 && p < rows_here * NE) ? (ep << 8) | ((rp - ep * NA) << 4) | (p - rp * NE) : -1;
+    }
     const uint64_t off0 = a.offset_dev ? *a.offset_dev : 0ull;
     // the sampling uniform of (step, row) drawn one step ahead by wave 5, beside the head (csrc/rollout.hip has the story)
     const int ur = (int)threadIdx.x - 320, u_el = ur / NA, u_ai = ur - u_el * NA;
@@ -204,6 +213,19 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         }
         if (u_lane && t + 1 < a.n_steps)
             s_u[((t + 1) & 1) * R + ur] = tsm_philox_uniform(a.pol_seed[u_team], a.offset[u_team] + off0 + (uint64_t)(t + 1) * B * NA + u_gi);
+        // The pair forces of THIS step depend on the positions alone, not on the actions the head is sampling: waves 6 and 7 evaluate
+        // them beside the head, one (agent row, other entity) task per lane, and phase D starts at the fold (csrc/rollout.hip has the
+        // measurement; they ran as a phase of their own behind the head's barrier).
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (pair_id[q] >= 0) {
+                const int ep = pair_id[q] >> 8, ip = (pair_id[q] >> 4) & 15, jp = pair_id[q] & 15;
+                float sx = 0.f, sy = 0.f;
+                int ok = 0;
+                if (jp != ip) ok = tag_pair_force(c, s_ap + ep * st, s_lp + ep * lst, ip, jp, sx, sy) ? 1 : 0;
+                const int slot = kPS * (ep * NA + ip) + jp;
+                s_cx[slot] = sx; s_cy[slot] = sy; s_cv[slot] = ok;
+            }
         // C. head: 16 lanes per row compute exp(logit - max) in parallel; lane 0 of the row then folds them in
         //    action order (same arithmetic order as tsm_policy_forward => identical samples and log-probs)
         if (threadIdx.x < NT) {
@@ -243,28 +265,15 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
         }
         __syncthreads();
         TSTAMP(2);
-        // D. env step (mpe_tag_dev.h): pair forces -> barrier -> fold, integrate, publish -> barrier -> reward terms.
+        // D. env step (mpe_tag_dev.h): fold of the pair forces (evaluated beside the head, above: one (agent row, other entity) task
+        //    per lane instead of one lane per agent walking its 5 partners -- sqrt, exp, log1p, a division each when the pair is in
+        //    range), integrate, publish -> barrier -> reward terms.
         //    (The env lanes' buffer index algebra on their register-resident sub-buffer state -- buffer_base.py:373-410 +
-        //    manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h -- runs beside the head, above.)
-        // (round 5: the pair forces as one (agent row, other entity) task per thread of waves 0-3, folded by the agent lanes in entity
-        //  order -- tag_agent_move's sums.  One lane per agent ran its 5 pair evaluations -- sqrt, exp, log1p, a division each when the
-        //  pair is in range -- one after the other; csrc/rollout.hip has the measurement.)
-        if (threadIdx.x < R * kPS) {
-            const int rp = threadIdx.x / kPS, jp = threadIdx.x % kPS;
-            float sx = 0.f, sy = 0.f;
-            int ok = 0;
-            if (rp < rows_here && jp < NA + c.n_obst) {
-                const int ep = rp / NA, ip = rp - ep * NA;
-                if (jp != ip) ok = tag_pair_force(c, s_ap + ep * st, s_lp + ep * lst, ip, jp, sx, sy) ? 1 : 0;
-            }
-            s_cx[threadIdx.x] = sx; s_cy[threadIdx.x] = sy; s_cv[threadIdx.x] = ok;
-        }
+        //    manager.py:170-177; same arithmetic as vrb_add_row in vrb_dev.h -- runs beside the head too.)
         float npx = 0.f, npy = 0.f;
-        __syncthreads();
         if (lane_live) {   // fold, integrate, publish: a lane reads and writes its own agent's position / velocity only
             float fx, fy, nvx, nvy;
             tag_action_force(c, ai, s_act[r], fx, fy);
-            const int NE = NA + c.n_obst;
 #pragma unroll
             for (int q = 0; q < kPS / 4; ++q) {
                 typedef int i4 __attribute__((ext_vector_type(4)));
@@ -280,22 +289,23 @@ __global__ __launch_bounds__(NT2) void rollout_tag_kernel(TagRolloutArgs a) {
             s_av[el * st + 2 * ai] = nvx; s_av[el * st + 2 * ai + 1] = nvy;
         }
         __syncthreads();
+        // reward terms on wave 0 (the agent lanes); obs_next rows (terminal observation for finished episodes) on waves 1-7 beside it
         float my_rew = 0.f;
-        if (lane_live) {
-            float hit;
-            my_rew = tag_own_reward(c, s_ap + el * st, ai, npx, npy, hit);
-            s_hit[r] = hit;
-        }
-        // obs_next rows (terminal observation for finished episodes) on waves 1-7 while wave 0 works on the reward terms
-        if (threadIdx.x >= 64)
+        if (threadIdx.x < 64) {
+            float hit = 0.f;
+            if (lane_live) my_rew = tag_own_reward(c, s_ap + el * st, ai, npx, npy, hit);
+            // an adversary adds the hits of its env's good agents in agent order (shared by the team): the agent lanes of a tile are
+            // lanes of this one wave, so the terms come by shuffle (they went through LDS and a barrier)
+            for (int gg = c.n_adv; gg < NA; ++gg) {
+                const float h = __shfl(hit, el * NA + gg, 64);
+                if (ai < c.n_adv) my_rew += h;
+            }
+            if (lane_live) s_rew[r] = my_rew;
+        } else {
             for (int i = threadIdx.x - 64; i < rows_here * D; i += NT2 - 64) {
                 const int rr = i / D, k = i - rr * D, ee = rr / NA;
                 XN[rr * d.ld1 + k] = tag_obs_elem(c, s_ap + ee * st, s_av + ee * st, s_lp + ee * lst, rr - ee * NA, k);
             }
-        __syncthreads();
-        if (lane_live) {
-            if (ai < c.n_adv) for (int g = c.n_adv; g < NA; ++g) my_rew += s_hit[el * NA + g];  // shared by the team
-            s_rew[r] = my_rew;
         }
         __syncthreads();
         if (env_lane) {  // episode returns (needs the rewards); runs beside the payload scatter below
