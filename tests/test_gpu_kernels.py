@@ -669,3 +669,23 @@ def test_update_kernel_one_net_per_workgroup_equals_both_nets_bit_for_bit(case):
     finally:
         lib.tsm_debug_set_update_variant(0)
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_stream_ptr_is_torchs_current_stream():
+    """_abi.stream_ptr asks torch's C layer for the raw stream: it must be the hipStream_t of torch.cuda.current_stream() on the
+    default stream, on a side stream and on the stream a graph is being captured on."""
+    assert ops.stream_ptr() == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert ops.stream_ptr() == side.cuda_stream == torch.cuda.current_stream().cuda_stream
+    assert ops.stream_ptr() == torch.cuda.current_stream().cuda_stream
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    g = torch.cuda.CUDAGraph()
+    seen = []
+    with ops.graph_capture(g):
+        seen.append((ops.stream_ptr(), torch.cuda.current_stream().cuda_stream))
+        ops.call("tsm_u64_add", ops.ptr(ctr), 3, ops.stream_ptr())
+    assert seen[0][0] == seen[0][1]
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert int(ctr.item()) == 6

@@ -298,7 +298,24 @@ def ptr(t) -> int | None:
     return t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device (the stream every op launches on; inside a capture, the
+    capturing stream).  Asked of torch's C layer directly: `torch.cuda.current_stream().cuda_stream` builds a Stream object and
+    resolves the device through four Python layers -- 4 us a call, six calls per step of the tag job (profiles/r05_host_tag.txt)."""
+    global _raw_stream
     import torch
 
-    return torch.cuda.current_stream().cuda_stream
+    if _raw_stream is None:
+        get, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if get is None or dev is None:
+            _raw_stream = False
+        else:
+            torch.cuda.init()
+            _raw_stream = (get, dev)
+    if _raw_stream is False:
+        return torch.cuda.current_stream().cuda_stream
+    get, dev = _raw_stream
+    return get(dev())

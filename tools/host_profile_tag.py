@@ -64,4 +64,4 @@ for k in seg: seg[k] = 0.0
 t0 = time.perf_counter(); loop(300); dt = time.perf_counter() - t0
 print("step %.1f us; host segments us/step: %s" % (dt / 300 * 1e6, {k: round(v / 300 * 1e6, 1) for k, v in seg.items()}))
 pr = cProfile.Profile(); pr.enable(); loop(300); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(sys.argv[2] if len(sys.argv) > 2 else "tottime").print_stats(60); print(s.getvalue()[:14000])
